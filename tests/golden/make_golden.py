@@ -1,0 +1,489 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING the reference.
+
+This script imports ivclab/CPG from /root/reference (read-only, present only in
+the build container) and records inputs + outputs of its hot-path functions as
+small .npz / .json fixtures.  Nothing of the reference's source travels: the
+fixtures are tensors and scalars only.  Re-run with
+
+    python tests/golden/make_golden.py
+
+The fixtures pin:
+  * Binarizer edge cases                      (models/layers.py:11-23)
+  * masked conv / linear forward + backward   (models/layers.py:98-109,184-194)
+  * gradient routing                          (utils/prune.py:195-211)
+  * rank prune, schedule and update gate      (utils/prune.py:30-92)
+  * mask statistics                           (utils/prune.py:111-193)
+  * apply_mask / make_pruned_zero / make_finetuning_mask (utils/prune.py:213-243)
+  * module names/shapes + first forward of VGG / ResNet-50 / SphereNet-20
+  * a 12-step prune-mode trajectory of a narrow VGG16-BN (utils/manager.py:39-100)
+
+torch version is recorded in every fixture: the reference has no tests of its
+own, so "reference source + this torch CPU build" is the operative oracle.
+"""
+import json
+import os
+import zlib
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+warnings.filterwarnings('ignore')
+
+# The reference calls .cuda() unconditionally on the prune path
+# (utils/prune.py:39,188,228); on this GPU-less container make it the identity.
+torch.Tensor.cuda = lambda self, *a, **k: self
+
+import models  # noqa: E402  (reference)
+import models.layers as nl  # noqa: E402
+from utils.prune import SparsePruner  # noqa: E402
+from utils import Optimizers  # noqa: E402
+
+META = {'torch': torch.__version__, 'generator': 'tests/golden/make_golden.py'}
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    out['_torch_version'] = np.asarray(torch.__version__)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print('wrote', name, {k: getattr(v, 'shape', None) for k, v in out.items() if not k.startswith('_')})
+
+
+# --------------------------------------------------------------------------
+# 1. Binarizer
+# --------------------------------------------------------------------------
+def gen_binarizer():
+    g = torch.Generator().manual_seed(11)
+    edge = torch.tensor([0.005, 0.0050001, 0.004999, -1.0, 0.01, float('nan'),
+                         0.0, -0.0, float('inf'), float('-inf'), 5e-3 + 1e-9, 1e-38],
+                        dtype=torch.float32)
+    rnd = (torch.rand(257, generator=g) - 0.5) * 0.03
+    x = torch.cat([edge, rnd])
+    y = nl.Binarizer.apply(x, nl.DEFAULT_THRESHOLD)
+    xr = x.clone().requires_grad_(True)
+    yr = nl.Binarizer.apply(xr, nl.DEFAULT_THRESHOLD)
+    go = torch.randn(x.shape, generator=g)
+    yr.backward(go)
+    save('binarizer', x=x, y=y, grad_out=go, grad_in=xr.grad, threshold=nl.DEFAULT_THRESHOLD)
+
+
+# --------------------------------------------------------------------------
+# 2./3. masked conv / linear forward + backward
+# --------------------------------------------------------------------------
+CONV_CASES = [
+    # name, N, Cin, H, W, Cout, k, stride, pad, dil, bias
+    ('c3s1p1',       2,  5, 9, 11,  7, 3, 1, 1, 1, False),   # VGG class
+    ('c3s1p1_wide',  1,  8, 6, 37, 33, 3, 1, 1, 1, False),   # ragged vs 32-wide tiles
+    ('c3s1p1_bias',  2,  4, 8,  8,  6, 3, 1, 1, 1, True),    # SphereNet class
+    ('c3s2p1_bias',  2,  3, 9, 10,  5, 3, 2, 1, 1, True),    # SphereNet downsample
+    ('c3s2p1',       2,  6, 8,  8,  4, 3, 2, 1, 1, False),   # ResNet conv2 stride 2
+    ('c1s1',         2,  6, 5,  7,  9, 1, 1, 0, 1, False),   # ResNet 1x1
+    ('c1s2',         2,  6, 6,  8,  9, 1, 2, 0, 1, False),   # ResNet downsample
+    ('c7s2p3',       1,  3, 17, 19, 4, 7, 2, 3, 1, False),   # ResNet stem
+    ('c3s1p2d2',     1,  4, 9,  9,  3, 3, 1, 2, 2, False),   # dilation (conv3x3 helper)
+]
+
+
+def gen_conv():
+    for (name, N, C, H, W, M, k, s, p, d, bias) in CONV_CASES:
+        for masked in (False, True):
+            g = torch.Generator().manual_seed(zlib.crc32(('%s-%s' % (name, masked)).encode()))
+            layer = nl.SharableConv2d(C, M, k, stride=s, padding=p, dilation=d, bias=bias)
+            layer.weight.data = torch.randn(layer.weight.shape, generator=g) * 0.3
+            if bias:
+                layer.bias.data = torch.randn(M, generator=g) * 0.1
+            if masked:
+                pm = (torch.rand(layer.weight.shape, generator=g) * 0.012)  # ~58 % above 5e-3
+                pm.view(-1)[0] = 0.005          # exactly at threshold -> 0
+                pm.view(-1)[1] = 0.0050001      # just above -> 1
+                layer.piggymask = nn.Parameter(pm)
+            x = torch.randn(N, C, H, W, generator=g).requires_grad_(True)
+            y = layer(x)
+            gy = torch.randn(y.shape, generator=g)
+            y.backward(gy)
+            arrs = dict(x=x, w=layer.weight, y=y, gy=gy, gx=x.grad, gw=layer.weight.grad,
+                        cfg=np.array([N, C, H, W, M, k, s, p, d, int(bias)]))
+            if bias:
+                arrs.update(b=layer.bias, gb=layer.bias.grad)
+            if masked:
+                arrs.update(pm=layer.piggymask, gpm=layer.piggymask.grad)
+            save('conv_%s_%s' % (name, 'pm' if masked else 'plain'), **arrs)
+
+
+def gen_linear():
+    for (name, B, I, O) in [('small', 3, 10, 7), ('ragged', 5, 67, 33), ('k1', 2, 1, 4)]:
+        for masked in (False, True):
+            g = torch.Generator().manual_seed(zlib.crc32(('lin-%s-%s' % (name, masked)).encode()))
+            layer = nl.SharableLinear(I, O)
+            layer.weight.data = torch.randn(O, I, generator=g) * 0.2
+            layer.bias.data = torch.randn(O, generator=g) * 0.1
+            if masked:
+                layer.piggymask = nn.Parameter(torch.rand(O, I, generator=g) * 0.012)
+            x = torch.randn(B, I, generator=g).requires_grad_(True)
+            y = layer(x)
+            gy = torch.randn(y.shape, generator=g)
+            y.backward(gy)
+            arrs = dict(x=x, w=layer.weight, b=layer.bias, y=y, gy=gy, gx=x.grad,
+                        gw=layer.weight.grad, gb=layer.bias.grad)
+            if masked:
+                arrs.update(pm=layer.piggymask, gpm=layer.piggymask.grad)
+            save('linear_%s_%s' % (name, 'pm' if masked else 'plain'), **arrs)
+
+
+# --------------------------------------------------------------------------
+# helpers to stand up a reference pruner on a tiny model
+# --------------------------------------------------------------------------
+class TinyNet(nn.Module):
+    """Two masked layers; enough structure for SparsePruner's named_modules walk."""
+
+    def __init__(self, datasets):
+        super().__init__()
+        self.datasets = datasets
+        self.conv = nl.SharableConv2d(3, 4, 3, padding=1, bias=False)
+        self.fc = nl.SharableLinear(6, 5)
+
+    def forward(self, x):
+        return x
+
+
+def make_pruner(mode, datasets, dataset, owners, weights, begin=0, end=100, freq=10,
+                initial=0.0, target=0.1, wd=4e-5, width=1.0, finetune_again=False,
+                inference_idx=None, piggymasks=None):
+    net = TinyNet(list(datasets))
+    net.conv.weight.data = weights['conv'].clone()
+    net.fc.weight.data = weights['fc'].clone()
+    net.fc.bias.data.zero_()
+    if piggymasks is not None:
+        net.conv.piggymask = nn.Parameter(piggymasks['conv'].clone())
+        net.fc.piggymask = nn.Parameter(piggymasks['fc'].clone())
+    model = nn.DataParallel(net)
+    masks = {'module.conv': owners['conv'].clone(), 'module.fc': owners['fc'].clone()}
+    args = types.SimpleNamespace(mode=mode, dataset=dataset, finetune_again=finetune_again,
+                                 target_sparsity=target, initial_sparsity=initial,
+                                 pruning_frequency=freq, weight_decay=wd,
+                                 network_width_multiplier=width)
+    if inference_idx is None:
+        inference_idx = list(datasets).index(dataset) + 1
+    return SparsePruner(model, masks, args, begin, end, inference_idx), model, masks
+
+
+def rand_state(seed, ntasks=3):
+    g = torch.Generator().manual_seed(seed)
+    w = {'conv': torch.randn(4, 3, 3, 3, generator=g), 'fc': torch.randn(5, 6, generator=g)}
+    o = {'conv': torch.randint(0, ntasks + 1, (4, 3, 3, 3), generator=g, dtype=torch.uint8),
+         'fc': torch.randint(0, ntasks + 1, (5, 6), generator=g, dtype=torch.uint8)}
+    pm = {'conv': torch.rand(4, 3, 3, 3, generator=g) * 0.012, 'fc': torch.rand(5, 6, generator=g) * 0.012}
+    gw = {'conv': torch.randn(4, 3, 3, 3, generator=g), 'fc': torch.randn(5, 6, generator=g)}
+    gpm = {'conv': torch.randn(4, 3, 3, 3, generator=g), 'fc': torch.randn(5, 6, generator=g)}
+    return w, o, pm, gw, gpm
+
+
+# --------------------------------------------------------------------------
+# 4. gradient routing
+# --------------------------------------------------------------------------
+def gen_route():
+    cases = [('finetune_t3', 'finetune', ['a', 'b', 'c'], 'c', True, False),
+             ('prune_t2', 'prune', ['a', 'b', 'c'], 'b', True, False),
+             ('finetune_again_t2', 'finetune', ['a', 'b', 'c'], 'b', True, True),
+             ('prune_t1_nopm', 'prune', ['a'], 'a', False, False),
+             ('finetune_t1_nopm', 'finetune', ['a'], 'a', False, False)]
+    for i, (name, mode, ds, d, with_pm, again) in enumerate(cases):
+        w, o, pm, gw, gpm = rand_state(100 + i, ntasks=len(ds))
+        pruner, model, masks = make_pruner(mode, ds, d, o, w, finetune_again=again,
+                                           piggymasks=pm if with_pm else None)
+        if mode == 'finetune' and not again:
+            pruner.make_finetuning_mask()   # reference does this before finetune training
+        owner_used = {k: masks['module.' + k].clone() for k in ('conv', 'fc')}
+        net = model.module
+        net.conv.weight.grad = gw['conv'].clone()
+        net.fc.weight.grad = gw['fc'].clone()
+        if with_pm:
+            net.conv.piggymask.grad = gpm['conv'].clone()
+            net.fc.piggymask.grad = gpm['fc'].clone()
+        pruner.do_weight_decay_and_make_grads_zero()
+        arrs = dict(cur=pruner.current_dataset_idx, wd=4e-5, mode=mode,
+                    w_conv=w['conv'], w_fc=w['fc'], owner_conv=owner_used['conv'], owner_fc=owner_used['fc'],
+                    gw_in_conv=gw['conv'], gw_in_fc=gw['fc'],
+                    gw_out_conv=net.conv.weight.grad, gw_out_fc=net.fc.weight.grad)
+        if with_pm:
+            arrs.update(gpm_in_conv=gpm['conv'], gpm_in_fc=gpm['fc'],
+                        gpm_out_conv=net.conv.piggymask.grad, gpm_out_fc=net.fc.piggymask.grad)
+        save('route_' + name, **arrs)
+
+
+# --------------------------------------------------------------------------
+# 5. rank prune on crafted tensors, 6. schedule
+# --------------------------------------------------------------------------
+def gen_rank_prune():
+    recs = {}
+    g = torch.Generator().manual_seed(7)
+
+    def run(tag, w, owner, cur, ratio):
+        w = w.float()
+        owner = owner.to(torch.uint8)
+        ds = ['t%d' % i for i in range(1, max(cur, 1) + 1)]
+        pruner, model, masks = make_pruner('prune', ds, ds[cur - 1],
+                                           {'conv': torch.zeros(4, 3, 3, 3, dtype=torch.uint8), 'fc': torch.zeros(5, 6, dtype=torch.uint8)},
+                                           {'conv': torch.zeros(4, 3, 3, 3), 'fc': torch.zeros(5, 6)})
+        status = 0
+        try:
+            out = pruner._pruning_mask(w.clone(), owner.clone(), tag, ratio)
+        except SystemExit as e:
+            status = int(e.code)
+            out = owner.clone()
+        recs[tag + '_w'] = w.numpy()
+        recs[tag + '_owner'] = owner.numpy()
+        recs[tag + '_cur'] = np.asarray(cur)
+        recs[tag + '_ratio'] = np.asarray(ratio, dtype=np.float64)
+        recs[tag + '_out'] = out.numpy()
+        recs[tag + '_status'] = np.asarray(status)
+
+    # plain random, single owner
+    run('rand_t1', torch.randn(6, 5, 3, 3, generator=g), torch.ones(6, 5, 3, 3), 1, 0.3)
+    # multi-owner with released slots (owner 0, value 0 after apply_mask) among candidates
+    w = torch.randn(8, 4, 3, 3, generator=g)
+    o = torch.randint(0, 4, (8, 4, 3, 3), generator=g)
+    w[o == 0] = 0.0
+    run('multi_t2', w, o, 2, 0.25)
+    run('multi_t3', w, o, 3, 0.6)
+    # ties at the cutoff: many equal magnitudes, +/- signs
+    w = torch.tensor([0.5, -0.5, 0.5, 0.25, -0.25, 1.0, 2.0, -0.5, 0.125, 3.0, -3.0, 0.5]).view(3, 4)
+    run('ties', w, torch.ones(3, 4), 1, 0.4)
+    # banker's rounding of k: n=5, ratio .5 -> 2.5 -> 2 ; n=3, ratio .5 -> 1.5 -> 2
+    run('round_2p5', torch.tensor([5., 1., 4., 2., 3.]).view(1, 5), torch.ones(1, 5), 1, 0.5)
+    run('round_1p5', torch.tensor([3., 1., 2.]).view(1, 3), torch.ones(1, 3), 1, 0.5)
+    # k == 0 -> kthvalue raises -> exit(2)
+    run('k_zero', torch.tensor([3., 1., 2., 7.]).view(2, 2), torch.ones(2, 2), 1, 0.1)
+    # no candidates at all -> exit(2)
+    run('no_cand', torch.randn(2, 3, generator=g), torch.full((2, 3), 2), 1, 0.5)
+    # ratio 1.0 -> k == n, everything of the current task released
+    run('all', torch.randn(3, 3, generator=g), torch.tensor([[1, 1, 2], [0, 1, 1], [2, 1, 0]]), 1, 1.0)
+    # zeros, negative zero, denormals, inf
+    w = torch.tensor([0.0, -0.0, 1e-40, -1e-40, 1e-38, float('inf'), -1.0, 1.0, 1e-20, 2.0]).view(2, 5)
+    run('special', w, torch.ones(2, 5), 1, 0.5)
+    # larger layer-shaped case
+    w = torch.randn(64, 32, 3, 3, generator=g) * 0.05
+    o = torch.where(torch.rand(64, 32, 3, 3, generator=g) < 0.2, torch.tensor(0), torch.tensor(1))
+    w[o == 0] = 0
+    run('layer', w, o, 1, 0.0399)
+    save('rank_prune', **recs)
+
+
+def gen_schedule():
+    rows = []
+    for (begin, end, freq, init, target) in [(0, 64, 10, 0.0, 0.1), (40, 120, 10, 0.1, 0.2),
+                                             (0, 4000, 1000, 0.0, 0.5), (100, 140, 7, 0.9, 0.95)]:
+        w, o, *_ = rand_state(1)
+        o = {k: torch.ones_like(v) for k, v in o.items()}
+        pruner, _, _ = make_pruner('prune', ['a'], 'a', o, w, begin=begin, end=end, freq=freq,
+                                   initial=init, target=target)
+        last = pruner.last_prune_step
+        for step in range(begin - 3, end + 25):
+            upd = pruner._time_to_update_masks(step)
+            if upd:
+                pruner.last_prune_step = step
+            rows.append((begin, end, freq, init, target, step, int(upd), pruner._adjust_sparsity(step)))
+        del last
+    a = np.array(rows, dtype=np.float64)
+    save('schedule', table=a)
+
+
+# --------------------------------------------------------------------------
+# 7. statistics, 8. apply / zero / claim
+# --------------------------------------------------------------------------
+def gen_stats_and_masks():
+    recs = {}
+    for i, (cur_name, ds, width) in enumerate([('b', ['a', 'b', 'c'], 1.0), ('c', ['a', 'b', 'c'], 1.2247448713915890), ('a', ['a'], 1.0)]):
+        w, o, pm, *_ = rand_state(300 + i, ntasks=len(ds))
+        pruner, model, masks = make_pruner('prune', ds, cur_name, o, w, width=width, piggymasks=pm)
+        tag = 'case%d' % i
+        recs[tag + '_owner_conv'] = o['conv'].numpy()
+        recs[tag + '_owner_fc'] = o['fc'].numpy()
+        recs[tag + '_pm_conv'] = pm['conv'].numpy()
+        recs[tag + '_pm_fc'] = pm['fc'].numpy()
+        recs[tag + '_w_conv'] = w['conv'].numpy()
+        recs[tag + '_w_fc'] = w['fc'].numpy()
+        recs[tag + '_inference_idx'] = np.asarray(pruner.inference_dataset_idx)
+        recs[tag + '_width'] = np.asarray(width)
+        recs[tag + '_sparsity'] = np.asarray(pruner.calculate_sparsity())
+        recs[tag + '_curr_task_ratio'] = np.asarray(pruner.calculate_curr_task_ratio())
+        recs[tag + '_zero_ratio'] = np.asarray(pruner.calculate_zero_ratio())
+        recs[tag + '_shared_part_ratio'] = np.asarray(pruner.calculate_shared_part_ratio())
+        # apply_mask (destructive)
+        pruner.apply_mask()
+        recs[tag + '_applied_conv'] = model.module.conv.weight.data.clone().numpy()
+        recs[tag + '_applied_fc'] = model.module.fc.weight.data.clone().numpy()
+        # make_pruned_zero on a fresh copy
+        pruner2, model2, masks2 = make_pruner('prune', ds, cur_name, o, w, width=width)
+        pruner2.make_pruned_zero()
+        recs[tag + '_zeroed_conv'] = model2.module.conv.weight.data.clone().numpy()
+        recs[tag + '_zeroed_fc'] = model2.module.fc.weight.data.clone().numpy()
+        # make_finetuning_mask in finetune mode (idx = len(datasets)-1, then +1)
+        pruner3, model3, masks3 = make_pruner('finetune', ds, ds[-1], o, w, width=width)
+        pruner3.make_finetuning_mask()
+        recs[tag + '_claimed_conv'] = masks3['module.conv'].numpy()
+        recs[tag + '_claimed_fc'] = masks3['module.fc'].numpy()
+        recs[tag + '_claimed_idx'] = np.asarray(pruner3.current_dataset_idx)
+    # all-empty statistics -> 0.0 branches
+    w, o, pm, *_ = rand_state(5)
+    o = {k: torch.full_like(v, 2) for k, v in o.items()}
+    pruner, _, _ = make_pruner('prune', ['a', 'b'], 'a', o, w, piggymasks=pm)
+    recs['empty_sparsity'] = np.asarray(pruner.calculate_sparsity())
+    recs['empty_shared'] = np.asarray(pruner.calculate_shared_part_ratio())
+    save('stats_masks', **recs)
+
+
+# --------------------------------------------------------------------------
+# 9. topologies
+# --------------------------------------------------------------------------
+VGG_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+
+
+def build_ref(arch, width, num_classes=5, dataset='t1'):
+    torch.manual_seed(1)
+    kw = dict(dataset_history=[], dataset2num_classes={}, network_width_multiplier=width, shared_layer_info={})
+    if arch == 'vgg_cifar100':
+        m = models.custom_vgg_cifar100(VGG_CFG, **kw)
+    elif arch == 'vgg':
+        m = models.custom_vgg(VGG_CFG, **kw)
+    elif arch == 'resnet50':
+        m = models.resnet50(**kw)
+    elif arch == 'spherenet20':
+        m = models.spherenet20(**kw)
+    m.add_dataset(dataset, num_classes)
+    m.set_dataset(dataset)
+    return m
+
+
+def gen_topology():
+    info = {}
+    for arch, width, inp in [('vgg_cifar100', 1.0, None), ('vgg', 1.0, None), ('resnet50', 1.0, None),
+                             ('spherenet20', 1.0, None)]:
+        m = nn.DataParallel(build_ref(arch, width))
+        layers = []
+        for name, mod in m.named_modules():
+            if isinstance(mod, nl.SharableConv2d):
+                layers.append([name, 'conv', list(mod.weight.shape), list(mod.stride), list(mod.padding),
+                               mod.bias is not None])
+            elif isinstance(mod, nl.SharableLinear):
+                layers.append([name, 'linear', list(mod.weight.shape), None, None, mod.bias is not None])
+        info[arch] = {'masked_layers': layers,
+                      'param_names': [[n, list(p.shape)] for n, p in m.named_parameters()],
+                      'n_params': sum(p.numel() for p in m.parameters())}
+    info['_meta'] = META
+    with open(os.path.join(OUT, 'topology.json'), 'w') as f:
+        json.dump(info, f, indent=0)
+    print('wrote topology.json')
+
+    # first-forward logits of narrow nets at seed 1 (init parity + topology parity)
+    for arch, width, shape in [('vgg_cifar100', 0.125, (4, 3, 32, 32)), ('vgg', 0.125, (2, 3, 224, 224)),
+                               ('resnet50', 0.25, (2, 3, 64, 64)), ('spherenet20', 0.25, (2, 3, 112, 112))]:
+        ncls = 5 if arch != 'spherenet20' else 7
+        m = build_ref(arch, width, num_classes=ncls)
+        if arch == 'spherenet20':
+            # the face driver swaps in an AngleLinear head only for face_verification; other
+            # face tasks (gender/emotion/age) use nn.Linear heads like this one.
+            pass
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(*shape, generator=g)
+        m.eval()
+        with torch.no_grad():
+            y = m(x)
+        # digest of the initial weights (sum, abs-sum per parameter) rather than the weights
+        digest = np.array([[float(p.double().sum()), float(p.double().abs().sum())] for p in m.parameters()])
+        first = next(iter(m.parameters())).detach().reshape(-1)[:64].clone()
+        save('first_forward_' + arch, x=x, y=y, param_digest=digest, first_param_head=first,
+             width=width, num_classes=ncls)
+
+
+# --------------------------------------------------------------------------
+# 10. trajectory: the Manager.train step order on a narrow VGG16-BN
+# --------------------------------------------------------------------------
+def gen_trajectory():
+    """Replays utils/manager.py:50-75 by hand (the Manager itself needs tqdm + a loader;
+    the op order below is the reference's: zero_grad, forward, loss, backward, routing,
+    step, gradually_prune) with the reference's own modules and pruner."""
+    import torch.optim as optim
+    width = 0.125
+    B, steps, freq = 8, 12, 3
+    for mode in ('prune', 'finetune'):
+        net = build_ref('vgg_cifar100', width)
+        model = nn.DataParallel(net)
+        masks = {}
+        for name, mod in model.named_modules():
+            if isinstance(mod, (nl.SharableConv2d, nl.SharableLinear)):
+                masks[name] = torch.zeros(mod.weight.shape, dtype=torch.uint8)
+        args = types.SimpleNamespace(mode=mode, dataset='t1', finetune_again=False, target_sparsity=0.3,
+                                     initial_sparsity=0.0, pruning_frequency=freq, weight_decay=4e-5,
+                                     network_width_multiplier=width)
+        pruner = SparsePruner(model, masks, args, 0, 8, 1)
+        if mode == 'finetune':
+            pruner.make_finetuning_mask()
+        else:
+            for k in masks:
+                masks[k].fill_(1)
+        init_state = {k: v.clone() for k, v in net.state_dict().items()}
+        params = [p for n, p in model.named_parameters()]
+        opt = optim.SGD(params, lr=1e-2 if mode == 'finetune' else 1e-3, weight_decay=0.0, momentum=0.9, nesterov=True)
+        optimizers = Optimizers()
+        optimizers.add(opt, 1e-2)
+        g = torch.Generator().manual_seed(3)
+        xs = torch.randn(steps, B, 3, 32, 32, generator=g)
+        ts = torch.randint(0, 5, (steps, B), generator=g)
+        crit = nn.CrossEntropyLoss()
+        model.train()
+        logits, losses, ratios, sparsities = [], [], [], []
+        step_idx = 0
+        for s in range(steps):
+            optimizers.zero_grad()
+            out = model(xs[s])
+            loss = crit(out, ts[s])
+            loss.backward()
+            pruner.do_weight_decay_and_make_grads_zero()
+            optimizers.step()
+            if mode == 'prune':
+                ratios.append(pruner.gradually_prune(step_idx))
+                step_idx += 1
+            logits.append(out.detach().clone())
+            losses.append(float(loss))
+            sparsities.append(pruner.calculate_sparsity())
+        # validate-like tail: apply_mask then eval forward (utils/manager.py:103-121)
+        pruner.apply_mask()
+        model.eval()
+        with torch.no_grad():
+            eval_out = model(xs[0])
+        arrs = dict(width=width, lr=opt.param_groups[0]['lr'], freq=freq, begin=0, end=8, target=0.3, initial=0.0,
+                    wd=4e-5, x=xs, t=ts, logits=torch.stack(logits), losses=np.array(losses),
+                    sparsities=np.array(sparsities), ratios=np.array(ratios, dtype=np.float64),
+                    eval_logits=eval_out)
+        for k, v in init_state.items():
+            arrs['init/' + k] = v
+        for k, v in masks.items():
+            arrs['mask/' + k] = v
+        for k, v in net.state_dict().items():
+            if 'features.0.weight' in k or 'features.41.weight' in k or k.endswith('features.44.weight'):
+                arrs['final/' + k] = v
+        save('trajectory_' + mode, **arrs)
+
+
+if __name__ == '__main__':
+    gen_binarizer()
+    gen_conv()
+    gen_linear()
+    gen_route()
+    gen_rank_prune()
+    gen_schedule()
+    gen_stats_and_masks()
+    gen_topology()
+    gen_trajectory()
