@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of one CPG train -> gradual-prune -> retrain cycle, VGG16-BN task 1.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is
+launched by torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): `custom_vgg` (VGG16-BN, 224x224, Dropout),
+5-way head, fp32, batch 256 PER GPU (weak scaling; configs[2] is 2048 = 8 x 256), synthetic
+N(0,1) images / randint(0,5) labels already resident in HBM, weights from the reference's init at
+seed 1, wd 4e-5.  The K timed steps are one scaled CPG task-1 cycle:
+
+    epoch length E = max(1, K // 11)
+    phase A  "finetune": E steps, SGD-nesterov lr 1e-2, free slots claimed by task 1
+    phase B  "prune 0.0 -> 0.1": K - E steps, lr 1e-3, pruning window = first 2E steps of the phase,
+             rank-prune event every max(1, E // 2) steps inside the window, then fixed-mask recovery
+    validate (apply_mask + 2 eval batches of 100) after every E steps, mask statistics per step.
+
+A "step" is one minibatch through the hot path (zero_grad, forward, loss, backward, gradient routing,
+SGD step, prune event when due, statistics); validates are inside the timed region.  value =
+global_batch * K / wall, wall = max over ranks of the barrier-bracketed timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import cpg_amd.models as models                     # noqa: E402
+from cpg_amd import dist as cdist                    # noqa: E402
+from cpg_amd.models import layers as nl              # noqa: E402
+from cpg_amd.utils import Optimizers                 # noqa: E402
+from cpg_amd.utils.manager import Manager            # noqa: E402
+
+VGG_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
+FLOP_PER_IMG_TRAIN = 92.62e9         # fwd + dgrad + wgrad of the 15 masked layers
+
+
+class KernelClock:
+    """HIP-event timing of every masked-layer kernel launch inside the timed region (events are
+    recorded on torch's current stream, the stream the C ABI launches on)."""
+
+    def __init__(self):
+        self.records = []           # (kind, flops, start_event, end_event)
+        self.enabled = False
+
+    def wrap(self, lib):
+        clock = self
+
+        def timed(name, kind, flops_fn):
+            raw = getattr(lib, name)
+
+            def call(*args):
+                if not clock.enabled:
+                    return raw(*args)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                rc = raw(*args)
+                e.record()
+                clock.records.append((kind(args), flops_fn(args), s, e))
+                return rc
+            return call
+
+        def conv_flops(args):
+            d = args[0]._obj
+            oh = (d.H + 2 * d.pad_h - d.dil_h * (d.R - 1) - 1) // d.stride_h + 1
+            ow = (d.W + 2 * d.pad_w - d.dil_w * (d.S - 1) - 1) // d.stride_w + 1
+            return 2.0 * d.N * d.K * oh * ow * d.C * d.R * d.S
+
+        def conv_kind(prefix):
+            def k(args):
+                d = args[0]._obj
+                return '%s %dx%d c%d->%d @%d' % (prefix, d.R, d.S, d.C, d.K, d.H)
+            return k
+
+        def lin_flops(bi):
+            return lambda a: 2.0 * a[bi] * a[bi + 1] * a[bi + 2]
+
+        class Proxy(object):
+            pass
+        p = Proxy()
+        for n in dir(lib):
+            if n.startswith('cpg_'):
+                setattr(p, n, getattr(lib, n))
+        p.cpg_conv2d_fwd = timed('cpg_conv2d_fwd', conv_kind('conv_fwd'), conv_flops)
+        p.cpg_conv2d_dgrad = timed('cpg_conv2d_dgrad', conv_kind('conv_dgrad'), conv_flops)
+        p.cpg_conv2d_wgrad = timed('cpg_conv2d_wgrad', conv_kind('conv_wgrad'), conv_flops)
+        p.cpg_linear_fwd = timed('cpg_linear_fwd', lambda a: 'linear_fwd', lin_flops(6))
+        p.cpg_linear_dgrad = timed('cpg_linear_dgrad', lambda a: 'linear_dgrad', lin_flops(5))
+        p.cpg_linear_wgrad = timed('cpg_linear_wgrad', lambda a: 'linear_wgrad', lin_flops(8))
+        return p
+
+    def summary(self):
+        agg = {}
+        for kind, flops, s, e in self.records:
+            ms = s.elapsed_time(e)
+            a = agg.setdefault(kind, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += ms
+            a[2] += flops
+        return agg
+
+
+def build_model(device):
+    torch.manual_seed(1)                       # reference default seed (CPG_cifar100_main_normal.py:79,135)
+    net = models.custom_vgg(VGG_CFG, dataset_history=[], dataset2num_classes={}, network_width_multiplier=1.0,
+                            shared_layer_info={})
+    net.add_dataset('task1', 5)
+    net.set_dataset('task1')
+    return net.to(device)
+
+
+def make_args(mode, freq, width=1.0):
+    return types.SimpleNamespace(mode=mode, dataset='task1', finetune_again=False, target_sparsity=0.1,
+                                 initial_sparsity=0.0, pruning_frequency=freq, weight_decay=4e-5,
+                                 network_width_multiplier=width, cuda=True, log_path=None, progress=False)
+
+
+def run_cycle(model, masks, pool, val_pool, steps, clock=None):
+    """The K-step scaled task-1 cycle.  Returns number of train steps executed."""
+    E = max(1, steps // 11)
+    done = 0
+
+    def loader(n, offset):
+        return [pool[(offset + i) % len(pool)] for i in range(n)]
+
+    def sgd(lr):
+        opt = torch.optim.SGD([p for p in model.parameters()], lr=lr, weight_decay=0.0, momentum=0.9, nesterov=True)
+        o = Optimizers()
+        o.add(opt, lr)
+        return o
+
+    # phase A: finetune
+    nA = min(E, steps)
+    mgr = Manager(make_args('finetune', max(1, E // 2)), model, {}, masks, loader(nA, 0), val_pool, 0, 0)
+    mgr.pruner.make_finetuning_mask()
+    mgr.train(sgd(1e-2), 0, [1e-2], 0)
+    mgr.validate(0)
+    done += nA
+    # phase B: prune 0.0 -> 0.1 then recovery at fixed mask
+    remaining = steps - done
+    step = 0
+    epoch = 1
+    if remaining > 0:
+        mgrB = Manager(make_args('prune', max(1, E // 2)), model, {}, masks, None, val_pool, 0, 2 * E)
+        opt = sgd(1e-3)
+        while remaining > 0:
+            n = min(E, remaining)
+            mgrB.train_loader = loader(n, done)
+            _, step = mgrB.train(opt, epoch, [1e-3], step)
+            mgrB.validate(epoch)
+            done += n
+            remaining -= n
+            epoch += 1
+    return done
+
+
+def cpu_baseline(budget_s=25.0):
+    """Oracle ("port") of the same train step on the host cores: a bounded sample, reported beside the
+    GPU number (never the target).  oracle/ is only ever used here as the measured CPU baseline."""
+    from oracle import net as onet
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    b = 8
+    model, pruner, opt = onet.make_task1(1.0, 'imagenet', 'finetune', lr=1e-2, wd=4e-5)
+    model.train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(b, 3, 224, 224, generator=g)
+    t = torch.randint(0, 5, (b,), generator=g)
+    onet.train_step(model, pruner, opt, x, t)            # warm-up (allocations, oneDNN primitive cache)
+    t0 = time.time()
+    n = 0
+    while True:
+        onet.train_step(model, pruner, opt, x, t)
+        n += 1
+        if time.time() - t0 > budget_s or n >= 12:
+            break
+    dt = time.time() - t0
+    return {'value': round(b * n / dt, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': '%d train steps (fwd+bwd+routing+SGD) of oracle VGG16-BN 224x224 at batch %d, torch-CPU fp32, '
+                      '%d threads; prune events / validates not in the sample' % (n, b, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=44)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (config 2: 256)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-clock', action='store_true')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if a.gpus > 1 or world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device('cuda', torch.cuda.current_device())
+
+    from cpg_amd import _lib
+    clock = KernelClock()
+    if not a.no_kernel_clock and rank == 0:
+        proxy = clock.wrap(_lib.lib())
+        _lib._lib = proxy                                  # route the Python mirror's calls through the timers
+
+    net = build_model(device)
+    model = cdist.DataParallel(net)
+    masks = {n: torch.zeros(m.weight.shape, dtype=torch.uint8, device=device) for n, m in model.named_modules()
+             if isinstance(m, (nl.SharableConv2d, nl.SharableLinear))}
+
+    g = torch.Generator(device=device).manual_seed(1 + rank)
+    pool = [(torch.randn(a.batch, 3, 224, 224, generator=g, device=device),
+             torch.randint(0, 5, (a.batch,), generator=g, device=device)) for _ in range(3)]
+    val_pool = [(torch.randn(100, 3, 224, 224, generator=g, device=device),
+                 torch.randint(0, 5, (100,), generator=g, device=device)) for _ in range(2)]
+
+    # warm-up: W untimed plain train steps (allocator, first-launch code loading)
+    if a.warmup > 0:
+        wm = Manager(make_args('finetune', 1), model, {}, {k: v.clone() for k, v in masks.items()},
+                     [pool[i % len(pool)] for i in range(a.warmup)], val_pool, 0, 0)
+        wm.pruner.make_finetuning_mask()
+        opt = Optimizers()
+        opt.add(torch.optim.SGD(model.parameters(), lr=0.0, momentum=0.9, nesterov=True), 0.0)
+        wm.train(opt, 0, [0.0], 0)
+        for bn in model.modules():                        # lr = 0 keeps weights; also restore BN statistics
+            if isinstance(bn, nn.BatchNorm2d):
+                bn.reset_running_stats()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    clock.enabled = True
+    t0 = time.perf_counter()
+    done = run_cycle(model, masks, pool, val_pool, a.steps, clock)
+    barrier()
+    dt = time.perf_counter() - t0
+    clock.enabled = False
+    assert done == a.steps
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        global_batch = a.batch * world
+        value = global_batch * a.steps / dt
+        out = {'metric': 'images/sec per CPG train-prune-retrain cycle, VGG16 task-1', 'value': round(value, 2),
+               'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+               'ms_per_step': round(1000.0 * dt / a.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+               'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'configs[1]: VGG16-BN custom_vgg 224x224, task-1 CPG cycle (finetune -> prune 0.0->0.1 -> recovery, '
+                                      'validate each epoch), batch %d per GPU' % a.batch,
+                          'global_batch': global_batch, 'per_gpu_batch': a.batch, 'parallelism': 'dp%d' % world,
+                          'epoch_steps': max(1, a.steps // 11)},
+               'frac_of_fp32_mfma_roofline_whole_step': round(value * FLOP_PER_IMG_TRAIN / world / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)}
+        agg = clock.summary()
+        if agg:
+            tot_ms = sum(v[1] for v in agg.values())
+            fam = {}
+            for kind, (cnt, ms, fl) in agg.items():
+                f = fam.setdefault(kind.split(' ')[0], [0, 0.0, 0.0])
+                f[0] += cnt
+                f[1] += ms
+                f[2] += fl
+            dom = max(fam, key=lambda k: fam[k][1])
+            cnt, ms, fl = fam[dom]
+            ach = fl / (ms * 1e-3) / 1e12
+            out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                               'launches': cnt, 'avg_launch_ms': round(ms / cnt, 4),
+                               'share_of_masked_kernel_time': round(ms / tot_ms, 3)}
+            out['kernel_families'] = {k: {'launches': v[0], 'ms': round(v[1], 2), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
+                                      for k, v in sorted(fam.items())}
+            out['masked_kernel_ms_per_step'] = round(tot_ms / a.steps, 2)
+            if os.environ.get('CPG_BENCH_DETAIL'):
+                out['kernel_detail'] = {k: {'n': v[0], 'ms': round(v[1], 2), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
+                                        for k, v in sorted(agg.items())}
+        if not a.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,130 @@
+"""ctypes binding of libcpg_hip.so (include/cpg_hip.h) -- the only bridge between the Python
+mirror of the reference's classes and the HIP kernels.
+
+There is NO CPU fallback: if the shared library is missing or a tensor is not a contiguous
+fp32/uint8 HIP tensor, the call raises.  (The CPU oracle under oracle/ is test infrastructure
+and is never imported from here.)
+"""
+import ctypes
+import os
+import sys
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libcpg_hip.so')
+
+CPG_OK = 0
+CPG_E_KRANGE = 2
+MODE_FINETUNE = 0
+MODE_PRUNE = 1
+
+_c_f32p = ctypes.c_void_p
+_vp = ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ('N', 'C', 'H', 'W', 'K', 'R', 'S', 'stride_h', 'stride_w', 'pad_h', 'pad_w', 'dil_h', 'dil_w', 'groups')]
+
+
+class PruneResult(ctypes.Structure):
+    _fields_ = [('n_candidates', ctypes.c_int64), ('k', ctypes.c_int64), ('n_released', ctypes.c_int64),
+                ('cutoff', ctypes.c_float), ('status', ctypes.c_int32)]
+
+
+PRUNE_RESULT_BYTES = ctypes.sizeof(PruneResult)
+assert PRUNE_RESULT_BYTES == 32
+
+# name -> (restype, argtypes); mirrors include/cpg_hip.h one to one
+_SIGNATURES = {
+    'cpg_version': (ctypes.c_int, []),
+    'cpg_last_error': (ctypes.c_char_p, []),
+    'cpg_binarize_mask_weight': (ctypes.c_int, [_vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, _vp]),
+    'cpg_conv2d_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
+    'cpg_conv2d_fwd': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    'cpg_conv2d_dgrad': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_size_t, _vp]),
+    'cpg_conv2d_wgrad': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    'cpg_linear_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    'cpg_linear_fwd': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
+    'cpg_linear_dgrad': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
+    'cpg_linear_wgrad': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
+    'cpg_route_grads': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, ctypes.c_float, _vp, ctypes.c_int32, ctypes.c_int64, _vp]),
+    'cpg_rank_prune_workspace_bytes': (ctypes.c_size_t, []),
+    'cpg_rank_prune': (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_double, ctypes.c_int64, _vp, _vp, ctypes.c_size_t, _vp]),
+    'cpg_mask_hist': (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int64, _vp, _vp]),
+    'cpg_apply_mask': (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int64, _vp]),
+    'cpg_zero_pruned': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp]),
+    'cpg_claim_free': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int64, _vp]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class CpgHipError(RuntimeError):
+    def __init__(self, fn, code, text):
+        super().__init__('%s failed with status %d: %s' % (fn, code, text))
+        self.code = code
+
+
+def lib():
+    """Load libcpg_hip.so once; raise (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'cpg_amd: %s is missing -- build it with `python -m cpg_amd.build` (hipcc, gfx950). '
+                'There is no CPU fallback for the masked-layer / prune path.' % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        if handle.cpg_version() != 1:
+            raise RuntimeError('cpg_amd: ABI version mismatch (library %d, binding 1)' % handle.cpg_version())
+        _lib = handle
+    return _lib
+
+
+def check(fn_name, code):
+    if code != CPG_OK:
+        text = lib().cpg_last_error()
+        raise CpgHipError(fn_name, code, text.decode(errors='replace') if text else '')
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream on the current device."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t, dtype=torch.float32, name='tensor'):
+    """Device pointer of a contiguous HIP tensor of the expected dtype (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('cpg_amd: %s lives on %s; the masked-layer kernels only run on a HIP device '
+                           '(no CPU fallback -- move the module with .cuda())' % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError('cpg_amd: %s must be %s, got %s' % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError('cpg_amd: %s must be contiguous' % name)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def workspace(nbytes, device):
+    """Scratch buffer from torch's caching allocator (stream-ordered reuse, no hipMalloc in steady state)."""
+    if nbytes == 0:
+        return None, 0
+    buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+    return buf, buf.numel() * 4
+
+
+def _selftest():
+    h = lib()
+    print('libcpg_hip.so ABI', h.cpg_version(), 'exports', len(EXPORTS))
+
+
+if __name__ == '__main__':
+    _selftest()
+    sys.exit(0)

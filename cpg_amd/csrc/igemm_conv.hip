@@ -1,0 +1,634 @@
+// Generic masked conv2d on fp32 MFMA: forward, input-gradient and weight-gradient of
+// models/layers.py:108-109 for ANY kernel size / stride / padding / dilation (groups == 1).
+// This is the shape-complete path (ResNet 1x1, 7x7 s2, 3x3 s2; SphereNet 3x3 s2) and the
+// fallback for the specialised 3x3 s1 p1 kernels of conv3x3.hip.
+//
+// Implicit GEMM, no im2col buffer: the B operand loader gathers the input window straight
+// from the NCHW tensor into the k-major LDS tile (lanes run along output pixels, so the
+// gathers are coalesced for stride 1); the A loader applies W * bin(piggymask) on the fly.
+//
+//   fwd  : D[co][p]        = sum_{ci,r,s} Weff[co][ci][r][s] * x[n_p][ci][ih][iw]
+//   dgrad: D[ci][q]        = sum_{co,r,s} Weff[co][ci][r][s] * gy[n_q][co][oh][ow]
+//   wgrad: D[co][(ci,r,s)] = sum_{p}      gy[n_p][co][p]      * x[n_p][ci][ih][iw]     (split-K over p)
+#include <algorithm>
+#include "igemm_core.h"
+
+using namespace cpg;
+
+namespace {
+
+struct ConvGeom {
+    int N, C, H, W, K, R, S, sh, sw, ph, pw, dh, dw, OH, OW;
+};
+
+// ---------------------------------------------------------------------------------- loaders
+// conv fwd B: B[k=(ci,r,s)][j=p]
+template <int BN, int BK>
+struct FwdBLoader {
+    static constexpr int N = BN * BK / 256;
+    static constexpr int KSTEP = 256 / BN;
+    const float *x;
+    int C, H, W, R, S, dh, dw, Kg;
+    int ih0, iw0, t_j, t_k;
+    int64_t xbase;
+    bool jvalid;
+    __device__ __forceinline__ void init(const float *x_, const ConvGeom &g, int64_t p0, int64_t P) {
+        x = x_; C = g.C; H = g.H; W = g.W; R = g.R; S = g.S; dh = g.dh; dw = g.dw; Kg = g.C * g.R * g.S;
+        t_j = threadIdx.x % BN;
+        t_k = threadIdx.x / BN;
+        const int64_t p = p0 + t_j;
+        jvalid = p < P;
+        const int ohw = g.OH * g.OW;
+        const int n = jvalid ? (int)(p / ohw) : 0;
+        const int q = jvalid ? (int)(p % ohw) : 0;
+        const int oh = q / g.OW, ow = q % g.OW;
+        ih0 = oh * g.sh - g.ph;
+        iw0 = ow * g.sw - g.pw;
+        xbase = (int64_t)n * C * H * W;
+    }
+    __device__ __forceinline__ void fetch(int kt, float (&r)[N]) {
+        const int RS = R * S;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int k = kt * BK + t_k + KSTEP * i;
+            const int ci = k / RS, rs = k - ci * RS;
+            const int rr = rs / S, ss = rs - rr * S;
+            const int ih = ih0 + rr * dh, iw = iw0 + ss * dw;
+            const bool ok = jvalid && k < Kg && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            r[i] = ok ? x[xbase + ((int64_t)ci * H + ih) * W + iw] : 0.0f;
+        }
+    }
+    __device__ __forceinline__ void put(const float (&r)[N], float *lds) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) lds[(t_k + KSTEP * i) * (BN + 1) + t_j] = r[i];
+    }
+};
+
+// conv dgrad B: B[k=(co,r,s)][j=q=(n,h,w)] = gy[n][co][(h+ph-r*dh)/sh][(w+pw-s*dw)/sw] when divisible & in range
+template <int BN, int BK>
+struct DgradBLoader {
+    static constexpr int N = BN * BK / 256;
+    static constexpr int KSTEP = 256 / BN;
+    const float *gy;
+    int K, OH, OW, R, S, dh, dw, sh, sw, Kg;
+    int th0, tw0, t_j, t_k;
+    int64_t base;
+    bool jvalid;
+    __device__ __forceinline__ void init(const float *gy_, const ConvGeom &g, int64_t q0, int64_t Q) {
+        gy = gy_; K = g.K; OH = g.OH; OW = g.OW; R = g.R; S = g.S; dh = g.dh; dw = g.dw; sh = g.sh; sw = g.sw;
+        Kg = g.K * g.R * g.S;
+        t_j = threadIdx.x % BN;
+        t_k = threadIdx.x / BN;
+        const int64_t q = q0 + t_j;
+        jvalid = q < Q;
+        const int hw = g.H * g.W;
+        const int n = jvalid ? (int)(q / hw) : 0;
+        const int rem = jvalid ? (int)(q % hw) : 0;
+        th0 = rem / g.W + g.ph;
+        tw0 = rem % g.W + g.pw;
+        base = (int64_t)n * K * OH * OW;
+    }
+    __device__ __forceinline__ void fetch(int kt, float (&r)[N]) {
+        const int RS = R * S;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int k = kt * BK + t_k + KSTEP * i;
+            const int co = k / RS, rs = k - co * RS;
+            const int rr = rs / S, ss = rs - rr * S;
+            const int th = th0 - rr * dh, tw = tw0 - ss * dw;
+            bool ok = jvalid && k < Kg && th >= 0 && tw >= 0;
+            int oh = th, ow = tw;
+            if (sh != 1) { oh = th / sh; ok = ok && (oh * sh == th); }
+            if (sw != 1) { ow = tw / sw; ok = ok && (ow * sw == tw); }
+            ok = ok && oh < OH && ow < OW;
+            r[i] = ok ? gy[base + ((int64_t)co * OH + oh) * OW + ow] : 0.0f;
+        }
+    }
+    __device__ __forceinline__ void put(const float (&r)[N], float *lds) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) lds[(t_k + KSTEP * i) * (BN + 1) + t_j] = r[i];
+    }
+};
+
+// conv dgrad A: A[k=(co,r,s)][m=ci] = Weff[co][ci][r][s]
+template <int BM, int BK>
+struct DgradALoader {
+    static constexpr int N = BM * BK / 256;
+    static constexpr int MSTEP = 256 / BK;
+    const float *w, *pm;
+    float thr;
+    int C, RS, Kg, m0, t_k, t_m;
+    __device__ __forceinline__ void init(const float *w_, const float *pm_, float thr_, const ConvGeom &g, int m0_) {
+        w = w_; pm = pm_; thr = thr_; C = g.C; RS = g.R * g.S; Kg = g.K * RS; m0 = m0_;
+        t_k = threadIdx.x % BK;
+        t_m = threadIdx.x / BK;
+    }
+    __device__ __forceinline__ void fetch(int kt, float (&r)[N]) {
+        const int k = kt * BK + t_k;
+        const int co = k / RS, rs = k - co * RS;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int ci = m0 + t_m + MSTEP * i;
+            float v = 0.0f;
+            if (k < Kg && ci < C) {
+                const int64_t off = ((int64_t)co * C + ci) * RS + rs;
+                v = w[off];
+                if (pm != nullptr) v *= binarize(pm[off], thr);
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void put(const float (&r)[N], float *lds) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) lds[t_k * (BM + 1) + t_m + MSTEP * i] = r[i];
+    }
+};
+
+// conv wgrad A: A[k=p][m=co] = gy[n_p][co][q_p]
+template <int BM, int BK>
+struct WgradALoader {
+    static constexpr int N = BM * BK / 256;
+    static constexpr int MSTEP = 256 / BK;
+    const float *gy;
+    int K, OHW, m0, t_k, t_m;
+    int64_t P;
+    __device__ __forceinline__ void init(const float *gy_, const ConvGeom &g, int m0_) {
+        gy = gy_; K = g.K; OHW = g.OH * g.OW; m0 = m0_; P = (int64_t)g.N * OHW;
+        t_k = threadIdx.x % BK;
+        t_m = threadIdx.x / BK;
+    }
+    __device__ __forceinline__ void fetch(int kt, float (&r)[N]) {
+        const int64_t p = (int64_t)kt * BK + t_k;
+        const bool pv = p < P;
+        const int n = pv ? (int)(p / OHW) : 0;
+        const int q = pv ? (int)(p % OHW) : 0;
+        const int64_t b = (int64_t)n * K * OHW + q;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int co = m0 + t_m + MSTEP * i;
+            r[i] = (pv && co < K) ? gy[b + (int64_t)co * OHW] : 0.0f;
+        }
+    }
+    __device__ __forceinline__ void put(const float (&r)[N], float *lds) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) lds[t_k * (BM + 1) + t_m + MSTEP * i] = r[i];
+    }
+};
+
+// conv wgrad B: B[k=p][j=(ci,r,s)] = x[n_p][ci][oh*sh-ph+r*dh][ow*sw-pw+s*dw]
+template <int BN, int BK>
+struct WgradBLoader {
+    static constexpr int N = BN * BK / 256;
+    static constexpr int JSTEP = 256 / BK;
+    const float *x;
+    int C, H, W, OW, OHW, sh, sw, ph, pw, t_k, t_j;
+    int64_t P;
+    int joff[N];      // ci*H*W + r*dh*W + s*dw, or -1 when j is out of range
+    int jrs[N];       // (r*dh) << 16 | (s*dw)
+    __device__ __forceinline__ void init(const float *x_, const ConvGeom &g, int j0) {
+        x = x_; C = g.C; H = g.H; W = g.W; OW = g.OW; OHW = g.OH * g.OW; sh = g.sh; sw = g.sw; ph = g.ph; pw = g.pw;
+        P = (int64_t)g.N * OHW;
+        t_k = threadIdx.x % BK;
+        t_j = threadIdx.x / BK;
+        const int RS = g.R * g.S, J = g.C * RS;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int j = j0 + t_j + JSTEP * i;
+            if (j < J) {
+                const int ci = j / RS, rs = j - ci * RS;
+                const int rr = (rs / g.S) * g.dh, ss = (rs % g.S) * g.dw;
+                joff[i] = ci * H * W + rr * W + ss;
+                jrs[i] = (rr << 16) | ss;
+            } else {
+                joff[i] = -1;
+                jrs[i] = 0;
+            }
+        }
+    }
+    __device__ __forceinline__ void fetch(int kt, float (&r)[N]) {
+        const int64_t p = (int64_t)kt * BK + t_k;
+        const bool pv = p < P;
+        const int n = pv ? (int)(p / OHW) : 0;
+        const int q = pv ? (int)(p % OHW) : 0;
+        const int oh = q / OW, ow = q - oh * OW;
+        const int ih0 = oh * sh - ph, iw0 = ow * sw - pw;
+        const int64_t b = (int64_t)n * C * H * W + (int64_t)ih0 * W + iw0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int ih = ih0 + (jrs[i] >> 16), iw = iw0 + (jrs[i] & 0xFFFF);
+            const bool ok = pv && joff[i] >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            r[i] = ok ? x[b + joff[i]] : 0.0f;
+        }
+    }
+    __device__ __forceinline__ void put(const float (&r)[N], float *lds) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) lds[t_k * (BN + 1) + t_j + JSTEP * i] = r[i];
+    }
+};
+
+// ---------------------------------------------------------------------------------- kernels
+// out-of-tile guards live in the loaders (zeros) and in the store lambdas.
+template <class Cfg>
+__global__ __launch_bounds__(256) void k_conv_fwd(ConvGeom g, const float *__restrict__ x, const float *__restrict__ w,
+                                                  const float *__restrict__ pm, float thr, Epilogue ep, int tiles_m) {
+    __shared__ float smem[Cfg::SMEM_FLOATS];
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lb % tiles_m, tn = lb / tiles_m;
+    const int Kg = g.C * g.R * g.S;
+    const int ohw = g.OH * g.OW;
+    const int64_t P = (int64_t)g.N * ohw;
+    const int m0 = tm * Cfg::BM;
+    const int64_t p0 = (int64_t)tn * Cfg::BN;
+    DenseLoader<Cfg::BM, Cfg::BK, true, true> la;      // pm == nullptr handled below
+    la.init(w, pm, thr, Kg, m0, g.K, Kg);
+    FwdBLoader<Cfg::BN, Cfg::BK> lbB;
+    lbB.init(x, g, p0, P);
+    f32x16 acc[Cfg::FM][Cfg::FN];
+    const int nkt = (Kg + Cfg::BK - 1) / Cfg::BK;
+    if (pm != nullptr) {
+        igemm_mainloop<Cfg>(la, lbB, 0, nkt, smem, acc);
+    } else {
+        DenseLoader<Cfg::BM, Cfg::BK, true, false> la0;
+        la0.init(w, nullptr, thr, Kg, m0, g.K, Kg);
+        igemm_mainloop<Cfg>(la0, lbB, 0, nkt, smem, acc);
+    }
+    const int K = g.K;
+    int64_t colbase[Cfg::FN];           // n*K*ohw + q per fragment column, -1 when past the end
+    col_setup<Cfg>(colbase, [&](int j) -> int64_t {
+        const int64_t p = p0 + j;
+        if (p >= P) return -1;
+        const int n = (int)(p / ohw), q = (int)(p - (int64_t)n * ohw);
+        return (int64_t)n * K * ohw + q;
+    });
+    for_each_acc<Cfg>(acc, [&](int m, int j, int fn, float v) {
+        const int co = m0 + m;
+        if (co < K && colbase[fn] >= 0) epilogue_store(ep, colbase[fn] + (int64_t)co * ohw, v);
+    });
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(256) void k_conv_dgrad(ConvGeom g, const float *__restrict__ gy, const float *__restrict__ w,
+                                                    const float *__restrict__ pm, float thr, Epilogue ep, int tiles_m) {
+    __shared__ float smem[Cfg::SMEM_FLOATS];
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lb % tiles_m, tn = lb / tiles_m;
+    const int Kg = g.K * g.R * g.S;
+    const int hw = g.H * g.W;
+    const int64_t Q = (int64_t)g.N * hw;
+    const int m0 = tm * Cfg::BM;
+    const int64_t q0 = (int64_t)tn * Cfg::BN;
+    DgradALoader<Cfg::BM, Cfg::BK> la;
+    la.init(w, pm, thr, g, m0);
+    DgradBLoader<Cfg::BN, Cfg::BK> lbB;
+    lbB.init(gy, g, q0, Q);
+    f32x16 acc[Cfg::FM][Cfg::FN];
+    igemm_mainloop<Cfg>(la, lbB, 0, (Kg + Cfg::BK - 1) / Cfg::BK, smem, acc);
+    const int C = g.C;
+    int64_t colbase[Cfg::FN];
+    col_setup<Cfg>(colbase, [&](int j) -> int64_t {
+        const int64_t q = q0 + j;
+        if (q >= Q) return -1;
+        const int n = (int)(q / hw), rem = (int)(q - (int64_t)n * hw);
+        return (int64_t)n * C * hw + rem;
+    });
+    for_each_acc<Cfg>(acc, [&](int m, int j, int fn, float v) {
+        const int ci = m0 + m;
+        if (ci < C && colbase[fn] >= 0) epilogue_store(ep, colbase[fn] + (int64_t)ci * hw, v);
+    });
+}
+
+// split-K over output pixels; blockIdx.y = split.  With nsplit > 1 raw partials go to `part`
+// ([nsplit][K*C*R*S]) and k_splitk_reduce applies the epilogue.
+template <class Cfg>
+__global__ __launch_bounds__(256) void k_conv_wgrad(ConvGeom g, const float *__restrict__ x, const float *__restrict__ gy,
+                                                    Epilogue ep, float *__restrict__ part, int tiles_m, int kt_per_split) {
+    __shared__ float smem[Cfg::SMEM_FLOATS];
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lb % tiles_m, tn = lb / tiles_m;
+    const int J = g.C * g.R * g.S;
+    const int64_t P = (int64_t)g.N * g.OH * g.OW;
+    const int nkt = (int)((P + Cfg::BK - 1) / Cfg::BK);
+    const int m0 = tm * Cfg::BM, j0 = tn * Cfg::BN;
+    WgradALoader<Cfg::BM, Cfg::BK> la;
+    la.init(gy, g, m0);
+    WgradBLoader<Cfg::BN, Cfg::BK> lbB;
+    lbB.init(x, g, j0);
+    f32x16 acc[Cfg::FM][Cfg::FN];
+    const int kt0 = blockIdx.y * kt_per_split;
+    const int kt1 = min(nkt, kt0 + kt_per_split);
+    igemm_mainloop<Cfg>(la, lbB, kt0, kt1, smem, acc);
+    const int K = g.K;
+    const int64_t out_elems = (int64_t)K * J;
+    float *dst = part ? part + (int64_t)blockIdx.y * out_elems : nullptr;
+    for_each_acc<Cfg>(acc, [&](int m, int j, int, float v) {
+        const int co = m0 + m, jj = j0 + j;
+        if (co < K && jj < J) {
+            const int64_t e = (int64_t)co * J + jj;
+            if (dst) dst[e] = v;
+            else epilogue_store(ep, e, v);
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------- linear
+// fwd  : y[b][o]  = sum_i x[b][i] * Weff[o][i]       A = x (KC), B = W (KC)      split-K over i
+// dgrad: gx[b][i] = sum_o gy[b][o] * Weff[o][i]      A = gy (KC), B = W (RC)     split-K over o
+// wgrad: gw[o][i] = sum_b gy[b][o] * x[b][i]         A = gy (RC), B = x (RC)     split-K over b
+template <class Cfg, bool A_KC, bool B_KC, int MASK_SIDE /*0 none,2 B*/>
+__global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
+                                              int64_t ldb, const float *__restrict__ pm, float thr, int M, int Nn, int Kd,
+                                              Epilogue ep, float *__restrict__ part, int tiles_m, int kt_per_split) {
+    __shared__ float smem[Cfg::SMEM_FLOATS];
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lb % tiles_m, tn = lb / tiles_m;
+    const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
+    const int nkt = (Kd + Cfg::BK - 1) / Cfg::BK;
+    const int kt0 = blockIdx.y * kt_per_split;
+    const int kt1 = min(nkt, kt0 + kt_per_split);
+    DenseLoader<Cfg::BM, Cfg::BK, A_KC, false> la;
+    la.init(A, nullptr, thr, lda, m0, M, Kd);
+    f32x16 acc[Cfg::FM][Cfg::FN];
+    if (MASK_SIDE == 2 && pm != nullptr) {
+        DenseLoader<Cfg::BN, Cfg::BK, B_KC, true> lbm;
+        lbm.init(B, pm, thr, ldb, n0, Nn, Kd);
+        igemm_mainloop<Cfg>(la, lbm, kt0, kt1, smem, acc);
+    } else {
+        DenseLoader<Cfg::BN, Cfg::BK, B_KC, false> lb0;
+        lb0.init(B, nullptr, thr, ldb, n0, Nn, Kd);
+        igemm_mainloop<Cfg>(la, lb0, kt0, kt1, smem, acc);
+    }
+    const int64_t out_elems = (int64_t)M * Nn;
+    float *dst = part ? part + (int64_t)blockIdx.y * out_elems : nullptr;
+    for_each_acc<Cfg>(acc, [&](int m, int j, int, float v) {
+        const int mm = m0 + m, jj = n0 + j;
+        if (mm < M && jj < Nn) {
+            const int64_t e = (int64_t)mm * Nn + jj;
+            if (dst) dst[e] = v;
+            else epilogue_store(ep, e, v);
+        }
+    });
+}
+
+// out[e] = epilogue(sum_s part[s][e]) -- deterministic order, one streaming pass
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float *__restrict__ part, int nsplit, int64_t out_elems,
+                                                       Epilogue ep) {
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < out_elems; e += nthreads) {
+        float s = 0.0f;
+        for (int k = 0; k < nsplit; ++k) s += part[(int64_t)k * out_elems + e];
+        epilogue_store(ep, e, s);
+    }
+}
+
+// gb[c] = sum over n, q of gy[n][c][q]   (conv: rows = N, inner = OH*OW; linear: inner = 1 with stride C)
+__global__ __launch_bounds__(256) void k_bias_grad(const float *__restrict__ gy, float *__restrict__ gb, int rows, int C,
+                                                   int inner) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float s = 0.0f;
+    const int64_t total = (int64_t)rows * inner;
+    for (int64_t i = threadIdx.x; i < total; i += 256) {
+        const int64_t n = i / inner, q = i - n * inner;
+        s += gy[(n * C + c) * inner + q];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) gb[c] = red[0];
+}
+
+using CfgA = TileCfg<128, 128, 16, 2, 2>;
+using CfgB = TileCfg<64, 256, 16, 1, 4>;
+
+int make_geom(const cpg_conv_desc *d, ConvGeom &g) {
+    CPG_REQUIRE(d != nullptr, "conv: null descriptor");
+    CPG_REQUIRE(d->N > 0 && d->C > 0 && d->H > 0 && d->W > 0 && d->K > 0 && d->R > 0 && d->S > 0, "conv: non-positive dimension");
+    CPG_REQUIRE(d->stride_h > 0 && d->stride_w > 0 && d->dil_h > 0 && d->dil_w > 0 && d->pad_h >= 0 && d->pad_w >= 0,
+                "conv: bad stride/dilation/padding");
+    if (d->groups != 1) return fail(CPG_E_UNSUPPORTED, "conv: groups=%d not implemented (all CPG configs use 1)", d->groups);
+    g = ConvGeom{d->N, d->C, d->H, d->W, d->K, d->R, d->S, d->stride_h, d->stride_w, d->pad_h, d->pad_w, d->dil_h, d->dil_w, 0, 0};
+    g.OH = (d->H + 2 * d->pad_h - d->dil_h * (d->R - 1) - 1) / d->stride_h + 1;
+    g.OW = (d->W + 2 * d->pad_w - d->dil_w * (d->S - 1) - 1) / d->stride_w + 1;
+    CPG_REQUIRE(g.OH > 0 && g.OW > 0, "conv: empty output");
+    CPG_REQUIRE((int64_t)d->C * d->H * d->W < (1ll << 31) && (int64_t)d->K * g.OH * g.OW < (1ll << 31) &&
+                    (int64_t)d->C * d->R * d->S < (1ll << 31),
+                "conv: per-image tensor exceeds 2^31 elements");
+    return CPG_OK;
+}
+
+// wgrad split-K plan: enough blocks to fill the chip (~4 per CU) without shrinking a split
+// below 8 K tiles; the partial buffer is nsplit * K*C*R*S floats.
+void wgrad_plan(int64_t tiles, int nkt, int &nsplit, int &kt_per_split) {
+    int64_t want = (4 * kCUs + tiles - 1) / tiles;
+    int64_t max_by_k = (nkt + 7) / 8;
+    if (want > max_by_k) want = max_by_k;
+    if (want < 1) want = 1;
+    if (want > 1024) want = 1024;
+    kt_per_split = (int)((nkt + want - 1) / want);
+    nsplit = (nkt + kt_per_split - 1) / kt_per_split;
+}
+
+template <class Cfg>
+void conv_wgrad_tiles(const ConvGeom &g, int &tiles_m, int &tiles_n) {
+    tiles_m = (g.K + Cfg::BM - 1) / Cfg::BM;
+    tiles_n = (g.C * g.R * g.S + Cfg::BN - 1) / Cfg::BN;
+}
+
+}  // namespace
+
+// The specialised 3x3 kernels (conv3x3.hip) take over when they support the shape.
+extern "C" int cpg_conv3x3_supported(const cpg_conv_desc *d);
+int cpg_conv3x3_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
+                    float *y, hipStream_t stream);
+int cpg_conv3x3_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx,
+                      hipStream_t stream);
+
+extern "C" size_t cpg_conv2d_workspace_bytes(const cpg_conv_desc *d) {
+    ConvGeom g;
+    if (make_geom(d, g) != CPG_OK) return 0;
+    int tm, tn, nsplit, per;
+    conv_wgrad_tiles<CfgA>(g, tm, tn);
+    const int64_t P = (int64_t)g.N * g.OH * g.OW;
+    wgrad_plan((int64_t)tm * tn, (int)((P + CfgA::BK - 1) / CfgA::BK), nsplit, per);
+    return nsplit > 1 ? (size_t)nsplit * g.K * g.C * g.R * g.S * sizeof(float) : 0;
+}
+
+extern "C" int cpg_conv2d_fwd_generic(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr,
+                                      const float *bias, float *y, void *stream_v) {
+    ConvGeom g;
+    int rc = make_geom(d, g);
+    if (rc) return rc;
+    CPG_REQUIRE(x && w && y, "cpg_conv2d_fwd: null pointer");
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int64_t P = (int64_t)g.N * g.OH * g.OW;
+    Epilogue ep{y, bias, bias ? BIAS_OUTER : BIAS_NONE, (int64_t)g.OH * g.OW, g.K, nullptr, nullptr, nullptr, thr};
+    if (g.K <= 64) {
+        const int tm = (g.K + CfgB::BM - 1) / CfgB::BM;
+        const int64_t tn = (P + CfgB::BN - 1) / CfgB::BN;
+        hipLaunchKernelGGL(k_conv_fwd<CfgB>, dim3((unsigned)(tm * tn)), dim3(256), 0, stream, g, x, w, pm, thr, ep, tm);
+    } else {
+        const int tm = (g.K + CfgA::BM - 1) / CfgA::BM;
+        const int64_t tn = (P + CfgA::BN - 1) / CfgA::BN;
+        hipLaunchKernelGGL(k_conv_fwd<CfgA>, dim3((unsigned)(tm * tn)), dim3(256), 0, stream, g, x, w, pm, thr, ep, tm);
+    }
+    CPG_CHECK_LAUNCH("cpg_conv2d_fwd");
+    return CPG_OK;
+}
+
+extern "C" int cpg_conv2d_dgrad_generic(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr,
+                                        float *gx, void *stream_v) {
+    ConvGeom g;
+    int rc = make_geom(d, g);
+    if (rc) return rc;
+    CPG_REQUIRE(gy && w && gx, "cpg_conv2d_dgrad: null pointer");
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int64_t Q = (int64_t)g.N * g.H * g.W;
+    Epilogue ep{gx, nullptr, BIAS_NONE, 1, 1, nullptr, nullptr, nullptr, thr};
+    if (g.C <= 64) {
+        const int tm = (g.C + CfgB::BM - 1) / CfgB::BM;
+        const int64_t tn = (Q + CfgB::BN - 1) / CfgB::BN;
+        hipLaunchKernelGGL(k_conv_dgrad<CfgB>, dim3((unsigned)(tm * tn)), dim3(256), 0, stream, g, gy, w, pm, thr, ep, tm);
+    } else {
+        const int tm = (g.C + CfgA::BM - 1) / CfgA::BM;
+        const int64_t tn = (Q + CfgA::BN - 1) / CfgA::BN;
+        hipLaunchKernelGGL(k_conv_dgrad<CfgA>, dim3((unsigned)(tm * tn)), dim3(256), 0, stream, g, gy, w, pm, thr, ep, tm);
+    }
+    CPG_CHECK_LAUNCH("cpg_conv2d_dgrad");
+    return CPG_OK;
+}
+
+extern "C" int cpg_conv2d_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr,
+                              const float *bias, float *y, void *ws, size_t ws_bytes, void *stream) {
+    (void)ws; (void)ws_bytes;
+    if (d && cpg_conv3x3_supported(d)) return cpg_conv3x3_fwd(d, x, w, pm, thr, bias, y, (hipStream_t)stream);
+    return cpg_conv2d_fwd_generic(d, x, w, pm, thr, bias, y, stream);
+}
+
+extern "C" int cpg_conv2d_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr,
+                                float *gx, void *ws, size_t ws_bytes, void *stream) {
+    (void)ws; (void)ws_bytes;
+    if (d && cpg_conv3x3_supported(d)) return cpg_conv3x3_dgrad(d, gy, w, pm, thr, gx, (hipStream_t)stream);
+    return cpg_conv2d_dgrad_generic(d, gy, w, pm, thr, gx, stream);
+}
+
+extern "C" int cpg_conv2d_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm,
+                                float thr, float *gw, float *gpm, float *gb, void *ws, size_t ws_bytes, void *stream_v) {
+    ConvGeom g;
+    int rc = make_geom(d, g);
+    if (rc) return rc;
+    CPG_REQUIRE(x && gy && gw, "cpg_conv2d_wgrad: null pointer");
+    CPG_REQUIRE((pm == nullptr) == (gpm == nullptr), "cpg_conv2d_wgrad: pm and gpm must both be given or both be NULL");
+    CPG_REQUIRE(pm == nullptr || w != nullptr, "cpg_conv2d_wgrad: w is required to form the piggymask gradient");
+    hipStream_t stream = (hipStream_t)stream_v;
+    int tm, tn, nsplit, per;
+    conv_wgrad_tiles<CfgA>(g, tm, tn);
+    const int64_t P = (int64_t)g.N * g.OH * g.OW;
+    const int nkt = (int)((P + CfgA::BK - 1) / CfgA::BK);
+    wgrad_plan((int64_t)tm * tn, nkt, nsplit, per);
+    const int64_t out_elems = (int64_t)g.K * g.C * g.R * g.S;
+    if (nsplit > 1 && ws_bytes < (size_t)nsplit * out_elems * sizeof(float))
+        return fail(CPG_E_WORKSPACE, "cpg_conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes,
+                    (size_t)nsplit * out_elems * sizeof(float));
+    Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
+    float *part = nsplit > 1 ? (float *)ws : nullptr;
+    hipLaunchKernelGGL(k_conv_wgrad<CfgA>, dim3((unsigned)(tm * tn), (unsigned)nsplit), dim3(256), 0, stream, g, x, gy, ep,
+                       part, tm, per);
+    if (nsplit > 1)
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(stream_grid(out_elems, 256)), dim3(256), 0, stream, part, nsplit, out_elems, ep);
+    if (gb) hipLaunchKernelGGL(k_bias_grad, dim3((unsigned)g.K), dim3(256), 0, stream, gy, gb, g.N, g.K, g.OH * g.OW);
+    CPG_CHECK_LAUNCH("cpg_conv2d_wgrad");
+    return CPG_OK;
+}
+
+// ---------------------------------------------------------------------------------- linear host side
+namespace {
+void gemm_plan(int64_t tiles, int nkt, int &nsplit, int &per) {
+    int64_t want = (2 * kCUs + tiles - 1) / tiles;      // aim for >= 2 blocks per CU
+    if (tiles >= 2 * kCUs) want = 1;
+    int64_t max_by_k = (nkt + 15) / 16;                  // >= 16 K tiles per split
+    if (want > max_by_k) want = max_by_k;
+    if (want < 1) want = 1;
+    if (want > 64) want = 64;
+    per = (int)((nkt + want - 1) / want);
+    nsplit = (nkt + per - 1) / per;
+}
+size_t linear_ws(int batch, int in_f, int out_f) {
+    size_t best = 0;
+    int ns, per;
+    {   // fwd: M=batch N=out K=in
+        int64_t tiles = (int64_t)((batch + 127) / 128) * ((out_f + 127) / 128);
+        gemm_plan(tiles, (in_f + 15) / 16, ns, per);
+        if (ns > 1) best = std::max(best, (size_t)ns * batch * out_f * sizeof(float));
+    }
+    {   // dgrad: M=batch N=in K=out
+        int64_t tiles = (int64_t)((batch + 127) / 128) * ((in_f + 127) / 128);
+        gemm_plan(tiles, (out_f + 15) / 16, ns, per);
+        if (ns > 1) best = std::max(best, (size_t)ns * batch * in_f * sizeof(float));
+    }
+    {   // wgrad: M=out N=in K=batch
+        int64_t tiles = (int64_t)((out_f + 127) / 128) * ((in_f + 127) / 128);
+        gemm_plan(tiles, (batch + 15) / 16, ns, per);
+        if (ns > 1) best = std::max(best, (size_t)ns * out_f * in_f * sizeof(float));
+    }
+    return best;
+}
+
+template <bool A_KC, bool B_KC, int MASK_SIDE>
+int launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, const float *pm, float thr, int M, int Nn, int Kd,
+                const Epilogue &ep, void *ws, size_t ws_bytes, hipStream_t stream, const char *what) {
+    const int tm = (M + CfgA::BM - 1) / CfgA::BM, tn = (Nn + CfgA::BN - 1) / CfgA::BN;
+    int nsplit, per;
+    gemm_plan((int64_t)tm * tn, (Kd + CfgA::BK - 1) / CfgA::BK, nsplit, per);
+    const int64_t out_elems = (int64_t)M * Nn;
+    if (nsplit > 1 && ws_bytes < (size_t)nsplit * out_elems * sizeof(float))
+        return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, (size_t)nsplit * out_elems * sizeof(float));
+    float *part = nsplit > 1 ? (float *)ws : nullptr;
+    hipLaunchKernelGGL((k_gemm<CfgA, A_KC, B_KC, MASK_SIDE>), dim3((unsigned)(tm * tn), (unsigned)nsplit), dim3(256), 0, stream,
+                       A, lda, B, ldb, pm, thr, M, Nn, Kd, ep, part, tm, per);
+    if (nsplit > 1)
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(stream_grid(out_elems, 256)), dim3(256), 0, stream, part, nsplit, out_elems, ep);
+    CPG_CHECK_LAUNCH(what);
+    return CPG_OK;
+}
+}  // namespace
+
+extern "C" size_t cpg_linear_workspace_bytes(int32_t batch, int32_t in_f, int32_t out_f) {
+    if (batch <= 0 || in_f <= 0 || out_f <= 0) return 0;
+    return linear_ws(batch, in_f, out_f);
+}
+
+extern "C" int cpg_linear_fwd(const float *x, const float *w, const float *pm, float thr, const float *bias, float *y,
+                              int32_t batch, int32_t in_f, int32_t out_f, void *ws, size_t ws_bytes, void *stream) {
+    CPG_REQUIRE(x && w && y && batch > 0 && in_f > 0 && out_f > 0, "cpg_linear_fwd: bad argument");
+    Epilogue ep{y, bias, bias ? BIAS_INNER : BIAS_NONE, out_f, 1, nullptr, nullptr, nullptr, thr};
+    return launch_gemm<true, true, 2>(x, in_f, w, in_f, pm, thr, batch, out_f, in_f, ep, ws, ws_bytes, (hipStream_t)stream,
+                                      "cpg_linear_fwd");
+}
+
+extern "C" int cpg_linear_dgrad(const float *gy, const float *w, const float *pm, float thr, float *gx, int32_t batch,
+                                int32_t in_f, int32_t out_f, void *ws, size_t ws_bytes, void *stream) {
+    CPG_REQUIRE(gy && w && gx && batch > 0 && in_f > 0 && out_f > 0, "cpg_linear_dgrad: bad argument");
+    Epilogue ep{gx, nullptr, BIAS_NONE, 1, 1, nullptr, nullptr, nullptr, thr};
+    return launch_gemm<true, false, 2>(gy, out_f, w, in_f, pm, thr, batch, in_f, out_f, ep, ws, ws_bytes, (hipStream_t)stream,
+                                       "cpg_linear_dgrad");
+}
+
+extern "C" int cpg_linear_wgrad(const float *x, const float *gy, const float *w, const float *pm, float thr, float *gw,
+                                float *gpm, float *gb, int32_t batch, int32_t in_f, int32_t out_f, void *ws, size_t ws_bytes,
+                                void *stream) {
+    CPG_REQUIRE(x && gy && gw && batch > 0 && in_f > 0 && out_f > 0, "cpg_linear_wgrad: bad argument");
+    CPG_REQUIRE((pm == nullptr) == (gpm == nullptr), "cpg_linear_wgrad: pm and gpm must both be given or both be NULL");
+    CPG_REQUIRE(pm == nullptr || w != nullptr, "cpg_linear_wgrad: w is required to form the piggymask gradient");
+    Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
+    int rc = launch_gemm<false, false, 0>(gy, out_f, x, in_f, nullptr, thr, out_f, in_f, batch, ep, ws, ws_bytes,
+                                          (hipStream_t)stream, "cpg_linear_wgrad");
+    if (rc) return rc;
+    if (gb) {
+        hipLaunchKernelGGL(k_bias_grad, dim3((unsigned)out_f), dim3(256), 0, (hipStream_t)stream, gy, gb, batch, out_f, 1);
+        CPG_CHECK_LAUNCH("cpg_linear_wgrad(bias)");
+    }
+    return CPG_OK;
+}

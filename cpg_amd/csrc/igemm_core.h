@@ -1,0 +1,219 @@
+// Shared main loop of the fp32 MFMA implicit-GEMM kernels (conv fwd / dgrad / wgrad, linear).
+//
+//   D[m][j] += sum_k A[k][m] * B[k][j]          (m: BM rows, j: BN cols, k: BK per step)
+//
+// Both operands are staged in LDS k-major ([BK][BM+1] and [BK][BN+1] floats) so that the
+// v_mfma_f32_32x32x2_f32 operand fetch -- lane l reads A[k = l>>5][m = l&31] and
+// B[k = l>>5][j = l&31] (one VGPR each) -- is a conflict-free ds_read_b32 of 32 consecutive
+// floats per half-wave.  The effective weight W * bin(piggymask) is formed by the operand
+// loaders while they stage the tile (never materialised in HBM).
+//
+// Pipeline: two LDS stages; the global loads of tile t+1 are issued into registers before the
+// MFMAs of tile t and written to the other stage after them => one __syncthreads per K tile
+// and HBM/L2 latency hidden under 2*BK... MFMA issue cycles.  fp32-in MFMA is 64 FLOP/clk/SIMD
+// (1/16 of bf16), so a 2x2 register block (4 ds_read_b32 per 4 MFMAs = 256 cycles) leaves the
+// LDS pipe ~95 % idle; the kernel is MFMA-issue bound by construction.
+#pragma once
+#include "cpg_common.h"
+
+namespace cpg {
+
+template <int BM_, int BN_, int BK_, int WM_, int WN_>
+struct TileCfg {
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
+    static constexpr int THREADS = 256;
+    static_assert(WM * WN == 4, "4 waves per block");
+    static constexpr int FM = BM / 32 / WM;       // 32x32 fragments per wave along m
+    static constexpr int FN = BN / 32 / WN;
+    static_assert(FM >= 1 && FN >= 1 && BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile/wave mismatch");
+    static constexpr int LDA = BM + 1, LDB = BN + 1;
+    static constexpr int A_ELEMS = BK * LDA, B_ELEMS = BK * LDB;
+    static constexpr int STAGE_ELEMS = A_ELEMS + B_ELEMS;
+    static constexpr int SMEM_FLOATS = 2 * STAGE_ELEMS;
+    static constexpr int NA = BM * BK / THREADS;  // staged elements per thread
+    static constexpr int NB = BN * BK / THREADS;
+    static_assert((BM * BK) % THREADS == 0 && (BN * BK) % THREADS == 0, "staging must divide evenly");
+};
+
+// XCD-aware, bijective remap of the linear block id: the dispatcher places block b on XCD b % 8;
+// hand each XCD a contiguous run of logical tiles so neighbours (same pixel tile, next channel
+// tile; adjacent pixel tiles) share that XCD's 4 MiB L2.  Speed only, never correctness.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
+    const unsigned q = nblocks / kXCDs, r = nblocks % kXCDs;
+    const unsigned xcd = bid % kXCDs, idx = bid / kXCDs;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+template <class Cfg>
+__device__ __forceinline__ void mma_stage(const float *__restrict__ As, const float *__restrict__ Bs,
+                                          f32x16 (&acc)[Cfg::FM][Cfg::FN], int a_off, int b_off) {
+    // a_off = (lane>>5)*LDA + wave_m*FM*32 + (lane&31) ; b_off likewise
+#pragma unroll
+    for (int s = 0; s < Cfg::BK / 2; ++s) {
+        float a[Cfg::FM], b[Cfg::FN];
+#pragma unroll
+        for (int fm = 0; fm < Cfg::FM; ++fm) a[fm] = As[a_off + 2 * s * Cfg::LDA + fm * 32];
+#pragma unroll
+        for (int fn = 0; fn < Cfg::FN; ++fn) b[fn] = Bs[b_off + 2 * s * Cfg::LDB + fn * 32];
+#pragma unroll
+        for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < Cfg::FN; ++fn)
+                acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fm], b[fn], acc[fm][fn], 0, 0, 0);
+    }
+}
+
+// ALoader / BLoader concept:
+//   void fetch(int kt, float (&r)[N])            issue the global loads of K tile kt into registers
+//   void put(const float (&r)[N], float *lds)    write them to an LDS stage
+template <class Cfg, class ALoader, class BLoader>
+__device__ __forceinline__ void igemm_mainloop(ALoader &la, BLoader &lb, int kt_begin, int kt_end, float *smem,
+                                               f32x16 (&acc)[Cfg::FM][Cfg::FN]) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int a_off = (lane >> 5) * Cfg::LDA + wm * Cfg::FM * 32 + (lane & 31);
+    const int b_off = (lane >> 5) * Cfg::LDB + wn * Cfg::FN * 32 + (lane & 31);
+#pragma unroll
+    for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < Cfg::FN; ++fn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[fm][fn][e] = 0.0f;
+    if (kt_begin >= kt_end) return;
+
+    float ra[Cfg::NA], rb[Cfg::NB];
+    la.fetch(kt_begin, ra);
+    lb.fetch(kt_begin, rb);
+    la.put(ra, smem);
+    lb.put(rb, smem + Cfg::A_ELEMS);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        float *stage = smem + cur * Cfg::STAGE_ELEMS;
+        float *next = smem + (cur ^ 1) * Cfg::STAGE_ELEMS;
+        const bool more = (kt + 1 < kt_end);
+        if (more) {
+            la.fetch(kt + 1, ra);
+            lb.fetch(kt + 1, rb);
+        }
+        mma_stage<Cfg>(stage, stage + Cfg::A_ELEMS, acc, a_off, b_off);
+        if (more) {
+            la.put(ra, next);
+            lb.put(rb, next + Cfg::A_ELEMS);
+        }
+        __syncthreads();
+    }
+}
+
+// Walk the accumulator fragments: f(m_local, j_local, fn, value).  C/D layout of 32x32 MFMA:
+// col j = lane & 31, row m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+template <class Cfg, class F>
+__device__ __forceinline__ void for_each_acc(const f32x16 (&acc)[Cfg::FM][Cfg::FN], F &&f) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+#pragma unroll
+    for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < Cfg::FN; ++fn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int j = (wn * Cfg::FN + fn) * 32 + (lane & 31);
+                f(m, j, fn, acc[fm][fn][e]);
+            }
+}
+
+// per-fragment-column setup: out[fn] = f(j_local of this lane in fragment column fn)
+template <class Cfg, class F>
+__device__ __forceinline__ void col_setup(int64_t (&out)[Cfg::FN], F &&f) {
+    const int lane = threadIdx.x & 63;
+    const int wn = (threadIdx.x >> 6) % Cfg::WN;
+#pragma unroll
+    for (int fn = 0; fn < Cfg::FN; ++fn) out[fn] = f((wn * Cfg::FN + fn) * 32 + (lane & 31));
+}
+
+// ------------------------------------------------------------------------------------------
+// Dense operand loaders (linear layers; weights of conv fwd)
+// ------------------------------------------------------------------------------------------
+// "KC": element (k, row) at base[row * ld + k]  -- K contiguous in memory (lanes run along k)
+// "RC": element (k, row) at base[k * ld + row]  -- row contiguous in memory (lanes run along row)
+// ROWS = BM or BN, LD_LDS = ROWS + 1.  Optional piggymask with the same indexing.
+template <int ROWS, int BK, bool KC, bool HAS_PM>
+struct DenseLoader {
+    static constexpr int N = ROWS * BK / 256;
+    static constexpr int LDS_LD = ROWS + 1;
+    const float *base;
+    const float *pm;
+    float thr;
+    int64_t ld;
+    int row0, rows_total, k_total;
+    // per-thread mapping
+    int t_k, t_row;          // KC: k = t_k, row = t_row + (256/BK)*i ; RC: row = t_row, k = t_k + (256/ROWS)*i
+
+    __device__ __forceinline__ void init(const float *b, const float *p, float th, int64_t ld_, int row0_, int rows_total_,
+                                         int k_total_) {
+        base = b; pm = p; thr = th; ld = ld_; row0 = row0_; rows_total = rows_total_; k_total = k_total_;
+        if (KC) {
+            t_k = threadIdx.x % BK;
+            t_row = threadIdx.x / BK;
+        } else {
+            t_row = threadIdx.x % ROWS;
+            t_k = threadIdx.x / ROWS;
+        }
+    }
+    __device__ __forceinline__ void fetch(int kt, float (&r)[N]) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int k = kt * BK + (KC ? t_k : t_k + (256 / ROWS) * i);
+            const int row = row0 + (KC ? t_row + (256 / BK) * i : t_row);
+            float v = 0.0f;
+            if (k < k_total && row < rows_total) {
+                const int64_t off = KC ? (int64_t)row * ld + k : (int64_t)k * ld + row;
+                v = base[off];
+                if (HAS_PM) v *= binarize(pm[off], thr);
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void put(const float (&r)[N], float *lds) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int kk = KC ? t_k : t_k + (256 / ROWS) * i;
+            const int rr = KC ? t_row + (256 / BK) * i : t_row;
+            lds[kk * LDS_LD + rr] = r[i];
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Output description shared by the direct epilogue and the split-K reduction.
+// ------------------------------------------------------------------------------------------
+enum BiasMode { BIAS_NONE = 0, BIAS_OUTER = 1, BIAS_INNER = 2 };
+// flat output index e:   BIAS_OUTER: channel = (e / inner) % outer   (conv: inner = OH*OW, outer = K)
+//                        BIAS_INNER: channel = e % inner             (linear: inner = out_features)
+struct Epilogue {
+    float *out;            // y / gx / gw
+    const float *bias;     // or nullptr
+    int bias_mode;
+    int64_t inner, outer;
+    const float *pm;       // wgrad: piggymask (nullptr -> plain copy)
+    const float *w;        // wgrad: weight, for gpm
+    float *gpm;            // wgrad: piggymask grad out (nullptr if pm == nullptr)
+    float thr;
+};
+
+__device__ __forceinline__ void epilogue_store(const Epilogue &ep, int64_t e, float v) {
+    if (ep.bias_mode == BIAS_OUTER) v += ep.bias[(e / ep.inner) % ep.outer];
+    else if (ep.bias_mode == BIAS_INNER) v += ep.bias[e % ep.inner];
+    if (ep.pm != nullptr) {
+        // autograd of `bin(pm) * W` (models/layers.py:103): gW = g * bin(pm), gPM = g * W (straight-through)
+        ep.gpm[e] = v * ep.w[e];
+        v *= binarize(ep.pm[e], ep.thr);
+    }
+    ep.out[e] = v;
+}
+
+}  // namespace cpg

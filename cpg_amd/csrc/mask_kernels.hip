@@ -1,0 +1,287 @@
+// HBM-bound mask / gradient-routing kernels (K1, K4e, K7, K8 of SURVEY.md section 2).
+// Each is a single streaming pass: 16 B per lane per access for fp32, 4 owner bytes as one
+// dword, grid capped at 8 blocks per CU with a grid-stride loop.  gfx950 only.
+#include "cpg_common.h"
+
+using namespace cpg;
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct alignas(16) F4 { float x, y, z, w; };
+
+__device__ __forceinline__ bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---------------------------------------------------------------- K1
+__global__ __launch_bounds__(kThreads) void k_binarize_mul(const float *__restrict__ w,
+                                                           const float *__restrict__ pm, float thr,
+                                                           float *__restrict__ out, int64_t n, int vec_ok) {
+    // w == nullptr: plain Binarizer (out = bin(pm)); else out = w * bin(pm)
+    const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * kThreads;
+    const bool has_w = (w != nullptr);
+    if (vec_ok) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += nthreads) {
+            const F4 m = reinterpret_cast<const F4 *>(pm)[i];
+            F4 r = {binarize(m.x, thr), binarize(m.y, thr), binarize(m.z, thr), binarize(m.w, thr)};
+            if (has_w) {
+                const F4 a = reinterpret_cast<const F4 *>(w)[i];
+                r = F4{a.x * r.x, a.y * r.y, a.z * r.z, a.w * r.w};
+            }
+            reinterpret_cast<F4 *>(out)[i] = r;
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += nthreads) out[i] = (has_w ? w[i] : 1.0f) * binarize(pm[i], thr);
+    } else {
+        for (int64_t i = tid; i < n; i += nthreads) out[i] = (has_w ? w[i] : 1.0f) * binarize(pm[i], thr);
+    }
+}
+
+// ---------------------------------------------------------------- K4e
+// utils/prune.py:203-210 in one pass.  MODE: 0 finetune, 1 prune.
+template <bool HAS_PM>
+__global__ __launch_bounds__(kThreads) void k_route(float *__restrict__ gw, const float *__restrict__ w,
+                                                    const uint8_t *__restrict__ owner, int cur, float wd,
+                                                    float *__restrict__ gpm, int mode, int64_t n, int vec_ok) {
+    const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * kThreads;
+    auto route1 = [&](int64_t i) {
+        const int o = owner[i];
+        gw[i] = (o == cur) ? fmaf(wd, w[i], gw[i]) : 0.0f;
+        if (HAS_PM) {
+            if (mode == CPG_MODE_PRUNE || o == 0 || o >= cur) gpm[i] = 0.0f;
+        }
+    };
+    if (vec_ok) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += nthreads) {
+            const uint32_t o4 = reinterpret_cast<const uint32_t *>(owner)[i];
+            const int o0 = o4 & 255, o1 = (o4 >> 8) & 255, o2 = (o4 >> 16) & 255, o3 = o4 >> 24;
+            F4 g = {0.f, 0.f, 0.f, 0.f};
+            if (o0 == cur || o1 == cur || o2 == cur || o3 == cur) {      // frozen quads: no gw / w read at all
+                const F4 gi = reinterpret_cast<const F4 *>(gw)[i];
+                const F4 wi = reinterpret_cast<const F4 *>(w)[i];
+                g.x = (o0 == cur) ? fmaf(wd, wi.x, gi.x) : 0.0f;
+                g.y = (o1 == cur) ? fmaf(wd, wi.y, gi.y) : 0.0f;
+                g.z = (o2 == cur) ? fmaf(wd, wi.z, gi.z) : 0.0f;
+                g.w = (o3 == cur) ? fmaf(wd, wi.w, gi.w) : 0.0f;
+            }
+            reinterpret_cast<F4 *>(gw)[i] = g;
+            if (HAS_PM) {
+                if (mode == CPG_MODE_PRUNE) {
+                    reinterpret_cast<F4 *>(gpm)[i] = F4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    const bool z0 = (o0 == 0 || o0 >= cur), z1 = (o1 == 0 || o1 >= cur);
+                    const bool z2 = (o2 == 0 || o2 >= cur), z3 = (o3 == 0 || o3 >= cur);
+                    if (z0 || z1 || z2 || z3) {
+                        F4 p = {0.f, 0.f, 0.f, 0.f};
+                        if (!(z0 && z1 && z2 && z3)) {
+                            p = reinterpret_cast<const F4 *>(gpm)[i];
+                            if (z0) p.x = 0.f;
+                            if (z1) p.y = 0.f;
+                            if (z2) p.z = 0.f;
+                            if (z3) p.w = 0.f;
+                        }
+                        reinterpret_cast<F4 *>(gpm)[i] = p;
+                    }
+                }
+            }
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += nthreads) route1(i);
+    } else {
+        for (int64_t i = tid; i < n; i += nthreads) route1(i);
+    }
+}
+
+// ---------------------------------------------------------------- K7
+// Owner-id histogram.  Owner ids take very few distinct values per layer, so plain LDS atomics
+// would serialise 64-way on one bin; instead each wave peels off one distinct value per
+// iteration with readfirstlane + ballot + popcount and issues ONE LDS atomic for it.
+__device__ __forceinline__ void wave_count_byte(unsigned v, unsigned *hist_lds) {
+    for (;;) {
+        const unsigned u = __builtin_amdgcn_readfirstlane(v);
+        const unsigned long long m = __ballot(v == u);
+        if (v == u) {
+            const int first = __ffsll((long long)m) - 1;
+            if ((int)(threadIdx.x & 63) == first) atomicAdd(&hist_lds[u], (unsigned)__popcll(m));
+            break;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_mask_hist(const uint8_t *__restrict__ owner,
+                                                        const float *__restrict__ pm, int idx, int64_t n,
+                                                        unsigned long long *__restrict__ hist, int vec_ok) {
+    __shared__ unsigned h[257];
+    for (int i = threadIdx.x; i < 257; i += kThreads) h[i] = 0;
+    __syncthreads();
+    const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * kThreads;
+    unsigned shared_cnt = 0;
+    const float pick_thr = 0.005f;                 // literal of utils/prune.py:188
+    if (vec_ok) {
+        const int64_t n4 = n >> 2;
+        // all lanes of a wave iterate together (uniform trip count) so ballots see whole waves
+        const int64_t iters = (n4 + nthreads - 1) / nthreads;
+        for (int64_t it = 0; it < iters; ++it) {
+            const int64_t i = tid + it * nthreads;
+            if (i < n4) {
+                const uint32_t o4 = reinterpret_cast<const uint32_t *>(owner)[i];
+                if (pm != nullptr) {
+                    const bool a0 = (o4 & 255) > 0 && (int)(o4 & 255) < idx;
+                    const bool a1 = ((o4 >> 8) & 255) > 0 && (int)((o4 >> 8) & 255) < idx;
+                    const bool a2 = ((o4 >> 16) & 255) > 0 && (int)((o4 >> 16) & 255) < idx;
+                    const bool a3 = (o4 >> 24) > 0 && (int)(o4 >> 24) < idx;
+                    if (a0 || a1 || a2 || a3) {
+                        const F4 p = reinterpret_cast<const F4 *>(pm)[i];
+                        shared_cnt += (a0 && p.x > pick_thr) + (a1 && p.y > pick_thr) + (a2 && p.z > pick_thr) +
+                                      (a3 && p.w > pick_thr);
+                    }
+                }
+                wave_count_byte(o4 & 255, h);
+                wave_count_byte((o4 >> 8) & 255, h);
+                wave_count_byte((o4 >> 16) & 255, h);
+                wave_count_byte(o4 >> 24, h);
+            }
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += nthreads) {
+            const unsigned o = owner[i];
+            atomicAdd(&h[o], 1u);
+            if (pm != nullptr && o > 0 && (int)o < idx && pm[i] > pick_thr) shared_cnt++;
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += nthreads) {
+            const unsigned o = owner[i];
+            atomicAdd(&h[o], 1u);
+            if (pm != nullptr && o > 0 && (int)o < idx && pm[i] > pick_thr) shared_cnt++;
+        }
+    }
+    if (shared_cnt) atomicAdd(&h[256], shared_cnt);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 257; i += kThreads)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+// ---------------------------------------------------------------- K8
+// zero w where owner == 0 (zero_pruned) or additionally owner > idx (apply_mask, idx < 256)
+__global__ __launch_bounds__(kThreads) void k_zero_by_owner(float *__restrict__ w, const uint8_t *__restrict__ owner,
+                                                            int idx, int64_t n, int vec_ok) {
+    const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * kThreads;
+    auto dead = [idx](int o) { return o == 0 || o > idx; };
+    if (vec_ok) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += nthreads) {
+            const uint32_t o4 = reinterpret_cast<const uint32_t *>(owner)[i];
+            const bool d0 = dead(o4 & 255), d1 = dead((o4 >> 8) & 255), d2 = dead((o4 >> 16) & 255), d3 = dead(o4 >> 24);
+            if (d0 && d1 && d2 && d3) {
+                reinterpret_cast<F4 *>(w)[i] = F4{0.f, 0.f, 0.f, 0.f};
+            } else if (d0 || d1 || d2 || d3) {
+                F4 v = reinterpret_cast<const F4 *>(w)[i];
+                if (d0) v.x = 0.f;
+                if (d1) v.y = 0.f;
+                if (d2) v.z = 0.f;
+                if (d3) v.w = 0.f;
+                reinterpret_cast<F4 *>(w)[i] = v;
+            }
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += nthreads)
+            if (dead(owner[i])) w[i] = 0.0f;
+    } else {
+        for (int64_t i = tid; i < n; i += nthreads)
+            if (dead(owner[i])) w[i] = 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_claim_free(uint8_t *__restrict__ owner, unsigned new_idx, int64_t n,
+                                                         int vec_ok) {
+    const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * kThreads;
+    if (vec_ok) {
+        const int64_t n16 = n >> 4;
+        for (int64_t i = tid; i < n16; i += nthreads) {
+            uint4 v = reinterpret_cast<const uint4 *>(owner)[i];
+            auto fix = [new_idx](uint32_t x) {
+                // bytes that are zero -> new_idx.  exact zero-byte detect (no borrow artefacts)
+                uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+                t = ~(t | x | 0x7F7F7F7Fu);            // 0x80 in every zero byte
+                return x | ((t >> 7) * new_idx);
+            };
+            const uint4 r = {fix(v.x), fix(v.y), fix(v.z), fix(v.w)};
+            if (r.x != v.x || r.y != v.y || r.z != v.z || r.w != v.w) reinterpret_cast<uint4 *>(owner)[i] = r;
+        }
+        for (int64_t i = (n16 << 4) + tid; i < n; i += nthreads)
+            if (owner[i] == 0) owner[i] = (uint8_t)new_idx;
+    } else {
+        for (int64_t i = tid; i < n; i += nthreads)
+            if (owner[i] == 0) owner[i] = (uint8_t)new_idx;
+    }
+}
+
+inline int is16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int cpg_binarize_mask_weight(const float *w, const float *pm, float thr, float *w_eff, int64_t n,
+                                        void *stream) {
+    CPG_REQUIRE(pm && w_eff && n >= 0, "cpg_binarize_mask_weight: null pointer or negative n");
+    if (n == 0) return CPG_OK;
+    const int vec = (!w || is16(w)) && is16(pm) && is16(w_eff);
+    hipLaunchKernelGGL(k_binarize_mul, dim3(stream_grid(n, kThreads * 4)), dim3(kThreads), 0, (hipStream_t)stream, w, pm,
+                       thr, w_eff, n, vec);
+    CPG_CHECK_LAUNCH("cpg_binarize_mask_weight");
+    return CPG_OK;
+}
+
+extern "C" int cpg_route_grads(float *gw, const float *w, const uint8_t *owner, int32_t cur, float wd, float *gpm,
+                               int32_t mode, int64_t n, void *stream) {
+    CPG_REQUIRE(gw && w && owner && n >= 0, "cpg_route_grads: null pointer or negative n");
+    CPG_REQUIRE(mode == CPG_MODE_FINETUNE || mode == CPG_MODE_PRUNE, "cpg_route_grads: unknown mode %d", mode);
+    CPG_REQUIRE(cur >= 0 && cur <= 255, "cpg_route_grads: owner id %d out of uint8 range", cur);
+    if (n == 0) return CPG_OK;
+    const int vec = is16(gw) && is16(w) && (((uintptr_t)owner) & 3) == 0 && (!gpm || is16(gpm));
+    const dim3 grid(stream_grid(n, kThreads * 4)), block(kThreads);
+    if (gpm)
+        hipLaunchKernelGGL(k_route<true>, grid, block, 0, (hipStream_t)stream, gw, w, owner, cur, wd, gpm, mode, n, vec);
+    else
+        hipLaunchKernelGGL(k_route<false>, grid, block, 0, (hipStream_t)stream, gw, w, owner, cur, wd, gpm, mode, n, vec);
+    CPG_CHECK_LAUNCH("cpg_route_grads");
+    return CPG_OK;
+}
+
+extern "C" int cpg_mask_hist(const uint8_t *owner, const float *pm, int32_t inference_idx, int64_t n, uint64_t *hist,
+                             void *stream) {
+    CPG_REQUIRE(owner && hist && n >= 0, "cpg_mask_hist: null pointer or negative n");
+    if (n == 0) return CPG_OK;
+    const int vec = (((uintptr_t)owner) & 3) == 0 && (!pm || is16(pm));
+    hipLaunchKernelGGL(k_mask_hist, dim3(stream_grid(n, kThreads * 16)), dim3(kThreads), 0, (hipStream_t)stream, owner, pm,
+                       inference_idx, n, (unsigned long long *)hist, vec);
+    CPG_CHECK_LAUNCH("cpg_mask_hist");
+    return CPG_OK;
+}
+
+extern "C" int cpg_apply_mask(float *w, const uint8_t *owner, int32_t inference_idx, int64_t n, void *stream) {
+    CPG_REQUIRE(w && owner && n >= 0, "cpg_apply_mask: null pointer or negative n");
+    if (n == 0) return CPG_OK;
+    const int vec = is16(w) && (((uintptr_t)owner) & 3) == 0;
+    hipLaunchKernelGGL(k_zero_by_owner, dim3(stream_grid(n, kThreads * 4)), dim3(kThreads), 0, (hipStream_t)stream, w,
+                       owner, inference_idx, n, vec);
+    CPG_CHECK_LAUNCH("cpg_apply_mask");
+    return CPG_OK;
+}
+
+extern "C" int cpg_zero_pruned(float *w, const uint8_t *owner, int64_t n, void *stream) {
+    return cpg_apply_mask(w, owner, 255, n, stream);      // no uint8 owner exceeds 255: only owner == 0 dies
+}
+
+extern "C" int cpg_claim_free(uint8_t *owner, int32_t new_idx, int64_t n, void *stream) {
+    CPG_REQUIRE(owner && n >= 0, "cpg_claim_free: null pointer or negative n");
+    CPG_REQUIRE(new_idx >= 1 && new_idx <= 255, "cpg_claim_free: owner id %d out of uint8 range", new_idx);
+    if (n == 0) return CPG_OK;
+    const int vec = is16(owner);
+    hipLaunchKernelGGL(k_claim_free, dim3(stream_grid(n, kThreads * 16)), dim3(kThreads), 0, (hipStream_t)stream, owner,
+                       (unsigned)new_idx, n, vec);
+    CPG_CHECK_LAUNCH("cpg_claim_free");
+    return CPG_OK;
+}

@@ -1,0 +1,113 @@
+"""Data parallelism for the CPG hot path: one process per GPU, gradients all-reduced with RCCL over xGMI.
+
+Replaces the reference's single-process `nn.DataParallel(model)` (CPG_cifar100_main_normal.py:199-200),
+which re-broadcasts every parameter and piggymask (~537 MB for VGG16@224) to all replicas each step and
+reduces gradients onto GPU 0.  Here every rank keeps resident weights / owner masks / optimizer state and
+only gradients move: each parameter's gradient is all-reduced (mean) as soon as autograd has produced it,
+on RCCL's own stream, overlapping the rest of backward; large tensors go out individually (no staging
+copy), small ones (BN, biases, heads) are coalesced into one flat message.
+
+Semantics kept from the reference:
+  * loss is the mean over the GLOBAL batch  <=> mean over ranks of equal-size shard means;
+  * BatchNorm uses per-replica batch statistics; running stats are rank 0's (sync_buffers());
+  * gradient routing / optimizer step / rank prune / statistics are deterministic functions of
+    replicated state and run redundantly on every rank -- no further collective.
+The wrapper keeps the `.module` attribute and the `module.` prefix in named_modules(), so owner-mask
+dictionaries keyed like the reference's (`module.features.0`, ...) work unchanged.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+
+
+class DataParallel(nn.Module):
+    def __init__(self, module, process_group=None, large_numel=1 << 20, broadcast_init=True):
+        super().__init__()
+        self.module = module
+        self.process_group = process_group
+        self.large_numel = int(large_numel)
+        self._active = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        self._world = dist.get_world_size(process_group) if self._active else 1
+        self._handles = []
+        self._small = []
+        self._hooked = set()
+        if self._active and broadcast_init:
+            self.sync_parameters()
+        self._install_hooks()
+
+    # -- wiring -------------------------------------------------------------------------------
+    def _install_hooks(self):
+        """(Re)attach the post-accumulate hooks; call again after assigning new Parameters
+        (e.g. piggymasks created after wrapping, CPG_cifar100_main_normal.py:263-270)."""
+        if not self._active:
+            return
+        for p in self.module.parameters():
+            if p.requires_grad and id(p) not in self._hooked:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+                self._hooked.add(id(p))
+
+    refresh_hooks = _install_hooks
+
+    def _on_grad(self, p):
+        if p.grad is None:
+            return
+        if p.numel() >= self.large_numel:
+            g = p.grad
+            if not g.is_contiguous():
+                p.grad = g = g.contiguous()
+            self._handles.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True), g))
+        else:
+            self._small.append(p)
+
+    # -- public API ---------------------------------------------------------------------------
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def finish_gradient_sync(self):
+        """Block the current stream until every gradient holds the global-batch mean.  Call once after
+        backward() and before gradient routing / optimizer.step() (Manager.train does)."""
+        if not self._active:
+            return
+        inv = 1.0 / self._world
+        if self._small:
+            grads = [p.grad for p in self._small]
+            flat = _flatten_dense_tensors(grads)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
+            flat.mul_(inv)
+            for g, s in zip(grads, _unflatten_dense_tensors(flat, grads)):
+                g.copy_(s)
+            self._small = []
+        for work, g in self._handles:
+            work.wait()
+            g.mul_(inv)
+        self._handles = []
+
+    def sync_parameters(self, src=0):
+        """Make every rank start from rank `src`'s parameters and buffers."""
+        if not self._active:
+            return
+        for t in list(self.module.parameters()) + list(self.module.buffers()):
+            dist.broadcast(t.data, src=src, group=self.process_group)
+
+    def sync_buffers(self, src=0):
+        """BatchNorm running statistics: keep rank 0's, as the reference's replica 0 does."""
+        if not self._active:
+            return
+        for b in self.module.buffers():
+            dist.broadcast(b.data, src=src, group=self.process_group)
+
+
+def shard_batch(data, target, rank=None, world=None):
+    """Even split of a global batch over ranks (the scatter of nn.DataParallel, along dim 0)."""
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1:
+        return data, target
+    n = data.size(0)
+    if n % world:
+        raise ValueError('global batch %d is not divisible by world size %d' % (n, world))
+    per = n // world
+    return data[rank * per:(rank + 1) * per], target[rank * per:(rank + 1) * per]

@@ -1,0 +1,237 @@
+"""Masked operators of CPG on MI355X: drop-in counterparts of the reference's models/layers.py.
+
+    Binarizer        models/layers.py:11-23
+    SharableConv2d   models/layers.py:43-145
+    SharableLinear   models/layers.py:147-218
+
+Same constructor signatures, attributes (.weight/.bias/.piggymask/.info/...) and forward
+semantics; the arithmetic is libcpg_hip.so's: the effective weight W * bin(piggymask) is formed
+inside the conv / GEMM kernels' LDS staging pass (never materialised), the contraction runs on
+fp32 MFMA, and backward returns gW = gW_eff * bin(pm), gPM = gW_eff * W exactly as autograd of
+the reference's `mask_thresholded * self.weight` does (models/layers.py:103,190).
+
+Ternarizer (models/layers.py:25-40) is dead code in the reference (pre-0.4 autograd API, never
+selected by any script); asking for it raises NotImplementedError here.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+from torch.nn.modules.utils import _pair
+from torch.nn.parameter import Parameter
+
+from .. import _lib
+
+DEFAULT_THRESHOLD = 5e-3      # models/layers.py:9
+
+
+class Binarizer(torch.autograd.Function):
+    """{0,1} hard threshold with straight-through gradient (models/layers.py:11-23)."""
+
+    @staticmethod
+    def forward(ctx, inputs, threshold):
+        out = torch.empty_like(inputs, memory_format=torch.contiguous_format)
+        src = inputs.contiguous()
+        rc = _lib.lib().cpg_binarize_mask_weight(None, _lib.dptr(src, name='inputs'), float(threshold),
+                                                 _lib.dptr(out), src.numel(), _lib.stream_ptr())
+        _lib.check('cpg_binarize_mask_weight', rc)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return grad_out, None
+
+
+def _conv_desc(x_shape, w_shape, stride, padding, dilation, groups):
+    d = _lib.ConvDesc()
+    d.N, d.C, d.H, d.W = [int(v) for v in x_shape]
+    d.K, d.R, d.S = int(w_shape[0]), int(w_shape[2]), int(w_shape[3])
+    d.stride_h, d.stride_w = stride
+    d.pad_h, d.pad_w = padding
+    d.dil_h, d.dil_w = dilation
+    d.groups = groups
+    return d
+
+
+def _out_hw(d):
+    oh = (d.H + 2 * d.pad_h - d.dil_h * (d.R - 1) - 1) // d.stride_h + 1
+    ow = (d.W + 2 * d.pad_w - d.dil_w * (d.S - 1) - 1) // d.stride_w + 1
+    return oh, ow
+
+
+class _MaskedConv2dFn(torch.autograd.Function):
+    """y = conv2d(x, W * bin(pm), b) and its gradients, all through the C ABI."""
+
+    @staticmethod
+    def forward(ctx, x, weight, pm, bias, thr, stride, padding, dilation, groups):
+        if x.dim() != 4 or x.shape[1] != weight.shape[1] * groups:
+            raise RuntimeError('SharableConv2d: input %s does not match weight %s (groups=%d)'
+                               % (tuple(x.shape), tuple(weight.shape), groups))
+        x = x.contiguous()
+        w = weight.contiguous()
+        p = None if pm is None else pm.contiguous()
+        d = _conv_desc(x.shape, w.shape, stride, padding, dilation, groups)
+        oh, ow = _out_hw(d)
+        if oh <= 0 or ow <= 0:
+            raise RuntimeError('SharableConv2d: kernel larger than padded input')
+        y = torch.empty((d.N, d.K, oh, ow), dtype=torch.float32, device=x.device)
+        L = _lib.lib()
+        rc = L.cpg_conv2d_fwd(ctypes.byref(d), _lib.dptr(x, name='input'), _lib.dptr(w, name='weight'),
+                              _lib.dptr(p, name='piggymask'), float(thr), _lib.dptr(bias, name='bias'),
+                              _lib.dptr(y), None, 0, _lib.stream_ptr())
+        _lib.check('cpg_conv2d_fwd', rc)
+        ctx.save_for_backward(x, w, p)
+        ctx.desc, ctx.thr, ctx.has_bias = d, float(thr), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, p = ctx.saved_tensors
+        d, thr = ctx.desc, ctx.thr
+        gy = gy.contiguous()
+        L = _lib.lib()
+        s = _lib.stream_ptr()
+        gx = gw = gpm = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            rc = L.cpg_conv2d_dgrad(ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr,
+                                    _lib.dptr(gx), None, 0, s)
+            _lib.check('cpg_conv2d_dgrad', rc)
+        if ctx.needs_input_grad[1] or (p is not None and ctx.needs_input_grad[2]) or (ctx.has_bias and ctx.needs_input_grad[3]):
+            gw = torch.empty_like(w)
+            gpm = None if p is None else torch.empty_like(p)
+            gb = torch.empty(d.K, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            ws, nbytes = _lib.workspace(L.cpg_conv2d_workspace_bytes(ctypes.byref(d)), x.device)
+            rc = L.cpg_conv2d_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), _lib.dptr(p), thr,
+                                    _lib.dptr(gw), _lib.dptr(gpm), _lib.dptr(gb), _lib.dptr(ws), nbytes, s)
+            _lib.check('cpg_conv2d_wgrad', rc)
+        return gx, gw, gpm, gb, None, None, None, None, None
+
+
+class _MaskedLinearFn(torch.autograd.Function):
+    """y = x @ (W * bin(pm))^T + b and its gradients through the C ABI."""
+
+    @staticmethod
+    def forward(ctx, x, weight, pm, bias, thr):
+        if x.shape[-1] != weight.shape[1]:
+            raise RuntimeError('SharableLinear: input %s does not match weight %s' % (tuple(x.shape), tuple(weight.shape)))
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        w = weight.contiguous()
+        p = None if pm is None else pm.contiguous()
+        batch, fin, fout = x2.shape[0], w.shape[1], w.shape[0]
+        y = torch.empty((batch, fout), dtype=torch.float32, device=x.device)
+        L = _lib.lib()
+        ws, nbytes = _lib.workspace(L.cpg_linear_workspace_bytes(batch, fin, fout), x.device)
+        rc = L.cpg_linear_fwd(_lib.dptr(x2, name='input'), _lib.dptr(w, name='weight'), _lib.dptr(p, name='piggymask'),
+                              float(thr), _lib.dptr(bias, name='bias'), _lib.dptr(y), batch, fin, fout,
+                              _lib.dptr(ws), nbytes, _lib.stream_ptr())
+        _lib.check('cpg_linear_fwd', rc)
+        ctx.save_for_backward(x2, w, p)
+        ctx.thr, ctx.has_bias, ctx.lead = float(thr), bias is not None, lead
+        return y.view(*lead, fout)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w, p = ctx.saved_tensors
+        thr = ctx.thr
+        batch, fin, fout = x2.shape[0], w.shape[1], w.shape[0]
+        gy2 = gy.reshape(-1, fout).contiguous()
+        L = _lib.lib()
+        s = _lib.stream_ptr()
+        ws, nbytes = _lib.workspace(L.cpg_linear_workspace_bytes(batch, fin, fout), x2.device)
+        gx = gw = gpm = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x2)
+            rc = L.cpg_linear_dgrad(_lib.dptr(gy2, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr, _lib.dptr(gx),
+                                    batch, fin, fout, _lib.dptr(ws), nbytes, s)
+            _lib.check('cpg_linear_dgrad', rc)
+            gx = gx.view(*ctx.lead, fin)
+        if ctx.needs_input_grad[1] or (p is not None and ctx.needs_input_grad[2]) or (ctx.has_bias and ctx.needs_input_grad[3]):
+            gw = torch.empty_like(w)
+            gpm = None if p is None else torch.empty_like(p)
+            gb = torch.empty(fout, dtype=torch.float32, device=x2.device) if ctx.has_bias else None
+            rc = L.cpg_linear_wgrad(_lib.dptr(x2), _lib.dptr(gy2), _lib.dptr(w), _lib.dptr(p), thr, _lib.dptr(gw),
+                                    _lib.dptr(gpm), _lib.dptr(gb), batch, fin, fout, _lib.dptr(ws), nbytes, s)
+            _lib.check('cpg_linear_wgrad', rc)
+        return gx, gw, gpm, gb, None
+
+
+class _Sharable(nn.Module):
+    """State shared by both masked layers: threshold bookkeeping and the late-bound piggymask.
+
+    `piggymask` starts as None (task 1) and is later ASSIGNED an nn.Parameter shaped like the weight
+    by the driver (CPG_cifar100_main_normal.py:263-270); nn.Module.__setattr__ then registers it,
+    so it appears in named_parameters()/state_dict() and follows .cuda()/.to() like the reference's.
+    """
+
+    def _init_mask_state(self, mask_init, mask_scale, threshold_fn, threshold):
+        self.mask_init, self.mask_scale = mask_init, mask_scale
+        self.info = {'threshold_fn': threshold_fn,
+                     'threshold': DEFAULT_THRESHOLD if threshold is None else threshold}
+        if threshold_fn == 'binarizer':
+            self.threshold_fn = Binarizer.apply
+        elif threshold_fn == 'ternarizer':
+            raise NotImplementedError('ternarizer is dead code in the reference (old autograd API); only '
+                                      "'binarizer' is implemented")
+        else:
+            raise ValueError('unknown threshold_fn %r' % (threshold_fn,))
+        self.piggymask = None
+
+
+class SharableConv2d(_Sharable):
+    """Conv2d whose effective weight is W * binarize(piggymask) (models/layers.py:43-109)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, mask_init='1s', mask_scale=1e-2, threshold_fn='binarizer', threshold=None):
+        super().__init__()
+        if in_channels % groups or out_channels % groups:
+            raise ValueError('in_channels and out_channels must be divisible by groups')
+        self.in_channels, self.out_channels, self.groups = in_channels, out_channels, groups
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.dilation = _pair(padding), _pair(dilation)
+        self.transposed, self.output_padding = False, _pair(0)
+        # uninitialised storage, no RNG consumed here (init happens in the model, models/vgg.py:59-70)
+        self.weight = Parameter(torch.empty(out_channels, in_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self._init_mask_state(mask_init, mask_scale, threshold_fn, threshold)
+
+    def forward(self, input, layer_info=None, name=None):
+        return _MaskedConv2dFn.apply(input, self.weight, self.piggymask, self.bias, self.info['threshold'],
+                                     self.stride, self.padding, self.dilation, self.groups)
+
+    def extra_repr(self):
+        s = '{in_channels}, {out_channels}, kernel_size={kernel_size}, stride={stride}'
+        if any(self.padding):
+            s += ', padding={padding}'
+        if self.dilation != (1, 1):
+            s += ', dilation={dilation}'
+        if self.groups != 1:
+            s += ', groups={groups}'
+        if self.bias is None:
+            s += ', bias=False'
+        return s.format(**self.__dict__)
+
+
+class SharableLinear(_Sharable):
+    """Linear layer whose effective weight is W * binarize(piggymask) (models/layers.py:147-194)."""
+
+    def __init__(self, in_features, out_features, bias=True, mask_init='1s', mask_scale=1e-2,
+                 threshold_fn='binarizer', threshold=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = Parameter(torch.empty(out_features, in_features))
+        if bias:
+            self.bias = Parameter(torch.empty(out_features))
+        else:
+            self.register_parameter('bias', None)
+        self._init_mask_state(mask_init, mask_scale, threshold_fn, threshold)
+
+    def forward(self, input):
+        return _MaskedLinearFn.apply(input, self.weight, self.piggymask, self.bias, self.info['threshold'])
+
+    def extra_repr(self):
+        return 'in_features=%d, out_features=%d' % (self.in_features, self.out_features)

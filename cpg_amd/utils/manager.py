@@ -1,0 +1,167 @@
+"""Manager: the per-minibatch train / validate loops of the reference's utils/manager.py:16-152,
+driving the HIP-backed SparsePruner and masked layers.
+
+Op order per step is the reference's (utils/manager.py:50-75): zero_grad -> forward -> accuracy ->
+loss -> backward -> do_weight_decay_and_make_grads_zero -> optimizers.step -> (prune mode)
+gradually_prune -> statistics.  `validate` calls apply_mask() FIRST and leaves the weights mutated,
+as the reference does (utils/manager.py:105).
+
+What is not reproduced is the reference's per-step host stall: loss / accuracy accumulate on the
+device and the progress line (tqdm postfix with the mask statistics) is refreshed on a wall-clock
+interval instead of forcing `.item()` + 15 reductions + `.cpu()` every step.  Returned values are
+identical.  Checkpoint save/load and LFW evaluation (utils/manager.py:156-320) are outside the hot
+path and not implemented here.
+"""
+import logging
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import Metric, classification_accuracy
+from .prune import SparsePruner
+
+try:                                    # progress bar is cosmetic; tqdm is present in the image
+    from tqdm import tqdm
+except ImportError:                     # pragma: no cover
+    tqdm = None
+
+
+class _NullBar(object):
+    def __init__(self, *a, **k):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def set_postfix(self, *a, **k):
+        pass
+
+    def update(self, n=1):
+        pass
+
+
+class Manager(object):
+    """Handles training and pruning (utils/manager.py:16-37)."""
+
+    def __init__(self, args, model, shared_layer_info, masks, train_loader, val_loader, begin_prune_step, end_prune_step):
+        self.args = args
+        self.model = model
+        self.shared_layer_info = shared_layer_info
+        root = model.module if hasattr(model, 'module') else model
+        self.inference_dataset_idx = root.datasets.index(args.dataset) + 1
+        self.pruner = SparsePruner(self.model, masks, self.args, begin_prune_step, end_prune_step,
+                                   self.inference_dataset_idx)
+        self.train_loader = train_loader
+        self.val_loader = val_loader
+        self.progress = bool(getattr(args, 'progress', True)) and tqdm is not None
+        self.postfix_interval = float(getattr(args, 'postfix_interval', 0.5))
+        if args.dataset == 'face_verification':
+            from ..models.spherenet import AngleLoss
+            self.criterion = AngleLoss()
+        elif args.dataset == 'emotion':
+            counts = torch.from_numpy(np.array([74874, 134415, 25459, 14090, 6378, 3803, 24882]).astype(np.float32))
+            weights = (torch.sum(counts) - counts) / counts
+            self.criterion = nn.CrossEntropyLoss(weight=weights.cuda() if getattr(args, 'cuda', True) else weights)
+        else:
+            self.criterion = nn.CrossEntropyLoss()
+
+    def _bar(self, total, desc):
+        return tqdm(total=total, desc=desc, ascii=True) if self.progress else _NullBar()
+
+    def _to_device(self, data, target):
+        if getattr(self.args, 'cuda', True):
+            data, target = data.cuda(non_blocking=True), target.cuda(non_blocking=True)
+        return data, target
+
+    def train(self, optimizers, epoch_idx, curr_lrs, curr_prune_step):
+        """One epoch of the hot loop (utils/manager.py:39-100). Returns (avg_train_acc, curr_prune_step)."""
+        self.model.train()
+        train_loss = Metric('train_loss')
+        train_accuracy = Metric('train_accuracy')
+        last_post = 0.0
+        nbatches = len(self.train_loader)
+        with self._bar(nbatches, 'Train Ep. #{}: '.format(epoch_idx + 1)) as t:
+            for batch_idx, (data, target) in enumerate(self.train_loader):
+                data, target = self._to_device(data, target)
+                optimizers.zero_grad()
+                output = self.model(data)
+                num = data.size(0)
+                if self.args.dataset != 'face_verification':
+                    train_accuracy.update(classification_accuracy(output, target), num)
+                loss = self.criterion(output, target)
+                train_loss.update(loss, num)
+                loss.backward()
+                # Set fixed param grads to 0 (after the data-parallel all-reduce hooks have filled .grad)
+                if hasattr(self.model, 'finish_gradient_sync'):
+                    self.model.finish_gradient_sync()
+                self.pruner.do_weight_decay_and_make_grads_zero()
+                optimizers.step()
+                if self.args.mode == 'prune':
+                    self.pruner.gradually_prune(curr_prune_step)
+                    curr_prune_step += 1
+                now = time.time()
+                if self.progress and (now - last_post >= self.postfix_interval or batch_idx + 1 == nbatches):
+                    last_post = now
+                    t.set_postfix({'loss': train_loss.avg.item(),
+                                   'accuracy': '{:.2f}'.format(100. * train_accuracy.avg.item()),
+                                   'lr': curr_lrs[0],
+                                   'sparsity': self.pruner.calculate_sparsity(),
+                                   'network_width_mpl': self.args.network_width_multiplier})
+                t.update(1)
+        summary = {'loss': '{:.3f}'.format(train_loss.avg.item()),
+                   'accuracy': '{:.2f}'.format(100. * train_accuracy.avg.item()),
+                   'lr': curr_lrs[0],
+                   'sparsity': '{:.3f}'.format(self.pruner.calculate_sparsity()),
+                   'network_width_mpl': self.args.network_width_multiplier}
+        if getattr(self.args, 'log_path', None):
+            logging.info(('In train()-> Train Ep. #{} '.format(epoch_idx + 1)
+                          + ', '.join(['{}: {}'.format(k, v) for k, v in summary.items()])))
+        return train_accuracy.avg.item(), curr_prune_step
+
+    def validate(self, epoch_idx, biases=None):
+        """Evaluation (utils/manager.py:103-152): apply_mask() first, then an eval-mode forward pass."""
+        self.pruner.apply_mask()
+        self.model.eval()
+        val_loss = Metric('val_loss')
+        val_accuracy = Metric('val_accuracy')
+        idx = self.inference_dataset_idx
+        last_post = 0.0
+        nbatches = len(self.val_loader)
+        with self._bar(nbatches, 'Val Ep. #{}: '.format(epoch_idx + 1)) as t:
+            with torch.no_grad():
+                for bi, (data, target) in enumerate(self.val_loader):
+                    data, target = self._to_device(data, target)
+                    output = self.model(data)
+                    num = data.size(0)
+                    val_loss.update(self.criterion(output, target), num)
+                    val_accuracy.update(classification_accuracy(output, target), num)
+                    now = time.time()
+                    if self.progress and (now - last_post >= self.postfix_interval or bi + 1 == nbatches):
+                        last_post = now
+                        post = {'loss': val_loss.avg.item(),
+                                'accuracy': '{:.2f}'.format(100. * val_accuracy.avg.item()),
+                                'sparsity': self.pruner.calculate_sparsity(),
+                                'task{} ratio'.format(idx): self.pruner.calculate_curr_task_ratio(),
+                                'zero ratio': self.pruner.calculate_zero_ratio(),
+                                'mpl': self.args.network_width_multiplier}
+                        if idx != 1:
+                            post['shared_ratio'] = self.pruner.calculate_shared_part_ratio()
+                        t.set_postfix(post)
+                    t.update(1)
+        summary = {'loss': '{:.3f}'.format(val_loss.avg.item()),
+                   'accuracy': '{:.2f}'.format(100. * val_accuracy.avg.item()),
+                   'sparsity': '{:.3f}'.format(self.pruner.calculate_sparsity()),
+                   'task{} ratio'.format(idx): '{:.3f}'.format(self.pruner.calculate_curr_task_ratio()),
+                   'zero ratio': '{:.3f}'.format(self.pruner.calculate_zero_ratio()),
+                   'mpl': self.args.network_width_multiplier}
+        if idx != 1:
+            summary['shared_ratio'] = '{:.3f}'.format(self.pruner.calculate_shared_part_ratio())
+        if getattr(self.args, 'log_path', None):
+            logging.info(('In validate()-> Val Ep. #{} '.format(epoch_idx + 1)
+                          + ', '.join(['{}: {}'.format(k, v) for k, v in summary.items()])))
+        return val_accuracy.avg.item()

@@ -1,0 +1,146 @@
+/*
+ * cpg_hip.h -- C ABI of libcpg_hip.so, the MI355X (gfx950) implementation of the
+ * ivclab/CPG masked-CNN train / prune / retrain hot path.
+ *
+ * The reference has no FFI layer: its boundary is the Python class contract of
+ * models/layers.py + utils/prune.py.  Every entry point below
+ * replaces one stock-PyTorch call sequence of the reference and cites it; the
+ * reference-side binding (a ctypes stub inside SharableConv2d / SharableLinear /
+ * SparsePruner) is shown in INTEGRATION.md, and cpg_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (HBM) unless named *_host.  The caller (PyTorch)
+ *     owns every buffer; kernels borrow them for the duration of the call.
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued there and the call
+ *     returns without synchronising.  No global mutable state: the library is re-entrant
+ *     and may be called concurrently from several host threads on different streams.
+ *   - Tensors are dense, contiguous fp32 (NCHW activations, [Cout][Cin/g][R][S] conv
+ *     weights, [out][in] linear weights) and uint8 owner ids shaped like the weight
+ *     (reference: torch.ByteTensor masks, CPG_cifar100_main_normal.py:204).
+ *   - `pm` is the real-valued piggymask (same shape as the weight) or NULL (task 1,
+ *     CPG_cifar100_main_normal.py:263-270).  When non-NULL the effective weight is
+ *     W * (pm > thr ? 1 : 0) -- models/layers.py:11-23,99-105 -- computed inside the
+ *     kernels' LDS staging pass; it is never materialised in HBM.
+ *   - Return value: 0 ok; <0 invalid argument / unsupported; CPG_E_KRANGE is rank-prune's
+ *     "not enough weights" (reference: sys.exit(2), utils/prune.py:38-42);
+ *     >= CPG_E_HIP_BASE is CPG_E_HIP_BASE + hipError_t.
+ *   - Workspaces: query with the *_workspace_bytes function, pass any buffer at least
+ *     that large (contents undefined on entry and exit).
+ */
+#ifndef CPG_HIP_H
+#define CPG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPG_ABI_VERSION 1
+
+#define CPG_OK 0
+#define CPG_E_INVALID (-1)
+#define CPG_E_UNSUPPORTED (-2)
+#define CPG_E_WORKSPACE (-3)
+#define CPG_E_KRANGE 2
+#define CPG_E_HIP_BASE 1000
+
+/* gradient-routing modes (args.mode of utils/prune.py:206-210) */
+#define CPG_MODE_FINETUNE 0
+#define CPG_MODE_PRUNE 1
+
+/* geometry of one SharableConv2d call (models/layers.py:46-49,108-109) */
+typedef struct cpg_conv_desc {
+    int32_t N, C, H, W;       /* input  NCHW                                  */
+    int32_t K;                /* out_channels                                 */
+    int32_t R, S;             /* kernel_size                                  */
+    int32_t stride_h, stride_w;
+    int32_t pad_h, pad_w;
+    int32_t dil_h, dil_w;
+    int32_t groups;           /* only 1 is implemented (all CPG configs)      */
+} cpg_conv_desc;
+
+/* result record of cpg_rank_prune, written to DEVICE memory (one per call) */
+typedef struct cpg_prune_result {
+    int64_t n_candidates;     /* #(owner == cur || owner == 0)                */
+    int64_t k;                /* round-half-even(ratio * n_candidates)        */
+    int64_t n_released;       /* #slots whose owner went cur -> 0             */
+    float cutoff;             /* k-th smallest |w| among the candidates       */
+    int32_t status;           /* CPG_OK or CPG_E_KRANGE (owner left untouched)*/
+} cpg_prune_result;
+
+int cpg_version(void);
+/* human-readable text for the last non-zero status returned on THIS thread */
+const char *cpg_last_error(void);
+
+/* ---- K1: models/layers.py:11-23 + :103 / :190 (Binarizer + elementwise product) ----
+ * w_eff[i] = w[i] * (pm[i] > thr ? 1 : pm[i] <= thr ? 0 : pm[i]); w == NULL gives the bare Binarizer
+ * output.  Exported for callers that need W_eff itself (tests, checkpoint export); the conv/linear
+ * kernels fuse this step. */
+int cpg_binarize_mask_weight(const float *w, const float *pm, float thr, float *w_eff,
+                             int64_t n, void *stream);
+
+/* ---- K2/K3/K4: F.conv2d of models/layers.py:108-109 and its autograd ----
+ * fwd   : y  = conv2d(x, W_eff, bias)                       bias may be NULL
+ * dgrad : gx = conv2d_input_grad(gy, W_eff)
+ * wgrad : gW_eff = conv2d_weight_grad(x, gy); then, as autograd of `bin(pm) * W`
+ *         (models/layers.py:103): gw = gW_eff * bin(pm), gpm = gW_eff * W (gpm NULL when pm
+ *         is NULL).  gb (may be NULL) = sum of gy over N,H,W.
+ *         gw / gpm / gb are OVERWRITTEN (caller accumulates if it needs to). */
+size_t cpg_conv2d_workspace_bytes(const cpg_conv_desc *d);
+int cpg_conv2d_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm,
+                   float thr, const float *bias, float *y, void *ws, size_t ws_bytes, void *stream);
+int cpg_conv2d_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm,
+                     float thr, float *gx, void *ws, size_t ws_bytes, void *stream);
+int cpg_conv2d_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w,
+                     const float *pm, float thr, float *gw, float *gpm, float *gb,
+                     void *ws, size_t ws_bytes, void *stream);
+
+/* ---- K5: F.linear of models/layers.py:194 and its autograd ----
+ * x [batch][in], w [out][in], y [batch][out]; same masking / gradient rules as conv. */
+size_t cpg_linear_workspace_bytes(int32_t batch, int32_t in_features, int32_t out_features);
+int cpg_linear_fwd(const float *x, const float *w, const float *pm, float thr, const float *bias,
+                   float *y, int32_t batch, int32_t in_features, int32_t out_features,
+                   void *ws, size_t ws_bytes, void *stream);
+int cpg_linear_dgrad(const float *gy, const float *w, const float *pm, float thr, float *gx,
+                     int32_t batch, int32_t in_features, int32_t out_features,
+                     void *ws, size_t ws_bytes, void *stream);
+int cpg_linear_wgrad(const float *x, const float *gy, const float *w, const float *pm, float thr,
+                     float *gw, float *gpm, float *gb, int32_t batch, int32_t in_features,
+                     int32_t out_features, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- K4e: utils/prune.py:195-211 (do_weight_decay_and_make_grads_zero), one layer ----
+ * gw = (owner == cur) ? gw + wd * w : 0.   gpm (may be NULL): FINETUNE -> 0 where owner == 0 or
+ * owner >= cur; PRUNE -> 0 everywhere.  One pass, in place. */
+int cpg_route_grads(float *gw, const float *w, const uint8_t *owner, int32_t cur, float wd,
+                    float *gpm, int32_t mode, int64_t n, void *stream);
+
+/* ---- K6: utils/prune.py:30-53 (_pruning_mask), one layer, fully on device ----
+ * candidates = owner in {cur, 0}; k = round-half-even(ratio * n_cand) in fp64 (python round());
+ * cutoff = k-th smallest |w| over the candidates (radix select on the fp32 bit pattern);
+ * owner[(|w| <= cutoff) & (owner == cur)] = 0.  k < 1 or k > n_cand -> status CPG_E_KRANGE in
+ * *result and owner untouched.  `result` is a device pointer; nothing is synchronised. */
+size_t cpg_rank_prune_workspace_bytes(void);
+int cpg_rank_prune(const float *w, uint8_t *owner, int32_t cur, double ratio, int64_t n,
+                   cpg_prune_result *result, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- K7: utils/prune.py:111-193 (the four mask statistics), one layer ----
+ * hist[0..255] += #(owner == id); hist[256] += #(0 < owner < inference_idx && pm > 0.005f)
+ * (only when pm != NULL).  `hist` = 257 uint64 in device memory, ACCUMULATED so one buffer can
+ * collect all layers; the caller zeroes it. */
+int cpg_mask_hist(const uint8_t *owner, const float *pm, int32_t inference_idx, int64_t n,
+                  uint64_t *hist, void *stream);
+
+/* ---- K8: utils/prune.py:213-243 ---- */
+/* apply_mask (:223-231): w[owner == 0 || owner > inference_idx] = 0 */
+int cpg_apply_mask(float *w, const uint8_t *owner, int32_t inference_idx, int64_t n, void *stream);
+/* make_pruned_zero (:213-221): w[owner == 0] = 0 */
+int cpg_zero_pruned(float *w, const uint8_t *owner, int64_t n, void *stream);
+/* make_finetuning_mask (:233-243): owner[owner == 0] = new_idx */
+int cpg_claim_free(uint8_t *owner, int32_t new_idx, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPG_HIP_H */

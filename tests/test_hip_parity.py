@@ -1,0 +1,448 @@
+"""GPU parity tests: the HIP path (through cpg_amd's Python mirror -> C ABI -> kernels) against
+(a) the golden fixtures produced by the reference itself and (b) the CPU oracle on seeded inputs.
+
+Tolerances: integer / byte / index results (owner masks, counts, zero patterns) are bit-exact; fp32
+contractions are compared at rtol 1e-4 (north_star: "forward logits match the reference within 1e-4
+fp32") with an absolute floor scaled to the reduction length."""
+import glob
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+import cpg_amd.models as M                      # noqa: E402
+from cpg_amd.models import layers as nl          # noqa: E402
+from cpg_amd.utils import Optimizers             # noqa: E402
+from cpg_amd.utils.prune import SparsePruner     # noqa: E402
+from oracle import ops                           # noqa: E402  (checker only)
+
+DEV = 'cuda:0'
+VGG_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+
+
+def T(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV, dtype)
+
+
+def close(got, want, rtol=1e-4, atol=1e-5, msg=''):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=msg)
+
+
+# --------------------------------------------------------------------------- binarizer
+def test_binarizer_golden():
+    g = load_golden('binarizer')
+    x = T(g['x']).requires_grad_(True)
+    y = nl.Binarizer.apply(x, float(g['threshold']))
+    got, want = y.detach().cpu().numpy(), g['y']
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_array_equal(np.nan_to_num(got, nan=7.0), np.nan_to_num(want, nan=7.0))
+    y.backward(T(g['grad_out']))
+    np.testing.assert_array_equal(x.grad.cpu().numpy(), g['grad_in'])
+
+
+# --------------------------------------------------------------------------- conv / linear vs golden
+CONV_FILES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'conv_*.npz')))
+
+
+@pytest.mark.parametrize('name', CONV_FILES)
+def test_conv_golden(name):
+    g = load_golden(name)
+    N, C, H, W, Mo, k, s, p, d, has_bias = [int(v) for v in g['cfg']]
+    layer = nl.SharableConv2d(C, Mo, k, stride=s, padding=p, dilation=d, bias=bool(has_bias)).to(DEV)
+    layer.weight.data.copy_(T(g['w']))
+    if has_bias:
+        layer.bias.data.copy_(T(g['b']))
+    if 'pm' in g.files:
+        layer.piggymask = nn.Parameter(T(g['pm']))
+    x = T(g['x']).requires_grad_(True)
+    y = layer(x)
+    close(y, g['y'], msg='y')
+    y.backward(T(g['gy']))
+    close(x.grad, g['gx'], msg='gx')
+    close(layer.weight.grad, g['gw'], msg='gw')
+    if 'pm' in g.files:
+        close(layer.piggymask.grad, g['gpm'], msg='gpm')
+        # masked-out slots get exactly zero weight gradient
+        np.testing.assert_array_equal(layer.weight.grad.cpu().numpy()[g['pm'] <= 5e-3] == 0, True)
+    if has_bias:
+        close(layer.bias.grad, g['gb'], msg='gb')
+
+
+LIN_FILES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'linear_*.npz')))
+
+
+@pytest.mark.parametrize('name', LIN_FILES)
+def test_linear_golden(name):
+    g = load_golden(name)
+    O, I = g['w'].shape
+    layer = nl.SharableLinear(I, O).to(DEV)
+    layer.weight.data.copy_(T(g['w']))
+    layer.bias.data.copy_(T(g['b']))
+    if 'pm' in g.files:
+        layer.piggymask = nn.Parameter(T(g['pm']))
+    x = T(g['x']).requires_grad_(True)
+    y = layer(x)
+    close(y, g['y'], msg='y')
+    y.backward(T(g['gy']))
+    close(x.grad, g['gx'], msg='gx')
+    close(layer.weight.grad, g['gw'], msg='gw')
+    close(layer.bias.grad, g['gb'], msg='gb')
+    if 'pm' in g.files:
+        close(layer.piggymask.grad, g['gpm'], msg='gpm')
+
+
+# --------------------------------------------------------------------------- conv / linear vs oracle, larger
+@pytest.mark.parametrize('N,C,H,W,K,k,s,p,bias,pm', [
+    (4, 64, 56, 56, 128, 3, 1, 1, False, False),     # VGG mid layer (3x3 s1 p1), several tiles
+    (3, 3, 224, 224, 64, 3, 1, 1, False, False),     # VGG first layer, Cin = 3
+    (2, 128, 28, 28, 256, 3, 1, 1, False, True),     # with piggymask
+    (5, 512, 14, 14, 512, 3, 1, 1, False, False),    # deep K (4608), small spatial
+    (2, 64, 33, 47, 70, 3, 1, 1, True, True),        # ragged everything
+    (2, 3, 64, 64, 16, 7, 2, 3, False, False),       # ResNet stem
+    (3, 64, 28, 28, 256, 1, 1, 0, False, True),      # ResNet 1x1
+    (3, 256, 28, 28, 512, 1, 2, 0, False, False),    # ResNet downsample
+    (2, 64, 56, 56, 64, 3, 2, 1, True, False),       # SphereNet stride-2 with bias
+])
+def test_conv_oracle(N, C, H, W, K, k, s, p, bias, pm):
+    g = torch.Generator().manual_seed(N * 1000 + C + K)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, k, k, generator=g) * (2.0 / (C * k * k)) ** 0.5
+    b = torch.randn(K, generator=g) * 0.1 if bias else None
+    pmv = torch.rand(K, C, k, k, generator=g) * 0.012 if pm else None
+    layer = nl.SharableConv2d(C, K, k, stride=s, padding=p, bias=bias).to(DEV)
+    layer.weight.data.copy_(w)
+    if bias:
+        layer.bias.data.copy_(b)
+    if pm:
+        layer.piggymask = nn.Parameter(pmv.to(DEV))
+    xd = x.to(DEV).requires_grad_(True)
+    y = layer(xd)
+    want = ops.conv2d_forward(x.numpy(), w.numpy(), None if pmv is None else pmv.numpy(), None if b is None else b.numpy(), s, p)
+    close(y, want, rtol=1e-4, atol=2e-5, msg='y')
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.to(DEV))
+    r = ops.conv2d_backward(x.numpy(), w.numpy(), gy.numpy(), None if pmv is None else pmv.numpy(), bias, s, p)
+    scale = float(np.abs(r['gw']).max())
+    close(xd.grad, r['gx'], rtol=1e-4, atol=2e-5, msg='gx')
+    close(layer.weight.grad, r['gw'], rtol=1e-4, atol=1e-5 * max(scale, 1.0), msg='gw')
+    if pm:
+        close(layer.piggymask.grad, r['gpm'], rtol=1e-4, atol=1e-5 * max(scale, 1.0), msg='gpm')
+    if bias:
+        close(layer.bias.grad, r['gb'], rtol=1e-4, atol=1e-3, msg='gb')
+
+
+@pytest.mark.parametrize('B,I,O,pm', [(32, 25088, 512, False), (256, 4096, 4096, True), (7, 513, 129, True), (1, 64, 5, False)])
+def test_linear_oracle(B, I, O, pm):
+    g = torch.Generator().manual_seed(B + I + O)
+    x = torch.randn(B, I, generator=g)
+    w = torch.randn(O, I, generator=g) * I ** -0.5
+    b = torch.randn(O, generator=g) * 0.1
+    pmv = torch.rand(O, I, generator=g) * 0.012 if pm else None
+    layer = nl.SharableLinear(I, O).to(DEV)
+    layer.weight.data.copy_(w)
+    layer.bias.data.copy_(b)
+    if pm:
+        layer.piggymask = nn.Parameter(pmv.to(DEV))
+    xd = x.to(DEV).requires_grad_(True)
+    y = layer(xd)
+    close(y, ops.linear_forward(x.numpy(), w.numpy(), None if pmv is None else pmv.numpy(), b.numpy()), rtol=1e-4, atol=2e-5)
+    gy = torch.randn(B, O, generator=g)
+    y.backward(gy.to(DEV))
+    r = ops.linear_backward(x.numpy(), w.numpy(), gy.numpy(), None if pmv is None else pmv.numpy())
+    close(xd.grad, r['gx'], rtol=1e-4, atol=2e-5, msg='gx')
+    close(layer.weight.grad, r['gw'], rtol=1e-4, atol=2e-5, msg='gw')
+    close(layer.bias.grad, r['gb'], rtol=1e-4, atol=1e-4, msg='gb')
+    if pm:
+        close(layer.piggymask.grad, r['gpm'], rtol=1e-4, atol=2e-5, msg='gpm')
+
+
+# --------------------------------------------------------------------------- pruner pieces vs golden
+class TinyNet(nn.Module):
+    def __init__(self, datasets):
+        super().__init__()
+        self.datasets = datasets
+        self.conv = nl.SharableConv2d(3, 4, 3, padding=1, bias=False)
+        self.fc = nl.SharableLinear(6, 5)
+
+
+class Wrap(nn.Module):
+    def __init__(self, m):
+        super().__init__()
+        self.module = m
+
+    def forward(self, x):
+        return self.module(x)
+
+
+def make_pruner(mode, datasets, dataset, owners, weights, begin=0, end=100, freq=10, initial=0.0, target=0.1, wd=4e-5,
+                width=1.0, finetune_again=False, piggymasks=None):
+    net = TinyNet(list(datasets)).to(DEV)
+    net.conv.weight.data.copy_(T(weights['conv']))
+    net.fc.weight.data.copy_(T(weights['fc']))
+    net.fc.bias.data.zero_()
+    if piggymasks is not None:
+        net.conv.piggymask = nn.Parameter(T(piggymasks['conv']))
+        net.fc.piggymask = nn.Parameter(T(piggymasks['fc']))
+    model = Wrap(net)
+    masks = {'module.conv': T(owners['conv'], torch.uint8), 'module.fc': T(owners['fc'], torch.uint8)}
+    args = types.SimpleNamespace(mode=mode, dataset=dataset, finetune_again=finetune_again, target_sparsity=target,
+                                 initial_sparsity=initial, pruning_frequency=freq, weight_decay=wd, network_width_multiplier=width)
+    return SparsePruner(model, masks, args, begin, end, list(datasets).index(dataset) + 1), model, masks
+
+
+ROUTE = {'finetune_t3': ('finetune', ['a', 'b', 'c'], 'c', False), 'prune_t2': ('prune', ['a', 'b', 'c'], 'b', False),
+         'finetune_again_t2': ('finetune', ['a', 'b', 'c'], 'b', True), 'prune_t1_nopm': ('prune', ['a'], 'a', False),
+         'finetune_t1_nopm': ('finetune', ['a'], 'a', False)}
+
+
+@pytest.mark.parametrize('name', sorted(ROUTE))
+def test_route_golden(name):
+    g = load_golden('route_' + name)
+    mode, ds, d, again = ROUTE[name]
+    with_pm = 'gpm_in_conv' in g.files
+    w = {'conv': g['w_conv'], 'fc': g['w_fc']}
+    o = {'conv': g['owner_conv'], 'fc': g['owner_fc']}         # owners as used by the reference AFTER claim
+    pm = {'conv': np.full_like(g['w_conv'], 0.01), 'fc': np.full_like(g['w_fc'], 0.01)} if with_pm else None
+    pruner, model, masks = make_pruner(mode, ds, d, o, w, finetune_again=again, piggymasks=pm)
+    pruner.current_dataset_idx = int(g['cur'])
+    net = model.module
+    net.conv.weight.grad = T(g['gw_in_conv'])
+    net.fc.weight.grad = T(g['gw_in_fc'])
+    if with_pm:
+        net.conv.piggymask.grad = T(g['gpm_in_conv'])
+        net.fc.piggymask.grad = T(g['gpm_in_fc'])
+    pruner.do_weight_decay_and_make_grads_zero()
+    for layer, mod in (('conv', net.conv), ('fc', net.fc)):
+        got = mod.weight.grad.cpu().numpy()
+        np.testing.assert_array_equal(got == 0, g['gw_out_' + layer] == 0)
+        np.testing.assert_allclose(got, g['gw_out_' + layer], rtol=3e-7, atol=0)
+        if with_pm:
+            np.testing.assert_array_equal(mod.piggymask.grad.cpu().numpy(), g['gpm_out_' + layer])
+
+
+RANK_CASES = ['rand_t1', 'multi_t2', 'multi_t3', 'ties', 'round_2p5', 'round_1p5', 'k_zero', 'no_cand', 'all', 'special', 'layer']
+
+
+@pytest.mark.parametrize('tag', RANK_CASES)
+def test_rank_prune_golden(tag):
+    g = load_golden('rank_prune')
+    cur, ratio, status = int(g[tag + '_cur']), float(g[tag + '_ratio']), int(g[tag + '_status'])
+    ds = ['t%d' % i for i in range(1, cur + 1)]
+    z = {'conv': np.zeros((4, 3, 3, 3), np.float32), 'fc': np.zeros((5, 6), np.float32)}
+    zo = {'conv': np.zeros((4, 3, 3, 3), np.uint8), 'fc': np.zeros((5, 6), np.uint8)}
+    pruner, _, _ = make_pruner('prune', ds, ds[cur - 1], zo, z)
+    w, owner = T(g[tag + '_w']), T(g[tag + '_owner'], torch.uint8)
+    if status == 2:
+        with pytest.raises(SystemExit) as e:
+            pruner._pruning_mask(w, owner, tag, ratio)
+        assert e.value.code == 2
+        np.testing.assert_array_equal(owner.cpu().numpy(), g[tag + '_owner'])     # untouched
+        return
+    out = pruner._pruning_mask(w, owner, tag, ratio)
+    np.testing.assert_array_equal(out.cpu().numpy(), g[tag + '_out'])             # bit-exact
+
+
+@pytest.mark.parametrize('n,cur,ratio,zero_frac', [(1 << 20, 1, 0.37, 0.0), (3_000_001, 2, 0.5, 0.3), (50_000, 1, 0.999, 0.9)])
+def test_rank_prune_oracle_random(n, cur, ratio, zero_frac):
+    g = torch.Generator().manual_seed(n)
+    w = torch.randn(n, generator=g) * 0.05
+    owner = torch.randint(0, 4, (n,), generator=g, dtype=torch.uint8)
+    w[(owner == 0) & (torch.rand(n, generator=g) < zero_frac)] = 0.0
+    want, k, cutoff = ops.rank_prune(w.numpy(), owner.numpy(), cur, ratio)
+    ds = ['t%d' % i for i in range(1, cur + 1)]
+    z = {'conv': np.zeros((4, 3, 3, 3), np.float32), 'fc': np.zeros((5, 6), np.float32)}
+    zo = {'conv': np.zeros((4, 3, 3, 3), np.uint8), 'fc': np.zeros((5, 6), np.uint8)}
+    pruner, _, _ = make_pruner('prune', ds, ds[cur - 1], zo, z)
+    od = owner.to(DEV)
+    pruner._pruning_mask(w.to(DEV), od, 'rand', ratio)
+    np.testing.assert_array_equal(od.cpu().numpy(), want)
+
+
+def test_stats_and_mask_ops_golden():
+    g = load_golden('stats_masks')
+    for i, (cur_name, ds) in enumerate([('b', ['a', 'b', 'c']), ('c', ['a', 'b', 'c']), ('a', ['a'])]):
+        t = 'case%d_' % i
+        w = {'conv': g[t + 'w_conv'], 'fc': g[t + 'w_fc']}
+        o = {'conv': g[t + 'owner_conv'], 'fc': g[t + 'owner_fc']}
+        pm = {'conv': g[t + 'pm_conv'], 'fc': g[t + 'pm_fc']}
+        width = float(g[t + 'width'])
+        pruner, model, masks = make_pruner('prune', ds, cur_name, o, w, width=width, piggymasks=pm)
+        assert pruner.calculate_sparsity() == float(g[t + 'sparsity'])
+        assert pruner.calculate_curr_task_ratio() == float(g[t + 'curr_task_ratio'])
+        assert pruner.calculate_zero_ratio() == float(g[t + 'zero_ratio'])
+        assert pruner.calculate_shared_part_ratio() == float(g[t + 'shared_part_ratio'])
+        pruner.apply_mask()
+        np.testing.assert_array_equal(model.module.conv.weight.data.cpu().numpy(), g[t + 'applied_conv'])
+        np.testing.assert_array_equal(model.module.fc.weight.data.cpu().numpy(), g[t + 'applied_fc'])
+        pruner2, model2, _ = make_pruner('prune', ds, cur_name, o, w, width=width)
+        pruner2.make_pruned_zero()
+        np.testing.assert_array_equal(model2.module.conv.weight.data.cpu().numpy(), g[t + 'zeroed_conv'])
+        np.testing.assert_array_equal(model2.module.fc.weight.data.cpu().numpy(), g[t + 'zeroed_fc'])
+        pruner3, _, masks3 = make_pruner('finetune', ds, ds[-1], o, w, width=width)
+        pruner3.make_finetuning_mask()
+        assert pruner3.current_dataset_idx == int(g[t + 'claimed_idx'])
+        np.testing.assert_array_equal(masks3['module.conv'].cpu().numpy(), g[t + 'claimed_conv'])
+        np.testing.assert_array_equal(masks3['module.fc'].cpu().numpy(), g[t + 'claimed_fc'])
+        # statistics cache must notice the in-place claim
+        assert pruner3.calculate_zero_ratio() == 0.0
+
+
+def test_mask_kernels_ragged_sizes_vs_oracle():
+    """odd lengths / unaligned tails through every elementwise kernel"""
+    for n in (1, 3, 5, 17, 255, 1025, 4099, 70001):
+        g = torch.Generator().manual_seed(n)
+        w = torch.randn(n, generator=g)
+        gw = torch.randn(n, generator=g)
+        gpm = torch.randn(n, generator=g)
+        owner = torch.randint(0, 5, (n,), generator=g, dtype=torch.uint8)
+        pm = torch.rand(n, generator=g) * 0.012
+        conv = {'conv': w.numpy().reshape(1, 1, 1, n) * 0 if False else np.zeros((4, 3, 3, 3), np.float32), 'fc': np.zeros((5, 6), np.float32)}
+        zo = {'conv': np.zeros((4, 3, 3, 3), np.uint8), 'fc': np.zeros((5, 6), np.uint8)}
+        pruner, model, masks = make_pruner('finetune', ['a', 'b', 'c'], 'c', zo, conv)
+        # swap the conv layer's tensors for 1-D ones of length n
+        mod = model.module.conv
+        mod.weight = nn.Parameter(w.to(DEV))
+        mod.piggymask = nn.Parameter(pm.to(DEV))
+        mod.weight.grad = gw.to(DEV)
+        mod.piggymask.grad = gpm.to(DEV)
+        masks['module.conv'] = owner.to(DEV)
+        pruner.current_dataset_idx = 3
+        pruner.do_weight_decay_and_make_grads_zero()
+        wg, wp = ops.route_grads(gw.numpy(), w.numpy(), owner.numpy(), 3, 4e-5, gpm.numpy(), 'finetune')
+        np.testing.assert_allclose(mod.weight.grad.cpu().numpy(), wg, rtol=3e-7, atol=0)
+        np.testing.assert_array_equal(mod.piggymask.grad.cpu().numpy(), wp)
+        owners = [owner.numpy(), zo['fc']]
+        assert pruner.calculate_sparsity() == ops.sparsity(owners, 3)
+        assert pruner.calculate_shared_part_ratio() == ops.shared_part_ratio(owners, [pm.numpy(), np.zeros((5, 6), np.float32)], 3)
+        pruner.inference_dataset_idx = 2
+        pruner.apply_mask()
+        np.testing.assert_array_equal(mod.weight.data.cpu().numpy(), ops.apply_mask(w.numpy(), owner.numpy(), 2))
+        pruner.current_dataset_idx = 3
+        pruner.make_finetuning_mask()
+        np.testing.assert_array_equal(masks['module.conv'].cpu().numpy(), ops.claim_free(owner.numpy(), 4))
+
+
+# --------------------------------------------------------------------------- whole networks vs golden
+def build(arch, width, ncls=5):
+    torch.manual_seed(1)
+    kw = dict(dataset_history=[], dataset2num_classes={}, network_width_multiplier=width, shared_layer_info={})
+    m = {'vgg_cifar100': lambda: M.custom_vgg_cifar100(VGG_CFG, **kw), 'vgg': lambda: M.custom_vgg(VGG_CFG, **kw),
+         'resnet50': lambda: M.resnet50(**kw), 'spherenet20': lambda: M.spherenet20(**kw)}[arch]()
+    m.add_dataset('t1', ncls)
+    m.set_dataset('t1')
+    return m
+
+
+@pytest.mark.parametrize('arch,width,fx', [('vgg_cifar100', 0.125, 'first_forward_vgg_cifar100'), ('vgg', 0.125, 'first_forward_vgg'),
+                                           ('resnet50', 0.25, 'first_forward_resnet50'), ('spherenet20', 0.25, 'first_forward_spherenet20')])
+def test_first_forward_logits_golden(arch, width, fx):
+    """seed-1 init on CPU (RNG parity), eval forward on the GPU, logits within 1e-4 of the reference's"""
+    g = load_golden(fx)
+    m = build(arch, width, int(g['num_classes'])).to(DEV).eval()
+    with torch.no_grad():
+        y = m(T(g['x']))
+    scale = float(np.abs(g['y']).max())
+    close(y, g['y'], rtol=1e-4, atol=1e-4 * scale, msg=arch)
+
+
+@pytest.mark.parametrize('mode', ['prune', 'finetune'])
+def test_trajectory_golden(mode):
+    """12 steps of the Manager.train op order on a narrow VGG16-BN: logits per step, prune ratios,
+    sparsities; owner masks compared bit-exact where fp32 round-off cannot flip a rank."""
+    g = load_golden('trajectory_' + mode)
+    width = float(g['width'])
+    net = build('vgg_cifar100', width)
+    sd = net.state_dict()
+    for k in sd:                                      # same initial state as the reference run
+        np.testing.assert_array_equal(sd[k].numpy(), g['init/' + k], err_msg=k)
+    net = net.to(DEV)
+    model = Wrap(net)
+    masks = {n: torch.zeros(m.weight.shape, dtype=torch.uint8, device=DEV) for n, m in model.named_modules()
+             if isinstance(m, (nl.SharableConv2d, nl.SharableLinear))}
+    args = types.SimpleNamespace(mode=mode, dataset='t1', finetune_again=False, target_sparsity=float(g['target']),
+                                 initial_sparsity=float(g['initial']), pruning_frequency=int(g['freq']),
+                                 weight_decay=float(g['wd']), network_width_multiplier=width)
+    pruner = SparsePruner(model, masks, args, int(g['begin']), int(g['end']), 1)
+    if mode == 'finetune':
+        pruner.make_finetuning_mask()
+    else:
+        for k in masks:
+            masks[k].fill_(1)
+    opt = torch.optim.SGD(list(model.parameters()), lr=float(g['lr']), weight_decay=0.0, momentum=0.9, nesterov=True)
+    optimizers = Optimizers()
+    optimizers.add(opt, float(g['lr']))
+    crit = nn.CrossEntropyLoss()
+    xs, ts = T(g['x']), torch.from_numpy(g['t']).to(DEV)
+    model.train()
+    for s in range(xs.shape[0]):
+        optimizers.zero_grad()
+        out = model(xs[s])
+        loss = crit(out, ts[s])
+        loss.backward()
+        pruner.do_weight_decay_and_make_grads_zero()
+        optimizers.step()
+        if mode == 'prune':
+            assert pruner.gradually_prune(s) == g['ratios'][s]
+        close(out, g['logits'][s], rtol=1e-3, atol=2e-6, msg='logits step %d' % s)
+        assert abs(float(loss) - g['losses'][s]) < 1e-5
+        assert abs(pruner.calculate_sparsity() - g['sparsities'][s]) < 2e-4, s
+    mism = sum(int((masks[n].cpu().numpy() != g['mask/' + n]).sum()) for n in masks)
+    total = sum(masks[n].numel() for n in masks)
+    assert mism <= 1e-4 * total, 'owner masks differ in %d of %d slots' % (mism, total)
+    pruner.apply_mask()
+    model.eval()
+    with torch.no_grad():
+        ev = model(xs[0])
+    close(ev, g['eval_logits'], rtol=1e-3, atol=2e-6, msg='eval logits')
+
+
+# --------------------------------------------------------------------------- full-size properties
+def test_rank_prune_full_size_properties():
+    """features.45 of config 2 (4096 x 25088 = 102.8 M weights): size-independent properties."""
+    n = 4096 * 25088
+    g = torch.Generator(device=DEV).manual_seed(1)
+    w = torch.randn(n, generator=g, device=DEV) * 0.01
+    owner = torch.ones(n, dtype=torch.uint8, device=DEV)
+    z = {'conv': np.zeros((4, 3, 3, 3), np.float32), 'fc': np.zeros((5, 6), np.float32)}
+    zo = {'conv': np.zeros((4, 3, 3, 3), np.uint8), 'fc': np.zeros((5, 6), np.uint8)}
+    pruner, _, _ = make_pruner('prune', ['a'], 'a', zo, z)
+    ratio = 0.0399
+    pruner._pruning_mask(w, owner, 'fc', ratio)
+    k = round(ratio * n)
+    released = int((owner == 0).sum())
+    assert released == k                                    # no ties in continuous random data
+    aw = w.abs()
+    assert float(aw[owner == 0].max()) <= float(aw[owner == 1].min())     # a true magnitude cut
+    # second event at a higher ratio: candidates include the released slots (still holding stale values)
+    pruner._pruning_mask(w, owner, 'fc', 0.1)
+    assert int((owner == 0).sum()) == round(0.1 * n)
+    # idempotence: same ratio again releases nothing new
+    before = owner.clone()
+    pruner._pruning_mask(w, owner, 'fc', 0.1)
+    assert torch.equal(before, owner)
+
+
+def test_route_and_hist_full_size_properties():
+    n = 4096 * 25088
+    g = torch.Generator(device=DEV).manual_seed(2)
+    w = torch.randn(n, generator=g, device=DEV)
+    gw = torch.randn(n, generator=g, device=DEV)
+    owner = torch.randint(0, 3, (n,), generator=g, device=DEV, dtype=torch.uint8)
+    L = __import__('cpg_amd._lib', fromlist=['x'])
+    rc = L.lib().cpg_route_grads(L.dptr(gw), L.dptr(w), L.dptr(owner, torch.uint8), 2, 4e-5, None, L.MODE_PRUNE, n, L.stream_ptr())
+    assert rc == 0
+    assert int((gw[owner != 2] != 0).sum()) == 0
+    hist = torch.zeros(257, dtype=torch.int64, device=DEV)
+    import ctypes
+    rc = L.lib().cpg_mask_hist(L.dptr(owner, torch.uint8), None, 2, n, ctypes.c_void_p(hist.data_ptr()), L.stream_ptr())
+    assert rc == 0
+    want = torch.bincount(owner.long(), minlength=256)
+    assert torch.equal(hist[:256], want) and int(hist[:256].sum()) == n
