@@ -120,7 +120,9 @@ class _MaskedLinearFn(torch.autograd.Function):
         w = weight.contiguous()
         p = None if pm is None else pm.contiguous()
         batch, fin, fout = x2.shape[0], w.shape[1], w.shape[0]
-        y = torch.empty((batch, fout), dtype=torch.float32, device=x.device)
+        # allocate with the caller-visible shape: returning a view of a Function output would forbid the
+        # in-place ReLU that follows these layers in the reference topologies
+        y = torch.empty((*lead, fout), dtype=torch.float32, device=x.device)
         L = _lib.lib()
         ws, nbytes = _lib.workspace(L.cpg_linear_workspace_bytes(batch, fin, fout), x.device)
         rc = L.cpg_linear_fwd(_lib.dptr(x2, name='input'), _lib.dptr(w, name='weight'), _lib.dptr(p, name='piggymask'),
@@ -129,7 +131,7 @@ class _MaskedLinearFn(torch.autograd.Function):
         _lib.check('cpg_linear_fwd', rc)
         ctx.save_for_backward(x2, w, p)
         ctx.thr, ctx.has_bias, ctx.lead = float(thr), bias is not None, lead
-        return y.view(*lead, fout)
+        return y
 
     @staticmethod
     def backward(ctx, gy):
@@ -142,11 +144,10 @@ class _MaskedLinearFn(torch.autograd.Function):
         ws, nbytes = _lib.workspace(L.cpg_linear_workspace_bytes(batch, fin, fout), x2.device)
         gx = gw = gpm = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.empty_like(x2)
+            gx = torch.empty((*ctx.lead, fin), dtype=torch.float32, device=x2.device)
             rc = L.cpg_linear_dgrad(_lib.dptr(gy2, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr, _lib.dptr(gx),
                                     batch, fin, fout, _lib.dptr(ws), nbytes, s)
             _lib.check('cpg_linear_dgrad', rc)
-            gx = gx.view(*ctx.lead, fin)
         if ctx.needs_input_grad[1] or (p is not None and ctx.needs_input_grad[2]) or (ctx.has_bias and ctx.needs_input_grad[3]):
             gw = torch.empty_like(w)
             gpm = None if p is None else torch.empty_like(p)
