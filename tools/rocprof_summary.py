@@ -23,8 +23,8 @@ def main():
     print('| kernel | calls | total ms | avg us | % of GPU time |')
     print('|---|---:|---:|---:|---:|')
     for name, calls, dur, avg, pct in rows[:top_n]:
-        print('| `%s` | %d | %.2f | %.1f | %.2f |' % (short(name), calls, dur / 1e6, avg / 1e3, pct))
-    print('\nGPU kernel time total: %.1f ms over %d kernels (durations in the db are ns).' % (total / 1e6, len(rows)))
+        print('| `%s` | %d | %.2f | %.1f | %.2f |' % (short(name), calls, dur / 1e3, avg, pct))
+    print('\nGPU kernel time total: %.1f ms over %d kernels (durations in the db are us).' % (total / 1e3, len(rows)))
 
 
 if __name__ == '__main__':
