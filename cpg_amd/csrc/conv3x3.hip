@@ -1,5 +1,468 @@
-// placeholder until the specialised 3x3 s1 p1 kernels land: everything routes to the generic path
-#include "cpg_common.h"
-extern "C" int cpg_conv3x3_supported(const cpg_conv_desc *d) { (void)d; return 0; }
-int cpg_conv3x3_fwd(const cpg_conv_desc *, const float *, const float *, const float *, float, const float *, float *, hipStream_t) { return CPG_E_UNSUPPORTED; }
-int cpg_conv3x3_dgrad(const cpg_conv_desc *, const float *, const float *, const float *, float, float *, hipStream_t) { return CPG_E_UNSUPPORTED; }
+// Specialised masked 3x3 / stride 1 / pad 1 convolution on fp32 MFMA -- the shape class of every
+// VGG16 conv (100 % of config 1-3 conv FLOPs), 16 of SphereNet-20's 20 convs and ResNet's 3x3 s1.
+//
+// forward + input-gradient (one kernel, the weight staging differs):
+//   block = BM output channels x (TH x TW) output pixels of ONE image; loop over input channels in
+//   chunks of CK.  Per chunk the block stages
+//     Ws[CK*9][BM+1]        W_eff[co][ci][tap] = W * bin(piggymask)  (binarise fused into this pass)
+//     Xs[CK][(TH+2)][(TW+2)] the zero-padded input patch -- every element is reused by 9 taps x BM
+//                            channels out of LDS ("im2col in LDS", no HBM im2col buffer)
+//   and each wave runs CK*9/2 k-steps of v_mfma_f32_32x32x2_f32 whose operand addresses are
+//   lane_base + compile-time immediates (no index arithmetic in the hot loop).  K ordering inside a
+//   chunk is (channel pair, tap): lanes 0-31 take channel 2p, lanes 32-63 channel 2p+1, same tap.
+//   dgrad is the same contraction with roles swapped: input = gy, output channels = ci, and the
+//   weights staged as Ws[(co,8-tap)][ci] (spatially flipped taps).
+//
+// weight-gradient:
+//   block = 64 co x 64 ci x 9 taps, K = pixels.  Each wave owns a 32 co x 32 ci fragment for ALL 9
+//   taps (9 accumulators): one gy operand read feeds 9 MFMAs against 9 shifted reads of the same
+//   LDS input patch.  Split-K over (image, pixel-tile) ranges; partials reduced by k_c3_wgrad_reduce,
+//   which also applies the autograd epilogue gW = g*bin(pm), gPM = g*W.
+#include <algorithm>
+#include "igemm_core.h"
+
+using namespace cpg;
+
+namespace {
+
+// Launder a value through an empty asm so the compiler cannot hoist the staging index arithmetic that
+// depends on it out of the chunk loop: the hoisted form costs 1-2 VGPRs per staged element (40-100
+// registers) and with it a wave per SIMD; recomputing costs VALU cycles the MFMA-bound loop has spare.
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// same, and additionally a compiler-level memory barrier (orders the staging batches of k_c3_wgrad)
+__device__ __forceinline__ int opaque_mem(int v) {
+    asm volatile("" : "+v"(v) : : "memory");
+    return v;
+}
+
+struct C3Geom {
+    int N, C, H, W, M;        // C: channels of the tensor being read, M: channels being produced
+    int Cw;                   // dim-1 extent of the weight tensor (conv in_channels)
+    int tiles_x, tiles_y, tiles_m;
+};
+
+template <int BM_, int TH_, int TW_, int WM_, int WN_, int CK_>
+struct C3Cfg {
+    static constexpr int BM = BM_, TH = TH_, TW = TW_, WM = WM_, WN = WN_, CK = CK_;
+    static constexpr int BN = TH * TW;
+    static_assert(WM * WN == 4 && BN % (32 * WN) == 0 && BM % (32 * WM) == 0 && CK % 2 == 0, "bad conv3x3 config");
+    static constexpr int FM = BM / 32 / WM, FN = BN / 32 / WN;
+    static constexpr int PH = TH + 2, PW = TW + 2, PLANE = PH * PW;
+    static constexpr int LDW = BM + 1;
+    static constexpr int KC = CK * 9;                       // k extent of one chunk
+    static constexpr int W_ELEMS = KC * LDW, X_ELEMS = CK * PLANE;
+    static constexpr int STAGE = W_ELEMS + X_ELEMS;
+    static constexpr int SMEM_FLOATS = 2 * STAGE;
+    static constexpr int NWL = (BM * KC + 255) / 256;       // staged weight elements per thread
+    static constexpr int NXL = (X_ELEMS + 255) / 256;
+};
+
+// ------------------------------------------------------------------------------ fwd / dgrad
+template <class Cfg, bool DGRAD>
+__global__ __launch_bounds__(256) void k_c3_fwd(C3Geom g, const float *__restrict__ x, const float *__restrict__ w,
+                                                const float *__restrict__ pm, float thr, const float *__restrict__ bias,
+                                                float *__restrict__ y) {
+    __shared__ float smem[Cfg::SMEM_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // block -> (m tile, x tile, y tile, image); m fastest so co-resident blocks of an XCD share the patch
+    unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lb % g.tiles_m; lb /= g.tiles_m;
+    const int tx = lb % g.tiles_x; lb /= g.tiles_x;
+    const int ty = lb % g.tiles_y;
+    const int n = lb / g.tiles_y;
+    const int m0 = tm * Cfg::BM, h0 = ty * Cfg::TH, w0 = tx * Cfg::TW;
+    const int HW = g.H * g.W;
+
+    const float *xin = x + (int64_t)n * g.C * HW;
+
+    float rw[Cfg::NWL], rx[Cfg::NXL];
+    auto fetch = [&](int c0) {
+        const int t = opaque(tid);
+#pragma unroll
+        for (int i = 0; i < Cfg::NWL; ++i) {
+            const int e = t + 256 * i;
+            float v = 0.0f;
+            if (e < Cfg::BM * Cfg::KC) {
+                int m, cl;
+                int64_t off;
+                if (!DGRAD) {           // W[m0+m][c0+cl][tap]: runs of KC contiguous floats per m
+                    m = e / Cfg::KC;
+                    const int rem = e - m * Cfg::KC;
+                    cl = rem / 9;
+                    off = ((int64_t)(m0 + m) * g.Cw + c0) * 9 + rem;
+                } else {                // W[c0+cl][m0+m][tap]: runs of BM*9 contiguous floats per cl
+                    cl = e / (Cfg::BM * 9);
+                    const int rem = e - cl * (Cfg::BM * 9);
+                    m = rem / 9;
+                    off = ((int64_t)(c0 + cl) * g.Cw + m0) * 9 + rem;
+                }
+                if (m0 + m < g.M && c0 + cl < g.C) {
+                    v = w[off];
+                    if (pm != nullptr) v *= binarize(pm[off], thr);
+                }
+            }
+            rw[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::NXL; ++i) {
+            const int e = t + 256 * i;
+            const int cl = e / Cfg::PLANE, rem = e - cl * Cfg::PLANE;
+            const int pr = rem / Cfg::PW, pc = rem - pr * Cfg::PW;
+            const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
+            const bool ok = e < Cfg::X_ELEMS && c0 + cl < g.C && (unsigned)gh < (unsigned)g.H && (unsigned)gw < (unsigned)g.W;
+            rx[i] = ok ? xin[(int64_t)(c0 + cl) * HW + gh * g.W + gw] : 0.0f;
+        }
+    };
+    auto put = [&](float *stage) {
+        const int t = opaque(tid);
+#pragma unroll
+        for (int i = 0; i < Cfg::NWL; ++i) {
+            const int e = t + 256 * i;
+            if (e < Cfg::BM * Cfg::KC) {
+                int row, m;
+                if (!DGRAD) {
+                    m = e / Cfg::KC;
+                    row = e - m * Cfg::KC;                       // cl*9 + tap
+                } else {
+                    const int cl = e / (Cfg::BM * 9);
+                    const int rem = e - cl * (Cfg::BM * 9);
+                    m = rem / 9;
+                    row = cl * 9 + 8 - (rem - m * 9);            // flipped tap
+                }
+                stage[row * Cfg::LDW + m] = rw[i];
+            }
+        }
+        float *xs = stage + Cfg::W_ELEMS;
+#pragma unroll
+        for (int i = 0; i < Cfg::NXL; ++i) {
+            const int e = t + 256 * i;
+            if (e < Cfg::X_ELEMS) xs[e] = rx[i];
+        }
+    };
+
+    // ---- operand lane bases ----
+    const int a_base = lh * 9 * Cfg::LDW + wm * Cfg::FM * 32 + li;
+    int b_base[Cfg::FN];
+#pragma unroll
+    for (int fn = 0; fn < Cfg::FN; ++fn) {
+        const int t = (wn * Cfg::FN + fn) * 32 + li;
+        b_base[fn] = lh * Cfg::PLANE + (t / Cfg::TW) * Cfg::PW + (t % Cfg::TW);
+    }
+
+    f32x16 acc[Cfg::FM][Cfg::FN];
+#pragma unroll
+    for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < Cfg::FN; ++fn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[fm][fn][e] = 0.0f;
+
+    const int nch = (g.C + Cfg::CK - 1) / Cfg::CK;
+    fetch(0);
+    put(smem);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const float *ws = smem + (ch & 1) * Cfg::STAGE;
+        const float *xs = ws + Cfg::W_ELEMS;
+        const bool more = ch + 1 < nch;
+        if (more) fetch((ch + 1) * Cfg::CK);
+#pragma unroll
+        for (int p = 0; p < Cfg::CK / 2; ++p) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                float a[Cfg::FM], b[Cfg::FN];
+#pragma unroll
+                for (int fm = 0; fm < Cfg::FM; ++fm) a[fm] = ws[a_base + (2 * p * 9 + tap) * Cfg::LDW + fm * 32];
+#pragma unroll
+                for (int fn = 0; fn < Cfg::FN; ++fn)
+                    b[fn] = xs[b_base[fn] + 2 * p * Cfg::PLANE + (tap / 3) * Cfg::PW + (tap % 3)];
+#pragma unroll
+                for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+                    for (int fn = 0; fn < Cfg::FN; ++fn)
+                        acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fm], b[fn], acc[fm][fn], 0, 0, 0);
+            }
+        }
+        if (more) put(smem + ((ch + 1) & 1) * Cfg::STAGE);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D col = pixel (lane & 31), D row = channel ----
+    float *yout = y + (int64_t)n * g.M * HW;
+#pragma unroll
+    for (int fn = 0; fn < Cfg::FN; ++fn) {
+        const int t = (wn * Cfg::FN + fn) * 32 + li;
+        const int oh = h0 + t / Cfg::TW, ow = w0 + t % Cfg::TW;
+        const bool pok = oh < g.H && ow < g.W;
+        const int poff = oh * g.W + ow;
+#pragma unroll
+        for (int fm = 0; fm < Cfg::FM; ++fm) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (pok && co < g.M) {
+                    float v = acc[fm][fn][e];
+                    if (bias != nullptr) v += bias[co];
+                    yout[(int64_t)co * HW + poff] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ wgrad
+// D[co][ci](tap) += sum_pix gy[co][pix] * x[ci][pix + tap offset]
+template <int TH_, int TW_>
+struct W3Cfg {
+    static constexpr int TH = TH_, TW = TW_, NPIX = TH * TW;
+    static_assert(TW % 2 == 0, "pixel pairs must not straddle rows");
+    static constexpr int BMC = 64, BCI = 64;                    // block tile: 64 co x 64 ci, 2 x 2 waves
+    static constexpr int PH = TH + 2, PW = TW + 2;
+    static constexpr int PLANE = (PH * PW) | 1;                 // odd stride: conflict-free lane = channel reads
+    static constexpr int LDG = NPIX | 1;
+    static constexpr int G_ELEMS = BMC * LDG, X_ELEMS = BCI * PLANE;
+    static constexpr int SMEM_FLOATS = G_ELEMS + X_ELEMS;
+    static constexpr int NG = (BMC * NPIX + 255) / 256, NX = (BCI * PH * PW + 255) / 256;
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W, int M, int tiles_x, int tiles_y, int tiles_ci,
+                                                  int units_per_split, const float *__restrict__ x,
+                                                  const float *__restrict__ gy, float *__restrict__ part) {
+    __shared__ float smem[Cfg::SMEM_FLOATS];
+    float *gs = smem, *xs = smem + Cfg::G_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wco = wave >> 1, wci = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int tci = blockIdx.x % tiles_ci, tco = blockIdx.x / tiles_ci;
+    const int co0 = tco * Cfg::BMC, ci0 = tci * Cfg::BCI;
+    const int HW = H * W;
+    const int units_per_img = tiles_x * tiles_y;
+    const int total_units = N * units_per_img;
+    const int u0 = blockIdx.y * units_per_split;
+    const int u1 = min(total_units, u0 + units_per_split);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+
+    // Staging of one K unit: gy tile [64][NPIX] and x patch [64][PH*PW], element e = tid + 256*i.  No
+    // register prefetch across the MFMA phase (9 accumulators = 144 registers leave no room for it): the
+    // load -> LDS phase of one block overlaps the MFMA phase of the other block resident on the CU.
+    auto stage = [&](int u) {
+        const int n = u / units_per_img, r = u - n * units_per_img;
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int h0 = ty * Cfg::TH, w0 = tx * Cfg::TW;
+        const float *gimg = gy + (int64_t)n * M * HW;
+        const float *ximg = x + (int64_t)n * C * HW;
+        // batches of <= SB loads in flight, each batch stored to LDS before the next is issued: keeps the
+        // transient (data + 64-bit addresses) inside the ~100 registers the 9 accumulators leave free
+        constexpr int SB = 16;
+#pragma unroll
+        for (int b0 = 0; b0 < Cfg::NG; b0 += SB) {
+            const int t = opaque_mem(tid);
+            float rg[SB];
+#pragma unroll
+            for (int i = b0; i < b0 + SB && i < Cfg::NG; ++i) {
+                const int e = t + 256 * i;
+                const int row = e / Cfg::NPIX, pix = e - row * Cfg::NPIX;
+                const int oh = h0 + pix / Cfg::TW, ow = w0 + pix % Cfg::TW;
+                const bool ok = row < Cfg::BMC && co0 + row < M && oh < H && ow < W;
+                rg[i - b0] = ok ? gimg[(int64_t)(co0 + row) * HW + oh * W + ow] : 0.0f;
+            }
+#pragma unroll
+            for (int i = b0; i < b0 + SB && i < Cfg::NG; ++i) {
+                const int e = t + 256 * i;
+                const int row = e / Cfg::NPIX, pix = e - row * Cfg::NPIX;
+                if (row < Cfg::BMC) gs[row * Cfg::LDG + pix] = rg[i - b0];
+            }
+        }
+#pragma unroll
+        for (int b0 = 0; b0 < Cfg::NX; b0 += SB) {
+            const int t = opaque_mem(tid);
+            float rx[SB];
+#pragma unroll
+            for (int i = b0; i < b0 + SB && i < Cfg::NX; ++i) {
+                const int e = t + 256 * i;
+                const int row = e / (Cfg::PH * Cfg::PW), rem = e - row * (Cfg::PH * Cfg::PW);
+                const int pr = rem / Cfg::PW, pc = rem - pr * Cfg::PW;
+                const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
+                const bool ok = row < Cfg::BCI && ci0 + row < C && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+                rx[i - b0] = ok ? ximg[(int64_t)(ci0 + row) * HW + gh * W + gw] : 0.0f;
+            }
+#pragma unroll
+            for (int i = b0; i < b0 + SB && i < Cfg::NX; ++i) {
+                const int e = t + 256 * i;
+                const int row = e / (Cfg::PH * Cfg::PW), rem = e - row * (Cfg::PH * Cfg::PW);
+                if (row < Cfg::BCI) xs[row * Cfg::PLANE + rem] = rx[i - b0];
+            }
+        }
+    };
+
+    const int a_base = (wco * 32 + li) * Cfg::LDG + lh;                 // gy[co][pix], pix = 2s + lh
+    const int b_base = (wci * 32 + li) * Cfg::PLANE + lh;               // x[ci][(r+kh)*PW + c + kw], c = 2s' + lh
+    for (int u = u0; u < u1; ++u) {
+        __syncthreads();                 // previous unit's operand reads are done
+        stage(u);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < Cfg::TH; ++r) {
+#pragma unroll
+            for (int c2 = 0; c2 < Cfg::TW / 2; ++c2) {
+                const float a = gs[a_base + r * Cfg::TW + 2 * c2];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float b = xs[b_base + (r + t / 3) * Cfg::PW + 2 * c2 + (t % 3)];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partial result: part[split][co][ci][tap]
+    float *dst = part + (int64_t)blockIdx.y * M * C * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co0 + wco * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const int ci = ci0 + wci * 32 + li;
+            if (co < M && ci < C) dst[((int64_t)co * C + ci) * 9 + t] = acc[t][e];
+        }
+}
+
+__global__ __launch_bounds__(256) void k_c3_wgrad_reduce(const float *__restrict__ part, int nsplit, int64_t out_elems,
+                                                         Epilogue ep) {
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < out_elems; e += nthreads) {
+        float s = 0.0f;
+        for (int k = 0; k < nsplit; ++k) s += part[(int64_t)k * out_elems + e];
+        epilogue_store(ep, e, s);
+    }
+}
+
+// ------------------------------------------------------------------------------ dispatch
+//                 BM  TH  TW  WM WN CK
+using CfgM128 = C3Cfg<128, 4, 32, 2, 2, 4>;     // >= 128 output channels, wide images
+using CfgM64 = C3Cfg<64, 8, 32, 1, 4, 4>;       // <= 64 output channels (VGG 224x224 layers)
+using CfgS16 = C3Cfg<128, 14, 16, 4, 1, 4>;     // 14x14 (and <= 16 wide) feature maps: whole image, 7 fragments
+
+template <class Cfg, bool DGRAD>
+int launch_fwd(const C3Geom &g0, const float *x, const float *w, const float *pm, float thr, const float *bias, float *y,
+               hipStream_t stream) {
+    C3Geom g = g0;
+    g.tiles_x = (g.W + Cfg::TW - 1) / Cfg::TW;
+    g.tiles_y = (g.H + Cfg::TH - 1) / Cfg::TH;
+    g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
+    const int64_t blocks = (int64_t)g.N * g.tiles_x * g.tiles_y * g.tiles_m;
+    if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "conv3x3: grid too large");
+    hipLaunchKernelGGL((k_c3_fwd<Cfg, DGRAD>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y);
+    CPG_CHECK_LAUNCH(DGRAD ? "cpg_conv2d_dgrad(3x3)" : "cpg_conv2d_fwd(3x3)");
+    return CPG_OK;
+}
+
+template <bool DGRAD>
+int dispatch_fwd(const C3Geom &g, const float *x, const float *w, const float *pm, float thr, const float *bias, float *y,
+                 hipStream_t stream) {
+    if (g.W <= 16 && g.H <= 16 && g.M > 64) return launch_fwd<CfgS16, DGRAD>(g, x, w, pm, thr, bias, y, stream);
+    if (g.M <= 64) return launch_fwd<CfgM64, DGRAD>(g, x, w, pm, thr, bias, y, stream);
+    return launch_fwd<CfgM128, DGRAD>(g, x, w, pm, thr, bias, y, stream);
+}
+
+}  // namespace
+
+extern "C" int cpg_conv3x3_supported(const cpg_conv_desc *d) {
+    if (getenv("CPG_DISABLE_CONV3X3")) return 0;
+    return d->R == 3 && d->S == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1 &&
+           d->dil_h == 1 && d->dil_w == 1 && d->groups == 1 && d->N > 0 && d->C > 0 && d->K > 0 && d->H > 0 && d->W > 0 &&
+           (int64_t)d->C * d->H * d->W < (1ll << 31) && (int64_t)d->K * d->H * d->W < (1ll << 31);
+}
+
+int cpg_conv3x3_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
+                    float *y, hipStream_t stream) {
+    CPG_REQUIRE(x && w && y, "cpg_conv2d_fwd: null pointer");
+    C3Geom g{d->N, d->C, d->H, d->W, d->K, d->C, 0, 0, 0};
+    return dispatch_fwd<false>(g, x, w, pm, thr, bias, y, stream);
+}
+
+int cpg_conv3x3_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx,
+                      hipStream_t stream) {
+    CPG_REQUIRE(gy && w && gx, "cpg_conv2d_dgrad: null pointer");
+    // reads gy (K channels), produces gx (C channels); weight dim-1 extent is still C
+    C3Geom g{d->N, d->K, d->H, d->W, d->C, d->C, 0, 0, 0};
+    return dispatch_fwd<true>(g, gy, w, pm, thr, nullptr, gx, stream);
+}
+
+// ---- wgrad host side -------------------------------------------------------------------------
+namespace {
+struct W3Plan {
+    int tiles_x, tiles_y, tiles_co, tiles_ci, nsplit, units_per_split;
+    size_t ws_bytes;
+};
+template <class Cfg>
+W3Plan w3_plan(const cpg_conv_desc *d) {
+    W3Plan p;
+    p.tiles_x = (d->W + Cfg::TW - 1) / Cfg::TW;
+    p.tiles_y = (d->H + Cfg::TH - 1) / Cfg::TH;
+    p.tiles_co = (d->K + Cfg::BMC - 1) / Cfg::BMC;
+    p.tiles_ci = (d->C + Cfg::BCI - 1) / Cfg::BCI;
+    const int64_t units = (int64_t)d->N * p.tiles_x * p.tiles_y;
+    const int64_t tiles = (int64_t)p.tiles_co * p.tiles_ci;
+    int64_t want = (2 * kCUs * 2 + tiles - 1) / tiles;         // ~2 rounds of 2 blocks per CU
+    if (want > units) want = units;
+    if (want < 1) want = 1;
+    if (want > 4096) want = 4096;
+    p.units_per_split = (int)((units + want - 1) / want);
+    p.nsplit = (int)((units + p.units_per_split - 1) / p.units_per_split);
+    p.ws_bytes = (size_t)p.nsplit * d->K * d->C * 9 * sizeof(float);
+    return p;
+}
+using W3Wide = W3Cfg<2, 32>;      // W >= 24
+using W3Mid = W3Cfg<7, 14>;       // 14 / 28 / 56 wide feature maps with H % 7 == 0: zero waste, 1.47x halo
+using W3Nar = W3Cfg<4, 16>;       // everything else that is narrow
+inline int w3_pick(const cpg_conv_desc *d) {
+    if (d->W % 14 == 0 && d->W <= 56 && d->H % 7 == 0) return 1;
+    if (d->W < 24) return 2;
+    return 0;
+}
+}  // namespace
+
+size_t cpg_conv3x3_wgrad_workspace(const cpg_conv_desc *d) {
+    switch (w3_pick(d)) {
+        case 1: return w3_plan<W3Mid>(d).ws_bytes;
+        case 2: return w3_plan<W3Nar>(d).ws_bytes;
+        default: return w3_plan<W3Wide>(d).ws_bytes;
+    }
+}
+
+template <class Cfg>
+static int w3_launch(const cpg_conv_desc *d, const float *x, const float *gy, const Epilogue &ep, void *ws, size_t ws_bytes,
+                     hipStream_t stream) {
+    const W3Plan p = w3_plan<Cfg>(d);
+    if (ws_bytes < p.ws_bytes) return fail(CPG_E_WORKSPACE, "cpg_conv2d_wgrad(3x3): workspace %zu < %zu bytes", ws_bytes, p.ws_bytes);
+    hipLaunchKernelGGL(k_c3_wgrad<Cfg>, dim3((unsigned)(p.tiles_co * p.tiles_ci), (unsigned)p.nsplit), dim3(256), 0, stream, d->N,
+                       d->C, d->H, d->W, d->K, p.tiles_x, p.tiles_y, p.tiles_ci, p.units_per_split, x, gy, (float *)ws);
+    const int64_t out_elems = (int64_t)d->K * d->C * 9;
+    hipLaunchKernelGGL(k_c3_wgrad_reduce, dim3(stream_grid(out_elems, 256)), dim3(256), 0, stream, (const float *)ws, p.nsplit,
+                       out_elems, ep);
+    CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(3x3)");
+    return CPG_OK;
+}
+
+int cpg_conv3x3_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
+                      float *gw, float *gpm, void *ws, size_t ws_bytes, hipStream_t stream) {
+    Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
+    switch (w3_pick(d)) {
+        case 1: return w3_launch<W3Mid>(d, x, gy, ep, ws, ws_bytes, stream);
+        case 2: return w3_launch<W3Nar>(d, x, gy, ep, ws, ws_bytes, stream);
+        default: return w3_launch<W3Wide>(d, x, gy, ep, ws, ws_bytes, stream);
+    }
+}

@@ -445,10 +445,17 @@ int cpg_conv3x3_fwd(const cpg_conv_desc *d, const float *x, const float *w, cons
                     float *y, hipStream_t stream);
 int cpg_conv3x3_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx,
                       hipStream_t stream);
+size_t cpg_conv3x3_wgrad_workspace(const cpg_conv_desc *d);
+int cpg_conv3x3_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
+                      float *gw, float *gpm, void *ws, size_t ws_bytes, hipStream_t stream);
+// the 3x3 weight-gradient kernel owns a 64-wide input-channel tile: below 16 channels (VGG / SphereNet stems)
+// the generic kernel's (ci, tap) column packing wastes less of the MFMA
+static inline bool use_c3_wgrad(const cpg_conv_desc *d) { return cpg_conv3x3_supported(d) && d->C >= 16; }
 
 extern "C" size_t cpg_conv2d_workspace_bytes(const cpg_conv_desc *d) {
     ConvGeom g;
     if (make_geom(d, g) != CPG_OK) return 0;
+    if (use_c3_wgrad(d)) return cpg_conv3x3_wgrad_workspace(d);
     int tm, tn, nsplit, per;
     conv_wgrad_tiles<CfgA>(g, tm, tn);
     const int64_t P = (int64_t)g.N * g.OH * g.OW;
@@ -523,6 +530,13 @@ extern "C" int cpg_conv2d_wgrad(const cpg_conv_desc *d, const float *x, const fl
     CPG_REQUIRE((pm == nullptr) == (gpm == nullptr), "cpg_conv2d_wgrad: pm and gpm must both be given or both be NULL");
     CPG_REQUIRE(pm == nullptr || w != nullptr, "cpg_conv2d_wgrad: w is required to form the piggymask gradient");
     hipStream_t stream = (hipStream_t)stream_v;
+    if (use_c3_wgrad(d)) {
+        rc = cpg_conv3x3_wgrad(d, x, gy, w, pm, thr, gw, gpm, ws, ws_bytes, stream);
+        if (rc) return rc;
+        if (gb) hipLaunchKernelGGL(k_bias_grad, dim3((unsigned)g.K), dim3(256), 0, stream, gy, gb, g.N, g.K, g.OH * g.OW);
+        CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(bias)");
+        return CPG_OK;
+    }
     int tm, tn, nsplit, per;
     conv_wgrad_tiles<CfgA>(g, tm, tn);
     const int64_t P = (int64_t)g.N * g.OH * g.OW;

@@ -106,6 +106,10 @@ def test_linear_golden(name):
     (2, 128, 28, 28, 256, 3, 1, 1, False, True),     # with piggymask
     (5, 512, 14, 14, 512, 3, 1, 1, False, False),    # deep K (4608), small spatial
     (2, 64, 33, 47, 70, 3, 1, 1, True, True),        # ragged everything
+    (2, 20, 15, 14, 130, 3, 1, 1, False, True),      # small-map config (<=16 wide), ragged rows, 2 channel tiles
+    (1, 70, 30, 56, 64, 3, 1, 1, True, False),       # <=64-channel config, partial 32-wide tiles
+    (3, 32, 14, 14, 96, 3, 1, 1, False, False),      # whole-image tiles; wgrad 7x14 units
+    (2, 17, 10, 40, 33, 3, 1, 1, False, True),       # channel counts not multiples of the chunk / fragment
     (2, 3, 64, 64, 16, 7, 2, 3, False, False),       # ResNet stem
     (3, 64, 28, 28, 256, 1, 1, 0, False, True),      # ResNet 1x1
     (3, 256, 28, 28, 512, 1, 2, 0, False, False),    # ResNet downsample
