@@ -45,8 +45,9 @@ struct C3Geom {
     int tiles_x, tiles_y, tiles_m;
 };
 
-template <int BM_, int TH_, int TW_, int WM_, int WN_, int CK_>
+template <int BM_, int TH_, int TW_, int WM_, int WN_, int CK_, int MINW_>
 struct C3Cfg {
+    static constexpr int MINW = MINW_;                      // waves per SIMD the register allocator must leave room for
     static constexpr int BM = BM_, TH = TH_, TW = TW_, WM = WM_, WN = WN_, CK = CK_;
     static constexpr int BN = TH * TW;
     static_assert(WM * WN == 4 && BN % (32 * WN) == 0 && BM % (32 * WM) == 0 && CK % 2 == 0, "bad conv3x3 config");
@@ -62,8 +63,8 @@ struct C3Cfg {
 };
 
 // ------------------------------------------------------------------------------ fwd / dgrad
-template <class Cfg, bool DGRAD>
-__global__ __launch_bounds__(256) void k_c3_fwd(C3Geom g, const float *__restrict__ x, const float *__restrict__ w,
+template <class Cfg, bool DGRAD, bool HAS_PM>
+__global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float *__restrict__ x, const float *__restrict__ w,
                                                 const float *__restrict__ pm, float thr, const float *__restrict__ bias,
                                                 float *__restrict__ y) {
     __shared__ float smem[Cfg::SMEM_FLOATS];
@@ -83,32 +84,38 @@ __global__ __launch_bounds__(256) void k_c3_fwd(C3Geom g, const float *__restric
     const float *xin = x + (int64_t)n * g.C * HW;
 
     float rw[Cfg::NWL], rx[Cfg::NXL];
+    static_assert(Cfg::NWL <= 32 && Cfg::NXL <= 32, "validity bitmasks are 32 bits");
+    // All staging loads are UNCONDITIONAL (out-of-range elements read element 0) and their results are not
+    // touched until put(): a predicated load compiles to an exec-masked branch with its own
+    // s_waitcnt vmcnt(0) (one serialised memory round trip per element), and any arithmetic on a loaded
+    // value inside fetch() would pull the wait in front of the MFMAs.  Validity travels as a bitmask.
+    float rp[HAS_PM ? Cfg::NWL : 1];    // raw piggymask values
+    unsigned wok = 0, xok = 0;
     auto fetch = [&](int c0) {
         const int t = opaque(tid);
+        wok = 0;
+        xok = 0;
 #pragma unroll
         for (int i = 0; i < Cfg::NWL; ++i) {
             const int e = t + 256 * i;
-            float v = 0.0f;
-            if (e < Cfg::BM * Cfg::KC) {
-                int m, cl;
-                int64_t off;
-                if (!DGRAD) {           // W[m0+m][c0+cl][tap]: runs of KC contiguous floats per m
-                    m = e / Cfg::KC;
-                    const int rem = e - m * Cfg::KC;
-                    cl = rem / 9;
-                    off = ((int64_t)(m0 + m) * g.Cw + c0) * 9 + rem;
-                } else {                // W[c0+cl][m0+m][tap]: runs of BM*9 contiguous floats per cl
-                    cl = e / (Cfg::BM * 9);
-                    const int rem = e - cl * (Cfg::BM * 9);
-                    m = rem / 9;
-                    off = ((int64_t)(c0 + cl) * g.Cw + m0) * 9 + rem;
-                }
-                if (m0 + m < g.M && c0 + cl < g.C) {
-                    v = w[off];
-                    if (pm != nullptr) v *= binarize(pm[off], thr);
-                }
+            int m, cl;
+            int64_t off;
+            if (!DGRAD) {           // W[m0+m][c0+cl][tap]: runs of KC contiguous floats per m
+                m = e / Cfg::KC;
+                const int rem = e - m * Cfg::KC;
+                cl = rem / 9;
+                off = ((int64_t)(m0 + m) * g.Cw + c0) * 9 + rem;
+            } else {                // W[c0+cl][m0+m][tap]: runs of BM*9 contiguous floats per cl
+                cl = e / (Cfg::BM * 9);
+                const int rem = e - cl * (Cfg::BM * 9);
+                m = rem / 9;
+                off = ((int64_t)(c0 + cl) * g.Cw + m0) * 9 + rem;
             }
-            rw[i] = v;
+            const bool ok = e < Cfg::BM * Cfg::KC && m0 + m < g.M && c0 + cl < g.C;
+            wok |= (ok ? 1u : 0u) << i;
+            off = ok ? off : 0;
+            rw[i] = w[off];
+            if (HAS_PM) rp[i] = pm[off];
         }
 #pragma unroll
         for (int i = 0; i < Cfg::NXL; ++i) {
@@ -117,7 +124,8 @@ __global__ __launch_bounds__(256) void k_c3_fwd(C3Geom g, const float *__restric
             const int pr = rem / Cfg::PW, pc = rem - pr * Cfg::PW;
             const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
             const bool ok = e < Cfg::X_ELEMS && c0 + cl < g.C && (unsigned)gh < (unsigned)g.H && (unsigned)gw < (unsigned)g.W;
-            rx[i] = ok ? xin[(int64_t)(c0 + cl) * HW + gh * g.W + gw] : 0.0f;
+            xok |= (ok ? 1u : 0u) << i;
+            rx[i] = xin[ok ? (int64_t)(c0 + cl) * HW + gh * g.W + gw : 0];
         }
     };
     auto put = [&](float *stage) {
@@ -136,14 +144,16 @@ __global__ __launch_bounds__(256) void k_c3_fwd(C3Geom g, const float *__restric
                     m = rem / 9;
                     row = cl * 9 + 8 - (rem - m * 9);            // flipped tap
                 }
-                stage[row * Cfg::LDW + m] = rw[i];
+                float v = rw[i];
+                if (HAS_PM) v *= binarize(rp[i], thr);
+                stage[row * Cfg::LDW + m] = ((wok >> i) & 1u) ? v : 0.0f;
             }
         }
         float *xs = stage + Cfg::W_ELEMS;
 #pragma unroll
         for (int i = 0; i < Cfg::NXL; ++i) {
             const int e = t + 256 * i;
-            if (e < Cfg::X_ELEMS) xs[e] = rx[i];
+            if (e < Cfg::X_ELEMS) xs[e] = ((xok >> i) & 1u) ? rx[i] : 0.0f;
         }
     };
 
@@ -204,14 +214,20 @@ __global__ __launch_bounds__(256) void k_c3_fwd(C3Geom g, const float *__restric
         const int poff = oh * g.W + ow;
 #pragma unroll
         for (int fm = 0; fm < Cfg::FM; ++fm) {
+            float bv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) bv[e] = 0.0f;
+            if (bias != nullptr) {          // one uniform branch per fragment, 16 loads issued together
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    bv[e] = bias[co < g.M ? co : 0];
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (pok && co < g.M) {
-                    float v = acc[fm][fn][e];
-                    if (bias != nullptr) v += bias[co];
-                    yout[(int64_t)co * HW + poff] = v;
-                }
+                if (pok && co < g.M) yout[(int64_t)co * HW + poff] = acc[fm][fn][e] + bv[e];
             }
         }
     }
@@ -277,7 +293,8 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
                 const int row = e / Cfg::NPIX, pix = e - row * Cfg::NPIX;
                 const int oh = h0 + pix / Cfg::TW, ow = w0 + pix % Cfg::TW;
                 const bool ok = row < Cfg::BMC && co0 + row < M && oh < H && ow < W;
-                rg[i - b0] = ok ? gimg[(int64_t)(co0 + row) * HW + oh * W + ow] : 0.0f;
+                const float v = gimg[ok ? (int64_t)(co0 + row) * HW + oh * W + ow : 0];     // unconditional load
+                rg[i - b0] = ok ? v : 0.0f;
             }
 #pragma unroll
             for (int i = b0; i < b0 + SB && i < Cfg::NG; ++i) {
@@ -297,7 +314,8 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
                 const int pr = rem / Cfg::PW, pc = rem - pr * Cfg::PW;
                 const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
                 const bool ok = row < Cfg::BCI && ci0 + row < C && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-                rx[i - b0] = ok ? ximg[(int64_t)(ci0 + row) * HW + gh * W + gw] : 0.0f;
+                const float v = ximg[ok ? (int64_t)(ci0 + row) * HW + gh * W + gw : 0];
+                rx[i - b0] = ok ? v : 0.0f;
             }
 #pragma unroll
             for (int i = b0; i < b0 + SB && i < Cfg::NX; ++i) {
@@ -350,10 +368,10 @@ __global__ __launch_bounds__(256) void k_c3_wgrad_reduce(const float *__restrict
 }
 
 // ------------------------------------------------------------------------------ dispatch
-//                 BM  TH  TW  WM WN CK
-using CfgM128 = C3Cfg<128, 4, 32, 2, 2, 4>;     // >= 128 output channels, wide images
-using CfgM64 = C3Cfg<64, 8, 32, 1, 4, 4>;       // <= 64 output channels (VGG 224x224 layers)
-using CfgS16 = C3Cfg<128, 14, 16, 4, 1, 4>;     // 14x14 (and <= 16 wide) feature maps: whole image, 7 fragments
+//                 BM  TH  TW  WM WN CK MINW
+using CfgM128 = C3Cfg<128, 4, 32, 2, 2, 4, 3>;     // >= 128 output channels, wide images
+using CfgM64 = C3Cfg<64, 8, 32, 1, 4, 4, 3>;       // <= 64 output channels (VGG 224x224 layers)
+using CfgS16 = C3Cfg<128, 14, 16, 4, 1, 4, 2>;     // 14x14 (and <= 16 wide) feature maps: whole image, 7 fragments
 
 template <class Cfg, bool DGRAD>
 int launch_fwd(const C3Geom &g0, const float *x, const float *w, const float *pm, float thr, const float *bias, float *y,
@@ -364,7 +382,10 @@ int launch_fwd(const C3Geom &g0, const float *x, const float *w, const float *pm
     g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
     const int64_t blocks = (int64_t)g.N * g.tiles_x * g.tiles_y * g.tiles_m;
     if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "conv3x3: grid too large");
-    hipLaunchKernelGGL((k_c3_fwd<Cfg, DGRAD>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y);
+    if (pm != nullptr)
+        hipLaunchKernelGGL((k_c3_fwd<Cfg, DGRAD, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y);
+    else
+        hipLaunchKernelGGL((k_c3_fwd<Cfg, DGRAD, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y);
     CPG_CHECK_LAUNCH(DGRAD ? "cpg_conv2d_dgrad(3x3)" : "cpg_conv2d_fwd(3x3)");
     return CPG_OK;
 }

@@ -46,8 +46,10 @@ struct FwdBLoader {
         iw0 = ow * g.sw - g.pw;
         xbase = (int64_t)n * C * H * W;
     }
+    unsigned okmask;
     __device__ __forceinline__ void fetch(int kt, float (&r)[N]) {
         const int RS = R * S;
+        okmask = 0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int k = kt * BK + t_k + KSTEP * i;
@@ -55,12 +57,13 @@ struct FwdBLoader {
             const int rr = rs / S, ss = rs - rr * S;
             const int ih = ih0 + rr * dh, iw = iw0 + ss * dw;
             const bool ok = jvalid && k < Kg && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-            r[i] = ok ? x[xbase + ((int64_t)ci * H + ih) * W + iw] : 0.0f;
+            okmask |= (ok ? 1u : 0u) << i;
+            r[i] = x[ok ? xbase + ((int64_t)ci * H + ih) * W + iw : 0];       // unconditional load, select in put()
         }
     }
     __device__ __forceinline__ void put(const float (&r)[N], float *lds) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) lds[(t_k + KSTEP * i) * (BN + 1) + t_j] = r[i];
+        for (int i = 0; i < N; ++i) lds[(t_k + KSTEP * i) * (BN + 1) + t_j] = ((okmask >> i) & 1u) ? r[i] : 0.0f;
     }
 };
 
@@ -88,8 +91,10 @@ struct DgradBLoader {
         tw0 = rem % g.W + g.pw;
         base = (int64_t)n * K * OH * OW;
     }
+    unsigned okmask;
     __device__ __forceinline__ void fetch(int kt, float (&r)[N]) {
         const int RS = R * S;
+        okmask = 0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int k = kt * BK + t_k + KSTEP * i;
@@ -101,12 +106,13 @@ struct DgradBLoader {
             if (sh != 1) { oh = th / sh; ok = ok && (oh * sh == th); }
             if (sw != 1) { ow = tw / sw; ok = ok && (ow * sw == tw); }
             ok = ok && oh < OH && ow < OW;
-            r[i] = ok ? gy[base + ((int64_t)co * OH + oh) * OW + ow] : 0.0f;
+            okmask |= (ok ? 1u : 0u) << i;
+            r[i] = gy[ok ? base + ((int64_t)co * OH + oh) * OW + ow : 0];
         }
     }
     __device__ __forceinline__ void put(const float (&r)[N], float *lds) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) lds[(t_k + KSTEP * i) * (BN + 1) + t_j] = r[i];
+        for (int i = 0; i < N; ++i) lds[(t_k + KSTEP * i) * (BN + 1) + t_j] = ((okmask >> i) & 1u) ? r[i] : 0.0f;
     }
 };
 
@@ -118,6 +124,8 @@ struct DgradALoader {
     const float *w, *pm;
     float thr;
     int C, RS, Kg, m0, t_k, t_m;
+    unsigned okmask;
+    float rp[N];
     __device__ __forceinline__ void init(const float *w_, const float *pm_, float thr_, const ConvGeom &g, int m0_) {
         w = w_; pm = pm_; thr = thr_; C = g.C; RS = g.R * g.S; Kg = g.K * RS; m0 = m0_;
         t_k = threadIdx.x % BK;
@@ -126,21 +134,24 @@ struct DgradALoader {
     __device__ __forceinline__ void fetch(int kt, float (&r)[N]) {
         const int k = kt * BK + t_k;
         const int co = k / RS, rs = k - co * RS;
+        okmask = 0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int ci = m0 + t_m + MSTEP * i;
-            float v = 0.0f;
-            if (k < Kg && ci < C) {
-                const int64_t off = ((int64_t)co * C + ci) * RS + rs;
-                v = w[off];
-                if (pm != nullptr) v *= binarize(pm[off], thr);
-            }
-            r[i] = v;
+            const bool ok = k < Kg && ci < C;
+            const int64_t off = ok ? ((int64_t)co * C + ci) * RS + rs : 0;
+            okmask |= (ok ? 1u : 0u) << i;
+            r[i] = w[off];
+            if (pm != nullptr) rp[i] = pm[off];            // wave-uniform condition
         }
     }
     __device__ __forceinline__ void put(const float (&r)[N], float *lds) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) lds[t_k * (BM + 1) + t_m + MSTEP * i] = r[i];
+        for (int i = 0; i < N; ++i) {
+            float v = r[i];
+            if (pm != nullptr) v *= binarize(rp[i], thr);
+            lds[t_k * (BM + 1) + t_m + MSTEP * i] = ((okmask >> i) & 1u) ? v : 0.0f;
+        }
     }
 };
 
@@ -151,6 +162,7 @@ struct WgradALoader {
     static constexpr int MSTEP = 256 / BK;
     const float *gy;
     int K, OHW, m0, t_k, t_m;
+    unsigned okmask;
     int64_t P;
     __device__ __forceinline__ void init(const float *gy_, const ConvGeom &g, int m0_) {
         gy = gy_; K = g.K; OHW = g.OH * g.OW; m0 = m0_; P = (int64_t)g.N * OHW;
@@ -163,15 +175,18 @@ struct WgradALoader {
         const int n = pv ? (int)(p / OHW) : 0;
         const int q = pv ? (int)(p % OHW) : 0;
         const int64_t b = (int64_t)n * K * OHW + q;
+        okmask = 0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int co = m0 + t_m + MSTEP * i;
-            r[i] = (pv && co < K) ? gy[b + (int64_t)co * OHW] : 0.0f;
+            const bool ok = pv && co < K;
+            okmask |= (ok ? 1u : 0u) << i;
+            r[i] = gy[ok ? b + (int64_t)co * OHW : 0];
         }
     }
     __device__ __forceinline__ void put(const float (&r)[N], float *lds) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) lds[t_k * (BM + 1) + t_m + MSTEP * i] = r[i];
+        for (int i = 0; i < N; ++i) lds[t_k * (BM + 1) + t_m + MSTEP * i] = ((okmask >> i) & 1u) ? r[i] : 0.0f;
     }
 };
 
@@ -183,6 +198,7 @@ struct WgradBLoader {
     const float *x;
     int C, H, W, OW, OHW, sh, sw, ph, pw, t_k, t_j;
     int64_t P;
+    unsigned okmask;
     int joff[N];      // ci*H*W + r*dh*W + s*dw, or -1 when j is out of range
     int jrs[N];       // (r*dh) << 16 | (s*dw)
     __device__ __forceinline__ void init(const float *x_, const ConvGeom &g, int j0) {
@@ -213,16 +229,18 @@ struct WgradBLoader {
         const int oh = q / OW, ow = q - oh * OW;
         const int ih0 = oh * sh - ph, iw0 = ow * sw - pw;
         const int64_t b = (int64_t)n * C * H * W + (int64_t)ih0 * W + iw0;
+        okmask = 0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int ih = ih0 + (jrs[i] >> 16), iw = iw0 + (jrs[i] & 0xFFFF);
             const bool ok = pv && joff[i] >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-            r[i] = ok ? x[b + joff[i]] : 0.0f;
+            okmask |= (ok ? 1u : 0u) << i;
+            r[i] = x[ok ? b + joff[i] : 0];
         }
     }
     __device__ __forceinline__ void put(const float (&r)[N], float *lds) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) lds[t_k * (BN + 1) + t_j + JSTEP * i] = r[i];
+        for (int i = 0; i < N; ++i) lds[t_k * (BN + 1) + t_j + JSTEP * i] = ((okmask >> i) & 1u) ? r[i] : 0.0f;
     }
 };
 

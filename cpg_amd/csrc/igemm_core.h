@@ -164,18 +164,25 @@ struct DenseLoader {
             t_k = threadIdx.x / ROWS;
         }
     }
+    // Loads are unconditional (clamped address) and nothing touches the loaded registers before put():
+    // a predicated load becomes an exec-masked branch with its own s_waitcnt vmcnt(0) (one serialised
+    // round trip per element), and arithmetic on a loaded value inside fetch() would drag the wait in
+    // front of the MFMAs of the current tile.  Validity is carried as a bitmask, piggymask values raw.
+    unsigned okmask;
+    float rp[HAS_PM ? N : 1];
     __device__ __forceinline__ void fetch(int kt, float (&r)[N]) {
+        static_assert(N <= 32, "validity bitmask is 32 bits");
+        okmask = 0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int k = kt * BK + (KC ? t_k : t_k + (256 / ROWS) * i);
             const int row = row0 + (KC ? t_row + (256 / BK) * i : t_row);
-            float v = 0.0f;
-            if (k < k_total && row < rows_total) {
-                const int64_t off = KC ? (int64_t)row * ld + k : (int64_t)k * ld + row;
-                v = base[off];
-                if (HAS_PM) v *= binarize(pm[off], thr);
-            }
-            r[i] = v;
+            const bool ok = k < k_total && row < rows_total;
+            int64_t off = KC ? (int64_t)row * ld + k : (int64_t)k * ld + row;
+            off = ok ? off : 0;
+            okmask |= (ok ? 1u : 0u) << i;
+            r[i] = base[off];
+            if (HAS_PM) rp[i] = pm[off];
         }
     }
     __device__ __forceinline__ void put(const float (&r)[N], float *lds) {
@@ -183,7 +190,9 @@ struct DenseLoader {
         for (int i = 0; i < N; ++i) {
             const int kk = KC ? t_k : t_k + (256 / ROWS) * i;
             const int rr = KC ? t_row + (256 / BK) * i : t_row;
-            lds[kk * LDS_LD + rr] = r[i];
+            float v = r[i];
+            if (HAS_PM) v *= binarize(rp[i], thr);
+            lds[kk * LDS_LD + rr] = ((okmask >> i) & 1u) ? v : 0.0f;
         }
     }
 };
