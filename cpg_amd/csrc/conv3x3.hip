@@ -41,7 +41,7 @@ __device__ __forceinline__ int opaque_mem(int v) {
 
 struct C3Geom {
     int N, C, H, W, M;        // C: channels of the tensor being read, M: channels being produced
-    int Cw;                   // dim-1 extent of the weight tensor (conv in_channels)
+    int Mp;                   // row stride of the packed weights (M rounded up to 128)
     int tiles_x, tiles_y, tiles_m;
 };
 
@@ -53,21 +53,51 @@ struct C3Cfg {
     static_assert(WM * WN == 4 && BN % (32 * WN) == 0 && BM % (32 * WM) == 0 && CK % 2 == 0, "bad conv3x3 config");
     static constexpr int FM = BM / 32 / WM, FN = BN / 32 / WN;
     static constexpr int PH = TH + 2, PW = TW + 2, PLANE = PH * PW;
-    static constexpr int LDW = BM + 1;
+    static constexpr int LDW = BM + 4;                      // +4: rows stay 16-byte aligned for ds_write_b128
     static constexpr int KC = CK * 9;                       // k extent of one chunk
+    static constexpr int W4 = BM / 4;                       // float4 per weight row
+    static constexpr int WROWS = 256 / W4;                  // weight rows staged per pass of the block
+    static constexpr int NW4 = (KC + WROWS - 1) / WROWS;    // float4 loads per thread per chunk
     static constexpr int W_ELEMS = KC * LDW, X_ELEMS = CK * PLANE;
     static constexpr int STAGE = W_ELEMS + X_ELEMS;
     static constexpr int SMEM_FLOATS = 2 * STAGE;
-    static constexpr int NWL = (BM * KC + 255) / 256;       // staged weight elements per thread
     static constexpr int NXL = (X_ELEMS + 255) / 256;
 };
 
+// ------------------------------------------------------------------------------ weight pack
+// Wp[(c*9 + tap')][m]  (row stride Mp, zero padded to CK channels x 128 columns)
+//   fwd  : c = ci, m = co, tap' = tap        value = W[co][ci][tap] * bin(pm)
+//   dgrad: c = co, m = ci, tap' = 8 - tap    (spatially flipped: conv of gy with the transposed filter)
+// One fused pass: binarise + mask + transpose into the K-major layout the conv kernel streams with
+// float4 loads.  Conv weights are 1.7 k ... 2.4 M elements per layer (59 MB for all of VGG16), so this
+// costs microseconds; rocprof PMC showed the alternative -- gathering W[co][ci][tap] inside the conv
+// kernel -- at 13.4 VALU instructions per MFMA and 57 % MFMA utilisation (profiles/r01c_pmc.md).
+__global__ __launch_bounds__(256) void k_c3_pack(const float *__restrict__ w, const float *__restrict__ pm, float thr,
+                                                 float *__restrict__ out, int K, int C, int rows_c, int Mp, int dgrad) {
+    // out index o = (c*9 + tp) * Mp + m ; consecutive threads -> consecutive m (coalesced writes)
+    const int64_t total = (int64_t)rows_c * 9 * Mp;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += nthreads) {
+        const int m = (int)(o % Mp);
+        const int r = (int)(o / Mp);
+        const int c = r / 9, tp = r - c * 9;
+        const int co = dgrad ? c : m, ci = dgrad ? m : c, tap = dgrad ? 8 - tp : tp;
+        float v = 0.0f;
+        if (co < K && ci < C) {
+            const int64_t off = ((int64_t)co * C + ci) * 9 + tap;
+            v = w[off];
+            if (pm != nullptr) v *= binarize(pm[off], thr);
+        }
+        out[o] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------ fwd / dgrad
-template <class Cfg, bool DGRAD, bool HAS_PM>
-__global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float *__restrict__ x, const float *__restrict__ w,
-                                                const float *__restrict__ pm, float thr, const float *__restrict__ bias,
-                                                float *__restrict__ y) {
-    __shared__ float smem[Cfg::SMEM_FLOATS];
+// y[n][m][h][w] = sum_{c,tap} Wp[(c*9+tap)][m] * x[n][c][h + tap/3 - 1][w + tap%3 - 1]
+template <class Cfg>
+__global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float *__restrict__ x, const float *__restrict__ wp,
+                                                           const float *__restrict__ bias, float *__restrict__ y) {
+    __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
     const int li = lane & 31, lh = lane >> 5;
@@ -81,78 +111,58 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
     const int m0 = tm * Cfg::BM, h0 = ty * Cfg::TH, w0 = tx * Cfg::TW;
     const int HW = g.H * g.W;
 
+    // ---- staging descriptors, all fixed for the life of the block (a handful of registers) ----
+    // weights: float4 (row = wrow0 + WROWS*i, 4 columns at wcol); Wp is zero padded, so no guards
+    const int wcol = (tid % Cfg::W4) * 4, wrow0 = tid / Cfg::W4;
+    const float *wsrc = wp + (int64_t)wrow0 * g.Mp + m0 + wcol;
+    const int wdst = wrow0 * Cfg::LDW + wcol;
+    // patch: element e = tid + 256*i of [CK][PH][PW]
+    int xoff[Cfg::NXL];            // offset inside the image for chunk 0, or -1 (zero padding / past the end)
+    int xcl[Cfg::NXL];
+#pragma unroll
+    for (int i = 0; i < Cfg::NXL; ++i) {
+        const int e = tid + 256 * i;
+        const int cl = e / Cfg::PLANE, rem = e - cl * Cfg::PLANE;
+        const int pr = rem / Cfg::PW, pc = rem - pr * Cfg::PW;
+        const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
+        const bool ok = e < Cfg::X_ELEMS && (unsigned)gh < (unsigned)g.H && (unsigned)gw < (unsigned)g.W;
+        xoff[i] = ok ? cl * HW + gh * g.W + gw : -1;
+        xcl[i] = cl;
+    }
     const float *xin = x + (int64_t)n * g.C * HW;
 
-    float rw[Cfg::NWL], rx[Cfg::NXL];
-    static_assert(Cfg::NWL <= 32 && Cfg::NXL <= 32, "validity bitmasks are 32 bits");
-    // All staging loads are UNCONDITIONAL (out-of-range elements read element 0) and their results are not
-    // touched until put(): a predicated load compiles to an exec-masked branch with its own
-    // s_waitcnt vmcnt(0) (one serialised memory round trip per element), and any arithmetic on a loaded
-    // value inside fetch() would pull the wait in front of the MFMAs.  Validity travels as a bitmask.
-    float rp[HAS_PM ? Cfg::NWL : 1];    // raw piggymask values
-    unsigned wok = 0, xok = 0;
+    // Loads are unconditional (clamped address) and their results untouched until put(): a predicated
+    // load is an exec-masked branch with its own s_waitcnt vmcnt(0), and arithmetic on a loaded value in
+    // fetch() would drag that wait in front of the MFMAs of the current chunk.
+    float4 rw[Cfg::NW4];
+    float rx[Cfg::NXL];
+    unsigned xok = 0;
     auto fetch = [&](int c0) {
-        const int t = opaque(tid);
-        wok = 0;
+        const float *wc = wsrc + (int64_t)c0 * 9 * g.Mp;
+#pragma unroll
+        for (int i = 0; i < Cfg::NW4; ++i) {
+            const bool live = (Cfg::KC % Cfg::WROWS == 0) || (wrow0 + Cfg::WROWS * i < Cfg::KC);
+            rw[i] = *reinterpret_cast<const float4 *>(live ? wc + (int64_t)Cfg::WROWS * i * g.Mp : wp);
+        }
+        const float *xc = xin + (int64_t)c0 * HW;
         xok = 0;
 #pragma unroll
-        for (int i = 0; i < Cfg::NWL; ++i) {
-            const int e = t + 256 * i;
-            int m, cl;
-            int64_t off;
-            if (!DGRAD) {           // W[m0+m][c0+cl][tap]: runs of KC contiguous floats per m
-                m = e / Cfg::KC;
-                const int rem = e - m * Cfg::KC;
-                cl = rem / 9;
-                off = ((int64_t)(m0 + m) * g.Cw + c0) * 9 + rem;
-            } else {                // W[c0+cl][m0+m][tap]: runs of BM*9 contiguous floats per cl
-                cl = e / (Cfg::BM * 9);
-                const int rem = e - cl * (Cfg::BM * 9);
-                m = rem / 9;
-                off = ((int64_t)(c0 + cl) * g.Cw + m0) * 9 + rem;
-            }
-            const bool ok = e < Cfg::BM * Cfg::KC && m0 + m < g.M && c0 + cl < g.C;
-            wok |= (ok ? 1u : 0u) << i;
-            off = ok ? off : 0;
-            rw[i] = w[off];
-            if (HAS_PM) rp[i] = pm[off];
-        }
-#pragma unroll
         for (int i = 0; i < Cfg::NXL; ++i) {
-            const int e = t + 256 * i;
-            const int cl = e / Cfg::PLANE, rem = e - cl * Cfg::PLANE;
-            const int pr = rem / Cfg::PW, pc = rem - pr * Cfg::PW;
-            const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
-            const bool ok = e < Cfg::X_ELEMS && c0 + cl < g.C && (unsigned)gh < (unsigned)g.H && (unsigned)gw < (unsigned)g.W;
+            const bool ok = xoff[i] >= 0 && c0 + xcl[i] < g.C;
             xok |= (ok ? 1u : 0u) << i;
-            rx[i] = xin[ok ? (int64_t)(c0 + cl) * HW + gh * g.W + gw : 0];
+            rx[i] = ok ? xc[xoff[i]] : xin[0];
         }
     };
     auto put = [&](float *stage) {
-        const int t = opaque(tid);
 #pragma unroll
-        for (int i = 0; i < Cfg::NWL; ++i) {
-            const int e = t + 256 * i;
-            if (e < Cfg::BM * Cfg::KC) {
-                int row, m;
-                if (!DGRAD) {
-                    m = e / Cfg::KC;
-                    row = e - m * Cfg::KC;                       // cl*9 + tap
-                } else {
-                    const int cl = e / (Cfg::BM * 9);
-                    const int rem = e - cl * (Cfg::BM * 9);
-                    m = rem / 9;
-                    row = cl * 9 + 8 - (rem - m * 9);            // flipped tap
-                }
-                float v = rw[i];
-                if (HAS_PM) v *= binarize(rp[i], thr);
-                stage[row * Cfg::LDW + m] = ((wok >> i) & 1u) ? v : 0.0f;
-            }
+        for (int i = 0; i < Cfg::NW4; ++i) {
+            const bool live = (Cfg::KC % Cfg::WROWS == 0) || (wrow0 + Cfg::WROWS * i < Cfg::KC);
+            if (live) *reinterpret_cast<float4 *>(stage + wdst + Cfg::WROWS * i * Cfg::LDW) = rw[i];
         }
         float *xs = stage + Cfg::W_ELEMS;
 #pragma unroll
         for (int i = 0; i < Cfg::NXL; ++i) {
-            const int e = t + 256 * i;
+            const int e = tid + 256 * i;
             if (e < Cfg::X_ELEMS) xs[e] = ((xok >> i) & 1u) ? rx[i] : 0.0f;
         }
     };
@@ -373,29 +383,37 @@ using CfgM128 = C3Cfg<128, 4, 32, 2, 2, 4, 3>;     // >= 128 output channels, wi
 using CfgM64 = C3Cfg<64, 8, 32, 1, 4, 4, 3>;       // <= 64 output channels (VGG 224x224 layers)
 using CfgS16 = C3Cfg<128, 14, 16, 4, 1, 4, 2>;     // 14x14 (and <= 16 wide) feature maps: whole image, 7 fragments
 
-template <class Cfg, bool DGRAD>
-int launch_fwd(const C3Geom &g0, const float *x, const float *w, const float *pm, float thr, const float *bias, float *y,
-               hipStream_t stream) {
-    C3Geom g = g0;
+inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+// packed-weight workspace: [roundup(C_read, 4) * 9][roundup(M, 128)] floats
+inline size_t pack_bytes(int c_read, int m) { return (size_t)pad_to(c_read, 4) * 9 * pad_to(m, 128) * sizeof(float); }
+
+template <class Cfg>
+int launch_fwd(C3Geom g, const float *x, const float *wp, const float *bias, float *y, hipStream_t stream, const char *what) {
     g.tiles_x = (g.W + Cfg::TW - 1) / Cfg::TW;
     g.tiles_y = (g.H + Cfg::TH - 1) / Cfg::TH;
     g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
     const int64_t blocks = (int64_t)g.N * g.tiles_x * g.tiles_y * g.tiles_m;
     if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "conv3x3: grid too large");
-    if (pm != nullptr)
-        hipLaunchKernelGGL((k_c3_fwd<Cfg, DGRAD, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y);
-    else
-        hipLaunchKernelGGL((k_c3_fwd<Cfg, DGRAD, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y);
-    CPG_CHECK_LAUNCH(DGRAD ? "cpg_conv2d_dgrad(3x3)" : "cpg_conv2d_fwd(3x3)");
+    hipLaunchKernelGGL((k_c3_fwd<Cfg>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y);
+    CPG_CHECK_LAUNCH(what);
     return CPG_OK;
 }
 
-template <bool DGRAD>
-int dispatch_fwd(const C3Geom &g, const float *x, const float *w, const float *pm, float thr, const float *bias, float *y,
-                 hipStream_t stream) {
-    if (g.W <= 16 && g.H <= 16 && g.M > 64) return launch_fwd<CfgS16, DGRAD>(g, x, w, pm, thr, bias, y, stream);
-    if (g.M <= 64) return launch_fwd<CfgM64, DGRAD>(g, x, w, pm, thr, bias, y, stream);
-    return launch_fwd<CfgM128, DGRAD>(g, x, w, pm, thr, bias, y, stream);
+// c_read / m: channels contracted over / produced.  w is the layer's [K][C][3][3] weight.
+int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, const float *x, const float *w, const float *pm,
+            float thr, const float *bias, float *y, void *ws, size_t ws_bytes, hipStream_t stream) {
+    const char *what = dgrad ? "cpg_conv2d_dgrad(3x3)" : "cpg_conv2d_fwd(3x3)";
+    const size_t need = pack_bytes(c_read, m);
+    if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
+    CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
+    float *wp = (float *)ws;
+    const int rows_c = pad_to(c_read, 4), Mp = pad_to(m, 128);
+    hipLaunchKernelGGL(k_c3_pack, dim3(stream_grid((int64_t)rows_c * 9 * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, K, C,
+                       rows_c, Mp, dgrad ? 1 : 0);
+    C3Geom g{N, c_read, H, W, m, Mp, 0, 0, 0};
+    if (W <= 16 && H <= 16 && m > 64) return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what);
+    if (m <= 64) return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what);
+    return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what);
 }
 
 }  // namespace
@@ -407,19 +425,19 @@ extern "C" int cpg_conv3x3_supported(const cpg_conv_desc *d) {
            (int64_t)d->C * d->H * d->W < (1ll << 31) && (int64_t)d->K * d->H * d->W < (1ll << 31);
 }
 
+size_t cpg_conv3x3_pack_workspace(const cpg_conv_desc *d) { return std::max(pack_bytes(d->C, d->K), pack_bytes(d->K, d->C)); }
+
 int cpg_conv3x3_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
-                    float *y, hipStream_t stream) {
+                    float *y, void *ws, size_t ws_bytes, hipStream_t stream) {
     CPG_REQUIRE(x && w && y, "cpg_conv2d_fwd: null pointer");
-    C3Geom g{d->N, d->C, d->H, d->W, d->K, d->C, 0, 0, 0};
-    return dispatch_fwd<false>(g, x, w, pm, thr, bias, y, stream);
+    return run_fwd(false, d->N, d->C, d->K, d->H, d->W, d->K, d->C, x, w, pm, thr, bias, y, ws, ws_bytes, stream);
 }
 
-int cpg_conv3x3_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx,
-                      hipStream_t stream) {
+int cpg_conv3x3_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx, void *ws,
+                      size_t ws_bytes, hipStream_t stream) {
     CPG_REQUIRE(gy && w && gx, "cpg_conv2d_dgrad: null pointer");
-    // reads gy (K channels), produces gx (C channels); weight dim-1 extent is still C
-    C3Geom g{d->N, d->K, d->H, d->W, d->C, d->C, 0, 0, 0};
-    return dispatch_fwd<true>(g, gy, w, pm, thr, nullptr, gx, stream);
+    // reads gy (K channels), produces gx (C channels)
+    return run_fwd(true, d->N, d->K, d->C, d->H, d->W, d->K, d->C, gy, w, pm, thr, nullptr, gx, ws, ws_bytes, stream);
 }
 
 // ---- wgrad host side -------------------------------------------------------------------------

@@ -460,9 +460,10 @@ void conv_wgrad_tiles(const ConvGeom &g, int &tiles_m, int &tiles_n) {
 // The specialised 3x3 kernels (conv3x3.hip) take over when they support the shape.
 extern "C" int cpg_conv3x3_supported(const cpg_conv_desc *d);
 int cpg_conv3x3_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
-                    float *y, hipStream_t stream);
-int cpg_conv3x3_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx,
-                      hipStream_t stream);
+                    float *y, void *ws, size_t ws_bytes, hipStream_t stream);
+int cpg_conv3x3_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx, void *ws,
+                      size_t ws_bytes, hipStream_t stream);
+size_t cpg_conv3x3_pack_workspace(const cpg_conv_desc *d);
 size_t cpg_conv3x3_wgrad_workspace(const cpg_conv_desc *d);
 int cpg_conv3x3_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
                       float *gw, float *gpm, void *ws, size_t ws_bytes, hipStream_t stream);
@@ -473,12 +474,13 @@ static inline bool use_c3_wgrad(const cpg_conv_desc *d) { return cpg_conv3x3_sup
 extern "C" size_t cpg_conv2d_workspace_bytes(const cpg_conv_desc *d) {
     ConvGeom g;
     if (make_geom(d, g) != CPG_OK) return 0;
-    if (use_c3_wgrad(d)) return cpg_conv3x3_wgrad_workspace(d);
+    const size_t pack = cpg_conv3x3_supported(d) ? cpg_conv3x3_pack_workspace(d) : 0;
+    if (use_c3_wgrad(d)) return std::max(pack, cpg_conv3x3_wgrad_workspace(d));
     int tm, tn, nsplit, per;
     conv_wgrad_tiles<CfgA>(g, tm, tn);
     const int64_t P = (int64_t)g.N * g.OH * g.OW;
     wgrad_plan((int64_t)tm * tn, (int)((P + CfgA::BK - 1) / CfgA::BK), nsplit, per);
-    return nsplit > 1 ? (size_t)nsplit * g.K * g.C * g.R * g.S * sizeof(float) : 0;
+    return std::max(pack, nsplit > 1 ? (size_t)nsplit * g.K * g.C * g.R * g.S * sizeof(float) : (size_t)0);
 }
 
 extern "C" int cpg_conv2d_fwd_generic(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr,
@@ -527,15 +529,13 @@ extern "C" int cpg_conv2d_dgrad_generic(const cpg_conv_desc *d, const float *gy,
 
 extern "C" int cpg_conv2d_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr,
                               const float *bias, float *y, void *ws, size_t ws_bytes, void *stream) {
-    (void)ws; (void)ws_bytes;
-    if (d && cpg_conv3x3_supported(d)) return cpg_conv3x3_fwd(d, x, w, pm, thr, bias, y, (hipStream_t)stream);
+    if (d && cpg_conv3x3_supported(d)) return cpg_conv3x3_fwd(d, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream);
     return cpg_conv2d_fwd_generic(d, x, w, pm, thr, bias, y, stream);
 }
 
 extern "C" int cpg_conv2d_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr,
                                 float *gx, void *ws, size_t ws_bytes, void *stream) {
-    (void)ws; (void)ws_bytes;
-    if (d && cpg_conv3x3_supported(d)) return cpg_conv3x3_dgrad(d, gy, w, pm, thr, gx, (hipStream_t)stream);
+    if (d && cpg_conv3x3_supported(d)) return cpg_conv3x3_dgrad(d, gy, w, pm, thr, gx, ws, ws_bytes, (hipStream_t)stream);
     return cpg_conv2d_dgrad_generic(d, gy, w, pm, thr, gx, stream);
 }
 

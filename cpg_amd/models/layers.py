@@ -76,9 +76,10 @@ class _MaskedConv2dFn(torch.autograd.Function):
             raise RuntimeError('SharableConv2d: kernel larger than padded input')
         y = torch.empty((d.N, d.K, oh, ow), dtype=torch.float32, device=x.device)
         L = _lib.lib()
+        ws, nbytes = _lib.workspace(L.cpg_conv2d_workspace_bytes(ctypes.byref(d)), x.device)
         rc = L.cpg_conv2d_fwd(ctypes.byref(d), _lib.dptr(x, name='input'), _lib.dptr(w, name='weight'),
                               _lib.dptr(p, name='piggymask'), float(thr), _lib.dptr(bias, name='bias'),
-                              _lib.dptr(y), None, 0, _lib.stream_ptr())
+                              _lib.dptr(y), _lib.dptr(ws), nbytes, _lib.stream_ptr())
         _lib.check('cpg_conv2d_fwd', rc)
         ctx.save_for_backward(x, w, p)
         ctx.desc, ctx.thr, ctx.has_bias = d, float(thr), bias is not None
@@ -92,16 +93,16 @@ class _MaskedConv2dFn(torch.autograd.Function):
         L = _lib.lib()
         s = _lib.stream_ptr()
         gx = gw = gpm = gb = None
+        ws, nbytes = _lib.workspace(L.cpg_conv2d_workspace_bytes(ctypes.byref(d)), x.device)
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             rc = L.cpg_conv2d_dgrad(ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr,
-                                    _lib.dptr(gx), None, 0, s)
+                                    _lib.dptr(gx), _lib.dptr(ws), nbytes, s)
             _lib.check('cpg_conv2d_dgrad', rc)
         if ctx.needs_input_grad[1] or (p is not None and ctx.needs_input_grad[2]) or (ctx.has_bias and ctx.needs_input_grad[3]):
             gw = torch.empty_like(w)
             gpm = None if p is None else torch.empty_like(p)
             gb = torch.empty(d.K, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            ws, nbytes = _lib.workspace(L.cpg_conv2d_workspace_bytes(ctypes.byref(d)), x.device)
             rc = L.cpg_conv2d_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), _lib.dptr(p), thr,
                                     _lib.dptr(gw), _lib.dptr(gpm), _lib.dptr(gb), _lib.dptr(ws), nbytes, s)
             _lib.check('cpg_conv2d_wgrad', rc)

@@ -19,8 +19,10 @@
  *     (reference: torch.ByteTensor masks, CPG_cifar100_main_normal.py:204).
  *   - `pm` is the real-valued piggymask (same shape as the weight) or NULL (task 1,
  *     CPG_cifar100_main_normal.py:263-270).  When non-NULL the effective weight is
- *     W * (pm > thr ? 1 : 0) -- models/layers.py:11-23,99-105 -- computed inside the
- *     kernels' LDS staging pass; it is never materialised in HBM.
+ *     W * (pm > thr ? 1 : 0) -- models/layers.py:11-23,99-105.  The linear and generic conv kernels
+ *     form it inside their LDS staging pass (never materialised); the 3x3 s1 p1 conv kernels stream it
+ *     from a K-major packed copy produced by a fused binarise+mask+transpose pass into the call's
+ *     workspace (conv weights are <= 9.4 MB per layer; the 411 MB linear weights are never copied).
  *   - Return value: 0 ok; <0 invalid argument / unsupported; CPG_E_KRANGE is rank-prune's
  *     "not enough weights" (reference: sys.exit(2), utils/prune.py:38-42);
  *     >= CPG_E_HIP_BASE is CPG_E_HIP_BASE + hipError_t.

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Per-layer microbenchmark of the masked conv / linear kernels through the C ABI (HIP events on the
+launch stream).  Prints TFLOP/s per (layer, pass).  Used for A/B work on kernel configurations and as
+the command profiled with rocprofv3 --pmc.
+
+    python tools/conv_bench.py [--batch 256] [--iters 5] [--only fwd,dgrad,wgrad] [--layers 3,7]
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cpg_amd import _lib                      # noqa: E402
+from cpg_amd.models.layers import _conv_desc  # noqa: E402
+
+# (name, Cin, Cout, H) of VGG16 @224 -- SURVEY.md section 8 table
+VGG = [('f0', 3, 64, 224), ('f3', 64, 64, 224), ('f7', 64, 128, 112), ('f10', 128, 128, 112), ('f14', 128, 256, 56),
+       ('f17', 256, 256, 56), ('f24', 256, 512, 28), ('f27', 512, 512, 28), ('f34', 512, 512, 14)]
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--only', default='fwd,dgrad,wgrad')
+    ap.add_argument('--layers', default='')
+    ap.add_argument('--pm', action='store_true')
+    a = ap.parse_args()
+    L = _lib.lib()
+    dev = 'cuda:0'
+    st = _lib.stream_ptr()
+    sel = set(a.layers.split(',')) if a.layers else None
+    print('%-6s %-6s %9s %9s' % ('layer', 'pass', 'ms', 'TFLOP/s'))
+    tot = {}
+    for name, C, K, H in VGG:
+        if sel and name not in sel:
+            continue
+        x = torch.randn(a.batch, C, H, H, device=dev)
+        w = torch.randn(K, C, 3, 3, device=dev) * 0.05
+        pm = torch.rand(K, C, 3, 3, device=dev) * 0.012 if a.pm else None
+        y = torch.empty(a.batch, K, H, H, device=dev)
+        gy = torch.randn(a.batch, K, H, H, device=dev)
+        gx = torch.empty_like(x)
+        gw = torch.empty_like(w)
+        gpm = torch.empty_like(w) if a.pm else None
+        d = _conv_desc(x.shape, w.shape, (1, 1), (1, 1), (1, 1), 1)
+        nws = L.cpg_conv2d_workspace_bytes(ctypes.byref(d))
+        ws, nb = _lib.workspace(nws, dev)
+        flops = 2.0 * a.batch * K * H * H * C * 9
+        P = _lib.dptr
+        runs = {'fwd': lambda: L.cpg_conv2d_fwd(ctypes.byref(d), P(x), P(w), P(pm), 5e-3, None, P(y), P(ws), nb, st),
+                'dgrad': lambda: L.cpg_conv2d_dgrad(ctypes.byref(d), P(gy), P(w), P(pm), 5e-3, P(gx), P(ws), nb, st),
+                'wgrad': lambda: L.cpg_conv2d_wgrad(ctypes.byref(d), P(x), P(gy), P(w), P(pm), 5e-3, P(gw), P(gpm), None, P(ws), nb, st)}
+        for k in a.only.split(','):
+            if k == 'dgrad' and name == 'f0':
+                continue
+            ms = timeit(runs[k], a.iters)
+            print('%-6s %-6s %9.3f %9.1f' % (name, k, ms, flops / ms / 1e9), flush=True)
+            t = tot.setdefault(k, [0.0, 0.0])
+            t[0] += ms
+            t[1] += flops
+    for k, (ms, fl) in tot.items():
+        print('TOTAL  %-6s %9.3f %9.1f' % (k, ms, fl / ms / 1e9))
+
+
+if __name__ == '__main__':
+    main()
