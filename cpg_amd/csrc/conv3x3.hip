@@ -39,6 +39,12 @@ __device__ __forceinline__ int opaque_mem(int v) {
     return v;
 }
 
+// uniform base + 32-bit per-lane BYTE offset: the shape LLVM folds into `global_load_dword v, v_off, s[base:base+1]`
+// (one VGPR of address per load instead of a 64-bit pair computed with VALU adds)
+__device__ __forceinline__ float ld_sv(const float *sbase, unsigned byte_off) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sbase) + byte_off);
+}
+
 struct C3Geom {
     int N, C, H, W, M;        // C: channels of the tensor being read, M: channels being produced
     int Mp;                   // row stride of the packed weights (M rounded up to 128)
@@ -245,27 +251,35 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
 
 // ------------------------------------------------------------------------------ wgrad
 // D[co][ci](tap) += sum_pix gy[co][pix] * x[ci][pix + tap offset]
+//
+// Staging map (zero per-element index arithmetic): wave `sub` (0..3) owns channels sub + 4*i, i < 16;
+// its 64 lanes own tile positions lane + 64*g.  A thread's global offset is a fixed per-(thread, g)
+// register plus wave-uniform scalars (unit origin, channel stride), its LDS address a fixed register
+// plus compile-time immediates.  The loads of unit u+1 are issued before the 288 MFMAs of unit u and
+// land in registers meanwhile.
 template <int TH_, int TW_>
 struct W3Cfg {
     static constexpr int TH = TH_, TW = TW_, NPIX = TH * TW;
     static_assert(TW % 2 == 0, "pixel pairs must not straddle rows");
     static constexpr int BMC = 64, BCI = 64;                    // block tile: 64 co x 64 ci, 2 x 2 waves
-    static constexpr int PH = TH + 2, PW = TW + 2;
-    static constexpr int PLANE = (PH * PW) | 1;                 // odd stride: conflict-free lane = channel reads
+    static constexpr int PH = TH + 2, PW = TW + 2, PHW = PH * PW;
+    static constexpr int PLANE = PHW | 1;                       // odd stride: conflict-free lane = channel reads
     static constexpr int LDG = NPIX | 1;
     static constexpr int G_ELEMS = BMC * LDG, X_ELEMS = BCI * PLANE;
     static constexpr int SMEM_FLOATS = G_ELEMS + X_ELEMS;
-    static constexpr int NG = (BMC * NPIX + 255) / 256, NX = (BCI * PH * PW + 255) / 256;
+    static constexpr int GP = (NPIX + 63) / 64, XP = (PHW + 63) / 64;      // 64-lane position groups
+    static constexpr int NI = 16;                                           // channels per wave
 };
 
 template <class Cfg>
 __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W, int M, int tiles_x, int tiles_y, int tiles_ci,
-                                                  int units_per_split, const float *__restrict__ x,
-                                                  const float *__restrict__ gy, float *__restrict__ part) {
+                                                     int units_per_split, const float *__restrict__ x,
+                                                     const float *__restrict__ gy, float *__restrict__ part) {
     __shared__ float smem[Cfg::SMEM_FLOATS];
     float *gs = smem, *xs = smem + Cfg::G_ELEMS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wco = wave >> 1, wci = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave id, provably uniform
+    const int wco = sub >> 1, wci = sub & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int tci = blockIdx.x % tiles_ci, tco = blockIdx.x / tiles_ci;
     const int co0 = tco * Cfg::BMC, ci0 = tci * Cfg::BCI;
@@ -274,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
     const int total_units = N * units_per_img;
     const int u0 = blockIdx.y * units_per_split;
     const int u1 = min(total_units, u0 + units_per_split);
+    const int co_lim = M - co0 - sub, ci_lim = C - ci0 - sub;           // channel sub + 4*i is valid iff 4*i < lim
 
     f32x16 acc[9];
 #pragma unroll
@@ -281,69 +296,104 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
 
-    // Staging of one K unit: gy tile [64][NPIX] and x patch [64][PH*PW], element e = tid + 256*i.  No
-    // register prefetch across the MFMA phase (9 accumulators = 144 registers leave no room for it): the
-    // load -> LDS phase of one block overlaps the MFMA phase of the other block resident on the CU.
-    auto stage = [&](int u) {
-        const int n = u / units_per_img, r = u - n * units_per_img;
-        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+    // fixed per-thread position descriptors
+    unsigned g_off[Cfg::GP], g_rc[Cfg::GP];     // offset inside the image relative to the tile origin; (row << 8) | col
+    unsigned x_off[Cfg::XP], x_rc[Cfg::XP];     // same for the patch, relative to (h0-1, w0-1), biased by +W+1 to stay >= 0
+#pragma unroll
+    for (int g = 0; g < Cfg::GP; ++g) {
+        const int pix = lane + 64 * g, r = pix / Cfg::TW, c = pix % Cfg::TW;
+        g_off[g] = 4u * (unsigned)(sub * HW + r * W + c);            // bytes
+        g_rc[g] = pix < Cfg::NPIX ? (r << 8) | c : 0xFFFFu;
+    }
+#pragma unroll
+    for (int g = 0; g < Cfg::XP; ++g) {
+        const int q = lane + 64 * g, r = q / Cfg::PW, c = q % Cfg::PW;
+        x_off[g] = 4u * (unsigned)(sub * HW + r * W + c);
+        x_rc[g] = q < Cfg::PHW ? (r << 8) | c : 0xFFFFu;
+    }
+
+    float rg[Cfg::GP][Cfg::NI], rx[Cfg::XP][Cfg::NI];
+    unsigned gmask = 0, xmask = 0;              // per-group position validity of the unit held in rg / rx
+    auto fetch_g = [&](int u) {
+        const int n = u / units_per_img, rr = u - n * units_per_img;
+        const int ty = rr / tiles_x, tx = rr - ty * tiles_x;
         const int h0 = ty * Cfg::TH, w0 = tx * Cfg::TW;
-        const float *gimg = gy + (int64_t)n * M * HW;
-        const float *ximg = x + (int64_t)n * C * HW;
-        // batches of <= SB loads in flight, each batch stored to LDS before the next is issued: keeps the
-        // transient (data + 64-bit addresses) inside the ~100 registers the 9 accumulators leave free
-        constexpr int SB = 16;
+        gmask = 0;
+        // gy tile.  Address = wave-uniform base (SGPR pair) + 32-bit per-lane offset; lanes that must not
+        // read (outside the image / past the last channel) are pointed at pixel (h0, w0) of a valid channel.
+        const float *gimg = gy + ((int64_t)n * M + co0) * HW + h0 * W + w0;
 #pragma unroll
-        for (int b0 = 0; b0 < Cfg::NG; b0 += SB) {
-            const int t = opaque_mem(tid);
-            float rg[SB];
+        for (int g = 0; g < Cfg::GP; ++g) {
+            const int r = g_rc[g] >> 8, c = g_rc[g] & 255;
+            const bool pv = g_rc[g] != 0xFFFFu && h0 + r < H && w0 + c < W;
+            gmask |= (pv ? 1u : 0u) << g;
 #pragma unroll
-            for (int i = b0; i < b0 + SB && i < Cfg::NG; ++i) {
-                const int e = t + 256 * i;
-                const int row = e / Cfg::NPIX, pix = e - row * Cfg::NPIX;
-                const int oh = h0 + pix / Cfg::TW, ow = w0 + pix % Cfg::TW;
-                const bool ok = row < Cfg::BMC && co0 + row < M && oh < H && ow < W;
-                const float v = gimg[ok ? (int64_t)(co0 + row) * HW + oh * W + ow : 0];     // unconditional load
-                rg[i - b0] = ok ? v : 0.0f;
+            for (int i = 0; i < Cfg::NI; ++i) {
+                const bool cv = 4 * i < co_lim;                                       // wave-uniform
+                const float *base = gimg + (int64_t)(cv ? 4 * i : 0) * HW;            // uniform
+                rg[g][i] = ld_sv(base, (pv && cv) ? g_off[g] : 0u);
             }
+        }
+    };
+    auto fetch_x = [&](int u) {
+        const int n = u / units_per_img, rr = u - n * units_per_img;
+        const int ty = rr / tiles_x, tx = rr - ty * tiles_x;
+        const int h0 = ty * Cfg::TH, w0 = tx * Cfg::TW;
+        xmask = 0;
+        // x patch, origin (h0 - 1, w0 - 1); patch element (1, 1) = pixel (h0, w0) is always inside the image
+        const float *ximg = x + ((int64_t)n * C + ci0) * HW + (int64_t)(h0 - 1) * W + (w0 - 1);
+        const unsigned safe = 4u * (unsigned)(W + 1);
 #pragma unroll
-            for (int i = b0; i < b0 + SB && i < Cfg::NG; ++i) {
-                const int e = t + 256 * i;
-                const int row = e / Cfg::NPIX, pix = e - row * Cfg::NPIX;
-                if (row < Cfg::BMC) gs[row * Cfg::LDG + pix] = rg[i - b0];
+        for (int g = 0; g < Cfg::XP; ++g) {
+            const int r = x_rc[g] >> 8, c = x_rc[g] & 255;
+            const int gh = h0 - 1 + r, gw = w0 - 1 + c;
+            const bool pv = x_rc[g] != 0xFFFFu && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            xmask |= (pv ? 1u : 0u) << g;
+#pragma unroll
+            for (int i = 0; i < Cfg::NI; ++i) {
+                const bool cv = 4 * i < ci_lim;
+                const float *base = ximg + (int64_t)(cv ? 4 * i : 0) * HW;
+                rx[g][i] = ld_sv(base, (pv && cv) ? x_off[g] : safe);
+            }
+        }
+    };
+    auto put = [&]() {
+#pragma unroll
+        for (int g = 0; g < Cfg::GP; ++g) {
+            if (g_rc[g] != 0xFFFFu) {
+                const bool pv = (gmask >> g) & 1u;
+                float *dst = gs + sub * Cfg::LDG + lane + 64 * g;
+#pragma unroll
+                for (int i = 0; i < Cfg::NI; ++i) dst[4 * i * Cfg::LDG] = (pv && 4 * i < co_lim) ? rg[g][i] : 0.0f;
             }
         }
 #pragma unroll
-        for (int b0 = 0; b0 < Cfg::NX; b0 += SB) {
-            const int t = opaque_mem(tid);
-            float rx[SB];
+        for (int g = 0; g < Cfg::XP; ++g) {
+            if (x_rc[g] != 0xFFFFu) {
+                const bool pv = (xmask >> g) & 1u;
+                float *dst = xs + sub * Cfg::PLANE + lane + 64 * g;
 #pragma unroll
-            for (int i = b0; i < b0 + SB && i < Cfg::NX; ++i) {
-                const int e = t + 256 * i;
-                const int row = e / (Cfg::PH * Cfg::PW), rem = e - row * (Cfg::PH * Cfg::PW);
-                const int pr = rem / Cfg::PW, pc = rem - pr * Cfg::PW;
-                const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
-                const bool ok = row < Cfg::BCI && ci0 + row < C && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-                const float v = ximg[ok ? (int64_t)(ci0 + row) * HW + gh * W + gw : 0];
-                rx[i - b0] = ok ? v : 0.0f;
-            }
-#pragma unroll
-            for (int i = b0; i < b0 + SB && i < Cfg::NX; ++i) {
-                const int e = t + 256 * i;
-                const int row = e / (Cfg::PH * Cfg::PW), rem = e - row * (Cfg::PH * Cfg::PW);
-                if (row < Cfg::BCI) xs[row * Cfg::PLANE + rem] = rx[i - b0];
+                for (int i = 0; i < Cfg::NI; ++i) dst[4 * i * Cfg::PLANE] = (pv && 4 * i < ci_lim) ? rx[g][i] : 0.0f;
             }
         }
     };
 
     const int a_base = (wco * 32 + li) * Cfg::LDG + lh;                 // gy[co][pix], pix = 2s + lh
     const int b_base = (wci * 32 + li) * Cfg::PLANE + lh;               // x[ci][(r+kh)*PW + c + kw], c = 2s' + lh
+    // The 32 patch loads of unit u+1 fly during the MFMAs of unit u; the 16 gy loads are issued after them
+    // (9 accumulators + 48 staged values + operands do not fit 256 registers without spilling) and overlap
+    // the barrier wait and the other resident block's MFMAs.
+    if (u0 < u1) {
+        fetch_x(u0);
+        fetch_g(u0);
+    }
     for (int u = u0; u < u1; ++u) {
         __syncthreads();                 // previous unit's operand reads are done
-        stage(u);
+        put();
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < Cfg::TH; ++r) {
+        if (u + 1 < u1) fetch_x(u + 1);
+#pragma unroll 1
+        for (int r = 0; r < Cfg::TH; ++r) {          // not unrolled: keeps the operand-read window (and VGPRs) small
 #pragma unroll
             for (int c2 = 0; c2 < Cfg::TW / 2; ++c2) {
                 const float a = gs[a_base + r * Cfg::TW + 2 * c2];
@@ -354,6 +404,7 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
                 }
             }
         }
+        if (u + 1 < u1) fetch_g(u + 1);
     }
     // partial result: part[split][co][ci][tap]
     float *dst = part + (int64_t)blockIdx.y * M * C * 9;
@@ -382,6 +433,8 @@ __global__ __launch_bounds__(256) void k_c3_wgrad_reduce(const float *__restrict
 using CfgM128 = C3Cfg<128, 4, 32, 2, 2, 4, 3>;     // >= 128 output channels, wide images
 using CfgM64 = C3Cfg<64, 8, 32, 1, 4, 4, 3>;       // <= 64 output channels (VGG 224x224 layers)
 using CfgS16 = C3Cfg<128, 14, 16, 4, 1, 4, 2>;     // 14x14 (and <= 16 wide) feature maps: whole image, 7 fragments
+using CfgD128 = C3Cfg<128, 4, 56, 4, 1, 4, 2>;     // 56 / 112 wide maps: 4 x 56 = 7 fragments per wave, zero tile waste
+using CfgD64 = C3Cfg<64, 8, 56, 2, 2, 4, 2>;       // same for <= 64 output channels
 
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 // packed-weight workspace: [roundup(C_read, 4) * 9][roundup(M, 128)] floats
@@ -412,6 +465,10 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
                        rows_c, Mp, dgrad ? 1 : 0);
     C3Geom g{N, c_read, H, W, m, Mp, 0, 0, 0};
     if (W <= 16 && H <= 16 && m > 64) return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what);
+    if (W % 56 == 0 && W % 32 != 0) {       // 56, 112, 168 ...: a 32-wide tile would waste 12.5 % of the MFMAs
+        if (m > 64) return launch_fwd<CfgD128>(g, x, wp, bias, y, stream, what);
+        return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what);
+    }
     if (m <= 64) return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what);
     return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what);
 }
@@ -464,13 +521,13 @@ W3Plan w3_plan(const cpg_conv_desc *d) {
     p.ws_bytes = (size_t)p.nsplit * d->K * d->C * 9 * sizeof(float);
     return p;
 }
-using W3Wide = W3Cfg<2, 32>;      // W >= 24
-using W3Mid = W3Cfg<7, 14>;       // 14 / 28 / 56 wide feature maps with H % 7 == 0: zero waste, 1.47x halo
+using W3Wide = W3Cfg<2, 28>;      // 112 / 224 wide feature maps: long contiguous rows, 2 x 64-lane patch groups exactly
+using W3Mid = W3Cfg<4, 14>;       // 14 / 28 / 56 wide feature maps: zero column waste
 using W3Nar = W3Cfg<4, 16>;       // everything else that is narrow
 inline int w3_pick(const cpg_conv_desc *d) {
-    if (d->W % 14 == 0 && d->W <= 56 && d->H % 7 == 0) return 1;
-    if (d->W < 24) return 2;
-    return 0;
+    if (d->W % 28 == 0 && d->W >= 112) return 0;
+    if (d->W % 14 == 0) return 1;
+    return 2;
 }
 }  // namespace
 
