@@ -152,6 +152,20 @@ class OraclePruner:
         for n, _ in self.model.masked_layers():
             self.owners[n] = ops.claim_free(self.owners[n], self.cur)
 
+    def route_torch(self):
+        """Same routing with torch-CPU ops, statement for statement as utils/prune.py:195-211 runs on a
+        CPU host (multi-threaded elementwise kernels) -- used by the timed CPU baseline."""
+        for n, m in self.model.masked_layers():
+            owner = torch.from_numpy(self.owners[n])
+            if m.weight.grad is not None:
+                m.weight.grad.data.add_(m.weight.data, alpha=self.wd)
+                m.weight.grad.data[owner.ne(self.cur)] = 0
+            if m.piggymask is not None and m.piggymask.grad is not None:
+                if self.mode == 'finetune':
+                    m.piggymask.grad.data[owner.eq(0) | owner.ge(self.cur)] = 0
+                elif self.mode == 'prune':
+                    m.piggymask.grad.data.fill_(0)
+
     def route(self):                                    # do_weight_decay_and_make_grads_zero
         for n, m in self.model.masked_layers():
             if m.weight.grad is None:
@@ -180,13 +194,16 @@ class OraclePruner:
         return ops.sparsity([self.owners[n] for n, _ in self.model.masked_layers()], self.inference_idx)
 
 
-def train_step(model, pruner, optimizer, x, target, prune_step=None):
+def train_step(model, pruner, optimizer, x, target, prune_step=None, torch_routing=False):
     """One iteration of utils/manager.py:50-75.  Returns (logits, loss, prune_ratio or None)."""
     optimizer.zero_grad()
     out = model(x)
     loss = F.cross_entropy(out, target)
     loss.backward()
-    pruner.route()
+    if torch_routing:
+        pruner.route_torch()
+    else:
+        pruner.route()
     optimizer.step()
     ratio = None
     if pruner.mode == 'prune':
