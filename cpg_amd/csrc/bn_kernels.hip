@@ -1,0 +1,352 @@
+// Fused BatchNorm2d (+ ReLU) forward / backward for NCHW fp32 -- SURVEY.md section 8(f) item 2: the
+// BN -> ReLU pairs that follow every masked conv in the VGG topologies (models/vgg.py:137-141).
+// All four kernels are HBM-bound streaming passes (16 B per lane):
+//
+//   stats      : 1 read            per-(channel, slice) sum / sum-of-squares in fp64, fixed-order finalize
+//                                  (mean, biased var, invstd; running stats updated in the same kernel)
+//   apply      : 1 read + 1 write  y = max(0, (x - mean) * invstd * gamma + beta)
+//   bwd reduce : 2 reads           sum(g), sum(g * xhat) with g = gy * [y > 0]; the ReLU mask is RECOMPUTED
+//                                  from x (same expression as apply), so y is never re-read
+//   bwd apply  : 2 reads + 1 write dx = (g - mean(g) - xhat * mean(g * xhat)) * invstd * gamma
+//
+// i.e. 3 passes forward and 5 backward over the activation, against 5 + 8 for the stock
+// BatchNorm -> ReLU(inplace) pair (and MIOpen's BN forward itself ran ~4x off its roofline here).
+// Two-stage reductions are deterministic (no float atomics): results do not depend on block scheduling.
+#include "cpg_common.h"
+
+using namespace cpg;
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct BnDims {
+    int N, C, HW;
+    int slices;          // reduction slices per channel (over images)
+    int imgs_per_slice;
+};
+
+__device__ __forceinline__ float bn_affine(float x, float mean, float invstd, float gamma, float beta) {
+    return (x - mean) * invstd * gamma + beta;
+}
+
+__device__ __forceinline__ double block_sum(double v, double *red) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];       // fixed order
+}
+
+// Walk channel c of images [n0, n1) with all 256 threads busy whatever HW is: the (image, pixel) pairs of
+// the slice are flattened, FLUSH consecutive visits are summed in fp32 and then folded into fp64.
+template <class F>
+__device__ __forceinline__ void walk_channel(const BnDims &d, int c, int n0, int n1, bool vec, F &&f /* f(offset, is_vec4) */) {
+    if (vec) {
+        const int q = d.HW >> 2;
+        const int64_t total = (int64_t)(n1 - n0) * q;
+        for (int64_t i = threadIdx.x; i < total; i += kThreads) {
+            const int n = n0 + (int)(i / q), j = (int)(i % q);
+            f(((int64_t)n * d.C + c) * d.HW + 4 * j);
+        }
+    } else {
+        const int64_t total = (int64_t)(n1 - n0) * d.HW;
+        for (int64_t i = threadIdx.x; i < total; i += kThreads) {
+            const int n = n0 + (int)(i / d.HW), j = (int)(i % d.HW);
+            f(((int64_t)n * d.C + c) * d.HW + j);
+        }
+    }
+}
+
+// grid (C, slices): partial[c][slice] = {sum, sumsq} over images [s*ips, (s+1)*ips)
+__global__ __launch_bounds__(kThreads) void k_bn_stats(const float *__restrict__ x, BnDims d, double *__restrict__ partial) {
+    __shared__ double red[4];
+    const int c = blockIdx.x, s = blockIdx.y;
+    const int n0 = s * d.imgs_per_slice, n1 = min(d.N, n0 + d.imgs_per_slice);
+    double ds = 0.0, dss = 0.0;
+    float fs = 0.f, fss = 0.f;
+    int cnt = 0;
+    const bool vec = (d.HW & 3) == 0 && (((uintptr_t)x) & 15) == 0;
+    walk_channel(d, c, n0, n1, vec, [&](int64_t off) {
+        if (vec) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + off);
+            fs += (v.x + v.y) + (v.z + v.w);
+            fss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        } else {
+            const float v = x[off];
+            fs += v;
+            fss += v * v;
+        }
+        if (++cnt == 32) {          // bound the fp32 partial to <= 128 terms
+            ds += (double)fs; dss += (double)fss; fs = 0.f; fss = 0.f; cnt = 0;
+        }
+    });
+    ds += (double)fs;
+    dss += (double)fss;
+    const double ts = block_sum(ds, red);
+    const double tss = block_sum(dss, red);
+    if (threadIdx.x == 0) {
+        partial[((int64_t)c * d.slices + s) * 2 + 0] = ts;
+        partial[((int64_t)c * d.slices + s) * 2 + 1] = tss;
+    }
+}
+
+// one thread per channel: fixed-order merge, mean / biased var / invstd, running statistics
+// (torch.nn.BatchNorm2d semantics: running_var uses the unbiased variance, momentum m)
+__global__ void k_bn_finalize(const double *__restrict__ partial, BnDims d, float eps, float momentum, float *__restrict__ mean,
+                              float *__restrict__ invstd, float *__restrict__ running_mean, float *__restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < d.slices; ++k) {
+        s += partial[((int64_t)c * d.slices + k) * 2 + 0];
+        ss += partial[((int64_t)c * d.slices + k) * 2 + 1];
+    }
+    const double n = (double)d.N * d.HW;
+    const double m = s / n;
+    double var = ss / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean != nullptr) {
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+
+// GROUP threads (a whole block, or one wave for small feature maps) own one (n, c) plane at a time, so the
+// four per-channel scalars sit in registers and every access is a contiguous 16 B per lane.
+template <bool RELU, int GROUP>
+__global__ __launch_bounds__(kThreads) void k_bn_apply(const float *__restrict__ x, float *__restrict__ y, BnDims d,
+                                                       const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta) {
+    const int64_t planes = (int64_t)d.N * d.C;
+    const bool vec = (d.HW & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 15) == 0;
+    const int gl = threadIdx.x % GROUP;
+    const int64_t g0 = (int64_t)blockIdx.x * (kThreads / GROUP) + threadIdx.x / GROUP;
+    const int64_t gstride = (int64_t)gridDim.x * (kThreads / GROUP);
+    for (int64_t pl = g0; pl < planes; pl += gstride) {
+        const int c = (int)(pl % d.C);
+        const float m = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
+        const float *p = x + pl * d.HW;
+        float *q = y + pl * d.HW;
+        if (vec) {
+            for (int i = gl; i < d.HW / 4; i += GROUP) {
+                float4 v = reinterpret_cast<const float4 *>(p)[i];
+                v.x = bn_affine(v.x, m, is, g, b);
+                v.y = bn_affine(v.y, m, is, g, b);
+                v.z = bn_affine(v.z, m, is, g, b);
+                v.w = bn_affine(v.w, m, is, g, b);
+                if (RELU) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                reinterpret_cast<float4 *>(q)[i] = v;
+            }
+        } else {
+            for (int i = gl; i < d.HW; i += GROUP) {
+                float v = bn_affine(p[i], m, is, g, b);
+                q[i] = RELU ? fmaxf(v, 0.f) : v;
+            }
+        }
+    }
+}
+
+// grid (C, slices): partial[c][slice] = {sum g, sum g*xhat}
+template <bool RELU>
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_reduce(const float *__restrict__ x, const float *__restrict__ gy, BnDims d,
+                                                            const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            double *__restrict__ partial) {
+    __shared__ double red[4];
+    const int c = blockIdx.x, s = blockIdx.y;
+    const int n0 = s * d.imgs_per_slice, n1 = min(d.N, n0 + d.imgs_per_slice);
+    const float m = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+    double dsg = 0.0, dsgx = 0.0;
+    float sg = 0.f, sgx = 0.f;
+    int cnt = 0;
+    const bool vec = (d.HW & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)gy) & 15) == 0;
+    auto visit = [&](float xv, float gv) {
+        if (RELU && !(bn_affine(xv, m, is, ga, be) > 0.f)) gv = 0.f;
+        sg += gv;
+        sgx += gv * ((xv - m) * is);
+    };
+    walk_channel(d, c, n0, n1, vec, [&](int64_t off) {
+        if (vec) {
+            const float4 xv = *reinterpret_cast<const float4 *>(x + off);
+            const float4 gv = *reinterpret_cast<const float4 *>(gy + off);
+            visit(xv.x, gv.x); visit(xv.y, gv.y); visit(xv.z, gv.z); visit(xv.w, gv.w);
+        } else {
+            visit(x[off], gy[off]);
+        }
+        if (++cnt == 32) {
+            dsg += (double)sg; dsgx += (double)sgx; sg = 0.f; sgx = 0.f; cnt = 0;
+        }
+    });
+    dsg += (double)sg;
+    dsgx += (double)sgx;
+    const double t0 = block_sum(dsg, red);
+    const double t1 = block_sum(dsgx, red);
+    if (threadIdx.x == 0) {
+        partial[((int64_t)c * d.slices + s) * 2 + 0] = t0;
+        partial[((int64_t)c * d.slices + s) * 2 + 1] = t1;
+    }
+}
+
+// one thread per channel: dgamma = sum g*xhat, dbeta = sum g; coefficients for the apply pass
+__global__ void k_bn_bwd_finalize(const double *__restrict__ partial, BnDims d, float *__restrict__ dgamma,
+                                  float *__restrict__ dbeta, float *__restrict__ coef /* [C][2]: mean(g), mean(g*xhat) */) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.C) return;
+    double sg = 0.0, sgx = 0.0;
+    for (int k = 0; k < d.slices; ++k) {
+        sg += partial[((int64_t)c * d.slices + k) * 2 + 0];
+        sgx += partial[((int64_t)c * d.slices + k) * 2 + 1];
+    }
+    const double n = (double)d.N * d.HW;
+    dbeta[c] = (float)sg;
+    dgamma[c] = (float)sgx;
+    coef[2 * c + 0] = (float)(sg / n);
+    coef[2 * c + 1] = (float)(sgx / n);
+}
+
+// TRAIN: dx = (g - mean(g) - xhat * mean(g xhat)) * invstd * gamma ; EVAL (fixed statistics): dx = g * invstd * gamma
+template <bool RELU, bool TRAIN, int GROUP>
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(const float *__restrict__ x, const float *__restrict__ gy,
+                                                           float *__restrict__ gx, BnDims d, const float *__restrict__ mean,
+                                                           const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, const float *__restrict__ coef) {
+    const int64_t planes = (int64_t)d.N * d.C;
+    const bool vec = (d.HW & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)gy) & 15) == 0 && (((uintptr_t)gx) & 15) == 0;
+    const int gl = threadIdx.x % GROUP;
+    const int64_t g0 = (int64_t)blockIdx.x * (kThreads / GROUP) + threadIdx.x / GROUP;
+    const int64_t gstride = (int64_t)gridDim.x * (kThreads / GROUP);
+    for (int64_t pl = g0; pl < planes; pl += gstride) {
+        const int c = (int)(pl % d.C);
+        const float m = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+        const float mg = TRAIN ? coef[2 * c] : 0.f, mgx = TRAIN ? coef[2 * c + 1] : 0.f;
+        const float scale = is * ga;
+        const int64_t off = pl * d.HW;
+        auto one = [&](float xv, float gv) {
+            if (RELU && !(bn_affine(xv, m, is, ga, be) > 0.f)) gv = 0.f;
+            return TRAIN ? (gv - mg - ((xv - m) * is) * mgx) * scale : gv * scale;
+        };
+        if (vec) {
+            for (int i = gl; i < d.HW / 4; i += GROUP) {
+                const float4 xv = reinterpret_cast<const float4 *>(x + off)[i];
+                const float4 gv = reinterpret_cast<const float4 *>(gy + off)[i];
+                float4 r = {one(xv.x, gv.x), one(xv.y, gv.y), one(xv.z, gv.z), one(xv.w, gv.w)};
+                reinterpret_cast<float4 *>(gx + off)[i] = r;
+            }
+        } else {
+            for (int i = gl; i < d.HW; i += GROUP) gx[off + i] = one(x[off + i], gy[off + i]);
+        }
+    }
+}
+
+int make_dims(int N, int C, int HW, BnDims &d) {
+    CPG_REQUIRE(N > 0 && C > 0 && HW > 0, "bn: non-positive dimension");
+    d.N = N; d.C = C; d.HW = HW;
+    // enough (channel, slice) blocks to fill the chip ~4x, at least one image per slice
+    int want = (4 * kCUs + C - 1) / C;
+    if (want > N) want = N;
+    if (want < 1) want = 1;
+    d.imgs_per_slice = (N + want - 1) / want;
+    d.slices = (N + d.imgs_per_slice - 1) / d.imgs_per_slice;
+    return CPG_OK;
+}
+
+// small feature maps: one wave per plane (4 planes per block); otherwise a block per plane
+inline bool wave_planes(const BnDims &d) { return d.HW < 4096; }
+unsigned plane_grid(const BnDims &d) {
+    int64_t groups = (int64_t)d.N * d.C;
+    if (wave_planes(d)) groups = (groups + 3) / 4;
+    const int64_t cap = (int64_t)kCUs * 16;
+    return (unsigned)(groups < cap ? groups : cap);
+}
+template <bool RELU>
+void launch_apply(const BnDims &d, const float *x, float *y, const float *mean, const float *invstd, const float *gamma,
+                  const float *beta, hipStream_t stream) {
+    if (wave_planes(d))
+        hipLaunchKernelGGL((k_bn_apply<RELU, 64>), dim3(plane_grid(d)), dim3(kThreads), 0, stream, x, y, d, mean, invstd, gamma, beta);
+    else
+        hipLaunchKernelGGL((k_bn_apply<RELU, 256>), dim3(plane_grid(d)), dim3(kThreads), 0, stream, x, y, d, mean, invstd, gamma, beta);
+}
+template <bool RELU, bool TRAIN>
+void launch_bwd_apply(const BnDims &d, const float *x, const float *gy, float *gx, const float *mean, const float *invstd,
+                      const float *gamma, const float *beta, const float *coef, hipStream_t stream) {
+    if (wave_planes(d))
+        hipLaunchKernelGGL((k_bn_bwd_apply<RELU, TRAIN, 64>), dim3(plane_grid(d)), dim3(kThreads), 0, stream, x, gy, gx, d, mean, invstd, gamma, beta, coef);
+    else
+        hipLaunchKernelGGL((k_bn_bwd_apply<RELU, TRAIN, 256>), dim3(plane_grid(d)), dim3(kThreads), 0, stream, x, gy, gx, d, mean, invstd, gamma, beta, coef);
+}
+
+}  // namespace
+
+extern "C" size_t cpg_bn_workspace_bytes(int32_t N, int32_t C, int32_t HW) {
+    BnDims d;
+    if (make_dims(N, C, HW, d) != CPG_OK) return 0;
+    return (size_t)C * d.slices * 2 * sizeof(double) + (size_t)C * 2 * sizeof(float);
+}
+
+// training forward: batch statistics (mean / invstd out, running stats updated in place when given), then y
+extern "C" int cpg_bn_relu_fwd_train(const float *x, const float *gamma, const float *beta, float eps, float momentum,
+                                     float *running_mean, float *running_var, float *mean, float *invstd, float *y, int32_t N,
+                                     int32_t C, int32_t HW, int32_t relu, void *ws, size_t ws_bytes, void *stream_v) {
+    BnDims d;
+    int rc = make_dims(N, C, HW, d);
+    if (rc) return rc;
+    CPG_REQUIRE(x && gamma && beta && mean && invstd && y && ws, "cpg_bn_relu_fwd_train: null pointer");
+    CPG_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "cpg_bn_relu_fwd_train: running stats must come as a pair");
+    if (ws_bytes < cpg_bn_workspace_bytes(N, C, HW)) return fail(CPG_E_WORKSPACE, "cpg_bn_relu_fwd_train: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_v;
+    double *partial = (double *)ws;
+    hipLaunchKernelGGL(k_bn_stats, dim3(C, d.slices), dim3(kThreads), 0, stream, x, d, partial);
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 63) / 64), dim3(64), 0, stream, partial, d, eps, momentum, mean, invstd,
+                       running_mean, running_var);
+    if (relu) launch_apply<true>(d, x, y, mean, invstd, gamma, beta, stream);
+    else launch_apply<false>(d, x, y, mean, invstd, gamma, beta, stream);
+    CPG_CHECK_LAUNCH("cpg_bn_relu_fwd_train");
+    return CPG_OK;
+}
+
+// inference forward with given statistics (mean, invstd = 1/sqrt(running_var + eps) prepared by the caller)
+extern "C" int cpg_bn_relu_fwd_eval(const float *x, const float *gamma, const float *beta, const float *mean,
+                                    const float *invstd, float *y, int32_t N, int32_t C, int32_t HW, int32_t relu,
+                                    void *stream_v) {
+    BnDims d;
+    int rc = make_dims(N, C, HW, d);
+    if (rc) return rc;
+    CPG_REQUIRE(x && gamma && beta && mean && invstd && y, "cpg_bn_relu_fwd_eval: null pointer");
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (relu) launch_apply<true>(d, x, y, mean, invstd, gamma, beta, stream);
+    else launch_apply<false>(d, x, y, mean, invstd, gamma, beta, stream);
+    CPG_CHECK_LAUNCH("cpg_bn_relu_fwd_eval");
+    return CPG_OK;
+}
+
+// backward of y = [relu](bn(x)); train != 0: batch statistics were used (full BN gradient), else fixed statistics
+extern "C" int cpg_bn_relu_bwd(const float *x, const float *gy, const float *gamma, const float *beta, const float *mean,
+                               const float *invstd, float *gx, float *dgamma, float *dbeta, int32_t N, int32_t C, int32_t HW,
+                               int32_t relu, int32_t train, void *ws, size_t ws_bytes, void *stream_v) {
+    BnDims d;
+    int rc = make_dims(N, C, HW, d);
+    if (rc) return rc;
+    CPG_REQUIRE(x && gy && gamma && beta && mean && invstd && gx && dgamma && dbeta && ws, "cpg_bn_relu_bwd: null pointer");
+    if (ws_bytes < cpg_bn_workspace_bytes(N, C, HW)) return fail(CPG_E_WORKSPACE, "cpg_bn_relu_bwd: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_v;
+    double *partial = (double *)ws;
+    float *coef = (float *)(partial + (size_t)C * d.slices * 2);
+    if (relu)
+        hipLaunchKernelGGL(k_bn_bwd_reduce<true>, dim3(C, d.slices), dim3(kThreads), 0, stream, x, gy, d, mean, invstd, gamma, beta, partial);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_reduce<false>, dim3(C, d.slices), dim3(kThreads), 0, stream, x, gy, d, mean, invstd, gamma, beta, partial);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 63) / 64), dim3(64), 0, stream, partial, d, dgamma, dbeta, coef);
+    if (relu && train) launch_bwd_apply<true, true>(d, x, gy, gx, mean, invstd, gamma, beta, coef, stream);
+    else if (relu) launch_bwd_apply<true, false>(d, x, gy, gx, mean, invstd, gamma, beta, coef, stream);
+    else if (train) launch_bwd_apply<false, true>(d, x, gy, gx, mean, invstd, gamma, beta, coef, stream);
+    else launch_bwd_apply<false, false>(d, x, gy, gx, mean, invstd, gamma, beta, coef, stream);
+    CPG_CHECK_LAUNCH("cpg_bn_relu_bwd");
+    return CPG_OK;
+}

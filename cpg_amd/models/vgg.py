@@ -3,12 +3,14 @@
 Module order, names (`features.{0,3,7,...}`, `classifiers.{i}`), parameter shapes and the
 initialisation sequence equal the reference's, so owner-mask dictionary keys, state_dict keys and
 `torch.manual_seed(s)` initial weights line up with it (pinned by tests/golden/topology.json and
-first_forward_vgg*.npz).  The torchvision-style vgg11..vgg19 factories of the reference are broken
+first_forward_vgg*.npz).  `features` is an nn.Sequential subclass (FusedSequential) that registers the very
+same modules but evaluates each BatchNorm2d -> ReLU pair with the fused HIP kernels.  The torchvision-style vgg11..vgg19 factories of the reference are broken
 upstream (they omit a required argument) and unused; they are not provided.
 """
 import torch.nn as nn
 
 from . import layers as nl
+from .fused_bn import FusedSequential
 
 __all__ = ['VGG', 'View', 'custom_vgg', 'custom_vgg_cifar100', 'make_layers', 'make_layers_cifar100']
 
@@ -46,7 +48,7 @@ def make_layers_cifar100(cfg, network_width_multiplier, batch_norm=False, groups
     mods += [View(-1, int(512 * m)),
              nl.SharableLinear(int(512 * m), int(4096 * m)), nn.ReLU(True),
              nl.SharableLinear(int(4096 * m), int(4096 * m)), nn.ReLU(True)]
-    return nn.Sequential(*mods)
+    return FusedSequential(*mods)
 
 
 def make_layers(cfg, network_width_multiplier, batch_norm=False, groups=1):
@@ -56,7 +58,7 @@ def make_layers(cfg, network_width_multiplier, batch_norm=False, groups=1):
     mods += [View(-1, int(512 * m) * 7 * 7),
              nl.SharableLinear(int(512 * m) * 7 * 7, int(4096 * m)), nn.ReLU(True), nn.Dropout(),
              nl.SharableLinear(int(4096 * m), int(4096 * m)), nn.ReLU(True), nn.Dropout()]
-    return nn.Sequential(*mods)
+    return FusedSequential(*mods)
 
 
 class VGG(nn.Module):

@@ -142,6 +142,27 @@ int cpg_zero_pruned(float *w, const uint8_t *owner, int64_t n, void *stream);
 /* make_finetuning_mask (:233-243): owner[owner == 0] = new_idx */
 int cpg_claim_free(uint8_t *owner, int32_t new_idx, int64_t n, void *stream);
 
+/* ---- nn.BatchNorm2d -> nn.ReLU(inplace) after each masked conv ----
+ * (models/vgg.py:137-141: `layers += [conv2d, nn.BatchNorm2d(c), nn.ReLU(inplace=True)]`).
+ * x, y, gy, gx: NCHW fp32 with HW = H*W; gamma/beta/mean/invstd/running_*: C floats.
+ * fwd_train: batch statistics (biased variance for normalisation; running_var gets the unbiased one,
+ *   running = (1 - momentum) * running + momentum * batch, as torch.nn.BatchNorm2d), writes mean and
+ *   invstd = 1/sqrt(var + eps) for the backward, then y = [max(0,] (x-mean)*invstd*gamma + beta [)].
+ *   running_mean/var may both be NULL.  Reductions are two-stage and deterministic.
+ * fwd_eval : same affine map with caller-provided statistics.
+ * bwd      : gradient of fwd_train (train != 0) or fwd_eval (train == 0); the ReLU mask is recomputed
+ *   from x, so neither y nor a mask tensor is read.  dgamma / dbeta are overwritten. */
+size_t cpg_bn_workspace_bytes(int32_t N, int32_t C, int32_t HW);
+int cpg_bn_relu_fwd_train(const float *x, const float *gamma, const float *beta, float eps, float momentum,
+                          float *running_mean, float *running_var, float *mean, float *invstd, float *y,
+                          int32_t N, int32_t C, int32_t HW, int32_t relu, void *ws, size_t ws_bytes, void *stream);
+int cpg_bn_relu_fwd_eval(const float *x, const float *gamma, const float *beta, const float *mean,
+                         const float *invstd, float *y, int32_t N, int32_t C, int32_t HW, int32_t relu,
+                         void *stream);
+int cpg_bn_relu_bwd(const float *x, const float *gy, const float *gamma, const float *beta, const float *mean,
+                    const float *invstd, float *gx, float *dgamma, float *dbeta, int32_t N, int32_t C,
+                    int32_t HW, int32_t relu, int32_t train, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

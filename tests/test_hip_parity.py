@@ -460,3 +460,63 @@ def test_route_and_hist_full_size_properties():
     assert rc == 0
     want = torch.bincount(owner.long(), minlength=256)
     assert torch.equal(hist[:256], want) and int(hist[:256].sum()) == n
+
+
+# --------------------------------------------------------------------------- fused BatchNorm -> ReLU
+@pytest.mark.parametrize('N,C,H,W', [(8, 64, 56, 56), (4, 16, 224, 224), (16, 512, 14, 14), (3, 5, 7, 9), (2, 3, 1, 1)])
+@pytest.mark.parametrize('training', [True, False])
+def test_fused_bn_relu_matches_torch(N, C, H, W, training):
+    from cpg_amd.models.fused_bn import bn_relu
+    g = torch.Generator().manual_seed(N * C + H)
+    x = (torch.randn(N, C, H, W, generator=g) * 2.0 + 0.5)
+    gy = torch.randn(N, C, H, W, generator=g)
+    ref_bn, bn = nn.BatchNorm2d(C).to(DEV), nn.BatchNorm2d(C).to(DEV)
+    for m in (ref_bn, bn):
+        m.weight.data.copy_(torch.linspace(0.5, 1.5, C))
+        m.bias.data.copy_(torch.linspace(-0.3, 0.3, C))
+        m.running_mean.copy_(torch.linspace(-0.1, 0.1, C))
+        m.running_var.copy_(torch.linspace(0.8, 1.2, C))
+        m.train(training)
+    if N * H * W == 1 and training:
+        pytest.skip('torch rejects a single value per channel in training mode')
+    xr = x.to(DEV).requires_grad_(True)
+    xf = x.to(DEV).requires_grad_(True)
+    yr = torch.relu(ref_bn(xr))
+    yf = bn_relu(xf, bn, relu=True)
+    close(yf, yr.detach().cpu().numpy(), rtol=1e-4, atol=1e-5, msg='y')
+    yr.backward(gy.to(DEV))
+    yf.backward(gy.to(DEV))
+    gscale = float(xr.grad.abs().max()) + 1e-12
+    close(xf.grad, xr.grad.cpu().numpy(), rtol=1e-3, atol=2e-5 * max(1.0, gscale), msg='gx')
+    close(bn.weight.grad, ref_bn.weight.grad.cpu().numpy(), rtol=1e-3, atol=1e-3, msg='dgamma')
+    close(bn.bias.grad, ref_bn.bias.grad.cpu().numpy(), rtol=1e-3, atol=1e-3, msg='dbeta')
+    close(bn.running_mean, ref_bn.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6, msg='running_mean')
+    close(bn.running_var, ref_bn.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6, msg='running_var')
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked)
+
+
+def test_fused_sequential_equals_unfused():
+    """the same VGG with FusedSequential.fuse on / off: logits and every parameter gradient agree"""
+    from cpg_amd.models.fused_bn import FusedSequential
+    net = build('vgg_cifar100', 0.25).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(16, 3, 32, 32, generator=g).to(DEV)
+    t = torch.randint(0, 5, (16,), generator=g).to(DEV)
+    res = {}
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    for fuse in (True, False):
+        net.load_state_dict(sd)
+        net.zero_grad()
+        net.train()
+        FusedSequential.fuse = fuse
+        out = net(x)
+        nn.functional.cross_entropy(out, t).backward()
+        res[fuse] = (out.detach().cpu().numpy(), {n: p.grad.cpu().numpy() for n, p in net.named_parameters() if p.grad is not None},
+                     {n: b.cpu().numpy() for n, b in net.named_buffers()})
+    FusedSequential.fuse = True
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=1e-4, atol=1e-6)
+    for n in res[True][1]:
+        sc = float(np.abs(res[False][1][n]).max()) + 1e-12
+        np.testing.assert_allclose(res[True][1][n], res[False][1][n], rtol=2e-3, atol=2e-4 * sc, err_msg=n)
+    for n in res[True][2]:
+        np.testing.assert_allclose(res[True][2][n], res[False][2][n], rtol=1e-4, atol=1e-6, err_msg=n)
