@@ -51,14 +51,16 @@ struct C3Geom {
     int tiles_x, tiles_y, tiles_m;
 };
 
-template <int BM_, int TH_, int TW_, int WM_, int WN_, int CK_, int MINW_>
+template <int BM_, int TH_, int TW_, int WM_, int WN_, int CK_, int MINW_, int NIMG_ = 1>
 struct C3Cfg {
+    static constexpr int NIMG = NIMG_;                      // images per tile (2: a 4x28 strip of two images = 7 fragments)
     static constexpr int MINW = MINW_;                      // waves per SIMD the register allocator must leave room for
     static constexpr int BM = BM_, TH = TH_, TW = TW_, WM = WM_, WN = WN_, CK = CK_;
-    static constexpr int BN = TH * TW;
+    static constexpr int TPIX = TH * TW;                    // pixels of one image in the tile
+    static constexpr int BN = NIMG * TPIX;
     static_assert(WM * WN == 4 && BN % (32 * WN) == 0 && BM % (32 * WM) == 0 && CK % 2 == 0, "bad conv3x3 config");
     static constexpr int FM = BM / 32 / WM, FN = BN / 32 / WN;
-    static constexpr int PH = TH + 2, PW = TW + 2, PLANE = PH * PW;
+    static constexpr int PH = TH + 2, PW = TW + 2, IPLANE = PH * PW, PLANE = NIMG * IPLANE;
     static constexpr int LDW = BM + 4;                      // +4: rows stay 16-byte aligned for ds_write_b128
     static constexpr int KC = CK * 9;                       // k extent of one chunk
     static constexpr int W4 = BM / 4;                       // float4 per weight row
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
     const int tm = lb % g.tiles_m; lb /= g.tiles_m;
     const int tx = lb % g.tiles_x; lb /= g.tiles_x;
     const int ty = lb % g.tiles_y;
-    const int n = lb / g.tiles_y;
+    const int n = (lb / g.tiles_y) * Cfg::NIMG;          // first image of the tile
     const int m0 = tm * Cfg::BM, h0 = ty * Cfg::TH, w0 = tx * Cfg::TW;
     const int HW = g.H * g.W;
 
@@ -128,11 +130,12 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
 #pragma unroll
     for (int i = 0; i < Cfg::NXL; ++i) {
         const int e = tid + 256 * i;
-        const int cl = e / Cfg::PLANE, rem = e - cl * Cfg::PLANE;
+        const int cl = e / Cfg::PLANE, rem0 = e - cl * Cfg::PLANE;
+        const int img = rem0 / Cfg::IPLANE, rem = rem0 - img * Cfg::IPLANE;
         const int pr = rem / Cfg::PW, pc = rem - pr * Cfg::PW;
         const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
-        const bool ok = e < Cfg::X_ELEMS && (unsigned)gh < (unsigned)g.H && (unsigned)gw < (unsigned)g.W;
-        xoff[i] = ok ? cl * HW + gh * g.W + gw : -1;
+        const bool ok = e < Cfg::X_ELEMS && n + img < g.N && (unsigned)gh < (unsigned)g.H && (unsigned)gw < (unsigned)g.W;
+        xoff[i] = ok ? (img * g.C + cl) * HW + gh * g.W + gw : -1;
         xcl[i] = cl;
     }
     const float *xin = x + (int64_t)n * g.C * HW;
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
     // Loads are unconditional (clamped address) and their results untouched until put(): a predicated
     // load is an exec-masked branch with its own s_waitcnt vmcnt(0), and arithmetic on a loaded value in
     // fetch() would drag that wait in front of the MFMAs of the current chunk.
-    float4 rw[Cfg::NW4];
+    f32x4 rw[Cfg::NW4];             // native vector type: HIP's float4 struct kept this array in scratch memory
     float rx[Cfg::NXL];
     unsigned xok = 0;
     auto fetch = [&](int c0) {
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
 #pragma unroll
         for (int i = 0; i < Cfg::NW4; ++i) {
             const bool live = (Cfg::KC % Cfg::WROWS == 0) || (wrow0 + Cfg::WROWS * i < Cfg::KC);
-            rw[i] = *reinterpret_cast<const float4 *>(live ? wc + (int64_t)Cfg::WROWS * i * g.Mp : wp);
+            rw[i] = *reinterpret_cast<const f32x4 *>(live ? wc + (int64_t)Cfg::WROWS * i * g.Mp : wp);
         }
         const float *xc = xin + (int64_t)c0 * HW;
         xok = 0;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
 #pragma unroll
         for (int i = 0; i < Cfg::NW4; ++i) {
             const bool live = (Cfg::KC % Cfg::WROWS == 0) || (wrow0 + Cfg::WROWS * i < Cfg::KC);
-            if (live) *reinterpret_cast<float4 *>(stage + wdst + Cfg::WROWS * i * Cfg::LDW) = rw[i];
+            if (live) *reinterpret_cast<f32x4 *>(stage + wdst + Cfg::WROWS * i * Cfg::LDW) = rw[i];
         }
         float *xs = stage + Cfg::W_ELEMS;
 #pragma unroll
@@ -179,7 +182,8 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
 #pragma unroll
     for (int fn = 0; fn < Cfg::FN; ++fn) {
         const int t = (wn * Cfg::FN + fn) * 32 + li;
-        b_base[fn] = lh * Cfg::PLANE + (t / Cfg::TW) * Cfg::PW + (t % Cfg::TW);
+        const int img = t / Cfg::TPIX, tt = t % Cfg::TPIX;
+        b_base[fn] = lh * Cfg::PLANE + img * Cfg::IPLANE + (tt / Cfg::TW) * Cfg::PW + (tt % Cfg::TW);
     }
 
     f32x16 acc[Cfg::FM][Cfg::FN];
@@ -221,13 +225,14 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
     }
 
     // ---- epilogue: D col = pixel (lane & 31), D row = channel ----
-    float *yout = y + (int64_t)n * g.M * HW;
 #pragma unroll
     for (int fn = 0; fn < Cfg::FN; ++fn) {
         const int t = (wn * Cfg::FN + fn) * 32 + li;
-        const int oh = h0 + t / Cfg::TW, ow = w0 + t % Cfg::TW;
-        const bool pok = oh < g.H && ow < g.W;
+        const int img = t / Cfg::TPIX, tt = t % Cfg::TPIX;
+        const int oh = h0 + tt / Cfg::TW, ow = w0 + tt % Cfg::TW;
+        const bool pok = oh < g.H && ow < g.W && n + img < g.N;
         const int poff = oh * g.W + ow;
+        float *yout = y + (int64_t)(n + img) * g.M * HW;
 #pragma unroll
         for (int fm = 0; fm < Cfg::FM; ++fm) {
             float bv[16];
@@ -418,6 +423,122 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
         }
 }
 
+// ------------------------------------------------------------------------------ wgrad, <= 3 input channels
+// The network stem (3 -> 64 @224x224): all (ci, tap) pairs fit ONE 32-wide fragment column (27 <= 32), the
+// contraction runs over 12.8 M pixels and the kernel is bound by streaming gy (3.3 GB) from HBM, not by MFMA.
+// Block = 64 co; waves 0/1 own the two 32-channel fragments for the first half of a unit's pixel pairs,
+// waves 2/3 for the second half (combined through LDS at the end).  x patch: C planes + one all-zero plane
+// that the 5 unused fragment columns read.
+struct WSCfg {
+    static constexpr int TH = 4, TW = 32, NPIX = TH * TW, PH = TH + 2, PW = TW + 2, IPLANE = PH * PW;
+    static constexpr int CMAX = 3, LDG = NPIX + 1;
+    static constexpr int G_ELEMS = 64 * LDG, X_ELEMS = (CMAX + 1) * IPLANE;
+    static constexpr int NG = 64 * NPIX / 256;               // 32 gy elements per thread per unit
+    static constexpr int NX = (CMAX * IPLANE + 255) / 256;
+};
+
+__global__ __launch_bounds__(256) void k_c3_wgrad_smallc(int N, int C, int H, int W, int M, int tiles_x, int tiles_y,
+                                                         int units_per_split, const float *__restrict__ x,
+                                                         const float *__restrict__ gy, float *__restrict__ part) {
+    using Cfg = WSCfg;
+    __shared__ float smem[Cfg::G_ELEMS + Cfg::X_ELEMS];
+    float *gs = smem, *xs = smem + Cfg::G_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wco = sub & 1, khalf = sub >> 1;
+    const int co0 = blockIdx.x * 64;
+    const int HW = H * W;
+    const int units_per_img = tiles_x * tiles_y;
+    const int total_units = N * units_per_img;
+    const int u0 = blockIdx.y * units_per_split;
+    const int u1 = min(total_units, u0 + units_per_split);
+    const int J = C * 9;
+
+    for (int i = tid; i < Cfg::IPLANE; i += 256) xs[Cfg::CMAX * Cfg::IPLANE + i] = 0.0f;     // the zero plane
+    // fragment column j = (ci, tap) -> fixed offset into the patch; unused columns read the zero plane
+    const int jci = li / 9, jt = li - jci * 9;
+    const int joff = li < J ? jci * Cfg::IPLANE + (jt / 3) * Cfg::PW + (jt % 3) : Cfg::CMAX * Cfg::IPLANE;
+    const int a_base = (wco * 32 + li) * Cfg::LDG + lh;
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+
+    // gy staging map: wave `sub` owns channels sub + 4*i (i < 16), lanes own pixels lane and lane + 64
+    for (int u = u0; u < u1; ++u) {
+        const int n = u / units_per_img, rr = u - n * units_per_img;
+        const int ty = rr / tiles_x, tx = rr - ty * tiles_x;
+        const int h0 = ty * Cfg::TH, w0 = tx * Cfg::TW;
+        __syncthreads();                                     // previous unit fully consumed
+        const float *gimg = gy + ((int64_t)n * M + co0) * HW + h0 * W + w0;
+        float rg[2][16];
+        bool pv[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int pix = lane + 64 * g, r = pix / Cfg::TW, c = pix % Cfg::TW;
+            pv[g] = h0 + r < H && w0 + c < W;
+            const unsigned off = 4u * (unsigned)(sub * HW + r * W + c);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool cv = co0 + sub + 4 * i < M;
+                const float *base = gimg + (int64_t)(cv ? 4 * i : 0) * HW;
+                rg[g][i] = ld_sv(base, (pv[g] && cv) ? off : 0u);
+            }
+        }
+        const float *ximg = x + (int64_t)n * C * HW;
+        float rx[Cfg::NX];
+        bool xv[Cfg::NX];
+#pragma unroll
+        for (int i = 0; i < Cfg::NX; ++i) {
+            const int e = tid + 256 * i;
+            const int ci = e / Cfg::IPLANE, rem = e - ci * Cfg::IPLANE;
+            const int gh = h0 - 1 + rem / Cfg::PW, gw = w0 - 1 + rem % Cfg::PW;
+            xv[i] = ci < C && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            rx[i] = ximg[xv[i] ? (int64_t)ci * HW + gh * W + gw : 0];
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                gs[(sub + 4 * i) * Cfg::LDG + lane + 64 * g] = (pv[g] && co0 + sub + 4 * i < M) ? rg[g][i] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < Cfg::NX; ++i) {
+            const int e = tid + 256 * i;
+            if (e < Cfg::CMAX * Cfg::IPLANE) xs[e] = xv[i] ? rx[i] : 0.0f;
+        }
+        __syncthreads();
+        // this wave's half of the pixel pairs: rows khalf*2, khalf*2 + 1
+#pragma unroll
+        for (int r2 = 0; r2 < Cfg::TH / 2; ++r2) {
+            const int r = khalf * (Cfg::TH / 2) + r2;
+#pragma unroll
+            for (int c2 = 0; c2 < Cfg::TW / 2; ++c2) {
+                const float a = gs[a_base + r * Cfg::TW + 2 * c2];
+                const float b = xs[joff + r * Cfg::PW + 2 * c2 + lh];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+        }
+    }
+    // combine the two pixel halves through LDS, then write part[split][co][j]
+    __syncthreads();
+    float *red = smem;                                       // [2 fragments][16][64]
+    if (khalf == 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[(wco * 16 + e) * 64 + lane] = acc[e];
+    }
+    __syncthreads();
+    if (khalf == 0) {
+        float *dst = part + (int64_t)blockIdx.y * M * J;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = acc[e] + red[(wco * 16 + e) * 64 + lane];
+            const int co = co0 + wco * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (co < M && li < J) dst[(int64_t)co * J + li] = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_c3_wgrad_reduce(const float *__restrict__ part, int nsplit, int64_t out_elems,
                                                          Epilogue ep) {
     const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
@@ -435,6 +556,7 @@ using CfgM64 = C3Cfg<64, 8, 32, 1, 4, 4, 3>;       // <= 64 output channels (VGG
 using CfgS16 = C3Cfg<128, 14, 16, 4, 1, 4, 2>;     // 14x14 (and <= 16 wide) feature maps: whole image, 7 fragments
 using CfgD128 = C3Cfg<128, 4, 56, 4, 1, 4, 2>;     // 56 / 112 wide maps: 4 x 56 = 7 fragments per wave, zero tile waste
 using CfgD64 = C3Cfg<64, 8, 56, 2, 2, 4, 2>;       // same for <= 64 output channels
+using CfgP28 = C3Cfg<128, 4, 28, 4, 1, 4, 2, 2>;   // 28-wide maps: a 4 x 28 strip of TWO images = 7 fragments, zero tile waste
 
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 // packed-weight workspace: [roundup(C_read, 4) * 9][roundup(M, 128)] floats
@@ -445,7 +567,7 @@ int launch_fwd(C3Geom g, const float *x, const float *wp, const float *bias, flo
     g.tiles_x = (g.W + Cfg::TW - 1) / Cfg::TW;
     g.tiles_y = (g.H + Cfg::TH - 1) / Cfg::TH;
     g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
-    const int64_t blocks = (int64_t)g.N * g.tiles_x * g.tiles_y * g.tiles_m;
+    const int64_t blocks = (int64_t)((g.N + Cfg::NIMG - 1) / Cfg::NIMG) * g.tiles_x * g.tiles_y * g.tiles_m;
     if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "conv3x3: grid too large");
     hipLaunchKernelGGL((k_c3_fwd<Cfg>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y);
     CPG_CHECK_LAUNCH(what);
@@ -465,6 +587,8 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
                        rows_c, Mp, dgrad ? 1 : 0);
     C3Geom g{N, c_read, H, W, m, Mp, 0, 0, 0};
     if (W <= 16 && H <= 16 && m > 64) return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what);
+    if (W == 28 && H % 4 == 0 && m > 64 && (int64_t)2 * c_read * H * W < (1ll << 31))
+        return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what);
     if (W % 56 == 0 && W % 32 != 0) {       // 56, 112, 168 ...: a 32-wide tile would waste 12.5 % of the MFMAs
         if (m > 64) return launch_fwd<CfgD128>(g, x, wp, bias, y, stream, what);
         return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what);
@@ -532,6 +656,16 @@ inline int w3_pick(const cpg_conv_desc *d) {
 }  // namespace
 
 size_t cpg_conv3x3_wgrad_workspace(const cpg_conv_desc *d) {
+    if (d->C <= 3) {            // stem kernel: same formula as ws_plan() below
+        const int tiles = ((d->W + 31) / 32) * ((d->H + 3) / 4);
+        const int64_t units = (int64_t)d->N * tiles;
+        const int blocks_co = (d->K + 63) / 64;
+        int64_t want = (8 * kCUs + blocks_co - 1) / blocks_co;
+        if (want > units) want = units;
+        if (want < 1) want = 1;
+        const int64_t per = (units + want - 1) / want;
+        return (size_t)((units + per - 1) / per) * d->K * d->C * 9 * sizeof(float);
+    }
     switch (w3_pick(d)) {
         case 1: return w3_plan<W3Mid>(d).ws_bytes;
         case 2: return w3_plan<W3Nar>(d).ws_bytes;
@@ -553,9 +687,41 @@ static int w3_launch(const cpg_conv_desc *d, const float *x, const float *gy, co
     return CPG_OK;
 }
 
+namespace {
+struct WSPlan {
+    int tiles_x, tiles_y, blocks_co, nsplit, units_per_split;
+    size_t ws_bytes;
+};
+WSPlan ws_plan(const cpg_conv_desc *d) {
+    WSPlan p;
+    p.tiles_x = (d->W + WSCfg::TW - 1) / WSCfg::TW;
+    p.tiles_y = (d->H + WSCfg::TH - 1) / WSCfg::TH;
+    p.blocks_co = (d->K + 63) / 64;
+    const int64_t units = (int64_t)d->N * p.tiles_x * p.tiles_y;
+    int64_t want = (8 * kCUs + p.blocks_co - 1) / p.blocks_co;     // HBM-streaming kernel: ~8 blocks per CU
+    if (want > units) want = units;
+    if (want < 1) want = 1;
+    p.units_per_split = (int)((units + want - 1) / want);
+    p.nsplit = (int)((units + p.units_per_split - 1) / p.units_per_split);
+    p.ws_bytes = (size_t)p.nsplit * d->K * d->C * 9 * sizeof(float);
+    return p;
+}
+}  // namespace
+
 int cpg_conv3x3_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
                       float *gw, float *gpm, void *ws, size_t ws_bytes, hipStream_t stream) {
     Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
+    if (d->C <= WSCfg::CMAX) {
+        const WSPlan p = ws_plan(d);
+        if (ws_bytes < p.ws_bytes) return fail(CPG_E_WORKSPACE, "cpg_conv2d_wgrad(3x3 stem): workspace %zu < %zu bytes", ws_bytes, p.ws_bytes);
+        hipLaunchKernelGGL(k_c3_wgrad_smallc, dim3((unsigned)p.blocks_co, (unsigned)p.nsplit), dim3(256), 0, stream, d->N, d->C, d->H,
+                           d->W, d->K, p.tiles_x, p.tiles_y, p.units_per_split, x, gy, (float *)ws);
+        const int64_t out_elems = (int64_t)d->K * d->C * 9;
+        hipLaunchKernelGGL(k_c3_wgrad_reduce, dim3(stream_grid(out_elems, 256)), dim3(256), 0, stream, (const float *)ws, p.nsplit,
+                           out_elems, ep);
+        CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(3x3 stem)");
+        return CPG_OK;
+    }
     switch (w3_pick(d)) {
         case 1: return w3_launch<W3Mid>(d, x, gy, ep, ws, ws_bytes, stream);
         case 2: return w3_launch<W3Nar>(d, x, gy, ep, ws, ws_bytes, stream);

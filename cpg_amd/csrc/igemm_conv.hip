@@ -467,9 +467,9 @@ size_t cpg_conv3x3_pack_workspace(const cpg_conv_desc *d);
 size_t cpg_conv3x3_wgrad_workspace(const cpg_conv_desc *d);
 int cpg_conv3x3_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
                       float *gw, float *gpm, void *ws, size_t ws_bytes, hipStream_t stream);
-// the 3x3 weight-gradient kernel owns a 64-wide input-channel tile: below 16 channels (VGG / SphereNet stems)
-// the generic kernel's (ci, tap) column packing wastes less of the MFMA
-static inline bool use_c3_wgrad(const cpg_conv_desc *d) { return cpg_conv3x3_supported(d) && d->C >= 16; }
+// the 3x3 weight-gradient kernel owns a 64-wide input-channel tile; <= 3 channels (the VGG stem) have their own
+// HBM-streaming kernel, 4..15 channels go to the generic kernel whose (ci, tap) column packing wastes less MFMA
+static inline bool use_c3_wgrad(const cpg_conv_desc *d) { return cpg_conv3x3_supported(d) && (d->C >= 16 || d->C <= 3); }
 
 extern "C" size_t cpg_conv2d_workspace_bytes(const cpg_conv_desc *d) {
     ConvGeom g;

@@ -112,6 +112,9 @@ def test_linear_golden(name):
     (2, 17, 10, 40, 33, 3, 1, 1, False, True),       # channel counts not multiples of the chunk / fragment
     (2, 24, 11, 56, 130, 3, 1, 1, True, False),      # 56-wide tiles (7 fragments), ragged rows, 2 channel tiles
     (1, 40, 9, 112, 48, 3, 1, 1, False, True),       # 56-wide tiles, <= 64 output channels; wgrad 2x28 units
+    (3, 2, 13, 37, 70, 3, 1, 1, False, True),        # stem weight-gradient kernel (C <= 3), ragged tiles, 2 co blocks
+    (5, 160, 28, 28, 136, 3, 1, 1, False, False),    # two-image 4x28 tiles with an odd image count
+    (2, 32, 12, 28, 128, 3, 1, 1, True, True),       # two-image tiles, bias + piggymask
     (2, 3, 64, 64, 16, 7, 2, 3, False, False),       # ResNet stem
     (3, 64, 28, 28, 256, 1, 1, 0, False, True),      # ResNet 1x1
     (3, 256, 28, 28, 512, 1, 2, 0, False, False),    # ResNet downsample
