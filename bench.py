@@ -193,7 +193,7 @@ def cpu_baseline(budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=44)
+    ap.add_argument('--steps', type=int, default=110)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (config 2: 256)')
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -262,8 +262,9 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
 // register plus wave-uniform scalars (unit origin, channel stride), its LDS address a fixed register
 // plus compile-time immediates.  The loads of unit u+1 are issued before the 288 MFMAs of unit u and
 // land in registers meanwhile.
-template <int TH_, int TW_>
+template <int TH_, int TW_, bool DB_ = false>
 struct W3Cfg {
+    static constexpr bool DB = DB_;                             // two LDS stages: one barrier per unit instead of two
     static constexpr int TH = TH_, TW = TW_, NPIX = TH * TW;
     static_assert(TW % 2 == 0, "pixel pairs must not straddle rows");
     static constexpr int BMC = 64, BCI = 64;                    // block tile: 64 co x 64 ci, 2 x 2 waves
@@ -271,7 +272,8 @@ struct W3Cfg {
     static constexpr int PLANE = PHW | 1;                       // odd stride: conflict-free lane = channel reads
     static constexpr int LDG = NPIX | 1;
     static constexpr int G_ELEMS = BMC * LDG, X_ELEMS = BCI * PLANE;
-    static constexpr int SMEM_FLOATS = G_ELEMS + X_ELEMS;
+    static constexpr int STAGE = G_ELEMS + X_ELEMS;
+    static constexpr int SMEM_FLOATS = (DB ? 2 : 1) * STAGE;
     static constexpr int GP = (NPIX + 63) / 64, XP = (PHW + 63) / 64;      // 64-lane position groups
     static constexpr int NI = 16;                                           // channels per wave
 };
@@ -281,7 +283,6 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
                                                      int units_per_split, const float *__restrict__ x,
                                                      const float *__restrict__ gy, float *__restrict__ part) {
     __shared__ float smem[Cfg::SMEM_FLOATS];
-    float *gs = smem, *xs = smem + Cfg::G_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave id, provably uniform
     const int wco = sub >> 1, wci = sub & 1;
@@ -362,7 +363,8 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
             }
         }
     };
-    auto put = [&]() {
+    auto put = [&](float *stage) {
+        float *gs = stage, *xs = stage + Cfg::G_ELEMS;
 #pragma unroll
         for (int g = 0; g < Cfg::GP; ++g) {
             if (g_rc[g] != 0xFFFFu) {
@@ -388,15 +390,8 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
     // The 32 patch loads of unit u+1 fly during the MFMAs of unit u; the 16 gy loads are issued after them
     // (9 accumulators + 48 staged values + operands do not fit 256 registers without spilling) and overlap
     // the barrier wait and the other resident block's MFMAs.
-    if (u0 < u1) {
-        fetch_x(u0);
-        fetch_g(u0);
-    }
-    for (int u = u0; u < u1; ++u) {
-        __syncthreads();                 // previous unit's operand reads are done
-        put();
-        __syncthreads();
-        if (u + 1 < u1) fetch_x(u + 1);
+    auto compute = [&](const float *stage) {
+        const float *gs = stage, *xs = stage + Cfg::G_ELEMS;
 #pragma unroll 1
         for (int r = 0; r < Cfg::TH; ++r) {          // not unrolled: keeps the operand-read window (and VGPRs) small
 #pragma unroll
@@ -409,7 +404,36 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
                 }
             }
         }
-        if (u + 1 < u1) fetch_g(u + 1);
+    };
+    if (u0 < u1) {
+        fetch_x(u0);
+        fetch_g(u0);
+    }
+    if (Cfg::DB) {
+        // two stages: the stage written after the MFMAs of unit u was last read during unit u-1, which every
+        // wave left at the previous barrier -> ONE barrier per unit
+        if (u0 < u1) put(smem);
+        __syncthreads();
+        for (int u = u0; u < u1; ++u) {
+            const int cur = (u - u0) & 1;
+            const bool more = u + 1 < u1;
+            if (more) fetch_x(u + 1);
+            compute(smem + cur * Cfg::STAGE);
+            if (more) {
+                fetch_g(u + 1);
+                put(smem + (cur ^ 1) * Cfg::STAGE);
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int u = u0; u < u1; ++u) {
+            __syncthreads();                 // previous unit's operand reads are done
+            put(smem);
+            __syncthreads();
+            if (u + 1 < u1) fetch_x(u + 1);
+            compute(smem);
+            if (u + 1 < u1) fetch_g(u + 1);
+        }
     }
     // partial result: part[split][co][ci][tap]
     float *dst = part + (int64_t)blockIdx.y * M * C * 9;
@@ -646,7 +670,7 @@ W3Plan w3_plan(const cpg_conv_desc *d) {
     return p;
 }
 using W3Wide = W3Cfg<2, 28>;      // 112 / 224 wide feature maps: long contiguous rows, 2 x 64-lane patch groups exactly
-using W3Mid = W3Cfg<4, 14>;       // 14 / 28 / 56 wide feature maps: zero column waste
+using W3Mid = W3Cfg<4, 14>;       // 14 / 28 / 56 wide feature maps: zero column waste (two LDS stages measured no gain)
 using W3Nar = W3Cfg<4, 16>;       // everything else that is narrow
 inline int w3_pick(const cpg_conv_desc *d) {
     if (d->W % 28 == 0 && d->W >= 112) return 0;

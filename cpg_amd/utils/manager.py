@@ -126,6 +126,8 @@ class Manager(object):
     def validate(self, epoch_idx, biases=None):
         """Evaluation (utils/manager.py:103-152): apply_mask() first, then an eval-mode forward pass."""
         self.pruner.apply_mask()
+        if hasattr(self.model, 'sync_buffers'):
+            self.model.sync_buffers()            # data parallel: evaluate with rank 0's BN running statistics
         self.model.eval()
         val_loss = Metric('val_loss')
         val_accuracy = Metric('val_accuracy')

@@ -477,7 +477,30 @@ def gen_trajectory():
         save('trajectory_' + mode, **arrs)
 
 
+def gen_angle():
+    """A-Softmax head of config 5 (models/spherenet.py:24-98): AngleLinear output pair and AngleLoss over 3 calls
+    (the loss is stateful: lambda anneals with the call count)."""
+    from models.spherenet import AngleLinear, AngleLoss
+    torch.manual_seed(3)
+    lin = AngleLinear(16, 10)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(6, 16, generator=g).requires_grad_(True)
+    t = torch.randint(0, 10, (6,), generator=g)
+    crit = AngleLoss()
+    losses, gws = [], []
+    cos, phi = lin(x)
+    for _ in range(3):
+        lin.zero_grad()
+        out = lin(x)
+        loss = crit(out, t)
+        loss.backward()
+        losses.append(float(loss))
+        gws.append(lin.weight.grad.clone())
+    save('angle_head', w=lin.weight, x=x, t=t, cos=cos, phi=phi, losses=np.array(losses), gw=torch.stack(gws), gx=x.grad)
+
+
 if __name__ == '__main__':
+    gen_angle()
     gen_binarizer()
     gen_conv()
     gen_linear()

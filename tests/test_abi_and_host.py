@@ -135,3 +135,24 @@ def test_current_dataset_idx_rules():
     assert _pruner('finetune', 0, 8, 3, 0.0, 0.1).current_dataset_idx == 0      # +1 in make_finetuning_mask
     with pytest.raises(SystemExit):
         _pruner('bogus', 0, 8, 3, 0.0, 0.1)
+
+
+def test_angle_head_matches_reference():
+    """AngleLinear / AngleLoss (config 5 head, stock torch ops on any device) against the reference's outputs."""
+    from cpg_amd.models.spherenet import AngleLinear, AngleLoss
+    g = load_golden('angle_head')
+    lin = AngleLinear(16, 10)
+    lin.weight.data.copy_(torch.from_numpy(g['w']))
+    x = torch.from_numpy(g['x']).requires_grad_(True)
+    t = torch.from_numpy(g['t'])
+    cos, phi = lin(x)
+    np.testing.assert_allclose(cos.detach().numpy(), g['cos'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(phi.detach().numpy(), g['phi'], rtol=1e-5, atol=1e-5)
+    crit = AngleLoss()
+    for k in range(3):
+        lin.zero_grad()
+        loss = crit(lin(x), t)
+        loss.backward()
+        assert abs(float(loss) - g['losses'][k]) < 1e-5
+        np.testing.assert_allclose(lin.weight.grad.numpy(), g['gw'][k], rtol=1e-4, atol=1e-6)
+    assert crit.it == 3

@@ -523,3 +523,38 @@ def test_fused_sequential_equals_unfused():
         np.testing.assert_allclose(res[True][1][n], res[False][1][n], rtol=2e-3, atol=2e-4 * sc, err_msg=n)
     for n in res[True][2]:
         np.testing.assert_allclose(res[True][2][n], res[False][2][n], rtol=1e-4, atol=1e-6, err_msg=n)
+
+
+# --------------------------------------------------------------------------- configs 4 / 5: whole-net train step
+@pytest.mark.parametrize('arch,width,shape,ncls', [('resnet50', 0.25, (4, 3, 64, 64), 5), ('spherenet20', 0.25, (4, 3, 112, 112), 7)])
+def test_resnet_spherenet_backward_matches_torch_ops(arch, width, shape, ncls, monkeypatch):
+    """Every conv shape class of ResNet-50 (7x7 s2, 1x1 s1/s2, 3x3 s1/s2) and SphereNet-20 (3x3 s1/s2 with bias)
+    in one forward + backward: parameter gradients from the HIP kernels vs the same network evaluated with
+    torch's own conv (MIOpen) on the same device."""
+    import torch.nn.functional as F
+    net = build(arch, width, ncls).to(DEV).train()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(*shape, generator=g).to(DEV)
+    t = torch.randint(0, ncls, (shape[0],), generator=g).to(DEV)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+
+    def run():
+        net.load_state_dict(sd)
+        net.zero_grad()
+        out = net(x)
+        F.cross_entropy(out, t).backward()
+        return out.detach().cpu().numpy(), {n: p.grad.cpu().numpy() for n, p in net.named_parameters() if p.grad is not None}
+
+    out_hip, g_hip = run()
+    monkeypatch.setattr(nl.SharableConv2d, 'forward',
+                        lambda self, input, layer_info=None, name=None: F.conv2d(input, self.weight, self.bias, self.stride,
+                                                                                 self.padding, self.dilation, self.groups))
+    out_ref, g_ref = run()
+    np.testing.assert_allclose(out_hip, out_ref, rtol=1e-3, atol=1e-4 * float(np.abs(out_ref).max()))
+    assert set(g_hip) == set(g_ref)
+    for n in g_ref:
+        sc = float(np.abs(g_ref[n]).max()) + 1e-20
+        err = float(np.abs(g_hip[n] - g_ref[n]).max())
+        # whole-net check through ~50 BatchNorm backward passes: round-off of either conv implementation is
+        # amplified on the way down to the stem (observed 4e-3 on conv1.weight); op-level tests hold 1e-4
+        assert err <= 1e-2 * sc, '%s: max err %g vs scale %g' % (n, err, sc)

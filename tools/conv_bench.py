@@ -16,9 +16,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cpg_amd import _lib                      # noqa: E402
 from cpg_amd.models.layers import _conv_desc  # noqa: E402
 
-# (name, Cin, Cout, H) of VGG16 @224 -- SURVEY.md section 8 table
-VGG = [('f0', 3, 64, 224), ('f3', 64, 64, 224), ('f7', 64, 128, 112), ('f10', 128, 128, 112), ('f14', 128, 256, 56),
-       ('f17', 256, 256, 56), ('f24', 256, 512, 28), ('f27', 512, 512, 28), ('f34', 512, 512, 14)]
+# (name, Cin, Cout, H, multiplicity) of VGG16 @224 -- SURVEY.md section 8 table (f17/f20, f27/f30, f34/f37/f40 share shapes)
+VGG = [('f0', 3, 64, 224, 1), ('f3', 64, 64, 224, 1), ('f7', 64, 128, 112, 1), ('f10', 128, 128, 112, 1), ('f14', 128, 256, 56, 1),
+       ('f17', 256, 256, 56, 2), ('f24', 256, 512, 28, 1), ('f27', 512, 512, 28, 2), ('f34', 512, 512, 14, 3)]
 
 
 def timeit(fn, iters):
@@ -47,7 +47,7 @@ def main():
     sel = set(a.layers.split(',')) if a.layers else None
     print('%-6s %-6s %9s %9s' % ('layer', 'pass', 'ms', 'TFLOP/s'))
     tot = {}
-    for name, C, K, H in VGG:
+    for name, C, K, H, mult in VGG:
         if sel and name not in sel:
             continue
         x = torch.randn(a.batch, C, H, H, device=dev)
@@ -72,10 +72,10 @@ def main():
             ms = timeit(runs[k], a.iters)
             print('%-6s %-6s %9.3f %9.1f' % (name, k, ms, flops / ms / 1e9), flush=True)
             t = tot.setdefault(k, [0.0, 0.0])
-            t[0] += ms
-            t[1] += flops
+            t[0] += ms * mult
+            t[1] += flops * mult
     for k, (ms, fl) in tot.items():
-        print('TOTAL  %-6s %9.3f %9.1f' % (k, ms, fl / ms / 1e9))
+        print('TOTAL  %-6s %9.3f %9.1f   (13 convs of one VGG16 pass)' % (k, ms, fl / ms / 1e9))
 
 
 if __name__ == '__main__':
