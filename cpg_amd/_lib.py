@@ -61,6 +61,10 @@ _SIGNATURES = {
                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
     'cpg_bn_relu_fwd_eval': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                             ctypes.c_int32, _vp]),
+    'cpg_bn_relu_pool_fwd': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32,
+                                            ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
+    'cpg_bn_relu_pool_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                            ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
     'cpg_bn_relu_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                        ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
 }

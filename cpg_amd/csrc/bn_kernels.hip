@@ -350,3 +350,205 @@ extern "C" int cpg_bn_relu_bwd(const float *x, const float *gy, const float *gam
     CPG_CHECK_LAUNCH("cpg_bn_relu_bwd");
     return CPG_OK;
 }
+
+// =====================================================================================================
+// BatchNorm2d -> ReLU -> MaxPool2d(2, 2) in one op (5 of the 13 VGG blocks, models/vgg.py:131-141).
+// The un-pooled activation never exists in HBM: forward reads x once (after the statistics pass) and
+// writes the pooled tensor (1/4 size); backward recomputes the four ReLU(BN(x)) values of each window
+// from x, routes the pooled gradient to the first maximum (torch's max_pool2d tie rule) if it is
+// positive, and continues with the BatchNorm gradient.  H and W must be even.
+// =====================================================================================================
+namespace {
+
+struct PoolDims {
+    int H, W, OW, wins;          // wins = (H/2) * (W/2) windows per plane
+};
+
+// the four values of window (pr, pc) of a plane and their common processing
+struct Win {
+    float v[4];
+};
+__device__ __forceinline__ Win load_win(const float *plane, int W, int pr, int pc) {
+    const float2 a = *reinterpret_cast<const float2 *>(plane + (2 * pr) * W + 2 * pc);
+    const float2 b = *reinterpret_cast<const float2 *>(plane + (2 * pr + 1) * W + 2 * pc);
+    return Win{{a.x, a.y, b.x, b.y}};
+}
+__device__ __forceinline__ int win_argmax(const float (&y)[4]) {
+    int idx = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (y[k] > y[idx]) idx = k;      // strict: first maximum wins, as torch's max_pool2d
+    return idx;
+}
+
+template <int GROUP>
+__global__ __launch_bounds__(kThreads) void k_bnp_apply(const float *__restrict__ x, float *__restrict__ yp, BnDims d, PoolDims p,
+                                                        const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta) {
+    const int64_t planes = (int64_t)d.N * d.C;
+    const int gl = threadIdx.x % GROUP;
+    const int64_t g0 = (int64_t)blockIdx.x * (kThreads / GROUP) + threadIdx.x / GROUP;
+    const int64_t gstride = (int64_t)gridDim.x * (kThreads / GROUP);
+    for (int64_t pl = g0; pl < planes; pl += gstride) {
+        const int c = (int)(pl % d.C);
+        const float m = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+        const float *plane = x + pl * d.HW;
+        float *out = yp + pl * p.wins;
+        for (int i = gl; i < p.wins; i += GROUP) {
+            const int pr = i / p.OW, pc = i - pr * p.OW;
+            const Win w = load_win(plane, p.W, pr, pc);
+            float best = 0.0f;                       // ReLU floor
+#pragma unroll
+            for (int k = 0; k < 4; ++k) best = fmaxf(best, bn_affine(w.v[k], m, is, ga, be));
+            out[i] = best;
+        }
+    }
+}
+
+// grid (C, slices): partial = {sum g, sum g * xhat} with g scattered from the pooled gradient
+__global__ __launch_bounds__(kThreads) void k_bnp_bwd_reduce(const float *__restrict__ x, const float *__restrict__ gp, BnDims d,
+                                                             PoolDims p, const float *__restrict__ mean,
+                                                             const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, double *__restrict__ partial) {
+    __shared__ double red[4];
+    const int c = blockIdx.x, s = blockIdx.y;
+    const int n0 = s * d.imgs_per_slice, n1 = min(d.N, n0 + d.imgs_per_slice);
+    const float m = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+    double dsg = 0.0, dsgx = 0.0;
+    float sg = 0.f, sgx = 0.f;
+    int cnt = 0;
+    const int64_t total = (int64_t)(n1 - n0) * p.wins;
+    for (int64_t i = threadIdx.x; i < total; i += kThreads) {
+        const int n = n0 + (int)(i / p.wins), wi = (int)(i % p.wins);
+        const int pr = wi / p.OW, pc = wi - pr * p.OW;
+        const int64_t pl = (int64_t)n * d.C + c;
+        const Win w = load_win(x + pl * d.HW, p.W, pr, pc);
+        float y[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = bn_affine(w.v[k], m, is, ga, be);
+        const int idx = win_argmax(y);
+        if (y[idx] > 0.f) {
+            const float g = gp[pl * p.wins + wi];
+            sg += g;
+            sgx += g * ((w.v[idx] - m) * is);
+        }
+        if (++cnt == 64) {
+            dsg += (double)sg; dsgx += (double)sgx; sg = 0.f; sgx = 0.f; cnt = 0;
+        }
+    }
+    dsg += (double)sg;
+    dsgx += (double)sgx;
+    const double t0 = block_sum(dsg, red);
+    const double t1 = block_sum(dsgx, red);
+    if (threadIdx.x == 0) {
+        partial[((int64_t)c * d.slices + s) * 2 + 0] = t0;
+        partial[((int64_t)c * d.slices + s) * 2 + 1] = t1;
+    }
+}
+
+template <bool TRAIN, int GROUP>
+__global__ __launch_bounds__(kThreads) void k_bnp_bwd_apply(const float *__restrict__ x, const float *__restrict__ gp,
+                                                            float *__restrict__ gx, BnDims d, PoolDims p,
+                                                            const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            const float *__restrict__ coef) {
+    const int64_t planes = (int64_t)d.N * d.C;
+    const int gl = threadIdx.x % GROUP;
+    const int64_t g0 = (int64_t)blockIdx.x * (kThreads / GROUP) + threadIdx.x / GROUP;
+    const int64_t gstride = (int64_t)gridDim.x * (kThreads / GROUP);
+    for (int64_t pl = g0; pl < planes; pl += gstride) {
+        const int c = (int)(pl % d.C);
+        const float m = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+        const float mg = TRAIN ? coef[2 * c] : 0.f, mgx = TRAIN ? coef[2 * c + 1] : 0.f;
+        const float scale = is * ga;
+        const float *plane = x + pl * d.HW;
+        float *gplane = gx + pl * d.HW;
+        for (int i = gl; i < p.wins; i += GROUP) {
+            const int pr = i / p.OW, pc = i - pr * p.OW;
+            const Win w = load_win(plane, p.W, pr, pc);
+            float y[4], r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = bn_affine(w.v[k], m, is, ga, be);
+            const int idx = win_argmax(y);
+            const float g = (y[idx] > 0.f) ? gp[pl * p.wins + i] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gk = (k == idx) ? g : 0.f;
+                r[k] = TRAIN ? (gk - mg - ((w.v[k] - m) * is) * mgx) * scale : gk * scale;
+            }
+            *reinterpret_cast<float2 *>(gplane + (2 * pr) * p.W + 2 * pc) = make_float2(r[0], r[1]);
+            *reinterpret_cast<float2 *>(gplane + (2 * pr + 1) * p.W + 2 * pc) = make_float2(r[2], r[3]);
+        }
+    }
+}
+
+int make_pool(int H, int W, PoolDims &p) {
+    CPG_REQUIRE(H > 0 && W > 0 && (H % 2) == 0 && (W % 2) == 0, "bn_relu_pool: H and W must be even (got %d x %d)", H, W);
+    p.H = H; p.W = W; p.OW = W / 2; p.wins = (H / 2) * (W / 2);
+    return CPG_OK;
+}
+unsigned pool_grid(const BnDims &d, const PoolDims &p, bool wave) {
+    int64_t groups = (int64_t)d.N * d.C;
+    if (wave) groups = (groups + 3) / 4;
+    const int64_t cap = (int64_t)kCUs * 16;
+    return (unsigned)(groups < cap ? groups : cap);
+}
+
+}  // namespace
+
+extern "C" int cpg_bn_relu_pool_fwd(const float *x, const float *gamma, const float *beta, float eps, float momentum,
+                                    float *running_mean, float *running_var, float *mean, float *invstd, float *y_pooled,
+                                    int32_t N, int32_t C, int32_t H, int32_t W, int32_t train, void *ws, size_t ws_bytes,
+                                    void *stream_v) {
+    BnDims d;
+    PoolDims p;
+    int rc = make_dims(N, C, H * W, d);
+    if (rc) return rc;
+    rc = make_pool(H, W, p);
+    if (rc) return rc;
+    CPG_REQUIRE(x && gamma && beta && mean && invstd && y_pooled, "cpg_bn_relu_pool_fwd: null pointer");
+    CPG_REQUIRE((((uintptr_t)x) & 7) == 0, "cpg_bn_relu_pool_fwd: x must be 8-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (train) {
+        CPG_REQUIRE(ws != nullptr, "cpg_bn_relu_pool_fwd: workspace required in training mode");
+        if (ws_bytes < cpg_bn_workspace_bytes(N, C, H * W)) return fail(CPG_E_WORKSPACE, "cpg_bn_relu_pool_fwd: workspace too small");
+        double *partial = (double *)ws;
+        hipLaunchKernelGGL(k_bn_stats, dim3(C, d.slices), dim3(kThreads), 0, stream, x, d, partial);
+        hipLaunchKernelGGL(k_bn_finalize, dim3((C + 63) / 64), dim3(64), 0, stream, partial, d, eps, momentum, mean, invstd,
+                           running_mean, running_var);
+    }
+    const bool wave = p.wins < 1024;
+    if (wave)
+        hipLaunchKernelGGL(k_bnp_apply<64>, dim3(pool_grid(d, p, true)), dim3(kThreads), 0, stream, x, y_pooled, d, p, mean, invstd, gamma, beta);
+    else
+        hipLaunchKernelGGL(k_bnp_apply<256>, dim3(pool_grid(d, p, false)), dim3(kThreads), 0, stream, x, y_pooled, d, p, mean, invstd, gamma, beta);
+    CPG_CHECK_LAUNCH("cpg_bn_relu_pool_fwd");
+    return CPG_OK;
+}
+
+extern "C" int cpg_bn_relu_pool_bwd(const float *x, const float *g_pooled, const float *gamma, const float *beta,
+                                    const float *mean, const float *invstd, float *gx, float *dgamma, float *dbeta, int32_t N,
+                                    int32_t C, int32_t H, int32_t W, int32_t train, void *ws, size_t ws_bytes, void *stream_v) {
+    BnDims d;
+    PoolDims p;
+    int rc = make_dims(N, C, H * W, d);
+    if (rc) return rc;
+    rc = make_pool(H, W, p);
+    if (rc) return rc;
+    CPG_REQUIRE(x && g_pooled && gamma && beta && mean && invstd && gx && dgamma && dbeta && ws, "cpg_bn_relu_pool_bwd: null pointer");
+    CPG_REQUIRE((((uintptr_t)x) & 7) == 0 && (((uintptr_t)gx) & 7) == 0, "cpg_bn_relu_pool_bwd: x / gx must be 8-byte aligned");
+    if (ws_bytes < cpg_bn_workspace_bytes(N, C, H * W)) return fail(CPG_E_WORKSPACE, "cpg_bn_relu_pool_bwd: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_v;
+    double *partial = (double *)ws;
+    float *coef = (float *)(partial + (size_t)C * d.slices * 2);
+    hipLaunchKernelGGL(k_bnp_bwd_reduce, dim3(C, d.slices), dim3(kThreads), 0, stream, x, g_pooled, d, p, mean, invstd, gamma, beta, partial);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 63) / 64), dim3(64), 0, stream, partial, d, dgamma, dbeta, coef);
+    const bool wave = p.wins < 1024;
+    const dim3 grid(pool_grid(d, p, wave)), block(kThreads);
+    if (wave && train) hipLaunchKernelGGL((k_bnp_bwd_apply<true, 64>), grid, block, 0, stream, x, g_pooled, gx, d, p, mean, invstd, gamma, beta, coef);
+    else if (wave) hipLaunchKernelGGL((k_bnp_bwd_apply<false, 64>), grid, block, 0, stream, x, g_pooled, gx, d, p, mean, invstd, gamma, beta, coef);
+    else if (train) hipLaunchKernelGGL((k_bnp_bwd_apply<true, 256>), grid, block, 0, stream, x, g_pooled, gx, d, p, mean, invstd, gamma, beta, coef);
+    else hipLaunchKernelGGL((k_bnp_bwd_apply<false, 256>), grid, block, 0, stream, x, g_pooled, gx, d, p, mean, invstd, gamma, beta, coef);
+    CPG_CHECK_LAUNCH("cpg_bn_relu_pool_bwd");
+    return CPG_OK;
+}

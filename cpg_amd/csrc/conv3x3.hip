@@ -387,9 +387,9 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
 
     const int a_base = (wco * 32 + li) * Cfg::LDG + lh;                 // gy[co][pix], pix = 2s + lh
     const int b_base = (wci * 32 + li) * Cfg::PLANE + lh;               // x[ci][(r+kh)*PW + c + kw], c = 2s' + lh
-    // The 32 patch loads of unit u+1 fly during the MFMAs of unit u; the 16 gy loads are issued after them
-    // (9 accumulators + 48 staged values + operands do not fit 256 registers without spilling) and overlap
-    // the barrier wait and the other resident block's MFMAs.
+    // The 48 staging loads of unit u+1 (32 patch + 16 gy) are issued before the MFMAs of unit u and land in
+    // registers meanwhile; 9 accumulators (144) + 48 staged values fit the 256-register budget of two waves
+    // per SIMD only because the row loop below is not unrolled.
     auto compute = [&](const float *stage) {
         const float *gs = stage, *xs = stage + Cfg::G_ELEMS;
 #pragma unroll 1
@@ -417,12 +417,12 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
         for (int u = u0; u < u1; ++u) {
             const int cur = (u - u0) & 1;
             const bool more = u + 1 < u1;
-            if (more) fetch_x(u + 1);
-            compute(smem + cur * Cfg::STAGE);
             if (more) {
+                fetch_x(u + 1);
                 fetch_g(u + 1);
-                put(smem + (cur ^ 1) * Cfg::STAGE);
             }
+            compute(smem + cur * Cfg::STAGE);
+            if (more) put(smem + (cur ^ 1) * Cfg::STAGE);
             __syncthreads();
         }
     } else {
@@ -430,9 +430,11 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
             __syncthreads();                 // previous unit's operand reads are done
             put(smem);
             __syncthreads();
-            if (u + 1 < u1) fetch_x(u + 1);
+            if (u + 1 < u1) {                // all 48 loads of the next unit fly during the MFMAs below
+                fetch_x(u + 1);
+                fetch_g(u + 1);
+            }
             compute(smem);
-            if (u + 1 < u1) fetch_g(u + 1);
         }
     }
     // partial result: part[split][co][ci][tap]

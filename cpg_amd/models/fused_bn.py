@@ -59,6 +59,62 @@ class _BnReluFn(torch.autograd.Function):
         return gx, dgamma, dbeta, None, None, None, None, None, None
 
 
+class _BnReluPoolFn(torch.autograd.Function):
+    """BatchNorm2d -> ReLU -> MaxPool2d(2, 2); only the pooled tensor is written."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, training):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        L = _lib.lib()
+        y = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        if training:
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        else:
+            mean, invstd = running_mean, torch.rsqrt(running_var + eps)
+        ws, nb = _lib.workspace(L.cpg_bn_workspace_bytes(N, C, H * W), x.device)
+        rc = L.cpg_bn_relu_pool_fwd(_lib.dptr(x, name='input'), _lib.dptr(gamma, name='bn.weight'), _lib.dptr(beta, name='bn.bias'),
+                                    float(eps), float(momentum), _lib.dptr(running_mean if training else None),
+                                    _lib.dptr(running_var if training else None), _lib.dptr(mean), _lib.dptr(invstd),
+                                    _lib.dptr(y), N, C, H, W, int(training), _lib.dptr(ws), nb, _lib.stream_ptr())
+        _lib.check('cpg_bn_relu_pool_fwd', rc)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.training = bool(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, gp):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        gp = gp.contiguous()
+        L = _lib.lib()
+        gx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        ws, nb = _lib.workspace(L.cpg_bn_workspace_bytes(N, C, H * W), x.device)
+        rc = L.cpg_bn_relu_pool_bwd(_lib.dptr(x), _lib.dptr(gp, name='grad_output'), _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(mean),
+                                    _lib.dptr(invstd), _lib.dptr(gx), _lib.dptr(dgamma), _lib.dptr(dbeta), N, C, H, W,
+                                    int(ctx.training), _lib.dptr(ws), nb, _lib.stream_ptr())
+        _lib.check('cpg_bn_relu_pool_bwd', rc)
+        return gx, dgamma, dbeta, None, None, None, None, None
+
+
+def _is_pool2(m):
+    def pair(v):
+        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    return (isinstance(m, nn.MaxPool2d) and pair(m.kernel_size) == (2, 2) and pair(m.stride) == (2, 2) and pair(m.padding) == (0, 0)
+            and pair(m.dilation) == (1, 1) and not m.ceil_mode and not m.return_indices)
+
+
+def bn_relu_pool(x, bn):
+    """max_pool2d(relu(bn(x)), 2, 2) with `bn` an nn.BatchNorm2d module; H and W must be even."""
+    training = bn.training or not bn.track_running_stats
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BnReluPoolFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, training)
+
+
 def fusable(bn, x):
     """An affine, stat-tracking (or eval-mode) BatchNorm2d on a 4-D fp32 HIP tensor with the default
     exponential-average momentum -- everything the CPG topologies construct."""
@@ -76,10 +132,11 @@ def bn_relu(x, bn, relu=True):
 
 
 class FusedSequential(nn.Sequential):
-    """nn.Sequential that runs [masked conv] -> BatchNorm2d -> ReLU triples through the fused kernels.
+    """nn.Sequential that runs BatchNorm2d -> ReLU (-> MaxPool2d(2, 2)) groups through the fused kernels.
     Module registration (names, parameters, buffers) is exactly nn.Sequential's."""
 
     fuse = True
+    fuse_pool = True
 
     def forward(self, input):
         mods = list(self._modules.values())
@@ -88,6 +145,11 @@ class FusedSequential(nn.Sequential):
             m = mods[i]
             if (self.fuse and i + 1 < n and isinstance(m, nn.BatchNorm2d) and isinstance(mods[i + 1], nn.ReLU)
                     and fusable(m, input)):
+                if (self.fuse_pool and i + 2 < n and _is_pool2(mods[i + 2]) and input.shape[2] % 2 == 0
+                        and input.shape[3] % 2 == 0 and m.track_running_stats):
+                    input = bn_relu_pool(input, m)
+                    i += 3
+                    continue
                 input = bn_relu(input, m, relu=True)
                 i += 2
                 continue

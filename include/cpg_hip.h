@@ -163,6 +163,19 @@ int cpg_bn_relu_bwd(const float *x, const float *gy, const float *gamma, const f
                     const float *invstd, float *gx, float *dgamma, float *dbeta, int32_t N, int32_t C,
                     int32_t HW, int32_t relu, int32_t train, void *ws, size_t ws_bytes, void *stream);
 
+/* BatchNorm2d -> ReLU -> MaxPool2d(2, 2) fused (the 5 VGG blocks that end in 'M', models/vgg.py:131-141).
+ * y_pooled / g_pooled: [N][C][H/2][W/2]; H and W even.  train != 0: batch statistics are computed (and
+ * running stats updated) first; train == 0: `mean` / `invstd` are inputs.  The un-pooled activation is never
+ * written: backward recomputes each window from x and routes the pooled gradient to its first maximum. */
+int cpg_bn_relu_pool_fwd(const float *x, const float *gamma, const float *beta, float eps, float momentum,
+                         float *running_mean, float *running_var, float *mean, float *invstd, float *y_pooled,
+                         int32_t N, int32_t C, int32_t H, int32_t W, int32_t train, void *ws, size_t ws_bytes,
+                         void *stream);
+int cpg_bn_relu_pool_bwd(const float *x, const float *g_pooled, const float *gamma, const float *beta,
+                         const float *mean, const float *invstd, float *gx, float *dgamma, float *dbeta,
+                         int32_t N, int32_t C, int32_t H, int32_t W, int32_t train, void *ws, size_t ws_bytes,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -498,6 +498,35 @@ def test_fused_bn_relu_matches_torch(N, C, H, W, training):
     assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked)
 
 
+@pytest.mark.parametrize('N,C,H,W', [(4, 64, 56, 56), (2, 16, 224, 224), (8, 512, 14, 14), (3, 5, 6, 10), (2, 3, 2, 2)])
+@pytest.mark.parametrize('training', [True, False])
+def test_fused_bn_relu_pool_matches_torch(N, C, H, W, training):
+    from cpg_amd.models.fused_bn import bn_relu_pool
+    g = torch.Generator().manual_seed(N * C + H + 1)
+    x = (torch.randn(N, C, H, W, generator=g) * 2.0 + 0.3)
+    gy = torch.randn(N, C, H // 2, W // 2, generator=g)
+    ref_bn, bn = nn.BatchNorm2d(C).to(DEV), nn.BatchNorm2d(C).to(DEV)
+    for m in (ref_bn, bn):
+        m.weight.data.copy_(torch.linspace(0.5, 1.5, C))
+        m.bias.data.copy_(torch.linspace(-0.3, 0.3, C))
+        m.running_mean.copy_(torch.linspace(-0.1, 0.1, C))
+        m.running_var.copy_(torch.linspace(0.8, 1.2, C))
+        m.train(training)
+    xr = x.to(DEV).requires_grad_(True)
+    xf = x.to(DEV).requires_grad_(True)
+    yr = nn.functional.max_pool2d(torch.relu(ref_bn(xr)), 2, 2)
+    yf = bn_relu_pool(xf, bn)
+    close(yf, yr.detach().cpu().numpy(), rtol=1e-4, atol=1e-5, msg='y')
+    yr.backward(gy.to(DEV))
+    yf.backward(gy.to(DEV))
+    gscale = float(xr.grad.abs().max()) + 1e-12
+    close(xf.grad, xr.grad.cpu().numpy(), rtol=1e-3, atol=2e-5 * max(1.0, gscale), msg='gx')
+    close(bn.weight.grad, ref_bn.weight.grad.cpu().numpy(), rtol=1e-3, atol=1e-3, msg='dgamma')
+    close(bn.bias.grad, ref_bn.bias.grad.cpu().numpy(), rtol=1e-3, atol=1e-3, msg='dbeta')
+    close(bn.running_mean, ref_bn.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6, msg='running_mean')
+    close(bn.running_var, ref_bn.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6, msg='running_var')
+
+
 def test_fused_sequential_equals_unfused():
     """the same VGG with FusedSequential.fuse on / off: logits and every parameter gradient agree"""
     from cpg_amd.models.fused_bn import FusedSequential
@@ -532,7 +561,18 @@ def test_resnet_spherenet_backward_matches_torch_ops(arch, width, shape, ncls, m
     in one forward + backward: parameter gradients from the HIP kernels vs the same network evaluated with
     torch's own conv (MIOpen) on the same device."""
     import torch.nn.functional as F
-    net = build(arch, width, ncls).to(DEV).train()
+    net = build(arch, width, ncls)
+    if arch == 'resnet50':
+        # the reference's N(0, 1e-3) conv init makes every BatchNorm see var << eps at step 0: round-off level
+        # differences between two conv implementations get amplified arbitrarily.  Compare at a
+        # well-conditioned point instead.
+        torch.manual_seed(2)
+        for m in net.modules():
+            if isinstance(m, nl.SharableConv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+    # BatchNorm in eval mode (fixed statistics): with batch-4 statistics over 2x2 maps in layer4 the gradient is
+    # chaotic w.r.t. round-off and no two conv implementations agree; the conv kernels are exercised identically
+    net = net.to(DEV).eval()
     g = torch.Generator().manual_seed(9)
     x = torch.randn(*shape, generator=g).to(DEV)
     t = torch.randint(0, ncls, (shape[0],), generator=g).to(DEV)
@@ -555,6 +595,5 @@ def test_resnet_spherenet_backward_matches_torch_ops(arch, width, shape, ncls, m
     for n in g_ref:
         sc = float(np.abs(g_ref[n]).max()) + 1e-20
         err = float(np.abs(g_hip[n] - g_ref[n]).max())
-        # whole-net check through ~50 BatchNorm backward passes: round-off of either conv implementation is
-        # amplified on the way down to the stem (observed 4e-3 on conv1.weight); op-level tests hold 1e-4
-        assert err <= 1e-2 * sc, '%s: max err %g vs scale %g' % (n, err, sc)
+        # whole-net check through up to ~50 BatchNorm backward passes; op-level tests hold 1e-4
+        assert err <= 5e-3 * sc, '%s: max err %g vs scale %g' % (n, err, sc)
