@@ -570,8 +570,17 @@ def test_resnet_spherenet_backward_matches_torch_ops(arch, width, shape, ncls, m
         for m in net.modules():
             if isinstance(m, nl.SharableConv2d):
                 nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
-    # BatchNorm in eval mode (fixed statistics): with batch-4 statistics over 2x2 maps in layer4 the gradient is
-    # chaotic w.r.t. round-off and no two conv implementations agree; the conv kernels are exercised identically
+        # Make the network SMOOTH for this comparison: with ReLU, one pre-activation of -1.6e-7 (HIP) vs +3.8e-7
+        # (MIOpen) at an element carrying 25 % of the peak gradient flipped its mask and moved layer2.2's
+        # gradients by 7 % although every conv matched to 1e-7 (tools/debug_resnet3.py).  Softplus / AvgPool keep
+        # the same conv shapes and data flow without kinks.
+        for mod in net.modules():
+            for name, child in list(mod.named_children()):
+                if isinstance(child, nn.ReLU):
+                    setattr(mod, name, nn.Softplus())
+                elif isinstance(child, nn.MaxPool2d):
+                    setattr(mod, name, nn.AvgPool2d(kernel_size=3, stride=2, padding=1))
+    # BatchNorm in eval mode: batch-4 statistics over the 2x2 maps of layer4 are another round-off amplifier
     net = net.to(DEV).eval()
     g = torch.Generator().manual_seed(9)
     x = torch.randn(*shape, generator=g).to(DEV)
@@ -596,4 +605,4 @@ def test_resnet_spherenet_backward_matches_torch_ops(arch, width, shape, ncls, m
         sc = float(np.abs(g_ref[n]).max()) + 1e-20
         err = float(np.abs(g_hip[n] - g_ref[n]).max())
         # whole-net check through up to ~50 BatchNorm backward passes; op-level tests hold 1e-4
-        assert err <= 5e-3 * sc, '%s: max err %g vs scale %g' % (n, err, sc)
+        assert err <= 2e-3 * sc, '%s: max err %g vs scale %g' % (n, err, sc)
