@@ -109,6 +109,21 @@ class KernelClock:
         return agg
 
 
+def pmc_traffic(family, batch):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected separately, gfx950 correction 2 x FETCH_SIZE + WRITE_SIZE; profiles/r01_traffic.json,
+    measured at batch 256, average over the 13 convs of a VGG16 pass).  None when no measurement applies."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
+            fam = json.load(f)['families'].get(family)
+        if fam is None or batch != 256:
+            return None
+        return {'hbm_bytes_per_launch': round(fam['hbm_bytes_per_launch_corrected']),
+                'algorithmic_bytes_per_launch': round(fam['algorithmic_bytes_per_launch']), 'source': 'profiles/r01_traffic.json'}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def build_model(device):
     torch.manual_seed(1)                       # reference default seed (CPG_cifar100_main_normal.py:79,135)
     net = models.custom_vgg(VGG_CFG, dataset_history=[], dataset2num_classes={}, network_width_multiplier=1.0,
@@ -284,7 +299,7 @@ def main():
             cnt, ms, fl = fam[dom]
             ach = fl / (ms * 1e-3) / 1e12
             out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                               'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(dom, a.batch),
                                'launches': cnt, 'avg_launch_ms': round(ms / cnt, 4),
                                'share_of_masked_kernel_time': round(ms / tot_ms, 3)}
             out['kernel_families'] = {k: {'launches': v[0], 'ms': round(v[1], 2), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)}

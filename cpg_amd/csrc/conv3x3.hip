@@ -279,20 +279,27 @@ struct W3Cfg {
 };
 
 template <class Cfg>
-__global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W, int M, int tiles_x, int tiles_y, int tiles_ci,
-                                                     int units_per_split, const float *__restrict__ x,
+__global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W, int M, int tiles_x, int tiles_y, int tiles_co,
+                                                     int tiles_ci, int units_per_split, const float *__restrict__ x,
                                                      const float *__restrict__ gy, float *__restrict__ part) {
     __shared__ float smem[Cfg::SMEM_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave id, provably uniform
     const int wco = sub >> 1, wci = sub & 1;
     const int li = lane & 31, lh = lane >> 5;
-    const int tci = blockIdx.x % tiles_ci, tco = blockIdx.x / tiles_ci;
+    // Block -> (split, channel tile).  All (co, ci) tiles of one split read the SAME gy / x units, so they are
+    // placed on one XCD (block b runs on XCD b % 8) and dispatched back to back: the units are then fetched
+    // from HBM once into that XCD's L2 instead of once per XCD.  PMC before this mapping: FETCH_SIZE 4-10x the
+    // algorithmic bytes (profiles/r01_traffic.json).  nsplit is a multiple of 8; speed only, never correctness.
+    const int tiles = tiles_co * tiles_ci;
+    const int xcd = blockIdx.x % kXCDs, j = blockIdx.x / kXCDs;
+    const int split = (j / tiles) * kXCDs + xcd, tile = j % tiles;
+    const int tci = tile % tiles_ci, tco = tile / tiles_ci;
     const int co0 = tco * Cfg::BMC, ci0 = tci * Cfg::BCI;
     const int HW = H * W;
     const int units_per_img = tiles_x * tiles_y;
     const int total_units = N * units_per_img;
-    const int u0 = blockIdx.y * units_per_split;
+    const int u0 = min(total_units, split * units_per_split);
     const int u1 = min(total_units, u0 + units_per_split);
     const int co_lim = M - co0 - sub, ci_lim = C - ci0 - sub;           // channel sub + 4*i is valid iff 4*i < lim
 
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
         }
     }
     // partial result: part[split][co][ci][tap]
-    float *dst = part + (int64_t)blockIdx.y * M * C * 9;
+    float *dst = part + (int64_t)split * M * C * 9;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -666,8 +673,9 @@ W3Plan w3_plan(const cpg_conv_desc *d) {
     if (want > units) want = units;
     if (want < 1) want = 1;
     if (want > 4096) want = 4096;
+    want = (want + kXCDs - 1) / kXCDs * kXCDs;                 // one split group per XCD (see k_c3_wgrad)
     p.units_per_split = (int)((units + want - 1) / want);
-    p.nsplit = (int)((units + p.units_per_split - 1) / p.units_per_split);
+    p.nsplit = (int)want;                                      // trailing splits may be empty: they write zeros
     p.ws_bytes = (size_t)p.nsplit * d->K * d->C * 9 * sizeof(float);
     return p;
 }
@@ -704,8 +712,8 @@ static int w3_launch(const cpg_conv_desc *d, const float *x, const float *gy, co
                      hipStream_t stream) {
     const W3Plan p = w3_plan<Cfg>(d);
     if (ws_bytes < p.ws_bytes) return fail(CPG_E_WORKSPACE, "cpg_conv2d_wgrad(3x3): workspace %zu < %zu bytes", ws_bytes, p.ws_bytes);
-    hipLaunchKernelGGL(k_c3_wgrad<Cfg>, dim3((unsigned)(p.tiles_co * p.tiles_ci), (unsigned)p.nsplit), dim3(256), 0, stream, d->N,
-                       d->C, d->H, d->W, d->K, p.tiles_x, p.tiles_y, p.tiles_ci, p.units_per_split, x, gy, (float *)ws);
+    hipLaunchKernelGGL(k_c3_wgrad<Cfg>, dim3((unsigned)(p.tiles_co * p.tiles_ci * p.nsplit)), dim3(256), 0, stream, d->N, d->C, d->H,
+                       d->W, d->K, p.tiles_x, p.tiles_y, p.tiles_co, p.tiles_ci, p.units_per_split, x, gy, (float *)ws);
     const int64_t out_elems = (int64_t)d->K * d->C * 9;
     hipLaunchKernelGGL(k_c3_wgrad_reduce, dim3(stream_grid(out_elems, 256)), dim3(256), 0, stream, (const float *)ws, p.nsplit,
                        out_elems, ep);
