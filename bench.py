@@ -221,8 +221,10 @@ def main():
     if a.gpus > 1 or world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        torch.cuda.set_device(local)
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        torch.cuda.set_device(local % torch.cuda.device_count())
+        # 'nccl' is RCCL on ROCm.  CPG_BENCH_BACKEND=gloo lets several ranks share one GPU for a functional test
+        # of the multi-process path on a single-GPU box (not a performance configuration).
+        dist.init_process_group(os.environ.get('CPG_BENCH_BACKEND', 'nccl'), rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     device = torch.device('cuda', torch.cuda.current_device())
