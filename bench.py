@@ -37,6 +37,7 @@ import cpg_amd.models as models                     # noqa: E402
 from cpg_amd import dist as cdist                    # noqa: E402
 from cpg_amd.models import layers as nl              # noqa: E402
 from cpg_amd.utils import Optimizers                 # noqa: E402
+from cpg_amd.utils.fused_sgd import MaskedSGD        # noqa: E402
 from cpg_amd.utils.manager import Manager            # noqa: E402
 
 VGG_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
@@ -147,8 +148,9 @@ def run_cycle(model, masks, pool, val_pool, steps, clock=None):
     def loader(n, offset):
         return [pool[(offset + i) % len(pool)] for i in range(n)]
 
-    def sgd(lr):
-        opt = torch.optim.SGD([p for p in model.parameters()], lr=lr, weight_decay=0.0, momentum=0.9, nesterov=True)
+    def sgd(lr, pruner):
+        # SGD-nesterov of CPG_cifar100_main_normal.py:339-340; the masked weights take the fused routing + step pass
+        opt = MaskedSGD([p for p in model.parameters()], pruner=pruner, lr=lr, momentum=0.9, nesterov=True)
         o = Optimizers()
         o.add(opt, lr)
         return o
@@ -157,7 +159,7 @@ def run_cycle(model, masks, pool, val_pool, steps, clock=None):
     nA = min(E, steps)
     mgr = Manager(make_args('finetune', max(1, E // 2)), model, {}, masks, loader(nA, 0), val_pool, 0, 0)
     mgr.pruner.make_finetuning_mask()
-    mgr.train(sgd(1e-2), 0, [1e-2], 0)
+    mgr.train(sgd(1e-2, mgr.pruner), 0, [1e-2], 0)
     mgr.validate(0)
     done += nA
     # phase B: prune 0.0 -> 0.1 then recovery at fixed mask
@@ -166,7 +168,7 @@ def run_cycle(model, masks, pool, val_pool, steps, clock=None):
     epoch = 1
     if remaining > 0:
         mgrB = Manager(make_args('prune', max(1, E // 2)), model, {}, masks, None, val_pool, 0, 2 * E)
-        opt = sgd(1e-3)
+        opt = sgd(1e-3, mgrB.pruner)
         while remaining > 0:
             n = min(E, remaining)
             mgrB.train_loader = loader(n, done)

@@ -219,9 +219,69 @@ __global__ __launch_bounds__(kThreads) void k_claim_free(uint8_t *__restrict__ o
     }
 }
 
+// ---------------------------------------------------------------- fused masked SGD
+// utils/prune.py:203-205 + torch.optim.SGD(momentum, nesterov, dampening 0, weight_decay 0) in ONE pass:
+//   g   = owner == cur ? gw + wd * w : 0            (gradient routing; written back so .grad is what the reference leaves)
+//   buf = first ? g : momentum * buf + g            (two roundings, as torch's _foreach_mul_ / _foreach_add_)
+//   d   = nesterov ? g + momentum * buf : buf
+//   w  -= lr * d
+// 17 B read + 12 B written per element instead of the 13 + 36 B of the routing pass plus torch's three foreach passes.
+__global__ __launch_bounds__(kThreads) void k_sgd_route(float *__restrict__ w, float *__restrict__ gw, float *__restrict__ buf,
+                                                        const uint8_t *__restrict__ owner, int cur, float wd, float lr,
+                                                        float momentum, int nesterov, int first, int64_t n, int vec_ok) {
+    const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * kThreads;
+    auto one = [&](float &wv, float &gv, float &bv, int o) {
+        const float g = (o == cur) ? fmaf(wd, wv, gv) : 0.0f;
+        const float b = first ? g : __fadd_rn(__fmul_rn(momentum, bv), g);
+        const float d = nesterov ? fmaf(momentum, b, g) : b;
+        wv = fmaf(-lr, d, wv);
+        gv = g;
+        bv = b;
+    };
+    if (vec_ok) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += nthreads) {
+            const uint32_t o4 = reinterpret_cast<const uint32_t *>(owner)[i];
+            F4 wv = reinterpret_cast<F4 *>(w)[i], gv = reinterpret_cast<F4 *>(gw)[i];
+            F4 bv = first ? F4{0.f, 0.f, 0.f, 0.f} : reinterpret_cast<F4 *>(buf)[i];
+            one(wv.x, gv.x, bv.x, o4 & 255);
+            one(wv.y, gv.y, bv.y, (o4 >> 8) & 255);
+            one(wv.z, gv.z, bv.z, (o4 >> 16) & 255);
+            one(wv.w, gv.w, bv.w, o4 >> 24);
+            reinterpret_cast<F4 *>(w)[i] = wv;
+            reinterpret_cast<F4 *>(gw)[i] = gv;
+            reinterpret_cast<F4 *>(buf)[i] = bv;
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += nthreads) {
+            float bv = first ? 0.f : buf[i];
+            one(w[i], gw[i], bv, owner[i]);
+            buf[i] = bv;
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += nthreads) {
+            float bv = first ? 0.f : buf[i];
+            one(w[i], gw[i], bv, owner[i]);
+            buf[i] = bv;
+        }
+    }
+}
+
 inline int is16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
+
+extern "C" int cpg_sgd_route_step(float *w, float *gw, float *momentum_buf, const uint8_t *owner, int32_t cur, float wd, float lr,
+                                  float momentum, int32_t nesterov, int32_t first_step, int64_t n, void *stream) {
+    CPG_REQUIRE(w && gw && momentum_buf && owner && n >= 0, "cpg_sgd_route_step: null pointer or negative n");
+    CPG_REQUIRE(cur >= 0 && cur <= 255, "cpg_sgd_route_step: owner id %d out of uint8 range", cur);
+    if (n == 0) return CPG_OK;
+    const int vec = is16(w) && is16(gw) && is16(momentum_buf) && (((uintptr_t)owner) & 3) == 0;
+    hipLaunchKernelGGL(k_sgd_route, dim3(stream_grid(n, kThreads * 4)), dim3(kThreads), 0, (hipStream_t)stream, w, gw, momentum_buf,
+                       owner, cur, wd, lr, momentum, nesterov, first_step, n, vec);
+    CPG_CHECK_LAUNCH("cpg_sgd_route_step");
+    return CPG_OK;
+}
 
 extern "C" int cpg_binarize_mask_weight(const float *w, const float *pm, float thr, float *w_eff, int64_t n,
                                         void *stream) {

@@ -1,0 +1,69 @@
+"""Fused masked SGD.
+
+`MaskedSGD` is a torch.optim.SGD whose step() handles every masked weight (SharableConv2d / SharableLinear
+`.weight`) with ONE libcpg_hip.so pass that also performs the reference's gradient routing
+(`SparsePruner.do_weight_decay_and_make_grads_zero`, utils/prune.py:203-205); all other parameters (BN affine,
+biases, the task head) take torch's own SGD path.  Results equal routing-then-torch-SGD to 1 ulp (the fused
+multiply-adds differ in rounding), including the momentum that keeps moving released / frozen weights for a few
+steps after their gradient is zeroed (SURVEY 8a note).
+
+Usage (drop-in for CPG_cifar100_main_normal.py:339-341 + utils/manager.py:67-70):
+
+    optimizer_network = MaskedSGD(params_to_optimize_via_SGD, pruner=manager.pruner, lr=lr, momentum=0.9, nesterov=True)
+    ...
+    loss.backward(); manager.pruner.do_weight_decay_and_make_grads_zero(); optimizers.step()
+
+While a MaskedSGD is attached, `do_weight_decay_and_make_grads_zero()` skips the weight part (piggymask
+gradients are still routed there) and step() does it fused; `.grad` ends up routed exactly as before.
+"""
+import torch
+
+from .. import _lib
+from ..models import layers as nl
+
+
+class MaskedSGD(torch.optim.SGD):
+    def __init__(self, params, pruner, lr, momentum=0.9, nesterov=True, **kw):
+        if kw.get('weight_decay', 0.0) != 0.0 or kw.get('dampening', 0.0) != 0.0:
+            raise ValueError('MaskedSGD mirrors the reference optimizer: weight_decay = dampening = 0 '
+                             '(the decay is applied by the gradient routing)')
+        super().__init__(params, lr=lr, momentum=momentum, nesterov=nesterov, weight_decay=0.0, dampening=0.0)
+        self.pruner = pruner
+        pruner.fused_weight_step = True          # tells the pruner to leave masked-weight grads to us
+        self._masked = {}                        # id(param) -> mask name
+
+    def _refresh(self):
+        self._masked = {}
+        for name, module in self.pruner.model.named_modules():
+            if isinstance(module, (nl.SharableConv2d, nl.SharableLinear)):
+                self._masked[id(module.weight)] = name
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if not self._masked:
+            self._refresh()
+        L = _lib.lib()
+        s = _lib.stream_ptr()
+        pr = self.pruner
+        held = []
+        for group in self.param_groups:
+            for p in group['params']:
+                name = self._masked.get(id(p))
+                if name is None or p.grad is None:
+                    continue
+                state = self.state[p]
+                first = 'momentum_buffer' not in state or state['momentum_buffer'] is None
+                if first:
+                    state['momentum_buffer'] = torch.empty_like(p, memory_format=torch.contiguous_format)
+                owner = pr._owner(name, p.data)
+                rc = L.cpg_sgd_route_step(_lib.dptr(p.data, name='weight'), _lib.dptr(p.grad, name='weight.grad'),
+                                          _lib.dptr(state['momentum_buffer'], name='momentum'), _lib.dptr(owner, torch.uint8, 'mask'),
+                                          int(pr.current_dataset_idx), float(pr.args.weight_decay), float(group['lr']),
+                                          float(group['momentum']), int(bool(group['nesterov'])), int(first), p.numel(), s)
+                _lib.check('cpg_sgd_route_step', rc)
+                held.append((p, p.grad))
+                p.grad = None                    # hide from torch's SGD for the rest of this step
+        loss = super().step(closure)
+        for p, g in held:
+            p.grad = g
+        return loss

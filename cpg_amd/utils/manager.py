@@ -9,8 +9,9 @@ as the reference does (utils/manager.py:105).
 What is not reproduced is the reference's per-step host stall: loss / accuracy accumulate on the
 device and the progress line (tqdm postfix with the mask statistics) is refreshed on a wall-clock
 interval instead of forcing `.item()` + 15 reductions + `.cpu()` every step.  Returned values are
-identical.  Checkpoint save/load and LFW evaluation (utils/manager.py:156-320) are outside the hot
-path and not implemented here.
+identical.  Checkpoint save / load (utils/manager.py:198-320) delegate to
+utils/checkpoint.py and keep the reference's file format; LFW evaluation (:156-195) needs real face pairs and
+sklearn and is out of scope.
 """
 import logging
 import time
@@ -20,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import Metric, classification_accuracy
+from . import checkpoint as ckpt
 from .prune import SparsePruner
 
 try:                                    # progress bar is cosmetic; tqdm is present in the image
@@ -167,3 +169,23 @@ class Manager(object):
             logging.info(('In validate()-> Val Ep. #{} '.format(epoch_idx + 1)
                           + ', '.join(['{}: {}'.format(k, v) for k, v in summary.items()])))
         return val_accuracy.avg.item()
+
+    # ------------------------------------------------------------------ checkpoints (utils/manager.py:198-320)
+    def _path(self, folder, epoch):
+        return self.args.checkpoint_format.format(save_folder=folder, epoch=epoch)
+
+    def save_checkpoint(self, optimizers, epoch_idx, save_folder):
+        """Same dict layout as the reference; optimizer state is not saved (momentum restarts each phase)."""
+        ckpt.save_checkpoint(self.model, self.pruner.masks, self.shared_layer_info, self.args.dataset,
+                             self._path(save_folder, epoch_idx + 1))
+
+    def load_checkpoint(self, optimizers, resume_from_epoch, save_folder):
+        if resume_from_epoch > 0:
+            state = torch.load(self._path(save_folder, resume_from_epoch), map_location='cpu', weights_only=False)
+            ckpt.load_state(self.model, state['model_state_dict'], for_evaluate=False)
+
+    def load_checkpoint_only_for_evaluate(self, resume_from_epoch, save_folder):
+        if resume_from_epoch > 0:
+            state = torch.load(self._path(save_folder, resume_from_epoch), map_location='cpu', weights_only=False)
+            ckpt.load_state(self.model, state['model_state_dict'], for_evaluate=True)
+            ckpt.attach_task_layers(self.model, self.shared_layer_info, self.args.dataset)

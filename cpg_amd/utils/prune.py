@@ -50,6 +50,7 @@ class SparsePruner(object):
             print("We do not support '{}' mode".format(args.mode))
             sys.exit(-1)
         self.inference_dataset_idx = inference_dataset_idx
+        self.fused_weight_step = False   # set by utils.fused_sgd.MaskedSGD: it routes masked-weight grads itself
         self._mutations = 0          # bumped whenever a kernel of ours rewrites a mask in place
         self._hist_key = None
         self._hist = None
@@ -223,6 +224,18 @@ class SparsePruner(object):
         mode = {'finetune': _lib.MODE_FINETUNE, 'prune': _lib.MODE_PRUNE}.get(self.args.mode)
         for name, module in self._layers():
             w = module.weight
+            if self.fused_weight_step:
+                # weight part deferred to MaskedSGD.step(); only the piggymask gradient is routed here
+                pm = module.piggymask
+                if pm is None or pm.grad is None or mode is None:
+                    continue
+                owner = self._owner(name, w.data)
+                scratch = torch.zeros_like(w.data)
+                rc = L.cpg_route_grads(_lib.dptr(scratch), _lib.dptr(w.data.contiguous(), name='weight'),
+                                       _lib.dptr(owner, torch.uint8, 'mask'), int(self.current_dataset_idx), 0.0,
+                                       _lib.dptr(pm.grad.data, name='piggymask.grad'), mode, scratch.numel(), s)
+                _lib.check('cpg_route_grads', rc)
+                continue
             if w.grad is None:
                 # the reference still routes a piggymask grad here; without a weight grad only that part applies
                 gw = None

@@ -142,6 +142,14 @@ int cpg_zero_pruned(float *w, const uint8_t *owner, int64_t n, void *stream);
 /* make_finetuning_mask (:233-243): owner[owner == 0] = new_idx */
 int cpg_claim_free(uint8_t *owner, int32_t new_idx, int64_t n, void *stream);
 
+/* ---- fused masked SGD step, one layer ----
+ * do_weight_decay_and_make_grads_zero (utils/prune.py:203-205) + torch.optim.SGD(lr, momentum, nesterov,
+ * dampening 0, weight_decay 0) (CPG_cifar100_main_normal.py:339-340) in one pass over w / gw / momentum / owner:
+ * g = owner == cur ? gw + wd*w : 0;  buf = first_step ? g : momentum*buf + g;  w -= lr * (nesterov ? g + momentum*buf : buf).
+ * gw is overwritten with the routed gradient g (the state the reference leaves in .grad). */
+int cpg_sgd_route_step(float *w, float *gw, float *momentum_buf, const uint8_t *owner, int32_t cur, float wd,
+                       float lr, float momentum, int32_t nesterov, int32_t first_step, int64_t n, void *stream);
+
 /* ---- nn.BatchNorm2d -> nn.ReLU(inplace) after each masked conv ----
  * (models/vgg.py:137-141: `layers += [conv2d, nn.BatchNorm2d(c), nn.ReLU(inplace=True)]`).
  * x, y, gy, gx: NCHW fp32 with HW = H*W; gamma/beta/mean/invstd/running_*: C floats.

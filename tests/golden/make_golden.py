@@ -499,7 +499,36 @@ def gen_angle():
     save('angle_head', w=lin.weight, x=x, t=t, cos=cos, phi=phi, losses=np.array(losses), gw=torch.stack(gws), gx=x.grad)
 
 
+def gen_checkpoint():
+    """A checkpoint file written by the REFERENCE's Manager.save_checkpoint (utils/manager.py:198-231) for a narrow
+    two-task VGG (task 2 carries piggymasks), plus the tensors needed to check a load: the interoperability fixture
+    for cpg_amd/utils/checkpoint.py."""
+    from utils.manager import Manager
+    width = 0.0625
+    net = build_ref('vgg_cifar100', width, dataset='t1')
+    net.add_dataset('t2', 5)
+    net.set_dataset('t2')
+    model = nn.DataParallel(net)
+    g = torch.Generator().manual_seed(21)
+    masks, shared = {}, {'t2': {k: {} for k in ('bias', 'bn_layer_running_mean', 'bn_layer_running_var', 'bn_layer_weight',
+                                                 'bn_layer_bias', 'piggymask')}}
+    shared['t2']['network_width_multiplier'] = width
+    for name, mod in model.named_modules():
+        if isinstance(mod, (nl.SharableConv2d, nl.SharableLinear)):
+            masks[name] = torch.randint(0, 3, mod.weight.shape, generator=g, dtype=torch.uint8)
+            mod.piggymask = nn.Parameter(torch.rand(mod.weight.shape, generator=g) * 0.012)
+        elif isinstance(mod, nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+    fake = types.SimpleNamespace(args=types.SimpleNamespace(checkpoint_format='{save_folder}/checkpoint-{epoch}.pth.tar', dataset='t2'),
+                                 model=model, shared_layer_info=shared, pruner=types.SimpleNamespace(masks=masks))
+    Manager.save_checkpoint(fake, None, 6, OUT)
+    os.replace(os.path.join(OUT, 'checkpoint-7.pth.tar'), os.path.join(OUT, 'reference_checkpoint-7.pth.tar'))
+    print('wrote reference_checkpoint-7.pth.tar', os.path.getsize(os.path.join(OUT, 'reference_checkpoint-7.pth.tar')))
+
+
 if __name__ == '__main__':
+    gen_checkpoint()
     gen_angle()
     gen_binarizer()
     gen_conv()

@@ -156,3 +156,67 @@ def test_angle_head_matches_reference():
         assert abs(float(loss) - g['losses'][k]) < 1e-5
         np.testing.assert_allclose(lin.weight.grad.numpy(), g['gw'][k], rtol=1e-4, atol=1e-6)
     assert crit.it == 3
+
+
+def _two_task_vgg(width):
+    torch.manual_seed(5)
+    kw = dict(dataset_history=[], dataset2num_classes={}, network_width_multiplier=width, shared_layer_info={})
+    net = M.custom_vgg_cifar100(VGG_CFG, **kw)
+    net.add_dataset('t1', 5)
+    net.add_dataset('t2', 5)
+    net.set_dataset('t2')
+    return net
+
+
+def test_checkpoint_written_by_the_reference_loads(tmp_path):
+    """tests/golden/reference_checkpoint-7.pth.tar was written by the reference's Manager.save_checkpoint; our loader
+    restores every tensor, and our writer produces the same dictionary layout."""
+    from cpg_amd.utils import checkpoint as ckpt
+    ref = torch.load(os.path.join(GOLDEN, 'reference_checkpoint-7.pth.tar'), map_location='cpu', weights_only=False)
+    assert set(ref) == {'model_state_dict', 'dataset_history', 'dataset2num_classes', 'masks', 'shared_layer_info'}
+    net = _two_task_vgg(0.0625)
+    model = _Wrap(net)
+    ckpt.load_state(model, ref['model_state_dict'], for_evaluate=False)
+    sd = net.state_dict()
+    for k, v in ref['model_state_dict'].items():
+        if 'piggymask' in k or k.startswith('classifier.'):
+            continue
+        assert torch.equal(sd[k], v), k
+    # the per-task layers re-attach (inference path) and become the module's own tensors
+    info = ref['shared_layer_info']
+    ckpt.load_state(model, ref['model_state_dict'], for_evaluate=True)
+    ckpt.attach_task_layers(model, info, 't2')
+    assert torch.equal(net.features[1].running_mean, info['t2']['bn_layer_running_mean']['features.1'])
+    # our writer: same keys at every level, same tensors
+    for name, mod in net.named_modules():
+        if isinstance(mod, (nl.SharableConv2d, nl.SharableLinear)):
+            mod.piggymask = info['t2']['piggymask'][name]
+    path = str(tmp_path / 'ours.pth.tar')
+    ckpt.save_checkpoint(model, ref['masks'], {'t2': {'network_width_multiplier': 0.0625}}, 't2', path)
+    ours = torch.load(path, map_location='cpu', weights_only=False)
+    assert set(ours) == set(ref) and ours['dataset_history'] == ref['dataset_history']
+    assert set(ours['model_state_dict']) == set(ref['model_state_dict'])
+    for k in ref['model_state_dict']:
+        if not k.startswith('classifier'):
+            assert torch.equal(ours['model_state_dict'][k], ref['model_state_dict'][k]), k
+    for key, table in ref['shared_layer_info']['t2'].items():
+        if isinstance(table, dict):
+            assert set(ours['shared_layer_info']['t2'][key]) == set(table), key
+    assert set(ours['masks']) == set(ref['masks'])
+
+
+def test_checkpoint_growth_and_crop():
+    """resume into a WIDER network copies into the top-left corner (utils/manager.py:247-257); inference into a
+    NARROWER one crops (utils/manager.py:286-297)."""
+    from cpg_amd.utils import checkpoint as ckpt
+    small, big = _two_task_vgg(0.0625), _two_task_vgg(0.125)
+    ssd = {k: v.clone() for k, v in small.state_dict().items()}
+    before = {k: v.clone() for k, v in big.state_dict().items()}
+    ckpt.load_state(_Wrap(big), ssd, for_evaluate=False)
+    w_s, w_b = ssd['features.3.weight'], big.state_dict()['features.3.weight']
+    assert torch.equal(w_b[:w_s.shape[0], :w_s.shape[1]], w_s)
+    assert torch.equal(w_b[w_s.shape[0]:], before['features.3.weight'][w_s.shape[0]:])
+    # (heads are rebuilt at each task's own width by _reconstruct_classifiers, so they never need cropping)
+    bsd = {k: v.clone() for k, v in big.state_dict().items() if not k.startswith('classifiers.')}
+    ckpt.load_state(_Wrap(small), bsd, for_evaluate=True)
+    assert torch.equal(small.state_dict()['features.45.weight'], bsd['features.45.weight'][:256, :32])

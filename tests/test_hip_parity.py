@@ -606,3 +606,152 @@ def test_resnet_spherenet_backward_matches_torch_ops(arch, width, shape, ncls, m
         err = float(np.abs(g_hip[n] - g_ref[n]).max())
         # whole-net check through up to ~50 BatchNorm backward passes; op-level tests hold 1e-4
         assert err <= 2e-3 * sc, '%s: max err %g vs scale %g' % (n, err, sc)
+
+
+# --------------------------------------------------------------------------- fused masked SGD
+@pytest.mark.parametrize('nesterov', [True, False])
+def test_masked_sgd_equals_routing_then_torch_sgd(nesterov):
+    """4 steps of MaskedSGD vs routing + torch.optim.SGD on two copies of a narrow VGG: weights, routed grads and
+    momentum buffers agree to fp32 round-off; owner masks mixed (current task, older task, free)."""
+    from cpg_amd.utils.fused_sgd import MaskedSGD
+    nets, pruners, opts = [], [], []
+    for fused in (False, True):
+        net = build('vgg_cifar100', 0.125).to(DEV)
+        model = Wrap(net)
+        g = torch.Generator().manual_seed(11)
+        masks = {n: torch.randint(0, 3, m.weight.shape, generator=g, dtype=torch.uint8).to(DEV) for n, m in model.named_modules()
+                 if isinstance(m, (nl.SharableConv2d, nl.SharableLinear))}
+        args = types.SimpleNamespace(mode='prune', dataset='t1', finetune_again=False, target_sparsity=0.3, initial_sparsity=0.0,
+                                     pruning_frequency=100, weight_decay=4e-5, network_width_multiplier=0.125)
+        pruner = SparsePruner(model, masks, args, 0, 8, 1)
+        if fused:
+            opt = MaskedSGD(model.parameters(), pruner=pruner, lr=1e-2, momentum=0.9, nesterov=nesterov)
+        else:
+            opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9, nesterov=nesterov)
+        nets.append(model); pruners.append(pruner); opts.append(opt)
+    g = torch.Generator().manual_seed(12)
+    for step in range(4):
+        x = torch.randn(8, 3, 32, 32, generator=g).to(DEV)
+        t = torch.randint(0, 5, (8,), generator=g).to(DEV)
+        for model, pruner, opt in zip(nets, pruners, opts):
+            model.train()
+            opt.zero_grad()
+            nn.functional.cross_entropy(model(x), t).backward()
+            pruner.do_weight_decay_and_make_grads_zero()
+            opt.step()
+        for (n, p), (_, q) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+            sc = float(p.abs().max()) + 1e-12
+            np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=0, atol=2e-6 * sc, err_msg='%s step %d' % (n, step))
+            if not nesterov:     # torch >= 2's foreach Nesterov path overwrites .grad with g + momentum * buf in place;
+                gs = float(p.grad.abs().max()) + 1e-20      # the fused step leaves the routed gradient g (as torch 1.x did)
+                np.testing.assert_allclose(q.grad.cpu().numpy(), p.grad.cpu().numpy(), rtol=2e-3, atol=1e-5 * gs, err_msg='grad ' + n)
+    for p, q in zip(nets[0].parameters(), nets[1].parameters()):
+        b0, b1 = opts[0].state[p].get('momentum_buffer'), opts[1].state[q].get('momentum_buffer')
+        np.testing.assert_allclose(b1.cpu().numpy(), b0.cpu().numpy(), rtol=2e-3, atol=1e-5 * (float(b0.abs().max()) + 1e-20))
+
+
+# --------------------------------------------------------------------------- two-task sequence through the driver (8f.4)
+def test_two_task_sequence_matches_oracle():
+    """Task 1 (finetune, prune with a rank-prune event) then task 2 (piggymasks picked through the binariser, SGD on
+    the free slots + Adam on the piggymasks, finetune-mode gradient routing) on a narrow VGG16-BN through
+    cpg_amd.driver.CPGSession, step by step against the CPU oracle running the same sequence."""
+    from cpg_amd.driver import CPGSession, default_args
+    from oracle import net as onet
+    width, B = 0.125, 8
+    torch.manual_seed(1)
+    sess = CPGSession('custom_vgg_cifar100', width, device=DEV)
+    captured = []
+    g = torch.Generator().manual_seed(31)
+    batches = [(torch.randn(B, 3, 32, 32, generator=g), torch.randint(0, 5, (B,), generator=g)) for _ in range(9)]
+
+    # ---- oracle twin
+    torch.manual_seed(1)
+    ref = onet.OracleVGG(width, 'cifar100')
+
+    def sync_heads():
+        for i, head in enumerate(sess.net.classifiers):
+            ref.classifiers[i].load_state_dict({k: v.cpu() for k, v in head.state_dict().items()})
+
+    def oracle_step(pruner, opts, x, t, prune_step=None):
+        for o in opts:
+            o.zero_grad()
+        out = ref(x)
+        loss = nn.functional.cross_entropy(out, t)
+        loss.backward()
+        pruner.route()
+        for o in opts:
+            o.step()
+        if pruner.mode == 'prune':
+            pruner.gradually_prune(prune_step)
+        return out.detach().numpy()
+
+    def hip_steps(mgr, opts, xs, start_step=0):
+        outs = []
+        h = sess.model.register_forward_hook(lambda m, i, o: outs.append(o.detach().cpu().numpy()))
+        mgr.train_loader = [(x.to(DEV), t.to(DEV)) for x, t in xs]
+        mgr.train(opts, 0, list(opts.lrs), start_step)
+        h.remove()
+        return outs
+
+    def compare(tag, outs, refs):
+        for k, (a, b) in enumerate(zip(outs, refs)):
+            np.testing.assert_allclose(a, b, rtol=2e-3, atol=3e-6, err_msg='%s step %d' % (tag, k))
+
+    # ================= task 1: finetune (3 steps), prune 0 -> 0.3 (3 steps, event at step 1) =================
+    args = default_args(dataset='t1', network_width_multiplier=width, lr=1e-2, pruning_frequency=1, cuda=True)
+    sess.start_task('t1', 5)
+    ref.add_dataset('t1', 5)
+    ref.set_dataset('t1')
+    sync_heads()
+    for (n, p), (_, q) in zip(sess.net.features.named_parameters(), ref.features.named_parameters()):
+        assert torch.equal(p.detach().cpu(), q.detach()), n               # same seeded init
+    from cpg_amd.utils.manager import Manager
+    a1 = default_args(**{**vars(args), 'mode': 'finetune'})
+    mgr = Manager(a1, sess.model, sess.shared_layer_info, sess.masks, None, None, 0, 0)
+    mgr.pruner.make_finetuning_mask()
+    opts = sess.make_optimizers(a1)
+    owners = {n: np.zeros(tuple(m.weight.shape), np.uint8) for n, m in ref.masked_layers()}
+    rp = onet.OraclePruner(ref, owners, 'finetune', 0, 1, 0, 0, 1, 0.0, 0.3, 4e-5, width)
+    rp.claim_free()
+    ropt = [torch.optim.SGD(ref.parameters(), lr=1e-2, momentum=0.9, nesterov=True)]
+    ref.train()
+    compare('t1 finetune', hip_steps(mgr, opts, batches[0:3]), [oracle_step(rp, ropt, x, t) for x, t in batches[0:3]])
+
+    a2 = default_args(**{**vars(args), 'mode': 'prune', 'initial_sparsity': 0.0, 'target_sparsity': 0.3, 'lr': 1e-3})
+    mgr = Manager(a2, sess.model, sess.shared_layer_info, sess.masks, None, None, 0, 2)
+    opts = sess.make_optimizers(a2)
+    rp2 = onet.OraclePruner(ref, rp.owners, 'prune', 1, 1, 0, 2, 1, 0.0, 0.3, 4e-5, width)
+    ropt = [torch.optim.SGD(ref.parameters(), lr=1e-3, momentum=0.9, nesterov=True)]
+    compare('t1 prune', hip_steps(mgr, opts, batches[3:6]), [oracle_step(rp2, ropt, x, t, s) for s, (x, t) in enumerate(batches[3:6])])
+    mism = sum(int((sess.masks['module.' + n].cpu().numpy() != rp2.owners[n]).sum()) for n, _ in ref.masked_layers())
+    assert mism <= 1e-4 * sum(v.numel() for v in sess.masks.values()), mism
+    assert abs(mgr.pruner.calculate_sparsity() - rp2.sparsity()) < 2e-4
+    mgr.validate(0) if False else mgr.pruner.apply_mask()
+    rp2.apply_mask()
+
+    # ================= task 2: piggymask finetune (3 steps) ==================================================
+    sess.start_task('t2', 5)
+    ref.add_dataset('t2', 5)
+    ref.set_dataset('t2')
+    sync_heads()
+    for n, m in ref.masked_layers():
+        m.piggymask = nn.Parameter(torch.full(tuple(m.weight.shape), 0.01))
+    a3 = default_args(**{**vars(args), 'dataset': 't2', 'mode': 'finetune', 'lr': 1e-2, 'lr_mask': 5e-4})
+    mgr = Manager(a3, sess.model, sess.shared_layer_info, sess.masks, None, None, 0, 0)
+    assert mgr.pruner.current_dataset_idx == 1 and mgr.inference_dataset_idx == 2
+    mgr.pruner.make_finetuning_mask()
+    opts = sess.make_optimizers(a3)
+    assert len(opts.optimizers) == 2                       # SGD + Adam on the piggymasks
+    rp3 = onet.OraclePruner(ref, rp2.owners, 'finetune', 1, 2, 0, 0, 1, 0.0, 0.3, 4e-5, width)
+    rp3.claim_free()
+    wparams = [p for n, p in ref.named_parameters() if 'piggymask' not in n and 'classifiers.0.' not in n]
+    pparams = [p for n, p in ref.named_parameters() if 'piggymask' in n]
+    ropt = [torch.optim.SGD(wparams, lr=1e-2, momentum=0.9, nesterov=True), torch.optim.Adam(pparams, lr=5e-4)]
+    compare('t2 finetune', hip_steps(mgr, opts, batches[6:9]), [oracle_step(rp3, ropt, x, t) for x, t in batches[6:9]])
+    # piggymasks and their routing agree: grads only on older-task slots, values moved identically
+    for n, m in ref.masked_layers():
+        hip_pm = dict(sess.net.named_modules())[n].piggymask
+        np.testing.assert_allclose(hip_pm.detach().cpu().numpy(), m.piggymask.detach().numpy(), rtol=0, atol=2e-5, err_msg=n)
+        older = (rp3.owners[n] > 0) & (rp3.owners[n] < 2)
+        assert not np.any(hip_pm.grad.cpu().numpy()[~older]), n
+    assert abs(mgr.pruner.calculate_shared_part_ratio() - 1.0) < 1e-12    # every piggymask value still > 0.005
