@@ -12,7 +12,7 @@ import sys
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libcpg_hip.so')
+LIB_PATH = os.environ.get('CPG_HIP_LIB') or os.path.join(_HERE, 'lib', 'libcpg_hip.so')   # override: A/B kernel experiments
 
 CPG_OK = 0
 CPG_E_KRANGE = 2

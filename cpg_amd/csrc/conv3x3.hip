@@ -44,6 +44,13 @@ __device__ __forceinline__ int opaque_mem(int v) {
 __device__ __forceinline__ float ld_sv(const float *sbase, unsigned byte_off) {
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sbase) + byte_off);
 }
+__device__ __forceinline__ f32x4 ld_sv4(const float *sbase, unsigned byte_off) {
+    return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(sbase) + byte_off);
+}
+
+#ifndef C3_EXP
+#define C3_EXP 0
+#endif
 
 struct C3Geom {
     int N, C, H, W, M;        // C: channels of the tensor being read, M: channels being produced
@@ -122,11 +129,12 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
     // ---- staging descriptors, all fixed for the life of the block (a handful of registers) ----
     // weights: float4 (row = wrow0 + WROWS*i, 4 columns at wcol); Wp is zero padded, so no guards
     const int wcol = (tid % Cfg::W4) * 4, wrow0 = tid / Cfg::W4;
-    const float *wsrc = wp + (int64_t)wrow0 * g.Mp + m0 + wcol;
     const int wdst = wrow0 * Cfg::LDW + wcol;
-    // patch: element e = tid + 256*i of [CK][PH][PW]
-    int xoff[Cfg::NXL];            // offset inside the image for chunk 0, or -1 (zero padding / past the end)
+    // patch: element e = tid + 256*i of [CK][PH][PW]; byte offset from the chunk's first channel, 0 when the element is
+    // zero padding (the load still happens -- from a valid address -- and put() writes 0 instead)
+    unsigned xbyte[Cfg::NXL];
     int xcl[Cfg::NXL];
+    unsigned xok_fixed = 0;
 #pragma unroll
     for (int i = 0; i < Cfg::NXL; ++i) {
         const int e = tid + 256 * i;
@@ -135,31 +143,38 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
         const int pr = rem / Cfg::PW, pc = rem - pr * Cfg::PW;
         const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
         const bool ok = e < Cfg::X_ELEMS && n + img < g.N && (unsigned)gh < (unsigned)g.H && (unsigned)gw < (unsigned)g.W;
-        xoff[i] = ok ? (img * g.C + cl) * HW + gh * g.W + gw : -1;
+        xbyte[i] = ok ? (unsigned)((img * g.C + cl) * HW + gh * g.W + gw) * 4u : 0u;
+        xok_fixed |= (ok ? 1u : 0u) << i;
         xcl[i] = cl;
     }
     const float *xin = x + (int64_t)n * g.C * HW;
+    const unsigned wbyte = (unsigned)(wrow0 * g.Mp + m0 + wcol) * 4u;
 
-    // Loads are unconditional (clamped address) and their results untouched until put(): a predicated
-    // load is an exec-masked branch with its own s_waitcnt vmcnt(0), and arithmetic on a loaded value in
-    // fetch() would drag that wait in front of the MFMAs of the current chunk.
+    // Every load is `global_load v, v_fixed_byte_offset, s[uniform base]`: the per-chunk address work is a few
+    // scalar adds.  Loads are unconditional and their results untouched until put(): a predicated load is an
+    // exec-masked branch with its own s_waitcnt vmcnt(0), and arithmetic on a loaded value in fetch() would
+    // drag that wait in front of the MFMAs of the current chunk.  (Rows of the last float4 pass that lie past
+    // the chunk are read -- the packed weights carry WROWS rows of slack -- and dropped in put().)
     f32x4 rw[Cfg::NW4];             // native vector type: HIP's float4 struct kept this array in scratch memory
     float rx[Cfg::NXL];
     unsigned xok = 0;
     auto fetch = [&](int c0) {
-        const float *wc = wsrc + (int64_t)c0 * 9 * g.Mp;
+        const float *wc = wp + (int64_t)c0 * 9 * g.Mp;
 #pragma unroll
-        for (int i = 0; i < Cfg::NW4; ++i) {
-            const bool live = (Cfg::KC % Cfg::WROWS == 0) || (wrow0 + Cfg::WROWS * i < Cfg::KC);
-            rw[i] = *reinterpret_cast<const f32x4 *>(live ? wc + (int64_t)Cfg::WROWS * i * g.Mp : wp);
-        }
+        for (int i = 0; i < Cfg::NW4; ++i) rw[i] = ld_sv4(wc + (int64_t)Cfg::WROWS * i * g.Mp, wbyte);
         const float *xc = xin + (int64_t)c0 * HW;
-        xok = 0;
+        if (c0 + Cfg::CK <= g.C) {          // uniform; the ragged tail (C % CK != 0) re-checks the channel
+            xok = xok_fixed;
 #pragma unroll
-        for (int i = 0; i < Cfg::NXL; ++i) {
-            const bool ok = xoff[i] >= 0 && c0 + xcl[i] < g.C;
-            xok |= (ok ? 1u : 0u) << i;
-            rx[i] = ok ? xc[xoff[i]] : xin[0];
+            for (int i = 0; i < Cfg::NXL; ++i) rx[i] = ld_sv(xc, xbyte[i]);
+        } else {
+            xok = 0;
+#pragma unroll
+            for (int i = 0; i < Cfg::NXL; ++i) {
+                const unsigned ok = ((xok_fixed >> i) & 1u) & (c0 + xcl[i] < g.C ? 1u : 0u);
+                xok |= ok << i;
+                rx[i] = ld_sv(xc, ok ? xbyte[i] : 0u);
+            }
         }
     };
     auto put = [&](float *stage) {
@@ -202,26 +217,49 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
         const float *ws = smem + (ch & 1) * Cfg::STAGE;
         const float *xs = ws + Cfg::W_ELEMS;
         const bool more = ch + 1 < nch;
+#if C3_EXP == 1 || C3_EXP == 2
+        (void)more;
+#else
         if (more) fetch((ch + 1) * Cfg::CK);
+#endif
+        // k-step s = (channel pair p = s / 9, tap = s % 9): lanes 0-31 hold channel 2p, lanes 32-63 channel 2p+1.
+        // The operands of step s+1 are read from LDS while the MFMAs of step s run (two register sets).
+        constexpr int NS = Cfg::CK / 2 * 9;
+        float a[2][Cfg::FM], b[2][Cfg::FN];
+        auto lds_operands = [&](int st, int set) {
+            const int p = st / 9, tap = st % 9;
 #pragma unroll
-        for (int p = 0; p < Cfg::CK / 2; ++p) {
+            for (int fm = 0; fm < Cfg::FM; ++fm) a[set][fm] = ws[a_base + (2 * p * 9 + tap) * Cfg::LDW + fm * 32];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                float a[Cfg::FM], b[Cfg::FN];
+            for (int fn = 0; fn < Cfg::FN; ++fn)
+                b[set][fn] = xs[b_base[fn] + 2 * p * Cfg::PLANE + (tap / 3) * Cfg::PW + (tap % 3)];
+        };
+        lds_operands(0, 0);
 #pragma unroll
-                for (int fm = 0; fm < Cfg::FM; ++fm) a[fm] = ws[a_base + (2 * p * 9 + tap) * Cfg::LDW + fm * 32];
+        for (int st = 0; st < NS; ++st) {
+            // The next chunk is written to the OTHER LDS stage half way through this chunk's MFMAs (its loads
+            // were issued NS/2 k-steps ago), so that only the barrier -- not the LDS writes -- sits between
+            // the last MFMA of this chunk and the first operand read of the next.
+#if C3_EXP != 1 && C3_EXP != 2
+            if (st == NS / 2 && more) put(smem + ((ch + 1) & 1) * Cfg::STAGE);
+#endif
+            if (st + 1 < NS) lds_operands(st + 1, (st + 1) & 1);
+#pragma unroll
+            for (int fm = 0; fm < Cfg::FM; ++fm)
 #pragma unroll
                 for (int fn = 0; fn < Cfg::FN; ++fn)
-                    b[fn] = xs[b_base[fn] + 2 * p * Cfg::PLANE + (tap / 3) * Cfg::PW + (tap % 3)];
+                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][fm], b[st & 1][fn], acc[fm][fn], 0, 0, 0);
+#if C3_EXP != 3
 #pragma unroll
-                for (int fm = 0; fm < Cfg::FM; ++fm)
-#pragma unroll
-                    for (int fn = 0; fn < Cfg::FN; ++fn)
-                        acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fm], b[fn], acc[fm][fn], 0, 0, 0);
+            for (int i = 0; i < Cfg::FM * Cfg::FN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
+#endif
         }
-        if (more) put(smem + ((ch + 1) & 1) * Cfg::STAGE);
+#if C3_EXP != 2
         __syncthreads();
+#endif
     }
 
     // ---- epilogue: D col = pixel (lane & 31), D row = channel ----
@@ -466,7 +504,6 @@ struct WSCfg {
     static constexpr int TH = 4, TW = 32, NPIX = TH * TW, PH = TH + 2, PW = TW + 2, IPLANE = PH * PW;
     static constexpr int CMAX = 3, LDG = NPIX + 1;
     static constexpr int G_ELEMS = 64 * LDG, X_ELEMS = (CMAX + 1) * IPLANE;
-    static constexpr int NG = 64 * NPIX / 256;               // 32 gy elements per thread per unit
     static constexpr int NX = (CMAX * IPLANE + 255) / 256;
 };
 
@@ -592,8 +629,8 @@ using CfgD64 = C3Cfg<64, 8, 56, 2, 2, 4, 2>;       // same for <= 64 output chan
 using CfgP28 = C3Cfg<128, 4, 28, 4, 1, 4, 2, 2>;   // 28-wide maps: a 4 x 28 strip of TWO images = 7 fragments, zero tile waste
 
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
-// packed-weight workspace: [roundup(C_read, 4) * 9][roundup(M, 128)] floats
-inline size_t pack_bytes(int c_read, int m) { return (size_t)pad_to(c_read, 4) * 9 * pad_to(m, 128) * sizeof(float); }
+// packed-weight workspace: [roundup(C_read, 4) * 9 (+ 16 rows of slack the last float4 staging pass may read)][roundup(M, 128)] floats
+inline size_t pack_bytes(int c_read, int m) { return ((size_t)pad_to(c_read, 4) * 9 + 16) * pad_to(m, 128) * sizeof(float); }
 
 template <class Cfg>
 int launch_fwd(C3Geom g, const float *x, const float *wp, const float *bias, float *y, hipStream_t stream, const char *what) {
@@ -620,7 +657,7 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
                        rows_c, Mp, dgrad ? 1 : 0);
     C3Geom g{N, c_read, H, W, m, Mp, 0, 0, 0};
     if (W <= 16 && H <= 16 && m > 64) return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what);
-    if (W == 28 && H % 4 == 0 && m > 64 && (int64_t)2 * c_read * H * W < (1ll << 31))
+    if (W == 28 && H % 4 == 0 && m > 64)
         return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what);
     if (W % 56 == 0 && W % 32 != 0) {       // 56, 112, 168 ...: a 32-wide tile would waste 12.5 % of the MFMAs
         if (m > 64) return launch_fwd<CfgD128>(g, x, wp, bias, y, stream, what);
@@ -636,7 +673,8 @@ extern "C" int cpg_conv3x3_supported(const cpg_conv_desc *d) {
     if (getenv("CPG_DISABLE_CONV3X3")) return 0;
     return d->R == 3 && d->S == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1 &&
            d->dil_h == 1 && d->dil_w == 1 && d->groups == 1 && d->N > 0 && d->C > 0 && d->K > 0 && d->H > 0 && d->W > 0 &&
-           (int64_t)d->C * d->H * d->W < (1ll << 31) && (int64_t)d->K * d->H * d->W < (1ll << 31);
+           // staging uses 32-bit byte offsets inside a tile's (up to two) images
+           (int64_t)d->C * d->H * d->W < (1ll << 28) && (int64_t)d->K * d->H * d->W < (1ll << 28);
 }
 
 size_t cpg_conv3x3_pack_workspace(const cpg_conv_desc *d) { return std::max(pack_bytes(d->C, d->K), pack_bytes(d->K, d->C)); }
