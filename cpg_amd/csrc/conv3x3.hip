@@ -295,11 +295,21 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
 // ------------------------------------------------------------------------------ wgrad
 // D[co][ci](tap) += sum_pix gy[co][pix] * x[ci][pix + tap offset]
 //
-// Staging map (zero per-element index arithmetic): wave `sub` (0..3) owns channels sub + 4*i, i < 16;
-// its 64 lanes own tile positions lane + 64*g.  A thread's global offset is a fixed per-(thread, g)
-// register plus wave-uniform scalars (unit origin, channel stride), its LDS address a fixed register
-// plus compile-time immediates.  The loads of unit u+1 are issued before the 288 MFMAs of unit u and
-// land in registers meanwhile.
+// A "unit" is one TH x TW tile of one image; the block walks `units_per_split` units, contracting over their
+// pixels (k of the MFMA = a pair of horizontally adjacent pixels, lanes 0-31 / 32-63).
+//
+// Staging map (zero per-element index arithmetic): wave `sub` (0..3) owns channels sub + 4*i, i < 16; its 64
+// lanes own tile positions lane + 64*g.  One staged element = ONE `buffer_load_dword v, v_pos, s[srd], s_chan offen`
+// and ONE `ds_write_b32 v_dst, v offset:imm`:
+//   * v_pos (per thread and position group, recomputed per unit) carries the position inside the channel plane, or
+//     0x80000000 for zero padding / beyond-the-image lanes: the buffer unit range-checks it against num_records and
+//     returns 0 without touching memory, so no select is needed before the LDS write;
+//   * s_chan (wave-uniform) is the channel's plane offset, clamped to the tensor's last channel -- rows of channels
+//     >= M / C hold duplicates, which only reach accumulator rows / columns that are never stored;
+//   * lanes of the last position group that have no position write to the row's padding column.
+// The loads and LDS writes are spread between the MFMAs of a unit (sched_group_barrier), so the chip never sees a
+// staging-only phase: before this, with the block's two waves per SIMD in lock step, wgrad ran at 74-77 % MFMA
+// utilisation against 95 % for the same loop with staging removed (profiles/r01j_*.md).
 template <int TH_, int TW_, bool DB_ = false>
 struct W3Cfg {
     static constexpr bool DB = DB_;                             // two LDS stages: one barrier per unit instead of two
@@ -307,13 +317,17 @@ struct W3Cfg {
     static_assert(TW % 2 == 0, "pixel pairs must not straddle rows");
     static constexpr int BMC = 64, BCI = 64;                    // block tile: 64 co x 64 ci, 2 x 2 waves
     static constexpr int PH = TH + 2, PW = TW + 2, PHW = PH * PW;
-    static constexpr int PLANE = PHW | 1;                       // odd stride: conflict-free lane = channel reads
-    static constexpr int LDG = NPIX | 1;
+    static_assert(PHW % 2 == 0, "the patch plane needs a padding column");
+    static constexpr int PLANE = PHW + 1;                       // odd strides: conflict-free lane = channel reads,
+    static constexpr int LDG = NPIX + 1;                        // and one padding column per row
+    static_assert(PLANE % 2 == 1 && LDG % 2 == 1, "row strides must be odd");
     static constexpr int G_ELEMS = BMC * LDG, X_ELEMS = BCI * PLANE;
     static constexpr int STAGE = G_ELEMS + X_ELEMS;
     static constexpr int SMEM_FLOATS = (DB ? 2 : 1) * STAGE;
     static constexpr int GP = (NPIX + 63) / 64, XP = (PHW + 63) / 64;      // 64-lane position groups
     static constexpr int NI = 16;                                           // channels per wave
+    static constexpr int NITEMS = (GP + XP) * NI;                           // staged elements per thread per unit
+    static constexpr int NC = TW / 2, NSTEP = TH * NC;                      // pixel-pair steps per row / per unit
 };
 
 template <class Cfg>
@@ -339,7 +353,6 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
     const int total_units = N * units_per_img;
     const int u0 = min(total_units, split * units_per_split);
     const int u1 = min(total_units, u0 + units_per_split);
-    const int co_lim = M - co0 - sub, ci_lim = C - ci0 - sub;           // channel sub + 4*i is valid iff 4*i < lim
 
     f32x16 acc[9];
 #pragma unroll
@@ -347,139 +360,155 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
 
-    // fixed per-thread position descriptors
-    unsigned g_off[Cfg::GP], g_rc[Cfg::GP];     // offset inside the image relative to the tile origin; (row << 8) | col
-    unsigned x_off[Cfg::XP], x_rc[Cfg::XP];     // same for the patch, relative to (h0-1, w0-1), biased by +W+1 to stay >= 0
+    // ---- fixed per-thread position descriptors (one small set per 64-lane position group) ----
+    constexpr int kOutOfRange = (int)0x80000000;
+    int g_fix[Cfg::GP], g_dst[Cfg::GP], x_fix[Cfg::XP], x_dst[Cfg::XP];
+    unsigned g_rc[Cfg::GP], x_rc[Cfg::XP];      // (row << 8) | col inside the tile / patch, 0xFFFF: no position
 #pragma unroll
     for (int g = 0; g < Cfg::GP; ++g) {
         const int pix = lane + 64 * g, r = pix / Cfg::TW, c = pix % Cfg::TW;
-        g_off[g] = 4u * (unsigned)(sub * HW + r * W + c);            // bytes
-        g_rc[g] = pix < Cfg::NPIX ? (r << 8) | c : 0xFFFFu;
+        const bool has = pix < Cfg::NPIX;
+        g_fix[g] = 4 * (r * W + c);                                       // bytes from the tile origin
+        g_rc[g] = has ? (unsigned)((r << 8) | c) : 0xFFFFu;
+        g_dst[g] = sub * Cfg::LDG + (has ? pix : Cfg::NPIX);              // LDS float index (padding column if none)
     }
 #pragma unroll
     for (int g = 0; g < Cfg::XP; ++g) {
         const int q = lane + 64 * g, r = q / Cfg::PW, c = q % Cfg::PW;
-        x_off[g] = 4u * (unsigned)(sub * HW + r * W + c);
-        x_rc[g] = q < Cfg::PHW ? (r << 8) | c : 0xFFFFu;
+        const bool has = q < Cfg::PHW;
+        x_fix[g] = 4 * (r * W + c);                                       // bytes from the patch origin (h0-1, w0-1)
+        x_rc[g] = has ? (unsigned)((r << 8) | c) : 0xFFFFu;
+        x_dst[g] = Cfg::G_ELEMS + sub * Cfg::PLANE + (has ? q : Cfg::PHW);
     }
+    // channel plane offsets (bytes, wave-uniform), clamped to the last channel of the tensor
+    auto g_chan = [&](int i) { return min(sub + 4 * i, M - 1 - co0) * HW * 4; };
+    auto x_chan = [&](int i) { return min(sub + 4 * i, C - 1 - ci0) * HW * 4; };
 
-    float rg[Cfg::GP][Cfg::NI], rx[Cfg::XP][Cfg::NI];
-    unsigned gmask = 0, xmask = 0;              // per-group position validity of the unit held in rg / rx
-    auto fetch_g = [&](int u) {
+    // ---- descriptor of the unit being loaded: two buffer resources + per-group byte offsets ----
+    __amdgpu_buffer_rsrc_t srd_g, srd_x;
+    int gv[Cfg::GP], xv[Cfg::XP];
+    auto describe = [&](int u) {
         const int n = u / units_per_img, rr = u - n * units_per_img;
         const int ty = rr / tiles_x, tx = rr - ty * tiles_x;
         const int h0 = ty * Cfg::TH, w0 = tx * Cfg::TW;
-        gmask = 0;
-        // gy tile.  Address = wave-uniform base (SGPR pair) + 32-bit per-lane offset; lanes that must not
-        // read (outside the image / past the last channel) are pointed at pixel (h0, w0) of a valid channel.
-        const float *gimg = gy + ((int64_t)n * M + co0) * HW + h0 * W + w0;
+        srd_g = __builtin_amdgcn_make_buffer_rsrc((void *)(gy + ((int64_t)n * M + co0) * HW), 0, 0x7FFFFFFF, 0x00020000);
+        srd_x = __builtin_amdgcn_make_buffer_rsrc((void *)(x + ((int64_t)n * C + ci0) * HW), 0, 0x7FFFFFFF, 0x00020000);
+        const int go = 4 * (h0 * W + w0), xo = 4 * ((h0 - 1) * W + (w0 - 1));
 #pragma unroll
         for (int g = 0; g < Cfg::GP; ++g) {
             const int r = g_rc[g] >> 8, c = g_rc[g] & 255;
             const bool pv = g_rc[g] != 0xFFFFu && h0 + r < H && w0 + c < W;
-            gmask |= (pv ? 1u : 0u) << g;
-#pragma unroll
-            for (int i = 0; i < Cfg::NI; ++i) {
-                const bool cv = 4 * i < co_lim;                                       // wave-uniform
-                const float *base = gimg + (int64_t)(cv ? 4 * i : 0) * HW;            // uniform
-                rg[g][i] = ld_sv(base, (pv && cv) ? g_off[g] : 0u);
-            }
+            gv[g] = pv ? go + g_fix[g] : kOutOfRange;
         }
-    };
-    auto fetch_x = [&](int u) {
-        const int n = u / units_per_img, rr = u - n * units_per_img;
-        const int ty = rr / tiles_x, tx = rr - ty * tiles_x;
-        const int h0 = ty * Cfg::TH, w0 = tx * Cfg::TW;
-        xmask = 0;
-        // x patch, origin (h0 - 1, w0 - 1); patch element (1, 1) = pixel (h0, w0) is always inside the image
-        const float *ximg = x + ((int64_t)n * C + ci0) * HW + (int64_t)(h0 - 1) * W + (w0 - 1);
-        const unsigned safe = 4u * (unsigned)(W + 1);
 #pragma unroll
         for (int g = 0; g < Cfg::XP; ++g) {
             const int r = x_rc[g] >> 8, c = x_rc[g] & 255;
             const int gh = h0 - 1 + r, gw = w0 - 1 + c;
             const bool pv = x_rc[g] != 0xFFFFu && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-            xmask |= (pv ? 1u : 0u) << g;
-#pragma unroll
-            for (int i = 0; i < Cfg::NI; ++i) {
-                const bool cv = 4 * i < ci_lim;
-                const float *base = ximg + (int64_t)(cv ? 4 * i : 0) * HW;
-                rx[g][i] = ld_sv(base, (pv && cv) ? x_off[g] : safe);
-            }
+            xv[g] = pv ? xo + x_fix[g] : kOutOfRange;
         }
     };
-    auto put = [&](float *stage) {
-        float *gs = stage, *xs = stage + Cfg::G_ELEMS;
-#pragma unroll
-        for (int g = 0; g < Cfg::GP; ++g) {
-            if (g_rc[g] != 0xFFFFu) {
-                const bool pv = (gmask >> g) & 1u;
-                float *dst = gs + sub * Cfg::LDG + lane + 64 * g;
-#pragma unroll
-                for (int i = 0; i < Cfg::NI; ++i) dst[4 * i * Cfg::LDG] = (pv && 4 * i < co_lim) ? rg[g][i] : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < Cfg::XP; ++g) {
-            if (x_rc[g] != 0xFFFFu) {
-                const bool pv = (xmask >> g) & 1u;
-                float *dst = xs + sub * Cfg::PLANE + lane + 64 * g;
-#pragma unroll
-                for (int i = 0; i < Cfg::NI; ++i) dst[4 * i * Cfg::PLANE] = (pv && 4 * i < ci_lim) ? rx[g][i] : 0.0f;
-            }
-        }
+    // staged element k: position group k / NI (patch groups first), channel slot k % NI
+    float st[Cfg::GP + Cfg::XP][Cfg::NI];
+    auto load_item = [&](int k) {
+        const int grp = k / Cfg::NI, i = k % Cfg::NI;
+        if (grp < Cfg::XP)
+            st[grp][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, xv[grp], x_chan(i), 0));
+        else
+            st[grp][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_g, gv[grp - Cfg::XP], g_chan(i), 0));
+    };
+    auto write_item = [&](int k, float *stage) {
+        const int grp = k / Cfg::NI, i = k % Cfg::NI;
+        if (grp < Cfg::XP)
+            stage[x_dst[grp] + 4 * i * Cfg::PLANE] = st[grp][i];
+        else
+            stage[g_dst[grp - Cfg::XP] + 4 * i * Cfg::LDG] = st[grp][i];
     };
 
-    const int a_base = (wco * 32 + li) * Cfg::LDG + lh;                 // gy[co][pix], pix = 2s + lh
-    const int b_base = (wci * 32 + li) * Cfg::PLANE + lh;               // x[ci][(r+kh)*PW + c + kw], c = 2s' + lh
-    // The 48 staging loads of unit u+1 (32 patch + 16 gy) are issued before the MFMAs of unit u and land in
-    // registers meanwhile; 9 accumulators (144) + 48 staged values fit the 256-register budget of two waves
-    // per SIMD only because the row loop below is not unrolled.
-    auto compute = [&](const float *stage) {
-        const float *gs = stage, *xs = stage + Cfg::G_ELEMS;
-#pragma unroll 1
-        for (int r = 0; r < Cfg::TH; ++r) {          // not unrolled: keeps the operand-read window (and VGPRs) small
+    const int a_base = (wco * 32 + li) * Cfg::LDG + lh;                                  // gy[co][pix], pix = 2s + lh
+    const int b_base = Cfg::G_ELEMS + (wci * 32 + li) * Cfg::PLANE + lh;                 // x[ci][(r+kh)*PW + c + kw]
+
+    // One unit: NSTEP steps of 9 MFMAs.  Sliding window along a row: step c2 needs patch columns 2*c2 + lh + {0,1,2};
+    // column +2 of one step is column +0 of the next, so a step reads 1 + 6 new LDS values, one step ahead of the
+    // MFMAs that consume them.  Each step also carries its share of the unit's staging: element k's LDS write (two
+    // stages: into the other stage; the value was loaded one unit ago) and the buffer load that refills its register.
+    auto unit = [&](const float *cur, float *other, bool stage_writes) {
+        float a[2], bn[2][3][2], b0[3], b0n[3];
+        auto rd = [&](int q, int set) {
+            const int r = q / Cfg::NC, c2 = q % Cfg::NC;
+            const float *ga = cur + a_base + r * Cfg::TW, *xb = cur + b_base + r * Cfg::PW;
+            a[set] = ga[2 * c2];
 #pragma unroll
-            for (int c2 = 0; c2 < Cfg::TW / 2; ++c2) {
-                const float a = gs[a_base + r * Cfg::TW + 2 * c2];
+            for (int kh = 0; kh < 3; ++kh) {
+                if (c2 == 0) b0n[kh] = xb[kh * Cfg::PW];
+                bn[set][kh][0] = xb[kh * Cfg::PW + 2 * c2 + 1];
+                bn[set][kh][1] = xb[kh * Cfg::PW + 2 * c2 + 2];
+            }
+        };
+        rd(0, 0);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const float b = xs[b_base + (r + t / 3) * Cfg::PW + 2 * c2 + (t % 3)];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        for (int q = 0; q < Cfg::NSTEP; ++q) {
+            const int set = q & 1;
+            if (q % Cfg::NC == 0) {
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) b0[kh] = b0n[kh];
+            }
+            if (q + 1 < Cfg::NSTEP) rd(q + 1, set ^ 1);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set], b0[kh], acc[kh * 3 + 0], 0, 0, 0);
+                acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set], bn[set][kh][0], acc[kh * 3 + 1], 0, 0, 0);
+                acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set], bn[set][kh][1], acc[kh * 3 + 2], 0, 0, 0);
+                b0[kh] = bn[set][kh][1];
+            }
+            const int k0 = q * Cfg::NITEMS / Cfg::NSTEP, k1 = (q + 1) * Cfg::NITEMS / Cfg::NSTEP;
+#pragma unroll
+            for (int k = k0; k < k1; ++k) {
+                if (stage_writes) write_item(k, other);
+                load_item(k);
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (i < k1 - k0) {
+                    if (stage_writes) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
             }
         }
     };
-    if (u0 < u1) {
-        fetch_x(u0);
-        fetch_g(u0);
-    }
-    if (Cfg::DB) {
-        // two stages: the stage written after the MFMAs of unit u was last read during unit u-1, which every
-        // wave left at the previous barrier -> ONE barrier per unit
-        if (u0 < u1) put(smem);
-        __syncthreads();
-        for (int u = u0; u < u1; ++u) {
-            const int cur = (u - u0) & 1;
-            const bool more = u + 1 < u1;
-            if (more) {
-                fetch_x(u + 1);
-                fetch_g(u + 1);
-            }
-            compute(smem + cur * Cfg::STAGE);
-            if (more) put(smem + (cur ^ 1) * Cfg::STAGE);
+
+    if (u0 < u1) {      // (an empty trailing split just writes zeros)
+        describe(u0);
+#pragma unroll
+        for (int k = 0; k < Cfg::NITEMS; ++k) load_item(k);
+        if (Cfg::DB) {
+            // Two LDS stages, ONE barrier per unit.  During unit u the registers (holding unit u+1) are written to the
+            // other stage and refilled with unit u+2; unit indices are clamped to the split's last unit so the tail needs
+            // no branches (it re-stages data nobody reads).
+#pragma unroll
+            for (int k = 0; k < Cfg::NITEMS; ++k) write_item(k, smem);
+            describe(min(u0 + 1, u1 - 1));
+#pragma unroll
+            for (int k = 0; k < Cfg::NITEMS; ++k) load_item(k);
             __syncthreads();
-        }
-    } else {
-        for (int u = u0; u < u1; ++u) {
-            __syncthreads();                 // previous unit's operand reads are done
-            put(smem);
-            __syncthreads();
-            if (u + 1 < u1) {                // all 48 loads of the next unit fly during the MFMAs below
-                fetch_x(u + 1);
-                fetch_g(u + 1);
+            for (int u = u0; u < u1; ++u) {
+                const int cur = (u - u0) & 1;
+                describe(min(u + 2, u1 - 1));
+                unit(smem + cur * Cfg::STAGE, smem + (cur ^ 1) * Cfg::STAGE, true);
+                __syncthreads();
             }
-            compute(smem);
+        } else {
+            // One stage: barrier, registers (unit u) -> LDS, barrier; the loads of unit u+1 ride inside unit u's MFMAs.
+            for (int u = u0; u < u1; ++u) {
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < Cfg::NITEMS; ++k) write_item(k, smem);
+                __syncthreads();
+                describe(min(u + 1, u1 - 1));
+                unit(smem, smem, false);
+            }
         }
     }
     // partial result: part[split][co][ci][tap]
@@ -674,7 +703,8 @@ extern "C" int cpg_conv3x3_supported(const cpg_conv_desc *d) {
     return d->R == 3 && d->S == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1 &&
            d->dil_h == 1 && d->dil_w == 1 && d->groups == 1 && d->N > 0 && d->C > 0 && d->K > 0 && d->H > 0 && d->W > 0 &&
            // staging uses 32-bit byte offsets inside a tile's (up to two) images
-           (int64_t)d->C * d->H * d->W < (1ll << 28) && (int64_t)d->K * d->H * d->W < (1ll << 28);
+           (int64_t)d->C * d->H * d->W < (1ll << 28) && (int64_t)d->K * d->H * d->W < (1ll << 28) &&
+           (int64_t)d->H * d->W <= (1ll << 22);       // wgrad: 64 channel planes addressed with a 31-bit byte offset
 }
 
 size_t cpg_conv3x3_pack_workspace(const cpg_conv_desc *d) { return std::max(pack_bytes(d->C, d->K), pack_bytes(d->K, d->C)); }
@@ -718,7 +748,7 @@ W3Plan w3_plan(const cpg_conv_desc *d) {
     return p;
 }
 using W3Wide = W3Cfg<2, 28>;      // 112 / 224 wide feature maps: long contiguous rows, 2 x 64-lane patch groups exactly
-using W3Mid = W3Cfg<4, 14>;       // 14 / 28 / 56 wide feature maps: zero column waste (two LDS stages measured no gain)
+using W3Mid = W3Cfg<4, 14, true>;  // 14 / 28 / 56 wide feature maps: zero column waste; two stages (2 x 77 KB per CU)
 using W3Nar = W3Cfg<4, 16>;       // everything else that is narrow
 inline int w3_pick(const cpg_conv_desc *d) {
     if (d->W % 28 == 0 && d->W >= 112) return 0;
