@@ -48,9 +48,6 @@ __device__ __forceinline__ f32x4 ld_sv4(const float *sbase, unsigned byte_off) {
     return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(sbase) + byte_off);
 }
 
-#ifndef C3_EXP
-#define C3_EXP 0
-#endif
 
 struct C3Geom {
     int N, C, H, W, M;        // C: channels of the tensor being read, M: channels being produced
@@ -73,10 +70,15 @@ struct C3Cfg {
     static constexpr int W4 = BM / 4;                       // float4 per weight row
     static constexpr int WROWS = 256 / W4;                  // weight rows staged per pass of the block
     static constexpr int NW4 = (KC + WROWS - 1) / WROWS;    // float4 loads per thread per chunk
-    static constexpr int W_ELEMS = KC * LDW, X_ELEMS = CK * PLANE;
-    static constexpr int STAGE = W_ELEMS + X_ELEMS;
+    static constexpr int X_ELEMS = CK * PLANE;
+    static constexpr int NXL = (X_ELEMS + 255) / 256;       // patch elements per thread per chunk
+    // both LDS regions are padded to whole staging passes, so that every staging store is unconditional
+    static constexpr int W_ELEMS = NW4 * WROWS * LDW, XS_ELEMS = NXL * 256;
+    static constexpr int STAGE = W_ELEMS + XS_ELEMS;
     static constexpr int SMEM_FLOATS = 2 * STAGE;
-    static constexpr int NXL = (X_ELEMS + 255) / 256;
+    static constexpr int NS = CK / 2 * 9;                   // k-steps (of 2 channels x 1 tap) per chunk
+    static constexpr int NITEMS = NW4 + NXL;                // staging loads (= staging stores) per thread per chunk
+    static_assert(NITEMS <= NS, "one staging load and one store per k-step at most");
 };
 
 // ------------------------------------------------------------------------------ weight pack
@@ -127,14 +129,17 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
     const int HW = g.H * g.W;
 
     // ---- staging descriptors, all fixed for the life of the block (a handful of registers) ----
-    // weights: float4 (row = wrow0 + WROWS*i, 4 columns at wcol); Wp is zero padded, so no guards
+    // weights: float4 (row = wrow0 + WROWS*i, 4 columns at wcol); Wp is zero padded (and carries WROWS rows of
+    // slack for the last pass), so no guards
     const int wcol = (tid % Cfg::W4) * 4, wrow0 = tid / Cfg::W4;
     const int wdst = wrow0 * Cfg::LDW + wcol;
-    // patch: element e = tid + 256*i of [CK][PH][PW]; byte offset from the chunk's first channel, 0 when the element is
-    // zero padding (the load still happens -- from a valid address -- and put() writes 0 instead)
-    unsigned xbyte[Cfg::NXL];
-    int xcl[Cfg::NXL];
-    unsigned xok_fixed = 0;
+    const unsigned wbyte = (unsigned)(wrow0 * g.Mp + m0 + wcol) * 4u;
+    // patch: element e = tid + 256*i of [CK][NIMG][PH][PW], fetched with buffer loads whose range check does the
+    // zero padding: byte offset from image n's channel 0, or 0x80000000 (>= num_records -> the load returns 0
+    // without touching memory) for halo positions outside the image.  Channels past C (ragged last chunk) fall
+    // out of range by themselves because num_records ends at the image's (NIMG = 2: the image pair's) last channel.
+    constexpr int kOutOfRange = (int)0x80000000;
+    int xbyte[Cfg::NXL];
 #pragma unroll
     for (int i = 0; i < Cfg::NXL; ++i) {
         const int e = tid + 256 * i;
@@ -143,52 +148,28 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
         const int pr = rem / Cfg::PW, pc = rem - pr * Cfg::PW;
         const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
         const bool ok = e < Cfg::X_ELEMS && n + img < g.N && (unsigned)gh < (unsigned)g.H && (unsigned)gw < (unsigned)g.W;
-        xbyte[i] = ok ? (unsigned)((img * g.C + cl) * HW + gh * g.W + gw) * 4u : 0u;
-        xok_fixed |= (ok ? 1u : 0u) << i;
-        xcl[i] = cl;
+        xbyte[i] = ok ? ((img * g.C + cl) * HW + gh * g.W + gw) * 4 : kOutOfRange;
     }
-    const float *xin = x + (int64_t)n * g.C * HW;
-    const unsigned wbyte = (unsigned)(wrow0 * g.Mp + m0 + wcol) * 4u;
+    const int nimg_here = min(Cfg::NIMG, g.N - n);
+    const __amdgpu_buffer_rsrc_t srd_x =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(x + (int64_t)n * g.C * HW), 0, nimg_here * g.C * HW * 4, 0x00020000);
 
-    // Every load is `global_load v, v_fixed_byte_offset, s[uniform base]`: the per-chunk address work is a few
-    // scalar adds.  Loads are unconditional and their results untouched until put(): a predicated load is an
-    // exec-masked branch with its own s_waitcnt vmcnt(0), and arithmetic on a loaded value in fetch() would
-    // drag that wait in front of the MFMAs of the current chunk.  (Rows of the last float4 pass that lie past
-    // the chunk are read -- the packed weights carry WROWS rows of slack -- and dropped in put().)
+    // staging item k < NW4: weight float4 k; else patch element k - NW4.  Results stay untouched in registers
+    // until store_item(): arithmetic on a loaded value would drag its s_waitcnt in front of the MFMAs.
     f32x4 rw[Cfg::NW4];             // native vector type: HIP's float4 struct kept this array in scratch memory
     float rx[Cfg::NXL];
-    unsigned xok = 0;
-    auto fetch = [&](int c0) {
-        const float *wc = wp + (int64_t)c0 * 9 * g.Mp;
-#pragma unroll
-        for (int i = 0; i < Cfg::NW4; ++i) rw[i] = ld_sv4(wc + (int64_t)Cfg::WROWS * i * g.Mp, wbyte);
-        const float *xc = xin + (int64_t)c0 * HW;
-        if (c0 + Cfg::CK <= g.C) {          // uniform; the ragged tail (C % CK != 0) re-checks the channel
-            xok = xok_fixed;
-#pragma unroll
-            for (int i = 0; i < Cfg::NXL; ++i) rx[i] = ld_sv(xc, xbyte[i]);
-        } else {
-            xok = 0;
-#pragma unroll
-            for (int i = 0; i < Cfg::NXL; ++i) {
-                const unsigned ok = ((xok_fixed >> i) & 1u) & (c0 + xcl[i] < g.C ? 1u : 0u);
-                xok |= ok << i;
-                rx[i] = ld_sv(xc, ok ? xbyte[i] : 0u);
-            }
-        }
+    auto load_item = [&](int k, int c0) {
+        if (k < Cfg::NW4)
+            rw[k] = ld_sv4(wp + ((int64_t)c0 * 9 + Cfg::WROWS * k) * g.Mp, wbyte);
+        else
+            rx[k - Cfg::NW4] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, xbyte[k - Cfg::NW4] + c0 * HW * 4, 0, 0));
     };
-    auto put = [&](float *stage) {
-#pragma unroll
-        for (int i = 0; i < Cfg::NW4; ++i) {
-            const bool live = (Cfg::KC % Cfg::WROWS == 0) || (wrow0 + Cfg::WROWS * i < Cfg::KC);
-            if (live) *reinterpret_cast<f32x4 *>(stage + wdst + Cfg::WROWS * i * Cfg::LDW) = rw[i];
-        }
-        float *xs = stage + Cfg::W_ELEMS;
-#pragma unroll
-        for (int i = 0; i < Cfg::NXL; ++i) {
-            const int e = tid + 256 * i;
-            if (e < Cfg::X_ELEMS) xs[e] = ((xok >> i) & 1u) ? rx[i] : 0.0f;
-        }
+    auto store_item = [&](int k, float *stage) {
+        if (k < Cfg::NW4)
+            *reinterpret_cast<f32x4 *>(stage + wdst + Cfg::WROWS * k * Cfg::LDW) = rw[k];
+        else
+            stage[Cfg::W_ELEMS + tid + 256 * (k - Cfg::NW4)] = rx[k - Cfg::NW4];
     };
 
     // ---- operand lane bases ----
@@ -210,21 +191,23 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
             for (int e = 0; e < 16; ++e) acc[fm][fn][e] = 0.0f;
 
     const int nch = (g.C + Cfg::CK - 1) / Cfg::CK;
-    fetch(0);
-    put(smem);
+#pragma unroll
+    for (int k = 0; k < Cfg::NITEMS; ++k) load_item(k, 0);
+#pragma unroll
+    for (int k = 0; k < Cfg::NITEMS; ++k) store_item(k, smem);
     __syncthreads();
+    // One chunk = NS k-steps; k-step s = (channel pair p = s / 9, tap = s % 9): lanes 0-31 hold channel 2p, lanes
+    // 32-63 channel 2p+1.  The body is branch free and its instruction order pinned (sched_group_barrier):
+    //   * the operands of step s+1 are read from LDS while the MFMAs of step s run (two register sets);
+    //   * the next chunk's staging loads ride in the first NITEMS steps, its LDS stores (into the OTHER stage)
+    //     in the last NITEMS steps -- never a staging-only phase, which the block's waves (two per SIMD, in
+    //     lock step) could not hide from one another.  The chunk index is clamped, so the last chunk re-stages
+    //     itself instead of branching.
     for (int ch = 0; ch < nch; ++ch) {
         const float *ws = smem + (ch & 1) * Cfg::STAGE;
         const float *xs = ws + Cfg::W_ELEMS;
-        const bool more = ch + 1 < nch;
-#if C3_EXP == 1 || C3_EXP == 2
-        (void)more;
-#else
-        if (more) fetch((ch + 1) * Cfg::CK);
-#endif
-        // k-step s = (channel pair p = s / 9, tap = s % 9): lanes 0-31 hold channel 2p, lanes 32-63 channel 2p+1.
-        // The operands of step s+1 are read from LDS while the MFMAs of step s run (two register sets).
-        constexpr int NS = Cfg::CK / 2 * 9;
+        float *other = smem + ((ch + 1) & 1) * Cfg::STAGE;
+        const int c_next = min(ch + 1, nch - 1) * Cfg::CK;
         float a[2][Cfg::FM], b[2][Cfg::FN];
         auto lds_operands = [&](int st, int set) {
             const int p = st / 9, tap = st % 9;
@@ -236,30 +219,24 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
         };
         lds_operands(0, 0);
 #pragma unroll
-        for (int st = 0; st < NS; ++st) {
-            // The next chunk is written to the OTHER LDS stage half way through this chunk's MFMAs (its loads
-            // were issued NS/2 k-steps ago), so that only the barrier -- not the LDS writes -- sits between
-            // the last MFMA of this chunk and the first operand read of the next.
-#if C3_EXP != 1 && C3_EXP != 2
-            if (st == NS / 2 && more) put(smem + ((ch + 1) & 1) * Cfg::STAGE);
-#endif
-            if (st + 1 < NS) lds_operands(st + 1, (st + 1) & 1);
+        for (int st = 0; st < Cfg::NS; ++st) {
+            if (st + 1 < Cfg::NS) lds_operands(st + 1, (st + 1) & 1);
 #pragma unroll
             for (int fm = 0; fm < Cfg::FM; ++fm)
 #pragma unroll
                 for (int fn = 0; fn < Cfg::FN; ++fn)
                     acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][fm], b[st & 1][fn], acc[fm][fn], 0, 0, 0);
-#if C3_EXP != 3
+            if (st < Cfg::NITEMS) load_item(st, c_next);
+            if (st >= Cfg::NS - Cfg::NITEMS) store_item(st - (Cfg::NS - Cfg::NITEMS), other);
 #pragma unroll
             for (int i = 0; i < Cfg::FM * Cfg::FN; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                if (i == 1 && st < Cfg::NITEMS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (i == 1 && st >= Cfg::NS - Cfg::NITEMS) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
-#endif
         }
-#if C3_EXP != 2
         __syncthreads();
-#endif
     }
 
     // ---- epilogue: D col = pixel (lane & 31), D row = channel ----
@@ -686,7 +663,7 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
                        rows_c, Mp, dgrad ? 1 : 0);
     C3Geom g{N, c_read, H, W, m, Mp, 0, 0, 0};
     if (W <= 16 && H <= 16 && m > 64) return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what);
-    if (W == 28 && H % 4 == 0 && m > 64)
+    if (W == 28 && H % 4 == 0 && m > 64 && c_read % 4 == 0)
         return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what);
     if (W % 56 == 0 && W % 32 != 0) {       // 56, 112, 168 ...: a 32-wide tile would waste 12.5 % of the MFMAs
         if (m > 64) return launch_fwd<CfgD128>(g, x, wp, bias, y, stream, what);
@@ -750,9 +727,11 @@ W3Plan w3_plan(const cpg_conv_desc *d) {
 using W3Wide = W3Cfg<2, 28>;      // 112 / 224 wide feature maps: long contiguous rows, 2 x 64-lane patch groups exactly
 using W3Mid = W3Cfg<4, 14, true>;  // 14 / 28 / 56 wide feature maps: zero column waste; two stages (2 x 77 KB per CU)
 using W3Nar = W3Cfg<4, 16>;       // everything else that is narrow
+using W3Tiny = W3Cfg<2, 14, true>; // 14-wide maps whose height is not a multiple of 4 (14 x 14: zero row waste)
 inline int w3_pick(const cpg_conv_desc *d) {
+    if (getenv("CPG_W3_PICK")) return atoi(getenv("CPG_W3_PICK"));
     if (d->W % 28 == 0 && d->W >= 112) return 0;
-    if (d->W % 14 == 0) return 1;
+    if (d->W % 14 == 0) return (d->H % 4 != 0 && d->H % 2 == 0) ? 3 : 1;
     return 2;
 }
 }  // namespace
@@ -771,6 +750,7 @@ size_t cpg_conv3x3_wgrad_workspace(const cpg_conv_desc *d) {
     switch (w3_pick(d)) {
         case 1: return w3_plan<W3Mid>(d).ws_bytes;
         case 2: return w3_plan<W3Nar>(d).ws_bytes;
+        case 3: return w3_plan<W3Tiny>(d).ws_bytes;
         default: return w3_plan<W3Wide>(d).ws_bytes;
     }
 }
@@ -827,6 +807,7 @@ int cpg_conv3x3_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, c
     switch (w3_pick(d)) {
         case 1: return w3_launch<W3Mid>(d, x, gy, ep, ws, ws_bytes, stream);
         case 2: return w3_launch<W3Nar>(d, x, gy, ep, ws, ws_bytes, stream);
+        case 3: return w3_launch<W3Tiny>(d, x, gy, ep, ws, ws_bytes, stream);
         default: return w3_launch<W3Wide>(d, x, gy, ep, ws, ws_bytes, stream);
     }
 }
