@@ -465,6 +465,56 @@ def test_route_and_hist_full_size_properties():
     assert torch.equal(hist[:256], want) and int(hist[:256].sum()) == n
 
 
+@pytest.mark.parametrize('C,K,H', [(64, 64, 224), (128, 128, 112), (256, 256, 56), (512, 512, 28), (512, 512, 14), (3, 64, 224)])
+def test_conv_full_size_properties(C, K, H):
+    """The conv layers of config 2 at their full size (batch 256): properties that need no CPU reference.
+    (1) adjoint identities  <conv(x, W), gy> = <x, dgrad(gy, W)> = <W, wgrad(x, gy)>  tie the three kernels to
+    one another; (2) sampled outputs / gradients are recomputed directly from the definition in fp64."""
+    N = 256
+    g = torch.Generator(device=DEV).manual_seed(C * 7 + H)
+    x = torch.randn(N, C, H, H, generator=g, device=DEV)
+    w = torch.randn(K, C, 3, 3, generator=g, device=DEV) * (2.0 / (C * 9)) ** 0.5
+    pm = torch.rand(K, C, 3, 3, generator=g, device=DEV) * 0.012
+    layer = nl.SharableConv2d(C, K, 3, padding=1, bias=False).to(DEV)
+    layer.weight.data.copy_(w)
+    layer.piggymask = nn.Parameter(pm.clone())
+    xd = x.clone().requires_grad_(True)
+    y = layer(xd)
+    gy = torch.randn(y.shape, generator=g, device=DEV)
+    y.backward(gy)
+    w_eff = (w * (pm > 5e-3).float()).double()
+
+    def dot(a, b):
+        return float((a.double() * b.double()).sum())
+    lhs = dot(y.detach(), gy)
+    scale = float(y.detach().double().norm() * gy.double().norm())
+    assert abs(lhs - dot(x, xd.grad)) <= 1e-6 * scale                       # fwd vs dgrad
+    # gW = gW_eff * bin(pm), and <W, gW> = <W_eff, gW_eff> because bin(pm) is 0/1
+    assert abs(lhs - dot(w, layer.weight.grad)) <= 1e-6 * scale              # fwd vs wgrad
+    # sampled entries from the definition
+    rs = np.random.RandomState(H + C)
+    xp = torch.nn.functional.pad(x, (1, 1, 1, 1)).double()
+    gyp = torch.nn.functional.pad(gy, (1, 1, 1, 1)).double()
+    for _ in range(24):
+        n, k, c = rs.randint(N), rs.randint(K), rs.randint(C)
+        h, ww = rs.randint(H), rs.randint(H)
+        if rs.rand() < 0.5:
+            h, ww = rs.choice([0, H - 1]), rs.choice([0, H - 1])                  # image corners: zero padding
+        want = float((xp[n, :, h:h + 3, ww:ww + 3] * w_eff[k]).sum())
+        assert abs(float(y.detach()[n, k, h, ww]) - want) <= 1e-4 * abs(want) + 2e-5
+        # gx[n,c,h,w] = sum_{k,r,s} gy[n,k,h-r+1,w-s+1] * W_eff[k,c,r,s]
+        patch = gyp[n, :, h:h + 3, ww:ww + 3].flip(-1, -2)
+        want = float((patch * w_eff[:, c]).sum())
+        assert abs(float(xd.grad[n, c, h, ww]) - want) <= 1e-4 * abs(want) + 2e-5
+    for _ in range(6):
+        k, c, r, t = rs.randint(K), rs.randint(C), rs.randint(3), rs.randint(3)
+        want = float((xp[:, c, r:r + H, t:t + H] * gy[:, k].double()).sum())
+        b = float(pm[k, c, r, t] > 5e-3)
+        tol = 1e-4 * abs(want) + 1e-5 * float(layer.weight.grad.abs().max())
+        assert abs(float(layer.weight.grad[k, c, r, t]) - want * b) <= tol
+        assert abs(float(layer.piggymask.grad[k, c, r, t]) - want * float(w[k, c, r, t])) <= tol + 1e-4 * abs(want * float(w[k, c, r, t]))
+
+
 # --------------------------------------------------------------------------- fused BatchNorm -> ReLU (SURVEY 8f.2)
 @pytest.mark.parametrize('N,C,H,W', [(8, 64, 56, 56), (4, 16, 224, 224), (16, 512, 14, 14), (3, 5, 7, 9), (2, 3, 1, 1)])
 @pytest.mark.parametrize('training', [True, False])

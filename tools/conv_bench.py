@@ -40,6 +40,7 @@ def main():
     ap.add_argument('--only', default='fwd,dgrad,wgrad')
     ap.add_argument('--layers', default='')
     ap.add_argument('--pm', action='store_true')
+    ap.add_argument('--pmc-pass', action='store_true', help='no timing: launch every conv of one VGG16 pass exactly once (for rocprofv3 --pmc)')
     a = ap.parse_args()
     L = _lib.lib()
     dev = 'cuda:0'
@@ -68,6 +69,11 @@ def main():
                 'wgrad': lambda: L.cpg_conv2d_wgrad(ctypes.byref(d), P(x), P(gy), P(w), P(pm), 5e-3, P(gw), P(gpm), None, P(ws), nb, st)}
         for k in a.only.split(','):
             if k == 'dgrad' and name == 'f0':
+                continue
+            if a.pmc_pass:
+                for _ in range(mult):
+                    runs[k]()
+                torch.cuda.synchronize()
                 continue
             ms = timeit(runs[k], a.iters)
             print('%-6s %-6s %9.3f %9.1f' % (name, k, ms, flops / ms / 1e9), flush=True)
