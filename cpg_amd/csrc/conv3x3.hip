@@ -662,13 +662,23 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
     hipLaunchKernelGGL(k_c3_pack, dim3(stream_grid((int64_t)rows_c * 9 * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, K, C,
                        rows_c, Mp, dgrad ? 1 : 0);
     C3Geom g{N, c_read, H, W, m, Mp, 0, 0, 0};
+    if (const char *f = getenv("CPG_C3_FORCE")) {        // A/B experiments only (tools/conv_bench.py --ab)
+        switch (atoi(f)) {
+            case 0: return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what);
+            case 1: return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what);
+            case 2: return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what);
+            case 3: return launch_fwd<CfgD128>(g, x, wp, bias, y, stream, what);
+            case 4: return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what);
+            default: if (c_read % 4 == 0) return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what);
+        }
+    }
     if (W <= 16 && H <= 16 && m > 64) return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what);
     if (W == 28 && H % 4 == 0 && m > 64 && c_read % 4 == 0)
         return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what);
-    if (W % 56 == 0 && W % 32 != 0) {       // 56, 112, 168 ...: a 32-wide tile would waste 12.5 % of the MFMAs
-        if (m > 64) return launch_fwd<CfgD128>(g, x, wp, bias, y, stream, what);
-        return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what);
-    }
+    // 56, 112, 168 ...: a 32-wide tile would waste 12.5 % of the MFMAs.  The 64-channel 8 x 56 tile (2 x 2 waves) measured
+    // 1-2 % faster than the 128-channel 4 x 56 tile (4 x 1 waves) on every 56- and 112-wide VGG layer, also for m > 64
+    // (interleaved in-process A/B, tools/conv_bench.py --ab CPG_C3_FORCE=3,4).
+    if (W % 56 == 0 && W % 32 != 0) return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what);
     if (m <= 64) return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what);
     return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what);
 }

@@ -40,6 +40,8 @@ def main():
     ap.add_argument('--only', default='fwd,dgrad,wgrad')
     ap.add_argument('--layers', default='')
     ap.add_argument('--pm', action='store_true')
+    ap.add_argument('--ab', default='', help='A/B inside one process: NAME=v1,v2,... toggles that env var between timed runs (median of --reps rounds)')
+    ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--pmc-pass', action='store_true', help='no timing: launch every conv of one VGG16 pass exactly once (for rocprofv3 --pmc)')
     a = ap.parse_args()
     L = _lib.lib()
@@ -74,6 +76,21 @@ def main():
                 for _ in range(mult):
                     runs[k]()
                 torch.cuda.synchronize()
+                continue
+            if a.ab:
+                var, vals = a.ab.split('=')
+                vals = vals.split(',')
+                res = {v: [] for v in vals}
+                for _ in range(a.reps):
+                    for v in vals:
+                        if v == '-':
+                            os.environ.pop(var, None)
+                        else:
+                            os.environ[var] = v
+                        res[v].append(timeit(runs[k], a.iters))
+                os.environ.pop(var, None)
+                print('%-6s %-6s ' % (name, k) + '  '.join('%s=%s: %.3f ms %.1f TF' % (var, v, sorted(t)[len(t) // 2], flops / sorted(t)[len(t) // 2] / 1e9)
+                                                          for v, t in res.items()), flush=True)
                 continue
             ms = timeit(runs[k], a.iters)
             print('%-6s %-6s %9.3f %9.1f' % (name, k, ms, flops / ms / 1e9), flush=True)
