@@ -302,8 +302,10 @@ def main():
             dom = max(fam, key=lambda k: fam[k][1])
             cnt, ms, fl = fam[dom]
             ach = fl / (ms * 1e-3) / 1e12
+            traffic = pmc_traffic(dom, a.batch)
             out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(dom, a.batch),
+                               'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                               'traffic': (traffic or {}).get('hbm_bytes_per_launch'), 'traffic_detail': traffic,
                                'launches': cnt, 'avg_launch_ms': round(ms / cnt, 4),
                                'share_of_masked_kernel_time': round(ms / tot_ms, 3)}
             out['kernel_families'] = {k: {'launches': v[0], 'ms': round(v[1], 2), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)}

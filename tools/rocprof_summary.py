@@ -25,6 +25,16 @@ def main():
     for name, calls, dur, avg, pct in rows[:top_n]:
         print('| `%s` | %d | %.2f | %.1f | %.2f |' % (short(name), calls, dur / 1e3, avg, pct))
     print('\nGPU kernel time total: %.1f ms over %d kernels (durations in the db are us).' % (total / 1e3, len(rows)))
+    # the families bench.py reports (its HIP-event clock brackets the whole library call: + k_c3_pack for fwd / dgrad,
+    # + k_c3_wgrad_reduce for wgrad)
+    fams = [('conv_fwd', r'k_c3_fwd<.*, false>|k_conv_fwd'), ('conv_dgrad', r'k_c3_fwd<.*, true>|k_conv_dgrad'),
+            ('conv_wgrad', r'k_c3_wgrad<|k_c3_wgrad_smallc|k_conv_wgrad')]
+    print('\n| family (main kernels only) | calls | total ms | avg ms |\n|---|---:|---:|---:|')
+    for fam, pat in fams:
+        sel = [r for r in rows if re.search(pat, r[0])]
+        calls, dur = sum(r[1] for r in sel), sum(r[2] for r in sel)
+        if calls:
+            print('| %s | %d | %.2f | %.3f |' % (fam, calls, dur / 1e3, dur / 1e3 / calls))
 
 
 if __name__ == '__main__':
