@@ -220,7 +220,7 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    if a.gpus > 1 or world > 1:
+    if a.gpus > 1 or world > 1 or os.environ.get('CPG_DP_FORCE') == '1':
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         torch.cuda.set_device(local % torch.cuda.device_count())
@@ -317,7 +317,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

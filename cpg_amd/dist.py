@@ -15,6 +15,8 @@ Semantics kept from the reference:
 The wrapper keeps the `.module` attribute and the `module.` prefix in named_modules(), so owner-mask
 dictionaries keyed like the reference's (`module.features.0`, ...) work unchanged.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -27,7 +29,9 @@ class DataParallel(nn.Module):
         self.module = module
         self.process_group = process_group
         self.large_numel = int(large_numel)
-        self._active = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        # CPG_DP_FORCE=1: run the hooks / collectives even at world size 1 (functional test of the RCCL path on one GPU)
+        self._active = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(process_group) > 1 or os.environ.get('CPG_DP_FORCE') == '1')
         self._world = dist.get_world_size(process_group) if self._active else 1
         self._handles = []
         self._small = []
