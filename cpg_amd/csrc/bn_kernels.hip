@@ -43,11 +43,11 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
 // callers keep fp32 running sums and fold them into fp64 there).  No per-element division: large planes are walked
 // image by image (4 independent visits per loop trip, so 4 loads are in flight per thread -- the one-visit-per-trip
 // version with a 64-bit (i / P, i % P) per element ran k_bn_stats at 4.9 TB/s and k_bnp_bwd_reduce at 3.3 TB/s);
-// planes smaller than the block are shared out kThreads / P images at a time.
+// small planes are walked flattened.
 template <class F, class FL>
 __device__ __forceinline__ void walk_planes(int P, int n0, int n1, F &&f, FL &&flush) {
     const int tid = threadIdx.x;
-    if (P >= kThreads) {
+    if (P >= 16 * kThreads) {
         for (int n = n0; n < n1; ++n) {
             int j = tid, trips = 0;
             for (; j + 3 * kThreads < P; j += 4 * kThreads) {
@@ -64,15 +64,16 @@ __device__ __forceinline__ void walk_planes(int P, int n0, int n1, F &&f, FL &&f
             flush();
         }
     } else {
-        const int G = kThreads / P, sub = tid / P, j = tid - sub * P;
-        if (sub < G) {
-            int cnt = 0;
-            for (int n = n0 + sub; n < n1; n += G) {
-                f(n, j);
-                if (++cnt == 64) {
-                    flush();
-                    cnt = 0;
-                }
+        // small planes: the (image, item) pairs of the slice are flattened so that every thread stays busy (a per-image
+        // walk would idle 23 % of the block on 784-item planes); 32-bit index arithmetic
+        const unsigned total = (unsigned)(n1 - n0) * (unsigned)P;
+        int cnt = 0;
+        for (unsigned i = tid; i < total; i += kThreads) {
+            const unsigned dn = i / (unsigned)P;
+            f(n0 + (int)dn, (int)(i - dn * (unsigned)P));
+            if (++cnt == 64) {
+                flush();
+                cnt = 0;
             }
         }
         flush();
