@@ -21,6 +21,18 @@ struct ConvGeom {
     int N, C, H, W, K, R, S, sh, sw, ph, pw, dh, dw, OH, OW;
 };
 
+// Input gradient of a STRIDED convolution, one residue class at a time.  gx[h][w] only receives taps r = (h + ph) mod sh
+// (+ sh, + 2 sh, ...): the positions of one residue class (rho, sigma) form the sub-grid h = h_start + sh*i, w = w_start +
+// sw*j, and on it the gradient is a dense, stride-1 transposed conv of gy with the sub-kernel W[..][rho + sh*r'][sigma +
+// sw*s'].  k_conv_dgrad runs that sub-problem with ConvGeom = {H, W := sub-grid extent; R, S := sub-kernel extent; stride
+// 1; ph, pw := the class's offset} and this struct says where its weights and outputs really live.  (The single-launch
+// form evaluated all R*S taps at every position and threw away (1 - 1/(sh*sw)) of the MFMAs and gathers: 8-13 TFLOP/s.)
+struct DgradSub {
+    int Hfull, Wfull;          // gx plane
+    int h_start, w_start, sh, sw;
+    int RSfull, Sfull, r0, s0; // weight layout [K][C][R][S] of the full kernel; first tap of the class
+};
+
 // ---------------------------------------------------------------------------------- loaders
 // conv fwd B: B[k=(ci,r,s)][j=p]
 template <int BN, int BK>
@@ -123,23 +135,27 @@ struct DgradALoader {
     static constexpr int MSTEP = 256 / BK;
     const float *w, *pm;
     float thr;
-    int C, RS, Kg, m0, t_k, t_m;
+    int C, RS, S, Kg, m0, t_k, t_m;
+    DgradSub sub;
     unsigned okmask;
     float rp[N];
-    __device__ __forceinline__ void init(const float *w_, const float *pm_, float thr_, const ConvGeom &g, int m0_) {
-        w = w_; pm = pm_; thr = thr_; C = g.C; RS = g.R * g.S; Kg = g.K * RS; m0 = m0_;
+    __device__ __forceinline__ void init(const float *w_, const float *pm_, float thr_, const ConvGeom &g, const DgradSub &sub_,
+                                         int m0_) {
+        w = w_; pm = pm_; thr = thr_; C = g.C; RS = g.R * g.S; S = g.S; Kg = g.K * RS; m0 = m0_; sub = sub_;
         t_k = threadIdx.x % BK;
         t_m = threadIdx.x / BK;
     }
     __device__ __forceinline__ void fetch(int kt, float (&r)[N]) {
         const int k = kt * BK + t_k;
-        const int co = k / RS, rs = k - co * RS;
+        const int co = k / RS, rs_sub = k - co * RS;
+        const int rr = rs_sub / S, ss = rs_sub - rr * S;
+        const int rs = (sub.r0 + sub.sh * rr) * sub.Sfull + sub.s0 + sub.sw * ss;      // tap of the full kernel
         okmask = 0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int ci = m0 + t_m + MSTEP * i;
             const bool ok = k < Kg && ci < C;
-            const int64_t off = ok ? ((int64_t)co * C + ci) * RS + rs : 0;
+            const int64_t off = ok ? ((int64_t)co * C + ci) * sub.RSfull + rs : 0;
             okmask |= (ok ? 1u : 0u) << i;
             r[i] = w[off];
             if (pm != nullptr) rp[i] = pm[off];            // wave-uniform condition
@@ -285,8 +301,9 @@ __global__ __launch_bounds__(256) void k_conv_fwd(ConvGeom g, const float *__res
 }
 
 template <class Cfg>
-__global__ __launch_bounds__(256) void k_conv_dgrad(ConvGeom g, const float *__restrict__ gy, const float *__restrict__ w,
-                                                    const float *__restrict__ pm, float thr, Epilogue ep, int tiles_m) {
+__global__ __launch_bounds__(256) void k_conv_dgrad(ConvGeom g, DgradSub sub, const float *__restrict__ gy,
+                                                    const float *__restrict__ w, const float *__restrict__ pm, float thr,
+                                                    Epilogue ep, int tiles_m) {
     __shared__ float smem[Cfg::SMEM_FLOATS];
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = lb % tiles_m, tn = lb / tiles_m;
@@ -296,22 +313,24 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(ConvGeom g, const float *__r
     const int m0 = tm * Cfg::BM;
     const int64_t q0 = (int64_t)tn * Cfg::BN;
     DgradALoader<Cfg::BM, Cfg::BK> la;
-    la.init(w, pm, thr, g, m0);
+    la.init(w, pm, thr, g, sub, m0);
     DgradBLoader<Cfg::BN, Cfg::BK> lbB;
     lbB.init(gy, g, q0, Q);
     f32x16 acc[Cfg::FM][Cfg::FN];
     igemm_mainloop<Cfg>(la, lbB, 0, (Kg + Cfg::BK - 1) / Cfg::BK, smem, acc);
     const int C = g.C;
+    const int64_t hw_full = (int64_t)sub.Hfull * sub.Wfull;
     int64_t colbase[Cfg::FN];
     col_setup<Cfg>(colbase, [&](int j) -> int64_t {
         const int64_t q = q0 + j;
         if (q >= Q) return -1;
         const int n = (int)(q / hw), rem = (int)(q - (int64_t)n * hw);
-        return (int64_t)n * C * hw + rem;
+        const int i = rem / g.W, j2 = rem - i * g.W;
+        return (int64_t)n * C * hw_full + (int64_t)(sub.h_start + sub.sh * i) * sub.Wfull + sub.w_start + sub.sw * j2;
     });
     for_each_acc<Cfg>(acc, [&](int m, int j, int fn, float v) {
         const int ci = m0 + m;
-        if (ci < C && colbase[fn] >= 0) epilogue_store(ep, colbase[fn] + (int64_t)ci * hw, v);
+        if (ci < C && colbase[fn] >= 0) epilogue_store(ep, colbase[fn] + (int64_t)ci * hw_full, v);
     });
 }
 
@@ -469,12 +488,20 @@ int cpg_conv3x3_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, c
                       float *gw, float *gpm, void *ws, size_t ws_bytes, hipStream_t stream);
 // the 3x3 weight-gradient kernel owns a 64-wide input-channel tile; <= 3 channels (the VGG stem) have their own
 // HBM-streaming kernel, 4..15 channels go to the generic kernel whose (ci, tap) column packing wastes less MFMA
+// ... and the pointwise kernels (pointwise.hip) for 1x1 convolutions (forward and input gradient)
+extern "C" int cpg_conv1x1_supported(const cpg_conv_desc *d);
+size_t cpg_conv1x1_pack_workspace(const cpg_conv_desc *d);
+int cpg_conv1x1_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
+                    float *y, void *ws, size_t ws_bytes, hipStream_t stream);
+int cpg_conv1x1_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx, void *ws,
+                      size_t ws_bytes, hipStream_t stream);
 static inline bool use_c3_wgrad(const cpg_conv_desc *d) { return cpg_conv3x3_supported(d) && (d->C >= 16 || d->C <= 3); }
 
 extern "C" size_t cpg_conv2d_workspace_bytes(const cpg_conv_desc *d) {
     ConvGeom g;
     if (make_geom(d, g) != CPG_OK) return 0;
-    const size_t pack = cpg_conv3x3_supported(d) ? cpg_conv3x3_pack_workspace(d) : 0;
+    const size_t pack = cpg_conv3x3_supported(d) ? cpg_conv3x3_pack_workspace(d)
+                                                 : cpg_conv1x1_supported(d) ? cpg_conv1x1_pack_workspace(d) : 0;
     if (use_c3_wgrad(d)) return std::max(pack, cpg_conv3x3_wgrad_workspace(d));
     int tm, tn, nsplit, per;
     conv_wgrad_tiles<CfgA>(g, tm, tn);
@@ -505,6 +532,23 @@ extern "C" int cpg_conv2d_fwd_generic(const cpg_conv_desc *d, const float *x, co
     return CPG_OK;
 }
 
+static int launch_dgrad_sub(const ConvGeom &g, const DgradSub &sub, const float *gy, const float *w, const float *pm, float thr,
+                            float *gx, hipStream_t stream) {
+    const int64_t Q = (int64_t)g.N * g.H * g.W;
+    Epilogue ep{gx, nullptr, BIAS_NONE, 1, 1, nullptr, nullptr, nullptr, thr};
+    if (g.C <= 64) {
+        const int tm = (g.C + CfgB::BM - 1) / CfgB::BM;
+        const int64_t tn = (Q + CfgB::BN - 1) / CfgB::BN;
+        hipLaunchKernelGGL(k_conv_dgrad<CfgB>, dim3((unsigned)(tm * tn)), dim3(256), 0, stream, g, sub, gy, w, pm, thr, ep, tm);
+    } else {
+        const int tm = (g.C + CfgA::BM - 1) / CfgA::BM;
+        const int64_t tn = (Q + CfgA::BN - 1) / CfgA::BN;
+        hipLaunchKernelGGL(k_conv_dgrad<CfgA>, dim3((unsigned)(tm * tn)), dim3(256), 0, stream, g, sub, gy, w, pm, thr, ep, tm);
+    }
+    CPG_CHECK_LAUNCH("cpg_conv2d_dgrad");
+    return CPG_OK;
+}
+
 extern "C" int cpg_conv2d_dgrad_generic(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr,
                                         float *gx, void *stream_v) {
     ConvGeom g;
@@ -512,30 +556,50 @@ extern "C" int cpg_conv2d_dgrad_generic(const cpg_conv_desc *d, const float *gy,
     if (rc) return rc;
     CPG_REQUIRE(gy && w && gx, "cpg_conv2d_dgrad: null pointer");
     hipStream_t stream = (hipStream_t)stream_v;
-    const int64_t Q = (int64_t)g.N * g.H * g.W;
-    Epilogue ep{gx, nullptr, BIAS_NONE, 1, 1, nullptr, nullptr, nullptr, thr};
-    if (g.C <= 64) {
-        const int tm = (g.C + CfgB::BM - 1) / CfgB::BM;
-        const int64_t tn = (Q + CfgB::BN - 1) / CfgB::BN;
-        hipLaunchKernelGGL(k_conv_dgrad<CfgB>, dim3((unsigned)(tm * tn)), dim3(256), 0, stream, g, gy, w, pm, thr, ep, tm);
-    } else {
-        const int tm = (g.C + CfgA::BM - 1) / CfgA::BM;
-        const int64_t tn = (Q + CfgA::BN - 1) / CfgA::BN;
-        hipLaunchKernelGGL(k_conv_dgrad<CfgA>, dim3((unsigned)(tm * tn)), dim3(256), 0, stream, g, gy, w, pm, thr, ep, tm);
+    const DgradSub whole{g.H, g.W, 0, 0, 1, 1, g.R * g.S, g.S, 0, 0};
+    if ((g.sh == 1 && g.sw == 1) || g.dh != 1 || g.dw != 1)      // dense, or strided + dilated (no CPG topology): one launch
+        return launch_dgrad_sub(g, whole, gy, w, pm, thr, gx, stream);
+    // strided: one dense sub-problem per residue class of (h + ph, w + pw) modulo the stride (see DgradSub)
+    bool need_zero = false;
+    for (int rho = 0; rho < g.sh; ++rho)
+        for (int sig = 0; sig < g.sw; ++sig) need_zero = need_zero || rho >= g.R || sig >= g.S;     // class without taps
+    if (need_zero) {
+        hipError_t e = hipMemsetAsync(gx, 0, (size_t)g.N * g.C * g.H * g.W * sizeof(float), stream);
+        if (e != hipSuccess) return hip_status(e, "cpg_conv2d_dgrad(memset)");
     }
-    CPG_CHECK_LAUNCH("cpg_conv2d_dgrad");
+    for (int rho = 0; rho < g.sh && rho < g.R; ++rho) {
+        const int h_start = ((rho - g.ph) % g.sh + g.sh) % g.sh;
+        if (h_start >= g.H) { need_zero = true; continue; }
+        for (int sig = 0; sig < g.sw && sig < g.S; ++sig) {
+            const int w_start = ((sig - g.pw) % g.sw + g.sw) % g.sw;
+            if (w_start >= g.W) continue;
+            ConvGeom s = g;
+            s.H = (g.H - h_start + g.sh - 1) / g.sh;
+            s.W = (g.W - w_start + g.sw - 1) / g.sw;
+            s.R = (g.R - rho + g.sh - 1) / g.sh;
+            s.S = (g.S - sig + g.sw - 1) / g.sw;
+            s.ph = (h_start + g.ph - rho) / g.sh;
+            s.pw = (w_start + g.pw - sig) / g.sw;
+            s.sh = s.sw = 1;
+            const DgradSub sub{g.H, g.W, h_start, w_start, g.sh, g.sw, g.R * g.S, g.S, rho, sig};
+            rc = launch_dgrad_sub(s, sub, gy, w, pm, thr, gx, stream);
+            if (rc) return rc;
+        }
+    }
     return CPG_OK;
 }
 
 extern "C" int cpg_conv2d_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr,
                               const float *bias, float *y, void *ws, size_t ws_bytes, void *stream) {
     if (d && cpg_conv3x3_supported(d)) return cpg_conv3x3_fwd(d, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream);
+    if (d && cpg_conv1x1_supported(d)) return cpg_conv1x1_fwd(d, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream);
     return cpg_conv2d_fwd_generic(d, x, w, pm, thr, bias, y, stream);
 }
 
 extern "C" int cpg_conv2d_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr,
                                 float *gx, void *ws, size_t ws_bytes, void *stream) {
     if (d && cpg_conv3x3_supported(d)) return cpg_conv3x3_dgrad(d, gy, w, pm, thr, gx, ws, ws_bytes, (hipStream_t)stream);
+    if (d && cpg_conv1x1_supported(d)) return cpg_conv1x1_dgrad(d, gy, w, pm, thr, gx, ws, ws_bytes, (hipStream_t)stream);
     return cpg_conv2d_dgrad_generic(d, gy, w, pm, thr, gx, stream);
 }
 

@@ -1,0 +1,302 @@
+// Masked 1x1 convolution (any stride, no padding) on fp32 MFMA: forward and input-gradient of
+// models/layers.py:108-109 for the pointwise layers -- 36 of ResNet-50's 53 convs (33 1x1 s1 + 3
+// 1x1 s2 downsample shortcuts, models/resnet.py), ~55 % of its FLOPs.
+//
+// A 1x1 conv over NCHW is a GEMM whose B operand is already k-major in memory:
+//     D[m][g] = sum_c Wp[c][m] * X[n_g][c][pix_g],     g = flattened (image, output pixel)
+// so no patch / halo is needed and the pixel tile can run ACROSS image boundaries: every tile is
+// BN = 224 flattened pixels = 7 MFMA fragments, with zero tile waste for 56x56, 28x28, 14x14 and 7x7
+// maps alike (a per-image tile would waste 12.5 % at 28x28 and 56 % at 7x7).
+//
+// Same loop discipline as conv3x3.hip's k_c3_fwd: packed K-major weights,
+// two LDS stages with one barrier per chunk, operands of k-step s+1 read while the MFMAs of step s
+// run, a branch-free chunk body with pinned instruction order in which the staging of later chunks
+// rides between the MFMAs (registers holding chunk ch+1 are stored to the other LDS stage and
+// refilled with chunk ch+2), activations fetched with range-checked buffer loads (out-of-range =>
+// 0, no selects).  LDS row strides are = 32 (mod 64) floats so that the two half-waves (channel
+// 2p / 2p+1 of a k-step) hit disjoint bank halves.
+//
+//   fwd  : reads x  [N][C][H][W]  at (oh*s, ow*s), writes y [N][K][OH][OW] densely
+//   dgrad: reads gy [N][K][OH][OW] densely, writes gx [N][C][H][W] at (oh*s, ow*s)
+//          (s > 1: the other positions of gx receive no gradient and are zeroed by a memset first)
+// The weight gradient of these layers stays on the generic split-K kernel of igemm_conv.hip.
+#include <algorithm>
+#include "igemm_core.h"
+
+using namespace cpg;
+
+namespace {
+
+struct PwGeom {
+    int N, C, M;               // images; channels read; channels produced
+    int Mp;                    // row stride of the packed weights (M rounded up to 128)
+    int OW, HWo;               // pixel grid the GEMM runs over (the conv's OUTPUT grid in both passes)
+    int in_plane, in_sy, in_sx;     // channel plane size of the tensor read, and its row / column pitch per grid step
+    int out_plane, out_sy, out_sx;  // same for the tensor written
+    int tiles_m;
+    long long G;               // N * HWo
+};
+
+__device__ __forceinline__ f32x4 ld_sv4(const float *sbase, unsigned byte_off) {
+    return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(sbase) + byte_off);
+}
+
+template <int BM_, int WM_, int WN_, int FN_, int CK_, bool VEC_, int MINW_>
+struct PwCfg {
+    static constexpr int BM = BM_, WM = WM_, WN = WN_, FN = FN_, CK = CK_, MINW = MINW_;
+    static constexpr bool VEC = VEC_;                        // activations staged as float4 (dense, 4 | HWo)
+    static_assert(WM * WN == 4 && BM % (32 * WM) == 0 && CK % 2 == 0, "bad pointwise config");
+    static constexpr int FM = BM / 32 / WM;
+    static constexpr int BN = 32 * FN * WN;
+    static constexpr int LDW = BM + 32, LDX = (BN % 64 == 32) ? BN : BN + 32;      // = 32 (mod 64)
+    static_assert(LDW % 64 == 32 && LDX % 64 == 32 && BM % 64 == 0, "row strides must be 32 mod 64");
+    static constexpr int W4 = BM / 4, WROWS = 256 / W4, NW4 = (CK + WROWS - 1) / WROWS;
+    static constexpr int XE = VEC ? CK * BN / 4 : CK * BN;   // staged activation items (float4 or float) per chunk
+    static constexpr int NX = (XE + 255) / 256;
+    // both LDS regions are padded to whole staging passes: every staging store is unconditional
+    static constexpr int W_ELEMS = NW4 * WROWS * LDW;
+    static constexpr int XS_ELEMS = (CK * LDX > NX * 256 * (VEC ? 4 : 1) ? CK * LDX : NX * 256 * (VEC ? 4 : 1)) + LDX;
+    static constexpr int STAGE = W_ELEMS + XS_ELEMS;
+    static constexpr int SMEM_FLOATS = 2 * STAGE;
+    static constexpr int NS = CK / 2;
+    static constexpr int NITEMS = NW4 + NX;
+    static constexpr int PER_STEP = (NITEMS + NS - 1) / NS;  // staged items handled per k-step
+};
+
+// Wp[c][m] (row stride Mp, zero padded to whole CK x 128 blocks + WROWS slack rows):
+//   fwd  : Wp[ci][co] = W[co][ci] * bin(pm)        dgrad: Wp[co][ci] = W[co][ci] * bin(pm)
+__global__ __launch_bounds__(256) void k_pw_pack(const float *__restrict__ w, const float *__restrict__ pm, float thr,
+                                                 float *__restrict__ out, int K, int C, int rows, int Mp, int dgrad) {
+    const int64_t total = (int64_t)rows * Mp, nthreads = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += nthreads) {
+        const int m = (int)(o % Mp), c = (int)(o / Mp);
+        const int co = dgrad ? c : m, ci = dgrad ? m : c;
+        float v = 0.0f;
+        if (co < K && ci < C) {
+            const int64_t off = (int64_t)co * C + ci;
+            v = w[off];
+            if (pm != nullptr) v *= binarize(pm[off], thr);
+        }
+        out[o] = v;
+    }
+}
+
+template <class Cfg, bool DGRAD>
+__global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__restrict__ x, const float *__restrict__ wp,
+                                                       const float *__restrict__ bias, float *__restrict__ y) {
+    __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    unsigned lb = xcd_remap(blockIdx.x, gridDim.x);      // m tile fastest: blocks sharing a pixel tile share an L2
+    const int tm = lb % g.tiles_m;
+    const long long g0 = (long long)(lb / g.tiles_m) * Cfg::BN;
+    const int m0 = tm * Cfg::BM;
+    const int n_first = (int)(g0 / g.HWo);
+
+    // ---- staging descriptors (fixed for the life of the block) ----
+    const int wcol = (tid % Cfg::W4) * 4, wrow0 = tid / Cfg::W4;
+    const int wdst = wrow0 * Cfg::LDW + wcol;
+    const unsigned wbyte = (unsigned)(wrow0 * g.Mp + m0 + wcol) * 4u;
+    // activations: byte offset from image n_first's channel 0 (of the current chunk), or 0x80000000 for grid
+    // positions past the last image -- the buffer unit's range check returns 0 for those
+    constexpr int kOutOfRange = (int)0x80000000;
+    int xbyte[Cfg::NX], xdst[Cfg::NX];
+#pragma unroll
+    for (int i = 0; i < Cfg::NX; ++i) {
+        const int e = tid + 256 * i;
+        constexpr int PER_ROW = Cfg::VEC ? Cfg::BN / 4 : Cfg::BN;
+        const int cl = e / PER_ROW, j = (e - cl * PER_ROW) * (Cfg::VEC ? 4 : 1);
+        const long long gg = g0 + j;
+        const bool ok = e < Cfg::XE && gg < g.G;
+        const int n_rel = ok ? (int)(gg / g.HWo) - n_first : 0;
+        const int q = ok ? (int)(gg % g.HWo) : 0;
+        const int pos = (q / g.OW) * g.in_sy + (q % g.OW) * g.in_sx;
+        xbyte[i] = ok ? ((n_rel * g.C + cl) * g.in_plane + pos) * 4 : kOutOfRange;
+        xdst[i] = e < Cfg::XE ? cl * Cfg::LDX + j : Cfg::CK * Cfg::LDX;            // spare row for the idle threads of the last pass
+    }
+    const long long remaining = (long long)(g.N - n_first) * g.C * g.in_plane * 4;
+    const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(x + (long long)n_first * g.C * g.in_plane), 0, (int)std::min<long long>(remaining, 0x7FFFFFFFll), 0x00020000);
+
+    f32x4 rw[Cfg::NW4];
+    f32x4 rxv[Cfg::VEC ? Cfg::NX : 1];
+    float rxs[Cfg::VEC ? 1 : Cfg::NX];
+    auto load_item = [&](int k, int c0) {
+        if (k < Cfg::NW4) {
+            rw[k] = ld_sv4(wp + ((int64_t)c0 + Cfg::WROWS * k) * g.Mp, wbyte);
+        } else if (Cfg::VEC) {
+            rxv[k - Cfg::NW4] = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, xbyte[k - Cfg::NW4] + c0 * g.in_plane * 4, 0, 0));
+        } else {
+            rxs[k - Cfg::NW4] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, xbyte[k - Cfg::NW4] + c0 * g.in_plane * 4, 0, 0));
+        }
+    };
+    auto store_item = [&](int k, float *stage) {
+        if (k < Cfg::NW4)
+            *reinterpret_cast<f32x4 *>(stage + wdst + Cfg::WROWS * k * Cfg::LDW) = rw[k];
+        else if (Cfg::VEC)
+            *reinterpret_cast<f32x4 *>(stage + Cfg::W_ELEMS + xdst[k - Cfg::NW4]) = rxv[k - Cfg::NW4];
+        else
+            stage[Cfg::W_ELEMS + xdst[k - Cfg::NW4]] = rxs[k - Cfg::NW4];
+    };
+
+    const int a_base = lh * Cfg::LDW + wm * Cfg::FM * 32 + li;
+    const int b_base = Cfg::W_ELEMS + lh * Cfg::LDX + wn * Cfg::FN * 32 + li;
+
+    f32x16 acc[Cfg::FM][Cfg::FN];
+#pragma unroll
+    for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < Cfg::FN; ++fn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[fm][fn][e] = 0.0f;
+
+    const int nch = g.C / Cfg::CK;                 // the host guarantees C % CK == 0
+#pragma unroll
+    for (int k = 0; k < Cfg::NITEMS; ++k) load_item(k, 0);
+#pragma unroll
+    for (int k = 0; k < Cfg::NITEMS; ++k) store_item(k, smem);
+#pragma unroll
+    for (int k = 0; k < Cfg::NITEMS; ++k) load_item(k, min(1, nch - 1) * Cfg::CK);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const float *cur = smem + (ch & 1) * Cfg::STAGE;
+        float *other = smem + ((ch + 1) & 1) * Cfg::STAGE;
+        const int c_next2 = min(ch + 2, nch - 1) * Cfg::CK;        // clamped: the tail re-stages data nobody reads
+        float a[2][Cfg::FM], b[2][Cfg::FN];
+        auto lds_operands = [&](int st, int set) {
+#pragma unroll
+            for (int fm = 0; fm < Cfg::FM; ++fm) a[set][fm] = cur[a_base + 2 * st * Cfg::LDW + fm * 32];
+#pragma unroll
+            for (int fn = 0; fn < Cfg::FN; ++fn) b[set][fn] = cur[b_base + 2 * st * Cfg::LDX + fn * 32];
+        };
+        lds_operands(0, 0);
+#pragma unroll
+        for (int st = 0; st < Cfg::NS; ++st) {
+            if (st + 1 < Cfg::NS) lds_operands(st + 1, (st + 1) & 1);
+#pragma unroll
+            for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < Cfg::FN; ++fn)
+                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][fm], b[st & 1][fn], acc[fm][fn], 0, 0, 0);
+            // this step's share of the staging: registers hold chunk ch+1 -> other stage, then refill with chunk ch+2
+#pragma unroll
+            for (int k = st * Cfg::PER_STEP; k < (st + 1) * Cfg::PER_STEP && k < Cfg::NITEMS; ++k) {
+                store_item(k, other);
+                load_item(k, c_next2);
+            }
+#pragma unroll
+            for (int i = 0; i < Cfg::FM * Cfg::FN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                if (i >= 1 && i <= Cfg::PER_STEP) {
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: D col = grid position (lane & 31), D row = channel ----
+#pragma unroll
+    for (int fn = 0; fn < Cfg::FN; ++fn) {
+        const long long gg = g0 + (wn * Cfg::FN + fn) * 32 + li;
+        const bool pok = gg < g.G;
+        const int n = pok ? (int)(gg / g.HWo) : 0, q = pok ? (int)(gg % g.HWo) : 0;
+        float *yout = y + (int64_t)n * g.M * g.out_plane + (q / g.OW) * g.out_sy + (q % g.OW) * g.out_sx;
+#pragma unroll
+        for (int fm = 0; fm < Cfg::FM; ++fm) {
+            float bv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) bv[e] = 0.0f;
+            if (bias != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    bv[e] = bias[co < g.M ? co : 0];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (pok && co < g.M) yout[(int64_t)co * g.out_plane] = acc[fm][fn][e] + bv[e];
+            }
+        }
+    }
+}
+
+//                BM  WM WN FN CK  VEC  MINW
+using PwV = PwCfg<128, 4, 1, 7, 16, true, 2>;       // dense reads, 4 | pixels per image: float4 staging
+using PwS = PwCfg<128, 4, 1, 7, 16, false, 2>;      // strided reads (1x1 s2 forward) or odd plane sizes (7x7 maps)
+
+inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+inline size_t pack_bytes(int c_read, int m) { return ((size_t)pad_to(c_read, 16) + 16) * pad_to(m, 128) * sizeof(float); }
+
+template <class Cfg, bool DGRAD>
+int launch(PwGeom g, const float *x, const float *wp, const float *bias, float *y, hipStream_t stream, const char *what) {
+    g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
+    const int64_t blocks = (g.G + Cfg::BN - 1) / Cfg::BN * g.tiles_m;
+    if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "conv1x1: grid too large");
+    hipLaunchKernelGGL((k_pw<Cfg, DGRAD>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y);
+    CPG_CHECK_LAUNCH(what);
+    return CPG_OK;
+}
+
+}  // namespace
+
+extern "C" int cpg_conv1x1_supported(const cpg_conv_desc *d) {
+    if (getenv("CPG_DISABLE_CONV1X1")) return 0;
+    if (!(d->R == 1 && d->S == 1 && d->pad_h == 0 && d->pad_w == 0 && d->groups == 1 && d->stride_h >= 1 && d->stride_w >= 1 &&
+          d->N > 0 && d->C > 0 && d->K > 0 && d->H > 0 && d->W > 0))
+        return 0;
+    const int OH = (d->H - 1) / d->stride_h + 1, OW = (d->W - 1) / d->stride_w + 1;
+    // whole 16-channel chunks on both sides (forward contracts over C, the input gradient over K); a tile's images are
+    // addressed with 31-bit byte offsets
+    const int64_t span = (int64_t)(224 / (OH * OW) + 2) * std::max(d->C, d->K) * d->H * d->W * 4;
+    return d->C % 16 == 0 && d->K % 16 == 0 && span < (1ll << 31) && (int64_t)std::max(d->C, d->K) * d->H * d->W < (1ll << 28);
+}
+
+size_t cpg_conv1x1_pack_workspace(const cpg_conv_desc *d) { return std::max(pack_bytes(d->C, d->K), pack_bytes(d->K, d->C)); }
+
+int cpg_conv1x1_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
+                    float *y, void *ws, size_t ws_bytes, hipStream_t stream) {
+    const char *what = "cpg_conv2d_fwd(1x1)";
+    CPG_REQUIRE(x && w && y, "%s: null pointer", what);
+    const size_t need = pack_bytes(d->C, d->K);
+    if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
+    CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
+    float *wp = (float *)ws;
+    const int rows = pad_to(d->C, 16), Mp = pad_to(d->K, 128);
+    hipLaunchKernelGGL(k_pw_pack, dim3(stream_grid((int64_t)rows * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, d->K, d->C, rows, Mp, 0);
+    const int OH = (d->H - 1) / d->stride_h + 1, OW = (d->W - 1) / d->stride_w + 1;
+    PwGeom g{d->N, d->C, d->K, Mp, OW, OH * OW, d->H * d->W, d->stride_h * d->W, d->stride_w, OH * OW, OW, 1, 0, (long long)d->N * OH * OW};
+    const bool dense = d->stride_h == 1 && d->stride_w == 1;
+    if (dense && (OH * OW) % 4 == 0 && (((uintptr_t)x) & 15) == 0) return launch<PwV, false>(g, x, wp, bias, y, stream, what);
+    return launch<PwS, false>(g, x, wp, bias, y, stream, what);
+}
+
+int cpg_conv1x1_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx, void *ws,
+                      size_t ws_bytes, hipStream_t stream) {
+    const char *what = "cpg_conv2d_dgrad(1x1)";
+    CPG_REQUIRE(gy && w && gx, "%s: null pointer", what);
+    const size_t need = pack_bytes(d->K, d->C);
+    if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
+    CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
+    float *wp = (float *)ws;
+    const int rows = pad_to(d->K, 16), Mp = pad_to(d->C, 128);
+    hipLaunchKernelGGL(k_pw_pack, dim3(stream_grid((int64_t)rows * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, d->K, d->C, rows, Mp, 1);
+    const int OH = (d->H - 1) / d->stride_h + 1, OW = (d->W - 1) / d->stride_w + 1;
+    const bool dense = d->stride_h == 1 && d->stride_w == 1;
+    if (!dense) {       // positions the strided conv never read receive no gradient
+        hipError_t e = hipMemsetAsync(gx, 0, (size_t)d->N * d->C * d->H * d->W * sizeof(float), stream);
+        if (e != hipSuccess) return hip_status(e, what);
+    }
+    // reads gy (K channels, dense over the output grid), produces gx (C channels) at the strided positions
+    PwGeom g{d->N, d->K, d->C, Mp, OW, OH * OW, OH * OW, OW, 1, d->H * d->W, d->stride_h * d->W, d->stride_w, 0, (long long)d->N * OH * OW};
+    if ((OH * OW) % 4 == 0 && (((uintptr_t)gy) & 15) == 0) return launch<PwV, true>(g, gy, wp, nullptr, gx, stream, what);
+    return launch<PwS, true>(g, gy, wp, nullptr, gx, stream, what);
+}

@@ -118,6 +118,14 @@ def test_linear_golden(name):
     (2, 3, 64, 64, 16, 7, 2, 3, False, False),       # ResNet stem
     (3, 64, 28, 28, 256, 1, 1, 0, False, True),      # ResNet 1x1
     (3, 256, 28, 28, 512, 1, 2, 0, False, False),    # ResNet downsample
+    (5, 32, 7, 7, 48, 1, 1, 0, False, True),         # pointwise kernel, 7x7 maps: scalar staging, tiles span 5 images
+    (9, 48, 14, 14, 80, 1, 1, 0, True, False),       # pointwise kernel, float4 staging, tiles straddle images, bias
+    (2, 16, 15, 15, 32, 1, 2, 0, False, True),       # pointwise stride 2 on an odd map (scatter + zero fill in dgrad)
+    (2, 24, 8, 8, 16, 1, 1, 0, False, False),        # 1x1 with C % 16 != 0 -> generic kernel
+    (2, 20, 15, 17, 24, 3, 2, 1, False, True),       # strided dgrad by residue classes, odd map
+    (1, 8, 20, 20, 8, 5, 3, 2, True, False),         # stride 3, 5x5: nine residue classes with 1..4 taps
+    (2, 8, 9, 9, 8, 1, 2, 0, False, False),          # 1x1 s2 on the generic kernel: three classes have no taps (zero fill)
+    (2, 130, 12, 12, 70, 3, 2, 1, False, False),     # strided dgrad, > 64 input channels (128-wide tile), ragged channels
     (2, 64, 56, 56, 64, 3, 2, 1, True, False),       # SphereNet stride-2 with bias
 ])
 def test_conv_oracle(N, C, H, W, K, k, s, p, bias, pm):
