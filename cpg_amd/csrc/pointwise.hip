@@ -55,7 +55,7 @@ struct PwCfg {
     static constexpr int NX = (XE + 255) / 256;
     // both LDS regions are padded to whole staging passes: every staging store is unconditional
     static constexpr int W_ELEMS = NW4 * WROWS * LDW;
-    static constexpr int XS_ELEMS = (CK * LDX > NX * 256 * (VEC ? 4 : 1) ? CK * LDX : NX * 256 * (VEC ? 4 : 1)) + LDX;
+    static constexpr int XS_ELEMS = CK * LDX + LDX;          // + one spare row: the idle threads of the last staging pass write there
     static constexpr int STAGE = W_ELEMS + XS_ELEMS;
     static constexpr int SMEM_FLOATS = 2 * STAGE;
     static constexpr int NS = CK / 2;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
 }
 
 //                BM  WM WN FN CK  VEC  MINW
-using PwV = PwCfg<128, 4, 1, 7, 16, true, 2>;       // dense reads, 4 | pixels per image: float4 staging
+using PwV = PwCfg<128, 4, 1, 7, 16, true, 3>;       // dense reads, 4 | pixels per image: float4 staging
 using PwS = PwCfg<128, 4, 1, 7, 16, false, 2>;      // strided reads (1x1 s2 forward) or odd plane sizes (7x7 maps)
 
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }

@@ -131,6 +131,18 @@ def bn_relu(x, bn, relu=True):
     return _BnReluFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, training, relu)
 
 
+ENABLED = True      # module-wide switch (tests compare the fused against the stock evaluation)
+
+
+def bn_act(bn, act, x):
+    """act(bn(x)) for the residual topologies (models/resnet.py: `self.relu(self.bn1(...))`, `self.bn3(...)`): one fused
+    kernel pair when `act` is a plain nn.ReLU (or None) and `bn` qualifies, the stock modules otherwise."""
+    if ENABLED and (act is None or type(act) is nn.ReLU) and fusable(bn, x):
+        return bn_relu(x, bn, relu=act is not None)
+    y = bn(x)
+    return y if act is None else act(y)
+
+
 class FusedSequential(nn.Sequential):
     """nn.Sequential that runs BatchNorm2d -> ReLU (-> MaxPool2d(2, 2)) groups through the fused kernels.
     Module registration (names, parameters, buffers) is exactly nn.Sequential's."""
@@ -143,7 +155,7 @@ class FusedSequential(nn.Sequential):
         i, n = 0, len(mods)
         while i < n:
             m = mods[i]
-            if (self.fuse and i + 1 < n and isinstance(m, nn.BatchNorm2d) and isinstance(mods[i + 1], nn.ReLU)
+            if (self.fuse and ENABLED and i + 1 < n and isinstance(m, nn.BatchNorm2d) and isinstance(mods[i + 1], nn.ReLU)
                     and fusable(m, input)):
                 if (self.fuse_pool and i + 2 < n and _is_pool2(mods[i + 2]) and input.shape[2] % 2 == 0
                         and input.shape[3] % 2 == 0 and m.track_running_stats):
@@ -152,6 +164,10 @@ class FusedSequential(nn.Sequential):
                     continue
                 input = bn_relu(input, m, relu=True)
                 i += 2
+                continue
+            if self.fuse and ENABLED and isinstance(m, nn.BatchNorm2d) and fusable(m, input):
+                input = bn_relu(input, m, relu=False)       # a lone BatchNorm2d (ResNet shortcut: conv1x1 -> BN)
+                i += 1
                 continue
             input = m(input)
             i += 1

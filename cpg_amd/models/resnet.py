@@ -8,6 +8,7 @@ network_width_multiplier with the reference's int() placement; heads are per-tas
 import torch.nn as nn
 
 from . import layers as nl
+from .fused_bn import FusedSequential, bn_act
 
 __all__ = ['ResNet', 'BasicBlock', 'Bottleneck', 'resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152',
            'resnext50_32x4d', 'resnext101_32x8d']
@@ -42,8 +43,8 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
+        out = bn_act(self.bn1, self.relu, self.conv1(x))
+        out = bn_act(self.bn2, None, self.conv2(out))
         out += x if self.downsample is None else self.downsample(x)
         return self.relu(out)
 
@@ -67,9 +68,9 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
+        out = bn_act(self.bn1, self.relu, self.conv1(x))
+        out = bn_act(self.bn2, self.relu, self.conv2(out))
+        out = bn_act(self.bn3, None, self.conv3(out))
         out += x if self.downsample is None else self.downsample(x)
         return self.relu(out)
 
@@ -131,7 +132,7 @@ class ResNet(nn.Module):
             self.dilation *= stride
             stride = 1
         if stride != 1 or self.inplanes != result_planes:
-            downsample = nn.Sequential(conv1x1(self.inplanes, result_planes, stride), norm_layer(result_planes))
+            downsample = FusedSequential(conv1x1(self.inplanes, result_planes, stride), norm_layer(result_planes))
         stack = [block(self.inplanes, planes, stride, downsample, self.groups, self.base_width, previous_dilation,
                        norm_layer)]
         self.inplanes = result_planes
@@ -155,7 +156,7 @@ class ResNet(nn.Module):
         self.classifier = self.classifiers[self.datasets.index(dataset)]
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(bn_act(self.bn1, self.relu, self.conv1(x)))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = self.avgpool(x)
         return self.classifier(x.view(x.size(0), -1))

@@ -666,6 +666,59 @@ def test_resnet_spherenet_backward_matches_torch_ops(arch, width, shape, ncls, m
         assert err <= 2e-3 * sc, '%s: max err %g vs scale %g' % (n, err, sc)
 
 
+@pytest.mark.parametrize('block,stride', [('Bottleneck', 1), ('Bottleneck', 2), ('BasicBlock', 1), ('BasicBlock', 2)])
+def test_resnet_block_fused_bn_equals_stock_bn(block, stride):
+    """One residual block in TRAIN mode: the fused BatchNorm(+ReLU) evaluation (main path and conv1x1 -> BN shortcut)
+    against the stock nn.BatchNorm2d / nn.ReLU modules -- output, running statistics, input and parameter gradients.
+    (Whole-network comparisons in train mode are chaotic: ~50 batch-8 BatchNorms amplify round-off and flip ReLU masks.)"""
+    from cpg_amd.models import fused_bn, resnet
+    torch.manual_seed(5)
+    cls = getattr(resnet, block)
+    inplanes, planes = 32, 16
+    out_planes = planes * cls.expansion
+    down = None
+    if stride != 1 or inplanes != out_planes:
+        down = fused_bn.FusedSequential(resnet.conv1x1(inplanes, out_planes, stride), nn.BatchNorm2d(out_planes))
+    blk = cls(inplanes, planes, stride, down)
+    for m in blk.modules():
+        if isinstance(m, nl.SharableConv2d):
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.uniform_(m.weight, 0.5, 1.5)
+            nn.init.uniform_(m.bias, -0.5, 0.5)
+    blk = blk.to(DEV).train()
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(16, inplanes, 28, 28, generator=g).to(DEV)
+    gy = None
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+
+    def run(enabled):
+        nonlocal gy
+        fused_bn.ENABLED = enabled
+        try:
+            blk.load_state_dict(sd)
+            blk.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            out = blk(x)
+            if gy is None:
+                gy = torch.randn(out.shape, generator=g).to(DEV)
+            out.backward(gy)
+        finally:
+            fused_bn.ENABLED = True
+        grads = {n: p.grad.cpu().numpy() for n, p in blk.named_parameters() if p.grad is not None}
+        grads['input'] = x.grad.cpu().numpy()
+        return out.detach().cpu().numpy(), grads, {n: b.detach().cpu().numpy() for n, b in blk.named_buffers()}
+    o1, g1, b1 = run(True)
+    o0, g0, b0 = run(False)
+    np.testing.assert_allclose(o1, o0, rtol=1e-3, atol=1e-4 * float(np.abs(o0).max()))
+    for n in b0:
+        np.testing.assert_allclose(b1[n], b0[n], rtol=1e-4, atol=1e-5 * float(np.abs(b0[n]).max()) + 1e-7, err_msg=n)
+    assert set(g1) == set(g0)
+    for n in g0:
+        sc = float(np.abs(g0[n]).max()) + 1e-20
+        assert float(np.abs(g1[n] - g0[n]).max()) <= 1e-3 * sc, n
+
+
 # --------------------------------------------------------------------------- fused masked SGD (SURVEY 8f.1)
 @pytest.mark.parametrize('nesterov', [True, False])
 def test_masked_sgd_equals_routing_then_torch_sgd(nesterov):
