@@ -16,7 +16,7 @@
 // weight-gradient:
 //   block = 64 co x 64 ci x 9 taps, K = pixels.  Each wave owns a 32 co x 32 ci fragment for ALL 9
 //   taps (9 accumulators): one gy operand read feeds 9 MFMAs against 9 shifted reads of the same
-//   LDS input patch.  Split-K over (image, pixel-tile) ranges; partials reduced by k_c3_wgrad_reduce,
+//   LDS input patch.  Split-K over (image, pixel-tile) ranges; partials reduced by k_split_reduce,
 //   which also applies the autograd epilogue gW = g*bin(pm), gPM = g*W.
 #include <algorithm>
 #include "igemm_core.h"
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
     }
     // partial result, tap-major: part[split][tap][co][ci] -- lanes 0-31 of a store cover 32 consecutive ci (128 bytes).
     // (The [co][ci][tap] order of the final gradient would make every lane's 4-byte store its own 32-byte sector:
-    // WRITE_SIZE showed 1.2 GB per launch for 0.15 GB of partials.)  k_c3_wgrad_reduce transposes while it sums.
+    // WRITE_SIZE showed 1.2 GB per launch for 0.15 GB of partials.)  k_split_reduce transposes while it sums.
     float *dst = part + (int64_t)split * M * C * 9;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -618,44 +618,6 @@ __global__ __launch_bounds__(256) void k_c3_wgrad_smallc(int N, int C, int H, in
             if (co < M && li < J) dst[(int64_t)co * J + li] = v;
         }
     }
-}
-
-// Sums the split partials in a fixed order (deterministic for a given shape) and applies the autograd epilogue.
-// tap_plane = 0: the partials are laid out like the output; tap_plane = M * C: they are tap-major,
-// part[split][tap][co][ci] (what k_c3_wgrad writes with 128-byte coalesced stores), and position p is scattered into
-// [co][ci][tap].  `ks` (a power of two <= 64) threads share one output, each summing every ks-th split, combined
-// through LDS: layers with few outputs have the most splits (64 -> 64 channels: 36 864 outputs x 1024 splits), and one
-// thread per output left that sum latency bound (764 us for the stem, 320 us for features.3).
-__global__ __launch_bounds__(256) void k_c3_wgrad_reduce(const float *__restrict__ part, int nsplit, int64_t out_elems,
-                                                         int64_t tap_plane, int ks, Epilogue ep) {
-    __shared__ float red[256];
-    const int tid = threadIdx.x, P = 256 / ks, pl = tid % P, sl = tid / P;
-    for (int64_t base = (int64_t)blockIdx.x * P; base < out_elems; base += (int64_t)gridDim.x * P) {
-        const int64_t p = base + pl;
-        float s = 0.0f;
-        if (p < out_elems)
-            for (int k = sl; k < nsplit; k += ks) s += part[(int64_t)k * out_elems + p];
-        if (ks > 1) {
-            red[tid] = s;
-            __syncthreads();
-            if (sl == 0)
-                for (int j = 1; j < ks; ++j) s += red[j * P + pl];
-            __syncthreads();
-        }
-        if (sl == 0 && p < out_elems) {
-            const int64_t e = tap_plane ? (p % tap_plane) * 9 + p / tap_plane : p;
-            epilogue_store(ep, e, s);
-        }
-    }
-}
-
-static void launch_wgrad_reduce(const float *part, int nsplit, int64_t out_elems, int64_t tap_plane, const Epilogue &ep,
-                                hipStream_t stream) {
-    int ks = 1;
-    while (ks < 64 && ks * 2 <= nsplit && out_elems * ks < 262144) ks *= 2;
-    const int64_t groups = (out_elems + 256 / ks - 1) / (256 / ks);
-    hipLaunchKernelGGL(k_c3_wgrad_reduce, dim3((unsigned)std::min<int64_t>(groups, 16384)), dim3(256), 0, stream, part, nsplit,
-                       out_elems, tap_plane, ks, ep);
 }
 
 // ------------------------------------------------------------------------------ dispatch
@@ -809,7 +771,7 @@ static int w3_launch(const cpg_conv_desc *d, const float *x, const float *gy, co
     hipLaunchKernelGGL(k_c3_wgrad<Cfg>, dim3((unsigned)(p.tiles_co * p.tiles_ci * p.nsplit)), dim3(256), 0, stream, d->N, d->C, d->H,
                        d->W, d->K, p.tiles_x, p.tiles_y, p.tiles_co, p.tiles_ci, p.units_per_split, x, gy, (float *)ws);
     const int64_t out_elems = (int64_t)d->K * d->C * 9;
-    launch_wgrad_reduce((const float *)ws, p.nsplit, out_elems, (int64_t)d->K * d->C, ep, stream);
+    launch_split_reduce((const float *)ws, p.nsplit, out_elems, (int64_t)d->K * d->C, ep, stream);
     CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(3x3)");
     return CPG_OK;
 }
@@ -844,7 +806,7 @@ int cpg_conv3x3_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, c
         hipLaunchKernelGGL(k_c3_wgrad_smallc, dim3((unsigned)p.blocks_co, (unsigned)p.nsplit), dim3(256), 0, stream, d->N, d->C, d->H,
                            d->W, d->K, p.tiles_x, p.tiles_y, p.units_per_split, x, gy, (float *)ws);
         const int64_t out_elems = (int64_t)d->K * d->C * 9;
-        launch_wgrad_reduce((const float *)ws, p.nsplit, out_elems, 0, ep, stream);
+        launch_split_reduce((const float *)ws, p.nsplit, out_elems, 0, ep, stream);
         CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(3x3 stem)");
         return CPG_OK;
     }

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(ConvGeom g, DgradSub sub, co
 }
 
 // split-K over output pixels; blockIdx.y = split.  With nsplit > 1 raw partials go to `part`
-// ([nsplit][K*C*R*S]) and k_splitk_reduce applies the epilogue.
+// ([nsplit][K*C*R*S]) and k_split_reduce (igemm_core.h) applies the epilogue.
 template <class Cfg>
 __global__ __launch_bounds__(256) void k_conv_wgrad(ConvGeom g, const float *__restrict__ x, const float *__restrict__ gy,
                                                     Epilogue ep, float *__restrict__ part, int tiles_m, int kt_per_split) {
@@ -404,17 +404,6 @@ __global__ __launch_bounds__(256) void k_gemm(const float *__restrict__ A, int64
             else epilogue_store(ep, e, v);
         }
     });
-}
-
-// out[e] = epilogue(sum_s part[s][e]) -- deterministic order, one streaming pass
-__global__ __launch_bounds__(256) void k_splitk_reduce(const float *__restrict__ part, int nsplit, int64_t out_elems,
-                                                       Epilogue ep) {
-    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < out_elems; e += nthreads) {
-        float s = 0.0f;
-        for (int k = 0; k < nsplit; ++k) s += part[(int64_t)k * out_elems + e];
-        epilogue_store(ep, e, s);
-    }
 }
 
 // gb[c] = sum over n, q of gy[n][c][q]   (conv: rows = N, inner = OH*OW; linear: inner = 1 with stride C)
@@ -495,6 +484,10 @@ int cpg_conv1x1_fwd(const cpg_conv_desc *d, const float *x, const float *w, cons
                     float *y, void *ws, size_t ws_bytes, hipStream_t stream);
 int cpg_conv1x1_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx, void *ws,
                       size_t ws_bytes, hipStream_t stream);
+extern "C" int cpg_conv1x1_wgrad_supported(const cpg_conv_desc *d);
+size_t cpg_conv1x1_wgrad_workspace(const cpg_conv_desc *d);
+int cpg_conv1x1_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
+                      float *gw, float *gpm, void *ws, size_t ws_bytes, hipStream_t stream);
 static inline bool use_c3_wgrad(const cpg_conv_desc *d) { return cpg_conv3x3_supported(d) && (d->C >= 16 || d->C <= 3); }
 
 extern "C" size_t cpg_conv2d_workspace_bytes(const cpg_conv_desc *d) {
@@ -503,6 +496,7 @@ extern "C" size_t cpg_conv2d_workspace_bytes(const cpg_conv_desc *d) {
     const size_t pack = cpg_conv3x3_supported(d) ? cpg_conv3x3_pack_workspace(d)
                                                  : cpg_conv1x1_supported(d) ? cpg_conv1x1_pack_workspace(d) : 0;
     if (use_c3_wgrad(d)) return std::max(pack, cpg_conv3x3_wgrad_workspace(d));
+    if (cpg_conv1x1_wgrad_supported(d)) return std::max(pack, cpg_conv1x1_wgrad_workspace(d));
     int tm, tn, nsplit, per;
     conv_wgrad_tiles<CfgA>(g, tm, tn);
     const int64_t P = (int64_t)g.N * g.OH * g.OW;
@@ -619,6 +613,13 @@ extern "C" int cpg_conv2d_wgrad(const cpg_conv_desc *d, const float *x, const fl
         CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(bias)");
         return CPG_OK;
     }
+    if (cpg_conv1x1_wgrad_supported(d)) {
+        rc = cpg_conv1x1_wgrad(d, x, gy, w, pm, thr, gw, gpm, ws, ws_bytes, stream);
+        if (rc) return rc;
+        if (gb) hipLaunchKernelGGL(k_bias_grad, dim3((unsigned)g.K), dim3(256), 0, stream, gy, gb, g.N, g.K, g.OH * g.OW);
+        CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(bias)");
+        return CPG_OK;
+    }
     int tm, tn, nsplit, per;
     conv_wgrad_tiles<CfgA>(g, tm, tn);
     const int64_t P = (int64_t)g.N * g.OH * g.OW;
@@ -633,7 +634,7 @@ extern "C" int cpg_conv2d_wgrad(const cpg_conv_desc *d, const float *x, const fl
     hipLaunchKernelGGL(k_conv_wgrad<CfgA>, dim3((unsigned)(tm * tn), (unsigned)nsplit), dim3(256), 0, stream, g, x, gy, ep,
                        part, tm, per);
     if (nsplit > 1)
-        hipLaunchKernelGGL(k_splitk_reduce, dim3(stream_grid(out_elems, 256)), dim3(256), 0, stream, part, nsplit, out_elems, ep);
+        launch_split_reduce(part, nsplit, out_elems, 0, ep, stream);
     if (gb) hipLaunchKernelGGL(k_bias_grad, dim3((unsigned)g.K), dim3(256), 0, stream, gy, gb, g.N, g.K, g.OH * g.OW);
     CPG_CHECK_LAUNCH("cpg_conv2d_wgrad");
     return CPG_OK;
@@ -685,7 +686,7 @@ int launch_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, const 
     hipLaunchKernelGGL((k_gemm<CfgA, A_KC, B_KC, MASK_SIDE>), dim3((unsigned)(tm * tn), (unsigned)nsplit), dim3(256), 0, stream,
                        A, lda, B, ldb, pm, thr, M, Nn, Kd, ep, part, tm, per);
     if (nsplit > 1)
-        hipLaunchKernelGGL(k_splitk_reduce, dim3(stream_grid(out_elems, 256)), dim3(256), 0, stream, part, nsplit, out_elems, ep);
+        launch_split_reduce(part, nsplit, out_elems, 0, ep, stream);
     CPG_CHECK_LAUNCH(what);
     return CPG_OK;
 }

@@ -14,6 +14,7 @@
 // (1/16 of bf16), so a 2x2 register block (4 ds_read_b32 per 4 MFMAs = 256 cycles) leaves the
 // LDS pipe ~95 % idle; the kernel is MFMA-issue bound by construction.
 #pragma once
+#include <algorithm>
 #include "cpg_common.h"
 
 namespace cpg {
@@ -224,5 +225,48 @@ __device__ __forceinline__ void epilogue_store(const Epilogue &ep, int64_t e, fl
     }
     ep.out[e] = v;
 }
+
+// ------------------------------------------------------------------------------------------
+// Split-K reduction shared by every weight-gradient / split GEMM path.
+// ------------------------------------------------------------------------------------------
+namespace {
+// Sums the split partials in a fixed order (deterministic for a given shape) and applies the autograd epilogue.
+// tap_plane = 0: the partials are laid out like the output; tap_plane = M * C: they are tap-major,
+// part[split][tap][co][ci] (what conv3x3.hip's k_c3_wgrad writes with 128-byte coalesced stores), and position p is scattered into
+// [co][ci][tap].  `ks` (a power of two <= 64) threads share one output, each summing every ks-th split, combined
+// through LDS: layers with few outputs have the most splits (64 -> 64 channels: 36 864 outputs x 1024 splits), and one
+// thread per output left that sum latency bound (764 us for the stem, 320 us for features.3).
+__global__ __launch_bounds__(256) void k_split_reduce(const float *__restrict__ part, int nsplit, int64_t out_elems,
+                                                         int64_t tap_plane, int ks, Epilogue ep) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x, P = 256 / ks, pl = tid % P, sl = tid / P;
+    for (int64_t base = (int64_t)blockIdx.x * P; base < out_elems; base += (int64_t)gridDim.x * P) {
+        const int64_t p = base + pl;
+        float s = 0.0f;
+        if (p < out_elems)
+            for (int k = sl; k < nsplit; k += ks) s += part[(int64_t)k * out_elems + p];
+        if (ks > 1) {
+            red[tid] = s;
+            __syncthreads();
+            if (sl == 0)
+                for (int j = 1; j < ks; ++j) s += red[j * P + pl];
+            __syncthreads();
+        }
+        if (sl == 0 && p < out_elems) {
+            const int64_t e = tap_plane ? (p % tap_plane) * 9 + p / tap_plane : p;
+            epilogue_store(ep, e, s);
+        }
+    }
+}
+
+inline void launch_split_reduce(const float *part, int nsplit, int64_t out_elems, int64_t tap_plane, const Epilogue &ep,
+                                hipStream_t stream) {
+    int ks = 1;
+    while (ks < 64 && ks * 2 <= nsplit && out_elems * ks < 262144) ks *= 2;
+    const int64_t groups = (out_elems + 256 / ks - 1) / (256 / ks);
+    hipLaunchKernelGGL(k_split_reduce, dim3((unsigned)std::min<int64_t>(groups, 16384)), dim3(256), 0, stream, part, nsplit,
+                       out_elems, tap_plane, ks, ep);
+}
+}  // namespace
 
 }  // namespace cpg

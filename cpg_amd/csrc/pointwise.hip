@@ -19,7 +19,8 @@
 //   fwd  : reads x  [N][C][H][W]  at (oh*s, ow*s), writes y [N][K][OH][OW] densely
 //   dgrad: reads gy [N][K][OH][OW] densely, writes gx [N][C][H][W] at (oh*s, ow*s)
 //          (s > 1: the other positions of gx receive no gradient and are zeroed by a memset first)
-// The weight gradient of these layers stays on the generic split-K kernel of igemm_conv.hip.
+//   wgrad: gW[k][c] = sum_g gy[k][g] * x[c][g] for dense (stride 1), 4 | pixels-per-image layers: k_pw_wgrad below;
+//          strided / odd-sized ones stay on the generic split-K kernel of igemm_conv.hip.
 #include <algorithm>
 #include "igemm_core.h"
 
@@ -229,6 +230,188 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
     }
 }
 
+// ------------------------------------------------------------------------------ weight gradient
+// D[co][ci] += sum over flattened pixels g = (image, pixel) of gy[n][co][q] * x[n][ci][q]; split-K over ranges of
+// 32-pixel units.  Both operands are pixel-contiguous in memory, so the LDS tiles are [channel][34]: a row stride of
+// 34 floats sends lane li (= channel) to bank 2*li and the other half-wave (pixel + 1) to the odd banks -- conflict-free
+// operand reads -- and keeps rows 8-byte aligned, so a float4 of 4 consecutive pixels is staged with one
+// buffer_load_dwordx4 and two ds_write_b64.  Two LDS stages, one barrier per unit; the 8 loads + 16 LDS stores of
+// unit u+2 / u+1 ride between the 64 MFMAs of unit u (conv3x3.hip's k_c3_wgrad scheme).  Block = BCO x BCI
+// channels, 2 x 2 waves, each wave (BCO/2) x (BCI/2).
+template <int BCO_, int BCI_>
+struct PwWCfg {
+    static constexpr int BCO = BCO_, BCI = BCI_, PIX = 32, LD = PIX + 2;
+    static constexpr int FM = BCO / 64, FN = BCI / 64;
+    static_assert(BCO % 64 == 0 && BCI % 64 == 0, "wave tiles are multiples of 32 x 32");
+    static constexpr int NA = BCO * (PIX / 4) / 256, NB = BCI * (PIX / 4) / 256;     // float4 per thread per unit
+    static constexpr int A_ELEMS = BCO * LD, STAGE = (BCO + BCI) * LD;
+    static constexpr int NITEMS = NA + NB, NS = PIX / 2;
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(256, 2) void k_pw_wgrad(int M, int C, int HWo, long long G, int tiles_co, int tiles_ci,
+                                                     int units_per_split, const float *__restrict__ x,
+                                                     const float *__restrict__ gy, float *__restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = sub >> 1, wci = sub & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    // all (co, ci) tiles of one split on one XCD (block b runs on XCD b % 8): the split's units are read once per L2
+    const int tiles = tiles_co * tiles_ci;
+    const int xcd = blockIdx.x % kXCDs, jb = blockIdx.x / kXCDs;
+    const int split = (jb / tiles) * kXCDs + xcd, tile = jb % tiles;
+    const int co0 = (tile / tiles_ci) * Cfg::BCO, ci0 = (tile % tiles_ci) * Cfg::BCI;
+    const long long total_units = (G + Cfg::PIX - 1) / Cfg::PIX;
+    const long long u0 = std::min<long long>(total_units, (long long)split * units_per_split);
+    const long long u1 = std::min<long long>(total_units, u0 + units_per_split);
+
+    f32x16 acc[Cfg::FM][Cfg::FN];
+#pragma unroll
+    for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < Cfg::FN; ++fn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[fm][fn][e] = 0.0f;
+
+    // staged float4 e = tid + 256*i: channel e / 8 of the tile, pixels 4*(e % 8) .. +3 of the unit.  Channels past the
+    // tensor are clamped (their accumulator rows / columns are never stored).
+    const int j4 = tid & 7, chl = tid >> 3;             // 32 channels per pass of the block
+    constexpr int kOutOfRange = (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t srd_g = __builtin_amdgcn_make_buffer_rsrc((void *)gy, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, 0x7FFFFFFF, 0x00020000);
+    int a_chan[Cfg::NA], b_chan[Cfg::NB];               // byte offset of the channel plane
+#pragma unroll
+    for (int i = 0; i < Cfg::NA; ++i) a_chan[i] = min(co0 + chl + 32 * i, M - 1) * HWo * 4;
+#pragma unroll
+    for (int i = 0; i < Cfg::NB; ++i) b_chan[i] = min(ci0 + chl + 32 * i, C - 1) * HWo * 4;
+    const int dst = chl * Cfg::LD + 4 * j4;
+    int pos_g = kOutOfRange, pos_x = kOutOfRange;       // byte offset of (image, pixel) in gy / x for the unit being loaded
+    auto describe = [&](long long u) {      // G < 2^29 (host check): 32-bit arithmetic
+        const int g = (int)u * Cfg::PIX + 4 * j4;
+        const int n = g / HWo, q = g - n * HWo;
+        const bool ok = g < (int)G;
+        pos_g = ok ? (n * M * HWo + q) * 4 : kOutOfRange;
+        pos_x = ok ? (n * C * HWo + q) * 4 : kOutOfRange;
+    };
+    f32x4 st[Cfg::NITEMS];
+    auto load_item = [&](int k) {
+        if (k < Cfg::NA)
+            st[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_g, pos_g + a_chan[k], 0, 0));
+        else
+            st[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, pos_x + b_chan[k - Cfg::NA], 0, 0));
+    };
+    auto store_item = [&](int k, float *stage) {
+        float *p = stage + (k < Cfg::NA ? 32 * k * Cfg::LD : Cfg::A_ELEMS + 32 * (k - Cfg::NA) * Cfg::LD) + dst;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<f32x2 *>(p) = f32x2{st[k][0], st[k][1]};
+        *reinterpret_cast<f32x2 *>(p + 2) = f32x2{st[k][2], st[k][3]};
+    };
+    const int a_base = (wco * (Cfg::BCO / 2) + li) * Cfg::LD + lh;
+    const int b_base = Cfg::A_ELEMS + (wci * (Cfg::BCI / 2) + li) * Cfg::LD + lh;
+
+    if (u0 < u1) {
+        describe(u0);
+#pragma unroll
+        for (int k = 0; k < Cfg::NITEMS; ++k) load_item(k);
+#pragma unroll
+        for (int k = 0; k < Cfg::NITEMS; ++k) store_item(k, smem);
+        describe(std::min(u0 + 1, u1 - 1));
+#pragma unroll
+        for (int k = 0; k < Cfg::NITEMS; ++k) load_item(k);
+        __syncthreads();
+        for (long long u = u0; u < u1; ++u) {
+            const int cur_i = (int)(u - u0) & 1;
+            const float *cur = smem + cur_i * Cfg::STAGE;
+            float *other = smem + (cur_i ^ 1) * Cfg::STAGE;
+            describe(std::min(u + 2, u1 - 1));          // clamped: the tail re-stages data nobody reads
+            float a[2][Cfg::FM], b[2][Cfg::FN];
+            auto rd = [&](int s, int set) {
+#pragma unroll
+                for (int fm = 0; fm < Cfg::FM; ++fm) a[set][fm] = cur[a_base + fm * 32 * Cfg::LD + 2 * s];
+#pragma unroll
+                for (int fn = 0; fn < Cfg::FN; ++fn) b[set][fn] = cur[b_base + fn * 32 * Cfg::LD + 2 * s];
+            };
+            rd(0, 0);
+#pragma unroll
+            for (int s = 0; s < Cfg::NS; ++s) {
+                if (s + 1 < Cfg::NS) rd(s + 1, (s + 1) & 1);
+#pragma unroll
+                for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+                    for (int fn = 0; fn < Cfg::FN; ++fn)
+                        acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][fm], b[s & 1][fn], acc[fm][fn], 0, 0, 0);
+                const int k0 = s * Cfg::NITEMS / Cfg::NS, k1 = (s + 1) * Cfg::NITEMS / Cfg::NS;
+#pragma unroll
+                for (int k = k0; k < k1; ++k) {
+                    store_item(k, other);
+                    load_item(k);
+                }
+#pragma unroll
+                for (int i = 0; i < Cfg::FM * Cfg::FN; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    if (i < k1 - k0) {
+                        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // partial result part[split][co][ci]: lanes 0-31 of a store cover 32 consecutive ci
+    float *dstp = part + (int64_t)split * M * C;
+#pragma unroll
+    for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < Cfg::FN; ++fn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wco * (Cfg::BCO / 2) + fm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int ci = ci0 + wci * (Cfg::BCI / 2) + fn * 32 + li;
+                if (co < M && ci < C) dstp[(int64_t)co * C + ci] = acc[fm][fn][e];
+            }
+}
+
+struct PwWPlan {
+    int tiles_co, tiles_ci, nsplit, units_per_split;
+    size_t ws_bytes;
+};
+template <class Cfg>
+PwWPlan pw_wgrad_plan(const cpg_conv_desc *d) {
+    PwWPlan p;
+    p.tiles_co = (d->K + Cfg::BCO - 1) / Cfg::BCO;
+    p.tiles_ci = (d->C + Cfg::BCI - 1) / Cfg::BCI;
+    const int64_t units = ((int64_t)d->N * d->H * d->W + Cfg::PIX - 1) / Cfg::PIX;
+    const int64_t tiles = (int64_t)p.tiles_co * p.tiles_ci;
+    int64_t want = (4 * kCUs + tiles - 1) / tiles;              // ~2 rounds of 2 blocks per CU
+    want = std::max<int64_t>(1, std::min<int64_t>(want, (units + 7) / 8));      // at least 8 units per split
+    want = (want + kXCDs - 1) / kXCDs * kXCDs;
+    p.units_per_split = (int)((units + want - 1) / want);
+    p.nsplit = (int)want;                                       // trailing splits may be empty: they write zeros
+    p.ws_bytes = (size_t)p.nsplit * d->K * d->C * sizeof(float);
+    return p;
+}
+using PwW128 = PwWCfg<128, 128>;
+using PwW64o = PwWCfg<64, 128>;      // <= 64 output channels
+using PwW64i = PwWCfg<128, 64>;      // <= 64 input channels
+using PwW64 = PwWCfg<64, 64>;
+inline int pw_wgrad_pick(const cpg_conv_desc *d) { return (d->K <= 64 ? 1 : 0) + (d->C <= 64 ? 2 : 0); }
+
+template <class Cfg>
+int pw_wgrad_launch(const cpg_conv_desc *d, const float *x, const float *gy, const Epilogue &ep, void *ws, size_t ws_bytes,
+                    hipStream_t stream) {
+    const PwWPlan p = pw_wgrad_plan<Cfg>(d);
+    if (ws == nullptr || ws_bytes < p.ws_bytes)
+        return fail(CPG_E_WORKSPACE, "cpg_conv2d_wgrad(1x1): workspace %zu < %zu bytes", ws_bytes, p.ws_bytes);
+    hipLaunchKernelGGL(k_pw_wgrad<Cfg>, dim3((unsigned)(p.tiles_co * p.tiles_ci * p.nsplit)), dim3(256), 0, stream, d->K, d->C,
+                       d->H * d->W, (long long)d->N * d->H * d->W, p.tiles_co, p.tiles_ci, p.units_per_split, x, gy, (float *)ws);
+    launch_split_reduce((const float *)ws, p.nsplit, (int64_t)d->K * d->C, 0, ep, stream);
+    CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(1x1)");
+    return CPG_OK;
+}
+
 //                BM  WM WN FN CK  VEC  MINW
 using PwV = PwCfg<128, 4, 1, 7, 16, true, 3>;       // dense reads, 4 | pixels per image: float4 staging
 using PwS = PwCfg<128, 4, 1, 7, 16, false, 2>;      // strided reads (1x1 s2 forward) or odd plane sizes (7x7 maps)
@@ -299,4 +482,32 @@ int cpg_conv1x1_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, c
     PwGeom g{d->N, d->K, d->C, Mp, OW, OH * OW, OH * OW, OW, 1, d->H * d->W, d->stride_h * d->W, d->stride_w, 0, (long long)d->N * OH * OW};
     if ((OH * OW) % 4 == 0 && (((uintptr_t)gy) & 15) == 0) return launch<PwV, true>(g, gy, wp, nullptr, gx, stream, what);
     return launch<PwS, true>(g, gy, wp, nullptr, gx, stream, what);
+}
+
+// dense pointwise layers whose activations can be staged as aligned float4 and addressed with 31-bit byte offsets
+extern "C" int cpg_conv1x1_wgrad_supported(const cpg_conv_desc *d) {
+    if (getenv("CPG_DISABLE_CONV1X1_WGRAD") || !cpg_conv1x1_supported(d)) return 0;
+    const int64_t hw = (int64_t)d->H * d->W;
+    return d->stride_h == 1 && d->stride_w == 1 && hw % 4 == 0 && (int64_t)d->N * std::max(d->C, d->K) * hw * 4 < (1ll << 31);
+}
+
+size_t cpg_conv1x1_wgrad_workspace(const cpg_conv_desc *d) {
+    switch (pw_wgrad_pick(d)) {
+        case 1: return pw_wgrad_plan<PwW64o>(d).ws_bytes;
+        case 2: return pw_wgrad_plan<PwW64i>(d).ws_bytes;
+        case 3: return pw_wgrad_plan<PwW64>(d).ws_bytes;
+        default: return pw_wgrad_plan<PwW128>(d).ws_bytes;
+    }
+}
+
+int cpg_conv1x1_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
+                      float *gw, float *gpm, void *ws, size_t ws_bytes, hipStream_t stream) {
+    CPG_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)gy) & 15) == 0, "cpg_conv2d_wgrad(1x1): tensors must be 16-byte aligned");
+    Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
+    switch (pw_wgrad_pick(d)) {
+        case 1: return pw_wgrad_launch<PwW64o>(d, x, gy, ep, ws, ws_bytes, stream);
+        case 2: return pw_wgrad_launch<PwW64i>(d, x, gy, ep, ws, ws_bytes, stream);
+        case 3: return pw_wgrad_launch<PwW64>(d, x, gy, ep, ws, ws_bytes, stream);
+        default: return pw_wgrad_launch<PwW128>(d, x, gy, ep, ws, ws_bytes, stream);
+    }
 }
