@@ -56,13 +56,18 @@ struct C3Geom {
     int dgrad;                // host side only: which instantiation to launch
 };
 
-template <int BM_, int TH_, int TW_, int WM_, int WN_, int CK_, int MINW_, int NIMG_ = 1>
+template <int BM_, int TH_, int TW_, int WM_, int WN_, int CK_, int MINW_, int NIMG_ = 1, int VROWS_ = 0>
 struct C3Cfg {
+    // VROWS > 0 ("virtual rows", for maps that are exactly TH x TW -- smaller than any sensible tile): the rows of ALL images
+    // are numbered consecutively (R = n * TH + h) and a tile is VROWS consecutive rows, straddling images.  7 x 7 maps: 32
+    // virtual rows x 7 columns = 224 pixels = 7 fragments exactly, where the 14 x 16 single-image tile wastes 78 %.
+    static constexpr int VROWS = VROWS_;
+    static_assert(VROWS == 0 || NIMG_ >= (TH_ - 1 + VROWS_ + TH_ - 1) / TH_, "a virtual-row tile must fit in NIMG images");
     static constexpr int NIMG = NIMG_;                      // images per tile (2: a 4x28 strip of two images = 7 fragments)
     static constexpr int MINW = MINW_;                      // waves per SIMD the register allocator must leave room for
     static constexpr int BM = BM_, TH = TH_, TW = TW_, WM = WM_, WN = WN_, CK = CK_;
     static constexpr int TPIX = TH * TW;                    // pixels of one image in the tile
-    static constexpr int BN = NIMG * TPIX;
+    static constexpr int BN = VROWS ? VROWS * TW : NIMG * TPIX;
     static_assert(WM * WN == 4 && BN % (32 * WN) == 0 && BM % (32 * WM) == 0 && CK % 2 == 0, "bad conv3x3 config");
     static constexpr int FM = BM / 32 / WM, FN = BN / 32 / WN;
     static constexpr int PH = TH + 2, PW = TW + 2, IPLANE = PH * PW, PLANE = NIMG * IPLANE;
@@ -127,9 +132,21 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
     const int tm = lb % g.tiles_m; lb /= g.tiles_m;
     const int tx = lb % g.tiles_x; lb /= g.tiles_x;
     const int ty = lb % g.tiles_y;
-    const int n = (lb / g.tiles_y) * Cfg::NIMG;          // first image of the tile
+    // first image of the tile; virtual rows: tile k starts at row vr0 of image n (tiles_x = tiles_y = 1, h0 = w0 = 0)
+    const int n = Cfg::VROWS ? (int)(lb * Cfg::VROWS) / Cfg::TH : (int)(lb / g.tiles_y) * Cfg::NIMG;
+    const int vr0 = Cfg::VROWS ? (int)(lb * Cfg::VROWS) % Cfg::TH : 0;
     const int m0 = tm * Cfg::BM, h0 = ty * Cfg::TH, w0 = tx * Cfg::TW;
     const int HW = g.H * g.W;
+    // tile pixel t -> (image of the tile, row, column inside that image's patch window)
+    auto pixel = [&](int t, int &img, int &r, int &c) {
+        if (Cfg::VROWS) {
+            const int R = vr0 + t / Cfg::TW;
+            img = R / Cfg::TH, r = R % Cfg::TH, c = t % Cfg::TW;
+        } else {
+            const int tt = t % Cfg::TPIX;
+            img = t / Cfg::TPIX, r = tt / Cfg::TW, c = tt % Cfg::TW;
+        }
+    };
 
     // ---- staging descriptors, all fixed for the life of the block (a handful of registers) ----
     // weights: float4 (row = wrow0 + WROWS*i, 4 columns at wcol); Wp is zero padded (and carries WROWS rows of
@@ -180,9 +197,9 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
     int b_base[Cfg::FN];
 #pragma unroll
     for (int fn = 0; fn < Cfg::FN; ++fn) {
-        const int t = (wn * Cfg::FN + fn) * 32 + li;
-        const int img = t / Cfg::TPIX, tt = t % Cfg::TPIX;
-        b_base[fn] = lh * Cfg::PLANE + img * Cfg::IPLANE + (tt / Cfg::TW) * Cfg::PW + (tt % Cfg::TW);
+        int img, r, c;
+        pixel((wn * Cfg::FN + fn) * 32 + li, img, r, c);
+        b_base[fn] = lh * Cfg::PLANE + img * Cfg::IPLANE + r * Cfg::PW + c;
     }
 
     f32x16 acc[Cfg::FM][Cfg::FN];
@@ -245,9 +262,9 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
     // ---- epilogue: D col = pixel (lane & 31), D row = channel ----
 #pragma unroll
     for (int fn = 0; fn < Cfg::FN; ++fn) {
-        const int t = (wn * Cfg::FN + fn) * 32 + li;
-        const int img = t / Cfg::TPIX, tt = t % Cfg::TPIX;
-        const int oh = h0 + tt / Cfg::TW, ow = w0 + tt % Cfg::TW;
+        int img, r, c;
+        pixel((wn * Cfg::FN + fn) * 32 + li, img, r, c);
+        const int oh = h0 + r, ow = w0 + c;
         const bool pok = oh < g.H && ow < g.W && n + img < g.N;
         const int poff = oh * g.W + ow;
         float *yout = y + (int64_t)(n + img) * g.M * HW;
@@ -627,6 +644,7 @@ using CfgM64 = C3Cfg<64, 8, 32, 1, 4, 4, 3>;       // <= 64 output channels (VGG
 using CfgS16 = C3Cfg<128, 14, 16, 4, 1, 4, 2>;     // 14x14 (and <= 16 wide) feature maps: whole image, 7 fragments
 using CfgD128 = C3Cfg<128, 4, 56, 4, 1, 4, 2>;     // 56 / 112 wide maps: 4 x 56 = 7 fragments per wave, zero tile waste
 using CfgD64 = C3Cfg<64, 8, 56, 2, 2, 4, 2>;       // same for <= 64 output channels
+using CfgV7 = C3Cfg<128, 7, 7, 4, 1, 4, 2, 6, 32>;     // 7 x 7 maps (ResNet layer4): 32 virtual rows over up to 6 images
 using CfgP28 = C3Cfg<128, 4, 28, 4, 1, 4, 2, 2>;   // 28-wide maps: a 4 x 28 strip of TWO images = 7 fragments, zero tile waste
 
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
@@ -638,7 +656,8 @@ int launch_fwd(C3Geom g, const float *x, const float *wp, const float *bias, flo
     g.tiles_x = (g.W + Cfg::TW - 1) / Cfg::TW;
     g.tiles_y = (g.H + Cfg::TH - 1) / Cfg::TH;
     g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
-    const int64_t blocks = (int64_t)((g.N + Cfg::NIMG - 1) / Cfg::NIMG) * g.tiles_x * g.tiles_y * g.tiles_m;
+    const int64_t blocks = Cfg::VROWS ? (int64_t)(((int64_t)g.N * Cfg::TH + Cfg::VROWS - 1) / Cfg::VROWS) * g.tiles_m
+                                      : (int64_t)((g.N + Cfg::NIMG - 1) / Cfg::NIMG) * g.tiles_x * g.tiles_y * g.tiles_m;
     if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "conv3x3: grid too large");
     if (g.dgrad)
         hipLaunchKernelGGL((k_c3_fwd<Cfg, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y);
@@ -670,6 +689,7 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
             default: if (c_read % 4 == 0) return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what);
         }
     }
+    if (W == 7 && H == 7 && c_read % 4 == 0) return launch_fwd<CfgV7>(g, x, wp, bias, y, stream, what);
     if (W <= 16 && H <= 16 && m > 64) return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what);
     if (W == 28 && H % 4 == 0 && m > 64 && c_read % 4 == 0)
         return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what);
@@ -735,9 +755,11 @@ W3Plan w3_plan(const cpg_conv_desc *d) {
 using W3Wide = W3Cfg<2, 28>;      // 112 / 224 wide feature maps: long contiguous rows, 2 x 64-lane patch groups exactly
 using W3Mid = W3Cfg<4, 14, true>;  // 14 / 28 / 56 wide feature maps: zero column waste; two stages (2 x 77 KB per CU)
 using W3Nar = W3Cfg<4, 16>;       // everything else that is narrow
+using W3Sev = W3Cfg<7, 8, true>;   // 7 x 7 maps: one unit = one image
 using W3Tiny = W3Cfg<2, 14, true>; // 14-wide maps whose height is not a multiple of 4 (14 x 14: zero row waste)
 inline int w3_pick(const cpg_conv_desc *d) {
     if (getenv("CPG_W3_PICK")) return atoi(getenv("CPG_W3_PICK"));
+    if (d->W <= 8 && d->H <= 7) return 4;
     if (d->W % 28 == 0 && d->W >= 112) return 0;
     if (d->W % 14 == 0) return (d->H % 4 != 0 && d->H % 2 == 0) ? 3 : 1;
     return 2;
@@ -759,6 +781,7 @@ size_t cpg_conv3x3_wgrad_workspace(const cpg_conv_desc *d) {
         case 1: return w3_plan<W3Mid>(d).ws_bytes;
         case 2: return w3_plan<W3Nar>(d).ws_bytes;
         case 3: return w3_plan<W3Tiny>(d).ws_bytes;
+        case 4: return w3_plan<W3Sev>(d).ws_bytes;
         default: return w3_plan<W3Wide>(d).ws_bytes;
     }
 }
@@ -814,6 +837,7 @@ int cpg_conv3x3_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, c
         case 1: return w3_launch<W3Mid>(d, x, gy, ep, ws, ws_bytes, stream);
         case 2: return w3_launch<W3Nar>(d, x, gy, ep, ws, ws_bytes, stream);
         case 3: return w3_launch<W3Tiny>(d, x, gy, ep, ws, ws_bytes, stream);
+        case 4: return w3_launch<W3Sev>(d, x, gy, ep, ws, ws_bytes, stream);
         default: return w3_launch<W3Wide>(d, x, gy, ep, ws, ws_bytes, stream);
     }
 }
