@@ -426,6 +426,49 @@ __global__ __launch_bounds__(256) void k_bias_grad(const float *__restrict__ gy,
     if (threadIdx.x == 0) gb[c] = red[0];
 }
 
+// conv bias gradient in two deterministic stages: grid (K, slices) partial sums over image slices, then one thread per
+// channel.  (One block per channel with a 64-bit (n, q) split per element took 340 us per SphereNet layer -- 10 % of its
+// training step -- with 64..512 blocks on 256 CUs.)
+__global__ __launch_bounds__(256) void k_conv_bias_partial(const float *__restrict__ gy, float *__restrict__ partial, int N, int C,
+                                                           int inner, int imgs_per_slice) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, s = blockIdx.y;
+    const int n0 = s * imgs_per_slice, n1 = min(N, n0 + imgs_per_slice);
+    const bool vec = (inner & 3) == 0 && (((uintptr_t)gy) & 15) == 0;
+    float acc = 0.0f;
+    for (int n = n0; n < n1; ++n) {
+        const float *plane = gy + ((int64_t)n * C + c) * inner;
+        if (vec) {
+            for (int j = threadIdx.x; j < (inner >> 2); j += 256) {
+                const float4 v = reinterpret_cast<const float4 *>(plane)[j];
+                acc += (v.x + v.y) + (v.z + v.w);
+            }
+        } else {
+            for (int j = threadIdx.x; j < inner; j += 256) acc += plane[j];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)c * gridDim.y + s] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void k_conv_bias_final(const float *__restrict__ partial, float *__restrict__ gb, int C, int slices) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.0f;
+    for (int k = 0; k < slices; ++k) s += partial[(int64_t)c * slices + k];
+    gb[c] = s;
+}
+inline int bias_slices(int N, int K) { return std::max(1, std::min(N, (8 * kCUs + K - 1) / K)); }
+inline size_t bias_ws_bytes(int N, int K) { return (size_t)K * bias_slices(N, K) * sizeof(float); }
+// the workspace is free again once the weight-gradient reduce has been enqueued (same stream)
+static void launch_conv_bias_grad(const float *gy, float *gb, int N, int K, int inner, void *ws, hipStream_t stream) {
+    const int slices = bias_slices(N, K), ips = (N + slices - 1) / slices;
+    const int used = (N + ips - 1) / ips;
+    hipLaunchKernelGGL(k_conv_bias_partial, dim3((unsigned)K, (unsigned)used), dim3(256), 0, stream, gy, (float *)ws, N, K, inner, ips);
+    hipLaunchKernelGGL(k_conv_bias_final, dim3((unsigned)((K + 63) / 64)), dim3(64), 0, stream, (const float *)ws, gb, K, used);
+}
+
 using CfgA = TileCfg<128, 128, 16, 2, 2>;
 using CfgB = TileCfg<64, 256, 16, 1, 4>;
 
@@ -493,8 +536,8 @@ static inline bool use_c3_wgrad(const cpg_conv_desc *d) { return cpg_conv3x3_sup
 extern "C" size_t cpg_conv2d_workspace_bytes(const cpg_conv_desc *d) {
     ConvGeom g;
     if (make_geom(d, g) != CPG_OK) return 0;
-    const size_t pack = cpg_conv3x3_supported(d) ? cpg_conv3x3_pack_workspace(d)
-                                                 : cpg_conv1x1_supported(d) ? cpg_conv1x1_pack_workspace(d) : 0;
+    size_t pack = cpg_conv3x3_supported(d) ? cpg_conv3x3_pack_workspace(d) : cpg_conv1x1_supported(d) ? cpg_conv1x1_pack_workspace(d) : 0;
+    pack = std::max(pack, bias_ws_bytes(g.N, g.K));          // the bias gradient's partial sums reuse the workspace
     if (use_c3_wgrad(d)) return std::max(pack, cpg_conv3x3_wgrad_workspace(d));
     if (cpg_conv1x1_wgrad_supported(d)) return std::max(pack, cpg_conv1x1_wgrad_workspace(d));
     int tm, tn, nsplit, per;
@@ -605,18 +648,20 @@ extern "C" int cpg_conv2d_wgrad(const cpg_conv_desc *d, const float *x, const fl
     CPG_REQUIRE(x && gy && gw, "cpg_conv2d_wgrad: null pointer");
     CPG_REQUIRE((pm == nullptr) == (gpm == nullptr), "cpg_conv2d_wgrad: pm and gpm must both be given or both be NULL");
     CPG_REQUIRE(pm == nullptr || w != nullptr, "cpg_conv2d_wgrad: w is required to form the piggymask gradient");
+    if (gb != nullptr && (ws == nullptr || ws_bytes < bias_ws_bytes(g.N, g.K)))
+        return fail(CPG_E_WORKSPACE, "cpg_conv2d_wgrad: workspace %zu < %zu bytes (bias gradient)", ws_bytes, bias_ws_bytes(g.N, g.K));
     hipStream_t stream = (hipStream_t)stream_v;
     if (use_c3_wgrad(d)) {
         rc = cpg_conv3x3_wgrad(d, x, gy, w, pm, thr, gw, gpm, ws, ws_bytes, stream);
         if (rc) return rc;
-        if (gb) hipLaunchKernelGGL(k_bias_grad, dim3((unsigned)g.K), dim3(256), 0, stream, gy, gb, g.N, g.K, g.OH * g.OW);
+        if (gb) launch_conv_bias_grad(gy, gb, g.N, g.K, g.OH * g.OW, ws, stream);
         CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(bias)");
         return CPG_OK;
     }
     if (cpg_conv1x1_wgrad_supported(d)) {
         rc = cpg_conv1x1_wgrad(d, x, gy, w, pm, thr, gw, gpm, ws, ws_bytes, stream);
         if (rc) return rc;
-        if (gb) hipLaunchKernelGGL(k_bias_grad, dim3((unsigned)g.K), dim3(256), 0, stream, gy, gb, g.N, g.K, g.OH * g.OW);
+        if (gb) launch_conv_bias_grad(gy, gb, g.N, g.K, g.OH * g.OW, ws, stream);
         CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(bias)");
         return CPG_OK;
     }
@@ -635,7 +680,7 @@ extern "C" int cpg_conv2d_wgrad(const cpg_conv_desc *d, const float *x, const fl
                        part, tm, per);
     if (nsplit > 1)
         launch_split_reduce(part, nsplit, out_elems, 0, ep, stream);
-    if (gb) hipLaunchKernelGGL(k_bias_grad, dim3((unsigned)g.K), dim3(256), 0, stream, gy, gb, g.N, g.K, g.OH * g.OW);
+    if (gb) launch_conv_bias_grad(gy, gb, g.N, g.K, g.OH * g.OW, ws, stream);
     CPG_CHECK_LAUNCH("cpg_conv2d_wgrad");
     return CPG_OK;
 }

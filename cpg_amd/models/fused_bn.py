@@ -131,6 +131,37 @@ def bn_relu(x, bn, relu=True):
     return _BnReluFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, training, relu)
 
 
+class _PReluFn(torch.autograd.Function):
+    """nn.PReLU with the stock forward and a one-pass HIP backward (cpg_prelu_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.prelu(x, weight)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C)
+        L = _lib.lib()
+        ws, nb = _lib.workspace(L.cpg_prelu_workspace_bytes(N, C, HW), x.device)
+        gx = torch.empty_like(x)
+        gw = torch.empty_like(weight)
+        _lib.check('cpg_prelu_bwd', L.cpg_prelu_bwd(_lib.dptr(x), _lib.dptr(gy), _lib.dptr(weight), _lib.dptr(gx), _lib.dptr(gw),
+                                                    N, C, HW, weight.numel(), _lib.dptr(ws), nb, _lib.stream_ptr()))
+        return gx, gw
+
+
+def prelu(mod, x):
+    """mod(x) for an nn.PReLU module (models/spherenet.py); HIP backward when the tensor qualifies."""
+    if (ENABLED and type(mod) is nn.PReLU and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and mod.weight.numel() in (1, x.shape[1])):
+        return _PReluFn.apply(x, mod.weight)
+    return mod(x)
+
+
 ENABLED = True      # module-wide switch (tests compare the fused against the stock evaluation)
 
 

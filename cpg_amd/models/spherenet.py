@@ -11,6 +11,7 @@ import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
 from . import layers as nl
+from .fused_bn import prelu
 from .vgg import View
 
 __all__ = ['SphereNet', 'spherenet20', 'AngleLoss', 'AngleLinear']
@@ -100,11 +101,11 @@ class SphereNet(nn.Module):
 
     def _trunk(self, x):
         for stage, _, units in _STAGES:
-            x = getattr(self, 'relu%d_1' % stage)(getattr(self, 'conv%d_1' % stage)(x))
+            x = prelu(getattr(self, 'relu%d_1' % stage), getattr(self, 'conv%d_1' % stage)(x))
             for u in range(units):
                 a, b = 2 * u + 2, 2 * u + 3
-                y = getattr(self, 'relu%d_%d' % (stage, a))(getattr(self, 'conv%d_%d' % (stage, a))(x))
-                x = x + getattr(self, 'relu%d_%d' % (stage, b))(getattr(self, 'conv%d_%d' % (stage, b))(y))
+                y = prelu(getattr(self, 'relu%d_%d' % (stage, a)), getattr(self, 'conv%d_%d' % (stage, a))(x))
+                x = x + prelu(getattr(self, 'relu%d_%d' % (stage, b)), getattr(self, 'conv%d_%d' % (stage, b))(y))
         return self.flatten(x)
 
     def forward(self, x):

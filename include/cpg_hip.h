@@ -184,6 +184,14 @@ int cpg_bn_relu_pool_bwd(const float *x, const float *g_pooled, const float *gam
                          int32_t N, int32_t C, int32_t H, int32_t W, int32_t train, void *ws, size_t ws_bytes,
                          void *stream);
 
+/* Backward of nn.PReLU on an NCHW tensor (SphereNet-20's activation after every masked conv,
+ * models/spherenet.py:126-166 `relu{stage}_{i} = nn.PReLU(channels)`):
+ *   gx = x > 0 ? gy : slope[c] * gy,   gslope[c] = sum_{n,hw} (x > 0 ? 0 : gy * x)
+ * in ONE pass over x and gy (deterministic two-stage slope reduction).  n_slopes = C (per-channel) or 1. */
+size_t cpg_prelu_workspace_bytes(int32_t N, int32_t C, int32_t HW);
+int cpg_prelu_bwd(const float *x, const float *gy, const float *slope, float *gx, float *gslope, int32_t N,
+                  int32_t C, int32_t HW, int32_t n_slopes, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

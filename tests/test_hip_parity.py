@@ -722,6 +722,33 @@ def test_resnet_block_fused_bn_equals_stock_bn(block, stride):
         assert float(np.abs(g1[n] - g0[n]).max()) <= 1e-3 * sc, n
 
 
+@pytest.mark.parametrize('N,C,H,W,shared', [(8, 64, 56, 56, False), (5, 12, 7, 9, False), (3, 16, 28, 28, True), (2, 3, 1, 1, False)])
+def test_prelu_backward_matches_torch(N, C, H, W, shared):
+    """cpg_prelu_bwd (one pass, deterministic slope reduction) against torch's PReLU backward."""
+    from cpg_amd.models import fused_bn
+    g = torch.Generator().manual_seed(N * 100 + C)
+    x = torch.randn(N, C, H, W, generator=g).to(DEV)
+    gy = torch.randn(N, C, H, W, generator=g).to(DEV)
+    mod = nn.PReLU(1 if shared else C).to(DEV)
+    with torch.no_grad():
+        mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) - 0.3)
+    out = {}
+    for enabled in (True, False):
+        fused_bn.ENABLED = enabled
+        try:
+            xi = x.clone().requires_grad_(True)
+            mod.zero_grad()
+            y = fused_bn.prelu(mod, xi)
+            y.backward(gy)
+        finally:
+            fused_bn.ENABLED = True
+        out[enabled] = (y.detach().cpu().numpy(), xi.grad.cpu().numpy(), mod.weight.grad.cpu().numpy())
+    np.testing.assert_array_equal(out[True][0], out[False][0])
+    np.testing.assert_array_equal(out[True][1], out[False][1])
+    sc = float(np.abs(out[False][2]).max()) + 1e-12
+    np.testing.assert_allclose(out[True][2], out[False][2], rtol=1e-4, atol=1e-5 * sc)
+
+
 # --------------------------------------------------------------------------- fused masked SGD (SURVEY 8f.1)
 @pytest.mark.parametrize('nesterov', [True, False])
 def test_masked_sgd_equals_routing_then_torch_sgd(nesterov):
