@@ -39,6 +39,7 @@ from cpg_amd.models import layers as nl              # noqa: E402
 from cpg_amd.utils import Optimizers                 # noqa: E402
 from cpg_amd.utils.fused_sgd import MaskedSGD        # noqa: E402
 from cpg_amd.utils.manager import Manager            # noqa: E402
+from cpg_amd.utils.prune import SparsePruner         # noqa: E402
 
 VGG_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
@@ -140,10 +141,18 @@ def make_args(mode, freq, width=1.0):
                                  network_width_multiplier=width, cuda=True, log_path=None, progress=False)
 
 
-def run_cycle(model, masks, pool, val_pool, steps, clock=None):
-    """The K-step scaled task-1 cycle.  Returns number of train steps executed."""
+def run_cycle(model, masks, pool, val_pool, steps, clock=None, marks=None):
+    """The K-step scaled task-1 cycle.  Returns number of train steps executed.  `marks` collects (label, steps, event)
+    at the phase boundaries (events only -- no synchronisation inside the timed region)."""
     E = max(1, steps // 11)
     done = 0
+
+    def mark(label, n=0):
+        if marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((label, n, ev))
+    mark('start')
 
     def loader(n, offset):
         return [pool[(offset + i) % len(pool)] for i in range(n)]
@@ -160,7 +169,9 @@ def run_cycle(model, masks, pool, val_pool, steps, clock=None):
     mgr = Manager(make_args('finetune', max(1, E // 2)), model, {}, masks, loader(nA, 0), val_pool, 0, 0)
     mgr.pruner.make_finetuning_mask()
     mgr.train(sgd(1e-2, mgr.pruner), 0, [1e-2], 0)
+    mark('finetune_train', nA)
     mgr.validate(0)
+    mark('validate', 1)
     done += nA
     # phase B: prune 0.0 -> 0.1 then recovery at fixed mask
     remaining = steps - done
@@ -172,12 +183,42 @@ def run_cycle(model, masks, pool, val_pool, steps, clock=None):
         while remaining > 0:
             n = min(E, remaining)
             mgrB.train_loader = loader(n, done)
+            in_window = step < 2 * E
             _, step = mgrB.train(opt, epoch, [1e-3], step)
+            mark('prune_window_train' if in_window else 'recovery_train', n)
             mgrB.validate(epoch)
+            mark('validate', 1)
             done += n
             remaining -= n
             epoch += 1
     return done
+
+
+def phase_report(marks, model, masks, batch):
+    """finetune-only / prune-window / recovery step times, validate time and the latency of one rank-prune
+    event over all 15 masked layers (measured after the timed region, on a copy of the owner masks)."""
+    acc = {}
+    for (_, _, e0), (label, n, e1) in zip(marks[:-1], marks[1:]):
+        a = acc.setdefault(label, [0.0, 0])
+        a[0] += e0.elapsed_time(e1)
+        a[1] += n
+    rep = {}
+    for label, (ms, n) in acc.items():
+        if n:
+            rep[label + ('_ms_per_call' if label == 'validate' else '_ms_per_step')] = round(ms / n, 3)
+    for label in ('finetune_train', 'prune_window_train', 'recovery_train'):
+        if label + '_ms_per_step' in rep:
+            rep[label + '_images_per_sec'] = round(batch / rep[label + '_ms_per_step'] * 1e3, 1)
+    pr = SparsePruner(model, {k: v.clone() for k, v in masks.items()}, make_args('prune', 1), 0, 100, None)
+    pr._rank_prune_layers(0.05)                        # warm
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    pr._rank_prune_layers(0.10)
+    e.record()
+    torch.cuda.synchronize()
+    rep['prune_event_ms'] = round(s.elapsed_time(e), 3)
+    return rep
 
 
 def cpu_baseline(budget_s=20.0):
@@ -268,7 +309,8 @@ def main():
     barrier()
     clock.enabled = True
     t0 = time.perf_counter()
-    done = run_cycle(model, masks, pool, val_pool, a.steps, clock)
+    marks = []
+    done = run_cycle(model, masks, pool, val_pool, a.steps, clock, marks)
     barrier()
     dt = time.perf_counter() - t0
     clock.enabled = False
@@ -314,6 +356,7 @@ def main():
             if os.environ.get('CPG_BENCH_DETAIL'):
                 out['kernel_detail'] = {k: {'n': v[0], 'ms': round(v[1], 2), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
                                         for k, v in sorted(agg.items())}
+        out['phases'] = phase_report(marks, model, masks, a.batch)
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
