@@ -1,23 +1,29 @@
 // Specialised masked 3x3 / stride 1 / pad 1 convolution on fp32 MFMA -- the shape class of every
 // VGG16 conv (100 % of config 1-3 conv FLOPs), 16 of SphereNet-20's 20 convs and ResNet's 3x3 s1.
+// (DESIGN.md section 4.1 has the measurements behind every choice below.)
 //
-// forward + input-gradient (one kernel, the weight staging differs):
-//   block = BM output channels x (TH x TW) output pixels of ONE image; loop over input channels in
-//   chunks of CK.  Per chunk the block stages
-//     Ws[CK*9][BM+1]        W_eff[co][ci][tap] = W * bin(piggymask)  (binarise fused into this pass)
-//     Xs[CK][(TH+2)][(TW+2)] the zero-padded input patch -- every element is reused by 9 taps x BM
-//                            channels out of LDS ("im2col in LDS", no HBM im2col buffer)
-//   and each wave runs CK*9/2 k-steps of v_mfma_f32_32x32x2_f32 whose operand addresses are
-//   lane_base + compile-time immediates (no index arithmetic in the hot loop).  K ordering inside a
-//   chunk is (channel pair, tap): lanes 0-31 take channel 2p, lanes 32-63 channel 2p+1, same tap.
+// forward + input-gradient (one kernel, k_c3_fwd; only the packed weights differ):
+//   k_c3_pack writes Wp[(c*9 + tap)][m] = W * bin(piggymask), K-major and zero padded (binarise +
+//   transpose fused in one tiny pass).  Block = BM output channels x a pixel tile (TH x TW of one
+//   image, 4 x 28 of two images, or 32 "virtual rows" of 7-wide images); loop over input channels in
+//   chunks of 4.  Per chunk the block stages
+//     Ws[36][BM+4]            rows of Wp (float4 global loads, ds_write_b128)
+//     Xs[4][TH+2][TW+2]       the zero-padded input patch -- every element is reused by 9 taps x BM
+//                             channels out of LDS ("im2col in LDS", no HBM im2col buffer); fetched
+//                             with range-checked buffer loads, so padding costs no select
+//   into the OTHER LDS stage while each wave runs 18 k-steps of v_mfma_f32_32x32x2_f32 on the current
+//   one; operand addresses are lane_base + compile-time immediates.  K order inside a chunk is
+//   (channel pair, tap): lanes 0-31 take channel 2p, lanes 32-63 channel 2p+1, same tap.  The chunk
+//   body is branch free with a pinned MFMA / LDS / VMEM interleave (sched_group_barrier).
 //   dgrad is the same contraction with roles swapped: input = gy, output channels = ci, and the
-//   weights staged as Ws[(co,8-tap)][ci] (spatially flipped taps).
+//   weights packed as Wp[(co, 8-tap)][ci] (spatially flipped taps).
 //
-// weight-gradient:
+// weight-gradient (k_c3_wgrad):
 //   block = 64 co x 64 ci x 9 taps, K = pixels.  Each wave owns a 32 co x 32 ci fragment for ALL 9
-//   taps (9 accumulators): one gy operand read feeds 9 MFMAs against 9 shifted reads of the same
-//   LDS input patch.  Split-K over (image, pixel-tile) ranges; partials reduced by k_split_reduce,
-//   which also applies the autograd epilogue gW = g*bin(pm), gPM = g*W.
+//   taps (9 accumulators): one gy operand read feeds 9 MFMAs against a sliding window over the LDS
+//   input patch.  Staging = one buffer_load_dword + one ds_write_b32 per element, spread between the
+//   MFMAs.  Split-K over (image, pixel-tile) units; tap-major partials reduced by k_split_reduce
+//   (igemm_core.h), which also applies the autograd epilogue gW = g*bin(pm), gPM = g*W.
 #include <algorithm>
 #include "igemm_core.h"
 
