@@ -137,12 +137,14 @@ __global__ void k_bn_finalize(const double *__restrict__ partial, BnDims d, floa
 
 // GROUP threads (a whole block, or one wave for small feature maps) own one (n, c) plane at a time, so the
 // four per-channel scalars sit in registers and every access is a contiguous 16 B per lane.
+// `res` (may be null): a residual added before the ReLU -- the tail of a ResNet block, relu(bn3(conv3) + identity).
 template <bool RELU, int GROUP>
-__global__ __launch_bounds__(kThreads) void k_bn_apply(const float *__restrict__ x, float *__restrict__ y, BnDims d,
-                                                       const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                       const float *__restrict__ gamma, const float *__restrict__ beta) {
+__global__ __launch_bounds__(kThreads) void k_bn_apply(const float *__restrict__ x, const float *__restrict__ res,
+                                                       float *__restrict__ y, BnDims d, const float *__restrict__ mean,
+                                                       const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta) {
     const int64_t planes = (int64_t)d.N * d.C;
-    const bool vec = (d.HW & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 15) == 0;
+    const bool vec = (d.HW & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 15) == 0 && (((uintptr_t)res) & 15) == 0;
     const int gl = threadIdx.x % GROUP;
     const int64_t g0 = (int64_t)blockIdx.x * (kThreads / GROUP) + threadIdx.x / GROUP;
     const int64_t gstride = (int64_t)gridDim.x * (kThreads / GROUP);
@@ -158,6 +160,10 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const float *__restrict__
                 v.y = bn_affine(v.y, m, is, g, b);
                 v.z = bn_affine(v.z, m, is, g, b);
                 v.w = bn_affine(v.w, m, is, g, b);
+                if (res != nullptr) {
+                    const float4 r = reinterpret_cast<const float4 *>(res + pl * d.HW)[i];
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
                 if (RELU) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 }
@@ -166,6 +172,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const float *__restrict__
         } else {
             for (int i = gl; i < d.HW; i += GROUP) {
                 float v = bn_affine(p[i], m, is, g, b);
+                if (res != nullptr) v += res[pl * d.HW + i];
                 q[i] = RELU ? fmaxf(v, 0.f) : v;
             }
         }
@@ -287,11 +294,11 @@ unsigned plane_grid(const BnDims &d) {
 }
 template <bool RELU>
 void launch_apply(const BnDims &d, const float *x, float *y, const float *mean, const float *invstd, const float *gamma,
-                  const float *beta, hipStream_t stream) {
+                  const float *beta, hipStream_t stream, const float *res = nullptr) {
     if (wave_planes(d))
-        hipLaunchKernelGGL((k_bn_apply<RELU, 64>), dim3(plane_grid(d)), dim3(kThreads), 0, stream, x, y, d, mean, invstd, gamma, beta);
+        hipLaunchKernelGGL((k_bn_apply<RELU, 64>), dim3(plane_grid(d)), dim3(kThreads), 0, stream, x, res, y, d, mean, invstd, gamma, beta);
     else
-        hipLaunchKernelGGL((k_bn_apply<RELU, 256>), dim3(plane_grid(d)), dim3(kThreads), 0, stream, x, y, d, mean, invstd, gamma, beta);
+        hipLaunchKernelGGL((k_bn_apply<RELU, 256>), dim3(plane_grid(d)), dim3(kThreads), 0, stream, x, res, y, d, mean, invstd, gamma, beta);
 }
 template <bool RELU, bool TRAIN>
 void launch_bwd_apply(const BnDims &d, const float *x, const float *gy, float *gx, const float *mean, const float *invstd,
@@ -343,6 +350,30 @@ extern "C" int cpg_bn_relu_fwd_eval(const float *x, const float *gamma, const fl
     if (relu) launch_apply<true>(d, x, y, mean, invstd, gamma, beta, stream);
     else launch_apply<false>(d, x, y, mean, invstd, gamma, beta, stream);
     CPG_CHECK_LAUNCH("cpg_bn_relu_fwd_eval");
+    return CPG_OK;
+}
+
+// y = relu(bn(x) + res): the tail of a residual block (models/resnet.py: `out = bn3(conv3(out)); out += identity;
+// relu(out)`) in the same two passes as plain BN -- 3 activation passes instead of 8 for the stock bn / add_ / relu_.
+extern "C" int cpg_bn_add_relu_fwd(const float *x, const float *res, const float *gamma, const float *beta, float eps, float momentum,
+                                   float *running_mean, float *running_var, float *mean, float *invstd, float *y, int32_t N,
+                                   int32_t C, int32_t HW, int32_t train, void *ws, size_t ws_bytes, void *stream_v) {
+    BnDims d;
+    int rc = make_dims(N, C, HW, d);
+    if (rc) return rc;
+    CPG_REQUIRE(x && res && gamma && beta && mean && invstd && y, "cpg_bn_add_relu_fwd: null pointer");
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (train) {
+        CPG_REQUIRE(ws != nullptr, "cpg_bn_add_relu_fwd: null workspace");
+        CPG_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "cpg_bn_add_relu_fwd: running stats must come as a pair");
+        if (ws_bytes < cpg_bn_workspace_bytes(N, C, HW)) return fail(CPG_E_WORKSPACE, "cpg_bn_add_relu_fwd: workspace too small");
+        double *partial = (double *)ws;
+        hipLaunchKernelGGL(k_bn_stats, dim3(C, d.slices), dim3(kThreads), 0, stream, x, d, partial);
+        hipLaunchKernelGGL(k_bn_finalize, dim3((C + 63) / 64), dim3(64), 0, stream, partial, d, eps, momentum, mean, invstd,
+                           running_mean, running_var);
+    }
+    launch_apply<true>(d, x, y, mean, invstd, gamma, beta, stream, res);
+    CPG_CHECK_LAUNCH("cpg_bn_add_relu_fwd");
     return CPG_OK;
 }
 

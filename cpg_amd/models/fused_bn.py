@@ -59,6 +59,49 @@ class _BnReluFn(torch.autograd.Function):
         return gx, dgamma, dbeta, None, None, None, None, None, None
 
 
+class _BnAddReluFn(torch.autograd.Function):
+    """relu(bn(x) + res) -- forward in the two passes of plain BN; backward = ReLU mask from the saved output, the plain
+    BN backward kernels, and the masked gradient itself for the residual."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, eps, momentum, training):
+        x, res = x.contiguous(), res.contiguous()
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C)
+        L = _lib.lib()
+        y = torch.empty_like(x)
+        if training:
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+            ws, nb = _lib.workspace(L.cpg_bn_workspace_bytes(N, C, HW), x.device)
+        else:
+            mean, invstd = running_mean, torch.rsqrt(running_var + eps)
+            ws, nb = None, 0
+        rc = L.cpg_bn_add_relu_fwd(_lib.dptr(x, name='input'), _lib.dptr(res, name='residual'), _lib.dptr(gamma), _lib.dptr(beta),
+                                   float(eps), float(momentum), _lib.dptr(running_mean if training else None),
+                                   _lib.dptr(running_var if training else None), _lib.dptr(mean), _lib.dptr(invstd), _lib.dptr(y),
+                                   N, C, HW, int(training), _lib.dptr(ws), nb, _lib.stream_ptr())
+        _lib.check('cpg_bn_add_relu_fwd', rc)
+        ctx.save_for_backward(x, y, gamma, beta, mean, invstd)
+        ctx.cfg = (N, C, HW, bool(training))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        N, C, HW, training = ctx.cfg
+        gz = torch.ops.aten.threshold_backward(gy.contiguous(), y, 0.0)
+        L = _lib.lib()
+        gx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        ws, nb = _lib.workspace(L.cpg_bn_workspace_bytes(N, C, HW), x.device)
+        rc = L.cpg_bn_relu_bwd(_lib.dptr(x), _lib.dptr(gz, name='grad_output'), _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(mean),
+                               _lib.dptr(invstd), _lib.dptr(gx), _lib.dptr(dgamma), _lib.dptr(dbeta), N, C, HW, 0, int(training),
+                               _lib.dptr(ws), nb, _lib.stream_ptr())
+        _lib.check('cpg_bn_relu_bwd', rc)
+        return gx, gz, dgamma, dbeta, None, None, None, None, None
+
+
 class _BnReluPoolFn(torch.autograd.Function):
     """BatchNorm2d -> ReLU -> MaxPool2d(2, 2); only the pooled tensor is written."""
 
@@ -172,6 +215,18 @@ def bn_act(bn, act, x):
         return bn_relu(x, bn, relu=act is not None)
     y = bn(x)
     return y if act is None else act(y)
+
+
+def bn_add_act(bn, act, x, res):
+    """act(bn(x) + res), the tail of a residual block; fused when `act` is a plain nn.ReLU and `bn` qualifies."""
+    if ENABLED and type(act) is nn.ReLU and fusable(bn, x) and bn.track_running_stats and res.shape == x.shape:
+        training = bn.training
+        if training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        return _BnAddReluFn.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, training)
+    out = bn(x)
+    out = out + res
+    return act(out)
 
 
 class FusedSequential(nn.Sequential):

@@ -8,7 +8,7 @@ network_width_multiplier with the reference's int() placement; heads are per-tas
 import torch.nn as nn
 
 from . import layers as nl
-from .fused_bn import FusedSequential, bn_act
+from .fused_bn import FusedSequential, bn_act, bn_add_act
 
 __all__ = ['ResNet', 'BasicBlock', 'Bottleneck', 'resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152',
            'resnext50_32x4d', 'resnext101_32x8d']
@@ -44,9 +44,7 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         out = bn_act(self.bn1, self.relu, self.conv1(x))
-        out = bn_act(self.bn2, None, self.conv2(out))
-        out += x if self.downsample is None else self.downsample(x)
-        return self.relu(out)
+        return bn_add_act(self.bn2, self.relu, self.conv2(out), x if self.downsample is None else self.downsample(x))
 
 
 class Bottleneck(nn.Module):
@@ -70,9 +68,7 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         out = bn_act(self.bn1, self.relu, self.conv1(x))
         out = bn_act(self.bn2, self.relu, self.conv2(out))
-        out = bn_act(self.bn3, None, self.conv3(out))
-        out += x if self.downsample is None else self.downsample(x)
-        return self.relu(out)
+        return bn_add_act(self.bn3, self.relu, self.conv3(out), x if self.downsample is None else self.downsample(x))
 
 
 class ResNet(nn.Module):

@@ -171,6 +171,14 @@ int cpg_bn_relu_bwd(const float *x, const float *gy, const float *gamma, const f
                     const float *invstd, float *gx, float *dgamma, float *dbeta, int32_t N, int32_t C,
                     int32_t HW, int32_t relu, int32_t train, void *ws, size_t ws_bytes, void *stream);
 
+/* y = relu(bn(x) + res): the tail of a residual block (models/resnet.py:69-74 `out = self.bn3(out); out += identity;
+ * out = self.relu(out)`).  train != 0: batch statistics (mean / invstd out, running stats updated); train == 0: `mean`
+ * / `invstd` are inputs.  Backward = relu mask from y, then cpg_bn_relu_bwd(relu = 0); the residual's gradient is the
+ * masked gradient itself. */
+int cpg_bn_add_relu_fwd(const float *x, const float *res, const float *gamma, const float *beta, float eps,
+                        float momentum, float *running_mean, float *running_var, float *mean, float *invstd, float *y,
+                        int32_t N, int32_t C, int32_t HW, int32_t train, void *ws, size_t ws_bytes, void *stream);
+
 /* BatchNorm2d -> ReLU -> MaxPool2d(2, 2) fused (the 5 VGG blocks that end in 'M', models/vgg.py:131-141).
  * y_pooled / g_pooled: [N][C][H/2][W/2]; H and W even.  train != 0: batch statistics are computed (and
  * running stats updated) first; train == 0: `mean` / `invstd` are inputs.  The un-pooled activation is never
