@@ -353,6 +353,52 @@ extern "C" int cpg_bn_relu_fwd_eval(const float *x, const float *gamma, const fl
     return CPG_OK;
 }
 
+// Batch statistics from the per-(channel, pixel tile) partial sums a conv forward already produced
+// (cpg_conv2d_fwd_bnstats): partials[c][tile] = {sum y, sum y^2} in fp32 over <= 448 outputs each; merged in fp64 in a
+// fixed order.  Writes mean / invstd (and updates the running statistics) exactly like k_bn_finalize, so the apply
+// pass is cpg_bn_relu_fwd_eval / cpg_bn_relu_pool_fwd(train = 0) and BatchNorm never re-reads y for statistics.
+namespace {
+__global__ __launch_bounds__(kThreads) void k_bn_finalize_tiles(const float *__restrict__ partials, int tiles, double count, float eps,
+                                                                float momentum, float *__restrict__ mean, float *__restrict__ invstd,
+                                                                float *__restrict__ running_mean, float *__restrict__ running_var) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    const float2 *p = reinterpret_cast<const float2 *>(partials) + (int64_t)c * tiles;
+    double s = 0.0, ss = 0.0;
+    for (int t = threadIdx.x; t < tiles; t += kThreads) {
+        const float2 v = p[t];
+        s += (double)v.x;
+        ss += (double)v.y;
+    }
+    const double ts = block_sum(s, red);
+    const double tss = block_sum(ss, red);
+    if (threadIdx.x == 0) {
+        const double m = ts / count;
+        double var = tss / count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)m;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean != nullptr) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int cpg_bn_stats_finalize(const float *partials, int32_t tiles, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
+                                     float *running_mean, float *running_var, float *mean, float *invstd, void *stream_v) {
+    CPG_REQUIRE(partials && mean && invstd, "cpg_bn_stats_finalize: null pointer");
+    CPG_REQUIRE(tiles > 0 && N > 0 && C > 0 && HW > 0, "cpg_bn_stats_finalize: non-positive dimension");
+    CPG_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "cpg_bn_stats_finalize: running stats must come as a pair");
+    CPG_REQUIRE((((uintptr_t)partials) & 7) == 0, "cpg_bn_stats_finalize: partials must be 8-byte aligned");
+    hipLaunchKernelGGL(k_bn_finalize_tiles, dim3(C), dim3(kThreads), 0, (hipStream_t)stream_v, partials, tiles, (double)N * HW, eps,
+                       momentum, mean, invstd, running_mean, running_var);
+    CPG_CHECK_LAUNCH("cpg_bn_stats_finalize");
+    return CPG_OK;
+}
+
 // y = relu(bn(x) + res): the tail of a residual block (models/resnet.py: `out = bn3(conv3(out)); out += identity;
 // relu(out)`) in the same two passes as plain BN -- 3 activation passes instead of 8 for the stock bn / add_ / relu_.
 extern "C" int cpg_bn_add_relu_fwd(const float *x, const float *res, const float *gamma, const float *beta, float eps, float momentum,

@@ -125,9 +125,13 @@ __global__ __launch_bounds__(256) void k_c3_pack(const float *__restrict__ w, co
 // y[n][m][h][w] = sum_{c,tap} Wp[(c*9+tap)][m] * x[n][c][h + tap/3 - 1][w + tap%3 - 1]
 // (DGRAD changes nothing in the code: the two passes differ only in the packed weights.  It gives the input-gradient
 // launches their own kernel name, so that a rocprofv3 kernel summary separates the conv_fwd and conv_dgrad families.)
-template <class Cfg, bool DGRAD>
+// STATS: the forward of a conv that feeds a training-mode BatchNorm also emits, per block, the sum and the sum of squares of
+// its outputs per channel -- stats[channel][pixel tile][2] -- so the BatchNorm needs no statistics pass over y
+// (cpg_conv2d_fwd_bnstats + cpg_bn_stats_finalize; deterministic: fixed-order merges only).
+template <class Cfg, bool DGRAD, bool STATS = false>
 __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float *__restrict__ x, const float *__restrict__ wp,
-                                                           const float *__restrict__ bias, float *__restrict__ y) {
+                                                           const float *__restrict__ bias, float *__restrict__ y,
+                                                           float *__restrict__ stats) {
     __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -136,6 +140,7 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
     // block -> (m tile, x tile, y tile, image); m fastest so co-resident blocks of an XCD share the patch
     unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = lb % g.tiles_m; lb /= g.tiles_m;
+    const unsigned tile_n = lb;                          // pixel-tile index (STATS)
     const int tx = lb % g.tiles_x; lb /= g.tiles_x;
     const int ty = lb % g.tiles_y;
     // first image of the tile; virtual rows: tile k starts at row vr0 of image n (tiles_x = tiles_y = 1, h0 = w0 = 0)
@@ -266,6 +271,13 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
     }
 
     // ---- epilogue: D col = pixel (lane & 31), D row = channel ----
+    float s1[STATS ? Cfg::FM : 1][16], s2[STATS ? Cfg::FM : 1][16];
+    if (STATS) {
+#pragma unroll
+        for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s1[fm][e] = s2[fm][e] = 0.0f;
+    }
 #pragma unroll
     for (int fn = 0; fn < Cfg::FN; ++fn) {
         int img, r, c;
@@ -289,8 +301,49 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (pok && co < g.M) yout[(int64_t)co * HW + poff] = acc[fm][fn][e] + bv[e];
+                const float v = acc[fm][fn][e] + bv[e];
+                if (pok && co < g.M) yout[(int64_t)co * HW + poff] = v;
+                if (STATS && pok) {
+                    s1[fm][e] += v;
+                    s2[fm][e] += v * v;
+                }
             }
+        }
+    }
+    if (STATS) {
+        // per channel row: sum over the 32 pixel lanes of this half-wave, then over the WN waves sharing the channels
+#pragma unroll
+        for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+#pragma unroll
+                for (int off = 1; off < 32; off <<= 1) {
+                    s1[fm][e] += __shfl_xor(s1[fm][e], off);
+                    s2[fm][e] += __shfl_xor(s2[fm][e], off);
+                }
+        float *red = smem;                               // [WN][BM][2]; the main loop's last barrier freed the LDS
+        if (li == 0) {
+#pragma unroll
+            for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ch = (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    red[(wn * Cfg::BM + ch) * 2 + 0] = s1[fm][e];
+                    red[(wn * Cfg::BM + ch) * 2 + 1] = s2[fm][e];
+                }
+        }
+        __syncthreads();
+        if (tid < Cfg::BM && m0 + tid < g.M) {
+            float a = 0.0f, b = 0.0f;
+#pragma unroll
+            for (int w2 = 0; w2 < Cfg::WN; ++w2) {
+                a += red[(w2 * Cfg::BM + tid) * 2 + 0];
+                b += red[(w2 * Cfg::BM + tid) * 2 + 1];
+            }
+            const unsigned ntiles = gridDim.x / g.tiles_m;
+            float *dst = stats + ((int64_t)(m0 + tid) * ntiles + tile_n) * 2;
+            dst[0] = a;
+            dst[1] = b;
         }
     }
 }
@@ -657,54 +710,64 @@ inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 // packed-weight workspace: [roundup(C_read, 4) * 9 (+ 16 rows of slack the last float4 staging pass may read)][roundup(M, 128)] floats
 inline size_t pack_bytes(int c_read, int m) { return ((size_t)pad_to(c_read, 4) * 9 + 16) * pad_to(m, 128) * sizeof(float); }
 
+// stats != nullptr: forward with fused BatchNorm statistics.  tiles_out (optional) receives the number of pixel tiles;
+// dry: only compute it.
 template <class Cfg>
-int launch_fwd(C3Geom g, const float *x, const float *wp, const float *bias, float *y, hipStream_t stream, const char *what) {
+int launch_fwd(C3Geom g, const float *x, const float *wp, const float *bias, float *y, hipStream_t stream, const char *what,
+               float *stats = nullptr, int *tiles_out = nullptr, bool dry = false) {
     g.tiles_x = (g.W + Cfg::TW - 1) / Cfg::TW;
     g.tiles_y = (g.H + Cfg::TH - 1) / Cfg::TH;
     g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
     const int64_t blocks = Cfg::VROWS ? (int64_t)(((int64_t)g.N * Cfg::TH + Cfg::VROWS - 1) / Cfg::VROWS) * g.tiles_m
                                       : (int64_t)((g.N + Cfg::NIMG - 1) / Cfg::NIMG) * g.tiles_x * g.tiles_y * g.tiles_m;
     if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "conv3x3: grid too large");
+    if (tiles_out) *tiles_out = (int)(blocks / g.tiles_m);
+    if (dry) return CPG_OK;
     if (g.dgrad)
-        hipLaunchKernelGGL((k_c3_fwd<Cfg, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y);
+        hipLaunchKernelGGL((k_c3_fwd<Cfg, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, nullptr);
+    else if (stats != nullptr)
+        hipLaunchKernelGGL((k_c3_fwd<Cfg, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, stats);
     else
-        hipLaunchKernelGGL((k_c3_fwd<Cfg, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y);
+        hipLaunchKernelGGL((k_c3_fwd<Cfg, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, nullptr);
     CPG_CHECK_LAUNCH(what);
     return CPG_OK;
 }
 
 // c_read / m: channels contracted over / produced.  w is the layer's [K][C][3][3] weight.
 int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, const float *x, const float *w, const float *pm,
-            float thr, const float *bias, float *y, void *ws, size_t ws_bytes, hipStream_t stream) {
+            float thr, const float *bias, float *y, void *ws, size_t ws_bytes, hipStream_t stream, float *stats = nullptr,
+            int *tiles_out = nullptr, bool dry = false) {
     const char *what = dgrad ? "cpg_conv2d_dgrad(3x3)" : "cpg_conv2d_fwd(3x3)";
-    const size_t need = pack_bytes(c_read, m);
-    if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
-    CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
     float *wp = (float *)ws;
     const int rows_c = pad_to(c_read, 4), Mp = pad_to(m, 128);
-    hipLaunchKernelGGL(k_c3_pack, dim3(stream_grid((int64_t)rows_c * 9 * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, K, C,
-                       rows_c, Mp, dgrad ? 1 : 0);
+    if (!dry) {
+        const size_t need = pack_bytes(c_read, m);
+        if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
+        CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
+        hipLaunchKernelGGL(k_c3_pack, dim3(stream_grid((int64_t)rows_c * 9 * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, K, C,
+                           rows_c, Mp, dgrad ? 1 : 0);
+    }
     C3Geom g{N, c_read, H, W, m, Mp, 0, 0, 0, dgrad ? 1 : 0};
     if (const char *f = getenv("CPG_C3_FORCE")) {        // A/B experiments only (tools/conv_bench.py --ab)
         switch (atoi(f)) {
-            case 0: return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what);
-            case 1: return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what);
-            case 2: return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what);
-            case 3: return launch_fwd<CfgD128>(g, x, wp, bias, y, stream, what);
-            case 4: return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what);
-            default: if (c_read % 4 == 0) return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what);
+            case 0: return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+            case 1: return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+            case 2: return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+            case 3: return launch_fwd<CfgD128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+            case 4: return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+            default: if (c_read % 4 == 0) return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
         }
     }
-    if (W == 7 && H == 7 && c_read % 4 == 0) return launch_fwd<CfgV7>(g, x, wp, bias, y, stream, what);
-    if (W <= 16 && H <= 16 && m > 64) return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what);
+    if (W == 7 && H == 7 && c_read % 4 == 0) return launch_fwd<CfgV7>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+    if (W <= 16 && H <= 16 && m > 64) return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
     if (W == 28 && H % 4 == 0 && m > 64 && c_read % 4 == 0)
-        return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what);
+        return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
     // 56, 112, 168 ...: a 32-wide tile would waste 12.5 % of the MFMAs.  The 64-channel 8 x 56 tile (2 x 2 waves) measured
     // 1-2 % faster than the 128-channel 4 x 56 tile (4 x 1 waves) on every 56- and 112-wide VGG layer, also for m > 64
     // (interleaved in-process A/B, tools/conv_bench.py --ab CPG_C3_FORCE=3,4).
-    if (W % 56 == 0 && W % 32 != 0) return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what);
-    if (m <= 64) return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what);
-    return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what);
+    if (W % 56 == 0 && W % 32 != 0) return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+    if (m <= 64) return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+    return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
 }
 
 }  // namespace
@@ -724,6 +787,20 @@ int cpg_conv3x3_fwd(const cpg_conv_desc *d, const float *x, const float *w, cons
                     float *y, void *ws, size_t ws_bytes, hipStream_t stream) {
     CPG_REQUIRE(x && w && y, "cpg_conv2d_fwd: null pointer");
     return run_fwd(false, d->N, d->C, d->K, d->H, d->W, d->K, d->C, x, w, pm, thr, bias, y, ws, ws_bytes, stream);
+}
+
+// forward that also writes the per-(channel, pixel tile) BatchNorm partial sums; tiles = cpg_conv3x3_bnstats_tiles(d)
+int cpg_conv3x3_bnstats_tiles(const cpg_conv_desc *d) {
+    int tiles = 0;
+    if (run_fwd(false, d->N, d->C, d->K, d->H, d->W, d->K, d->C, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, 0, nullptr,
+                nullptr, &tiles, true) != CPG_OK)
+        return 0;
+    return tiles;
+}
+int cpg_conv3x3_fwd_bnstats(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
+                            float *y, float *stats, void *ws, size_t ws_bytes, hipStream_t stream) {
+    CPG_REQUIRE(x && w && y && stats, "cpg_conv2d_fwd_bnstats: null pointer");
+    return run_fwd(false, d->N, d->C, d->K, d->H, d->W, d->K, d->C, x, w, pm, thr, bias, y, ws, ws_bytes, stream, stats);
 }
 
 int cpg_conv3x3_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx, void *ws,

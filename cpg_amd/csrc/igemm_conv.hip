@@ -520,6 +520,9 @@ int cpg_conv3x3_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, c
                       float *gw, float *gpm, void *ws, size_t ws_bytes, hipStream_t stream);
 // the 3x3 weight-gradient kernel owns a 64-wide input-channel tile; <= 3 channels (the VGG stem) have their own
 // HBM-streaming kernel, 4..15 channels go to the generic kernel whose (ci, tap) column packing wastes less MFMA
+int cpg_conv3x3_bnstats_tiles(const cpg_conv_desc *d);
+int cpg_conv3x3_fwd_bnstats(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
+                            float *y, float *stats, void *ws, size_t ws_bytes, hipStream_t stream);
 // ... and the pointwise kernels (pointwise.hip) for 1x1 convolutions (forward and input gradient)
 extern "C" int cpg_conv1x1_supported(const cpg_conv_desc *d);
 size_t cpg_conv1x1_pack_workspace(const cpg_conv_desc *d);
@@ -631,6 +634,21 @@ extern "C" int cpg_conv2d_fwd(const cpg_conv_desc *d, const float *x, const floa
     if (d && cpg_conv3x3_supported(d)) return cpg_conv3x3_fwd(d, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream);
     if (d && cpg_conv1x1_supported(d)) return cpg_conv1x1_fwd(d, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream);
     return cpg_conv2d_fwd_generic(d, x, w, pm, thr, bias, y, stream);
+}
+
+// Forward that also emits the BatchNorm partial sums of its output (3x3 s1 p1 shapes; 0 tiles = not available).
+extern "C" int32_t cpg_conv2d_bnstats_tiles(const cpg_conv_desc *d) {
+    return (d && cpg_conv3x3_supported(d)) ? cpg_conv3x3_bnstats_tiles(d) : 0;
+}
+extern "C" int cpg_conv2d_fwd_bnstats(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr,
+                                      const float *bias, float *y, float *stats, size_t stats_bytes, void *ws, size_t ws_bytes,
+                                      void *stream) {
+    const int tiles = cpg_conv2d_bnstats_tiles(d);
+    if (tiles <= 0) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_fwd_bnstats: no fused-statistics kernel for this shape");
+    const size_t need = (size_t)d->K * tiles * 2 * sizeof(float);
+    if (stats == nullptr || stats_bytes < need)
+        return fail(CPG_E_WORKSPACE, "cpg_conv2d_fwd_bnstats: statistics buffer %zu < %zu bytes", stats_bytes, need);
+    return cpg_conv3x3_fwd_bnstats(d, x, w, pm, thr, bias, y, stats, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int cpg_conv2d_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr,

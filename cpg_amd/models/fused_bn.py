@@ -16,14 +16,20 @@ from .. import _lib
 
 class _BnReluFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, training, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, training, relu, stats=None):
         x = x.contiguous()
         N, C = x.shape[0], x.shape[1]
         HW = x.numel() // (N * C)
         L = _lib.lib()
         y = torch.empty_like(x)
         s = _lib.stream_ptr()
-        if training:
+        if training and stats is not None:
+            # the producing conv already accumulated the partial sums: finalize, then the apply pass alone
+            mean, invstd = _finalize_stats(stats, N, C, HW, eps, momentum, running_mean, running_var, x.device)
+            rc = L.cpg_bn_relu_fwd_eval(_lib.dptr(x, name='input'), _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(mean),
+                                        _lib.dptr(invstd), _lib.dptr(y), N, C, HW, int(relu), s)
+            _lib.check('cpg_bn_relu_fwd_eval', rc)
+        elif training:
             mean = torch.empty(C, dtype=torch.float32, device=x.device)
             invstd = torch.empty(C, dtype=torch.float32, device=x.device)
             ws, nb = _lib.workspace(L.cpg_bn_workspace_bytes(N, C, HW), x.device)
@@ -56,7 +62,19 @@ class _BnReluFn(torch.autograd.Function):
                                _lib.dptr(invstd), _lib.dptr(gx), _lib.dptr(dgamma), _lib.dptr(dbeta), N, C, HW, int(relu),
                                int(training), _lib.dptr(ws), nb, _lib.stream_ptr())
         _lib.check('cpg_bn_relu_bwd', rc)
-        return gx, dgamma, dbeta, None, None, None, None, None, None
+        return gx, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def _finalize_stats(stats, N, C, HW, eps, momentum, running_mean, running_var, device):
+    """mean / invstd (+ running statistics update) from a conv's [C][tiles][2] partial sums (cpg_bn_stats_finalize)."""
+    L = _lib.lib()
+    mean = torch.empty(C, dtype=torch.float32, device=device)
+    invstd = torch.empty(C, dtype=torch.float32, device=device)
+    rc = L.cpg_bn_stats_finalize(_lib.dptr(stats, name='bn partial sums'), stats.shape[1], N, C, HW, float(eps), float(momentum),
+                                 _lib.dptr(running_mean, name='running_mean'), _lib.dptr(running_var, name='running_var'),
+                                 _lib.dptr(mean), _lib.dptr(invstd), _lib.stream_ptr())
+    _lib.check('cpg_bn_stats_finalize', rc)
+    return mean, invstd
 
 
 class _BnAddReluFn(torch.autograd.Function):
@@ -106,21 +124,24 @@ class _BnReluPoolFn(torch.autograd.Function):
     """BatchNorm2d -> ReLU -> MaxPool2d(2, 2); only the pooled tensor is written."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, training):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, training, stats=None):
         x = x.contiguous()
         N, C, H, W = x.shape
         L = _lib.lib()
         y = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
-        if training:
+        compute_stats = training and stats is None
+        if training and stats is not None:
+            mean, invstd = _finalize_stats(stats, N, C, H * W, eps, momentum, running_mean, running_var, x.device)
+        elif training:
             mean = torch.empty(C, dtype=torch.float32, device=x.device)
             invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         else:
             mean, invstd = running_mean, torch.rsqrt(running_var + eps)
         ws, nb = _lib.workspace(L.cpg_bn_workspace_bytes(N, C, H * W), x.device)
         rc = L.cpg_bn_relu_pool_fwd(_lib.dptr(x, name='input'), _lib.dptr(gamma, name='bn.weight'), _lib.dptr(beta, name='bn.bias'),
-                                    float(eps), float(momentum), _lib.dptr(running_mean if training else None),
-                                    _lib.dptr(running_var if training else None), _lib.dptr(mean), _lib.dptr(invstd),
-                                    _lib.dptr(y), N, C, H, W, int(training), _lib.dptr(ws), nb, _lib.stream_ptr())
+                                    float(eps), float(momentum), _lib.dptr(running_mean if compute_stats else None),
+                                    _lib.dptr(running_var if compute_stats else None), _lib.dptr(mean), _lib.dptr(invstd),
+                                    _lib.dptr(y), N, C, H, W, int(compute_stats), _lib.dptr(ws), nb, _lib.stream_ptr())
         _lib.check('cpg_bn_relu_pool_fwd', rc)
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         ctx.training = bool(training)
@@ -139,7 +160,7 @@ class _BnReluPoolFn(torch.autograd.Function):
                                     _lib.dptr(invstd), _lib.dptr(gx), _lib.dptr(dgamma), _lib.dptr(dbeta), N, C, H, W,
                                     int(ctx.training), _lib.dptr(ws), nb, _lib.stream_ptr())
         _lib.check('cpg_bn_relu_pool_bwd', rc)
-        return gx, dgamma, dbeta, None, None, None, None, None
+        return gx, dgamma, dbeta, None, None, None, None, None, None
 
 
 def _is_pool2(m):
@@ -149,13 +170,14 @@ def _is_pool2(m):
             and pair(m.dilation) == (1, 1) and not m.ceil_mode and not m.return_indices)
 
 
-def bn_relu_pool(x, bn):
-    """max_pool2d(relu(bn(x)), 2, 2) with `bn` an nn.BatchNorm2d module; H and W must be even."""
+def bn_relu_pool(x, bn, stats=None):
+    """max_pool2d(relu(bn(x)), 2, 2) with `bn` an nn.BatchNorm2d module; H and W must be even.  `stats`: partial sums
+    of x from the conv that produced it (SharableConv2d.forward_with_bn_stats)."""
     training = bn.training or not bn.track_running_stats
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return _BnReluPoolFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, training)
+    return _BnReluPoolFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, training, stats if training else None)
 
 
 def fusable(bn, x):
@@ -165,13 +187,14 @@ def fusable(bn, x):
             and bn.momentum is not None and (bn.track_running_stats or bn.training))
 
 
-def bn_relu(x, bn, relu=True):
+def bn_relu(x, bn, relu=True, stats=None):
     """y = relu(bn(x)) with `bn` an nn.BatchNorm2d module (its buffers are updated as torch would)."""
     training = bn.training or not bn.track_running_stats
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return _BnReluFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, training, relu)
+    return _BnReluFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, training, relu,
+                           stats if (training and rm is not None) else None)
 
 
 class _PReluFn(torch.autograd.Function):
@@ -235,26 +258,35 @@ class FusedSequential(nn.Sequential):
 
     fuse = True
     fuse_pool = True
+    fuse_stats = True       # conv -> BatchNorm2d: the conv kernel's epilogue produces the batch-statistics partial sums
 
     def forward(self, input):
         mods = list(self._modules.values())
         i, n = 0, len(mods)
+        stats = None            # partial sums of `input`, when the module that produced it was asked for them
         while i < n:
             m = mods[i]
             if (self.fuse and ENABLED and i + 1 < n and isinstance(m, nn.BatchNorm2d) and isinstance(mods[i + 1], nn.ReLU)
                     and fusable(m, input)):
                 if (self.fuse_pool and i + 2 < n and _is_pool2(mods[i + 2]) and input.shape[2] % 2 == 0
                         and input.shape[3] % 2 == 0 and m.track_running_stats):
-                    input = bn_relu_pool(input, m)
+                    input = bn_relu_pool(input, m, stats)
                     i += 3
-                    continue
-                input = bn_relu(input, m, relu=True)
-                i += 2
+                else:
+                    input = bn_relu(input, m, relu=True, stats=stats)
+                    i += 2
+                stats = None
                 continue
             if self.fuse and ENABLED and isinstance(m, nn.BatchNorm2d) and fusable(m, input):
-                input = bn_relu(input, m, relu=False)       # a lone BatchNorm2d (ResNet shortcut: conv1x1 -> BN)
+                input = bn_relu(input, m, relu=False, stats=stats)       # a lone BatchNorm2d (ResNet shortcut: conv1x1 -> BN)
                 i += 1
+                stats = None
                 continue
-            input = m(input)
+            nxt = mods[i + 1] if i + 1 < n else None
+            if (self.fuse and self.fuse_stats and ENABLED and hasattr(m, 'forward_with_bn_stats') and isinstance(nxt, nn.BatchNorm2d)
+                    and nxt.training and nxt.track_running_stats and nxt.affine and nxt.momentum is not None and input.is_cuda):
+                input, stats = m.forward_with_bn_stats(input)
+            else:
+                input, stats = m(input), None
             i += 1
         return input

@@ -63,7 +63,10 @@ class _MaskedConv2dFn(torch.autograd.Function):
     """y = conv2d(x, W * bin(pm), b) and its gradients, all through the C ABI."""
 
     @staticmethod
-    def forward(ctx, x, weight, pm, bias, thr, stride, padding, dilation, groups):
+    def forward(ctx, x, weight, pm, bias, thr, stride, padding, dilation, groups, bn_stats=False):
+        """bn_stats: also return the per-(channel, pixel tile) {sum, sum of squares} of y that the kernel accumulates
+        in its epilogue (cpg_conv2d_fwd_bnstats) -- a second, non-differentiable output, or None when the shape has
+        no fused-statistics kernel."""
         if x.dim() != 4 or x.shape[1] != weight.shape[1] * groups:
             raise RuntimeError('SharableConv2d: input %s does not match weight %s (groups=%d)'
                                % (tuple(x.shape), tuple(weight.shape), groups))
@@ -77,16 +80,30 @@ class _MaskedConv2dFn(torch.autograd.Function):
         y = torch.empty((d.N, d.K, oh, ow), dtype=torch.float32, device=x.device)
         L = _lib.lib()
         ws, nbytes = _lib.workspace(L.cpg_conv2d_workspace_bytes(ctypes.byref(d)), x.device)
-        rc = L.cpg_conv2d_fwd(ctypes.byref(d), _lib.dptr(x, name='input'), _lib.dptr(w, name='weight'),
-                              _lib.dptr(p, name='piggymask'), float(thr), _lib.dptr(bias, name='bias'),
-                              _lib.dptr(y), _lib.dptr(ws), nbytes, _lib.stream_ptr())
-        _lib.check('cpg_conv2d_fwd', rc)
+        tiles = L.cpg_conv2d_bnstats_tiles(ctypes.byref(d)) if bn_stats else 0
+        stats = None
+        if tiles > 0:
+            stats = torch.empty((d.K, tiles, 2), dtype=torch.float32, device=x.device)
+            rc = L.cpg_conv2d_fwd_bnstats(ctypes.byref(d), _lib.dptr(x, name='input'), _lib.dptr(w, name='weight'),
+                                          _lib.dptr(p, name='piggymask'), float(thr), _lib.dptr(bias, name='bias'), _lib.dptr(y),
+                                          _lib.dptr(stats), stats.numel() * 4, _lib.dptr(ws), nbytes, _lib.stream_ptr())
+            _lib.check('cpg_conv2d_fwd_bnstats', rc)
+        else:
+            rc = L.cpg_conv2d_fwd(ctypes.byref(d), _lib.dptr(x, name='input'), _lib.dptr(w, name='weight'),
+                                  _lib.dptr(p, name='piggymask'), float(thr), _lib.dptr(bias, name='bias'),
+                                  _lib.dptr(y), _lib.dptr(ws), nbytes, _lib.stream_ptr())
+            _lib.check('cpg_conv2d_fwd', rc)
         ctx.save_for_backward(x, w, p)
         ctx.desc, ctx.thr, ctx.has_bias = d, float(thr), bias is not None
-        return y
+        if not bn_stats:
+            return y
+        if stats is None:
+            stats = torch.empty(0, dtype=torch.float32, device=x.device)      # "not available" marker
+        ctx.mark_non_differentiable(stats)
+        return y, stats
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gstats=None):
         x, w, p = ctx.saved_tensors
         d, thr = ctx.desc, ctx.thr
         gy = gy.contiguous()
@@ -106,7 +123,7 @@ class _MaskedConv2dFn(torch.autograd.Function):
             rc = L.cpg_conv2d_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), _lib.dptr(p), thr,
                                     _lib.dptr(gw), _lib.dptr(gpm), _lib.dptr(gb), _lib.dptr(ws), nbytes, s)
             _lib.check('cpg_conv2d_wgrad', rc)
-        return gx, gw, gpm, gb, None, None, None, None, None
+        return gx, gw, gpm, gb, None, None, None, None, None, None
 
 
 class _MaskedLinearFn(torch.autograd.Function):
@@ -204,6 +221,13 @@ class SharableConv2d(_Sharable):
     def forward(self, input, layer_info=None, name=None):
         return _MaskedConv2dFn.apply(input, self.weight, self.piggymask, self.bias, self.info['threshold'],
                                      self.stride, self.padding, self.dilation, self.groups)
+
+    def forward_with_bn_stats(self, input):
+        """(y, stats): forward plus the BatchNorm partial sums of y from the same kernel; stats is None when this shape
+        has no fused-statistics kernel.  Used by cpg_amd.models.fused_bn.FusedSequential for conv -> BatchNorm2d runs."""
+        y, stats = _MaskedConv2dFn.apply(input, self.weight, self.piggymask, self.bias, self.info['threshold'],
+                                         self.stride, self.padding, self.dilation, self.groups, True)
+        return y, (stats if stats.numel() else None)
 
     def extra_repr(self):
         s = '{in_channels}, {out_channels}, kernel_size={kernel_size}, stride={stride}'

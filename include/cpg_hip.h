@@ -171,6 +171,19 @@ int cpg_bn_relu_bwd(const float *x, const float *gy, const float *gamma, const f
                     const float *invstd, float *gx, float *dgamma, float *dbeta, int32_t N, int32_t C,
                     int32_t HW, int32_t relu, int32_t train, void *ws, size_t ws_bytes, void *stream);
 
+/* Conv forward fused with the statistics pass of the BatchNorm2d that follows it in every CPG topology
+ * (models/vgg.py:137-141 `conv2d, BatchNorm2d, ReLU`): the kernel that produces y also writes, per output channel and
+ * pixel tile, {sum y, sum y^2} -> stats[K][tiles][2] (fp32), tiles = cpg_conv2d_bnstats_tiles(desc) (0: this shape has
+ * no fused path -- use cpg_conv2d_fwd + cpg_bn_relu_fwd_train).  cpg_bn_stats_finalize merges them (fp64, fixed order)
+ * into mean / invstd and the running statistics; the normalisation itself is then cpg_bn_relu_fwd_eval or
+ * cpg_bn_relu_pool_fwd(train = 0) with those statistics, and backward is unchanged (train = 1). */
+int32_t cpg_conv2d_bnstats_tiles(const cpg_conv_desc *desc);
+int cpg_conv2d_fwd_bnstats(const cpg_conv_desc *desc, const float *x, const float *w, const float *piggymask, float threshold,
+                           const float *bias, float *y, float *stats, size_t stats_bytes, void *workspace,
+                           size_t workspace_bytes, void *stream);
+int cpg_bn_stats_finalize(const float *stats, int32_t tiles, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
+                          float *running_mean, float *running_var, float *mean, float *invstd, void *stream);
+
 /* y = relu(bn(x) + res): the tail of a residual block (models/resnet.py:69-74 `out = self.bn3(out); out += identity;
  * out = self.relu(out)`).  train != 0: batch statistics (mean / invstd out, running stats updated); train == 0: `mean`
  * / `invstd` are inputs.  Backward = relu mask from y, then cpg_bn_relu_bwd(relu = 0); the residual's gradient is the

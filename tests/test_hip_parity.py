@@ -749,6 +749,49 @@ def test_prelu_backward_matches_torch(N, C, H, W, shared):
     np.testing.assert_allclose(out[True][2], out[False][2], rtol=1e-4, atol=1e-5 * sc)
 
 
+@pytest.mark.parametrize('N,C,K,H,W,pool', [(4, 16, 64, 56, 56, False), (6, 64, 128, 28, 28, True), (5, 32, 160, 14, 14, True),
+                                          (3, 3, 64, 64, 64, False), (2, 8, 24, 10, 12, True), (7, 16, 40, 7, 7, False)])
+def test_conv_epilogue_bn_statistics(N, C, K, H, W, pool):
+    """conv -> BatchNorm2d -> ReLU (-> MaxPool) in train mode with the statistics accumulated in the conv epilogue
+    (cpg_conv2d_fwd_bnstats + cpg_bn_stats_finalize) against the separate statistics pass: output, running statistics,
+    input and parameter gradients; every tile configuration of the forward kernel."""
+    from cpg_amd.models import fused_bn
+    torch.manual_seed(N * 10 + K)
+    mods = [nl.SharableConv2d(C, K, 3, padding=1, bias=False), nn.BatchNorm2d(K), nn.ReLU(inplace=True)]
+    if pool:
+        mods.append(nn.MaxPool2d(2, 2))
+    seq = fused_bn.FusedSequential(*mods)
+    nn.init.kaiming_normal_(seq[0].weight, mode='fan_out', nonlinearity='relu')
+    nn.init.uniform_(seq[1].weight, 0.5, 1.5)
+    nn.init.uniform_(seq[1].bias, -0.5, 0.5)
+    seq = seq.to(DEV).train()
+    g = torch.Generator().manual_seed(4)
+    x0 = (torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(DEV)
+    sd = {k: v.clone() for k, v in seq.state_dict().items()}
+    gy = None
+    res = {}
+    for fs in (True, False):
+        seq.fuse_stats = fs
+        seq.load_state_dict(sd)
+        seq.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        y = seq(x)
+        if gy is None:
+            gy = torch.randn(y.shape, generator=g).to(DEV)
+        y.backward(gy)
+        res[fs] = (y.detach().cpu().numpy(), x.grad.cpu().numpy(), {n: p.grad.cpu().numpy() for n, p in seq.named_parameters()},
+                   {n: b.detach().cpu().numpy() for n, b in seq.named_buffers()})
+    a, b = res[True], res[False]
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-4, atol=1e-5)
+    for n in b[3]:
+        np.testing.assert_allclose(a[3][n], b[3][n], rtol=1e-5, atol=1e-6, err_msg=n)
+    sc = float(np.abs(b[1]).max())
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-3, atol=1e-4 * sc)
+    for n in b[2]:
+        sc = float(np.abs(b[2][n]).max()) + 1e-12
+        np.testing.assert_allclose(a[2][n], b[2][n], rtol=1e-3, atol=1e-4 * sc, err_msg=n)
+
+
 # --------------------------------------------------------------------------- fused masked SGD (SURVEY 8f.1)
 @pytest.mark.parametrize('nesterov', [True, False])
 def test_masked_sgd_equals_routing_then_torch_sgd(nesterov):

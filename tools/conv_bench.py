@@ -66,7 +66,10 @@ def main():
         ws, nb = _lib.workspace(nws, dev)
         flops = 2.0 * a.batch * K * H * H * C * 9
         P = _lib.dptr
-        runs = {'fwd': lambda: L.cpg_conv2d_fwd(ctypes.byref(d), P(x), P(w), P(pm), 5e-3, None, P(y), P(ws), nb, st),
+        tiles = L.cpg_conv2d_bnstats_tiles(ctypes.byref(d))
+        stats = torch.empty(max(1, K * tiles * 2), device=dev)
+        runs = {'fwdstats': lambda: L.cpg_conv2d_fwd_bnstats(ctypes.byref(d), P(x), P(w), P(pm), 5e-3, None, P(y), P(stats), stats.numel() * 4, P(ws), nb, st),
+                'fwd': lambda: L.cpg_conv2d_fwd(ctypes.byref(d), P(x), P(w), P(pm), 5e-3, None, P(y), P(ws), nb, st),
                 'dgrad': lambda: L.cpg_conv2d_dgrad(ctypes.byref(d), P(gy), P(w), P(pm), 5e-3, P(gx), P(ws), nb, st),
                 'wgrad': lambda: L.cpg_conv2d_wgrad(ctypes.byref(d), P(x), P(gy), P(w), P(pm), 5e-3, P(gw), P(gpm), None, P(ws), nb, st)}
         for k in a.only.split(','):
