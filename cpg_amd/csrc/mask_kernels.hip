@@ -273,7 +273,7 @@ inline int is16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" int cpg_sgd_route_step(float *w, float *gw, float *momentum_buf, const uint8_t *owner, int32_t cur, float wd, float lr,
                                   float momentum, int32_t nesterov, int32_t first_step, int64_t n, void *stream) {
-    CPG_REQUIRE(w && gw && momentum_buf && owner && n >= 0, "cpg_sgd_route_step: null pointer or negative n");
+    CPG_REQUIRE(n >= 0 && (n == 0 || (w && gw && momentum_buf && owner)), "cpg_sgd_route_step: null pointer or negative n");
     CPG_REQUIRE(cur >= 0 && cur <= 255, "cpg_sgd_route_step: owner id %d out of uint8 range", cur);
     if (n == 0) return CPG_OK;
     const int vec = is16(w) && is16(gw) && is16(momentum_buf) && (((uintptr_t)owner) & 3) == 0;
@@ -285,7 +285,7 @@ extern "C" int cpg_sgd_route_step(float *w, float *gw, float *momentum_buf, cons
 
 extern "C" int cpg_binarize_mask_weight(const float *w, const float *pm, float thr, float *w_eff, int64_t n,
                                         void *stream) {
-    CPG_REQUIRE(pm && w_eff && n >= 0, "cpg_binarize_mask_weight: null pointer or negative n");
+    CPG_REQUIRE(n >= 0 && (n == 0 || (pm && w_eff)), "cpg_binarize_mask_weight: null pointer or negative n");
     if (n == 0) return CPG_OK;
     const int vec = (!w || is16(w)) && is16(pm) && is16(w_eff);
     hipLaunchKernelGGL(k_binarize_mul, dim3(stream_grid(n, kThreads * 4)), dim3(kThreads), 0, (hipStream_t)stream, w, pm,
@@ -296,7 +296,7 @@ extern "C" int cpg_binarize_mask_weight(const float *w, const float *pm, float t
 
 extern "C" int cpg_route_grads(float *gw, const float *w, const uint8_t *owner, int32_t cur, float wd, float *gpm,
                                int32_t mode, int64_t n, void *stream) {
-    CPG_REQUIRE(gw && w && owner && n >= 0, "cpg_route_grads: null pointer or negative n");
+    CPG_REQUIRE(n >= 0 && (n == 0 || (gw && w && owner)), "cpg_route_grads: null pointer or negative n");
     CPG_REQUIRE(mode == CPG_MODE_FINETUNE || mode == CPG_MODE_PRUNE, "cpg_route_grads: unknown mode %d", mode);
     CPG_REQUIRE(cur >= 0 && cur <= 255, "cpg_route_grads: owner id %d out of uint8 range", cur);
     if (n == 0) return CPG_OK;
@@ -312,7 +312,7 @@ extern "C" int cpg_route_grads(float *gw, const float *w, const uint8_t *owner, 
 
 extern "C" int cpg_mask_hist(const uint8_t *owner, const float *pm, int32_t inference_idx, int64_t n, uint64_t *hist,
                              void *stream) {
-    CPG_REQUIRE(owner && hist && n >= 0, "cpg_mask_hist: null pointer or negative n");
+    CPG_REQUIRE(n >= 0 && hist && (n == 0 || owner), "cpg_mask_hist: null pointer or negative n");
     if (n == 0) return CPG_OK;
     const int vec = (((uintptr_t)owner) & 3) == 0 && (!pm || is16(pm));
     hipLaunchKernelGGL(k_mask_hist, dim3(stream_grid(n, kThreads * 16)), dim3(kThreads), 0, (hipStream_t)stream, owner, pm,
@@ -322,7 +322,7 @@ extern "C" int cpg_mask_hist(const uint8_t *owner, const float *pm, int32_t infe
 }
 
 extern "C" int cpg_apply_mask(float *w, const uint8_t *owner, int32_t inference_idx, int64_t n, void *stream) {
-    CPG_REQUIRE(w && owner && n >= 0, "cpg_apply_mask: null pointer or negative n");
+    CPG_REQUIRE(n >= 0 && (n == 0 || (w && owner)), "cpg_apply_mask: null pointer or negative n");
     if (n == 0) return CPG_OK;
     const int vec = is16(w) && (((uintptr_t)owner) & 3) == 0;
     hipLaunchKernelGGL(k_zero_by_owner, dim3(stream_grid(n, kThreads * 4)), dim3(kThreads), 0, (hipStream_t)stream, w,
@@ -336,7 +336,7 @@ extern "C" int cpg_zero_pruned(float *w, const uint8_t *owner, int64_t n, void *
 }
 
 extern "C" int cpg_claim_free(uint8_t *owner, int32_t new_idx, int64_t n, void *stream) {
-    CPG_REQUIRE(owner && n >= 0, "cpg_claim_free: null pointer or negative n");
+    CPG_REQUIRE(n >= 0 && (n == 0 || owner), "cpg_claim_free: null pointer or negative n");
     CPG_REQUIRE(new_idx >= 1 && new_idx <= 255, "cpg_claim_free: owner id %d out of uint8 range", new_idx);
     if (n == 0) return CPG_OK;
     const int vec = is16(owner);

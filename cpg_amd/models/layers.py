@@ -79,6 +79,16 @@ class _MaskedConv2dFn(torch.autograd.Function):
             raise RuntimeError('SharableConv2d: kernel larger than padded input')
         y = torch.empty((d.N, d.K, oh, ow), dtype=torch.float32, device=x.device)
         L = _lib.lib()
+        ctx.empty = d.N == 0
+        if ctx.empty:                   # an empty batch is legal for F.conv2d: empty output, zero parameter gradients
+            _lib.dptr(x, name='input'), _lib.dptr(w, name='weight')            # still no CPU / dtype fallback
+            ctx.save_for_backward(x, w, p)
+            ctx.desc, ctx.thr, ctx.has_bias = d, float(thr), bias is not None
+            if not bn_stats:
+                return y
+            stats = torch.empty(0, dtype=torch.float32, device=x.device)
+            ctx.mark_non_differentiable(stats)
+            return y, stats
         ws, nbytes = _lib.workspace(L.cpg_conv2d_workspace_bytes(ctypes.byref(d)), x.device)
         tiles = L.cpg_conv2d_bnstats_tiles(ctypes.byref(d)) if bn_stats else 0
         stats = None
@@ -106,6 +116,9 @@ class _MaskedConv2dFn(torch.autograd.Function):
     def backward(ctx, gy, _gstats=None):
         x, w, p = ctx.saved_tensors
         d, thr = ctx.desc, ctx.thr
+        if ctx.empty:
+            return (torch.zeros_like(x), torch.zeros_like(w), None if p is None else torch.zeros_like(p),
+                    torch.zeros(d.K, dtype=torch.float32, device=x.device) if ctx.has_bias else None, None, None, None, None, None, None)
         gy = gy.contiguous()
         L = _lib.lib()
         s = _lib.stream_ptr()
@@ -142,6 +155,12 @@ class _MaskedLinearFn(torch.autograd.Function):
         # in-place ReLU that follows these layers in the reference topologies
         y = torch.empty((*lead, fout), dtype=torch.float32, device=x.device)
         L = _lib.lib()
+        ctx.empty = batch == 0
+        if ctx.empty:                   # F.linear accepts zero rows
+            _lib.dptr(x2, name='input'), _lib.dptr(w, name='weight')
+            ctx.save_for_backward(x2, w, p)
+            ctx.thr, ctx.has_bias, ctx.lead = float(thr), bias is not None, lead
+            return y
         ws, nbytes = _lib.workspace(L.cpg_linear_workspace_bytes(batch, fin, fout), x.device)
         rc = L.cpg_linear_fwd(_lib.dptr(x2, name='input'), _lib.dptr(w, name='weight'), _lib.dptr(p, name='piggymask'),
                               float(thr), _lib.dptr(bias, name='bias'), _lib.dptr(y), batch, fin, fout,
@@ -156,6 +175,10 @@ class _MaskedLinearFn(torch.autograd.Function):
         x2, w, p = ctx.saved_tensors
         thr = ctx.thr
         batch, fin, fout = x2.shape[0], w.shape[1], w.shape[0]
+        if ctx.empty:
+            return (torch.zeros((*ctx.lead, fin), dtype=torch.float32, device=x2.device), torch.zeros_like(w),
+                    None if p is None else torch.zeros_like(p),
+                    torch.zeros(fout, dtype=torch.float32, device=x2.device) if ctx.has_bias else None, None)
         gy2 = gy.reshape(-1, fout).contiguous()
         L = _lib.lib()
         s = _lib.stream_ptr()

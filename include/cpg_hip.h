@@ -17,6 +17,8 @@
  *   - Tensors are dense, contiguous fp32 (NCHW activations, [Cout][Cin/g][R][S] conv
  *     weights, [out][in] linear weights) and uint8 owner ids shaped like the weight
  *     (reference: torch.ByteTensor masks, CPG_cifar100_main_normal.py:204).
+ *   - Element-wise entry points accept n == 0 (and then NULL data pointers, as an empty
+ *     tensor has no storage) and return CPG_OK without launching anything.
  *   - `pm` is the real-valued piggymask (same shape as the weight) or NULL (task 1,
  *     CPG_cifar100_main_normal.py:263-270).  When non-NULL the effective weight is
  *     W * (pm > thr ? 1 : 0) -- models/layers.py:11-23,99-105.  The linear and generic conv kernels

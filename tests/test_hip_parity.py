@@ -792,6 +792,36 @@ def test_conv_epilogue_bn_statistics(N, C, K, H, W, pool):
         np.testing.assert_allclose(a[2][n], b[2][n], rtol=1e-3, atol=1e-4 * sc, err_msg=n)
 
 
+def test_empty_batch_and_empty_layers():
+    """Edge cases torch accepts: a batch of zero images / rows through the masked layers (empty output, zero parameter
+    gradients), and mask kernels over zero elements."""
+    conv = nl.SharableConv2d(8, 16, 3, padding=1, bias=True).to(DEV)
+    nn.init.normal_(conv.weight)
+    nn.init.normal_(conv.bias)
+    conv.piggymask = nn.Parameter(torch.full_like(conv.weight, 0.01))
+    x = torch.empty(0, 8, 12, 12, device=DEV, requires_grad=True)
+    y = conv(x)
+    assert tuple(y.shape) == (0, 16, 12, 12)
+    y.sum().backward()
+    assert float(conv.weight.grad.abs().sum()) == 0.0 and float(conv.bias.grad.abs().sum()) == 0.0
+    assert float(conv.piggymask.grad.abs().sum()) == 0.0 and tuple(x.grad.shape) == (0, 8, 12, 12)
+    lin = nl.SharableLinear(32, 5).to(DEV)
+    nn.init.normal_(lin.weight)
+    nn.init.zeros_(lin.bias)
+    z = lin(torch.empty(0, 32, device=DEV, requires_grad=True))
+    assert tuple(z.shape) == (0, 5)
+    z.sum().backward()
+    assert float(lin.weight.grad.abs().sum()) == 0.0
+    import ctypes
+    L = __import__('cpg_amd._lib', fromlist=['x'])
+    e8, e32 = torch.empty(0, dtype=torch.uint8, device=DEV), torch.empty(0, device=DEV)
+    hist = torch.zeros(257, dtype=torch.int64, device=DEV)
+    assert L.lib().cpg_route_grads(L.dptr(e32), L.dptr(e32), L.dptr(e8, torch.uint8), 1, 4e-5, None, L.MODE_PRUNE, 0, L.stream_ptr()) == 0
+    assert L.lib().cpg_mask_hist(L.dptr(e8, torch.uint8), None, 1, 0, ctypes.c_void_p(hist.data_ptr()), L.stream_ptr()) == 0
+    assert L.lib().cpg_apply_mask(L.dptr(e32), L.dptr(e8, torch.uint8), 1, 0, L.stream_ptr()) == 0
+    assert int(hist.sum()) == 0
+
+
 # --------------------------------------------------------------------------- fused masked SGD (SURVEY 8f.1)
 @pytest.mark.parametrize('nesterov', [True, False])
 def test_masked_sgd_equals_routing_then_torch_sgd(nesterov):
