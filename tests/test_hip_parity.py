@@ -351,6 +351,47 @@ def test_mask_kernels_ragged_sizes_vs_oracle():
         np.testing.assert_array_equal(masks['module.conv'].cpu().numpy(), ops.claim_free(owner.numpy(), 4))
 
 
+def test_owner_id_uint8_extremes_vs_oracle():
+    """Owner ids are uint8 (torch.ByteTensor masks): the last representable task (255) and its neighbours through
+    routing, statistics, apply_mask, rank prune and claim -- raw C ABI against the oracle."""
+    import ctypes
+    L = __import__('cpg_amd._lib', fromlist=['x'])
+    lib, s = L.lib(), L.stream_ptr()
+    n = 100003
+    g = torch.Generator().manual_seed(255)
+    owner = torch.tensor([0, 1, 127, 128, 254, 255], dtype=torch.uint8)[torch.randint(0, 6, (n,), generator=g)]
+    w, gw, gpm = torch.randn(n, generator=g), torch.randn(n, generator=g), torch.randn(n, generator=g)
+    pm = torch.rand(n, generator=g) * 0.012
+    for cur, mode, mname in ((255, L.MODE_FINETUNE, 'finetune'), (254, L.MODE_PRUNE, 'prune'), (128, L.MODE_FINETUNE, 'finetune')):
+        dgw, dgpm = gw.to(DEV), gpm.to(DEV)
+        assert lib.cpg_route_grads(L.dptr(dgw), L.dptr(w.to(DEV)), L.dptr(owner.to(DEV), torch.uint8), cur, 4e-5, L.dptr(dgpm), mode, n, s) == 0
+        wg, wp = ops.route_grads(gw.numpy(), w.numpy(), owner.numpy(), cur, 4e-5, gpm.numpy(), mname)
+        np.testing.assert_allclose(dgw.cpu().numpy(), wg, rtol=3e-7, atol=0)
+        np.testing.assert_array_equal(dgpm.cpu().numpy(), wp)
+    hist = torch.zeros(257, dtype=torch.int64, device=DEV)
+    assert lib.cpg_mask_hist(L.dptr(owner.to(DEV), torch.uint8), L.dptr(pm.to(DEV)), 255, n, ctypes.c_void_p(hist.data_ptr()), s) == 0
+    np.testing.assert_array_equal(hist[:256].cpu().numpy(), np.bincount(owner.numpy(), minlength=256))
+    shared = (owner.numpy() > 0) & (owner.numpy() < 255) & (pm.numpy() > 0.005)
+    assert int(hist[256]) == int(shared.sum())
+    for idx in (254, 255):
+        dw = w.to(DEV)
+        assert lib.cpg_apply_mask(L.dptr(dw), L.dptr(owner.to(DEV), torch.uint8), idx, n, s) == 0
+        np.testing.assert_array_equal(dw.cpu().numpy(), ops.apply_mask(w.numpy(), owner.numpy(), idx))
+    do = owner.to(DEV)
+    assert lib.cpg_claim_free(L.dptr(do, torch.uint8), 255, n, s) == 0
+    np.testing.assert_array_equal(do.cpu().numpy(), ops.claim_free(owner.numpy(), 255))
+    assert lib.cpg_claim_free(L.dptr(do, torch.uint8), 256, n, s) == -1          # not a uint8 owner id
+    # rank prune for task 255
+    do = owner.to(DEV)
+    res = torch.zeros(4, dtype=torch.int64, device=DEV)
+    ws, nb = L.workspace(lib.cpg_rank_prune_workspace_bytes(), DEV)
+    assert lib.cpg_rank_prune(L.dptr(w.to(DEV)), L.dptr(do, torch.uint8), 255, 0.3, n, ctypes.c_void_p(res.data_ptr()), L.dptr(ws), nb, s) == 0
+    want, k, cutoff = ops.rank_prune(w.numpy(), owner.numpy(), 255, 0.3)
+    np.testing.assert_array_equal(do.cpu().numpy(), want)
+    rec = L.PruneResult.from_buffer_copy(res.cpu().numpy().tobytes())
+    assert rec.k == k and rec.cutoff == np.float32(cutoff) and rec.status == 0
+
+
 # --------------------------------------------------------------------------- whole networks vs golden
 def build(arch, width, ncls=5):
     torch.manual_seed(1)
