@@ -98,8 +98,14 @@ class DataParallel(nn.Module):
         """BatchNorm running statistics: keep rank 0's, as the reference's replica 0 does."""
         if not self._active:
             return
+        by_dtype = {}
         for b in self.module.buffers():
-            dist.broadcast(b.data, src=src, group=self.process_group)
+            by_dtype.setdefault(b.dtype, []).append(b.data)
+        for bufs in by_dtype.values():          # one flat broadcast per dtype (running_mean / running_var; num_batches_tracked)
+            flat = _flatten_dense_tensors(bufs)
+            dist.broadcast(flat, src=src, group=self.process_group)
+            for b, f in zip(bufs, _unflatten_dense_tensors(flat, bufs)):
+                b.copy_(f)
 
 
 def shard_batch(data, target, rank=None, world=None):
