@@ -674,7 +674,7 @@ def test_resnet_spherenet_backward_matches_torch_ops(arch, width, shape, ncls, m
                 nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
         # Make the network SMOOTH for this comparison: with ReLU, one pre-activation of -1.6e-7 (HIP) vs +3.8e-7
         # (MIOpen) at an element carrying 25 % of the peak gradient flipped its mask and moved layer2.2's
-        # gradients by 7 % although every conv matched to 1e-7 (tools/debug_resnet3.py).  Softplus / AvgPool keep
+        # gradients by 7 % although every conv matched to 1e-7.  Softplus / AvgPool keep
         # the same conv shapes and data flow without kinks.
         for mod in net.modules():
             for name, child in list(mod.named_children()):
