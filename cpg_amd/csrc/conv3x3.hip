@@ -60,6 +60,7 @@ struct C3Geom {
     int Mp;                   // row stride of the packed weights (M rounded up to 128)
     int tiles_x, tiles_y, tiles_m;
     int dgrad;                // host side only: which instantiation to launch
+    int ksplit;               // 1, or 2: the channel chunks of a tile are shared by two blocks that atomically add into a zeroed y
 };
 
 template <int BM_, int TH_, int TW_, int WM_, int WN_, int CK_, int MINW_, int NIMG_ = 1, int VROWS_ = 0>
@@ -128,7 +129,9 @@ __global__ __launch_bounds__(256) void k_c3_pack(const float *__restrict__ w, co
 // STATS: the forward of a conv that feeds a training-mode BatchNorm also emits, per block, the sum and the sum of squares of
 // its outputs per channel -- stats[channel][pixel tile][2] -- so the BatchNorm needs no statistics pass over y
 // (cpg_conv2d_fwd_bnstats + cpg_bn_stats_finalize; deterministic: fixed-order merges only).
-template <class Cfg, bool DGRAD, bool STATS = false>
+// SPLITK: g.ksplit blocks share a tile's channel chunks and atomically add their accumulators into a zeroed y.  Two addends
+// per element commute, so the result does not depend on which block arrives first (0 + a + b = 0 + b + a bitwise).
+template <class Cfg, bool DGRAD, bool STATS = false, bool SPLITK = false>
 __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float *__restrict__ x, const float *__restrict__ wp,
                                                            const float *__restrict__ bias, float *__restrict__ y,
                                                            float *__restrict__ stats) {
@@ -140,6 +143,11 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
     // block -> (m tile, x tile, y tile, image); m fastest so co-resident blocks of an XCD share the patch
     unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = lb % g.tiles_m; lb /= g.tiles_m;
+    int ksp = 0;
+    if (SPLITK) {
+        ksp = lb % g.ksplit;
+        lb /= g.ksplit;
+    }
     const unsigned tile_n = lb;                          // pixel-tile index (STATS)
     const int tx = lb % g.tiles_x; lb /= g.tiles_x;
     const int ty = lb % g.tiles_y;
@@ -221,11 +229,13 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[fm][fn][e] = 0.0f;
 
-    const int nch = (g.C + Cfg::CK - 1) / Cfg::CK;
+    const int nch_all = (g.C + Cfg::CK - 1) / Cfg::CK;
+    const int per_split = SPLITK ? (nch_all + g.ksplit - 1) / g.ksplit : nch_all;
+    const int ch0 = ksp * per_split, nch = min(nch_all, ch0 + per_split);        // this block's chunks: [ch0, nch)
 #pragma unroll
-    for (int k = 0; k < Cfg::NITEMS; ++k) load_item(k, 0);
+    for (int k = 0; k < Cfg::NITEMS; ++k) load_item(k, ch0 * Cfg::CK);
 #pragma unroll
-    for (int k = 0; k < Cfg::NITEMS; ++k) store_item(k, smem);
+    for (int k = 0; k < Cfg::NITEMS; ++k) store_item(k, smem + (ch0 & 1) * Cfg::STAGE);
     __syncthreads();
     // One chunk = NS k-steps; k-step s = (channel pair p = s / 9, tap = s % 9): lanes 0-31 hold channel 2p, lanes
     // 32-63 channel 2p+1.  The body is branch free and its instruction order pinned (sched_group_barrier):
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
     //     in the last NITEMS steps -- never a staging-only phase, which the block's waves (two per SIMD, in
     //     lock step) could not hide from one another.  The chunk index is clamped, so the last chunk re-stages
     //     itself instead of branching.
-    for (int ch = 0; ch < nch; ++ch) {
+    for (int ch = ch0; ch < nch; ++ch) {
         const float *ws = smem + (ch & 1) * Cfg::STAGE;
         const float *xs = ws + Cfg::W_ELEMS;
         float *other = smem + ((ch + 1) & 1) * Cfg::STAGE;
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
             float bv[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) bv[e] = 0.0f;
-            if (bias != nullptr) {          // one uniform branch per fragment, 16 loads issued together
+            if (bias != nullptr && ksp == 0) {          // one uniform branch per fragment, 16 loads issued together
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -302,7 +312,10 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
             for (int e = 0; e < 16; ++e) {
                 const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 const float v = acc[fm][fn][e] + bv[e];
-                if (pok && co < g.M) yout[(int64_t)co * HW + poff] = v;
+                if (pok && co < g.M) {
+                    if (SPLITK) atomicAdd(&yout[(int64_t)co * HW + poff], v);
+                    else yout[(int64_t)co * HW + poff] = v;
+                }
                 if (STATS && pok) {
                     s1[fm][e] += v;
                     s2[fm][e] += v * v;
@@ -703,6 +716,7 @@ using CfgM64 = C3Cfg<64, 8, 32, 1, 4, 4, 3>;       // <= 64 output channels (VGG
 using CfgS16 = C3Cfg<128, 14, 16, 4, 1, 4, 2>;     // 14x14 (and <= 16 wide) feature maps: whole image, 7 fragments
 using CfgD128 = C3Cfg<128, 4, 56, 4, 1, 4, 2>;     // 56 / 112 wide maps: 4 x 56 = 7 fragments per wave, zero tile waste
 using CfgD64 = C3Cfg<64, 8, 56, 2, 2, 4, 2>;       // same for <= 64 output channels
+using CfgV14 = C3Cfg<128, 14, 14, 4, 1, 4, 2, 3, 16>;   // 14 x 14 maps: 16 virtual rows = 224 pixels, zero tile waste (with ksplit = 2)
 using CfgV7 = C3Cfg<128, 7, 7, 4, 1, 4, 2, 6, 32>;     // 7 x 7 maps (ResNet layer4): 32 virtual rows over up to 6 images
 using CfgP28 = C3Cfg<128, 4, 28, 4, 1, 4, 2, 2>;   // 28-wide maps: a 4 x 28 strip of TWO images = 7 fragments, zero tile waste
 
@@ -721,8 +735,19 @@ int launch_fwd(C3Geom g, const float *x, const float *wp, const float *bias, flo
     const int64_t blocks = Cfg::VROWS ? (int64_t)(((int64_t)g.N * Cfg::TH + Cfg::VROWS - 1) / Cfg::VROWS) * g.tiles_m
                                       : (int64_t)((g.N + Cfg::NIMG - 1) / Cfg::NIMG) * g.tiles_x * g.tiles_y * g.tiles_m;
     if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "conv3x3: grid too large");
-    if (tiles_out) *tiles_out = (int)(blocks / g.tiles_m);
+    if (tiles_out) *tiles_out = g.ksplit > 1 ? 0 : (int)(blocks / g.tiles_m);      // no fused statistics on split tiles
     if (dry) return CPG_OK;
+    if (g.ksplit > 1) {
+        if (stats != nullptr) return fail(CPG_E_UNSUPPORTED, "conv3x3: no fused statistics on channel-split tiles");
+        hipError_t e = hipMemsetAsync(y, 0, (size_t)g.N * g.M * g.H * g.W * sizeof(float), stream);
+        if (e != hipSuccess) return hip_status(e, what);
+        if (g.dgrad)
+            hipLaunchKernelGGL((k_c3_fwd<Cfg, true, false, true>), dim3((unsigned)(blocks * g.ksplit)), dim3(256), 0, stream, g, x, wp, bias, y, nullptr);
+        else
+            hipLaunchKernelGGL((k_c3_fwd<Cfg, false, false, true>), dim3((unsigned)(blocks * g.ksplit)), dim3(256), 0, stream, g, x, wp, bias, y, nullptr);
+        CPG_CHECK_LAUNCH(what);
+        return CPG_OK;
+    }
     if (g.dgrad)
         hipLaunchKernelGGL((k_c3_fwd<Cfg, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, nullptr);
     else if (stats != nullptr)
@@ -747,7 +772,7 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
         hipLaunchKernelGGL(k_c3_pack, dim3(stream_grid((int64_t)rows_c * 9 * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, K, C,
                            rows_c, Mp, dgrad ? 1 : 0);
     }
-    C3Geom g{N, c_read, H, W, m, Mp, 0, 0, 0, dgrad ? 1 : 0};
+    C3Geom g{N, c_read, H, W, m, Mp, 0, 0, 0, dgrad ? 1 : 0, 1};
     if (const char *f = getenv("CPG_C3_FORCE")) {        // A/B experiments only (tools/conv_bench.py --ab)
         switch (atoi(f)) {
             case 0: return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
@@ -759,6 +784,14 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
         }
     }
     if (W == 7 && H == 7 && c_read % 4 == 0) return launch_fwd<CfgV7>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+    // 14 x 14 maps: the 14 x 16 single-image tile wastes 1/8 of its MFMAs on two padding columns; the zero-waste virtual-row
+    // tile alone measured the same, because its N*14/16 tiles put 3.5 block-equivalents on each CU, which rounds up to 4
+    // (at batch 256 the layer is too small for 256 CUs).  Halving the blocks (two per tile, each half of the channel chunks,
+    // atomically added into a zeroed y) makes it 7 half-blocks per CU.
+    if (W == 14 && H == 14 && m > 64 && c_read % 8 == 0 && !getenv("CPG_NO_V14")) {
+        g.ksplit = 2;
+        return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+    }
     if (W <= 16 && H <= 16 && m > 64) return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
     if (W == 28 && H % 4 == 0 && m > 64 && c_read % 4 == 0)
         return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);

@@ -115,6 +115,7 @@ def test_linear_golden(name):
     (3, 2, 13, 37, 70, 3, 1, 1, False, True),        # stem weight-gradient kernel (C <= 3), ragged tiles, 2 co blocks
     (5, 160, 28, 28, 136, 3, 1, 1, False, False),    # two-image 4x28 tiles with an odd image count
     (2, 32, 12, 28, 128, 3, 1, 1, True, True),       # two-image tiles, bias + piggymask
+    (4, 16, 14, 14, 72, 3, 1, 1, True, True),        # 14x14 maps: channel-split virtual-row tiles (atomic accumulation), bias on one half
     (6, 32, 7, 7, 160, 3, 1, 1, False, True),        # 7x7 maps: virtual-row tiles over 6 images (fwd + dgrad), 7x8 wgrad units
     (37, 16, 7, 7, 24, 3, 1, 1, True, False),        # 7x7 maps, image count not a multiple of the tile, bias, <= 64 channels
     (5, 12, 6, 8, 20, 3, 1, 1, False, False),        # 6x8 maps: 7x8 wgrad units with a missing row

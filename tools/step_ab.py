@@ -3,6 +3,7 @@
 two settings in blocks of --iters steps, --reps times, and prints the median ms per step of each.
 
     python tools/step_ab.py cpg_amd.models.fused_bn.FusedSequential.fuse_stats
+    python tools/step_ab.py env:CPG_NO_V14
 """
 import argparse
 import importlib
@@ -25,12 +26,21 @@ def main():
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--batch', type=int, default=256)
     a = ap.parse_args()
-    path, attr = a.switch.rsplit('.', 1)
-    try:
-        owner = importlib.import_module(path)
-    except ImportError:
-        mod, cls = path.rsplit('.', 1)
-        owner = getattr(importlib.import_module(mod), cls)
+    if a.switch.startswith('env:'):             # env:NAME -- True = variable set to "1", False = unset (read by the library per call)
+        class _Env(object):
+            def __setattr__(self, name, value):
+                if value:
+                    os.environ[name] = '1'
+                else:
+                    os.environ.pop(name, None)
+        owner, attr = _Env(), a.switch[4:]
+    else:
+        path, attr = a.switch.rsplit('.', 1)
+        try:
+            owner = importlib.import_module(path)
+        except ImportError:
+            mod, cls = path.rsplit('.', 1)
+            owner = getattr(importlib.import_module(mod), cls)
     torch.manual_seed(1)
     net = M.custom_vgg(VGG_CFG, dataset_history=[], dataset2num_classes={}, network_width_multiplier=1.0, shared_layer_info={})
     net.add_dataset('t', 5)
