@@ -25,6 +25,7 @@
 //   MFMAs.  Split-K over (image, pixel-tile) units; tap-major partials reduced by k_split_reduce
 //   (igemm_core.h), which also applies the autograd epilogue gW = g*bin(pm), gPM = g*W.
 #include <algorithm>
+#include <cmath>
 #include "igemm_core.h"
 
 using namespace cpg;
@@ -789,8 +790,15 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
     // (at batch 256 the layer is too small for 256 CUs).  Halving the blocks (two per tile, each half of the channel chunks,
     // atomically added into a zeroed y) makes it 7 half-blocks per CU.
     if (W == 14 && H == 14 && m > 64 && c_read % 8 == 0 && !getenv("CPG_NO_V14")) {
-        g.ksplit = 2;
-        return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+        // ... when that balances: per-CU MFMA time in block-equivalents of either tiling (the split pays a memset, atomics
+        // and a second prologue; at 256 channels and batch 256 -- 3.5 half-blocks per CU -- it measured no gain)
+        const int tm = (m + 127) / 128;
+        const double t_single = std::ceil((double)N * tm / kCUs) * (16.0 / 14.0);
+        const double t_split = std::ceil(2.0 * (((int64_t)N * 14 + 15) / 16) * tm / kCUs) * 0.5 * 1.04;
+        if (t_split < 0.9 * t_single) {
+            g.ksplit = 2;
+            return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+        }
     }
     if (W <= 16 && H <= 16 && m > 64) return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
     if (W == 28 && H % 4 == 0 && m > 64 && c_read % 4 == 0)
