@@ -781,6 +781,8 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
             case 2: return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
             case 3: return launch_fwd<CfgD128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
             case 4: return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+            case 7: return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+            case 8: g.ksplit = 2; return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
             default: if (c_read % 4 == 0) return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
         }
     }

@@ -40,6 +40,7 @@ def main():
     ap.add_argument('--only', default='fwd,dgrad,wgrad')
     ap.add_argument('--layers', default='')
     ap.add_argument('--pm', action='store_true')
+    ap.add_argument('--shape', default='', help='extra 3x3 layer "C,K,H" (name x0) instead of the VGG list')
     ap.add_argument('--ab', default='', help='A/B inside one process: NAME=v1,v2,... toggles that env var between timed runs (median of --reps rounds)')
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--pmc-pass', action='store_true', help='no timing: launch every conv of one VGG16 pass exactly once (for rocprofv3 --pmc)')
@@ -50,7 +51,11 @@ def main():
     sel = set(a.layers.split(',')) if a.layers else None
     print('%-6s %-6s %9s %9s' % ('layer', 'pass', 'ms', 'TFLOP/s'))
     tot = {}
-    for name, C, K, H, mult in VGG:
+    layers = VGG
+    if a.shape:
+        c, k, h = (int(v) for v in a.shape.split(','))
+        layers = [('x0', c, k, h, 1)]
+    for name, C, K, H, mult in layers:
         if sel and name not in sel:
             continue
         x = torch.randn(a.batch, C, H, H, device=dev)
