@@ -58,6 +58,8 @@ _SIGNATURES = {
     'cpg_claim_free': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int64, _vp]),
     'cpg_sgd_route_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _vp]),
+    'cpg_adam_route_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+                                           ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_int64, _vp]),
     'cpg_bn_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'cpg_bn_relu_fwd_train': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp,
                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),

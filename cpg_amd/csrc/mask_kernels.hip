@@ -1,6 +1,7 @@
 // HBM-bound mask / gradient-routing kernels (K1, K4e, K7, K8 of SURVEY.md section 2).
 // Each is a single streaming pass: 16 B per lane per access for fp32, 4 owner bytes as one
 // dword, grid capped at 8 blocks per CU with a grid-stride loop.  gfx950 only.
+#include <cmath>
 #include "cpg_common.h"
 
 using namespace cpg;
@@ -267,9 +268,64 @@ __global__ __launch_bounds__(kThreads) void k_sgd_route(float *__restrict__ w, f
     }
 }
 
+// Fused piggymask step (CPG_cifar100_main_normal.py:342-346 Adam on the piggymasks + utils/prune.py:206-210 routing):
+//   g   = finetune: (owner == 0 || owner >= cur) ? 0 : gpm ; prune: 0        (only older tasks' slots learn to be picked)
+//   m   = m + (1 - beta1) * (g - m);   v = beta2 * v + (1 - beta2) * g * g    (torch.optim.Adam, amsgrad = False, wd = 0)
+//   pm -= step_size * m / (sqrt(v) / sqrt(bias_correction2) + eps),  step_size = lr / bias_correction1
+// and the routed g is written back to .grad.  21 B read + 16 B written per element in one pass.
+__global__ __launch_bounds__(kThreads) void k_adam_route(float *__restrict__ pm, float *__restrict__ gpm, float *__restrict__ m1,
+                                                         float *__restrict__ m2, const uint8_t *__restrict__ owner, int cur, int mode,
+                                                         float step_size, float beta1, float beta2, float eps, float bc2_sqrt,
+                                                         int64_t n, int vec_ok) {
+    const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * kThreads;
+    auto one = [&](float &p, float &g, float &a, float &b, int o) {
+        const bool keep = mode == CPG_MODE_FINETUNE && o != 0 && o < cur;
+        const float gr = keep ? g : 0.0f;
+        a = fmaf(1.0f - beta1, gr - a, a);
+        b = fmaf(1.0f - beta2, gr * gr, beta2 * b);
+        const float denom = sqrtf(b) / bc2_sqrt + eps;
+        p = fmaf(-step_size, a / denom, p);
+        g = gr;
+    };
+    if (vec_ok) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += nthreads) {
+            const uint32_t o4 = reinterpret_cast<const uint32_t *>(owner)[i];
+            F4 pv = reinterpret_cast<F4 *>(pm)[i], gv = reinterpret_cast<F4 *>(gpm)[i];
+            F4 av = reinterpret_cast<F4 *>(m1)[i], bv = reinterpret_cast<F4 *>(m2)[i];
+            one(pv.x, gv.x, av.x, bv.x, o4 & 255);
+            one(pv.y, gv.y, av.y, bv.y, (o4 >> 8) & 255);
+            one(pv.z, gv.z, av.z, bv.z, (o4 >> 16) & 255);
+            one(pv.w, gv.w, av.w, bv.w, o4 >> 24);
+            reinterpret_cast<F4 *>(pm)[i] = pv;
+            reinterpret_cast<F4 *>(gpm)[i] = gv;
+            reinterpret_cast<F4 *>(m1)[i] = av;
+            reinterpret_cast<F4 *>(m2)[i] = bv;
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += nthreads) one(pm[i], gpm[i], m1[i], m2[i], owner[i]);
+    } else {
+        for (int64_t i = tid; i < n; i += nthreads) one(pm[i], gpm[i], m1[i], m2[i], owner[i]);
+    }
+}
+
 inline int is16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
+
+extern "C" int cpg_adam_route_step(float *pm, float *gpm, float *exp_avg, float *exp_avg_sq, const uint8_t *owner, int32_t cur,
+                                   int32_t mode, float lr, float beta1, float beta2, float eps, int32_t step, int64_t n, void *stream) {
+    CPG_REQUIRE(n >= 0 && (n == 0 || (pm && gpm && exp_avg && exp_avg_sq && owner)), "cpg_adam_route_step: null pointer or negative n");
+    CPG_REQUIRE(mode == CPG_MODE_FINETUNE || mode == CPG_MODE_PRUNE, "cpg_adam_route_step: unknown mode %d", mode);
+    CPG_REQUIRE(cur >= 0 && cur <= 255 && step >= 1, "cpg_adam_route_step: owner id %d / step %d out of range", cur, step);
+    if (n == 0) return CPG_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const int vec = is16(pm) && is16(gpm) && is16(exp_avg) && is16(exp_avg_sq) && (((uintptr_t)owner) & 3) == 0;
+    hipLaunchKernelGGL(k_adam_route, dim3(stream_grid(n, kThreads * 4)), dim3(kThreads), 0, (hipStream_t)stream, pm, gpm, exp_avg,
+                       exp_avg_sq, owner, cur, mode, (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2), n, vec);
+    CPG_CHECK_LAUNCH("cpg_adam_route_step");
+    return CPG_OK;
+}
 
 extern "C" int cpg_sgd_route_step(float *w, float *gw, float *momentum_buf, const uint8_t *owner, int32_t cur, float wd, float lr,
                                   float momentum, int32_t nesterov, int32_t first_step, int64_t n, void *stream) {

@@ -55,8 +55,10 @@ class TaskResult(object):
 class CPGSession(object):
     """Holds everything the reference passes between processes through checkpoint files."""
 
-    def __init__(self, arch='custom_vgg_cifar100', width=1.0, device='cuda', cfg=VGG16_CFG, data_parallel=True):
+    def __init__(self, arch='custom_vgg_cifar100', width=1.0, device='cuda', cfg=VGG16_CFG, data_parallel=True,
+                 fused_optimizers=True):
         self.arch, self.width, self.device = arch, width, torch.device(device)
+        self.fused_optimizers = fused_optimizers      # MaskedSGD / MaskedAdam: gradient routing fused into the optimizer passes
         kw = dict(dataset_history=[], dataset2num_classes={}, network_width_multiplier=width, shared_layer_info={})
         build = getattr(models, arch)
         self.net = build(cfg, **kw) if 'vgg' in arch else build(**kw)
@@ -97,8 +99,9 @@ class CPGSession(object):
                 pm = torch.full_like(self.masks[prefix + name], 0.01, dtype=torch.float32)
                 module.piggymask = Parameter(pm)
 
-    def make_optimizers(self, args):
-        """Head of the current task + every non-piggymask parameter -> SGD(nesterov); piggymasks -> Adam (:320-346)."""
+    def make_optimizers(self, args, pruner=None):
+        """Head of the current task + every non-piggymask parameter -> SGD(nesterov); piggymasks -> Adam (:320-346).
+        With a pruner (and fused_optimizers) the masked weights / piggymasks take the fused routing + update passes."""
         idx = self.net.datasets.index(args.dataset)
         sgd_params, adam_params = [], []
         for name, p in self.model.named_parameters():
@@ -110,6 +113,12 @@ class CPGSession(object):
             else:
                 sgd_params.append(p)
         opts = Optimizers()
+        if pruner is not None and self.fused_optimizers:
+            from .utils.fused_sgd import MaskedAdam, MaskedSGD
+            opts.add(MaskedSGD(sgd_params, pruner=pruner, lr=args.lr, momentum=0.9, nesterov=True), args.lr)
+            if adam_params:
+                opts.add(MaskedAdam(adam_params, pruner=pruner, lr=args.lr_mask), args.lr_mask)
+            return opts
         opts.add(torch.optim.SGD(sgd_params, lr=args.lr, weight_decay=0.0, momentum=0.9, nesterov=True), args.lr)
         if adam_params:
             opts.add(torch.optim.Adam(adam_params, lr=args.lr_mask), args.lr_mask)
@@ -126,7 +135,7 @@ class CPGSession(object):
         mgr = self._manager(args, train_loader, val_loader, 0, 0)
         if not args.finetune_again:
             mgr.pruner.make_finetuning_mask()
-        opts = self.make_optimizers(args)
+        opts = self.make_optimizers(args, mgr.pruner)
         lrs = list(opts.lrs)
         stop_lr_mask = mgr.pruner.calculate_curr_task_ratio() != 0.0
         tr = va = 0.0
@@ -156,7 +165,7 @@ class CPGSession(object):
         steps_per_epoch = len(train_loader)
         mgr = self._manager(args, train_loader, val_loader, 0, args.pruning_interval * steps_per_epoch)
         mgr.validate(-1)
-        opts = self.make_optimizers(args)
+        opts = self.make_optimizers(args, mgr.pruner)
         lrs = list(opts.lrs)
         tr = va = 0.0
         step = 0

@@ -67,3 +67,59 @@ class MaskedSGD(torch.optim.SGD):
         for p, g in held:
             p.grad = g
         return loss
+
+
+class MaskedAdam(torch.optim.Adam):
+    """torch.optim.Adam for the piggymasks (CPG_cifar100_main_normal.py:342-346) whose step() handles every
+    `module.piggymask` with ONE pass that also performs the piggymask part of the gradient routing
+    (utils/prune.py:206-210) -- cpg_adam_route_step.  Other parameters in its groups take torch's own path.  While a
+    MaskedAdam is attached, `do_weight_decay_and_make_grads_zero()` leaves piggymask gradients alone; `.grad` ends up
+    routed exactly as before, and the optimizer state keeps torch's keys (step, exp_avg, exp_avg_sq)."""
+
+    def __init__(self, params, pruner, lr, betas=(0.9, 0.999), eps=1e-8, **kw):
+        if kw.get('weight_decay', 0.0) != 0.0 or kw.get('amsgrad', False) or kw.get('maximize', False):
+            raise ValueError('MaskedAdam mirrors the reference optimizer: weight_decay = 0, amsgrad = maximize = False')
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0.0)
+        self.pruner = pruner
+        pruner.fused_piggymask_step = True
+        self._masked = {}
+
+    def _refresh(self):
+        self._masked = {}
+        for name, module in self.pruner.model.named_modules():
+            if isinstance(module, (nl.SharableConv2d, nl.SharableLinear)) and module.piggymask is not None:
+                self._masked[id(module.piggymask)] = name
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self._refresh()                          # piggymasks are re-created between phases (driver._fresh_piggymasks)
+        L = _lib.lib()
+        s = _lib.stream_ptr()
+        pr = self.pruner
+        mode = {'finetune': _lib.MODE_FINETUNE, 'prune': _lib.MODE_PRUNE}.get(pr.args.mode)
+        held = []
+        for group in self.param_groups:
+            beta1, beta2 = group['betas']
+            for p in group['params']:
+                name = self._masked.get(id(p))
+                if name is None or p.grad is None or mode is None:
+                    continue
+                state = self.state[p]
+                if len(state) == 0:
+                    state['step'] = torch.tensor(0.0, dtype=torch.float32)
+                    state['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                state['step'] += 1
+                owner = pr._owner(name, p.data)
+                rc = L.cpg_adam_route_step(_lib.dptr(p.data, name='piggymask'), _lib.dptr(p.grad, name='piggymask.grad'),
+                                           _lib.dptr(state['exp_avg']), _lib.dptr(state['exp_avg_sq']),
+                                           _lib.dptr(owner, torch.uint8, 'mask'), int(pr.current_dataset_idx), mode,
+                                           float(group['lr']), float(beta1), float(beta2), float(group['eps']),
+                                           int(state['step']), p.numel(), s)
+                _lib.check('cpg_adam_route_step', rc)
+                held.append((p, p.grad))
+                p.grad = None
+        loss = super().step(closure)
+        for p, g in held:
+            p.grad = g
+        return loss

@@ -51,6 +51,7 @@ class SparsePruner(object):
             sys.exit(-1)
         self.inference_dataset_idx = inference_dataset_idx
         self.fused_weight_step = False   # set by utils.fused_sgd.MaskedSGD: it routes masked-weight grads itself
+        self.fused_piggymask_step = False   # set by utils.fused_sgd.MaskedAdam: it routes piggymask grads itself
         self._mutations = 0          # bumped whenever a kernel of ours rewrites a mask in place
         self._hist_key = None
         self._hist = None
@@ -227,8 +228,8 @@ class SparsePruner(object):
             if self.fused_weight_step:
                 # weight part deferred to MaskedSGD.step(); only the piggymask gradient is routed here
                 pm = module.piggymask
-                if pm is None or pm.grad is None or mode is None:
-                    continue
+                if pm is None or pm.grad is None or mode is None or self.fused_piggymask_step:
+                    continue       # (piggymask gradients are routed inside MaskedAdam.step() when one is attached)
                 owner = self._owner(name, w.data)
                 scratch = torch.zeros_like(w.data)
                 rc = L.cpg_route_grads(_lib.dptr(scratch), _lib.dptr(w.data.contiguous(), name='weight'),
@@ -242,7 +243,7 @@ class SparsePruner(object):
             else:
                 gw = w.grad.data
             pm = module.piggymask
-            gpm = pm.grad.data if (pm is not None and pm.grad is not None and mode is not None) else None
+            gpm = pm.grad.data if (pm is not None and pm.grad is not None and mode is not None and not self.fused_piggymask_step) else None
             if gw is None and gpm is None:
                 continue
             owner = self._owner(name, w.data)

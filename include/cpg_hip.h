@@ -152,6 +152,13 @@ int cpg_claim_free(uint8_t *owner, int32_t new_idx, int64_t n, void *stream);
 int cpg_sgd_route_step(float *w, float *gw, float *momentum_buf, const uint8_t *owner, int32_t cur, float wd,
                        float lr, float momentum, int32_t nesterov, int32_t first_step, int64_t n, void *stream);
 
+/* Fused piggymask step for task >= 2: the piggymask part of do_weight_decay_and_make_grads_zero (utils/prune.py:206-210:
+ * finetune -> gradient zeroed where owner == 0 or owner >= cur, prune -> all zero) followed by torch.optim.Adam's update
+ * (CPG_cifar100_main_normal.py:342-346; amsgrad = False, weight_decay = 0) in one pass; `step` is the 1-based Adam step
+ * count, exp_avg / exp_avg_sq its state (zeros before step 1).  The routed gradient is written back to gpm. */
+int cpg_adam_route_step(float *pm, float *gpm, float *exp_avg, float *exp_avg_sq, const uint8_t *owner, int32_t cur,
+                        int32_t mode, float lr, float beta1, float beta2, float eps, int32_t step, int64_t n, void *stream);
+
 /* ---- nn.BatchNorm2d -> nn.ReLU(inplace) after each masked conv ----
  * (models/vgg.py:137-141: `layers += [conv2d, nn.BatchNorm2d(c), nn.ReLU(inplace=True)]`).
  * x, y, gy, gx: NCHW fp32 with HW = H*W; gamma/beta/mean/invstd/running_*: C floats.

@@ -906,6 +906,60 @@ def test_masked_sgd_equals_routing_then_torch_sgd(nesterov):
         np.testing.assert_allclose(b1.cpu().numpy(), b0.cpu().numpy(), rtol=2e-3, atol=1e-5 * (float(b0.abs().max()) + 1e-20))
 
 
+@pytest.mark.parametrize('mode', ['finetune', 'prune'])
+def test_masked_adam_equals_routing_then_torch_adam(mode):
+    """Task-2 style step: piggymasks on every masked layer, SGD on the weights + Adam on the piggymasks.  4 steps of
+    MaskedSGD + MaskedAdam (routing fused into both optimizers) vs routing + torch.optim.SGD / Adam on two copies of a
+    narrow VGG: weights, piggymasks, routed piggymask gradients and Adam state agree to fp32 round-off."""
+    from cpg_amd.utils.fused_sgd import MaskedAdam, MaskedSGD
+    nets, pruners, opts = [], [], []
+    for fused in (False, True):
+        net = build('vgg_cifar100', 0.125).to(DEV)
+        model = Wrap(net)
+        g = torch.Generator().manual_seed(21)
+        masks, pms = {}, []
+        for n, m in model.named_modules():
+            if isinstance(m, (nl.SharableConv2d, nl.SharableLinear)):
+                masks[n] = torch.randint(0, 4, m.weight.shape, generator=g, dtype=torch.uint8).to(DEV)
+                m.piggymask = nn.Parameter((torch.rand(m.weight.shape, generator=g) * 0.012).to(DEV))
+                pms.append(m.piggymask)
+        rest = [p for p in model.parameters() if all(p is not q for q in pms)]
+        args = types.SimpleNamespace(mode=mode, dataset='t1', finetune_again=False, target_sparsity=0.3, initial_sparsity=0.0,
+                                     pruning_frequency=100, weight_decay=4e-5, network_width_multiplier=0.125)
+        pruner = SparsePruner(model, masks, args, 0, 8, 1)
+        pruner.current_dataset_idx = 3                    # owners 1, 2 are older tasks, 3 the current one, 0 free
+        if fused:
+            opt = [MaskedSGD(rest, pruner=pruner, lr=1e-2, momentum=0.9, nesterov=True), MaskedAdam(pms, pruner=pruner, lr=5e-4)]
+        else:
+            opt = [torch.optim.SGD(rest, lr=1e-2, momentum=0.9, nesterov=True), torch.optim.Adam(pms, lr=5e-4)]
+        nets.append(model); pruners.append(pruner); opts.append(opt)
+    g = torch.Generator().manual_seed(22)
+    for step in range(4):
+        x = torch.randn(8, 3, 32, 32, generator=g).to(DEV)
+        t = torch.randint(0, 5, (8,), generator=g).to(DEV)
+        for model, pruner, opt in zip(nets, pruners, opts):
+            model.train()
+            for o in opt:
+                o.zero_grad()
+            nn.functional.cross_entropy(model(x), t).backward()
+            pruner.do_weight_decay_and_make_grads_zero()
+            for o in opt:
+                o.step()
+        for (n, p), (_, q) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+            sc = float(p.detach().abs().max()) + 1e-12
+            np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=0, atol=3e-6 * sc, err_msg='%s step %d' % (n, step))
+            if 'piggymask' in n:
+                np.testing.assert_array_equal((q.grad == 0).cpu().numpy(), (p.grad == 0).cpu().numpy(), err_msg='routing ' + n)
+                gs = float(p.grad.abs().max()) + 1e-20
+                np.testing.assert_allclose(q.grad.cpu().numpy(), p.grad.cpu().numpy(), rtol=2e-3, atol=1e-5 * gs, err_msg='grad ' + n)
+    for (n, p), (_, q) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        if 'piggymask' in n:
+            for key in ('exp_avg', 'exp_avg_sq'):
+                a, b = opts[0][1].state[p][key], opts[1][1].state[q][key]
+                np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-3, atol=1e-5 * (float(a.abs().max()) + 1e-30), err_msg=key + ' ' + n)
+            assert float(opts[0][1].state[p]['step']) == float(opts[1][1].state[q]['step']) == 4.0
+
+
 # --------------------------------------------------------------------------- two-task sequence through the driver (8f.4)
 def test_two_task_sequence_matches_oracle():
     """Task 1 (finetune, prune with a rank-prune event) then task 2 (piggymasks picked through the binariser, SGD on
@@ -965,7 +1019,7 @@ def test_two_task_sequence_matches_oracle():
     a1 = default_args(**{**vars(args), 'mode': 'finetune'})
     mgr = Manager(a1, sess.model, sess.shared_layer_info, sess.masks, None, None, 0, 0)
     mgr.pruner.make_finetuning_mask()
-    opts = sess.make_optimizers(a1)
+    opts = sess.make_optimizers(a1, mgr.pruner)               # MaskedSGD: routing fused into the optimizer pass
     owners = {n: np.zeros(tuple(m.weight.shape), np.uint8) for n, m in ref.masked_layers()}
     rp = onet.OraclePruner(ref, owners, 'finetune', 0, 1, 0, 0, 1, 0.0, 0.3, 4e-5, width)
     rp.claim_free()
@@ -975,7 +1029,7 @@ def test_two_task_sequence_matches_oracle():
 
     a2 = default_args(**{**vars(args), 'mode': 'prune', 'initial_sparsity': 0.0, 'target_sparsity': 0.3, 'lr': 1e-3})
     mgr = Manager(a2, sess.model, sess.shared_layer_info, sess.masks, None, None, 0, 2)
-    opts = sess.make_optimizers(a2)
+    opts = sess.make_optimizers(a2, mgr.pruner)
     rp2 = onet.OraclePruner(ref, rp.owners, 'prune', 1, 1, 0, 2, 1, 0.0, 0.3, 4e-5, width)
     ropt = [torch.optim.SGD(ref.parameters(), lr=1e-3, momentum=0.9, nesterov=True)]
     compare('t1 prune', hip_steps(mgr, opts, batches[3:6]), [oracle_step(rp2, ropt, x, t, s) for s, (x, t) in enumerate(batches[3:6])])
@@ -996,7 +1050,7 @@ def test_two_task_sequence_matches_oracle():
     mgr = Manager(a3, sess.model, sess.shared_layer_info, sess.masks, None, None, 0, 0)
     assert mgr.pruner.current_dataset_idx == 1 and mgr.inference_dataset_idx == 2
     mgr.pruner.make_finetuning_mask()
-    opts = sess.make_optimizers(a3)
+    opts = sess.make_optimizers(a3, mgr.pruner)               # MaskedSGD + MaskedAdam
     assert len(opts.optimizers) == 2                       # SGD + Adam on the piggymasks
     rp3 = onet.OraclePruner(ref, rp2.owners, 'finetune', 1, 2, 0, 0, 1, 0.0, 0.3, 4e-5, width)
     rp3.claim_free()
