@@ -223,12 +223,15 @@ def phase_report(marks, model, masks, batch):
     return rep
 
 
-def cpu_baseline(budget_s=20.0):
-    """Oracle ("port") of the same train step on the host cores: a bounded sample, reported beside the
-    GPU number (never the target).  oracle/ is only ever used here as the measured CPU baseline.
-    Thread count is torch's default for the host (one per physical core): forcing every hardware thread
-    onto a small batch made oneDNN several times slower on the 2 x 64-core GPU host."""
+def cpu_baseline(budget_s=18.0, steps=110, batch=256):
+    """Oracle ("port") of the same cycle on the host cores: a bounded sample of each ingredient -- train steps, one
+    rank-prune event over all 15 layers, one validate batch -- extrapolated to the cycle the GPU ran (K train steps of
+    `batch` images, 4 prune events, 11 validates of 2 x 100 images), reported beside the GPU number (never the target).
+    oracle/ is only ever used here as the measured CPU baseline.  Thread count is torch's default for the host (one per
+    physical core): forcing every hardware thread onto a small batch made oneDNN several times slower on the 2 x 64-core
+    GPU host."""
     from oracle import net as onet
+    from oracle import ops as oops
     threads = torch.get_num_threads()
     b = 16
     model, pruner, opt = onet.make_task1(1.0, 'imagenet', 'finetune', lr=1e-2, wd=4e-5)
@@ -245,9 +248,28 @@ def cpu_baseline(budget_s=20.0):
         if time.time() - t0 > budget_s or n >= 10:
             break
     dt = time.time() - t0
-    return {'value': round(b * n / dt, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'sample': '%d train steps (fwd + bwd + gradient routing + SGD-nesterov) of the oracle VGG16-BN 224x224 at batch %d, '
-                      'torch-CPU fp32, %d threads, %.1f s; prune events / validates are not in the sample' % (n, b, threads, dt)}
+    train_ips = b * n / dt
+    # one rank-prune event (utils/prune.py:30-53 on every masked layer: boolean gather + k-th value + masked assign)
+    t0 = time.time()
+    for name, m in model.masked_layers():
+        pruner.owners[name], _, _ = oops.rank_prune(m.weight.data.numpy(), pruner.owners[name], pruner.cur, 0.05)
+    prune_s = time.time() - t0
+    # one validate batch (apply_mask + eval forward)
+    model.eval()
+    t0 = time.time()
+    pruner.apply_mask()
+    with torch.no_grad():
+        model(x)
+    val_s = time.time() - t0
+    E = max(1, steps // 11)
+    n_val = (steps + E - 1) // E
+    cycle_s = steps * batch / train_ips + 4 * prune_s + n_val * 200 * (val_s / b)
+    return {'value': round(steps * batch / cycle_s, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'train_images_per_sec': round(train_ips, 3), 'prune_event_s': round(prune_s, 2), 'validate_images_per_sec': round(b / val_s, 2),
+            'sample': '%d train steps (fwd + bwd + gradient routing + SGD-nesterov, %.1f s) + 1 rank-prune event over the 15 layers '
+                      '(%.1f s) + 1 validate batch (apply_mask + eval forward, %.1f s) of the oracle VGG16-BN 224x224 at batch %d, '
+                      'torch-CPU fp32, %d threads; value = the %d-step cycle (4 prune events, %d validates of 200 images) '
+                      'extrapolated from these rates' % (n, dt, prune_s, val_s, b, threads, steps, n_val)}
 
 
 def main():
@@ -360,7 +382,7 @@ def main():
                                         for k, v in sorted(agg.items())}
         out['phases'] = phase_report(marks, model, masks, a.batch)
         if not a.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(steps=a.steps, batch=a.batch)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -208,7 +208,7 @@ def train_step(model, pruner, optimizer, x, target, prune_step=None, torch_routi
     ratio = None
     if pruner.mode == 'prune':
         ratio = pruner.gradually_prune(prune_step)
-    return out.detach(), float(loss), ratio
+    return out.detach(), float(loss.detach()), ratio
 
 
 def make_task1(width, variant, mode, num_classes=5, lr=1e-2, begin=0, end=8, frequency=3,
