@@ -119,6 +119,9 @@ def test_linear_golden(name):
     (6, 32, 7, 7, 160, 3, 1, 1, False, True),        # 7x7 maps: virtual-row tiles over 6 images (fwd + dgrad), 7x8 wgrad units
     (37, 16, 7, 7, 24, 3, 1, 1, True, False),        # 7x7 maps, image count not a multiple of the tile, bias, <= 64 channels
     (5, 12, 6, 8, 20, 3, 1, 1, False, False),        # 6x8 maps: 7x8 wgrad units with a missing row
+    (2, 4, 1, 1, 8, 3, 1, 1, True, True),            # 1x1 map: every tap but the centre is padding
+    (1, 16, 2, 3, 16, 3, 1, 1, False, False),        # 2x3 map, single image
+    (3, 16, 1, 1, 32, 1, 1, 0, False, True),         # pointwise on 1x1 maps (a linear layer in disguise)
     (2, 3, 64, 64, 16, 7, 2, 3, False, False),       # ResNet stem
     (3, 64, 28, 28, 256, 1, 1, 0, False, True),      # ResNet 1x1
     (3, 256, 28, 28, 512, 1, 2, 0, False, False),    # ResNet downsample
