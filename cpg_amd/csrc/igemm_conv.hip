@@ -715,8 +715,20 @@ void gemm_plan(int64_t tiles, int nkt, int &nsplit, int &per) {
     per = (int)((nkt + want - 1) / want);
     nsplit = (nkt + per - 1) / per;
 }
+}  // namespace
+// plain-GEMM entry points of pointwise.hip (used when the layer has no piggymask)
+bool cpg_pw_gemm_nt_ok(const float *A, const float *B, int M, int C, int64_t K);
+size_t cpg_pw_gemm_nt_workspace(int M, int C, int64_t K);
+int cpg_pw_gemm_nt(const float *A, const float *B, int M, int C, int64_t K, const Epilogue &ep, void *ws, size_t ws_bytes,
+                   hipStream_t stream, const char *what);
+bool cpg_pw_gemm_nn_ok(const float *X, int M, int Mp, int Kd, int64_t G);
+int cpg_pw_gemm_nn(const float *wp, int Mp, const float *X, int M, int Kd, int64_t G, const float *bias, float *y, hipStream_t stream,
+                   const char *what);
+void cpg_pw_pack_transpose(const float *a, int R, int Cc, float *wp, hipStream_t stream);
+size_t cpg_pw_pack_transpose_bytes(int R, int Cc);
+namespace {
 size_t linear_ws(int batch, int in_f, int out_f) {
-    size_t best = 0;
+    size_t best = std::max(cpg_pw_gemm_nt_workspace(batch, out_f, in_f), cpg_pw_pack_transpose_bytes(batch, out_f));
     int ns, per;
     {   // fwd: M=batch N=out K=in
         int64_t tiles = (int64_t)((batch + 127) / 128) * ((out_f + 127) / 128);
@@ -764,6 +776,8 @@ extern "C" int cpg_linear_fwd(const float *x, const float *w, const float *pm, f
                               int32_t batch, int32_t in_f, int32_t out_f, void *ws, size_t ws_bytes, void *stream) {
     CPG_REQUIRE(x && w && y && batch > 0 && in_f > 0 && out_f > 0, "cpg_linear_fwd: bad argument");
     Epilogue ep{y, bias, bias ? BIAS_INNER : BIAS_NONE, out_f, 1, nullptr, nullptr, nullptr, thr};
+    if (pm == nullptr && cpg_pw_gemm_nt_ok(x, w, batch, out_f, in_f))          // y[b][o] = x[b][:] . W[o][:]
+        return cpg_pw_gemm_nt(x, w, batch, out_f, in_f, ep, ws, ws_bytes, (hipStream_t)stream, "cpg_linear_fwd");
     return launch_gemm<true, true, 2>(x, in_f, w, in_f, pm, thr, batch, out_f, in_f, ep, ws, ws_bytes, (hipStream_t)stream,
                                       "cpg_linear_fwd");
 }
@@ -772,6 +786,13 @@ extern "C" int cpg_linear_dgrad(const float *gy, const float *w, const float *pm
                                 int32_t in_f, int32_t out_f, void *ws, size_t ws_bytes, void *stream) {
     CPG_REQUIRE(gy && w && gx && batch > 0 && in_f > 0 && out_f > 0, "cpg_linear_dgrad: bad argument");
     Epilogue ep{gx, nullptr, BIAS_NONE, 1, 1, nullptr, nullptr, nullptr, thr};
+    const int Mp_b = (batch + 127) / 128 * 128;
+    if (pm == nullptr && ws != nullptr && ws_bytes >= cpg_pw_pack_transpose_bytes(batch, out_f) && (((uintptr_t)ws) & 15) == 0 &&
+        cpg_pw_gemm_nn_ok(w, batch, Mp_b, out_f, in_f)) {
+        // gx[b][i] = sum_o gy[b][o] W[o][i]: gy^T packed K-major (4 MB) is the "weight", W[o][:] the K-major operand
+        cpg_pw_pack_transpose(gy, batch, out_f, (float *)ws, (hipStream_t)stream);
+        return cpg_pw_gemm_nn((const float *)ws, Mp_b, w, batch, out_f, in_f, nullptr, gx, (hipStream_t)stream, "cpg_linear_dgrad");
+    }
     return launch_gemm<true, false, 2>(gy, out_f, w, in_f, pm, thr, batch, in_f, out_f, ep, ws, ws_bytes, (hipStream_t)stream,
                                        "cpg_linear_dgrad");
 }
@@ -783,7 +804,12 @@ extern "C" int cpg_linear_wgrad(const float *x, const float *gy, const float *w,
     CPG_REQUIRE((pm == nullptr) == (gpm == nullptr), "cpg_linear_wgrad: pm and gpm must both be given or both be NULL");
     CPG_REQUIRE(pm == nullptr || w != nullptr, "cpg_linear_wgrad: w is required to form the piggymask gradient");
     Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
-    int rc = launch_gemm<false, false, 0>(gy, out_f, x, in_f, nullptr, thr, out_f, in_f, batch, ep, ws, ws_bytes,
+    int rc;
+    if (pm == nullptr && (((uintptr_t)gy) & 15) == 0 && cpg_pw_gemm_nn_ok(x, out_f, out_f, batch, in_f))
+        // gW[o][i] = sum_b gy[b][o] x[b][i]: gy is already K-major ([b][o], o a multiple of 128), x[b][:] the other operand
+        rc = cpg_pw_gemm_nn(gy, out_f, x, out_f, batch, in_f, nullptr, gw, (hipStream_t)stream, "cpg_linear_wgrad");
+    else
+        rc = launch_gemm<false, false, 0>(gy, out_f, x, in_f, nullptr, thr, out_f, in_f, batch, ep, ws, ws_bytes,
                                           (hipStream_t)stream, "cpg_linear_wgrad");
     if (rc) return rc;
     if (gb) {

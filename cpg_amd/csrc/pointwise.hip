@@ -511,3 +511,67 @@ int cpg_conv1x1_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, c
         default: return pw_wgrad_launch<PwW128>(d, x, gy, ep, ws, ws_bytes, stream);
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same two kernels as plain GEMMs (N = 1 "image"): the masked linear layers without a piggymask (task 1) run on them.
+//   nt: D[M][C] = A[M][K] . B[C][K]^T (both operands K-contiguous)      = k_pw_wgrad with HWo = K    (linear forward)
+//   nn: D[M][G] = Wp[Kd][Mp]^T . X[Kd][G] (both operands K-major)       = k_pw with one image        (linear dgrad, wgrad)
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct NtPlan {
+    int tiles_co, tiles_ci, nsplit, units_per_split;
+    size_t ws_bytes;
+};
+template <class Cfg>
+NtPlan nt_plan(int M, int C, int64_t K) {
+    NtPlan p;
+    p.tiles_co = (M + Cfg::BCO - 1) / Cfg::BCO;
+    p.tiles_ci = (C + Cfg::BCI - 1) / Cfg::BCI;
+    const int64_t units = (K + Cfg::PIX - 1) / Cfg::PIX, tiles = (int64_t)p.tiles_co * p.tiles_ci;
+    int64_t want = (4 * kCUs + tiles - 1) / tiles;
+    want = std::max<int64_t>(1, std::min<int64_t>(want, (units + 7) / 8));
+    want = (want + kXCDs - 1) / kXCDs * kXCDs;
+    p.units_per_split = (int)((units + want - 1) / want);
+    p.nsplit = (int)want;
+    p.ws_bytes = (size_t)p.nsplit * M * C * sizeof(float);
+    return p;
+}
+}  // namespace
+
+bool cpg_pw_gemm_nt_ok(const float *A, const float *B, int M, int C, int64_t K) {
+    return !getenv("CPG_DISABLE_PW_GEMM") && K % 4 == 0 && (((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0 &&
+           (int64_t)std::max(M, C) * K * 4 < (1ll << 31) && K < (1ll << 29);
+}
+size_t cpg_pw_gemm_nt_workspace(int M, int C, int64_t K) { return nt_plan<PwW128>(M, C, K).ws_bytes; }
+int cpg_pw_gemm_nt(const float *A, const float *B, int M, int C, int64_t K, const Epilogue &ep, void *ws, size_t ws_bytes,
+                   hipStream_t stream, const char *what) {
+    const NtPlan p = nt_plan<PwW128>(M, C, K);
+    if (ws == nullptr || ws_bytes < p.ws_bytes) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, p.ws_bytes);
+    // k_pw_wgrad(M, C, HWo, G, ...): "gy" = A with M rows, "x" = B with C rows, one image of HWo = G = K pixels
+    hipLaunchKernelGGL(k_pw_wgrad<PwW128>, dim3((unsigned)(p.tiles_co * p.tiles_ci * p.nsplit)), dim3(256), 0, stream, M, C, (int)K,
+                       (long long)K, p.tiles_co, p.tiles_ci, p.units_per_split, B, A, (float *)ws);
+    launch_split_reduce((const float *)ws, p.nsplit, (int64_t)M * C, 0, ep, stream);
+    CPG_CHECK_LAUNCH(what);
+    return CPG_OK;
+}
+
+bool cpg_pw_gemm_nn_ok(const float *X, int M, int Mp, int Kd, int64_t G) {
+    // no split-K here: the output tiles alone must fill the chip (4096 -> 4096 dgrad at batch 256 has 38 of them: 4x slower)
+    if (((G + 223) / 224) * ((M + 127) / 128) < 192) return false;
+    return !getenv("CPG_DISABLE_PW_GEMM") && Kd % 16 == 0 && Mp % 128 == 0 && Mp >= M && G < (1ll << 28) &&
+           (int64_t)Kd * G * 4 < (1ll << 31) && (int64_t)M * G < (1ll << 31) && (((uintptr_t)X) & 15) == 0;
+}
+// y[M][G] (+ bias[m]) from K-major Wp (row stride Mp >= M, a multiple of 128; rows beyond Kd are never read)
+int cpg_pw_gemm_nn(const float *wp, int Mp, const float *X, int M, int Kd, int64_t G, const float *bias, float *y, hipStream_t stream,
+                   const char *what) {
+    PwGeom g{1, Kd, M, Mp, (int)G, (int)G, (int)G, 0, 1, (int)G, 0, 1, 0, (long long)G};
+    if (G % 4 == 0) return launch<PwV, false>(g, X, wp, bias, y, stream, what);
+    return launch<PwS, false>(g, X, wp, bias, y, stream, what);
+}
+// K-major transpose of a row-major [R][Cc] matrix into wp[Cc (padded to 16)][R (padded to 128)]
+void cpg_pw_pack_transpose(const float *a, int R, int Cc, float *wp, hipStream_t stream) {
+    const int rows = pad_to(Cc, 16), Mp = pad_to(R, 128);
+    hipLaunchKernelGGL(k_pw_pack, dim3(stream_grid((int64_t)rows * Mp, 256)), dim3(256), 0, stream, a, (const float *)nullptr, 0.f, wp, R, Cc,
+                       rows, Mp, 0);
+}
+size_t cpg_pw_pack_transpose_bytes(int R, int Cc) { return (size_t)(pad_to(Cc, 16) + 16) * pad_to(R, 128) * sizeof(float); }

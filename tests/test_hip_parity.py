@@ -163,7 +163,8 @@ def test_conv_oracle(N, C, H, W, K, k, s, p, bias, pm):
         close(layer.bias.grad, r['gb'], rtol=1e-4, atol=1e-3, msg='gb')
 
 
-@pytest.mark.parametrize('B,I,O,pm', [(32, 25088, 512, False), (256, 4096, 4096, True), (7, 513, 129, True), (1, 64, 5, False)])
+@pytest.mark.parametrize('B,I,O,pm', [(32, 25088, 512, False), (256, 4096, 4096, True), (7, 513, 129, True), (1, 64, 5, False),
+                                      (256, 4096, 4096, False), (100, 1024, 256, False), (48, 260, 384, False)])
 def test_linear_oracle(B, I, O, pm):
     g = torch.Generator().manual_seed(B + I + O)
     x = torch.randn(B, I, generator=g)
