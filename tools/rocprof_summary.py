@@ -27,9 +27,11 @@ def main():
     print('\nGPU kernel time total: %.1f ms over %d kernels (durations in the db are us).' % (total / 1e3, len(rows)))
     # the families bench.py reports (its HIP-event clock brackets the whole library call: + k_c3_pack for fwd / dgrad,
     # + k_c3_wgrad_reduce for wgrad)
-    fams = [('conv_fwd', r'k_c3_fwd<.*>, false(, (true|false))*>|k_pw<.*>, false>|k_conv_fwd'),
-            ('conv_dgrad', r'k_c3_fwd<.*>, true(, (true|false))*>|k_pw<.*>, true>|k_conv_dgrad'),
-            ('conv_wgrad', r'k_c3_wgrad<|k_c3_wgrad_smallc|k_pw_wgrad|k_conv_wgrad')]
+    # (k_pw / k_pw_wgrad serve the 1x1 convs AND the un-masked linear layers, so they get their own row)
+    fams = [('conv_fwd', r'k_c3_fwd<.*>, false(, (true|false))*>|k_conv_fwd'),
+            ('conv_dgrad', r'k_c3_fwd<.*>, true(, (true|false))*>|k_conv_dgrad'),
+            ('conv_wgrad', r'k_c3_wgrad<|k_c3_wgrad_smallc|k_conv_wgrad'),
+            ('pointwise conv / linear GEMM', r'k_pw<|k_pw_wgrad|k_gemm<')]
     print('\n| family (main kernels only) | calls | total ms | avg ms |\n|---|---:|---:|---:|')
     for fam, pat in fams:
         sel = [r for r in rows if re.search(pat, r[0])]
