@@ -36,6 +36,8 @@ class DataParallel(nn.Module):
         self._handles = []
         self._small = []
         self._hooked = set()
+        # RCCL averages inside the collective; gloo (CPU tests) has no AVG, there the sum is scaled afterwards
+        self._avg = self._active and dist.get_backend(process_group) == 'nccl'
         if self._active and broadcast_init:
             self.sync_parameters()
         self._install_hooks()
@@ -60,7 +62,8 @@ class DataParallel(nn.Module):
             g = p.grad
             if not g.is_contiguous():
                 p.grad = g = g.contiguous()
-            self._handles.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True), g))
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            self._handles.append((dist.all_reduce(g, op=op, group=self.process_group, async_op=True), g))
         else:
             self._small.append(p)
 
@@ -77,14 +80,18 @@ class DataParallel(nn.Module):
         if self._small:
             grads = [p.grad for p in self._small]
             flat = _flatten_dense_tensors(grads)
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
-            flat.mul_(inv)
+            if self._avg:
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.process_group)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
+                flat.mul_(inv)
             for g, s in zip(grads, _unflatten_dense_tensors(flat, grads)):
                 g.copy_(s)
             self._small = []
         for work, g in self._handles:
             work.wait()
-            g.mul_(inv)
+            if not self._avg:
+                g.mul_(inv)
         self._handles = []
 
     def sync_parameters(self, src=0):
