@@ -868,43 +868,6 @@ def test_empty_batch_and_empty_layers():
     assert int(hist.sum()) == 0
 
 
-def test_data_parallel_wrapper_over_rccl_world1(monkeypatch):
-    """The RCCL path of cpg_amd.dist.DataParallel on ONE GPU: a world-size-1 process group with the gradient hooks
-    forced on (CPG_DP_FORCE=1) must reproduce the plain model's gradients (all-reduce of one rank, x 1/1).  The
-    multi-rank arithmetic is covered by tests/test_dist_gloo.py; this checks that the collectives run on this stack."""
-    import torch.distributed as dist
-    from cpg_amd import dist as cdist
-    if dist.is_initialized():
-        pytest.skip('a process group already exists in this interpreter')
-    monkeypatch.setenv('CPG_DP_FORCE', '1')
-    try:
-        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29517', rank=0, world_size=1)
-    except Exception as e:                                  # no RCCL on this box: nothing to check here
-        pytest.skip('RCCL process group unavailable: %s' % e)
-    try:
-        torch.manual_seed(7)
-        net = build('vgg_cifar100', 0.125).to(DEV).train()
-        ref = {k: v.clone() for k, v in net.state_dict().items()}
-        g = torch.Generator().manual_seed(8)
-        x = torch.randn(8, 3, 32, 32, generator=g).to(DEV)
-        t = torch.randint(0, 5, (8,), generator=g).to(DEV)
-        nn.functional.cross_entropy(net(x), t).backward()
-        want = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
-        net.load_state_dict(ref)
-        net.zero_grad()
-        model = cdist.DataParallel(net, large_numel=1 << 12)
-        assert model._active
-        nn.functional.cross_entropy(model(x), t).backward()
-        model.finish_gradient_sync()
-        model.sync_buffers()
-        torch.cuda.synchronize()
-        for n, p in net.named_parameters():
-            if n in want:
-                np.testing.assert_allclose(p.grad.cpu().numpy(), want[n].cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=n)
-    finally:
-        dist.destroy_process_group()
-
-
 # --------------------------------------------------------------------------- fused masked SGD (SURVEY 8f.1)
 @pytest.mark.parametrize('nesterov', [True, False])
 def test_masked_sgd_equals_routing_then_torch_sgd(nesterov):
@@ -1106,3 +1069,41 @@ def test_two_task_sequence_matches_oracle():
         older = (rp3.owners[n] > 0) & (rp3.owners[n] < 2)
         assert not np.any(hip_pm.grad.cpu().numpy()[~older]), n
     assert abs(mgr.pruner.calculate_shared_part_ratio() - 1.0) < 1e-12    # every piggymask value still > 0.005
+
+
+# --------------------------------------------------------------------------- RCCL (kept last: it owns a process group)
+def test_data_parallel_wrapper_over_rccl_world1(monkeypatch):
+    """The RCCL path of cpg_amd.dist.DataParallel on ONE GPU: a world-size-1 process group with the gradient hooks
+    forced on (CPG_DP_FORCE=1) must reproduce the plain model's gradients (all-reduce of one rank, x 1/1).  The
+    multi-rank arithmetic is covered by tests/test_dist_gloo.py; this checks that the collectives run on this stack."""
+    import torch.distributed as dist
+    from cpg_amd import dist as cdist
+    if dist.is_initialized():
+        pytest.skip('a process group already exists in this interpreter')
+    monkeypatch.setenv('CPG_DP_FORCE', '1')
+    try:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29517', rank=0, world_size=1)
+    except Exception as e:                                  # no RCCL on this box: nothing to check here
+        pytest.skip('RCCL process group unavailable: %s' % e)
+    try:
+        torch.manual_seed(7)
+        net = build('vgg_cifar100', 0.125).to(DEV).train()
+        ref = {k: v.clone() for k, v in net.state_dict().items()}
+        g = torch.Generator().manual_seed(8)
+        x = torch.randn(8, 3, 32, 32, generator=g).to(DEV)
+        t = torch.randint(0, 5, (8,), generator=g).to(DEV)
+        nn.functional.cross_entropy(net(x), t).backward()
+        want = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        net.load_state_dict(ref)
+        net.zero_grad()
+        model = cdist.DataParallel(net, large_numel=1 << 12)
+        assert model._active
+        nn.functional.cross_entropy(model(x), t).backward()
+        model.finish_gradient_sync()
+        model.sync_buffers()
+        torch.cuda.synchronize()
+        for n, p in net.named_parameters():
+            if n in want:
+                np.testing.assert_allclose(p.grad.cpu().numpy(), want[n].cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=n)
+    finally:
+        dist.destroy_process_group()
