@@ -35,7 +35,11 @@ class DataParallel(nn.Module):
         self._world = dist.get_world_size(process_group) if self._active else 1
         self._handles = []
         self._small = []
-        self._hooked = set()
+        # marks the Parameters this wrapper has hooked: an attribute on the Parameter itself, which dies with it.  (A set of
+        # id()s does not work: piggymasks are re-created between phases and CPython reuses the ids of the freed ones, so new
+        # Parameters looked "already hooked" and their gradients were silently left un-reduced.)
+        self._token = object()
+        self.sync_events = None          # list of (start, end) HIP events around finish_gradient_sync() when timing is on
         # RCCL averages inside the collective; gloo (CPU tests) has no AVG, there the sum is scaled afterwards
         self._avg = self._active and dist.get_backend(process_group) == 'nccl'
         if self._active and broadcast_init:
@@ -49,9 +53,9 @@ class DataParallel(nn.Module):
         if not self._active:
             return
         for p in self.module.parameters():
-            if p.requires_grad and id(p) not in self._hooked:
+            if p.requires_grad and getattr(p, '_cpg_dp_token', None) is not self._token:
                 p.register_post_accumulate_grad_hook(self._on_grad)
-                self._hooked.add(id(p))
+                p._cpg_dp_token = self._token
 
     refresh_hooks = _install_hooks
 
@@ -76,6 +80,10 @@ class DataParallel(nn.Module):
         backward() and before gradient routing / optimizer.step() (Manager.train does)."""
         if not self._active:
             return
+        ev = None
+        if self.sync_events is not None and torch.cuda.is_available():
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         inv = 1.0 / self._world
         if self._small:
             grads = [p.grad for p in self._small]
@@ -93,6 +101,9 @@ class DataParallel(nn.Module):
             if not self._avg:
                 g.mul_(inv)
         self._handles = []
+        if ev is not None:
+            ev[1].record()
+            self.sync_events.append(ev)
 
     def sync_parameters(self, src=0):
         """Make every rank start from rank `src`'s parameters and buffers."""
@@ -113,6 +124,16 @@ class DataParallel(nn.Module):
             dist.broadcast(flat, src=src, group=self.process_group)
             for b, f in zip(bufs, _unflatten_dense_tensors(flat, bufs)):
                 b.copy_(f)
+
+
+def seed_per_rank(base=1, process_group=None):
+    """Re-seed torch's generators with a rank-dependent seed AFTER the (identically seeded) model construction, so that
+    Dropout masks differ between ranks the way nn.DataParallel's replicas draw different masks.
+    Returns the seed used."""
+    rank = dist.get_rank(process_group) if dist.is_available() and dist.is_initialized() else 0
+    seed = int(base) + 7919 * rank
+    torch.manual_seed(seed)
+    return seed
 
 
 def shard_batch(data, target, rank=None, world=None):

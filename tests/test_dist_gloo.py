@@ -91,6 +91,62 @@ def test_gloo_world2_gradients_match_single_process(tmp_path):
         np.testing.assert_allclose(r0['grads'][n].numpy(), p.grad.numpy(), rtol=1e-4, atol=1e-6 * scale, err_msg=n)
 
 
+def _worker_piggymasks(rank, world, port, out_dir):
+    """The driver's phase pattern: piggymask Parameters are re-created (twice) after wrapping; refresh_hooks() must hook
+    every new one even though CPython hands the freed Parameters' ids to the new ones."""
+    import gc
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from cpg_amd import dist as cdist
+    from oracle import net as onet
+    torch.manual_seed(5)
+    net = onet.OracleVGG(0.0625, 'cifar100')
+    net.add_dataset('t1', 5)
+    net.set_dataset('t1')
+    model = cdist.DataParallel(net, large_numel=1 << 10)
+    model.eval()
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    for rnd in range(3):
+        for _, m in net.masked_layers():
+            m.piggymask = torch.nn.Parameter(torch.full(tuple(m.weight.shape), 0.01))       # frees the previous one
+        gc.collect()
+        model.refresh_hooks()
+        x = torch.randn(8, 3, 32, 32, generator=g)
+        t = torch.randint(0, 5, (8,), generator=g)
+        xs, ts = cdist.shard_batch(x, t)
+        net.zero_grad()
+        F.cross_entropy(model(xs), ts).backward()
+        model.finish_gradient_sync()
+        out[rnd] = {n: m.piggymask.grad.clone() for n, m in net.masked_layers()}
+    torch.save(out, os.path.join(out_dir, 'pm_rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_recreated_piggymasks_stay_hooked(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker_piggymasks, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'pm_rank0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'pm_rank1.pt'))
+    for rnd in r0:
+        assert len(r0[rnd]) == 15
+        for n in r0[rnd]:
+            assert float(r0[rnd][n].abs().max()) > 0, (rnd, n)
+            assert torch.equal(r0[rnd][n], r1[rnd][n]), 'round %d: piggymask gradient of %s was not all-reduced' % (rnd, n)
+
+
+def test_seed_per_rank_differs():
+    sys.path.insert(0, ROOT)
+    from cpg_amd import dist as cdist
+    assert cdist.seed_per_rank(1) == 1                       # no process group: rank 0
+    a = torch.rand(3)
+    cdist.seed_per_rank(1)
+    assert torch.equal(a, torch.rand(3))
+
+
 def test_shard_batch_and_inactive_wrapper():
     sys.path.insert(0, ROOT)
     from cpg_amd import dist as cdist
