@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- images/sec of one CPG train -> gradual-prune -> retrain cycle, VGG16-BN task 1.
 
-Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is
-launched by torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 it runs one rank per GPU
+over RCCL: either it is launched by `torch.distributed.run` (RANK / WORLD_SIZE in the environment), or -- started as a
+plain `python bench.py --gpus N` -- it re-launches ITSELF through `torch.distributed.run --nproc-per-node N`; in both
+cases it refuses to run when the world size is not N.  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[1]): `custom_vgg` (VGG16-BN, 224x224, Dropout),
-5-way head, fp32, batch 256 PER GPU (weak scaling; configs[2] is 2048 = 8 x 256), synthetic
-N(0,1) images / randint(0,5) labels already resident in HBM, weights from the reference's init at
-seed 1, wd 4e-5.  The K timed steps are one scaled CPG task-1 cycle:
+Workload (BASELINE.json configs[1]): `custom_vgg` (VGG16-BN, 224x224, Dropout), 5-way head,
+fp32, batch 256 PER GPU (weak scaling; configs[2] is 2048 = 8 x 256), synthetic N(0,1) images / randint(0,5) labels
+already resident in HBM, weights from the reference's init at seed 1 (Dropout streams re-seeded per rank), wd 4e-5.
 
-    epoch length E = max(1, K // 11)
-    phase A  "finetune": E steps, SGD-nesterov lr 1e-2, free slots claimed by task 1
-    phase B  "prune 0.0 -> 0.1": K - E steps, lr 1e-3, pruning window = first 2E steps of the phase,
-             rank-prune event every max(1, E // 2) steps inside the window, then fixed-mask recovery
-    validate (apply_mask + 2 eval batches of 100) after every E steps, mask statistics per step.
+The K timed steps are the section-8d cycle with a shape that does NOT depend on K:
 
-A "step" is one minibatch through the hot path (zero_grad, forward, loss, backward, gradient routing,
-SGD step, prune event when due, statistics); validates are inside the timed region.  value =
-global_batch * K / wall, wall = max over ranks of the barrier-bracketed timed region.
+    validate (apply_mask + 2 eval batches of 100)   after every 20th train step (20-step epochs: 1 validate per 20 steps)
+    phase A "finetune"                              the first A = max(1, round(K / 11)) steps, SGD-nesterov lr 1e-2
+    phase B "prune 0.0 -> 0.1" + recovery           the other K - A steps, lr 1e-3; pruning window = first 4 f steps of the
+                                                    phase, rank-prune event every f = max(1, A // 2) steps -> 4 events,
+                                                    then fixed-mask recovery
+    mask statistics                                 every train step and every validate batch (utils/manager.py:77-88,126-136)
+
+At the default K = 220 this is exactly section 8d: 20-step epochs, 1 finetune + 10 prune-run epochs, events at steps
+10/20/30/40 of the prune run, 11 validates.  At the driver's K = 20 it is the same cycle compressed 11 x: 2 finetune
+steps, 18 prune-run steps with events at steps 1-4, 1 validate -- the same validate : train ratio and the same number of
+prune events, so the images/sec figure is the same quantity.
+
+A "step" is one minibatch through the hot path (zero_grad, forward, loss, backward, gradient routing, SGD step, prune
+event when due, statistics); validates are inside the timed region.  value = global_batch * K / wall, wall = max over
+ranks of the barrier-bracketed timed region.
 """
 import argparse
 import json
@@ -115,17 +124,19 @@ class KernelClock:
 
 def pmc_traffic(family, batch):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE collected separately, gfx950 correction 2 x FETCH_SIZE + WRITE_SIZE; profiles/r01_traffic.json,
+    WRITE_SIZE collected separately, gfx950 correction 2 x FETCH_SIZE + WRITE_SIZE; profiles/r02_traffic.json (r01 when absent),
     measured at batch 256, average over the 13 convs of a VGG16 pass).  None when no measurement applies."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
-            fam = json.load(f)['families'].get(family)
-        if fam is None or batch != 256:
-            return None
-        return {'hbm_bytes_per_launch': round(fam['hbm_bytes_per_launch_corrected']),
-                'algorithmic_bytes_per_launch': round(fam['algorithmic_bytes_per_launch']), 'source': 'profiles/r01_traffic.json'}
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ('r02_traffic.json', 'r01_traffic.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                fam = json.load(f)['families'].get(family)
+            if fam is None or batch != 256:
+                return None
+            return {'hbm_bytes_per_launch': round(fam['hbm_bytes_per_launch_corrected']),
+                    'algorithmic_bytes_per_launch': round(fam['algorithmic_bytes_per_launch']), 'source': 'profiles/' + name}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def build_model(device):
@@ -143,11 +154,24 @@ def make_args(mode, freq, width=1.0):
                                  network_width_multiplier=width, cuda=True, log_path=None, progress=False)
 
 
-def run_cycle(model, masks, pool, val_pool, steps, clock=None, marks=None):
-    """The K-step scaled task-1 cycle.  Returns number of train steps executed.  `marks` collects (label, steps, event)
-    at the phase boundaries (events only -- no synchronisation inside the timed region)."""
-    E = max(1, steps // 11)
+EPOCH_STEPS = 20                     # 20-step epochs, validate after every epoch
+
+
+def cycle_plan(steps):
+    """(A, f): finetune steps and rank-prune frequency of the K-step cycle (module docstring)."""
+    A = min(steps, max(1, int(round(steps / 11.0))))
+    f = max(1, A // 2)
+    return A, f
+
+
+def run_cycle(model, masks, pool, val_pool, steps, clock=None, marks=None, counts=None):
+    """The K-step task-1 cycle.  Returns number of train steps executed.  `marks` collects (label, steps, event) at the
+    phase boundaries (events only -- no synchronisation inside the timed region); `counts` receives the number of
+    validates and rank-prune events that actually ran."""
+    A, f = cycle_plan(steps)
+    window = 4 * f
     done = 0
+    n_val = 0
 
     def mark(label, n=0):
         if marks is not None:
@@ -166,33 +190,54 @@ def run_cycle(model, masks, pool, val_pool, steps, clock=None, marks=None):
         o.add(opt, lr)
         return o
 
-    # phase A: finetune
-    nA = min(E, steps)
-    mgr = Manager(make_args('finetune', max(1, E // 2)), model, {}, masks, loader(nA, 0), val_pool, 0, 0)
+    def chunks(n_phase):
+        """split a phase's steps at the global every-20th-step validate points: yields (n_steps, validate_after)"""
+        left = n_phase
+        pos = done
+        while left > 0:
+            n = min(left, EPOCH_STEPS - pos % EPOCH_STEPS)
+            yield n, (pos + n) % EPOCH_STEPS == 0
+            pos += n
+            left -= n
+
+    # phase A: finetune (free slots claimed by task 1)
+    mgr = Manager(make_args('finetune', f), model, {}, masks, None, val_pool, 0, 0)
     mgr.pruner.make_finetuning_mask()
-    mgr.train(sgd(1e-2, mgr.pruner), 0, [1e-2], 0)
-    mark('finetune_train', nA)
-    mgr.validate(0)
-    mark('validate', 1)
-    done += nA
-    # phase B: prune 0.0 -> 0.1 then recovery at fixed mask
-    remaining = steps - done
-    step = 0
-    epoch = 1
-    if remaining > 0:
-        mgrB = Manager(make_args('prune', max(1, E // 2)), model, {}, masks, None, val_pool, 0, 2 * E)
-        opt = sgd(1e-3, mgrB.pruner)
-        while remaining > 0:
-            n = min(E, remaining)
-            mgrB.train_loader = loader(n, done)
-            in_window = step < 2 * E
-            _, step = mgrB.train(opt, epoch, [1e-3], step)
-            mark('prune_window_train' if in_window else 'recovery_train', n)
-            mgrB.validate(epoch)
+    opt = sgd(1e-2, mgr.pruner)
+    epoch = 0
+    for n, val in list(chunks(A)):
+        mgr.train_loader = loader(n, done)
+        mgr.train(opt, epoch, [1e-2], 0)
+        mark('finetune_train', n)
+        done += n
+        if val:
+            mgr.validate(epoch)
             mark('validate', 1)
-            done += n
-            remaining -= n
+            n_val += 1
             epoch += 1
+    # phase B: prune 0.0 -> 0.1 (4 rank-prune events inside the window), then recovery at the fixed mask
+    events = 0
+    if steps - done > 0:
+        mgrB = Manager(make_args('prune', f), model, {}, masks, None, val_pool, 0, window)
+        opt = sgd(1e-3, mgrB.pruner)
+        step = 0
+        for n, val in list(chunks(steps - done)):
+            # keep window and recovery steps in separate marks
+            parts = [n] if step >= window or step + n <= window else [window - step, n - (window - step)]
+            for m in parts:
+                mgrB.train_loader = loader(m, done)
+                in_window = step < window
+                _, step = mgrB.train(opt, epoch, [1e-3], step)
+                mark('prune_window_train' if in_window else 'recovery_train', m)
+                done += m
+            if val:
+                mgrB.validate(epoch)
+                mark('validate', 1)
+                n_val += 1
+                epoch += 1
+        events = mgrB.pruner.prune_events
+    if counts is not None:
+        counts.update(validates=n_val, prune_events=events, finetune_steps=A, prune_frequency=f, prune_window_steps=window)
     return done
 
 
@@ -223,17 +268,18 @@ def phase_report(marks, model, masks, batch):
     return rep
 
 
-def cpu_baseline(budget_s=18.0, steps=110, batch=256):
+def cpu_baseline(budget_s=15.0, steps=220, batch=256, validates=11, prune_events=4, cpu_batch=64):
     """Oracle ("port") of the same cycle on the host cores: a bounded sample of each ingredient -- train steps, one
-    rank-prune event over all 15 layers, one validate batch -- extrapolated to the cycle the GPU ran (K train steps of
-    `batch` images, 4 prune events, 11 validates of 2 x 100 images), reported beside the GPU number (never the target).
-    oracle/ is only ever used here as the measured CPU baseline.  Thread count is torch's default for the host (one per
-    physical core): forcing every hardware thread onto a small batch made oneDNN several times slower on the 2 x 64-core
-    GPU host."""
+    rank-prune event over all 15 layers, one validate batch -- extrapolated to the cycle the GPU ACTUALLY ran (K train
+    steps of `batch` images, the counted prune events and validates of 2 x 100 images), reported beside the GPU number
+    (never the target).  oracle/ is only ever used here as the measured CPU baseline.  Threads: torch's default for the
+    host (one per physical core); SURVEY 8d asks for os.cpu_count(), but forcing every SMT thread onto oneDNN measured
+    several times slower on the 2 x 64-core GPU host, so the faster setting is the one reported (both counts are in
+    `sample`)."""
     from oracle import net as onet
     from oracle import ops as oops
     threads = torch.get_num_threads()
-    b = 16
+    b = cpu_batch
     model, pruner, opt = onet.make_task1(1.0, 'imagenet', 'finetune', lr=1e-2, wd=4e-5)
     model.train()
     g = torch.Generator().manual_seed(1)
@@ -261,37 +307,59 @@ def cpu_baseline(budget_s=18.0, steps=110, batch=256):
     with torch.no_grad():
         model(x)
     val_s = time.time() - t0
-    E = max(1, steps // 11)
-    n_val = (steps + E - 1) // E
-    cycle_s = steps * batch / train_ips + 4 * prune_s + n_val * 200 * (val_s / b)
+    cycle_s = steps * batch / train_ips + prune_events * prune_s + validates * 200 * (val_s / b)
     return {'value': round(steps * batch / cycle_s, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
             'train_images_per_sec': round(train_ips, 3), 'prune_event_s': round(prune_s, 2), 'validate_images_per_sec': round(b / val_s, 2),
             'sample': '%d train steps (fwd + bwd + gradient routing + SGD-nesterov, %.1f s) + 1 rank-prune event over the 15 layers '
                       '(%.1f s) + 1 validate batch (apply_mask + eval forward, %.1f s) of the oracle VGG16-BN 224x224 at batch %d, '
-                      'torch-CPU fp32, %d threads; value = the %d-step cycle (4 prune events, %d validates of 200 images) '
-                      'extrapolated from these rates' % (n, dt, prune_s, val_s, b, threads, steps, n_val)}
+                      'torch-CPU fp32, %d threads (os.cpu_count() = %d); value = the %d-step cycle the GPU ran (%d prune events, '
+                      '%d validates of 200 images) extrapolated from these rates'
+                      % (n, dt, prune_s, val_s, b, threads, os.cpu_count() or 0, steps, prune_events, validates)}
+
+
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=110)
+    ap.add_argument('--steps', type=int, default=220, help='timed train steps (220 = the full section-8d cycle)')
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (config 2: 256)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-clock', action='store_true')
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
+        # started as a plain `python bench.py --gpus N`: become N ranks, one per GPU
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
+
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    if a.gpus > 1 or world > 1 or os.environ.get('CPG_DP_FORCE') == '1':
+    if world != a.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE is %d; launch with torch.distributed.run --nproc-per-node %d '
+                 '(or plain `python bench.py --gpus %d`, which re-launches itself)' % (a.gpus, world, a.gpus, a.gpus))
+    backend = None
+    if world > 1 or os.environ.get('CPG_DP_FORCE') == '1':
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        torch.cuda.set_device(local % torch.cuda.device_count())
+        ndev = torch.cuda.device_count()
         # 'nccl' is RCCL on ROCm.  CPG_BENCH_BACKEND=gloo lets several ranks share one GPU for a functional test
         # of the multi-process path on a single-GPU box (not a performance configuration).
-        dist.init_process_group(os.environ.get('CPG_BENCH_BACKEND', 'nccl'), rank=rank, world_size=world)
+        backend = os.environ.get('CPG_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl' and world > ndev:
+            sys.exit('bench.py: %d ranks but only %d GPUs visible (RCCL needs one GPU per rank)' % (world, ndev))
+        torch.cuda.set_device(local % ndev)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     device = torch.device('cuda', torch.cuda.current_device())
@@ -302,18 +370,20 @@ def main():
         proxy = clock.wrap(_lib.lib())
         _lib._lib = proxy                                  # route the Python mirror's calls through the timers
 
-    net = build_model(device)
+    net = build_model(device)                              # every rank: the reference's seed-1 initial weights
     model = cdist.DataParallel(net)
+    dropout_seed = cdist.seed_per_rank(1)                  # Dropout masks differ per rank, as nn.DataParallel's replicas' do
+    model.sync_events = [] if world > 1 else None
     masks = {n: torch.zeros(m.weight.shape, dtype=torch.uint8, device=device) for n, m in model.named_modules()
              if isinstance(m, (nl.SharableConv2d, nl.SharableLinear))}
 
-    g = torch.Generator(device=device).manual_seed(1 + rank)
+    g = torch.Generator(device=device).manual_seed(1 + rank)          # each rank its own shard of the global batch
     pool = [(torch.randn(a.batch, 3, 224, 224, generator=g, device=device),
              torch.randint(0, 5, (a.batch,), generator=g, device=device)) for _ in range(3)]
     val_pool = [(torch.randn(100, 3, 224, 224, generator=g, device=device),
                  torch.randint(0, 5, (100,), generator=g, device=device)) for _ in range(2)]
 
-    # warm-up: W untimed plain train steps (allocator, first-launch code loading)
+    # warm-up: W untimed plain train steps (allocator, first-launch code loading) + one validate (eval-mode kernels)
     if a.warmup > 0:
         wm = Manager(make_args('finetune', 1), model, {}, {k: v.clone() for k, v in masks.items()},
                      [pool[i % len(pool)] for i in range(a.warmup)], val_pool, 0, 0)
@@ -321,9 +391,12 @@ def main():
         opt = Optimizers()
         opt.add(torch.optim.SGD(model.parameters(), lr=0.0, momentum=0.9, nesterov=True), 0.0)
         wm.train(opt, 0, [0.0], 0)
+        wm.validate(0)                                    # (all slots owned by task 1: apply_mask changes nothing)
         for bn in model.modules():                        # lr = 0 keeps weights; also restore BN statistics
             if isinstance(bn, nn.BatchNorm2d):
                 bn.reset_running_stats()
+        if model.sync_events is not None:
+            model.sync_events = []
 
     def barrier():
         if world > 1:
@@ -333,45 +406,66 @@ def main():
     barrier()
     clock.enabled = True
     t0 = time.perf_counter()
-    marks = []
-    done = run_cycle(model, masks, pool, val_pool, a.steps, clock, marks)
+    marks, counts = [], {}
+    done = run_cycle(model, masks, pool, val_pool, a.steps, clock, marks, counts)
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = dt = time.perf_counter() - t0
     clock.enabled = False
     assert done == a.steps
+    per_rank_ms = [1000.0 * dt / a.steps]
     if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
+        tt = torch.zeros(world, device=device, dtype=torch.float64)
+        tt[rank] = dt_local
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(1000.0 * float(v) / a.steps, 3) for v in tt.tolist()]
+        dt = float(tt.max().item())
+        # replicated state must still be identical: compare a checksum of the weights and owner masks across ranks
+        chk = torch.stack([sum(p.detach().double().sum() for p in net.parameters()),
+                           sum(m.double().sum() for m in masks.values())])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo, hi))
     if rank == 0:
         global_batch = a.batch * world
         value = global_batch * a.steps / dt
+        A, f = cycle_plan(a.steps)
         out = {'metric': 'images/sec per CPG train-prune-retrain cycle, VGG16 task-1', 'value': round(value, 2),
                'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
                'ms_per_step': round(1000.0 * dt / a.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
                'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': 'configs[1]: VGG16-BN custom_vgg 224x224, task-1 CPG cycle (finetune -> prune 0.0->0.1 -> recovery, '
-                                      'validate each epoch), batch %d per GPU' % a.batch,
+                                      'validate after every 20th train step), batch %d per GPU' % a.batch,
                           'global_batch': global_batch, 'per_gpu_batch': a.batch, 'parallelism': 'dp%d' % world,
-                          'epoch_steps': max(1, a.steps // 11)},
+                          'epoch_steps': EPOCH_STEPS, 'cycle': counts},
                'frac_of_fp32_mfma_roofline_whole_step': round(value * FLOP_PER_IMG_TRAIN / world / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)}
+        if world > 1:
+            ev = model.sync_events or []
+            sync_ms = sum(s.elapsed_time(e) for s, e in ev)
+            out['multi_gpu'] = {'backend': 'rccl' if backend == 'nccl' else backend, 'rccl_ranks': world if backend == 'nccl' else 0,
+                                'per_rank_ms_per_step': per_rank_ms,
+                                'exposed_allreduce_ms_per_step': round(sync_ms / max(1, len(ev)), 3),
+                                'allreduced_gradient_bytes_per_step': int(sum(p.numel() for p in net.parameters() if p.requires_grad) * 4),
+                                'dropout_seed_rank0': dropout_seed, 'replicas_identical_after_cycle': replicas_identical}
         agg = clock.summary()
         if agg:
             tot_ms = sum(v[1] for v in agg.values())
             fam = {}
             for kind, (cnt, ms, fl) in agg.items():
-                f = fam.setdefault(kind.split(' ')[0], [0, 0.0, 0.0])
-                f[0] += cnt
-                f[1] += ms
-                f[2] += fl
+                fk = fam.setdefault(kind.split(' ')[0], [0, 0.0, 0.0])
+                fk[0] += cnt
+                fk[1] += ms
+                fk[2] += fl
             dom = max(fam, key=lambda k: fam[k][1])
             cnt, ms, fl = fam[dom]
             ach = fl / (ms * 1e-3) / 1e12
             traffic = pmc_traffic(dom, a.batch)
             out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                               'traffic': (traffic or {}).get('hbm_bytes_per_launch'), 'traffic_detail': traffic,
+                               'traffic': (traffic or {}).get('hbm_bytes_per_launch'),
+                               'traffic_source': 'static: %s (rocprofv3 --pmc passes of this workload, committed; not collected in this run)'
+                                                 % traffic['source'] if traffic else None,
+                               'traffic_detail': traffic,
                                'launches': cnt, 'avg_launch_ms': round(ms / cnt, 4),
                                'share_of_masked_kernel_time': round(ms / tot_ms, 3)}
             out['kernel_families'] = {k: {'launches': v[0], 'ms': round(v[1], 2), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
@@ -382,9 +476,11 @@ def main():
                                         for k, v in sorted(agg.items())}
         out['phases'] = phase_report(marks, model, masks, a.batch)
         if not a.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(steps=a.steps, batch=a.batch)
+            out['cpu_baseline'] = cpu_baseline(steps=a.steps, batch=a.batch, validates=counts['validates'],
+                                               prune_events=counts['prune_events'])
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -119,6 +119,8 @@ class MaskedAdam(torch.optim.Adam):
                 _lib.check('cpg_adam_route_step', rc)
                 held.append((p, p.grad))
                 p.grad = None
+        if held:
+            pr._pm_mutations += 1                # the kernel wrote through data_ptr(): tensor._version did not move
         loss = super().step(closure)
         for p, g in held:
             p.grad = g

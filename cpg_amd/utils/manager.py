@@ -8,8 +8,8 @@ as the reference does (utils/manager.py:105).
 
 What is not reproduced is the reference's per-step host stall: loss / accuracy accumulate on the
 device and the progress line (tqdm postfix with the mask statistics) is refreshed on a wall-clock
-interval instead of forcing `.item()` + 15 reductions + `.cpu()` every step.  Returned values are
-identical.  Checkpoint save / load (utils/manager.py:198-320) delegate to
+interval instead of forcing `.item()` + 15 reductions + `.cpu()` every step; the statistics themselves
+ARE evaluated every step / validation batch (one cached histogram pass).  Returned values are identical.  Checkpoint save / load (utils/manager.py:198-320) delegate to
 utils/checkpoint.py and keep the reference's file format; LFW evaluation (:156-195) needs real face pairs and
 sklearn and is out of scope.
 """
@@ -61,6 +61,7 @@ class Manager(object):
         self.train_loader = train_loader
         self.val_loader = val_loader
         self.progress = bool(getattr(args, 'progress', True)) and tqdm is not None
+        self.last_stats = {}
         self.postfix_interval = float(getattr(args, 'postfix_interval', 0.5))
         if args.dataset == 'face_verification':
             from ..models.spherenet import AngleLoss
@@ -106,13 +107,16 @@ class Manager(object):
                 if self.args.mode == 'prune':
                     self.pruner.gradually_prune(curr_prune_step)
                     curr_prune_step += 1
+                # the mask statistic of the progress line is computed EVERY step, as the reference does
+                # (utils/manager.py:77-88); it is one histogram pass that is cached until a mask mutates
+                self.last_stats = {'sparsity': self.pruner.calculate_sparsity()}
                 now = time.time()
                 if self.progress and (now - last_post >= self.postfix_interval or batch_idx + 1 == nbatches):
                     last_post = now
                     t.set_postfix({'loss': train_loss.avg.item(),
                                    'accuracy': '{:.2f}'.format(100. * train_accuracy.avg.item()),
                                    'lr': curr_lrs[0],
-                                   'sparsity': self.pruner.calculate_sparsity(),
+                                   'sparsity': self.last_stats['sparsity'],
                                    'network_width_mpl': self.args.network_width_multiplier})
                 t.update(1)
         summary = {'loss': '{:.3f}'.format(train_loss.avg.item()),
@@ -144,17 +148,20 @@ class Manager(object):
                     num = data.size(0)
                     val_loss.update(self.criterion(output, target), num)
                     val_accuracy.update(classification_accuracy(output, target), num)
+                    # statistics per validation batch, as the reference (utils/manager.py:126-136); cached histogram
+                    stats = {'sparsity': self.pruner.calculate_sparsity(),
+                             'task{} ratio'.format(idx): self.pruner.calculate_curr_task_ratio(),
+                             'zero ratio': self.pruner.calculate_zero_ratio()}
+                    if idx != 1:
+                        stats['shared_ratio'] = self.pruner.calculate_shared_part_ratio()
+                    self.last_stats = stats
                     now = time.time()
                     if self.progress and (now - last_post >= self.postfix_interval or bi + 1 == nbatches):
                         last_post = now
                         post = {'loss': val_loss.avg.item(),
-                                'accuracy': '{:.2f}'.format(100. * val_accuracy.avg.item()),
-                                'sparsity': self.pruner.calculate_sparsity(),
-                                'task{} ratio'.format(idx): self.pruner.calculate_curr_task_ratio(),
-                                'zero ratio': self.pruner.calculate_zero_ratio(),
-                                'mpl': self.args.network_width_multiplier}
-                        if idx != 1:
-                            post['shared_ratio'] = self.pruner.calculate_shared_part_ratio()
+                                'accuracy': '{:.2f}'.format(100. * val_accuracy.avg.item())}
+                        post.update(stats)
+                        post['mpl'] = self.args.network_width_multiplier
                         t.set_postfix(post)
                     t.update(1)
         summary = {'loss': '{:.3f}'.format(val_loss.avg.item()),

@@ -53,9 +53,11 @@ class SparsePruner(object):
         self.fused_weight_step = False   # set by utils.fused_sgd.MaskedSGD: it routes masked-weight grads itself
         self.fused_piggymask_step = False   # set by utils.fused_sgd.MaskedAdam: it routes piggymask grads itself
         self._mutations = 0          # bumped whenever a kernel of ours rewrites a mask in place
+        self._pm_mutations = 0       # bumped when a kernel of ours rewrites a piggymask through its raw pointer (MaskedAdam)
         self._hist_key = None
         self._hist = None
         self.last_prune_records = []
+        self.prune_events = 0        # rank-prune events executed (gradually_prune + one_shot_prune)
 
     # ------------------------------------------------------------------ helpers
     def _root(self):
@@ -100,6 +102,7 @@ class SparsePruner(object):
                                   ctypes.c_void_p(res[i].data_ptr()), _lib.dptr(ws), nbytes, s)
             _lib.check('cpg_rank_prune', rc)
         self._mutations += 1
+        self.prune_events += 1
         raw = res.cpu().numpy().tobytes()
         recs = []
         for i, (name, _) in enumerate(layers):
@@ -166,7 +169,7 @@ class SparsePruner(object):
     def _histogram(self, with_piggymask=False):
         """257-entry count vector over all masked layers: [#owner==id for id in 0..255] + [#picked]."""
         layers = list(self._layers())
-        key = (self._mutations, with_piggymask, self.inference_dataset_idx,
+        key = (self._mutations, self._pm_mutations if with_piggymask else 0, with_piggymask, self.inference_dataset_idx,
                tuple((id(self.masks[n]), self.masks[n]._version) for n, _ in layers),
                tuple((id(m.piggymask), m.piggymask._version) for _, m in layers if m.piggymask is not None)
                if with_piggymask else ())
