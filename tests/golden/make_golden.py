@@ -477,6 +477,166 @@ def gen_trajectory():
         save('trajectory_' + mode, **arrs)
 
 
+# --------------------------------------------------------------------------
+# 11. one_shot_prune (utils/prune.py:94-109)
+# --------------------------------------------------------------------------
+def gen_one_shot():
+    recs = {}
+    for i, (cur_name, ds, perc) in enumerate([('a', ['a'], 0.4), ('b', ['a', 'b', 'c'], 0.5)]):
+        w, o, *_ = rand_state(500 + i, ntasks=len(ds))
+        if len(ds) == 1:
+            o = {k: torch.ones_like(v) for k, v in o.items()}
+        pruner, model, masks = make_pruner('prune', ds, cur_name, o, w)
+        pruner.one_shot_prune(perc)
+        tag = 'case%d' % i
+        recs.update({tag + '_w_conv': w['conv'], tag + '_w_fc': w['fc'], tag + '_owner_conv': o['conv'], tag + '_owner_fc': o['fc'],
+                     tag + '_cur': np.asarray(pruner.current_dataset_idx), tag + '_perc': np.asarray(perc, dtype=np.float64),
+                     tag + '_mask_conv': pruner.masks['module.conv'], tag + '_mask_fc': pruner.masks['module.fc'],
+                     tag + '_wout_conv': model.module.conv.weight.data.clone(), tag + '_wout_fc': model.module.fc.weight.data.clone()})
+    save('one_shot_prune', **recs)
+
+
+# --------------------------------------------------------------------------
+# 12. the reference's OWN Manager.train / Manager.validate (utils/manager.py:39-152)
+# --------------------------------------------------------------------------
+def quant(t, q=16.0):
+    """inputs on a 1/q grid: still N(0,1)-shaped, but the .npz compresses"""
+    return torch.round(t * q) / q
+
+
+def gen_manager_trajectory():
+    """One epoch of Manager.train followed by Manager.validate, run by the reference's Manager itself (list loaders,
+    args.cuda = False) on a narrow VGG16-BN, in finetune and in prune mode.  Records everything a replay needs: initial
+    state, batches, per-step logits, returned accuracies, the full state + masks BEFORE validate (so the validate kernels
+    can be pinned from identical inputs), the state AFTER validate (apply_mask leaves the weights mutated) and the eval
+    logits."""
+    import torch.optim as optim
+    from utils.manager import Manager
+    width, B = 0.0625, 8
+    for mode in ('finetune', 'prune'):
+        net = build_ref('vgg_cifar100', width)
+        model = nn.DataParallel(net)
+        masks = {name: torch.zeros(mod.weight.shape, dtype=torch.uint8) for name, mod in model.named_modules()
+                 if isinstance(mod, (nl.SharableConv2d, nl.SharableLinear))}
+        lr = 1e-2 if mode == 'finetune' else 1e-3
+        args = types.SimpleNamespace(mode=mode, dataset='t1', finetune_again=False, target_sparsity=0.3, initial_sparsity=0.0,
+                                     pruning_frequency=2, weight_decay=4e-5, network_width_multiplier=width, cuda=False,
+                                     log_path=None)
+        g = torch.Generator().manual_seed(41)
+        nsteps = 5
+        xs = quant(torch.randn(nsteps, B, 3, 32, 32, generator=g))
+        ts = torch.randint(0, 5, (nsteps, B), generator=g)
+        xv = quant(torch.randn(2, 6, 3, 32, 32, generator=g))
+        tv = torch.randint(0, 5, (2, 6), generator=g)
+        mgr = Manager(args, model, {}, masks, [(xs[i], ts[i]) for i in range(nsteps)], [(xv[i], tv[i]) for i in range(2)], 0, 4)
+        if mode == 'finetune':
+            mgr.pruner.make_finetuning_mask()
+        else:
+            for k in masks:
+                masks[k].fill_(1)
+        init_state = {k: v.clone() for k, v in net.state_dict().items()}
+        optimizers = Optimizers()
+        optimizers.add(optim.SGD(list(model.parameters()), lr=lr, weight_decay=0.0, momentum=0.9, nesterov=True), lr)
+        outs = []
+        h = model.register_forward_hook(lambda m, i, o: outs.append(o.detach().clone()))
+        train_acc, step = mgr.train(optimizers, 0, [lr], 0)
+        pre = {k: v.clone() for k, v in net.state_dict().items()}
+        pre_masks = {k: v.clone() for k, v in mgr.pruner.masks.items()}
+        val_acc = mgr.validate(0)
+        h.remove()
+        arrs = dict(width=width, lr=lr, freq=2, begin=0, end=4, target=0.3, initial=0.0, wd=4e-5, x=xs, t=ts, xv=xv, tv=tv,
+                    logits=torch.stack(outs[:nsteps]), eval_logits=torch.stack(outs[nsteps:]), train_acc=train_acc, val_acc=val_acc,
+                    prune_step=step, sparsity=mgr.pruner.calculate_sparsity(), zero_ratio=mgr.pruner.calculate_zero_ratio(),
+                    curr_task_ratio=mgr.pruner.calculate_curr_task_ratio())
+        for k, v in init_state.items():
+            arrs['init/' + k] = v
+        for k, v in pre.items():
+            arrs['pre/' + k] = v
+        for k, v in net.state_dict().items():
+            if k.endswith('weight') and v.dim() >= 2 and 'classifier' not in k:
+                arrs['post/' + k] = v
+        for k, v in pre_masks.items():
+            arrs['mask/' + k] = v
+        save('manager_' + mode, **arrs)
+
+
+# --------------------------------------------------------------------------
+# 13. train-mode steps of configs 4 / 5: narrow ResNet-50 and SphereNet-20 + AngleLinear head + AngleLoss
+# --------------------------------------------------------------------------
+def reinit_resnet(net, seed):
+    """The reference initialises ResNet convs with N(0, 0.001) (models/resnet.py:150-152; meant for loading ImageNet weights
+    over it): with batch statistics over a handful of samples that puts var(y) next to BatchNorm's eps.  The train-step
+    fixture uses a well-conditioned He init instead -- drawn HERE with a fixed seed in module order, and re-drawn the same
+    way by the test (checked against `param_digest`)."""
+    torch.manual_seed(seed)
+    for m in net.modules():
+        if isinstance(m, nl.SharableConv2d):
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+
+def gen_net_train_steps():
+    import torch.optim as optim
+    from models import AngleLoss
+    cases = [('resnet50', 0.25, (4, 3, 64, 64), 't1', 5), ('spherenet20', 0.25, (4, 3, 112, 112), 'face_verification', 10)]
+    for arch, width, shape, dataset, ncls in cases:
+        net = build_ref(arch, width, num_classes=ncls, dataset=dataset)
+        if arch == 'resnet50':
+            reinit_resnet(net, 2)
+        model = nn.DataParallel(net)
+        masks = {name: torch.ones(mod.weight.shape, dtype=torch.uint8) for name, mod in model.named_modules()
+                 if isinstance(mod, (nl.SharableConv2d, nl.SharableLinear))}
+        args = types.SimpleNamespace(mode='prune', dataset=dataset, finetune_again=False, target_sparsity=0.3, initial_sparsity=0.0,
+                                     pruning_frequency=1, weight_decay=4e-5, network_width_multiplier=width)
+        pruner = SparsePruner(model, masks, args, 0, 2, 1)
+        digest = np.array([[float(p.double().sum()), float(p.double().abs().sum())] for p in net.parameters()])
+        lr = 1e-3
+        opt = optim.SGD(list(model.parameters()), lr=lr, weight_decay=0.0, momentum=0.9, nesterov=True)
+        crit = AngleLoss() if dataset == 'face_verification' else nn.CrossEntropyLoss()
+        g = torch.Generator().manual_seed(17)
+        steps = 3
+        xs = quant(torch.randn(steps, *shape, generator=g))
+        ts = torch.randint(0, ncls, (steps, shape[0]), generator=g)
+        names = [n for n, m in net.named_modules() if isinstance(m, nl.SharableConv2d)]
+        watch = [names[0], names[1], names[len(names) // 2], names[-1]]         # stem, first body conv, a middle one, the last
+        model.train()
+        rec = {'logits': [], 'logits2': [], 'losses': [], 'ratios': []}
+        grads = {n: [] for n in watch}
+        extra = {}
+        for s in range(steps):
+            opt.zero_grad()
+            out = model(xs[s])
+            loss = crit(out, ts[s])
+            loss.backward()
+            mods = dict(net.named_modules())
+            for n in watch:
+                grads[n].append(mods[n].weight.grad.detach().clone())      # raw autograd gradient (before routing)
+            if s == 0:
+                for n, p in net.named_parameters():
+                    if p.grad is not None and p.dim() == 1 and p.numel() <= 512 and len(extra) < 6:
+                        extra['g0/' + n] = p.grad.detach().clone()           # BN affine / bias / PReLU slope gradients
+            pruner.do_weight_decay_and_make_grads_zero()
+            opt.step()
+            rec['ratios'].append(pruner.gradually_prune(s))
+            if isinstance(out, tuple):
+                rec['logits'].append(out[0].detach().clone())
+                rec['logits2'].append(out[1].detach().clone())
+            else:
+                rec['logits'].append(out.detach().clone())
+            rec['losses'].append(float(loss))
+        arrs = dict(width=width, lr=lr, wd=4e-5, num_classes=ncls, x=xs, t=ts, param_digest=digest,
+                    logits=torch.stack(rec['logits']), losses=np.array(rec['losses']), ratios=np.array(rec['ratios'], dtype=np.float64),
+                    sparsity=pruner.calculate_sparsity(), watch=np.array(watch))
+        if rec['logits2']:
+            arrs['logits2'] = torch.stack(rec['logits2'])
+        for n in watch:
+            arrs['grad/' + n] = torch.stack(grads[n])
+            arrs['final/' + n] = dict(net.named_modules())[n].weight.detach().clone()
+            arrs['mask/module.' + n] = pruner.masks['module.' + n]
+        arrs['mask_zero_counts'] = np.array([int((pruner.masks['module.' + n] == 0).sum()) for n in names])
+        arrs.update(extra)
+        save('train_steps_' + arch, **arrs)
+
+
 def gen_angle():
     """A-Softmax head of config 5 (models/spherenet.py:24-98): AngleLinear output pair and AngleLoss over 3 calls
     (the loss is stateful: lambda anneals with the call count)."""
@@ -528,6 +688,14 @@ def gen_checkpoint():
 
 
 if __name__ == '__main__':
+    only = sys.argv[1:]
+    if only:                                  # regenerate selected fixtures: python make_golden.py gen_one_shot ...
+        for fn in only:
+            globals()[fn]()
+        sys.exit(0)
+    gen_one_shot()
+    gen_manager_trajectory()
+    gen_net_train_steps()
     gen_checkpoint()
     gen_angle()
     gen_binarizer()

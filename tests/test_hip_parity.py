@@ -164,7 +164,10 @@ def test_conv_oracle(N, C, H, W, K, k, s, p, bias, pm):
 
 
 @pytest.mark.parametrize('B,I,O,pm', [(32, 25088, 512, False), (256, 4096, 4096, True), (7, 513, 129, True), (1, 64, 5, False),
-                                      (256, 4096, 4096, False), (100, 1024, 256, False), (48, 260, 384, False)])
+                                      (256, 4096, 4096, False), (100, 1024, 256, False), (48, 260, 384, False),
+                                      # features.45 of config 2 at its own shape (89 % of all masked weights), both mask modes,
+                                      # and at the per-GPU batch of the 8-GPU reference configuration / the validate batch
+                                      (256, 25088, 4096, False), (256, 25088, 4096, True), (32, 25088, 4096, True), (100, 25088, 4096, False)])
 def test_linear_oracle(B, I, O, pm):
     g = torch.Generator().manual_seed(B + I + O)
     x = torch.randn(B, I, generator=g)
@@ -289,6 +292,22 @@ def test_rank_prune_oracle_random(n, cur, ratio, zero_frac):
     od = owner.to(DEV)
     pruner._pruning_mask(w.to(DEV), od, 'rand', ratio)
     np.testing.assert_array_equal(od.cpu().numpy(), want)
+
+
+def test_one_shot_prune_golden():
+    """SparsePruner.one_shot_prune (utils/prune.py:94-109): masks bit-exact, released weights zeroed, others untouched."""
+    g = load_golden('one_shot_prune')
+    for i, (cur_name, ds) in enumerate([('a', ['a']), ('b', ['a', 'b', 'c'])]):
+        t = 'case%d_' % i
+        w = {'conv': g[t + 'w_conv'], 'fc': g[t + 'w_fc']}
+        o = {'conv': g[t + 'owner_conv'], 'fc': g[t + 'owner_fc']}
+        pruner, model, masks = make_pruner('prune', ds, cur_name, o, w)
+        assert pruner.current_dataset_idx == int(g[t + 'cur'])
+        pruner.one_shot_prune(float(g[t + 'perc']))
+        for layer, mod in (('conv', model.module.conv), ('fc', model.module.fc)):
+            np.testing.assert_array_equal(pruner.masks['module.' + layer].cpu().numpy(), g[t + 'mask_' + layer], err_msg=layer)
+            np.testing.assert_array_equal(mod.weight.detach().cpu().numpy(), g[t + 'wout_' + layer], err_msg=layer)
+        assert pruner.prune_events == 1
 
 
 def test_stats_and_mask_ops_golden():
@@ -449,6 +468,7 @@ def test_trajectory_golden(mode):
     crit = nn.CrossEntropyLoss()
     xs, ts = T(g['x']), torch.from_numpy(g['t']).to(DEV)
     model.train()
+    drift = 0.0
     for s in range(xs.shape[0]):
         optimizers.zero_grad()
         out = model(xs[s])
@@ -458,7 +478,14 @@ def test_trajectory_golden(mode):
         optimizers.step()
         if mode == 'prune':
             assert pruner.gradually_prune(s) == g['ratios'][s]
-        close(out, g['logits'][s], rtol=1e-3, atol=2e-6, msg='logits step %d' % s)
+        # step 0 runs on bit-identical weights: north_star's 1e-4.  Later steps compare two TRAINING RUNS (GPU vs CPU
+        # round-off fed back through 12 SGD steps of a BatchNorm net), so they get a drift allowance, reported below.
+        sc = float(np.abs(g['logits'][s]).max())
+        if s == 0:
+            close(out, g['logits'][s], rtol=1e-4, atol=1e-4 * sc, msg='logits step 0')
+        else:
+            close(out, g['logits'][s], rtol=1e-3, atol=1e-4 * sc, msg='logits step %d (drift)' % s)
+        drift = max(drift, float(np.abs(out.detach().cpu().numpy() - g['logits'][s]).max()) / sc)
         assert abs(float(loss) - g['losses'][s]) < 1e-5
         assert abs(pruner.calculate_sparsity() - g['sparsities'][s]) < 2e-4, s
     mism = sum(int((masks[n].cpu().numpy() != g['mask/' + n]).sum()) for n in masks)
@@ -468,7 +495,154 @@ def test_trajectory_golden(mode):
     model.eval()
     with torch.no_grad():
         ev = model(xs[0])
-    close(ev, g['eval_logits'], rtol=1e-3, atol=2e-6, msg='eval logits')
+    close(ev, g['eval_logits'], rtol=1e-3, atol=1e-4 * float(np.abs(g['eval_logits']).max()), msg='eval logits after 12 steps (drift)')
+    print('trajectory_%s: max logit drift over 12 steps %.2e of the logit scale' % (mode, drift))
+
+
+# --------------------------------------------------------------------------- the reference's own Manager.train / validate
+@pytest.mark.parametrize('mode', ['finetune', 'prune'])
+def test_manager_train_validate_golden(mode):
+    """cpg_amd's Manager.train + Manager.validate against a fixture produced by the REFERENCE'S OWN Manager
+    (utils/manager.py:39-152, list loaders): per-step logits, returned accuracies, owner masks, the weights validate()
+    leaves behind (apply_mask is destructive) and the eval logits.  validate() is also run from the reference's exact
+    pre-validate state, so its kernels are pinned at north_star's 1e-4 on identical inputs."""
+    from cpg_amd.utils.manager import Manager
+    g = load_golden('manager_' + mode)
+    width = float(g['width'])
+    net = build('vgg_cifar100', width)
+    sd = net.state_dict()
+    for k in sd:
+        np.testing.assert_array_equal(sd[k].numpy(), g['init/' + k], err_msg=k)          # seed-1 init parity
+    net = net.to(DEV)
+    model = Wrap(net)
+    masks = {n: torch.zeros(m.weight.shape, dtype=torch.uint8, device=DEV) for n, m in model.named_modules()
+             if isinstance(m, (nl.SharableConv2d, nl.SharableLinear))}
+    args = types.SimpleNamespace(mode=mode, dataset='t1', finetune_again=False, target_sparsity=float(g['target']),
+                                 initial_sparsity=float(g['initial']), pruning_frequency=int(g['freq']), weight_decay=float(g['wd']),
+                                 network_width_multiplier=width, cuda=True, log_path=None, progress=False)
+    xs, ts = T(g['x']), torch.from_numpy(g['t']).to(DEV)
+    xv, tv = T(g['xv']), torch.from_numpy(g['tv']).to(DEV)
+    mgr = Manager(args, model, {}, masks, [(xs[i], ts[i]) for i in range(xs.shape[0])], [(xv[i], tv[i]) for i in range(xv.shape[0])],
+                  int(g['begin']), int(g['end']))
+    if mode == 'finetune':
+        mgr.pruner.make_finetuning_mask()
+    else:
+        for k in masks:
+            masks[k].fill_(1)
+    lr = float(g['lr'])
+    optimizers = Optimizers()
+    optimizers.add(torch.optim.SGD(list(model.parameters()), lr=lr, weight_decay=0.0, momentum=0.9, nesterov=True), lr)
+    outs = []
+    h = model.register_forward_hook(lambda m, i, o: outs.append(o.detach().cpu().numpy()))
+    train_acc, step = mgr.train(optimizers, 0, [lr], 0)
+    assert step == int(g['prune_step'])
+    assert abs(train_acc - float(g['train_acc'])) < 1e-6
+    sc = float(np.abs(g['logits']).max())
+    close(outs[0], g['logits'][0], rtol=1e-4, atol=1e-4 * sc, msg='train logits step 0')
+    for k in range(1, xs.shape[0]):
+        close(outs[k], g['logits'][k], rtol=1e-3, atol=1e-4 * sc, msg='train logits step %d (drift)' % k)
+    mism = sum(int((mgr.pruner.masks[n].cpu().numpy() != g['mask/' + n]).sum()) for n in masks)
+    assert mism <= 1e-4 * sum(v.numel() for v in masks.values()), mism
+    for n, m in model.named_modules():                      # weights-before-validate: the trained state itself
+        if isinstance(m, (nl.SharableConv2d, nl.SharableLinear)):
+            ref = g['pre/' + n[len('module.'):] + '.weight']
+            close(m.weight, ref, rtol=1e-3, atol=1e-5 * float(np.abs(ref).max()), msg='weights after train ' + n)
+    # ---- validate, run for real, from the run's own state
+    del outs[:]
+    val_acc = mgr.validate(0)
+    close(np.stack(outs), g['eval_logits'], rtol=1e-3, atol=1e-4 * float(np.abs(g['eval_logits']).max()), msg='eval logits (own state)')
+    # ---- validate from the reference's exact pre-validate state: identical inputs -> 1e-4, zero pattern bit-exact
+    net.load_state_dict({k: torch.from_numpy(g['pre/' + k]) for k in sd}, strict=True)
+    for n in masks:
+        mgr.pruner.masks[n].copy_(T(g['mask/' + n], torch.uint8))
+    mgr.pruner._mutations += 1                                # masks were rewritten behind the pruner's back
+    del outs[:]
+    val_acc = mgr.validate(0)
+    h.remove()
+    for n, m in model.named_modules():
+        if isinstance(m, (nl.SharableConv2d, nl.SharableLinear)):
+            np.testing.assert_array_equal(m.weight.detach().cpu().numpy(), g['post/' + n[len('module.'):] + '.weight'],
+                                          err_msg='weights after validate ' + n)
+    esc = float(np.abs(g['eval_logits']).max())
+    close(np.stack(outs), g['eval_logits'], rtol=1e-4, atol=1e-4 * esc, msg='eval logits (reference state)')
+    assert abs(val_acc - float(g['val_acc'])) < 1e-6
+    assert mgr.pruner.calculate_sparsity() == float(g['sparsity'])
+    assert mgr.pruner.calculate_zero_ratio() == float(g['zero_ratio'])
+    assert mgr.pruner.calculate_curr_task_ratio() == float(g['curr_task_ratio'])
+    assert not model.training                                   # validate leaves the model in eval mode, as the reference
+
+
+# --------------------------------------------------------------------------- configs 4 / 5: train-mode steps vs the reference
+@pytest.mark.parametrize('arch', ['resnet50', 'spherenet20'])
+def test_train_steps_golden(arch):
+    """Three TRAIN-mode steps (forward, loss, backward, gradient routing, SGD-nesterov, rank-prune event) of a narrow
+    ResNet-50 and of SphereNet-20 with the AngleLinear head + AngleLoss, against a fixture produced by the reference's
+    modules on CPU: step-0 logits and raw weight gradients at 1e-4 of their scale (identical weights), later steps with a
+    drift allowance, losses, prune ratios, final masks (<= 1e-4 of the slots may flip at a cutoff) and sparsity."""
+    from cpg_amd.models.spherenet import AngleLoss
+    g = load_golden('train_steps_' + arch)
+    width, ncls = float(g['width']), int(g['num_classes'])
+    dataset = 'face_verification' if arch == 'spherenet20' else 't1'
+    torch.manual_seed(1)
+    kw = dict(dataset_history=[], dataset2num_classes={}, network_width_multiplier=width, shared_layer_info={})
+    net = M.resnet50(**kw) if arch == 'resnet50' else M.spherenet20(**kw)
+    net.add_dataset(dataset, ncls)
+    net.set_dataset(dataset)
+    if arch == 'resnet50':
+        # the fixture's documented well-conditioned init: He-normal drawn at seed 2 in module order (make_golden.reinit_resnet)
+        torch.manual_seed(2)
+        for m in net.modules():
+            if isinstance(m, nl.SharableConv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+    digest = np.array([[float(p.double().sum()), float(p.double().abs().sum())] for p in net.parameters()])
+    np.testing.assert_allclose(digest, g['param_digest'], rtol=1e-12, atol=1e-12)          # same initial weights as the reference run
+    net = net.to(DEV)
+    model = Wrap(net)
+    masks = {n: torch.ones(m.weight.shape, dtype=torch.uint8, device=DEV) for n, m in model.named_modules()
+             if isinstance(m, (nl.SharableConv2d, nl.SharableLinear))}
+    args = types.SimpleNamespace(mode='prune', dataset=dataset, finetune_again=False, target_sparsity=0.3, initial_sparsity=0.0,
+                                 pruning_frequency=1, weight_decay=float(g['wd']), network_width_multiplier=width)
+    pruner = SparsePruner(model, masks, args, 0, 2, 1)
+    opt = torch.optim.SGD(list(model.parameters()), lr=float(g['lr']), weight_decay=0.0, momentum=0.9, nesterov=True)
+    crit = AngleLoss() if dataset == 'face_verification' else nn.CrossEntropyLoss()
+    xs, ts = T(g['x']), torch.from_numpy(g['t']).to(DEV)
+    watch = [str(w) for w in g['watch']]
+    mods = dict(net.named_modules())
+    model.train()
+    for s in range(xs.shape[0]):
+        opt.zero_grad()
+        out = model(xs[s])
+        loss = crit(out, ts[s])
+        loss.backward()
+        rt = 1e-4 if s == 0 else 2e-3                        # step 0: identical weights; later: two training runs drift apart
+        o1 = out[0] if isinstance(out, tuple) else out
+        sc = float(np.abs(g['logits'][s]).max())
+        close(o1, g['logits'][s], rtol=rt, atol=rt * sc, msg='%s logits step %d' % (arch, s))
+        if isinstance(out, tuple):
+            close(out[1], g['logits2'][s], rtol=rt, atol=rt * float(np.abs(g['logits2'][s]).max()), msg='phi(theta) step %d' % s)
+        assert abs(float(loss) - g['losses'][s]) <= rt * max(1.0, abs(g['losses'][s])), (s, float(loss), g['losses'][s])
+        for n in watch:
+            ref = g['grad/' + n][s]
+            close(mods[n].weight.grad, ref, rtol=10 * rt, atol=rt * float(np.abs(ref).max()), msg='%s grad %s step %d' % (arch, n, s))
+        if s == 0:
+            for key in [k for k in g.files if k.startswith('g0/')]:
+                p = dict(net.named_parameters())[key[3:]]
+                close(p.grad, g[key], rtol=1e-3, atol=1e-4 * float(np.abs(g[key]).max()) + 1e-9, msg=key)
+        pruner.do_weight_decay_and_make_grads_zero()
+        opt.step()
+        assert pruner.gradually_prune(s) == g['ratios'][s]
+    names = [n for n, m in net.named_modules() if isinstance(m, nl.SharableConv2d)]
+    zero_counts = np.array([int((masks['module.' + n] == 0).sum()) for n in names])
+    # k = round(ratio * n) per layer is exact; the count of released slots can move by a slot where a weight released by the
+    # first event sits exactly at the second event's cutoff in one run and not in the other (momentum keeps moving it)
+    numel = np.array([masks['module.' + n].numel() for n in names])
+    assert np.all(np.abs(zero_counts - g['mask_zero_counts']) <= np.maximum(1, 1e-3 * numel)), (zero_counts, g['mask_zero_counts'])
+    for n in watch:
+        mism = int((masks['module.' + n].cpu().numpy() != g['mask/module.' + n]).sum())
+        assert mism <= max(2, 1e-3 * masks['module.' + n].numel()), (n, mism)
+        ref = g['final/' + n]
+        close(mods[n].weight, ref, rtol=2e-3, atol=1e-5 * float(np.abs(ref).max()), msg='final weights ' + n)
+    assert abs(pruner.calculate_sparsity() - float(g['sparsity'])) < 1e-6
 
 
 # --------------------------------------------------------------------------- full-size properties
@@ -570,6 +744,53 @@ def test_conv_full_size_properties(C, K, H):
         tol = 1e-4 * abs(want) + 1e-5 * float(layer.weight.grad.abs().max())
         assert abs(float(layer.weight.grad[k, c, r, t]) - want * b) <= tol
         assert abs(float(layer.piggymask.grad[k, c, r, t]) - want * float(w[k, c, r, t])) <= tol + 1e-4 * abs(want * float(w[k, c, r, t]))
+
+
+@pytest.mark.parametrize('B,I,O', [(256, 25088, 4096), (256, 4096, 4096)])
+@pytest.mark.parametrize('pm_on', [False, True])
+def test_linear_full_size_properties(B, I, O, pm_on):
+    """The two masked FC layers of config 2 at full size, with and without a piggymask: adjoint identities tie
+    fwd / dgrad / wgrad to one another and sampled entries are recomputed from the definition in fp64."""
+    g = torch.Generator(device=DEV).manual_seed(B + I + O + int(pm_on))
+    x = torch.randn(B, I, generator=g, device=DEV)
+    w = torch.randn(O, I, generator=g, device=DEV) * I ** -0.5
+    b = torch.randn(O, generator=g, device=DEV) * 0.1
+    pm = torch.rand(O, I, generator=g, device=DEV) * 0.012 if pm_on else None
+    layer = nl.SharableLinear(I, O).to(DEV)
+    layer.weight.data.copy_(w)
+    layer.bias.data.copy_(b)
+    if pm_on:
+        layer.piggymask = nn.Parameter(pm.clone())
+    xd = x.clone().requires_grad_(True)
+    y = layer(xd)
+    gy = torch.randn(B, O, generator=g, device=DEV)
+    y.backward(gy)
+    keep = (pm > 5e-3).float() if pm_on else torch.ones_like(w)
+
+    def dot(a, c):
+        return float((a.double() * c.double()).sum())
+    lhs = dot(y.detach() - b, gy)                                        # bias-free part of <y, gy>
+    scale = float((y.detach() - b).double().norm() * gy.double().norm())
+    assert abs(lhs - dot(x, xd.grad)) <= 1e-6 * scale                    # fwd vs dgrad
+    assert abs(lhs - dot(w, layer.weight.grad)) <= 1e-6 * scale          # fwd vs wgrad  (<W, gW> = <W_eff, gW_eff>)
+    np.testing.assert_allclose(layer.bias.grad.cpu().numpy(), gy.double().sum(0).cpu().numpy(), rtol=1e-4, atol=1e-4)
+    rs = np.random.RandomState(I + O)
+    wd, xdbl, gyd = (w * keep).double(), x.double(), gy.double()
+    for _ in range(32):
+        n, o, i = rs.randint(B), rs.randint(O), rs.randint(I)
+        want = float((xdbl[n] * wd[o]).sum() + b[o].double())
+        assert abs(float(y.detach()[n, o]) - want) <= 1e-4 * abs(want) + 2e-5
+        want = float((gyd[n] * wd[:, i]).sum())
+        assert abs(float(xd.grad[n, i]) - want) <= 1e-4 * abs(want) + 2e-5
+        want = float((gyd[:, o] * xdbl[:, i]).sum())
+        tol = 1e-4 * abs(want) + 1e-5 * float(layer.weight.grad.abs().max())
+        assert abs(float(layer.weight.grad[o, i]) - want * float(keep[o, i])) <= tol
+        if pm_on:
+            assert abs(float(layer.piggymask.grad[o, i]) - want * float(w[o, i])) <= tol * (abs(float(w[o, i])) + 1e-3) + 1e-7
+    if pm_on:
+        # the whole mask pattern of gW (bit-exact): zero exactly where the binarised piggymask is zero
+        assert torch.equal(layer.weight.grad == 0, (keep == 0) | (layer.weight.grad == 0))
+        assert int(((layer.weight.grad != 0) & (keep == 0)).sum()) == 0
 
 
 # --------------------------------------------------------------------------- fused BatchNorm -> ReLU (SURVEY 8f.2)
@@ -1040,8 +1261,24 @@ def test_two_task_sequence_matches_oracle():
     mism = sum(int((sess.masks['module.' + n].cpu().numpy() != rp2.owners[n]).sum()) for n, _ in ref.masked_layers())
     assert mism <= 1e-4 * sum(v.numel() for v in sess.masks.values()), mism
     assert abs(mgr.pruner.calculate_sparsity() - rp2.sparsity()) < 2e-4
-    mgr.validate(0) if False else mgr.pruner.apply_mask()
+    # validate for real (apply_mask + eval forward over a 2-batch loader), against the oracle doing the same
+    vals = [(x.to(DEV), t.to(DEV)) for x, t in batches[0:2]]
+    mgr.val_loader = vals
+    ev = []
+    h = sess.model.register_forward_hook(lambda m, i, o: ev.append(o.detach().cpu().numpy()))
+    acc = mgr.validate(0)
+    h.remove()
     rp2.apply_mask()
+    ref.eval()
+    with torch.no_grad():
+        rev = [ref(x).numpy() for x, _ in batches[0:2]]
+    ref.train()
+    compare('t1 validate', ev, rev)
+    racc = float(np.mean([(r.argmax(1) == t.numpy()).mean() for r, (_, t) in zip(rev, batches[0:2])]))
+    assert abs(acc - racc) < 1e-6
+    for n, m in ref.masked_layers():                       # validate left the weights masked, exactly where the oracle's are
+        hw = dict(sess.net.named_modules())[n].weight.detach().cpu().numpy()
+        np.testing.assert_array_equal(hw == 0, m.weight.detach().numpy() == 0, err_msg=n)
 
     # ================= task 2: piggymask finetune (3 steps) ==================================================
     sess.start_task('t2', 5)

@@ -166,3 +166,52 @@ def test_oracle_trajectory_matches_reference(mode):
     with torch.no_grad():
         ev = model(xs[0]).numpy()
     np.testing.assert_allclose(ev, g['eval_logits'], rtol=1e-4, atol=1e-6)
+
+
+def test_one_shot_prune_matches_reference():
+    """utils/prune.py:94-109: rank prune at a fixed ratio, then zero the released weights."""
+    g = load_golden('one_shot_prune')
+    for i in range(2):
+        t = 'case%d_' % i
+        for layer in ('conv', 'fc'):
+            out, _, _ = ops.rank_prune(g[t + 'w_' + layer], g[t + 'owner_' + layer], int(g[t + 'cur']), float(g[t + 'perc']))
+            np.testing.assert_array_equal(out, g[t + 'mask_' + layer])
+            np.testing.assert_array_equal(ops.zero_pruned(g[t + 'w_' + layer], out), g[t + 'wout_' + layer])
+
+
+@pytest.mark.parametrize('mode', ['finetune', 'prune'])
+def test_oracle_matches_reference_manager_train_and_validate(mode):
+    """The fixture was produced by the reference's OWN Manager.train + Manager.validate (utils/manager.py:39-152); the
+    oracle's step order, its validate (apply_mask first, weights left mutated) and the returned accuracies must agree."""
+    g = load_golden('manager_' + mode)
+    model, pruner, opt = onet.make_task1(float(g['width']), 'cifar100', mode, lr=float(g['lr']), begin=int(g['begin']),
+                                         end=int(g['end']), frequency=int(g['freq']), initial=float(g['initial']),
+                                         target=float(g['target']), wd=float(g['wd']))
+    sd = model.state_dict()
+    for k in sd:
+        if sd[k].dtype.is_floating_point:
+            np.testing.assert_array_equal(sd[k].numpy(), g['init/' + k.replace('head.', 'classifier.')], err_msg=k)
+    model.train()
+    xs, ts = torch.from_numpy(g['x']), torch.from_numpy(g['t'])
+    correct = 0
+    for s in range(xs.shape[0]):
+        out, loss, ratio = onet.train_step(model, pruner, opt, xs[s], ts[s], prune_step=s)
+        np.testing.assert_allclose(out.numpy(), g['logits'][s], rtol=1e-4, atol=1e-6, err_msg='step %d' % s)
+        correct += int((out.argmax(1) == ts[s]).sum())
+    assert abs(correct / ts.numel() - float(g['train_acc'])) < 1e-6
+    for n, m in model.masked_layers():
+        np.testing.assert_array_equal(pruner.owners[n], g['mask/module.' + n], err_msg=n)
+        np.testing.assert_allclose(m.weight.detach().numpy(), g['pre/' + n + '.weight'], rtol=1e-4, atol=1e-7, err_msg=n)
+    # validate from the reference's pre-validate state: identical inputs -> tight comparison
+    model.load_state_dict({k.replace('classifier.', 'head.'): torch.from_numpy(g['pre/' + k.replace('head.', 'classifier.')])
+                           for k in sd}, strict=True)
+    pruner.apply_mask()
+    for n, m in model.masked_layers():
+        np.testing.assert_array_equal(m.weight.detach().numpy(), g['post/' + n + '.weight'], err_msg=n)
+    model.eval()
+    xv, tv = torch.from_numpy(g['xv']), torch.from_numpy(g['tv'])
+    with torch.no_grad():
+        ev = torch.stack([model(xv[i]) for i in range(xv.shape[0])])
+    np.testing.assert_allclose(ev.numpy(), g['eval_logits'], rtol=1e-5, atol=1e-6)
+    assert abs(float((ev.argmax(2) == tv).float().mean()) - float(g['val_acc'])) < 1e-6
+    assert abs(pruner.sparsity() - float(g['sparsity'])) < 1e-12
