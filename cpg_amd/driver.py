@@ -9,9 +9,13 @@ files (experiment1/CPG_cifar100_scratch_mul_1.5.sh).  This m
 
 The set-up steps mirror CPG_cifar100_main_normal.py: model + head (:184-197), owner-mask allocation (:201-207),
 piggymask creation for task >= 2 (:251-270), prune window (:308-309), SGD-nesterov for weights + Adam for piggymasks
-(:320-346), LR schedule (:431-444).  What is policy rather than hot path is kept deliberately small: "grow the
-network" on a missed accuracy goal is reported to the caller (`TaskResult.needs_growth`, the reference's exit code 2)
-instead of being re-launched here, and data loading is whatever iterable of (images, labels) the caller provides.
+(:320-346), LR schedule (:431-444), the exit-code protocol (:456-506: 2 = grow, 5 = no free capacity, 6 = stop the
+sparsity sweep) and the two selection tools (tools/choose_appropriate_pruning_ratio_for_next_task.py,
+tools/choose_retrain_or_not.py).  Where the reference passes state between processes through checkpoint files, the
+session keeps SNAPSHOTS (cloned state_dict + owner masks): "copy the chosen ratio's checkpoint over the working one" is a
+snapshot restore, "grow" (exit 2 -> bash adds 0.5 to the width multiplier and re-runs finetune from the previous task's
+checkpoint) is `grow()`: a wider net, the previous state copied into its top-left corner, owner masks zero-padded
+(:208-249).  Data loading is whatever iterable of (images, labels) the caller provides.
 """
 import copy
 import types
@@ -24,6 +28,7 @@ from . import dist as cdist
 from . import models
 from .models import layers as nl
 from .utils import Optimizers
+from .utils import checkpoint as ckpt
 from .utils.manager import Manager
 
 VGG16_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
@@ -42,30 +47,66 @@ def masked_layers(model):
     return [(n, m) for n, m in model.named_modules() if isinstance(m, (nl.SharableConv2d, nl.SharableLinear))]
 
 
+def choose_ratio(ratio_to_acc, accuracy_goal, allow_acc_loss=0.0, forced=False):
+    """tools/choose_appropriate_pruning_ratio_for_next_task.py: walk the record (pruning ratio -> validation accuracy) from
+    the sparsest ratio down and take the first whose accuracy (+ allow_acc_loss) holds the goal -- or, when the network is
+    at its width cap and even the unpruned model missed the goal (`forced`), simply the sparsest.  0.0 = no stage qualifies:
+    the caller goes back to the pre-prune checkpoint."""
+    for s in sorted((k for k in ratio_to_acc if k > 0.0), reverse=True):
+        if ratio_to_acc[s] + allow_acc_loss >= accuracy_goal or forced:
+            return s
+    return 0.0
+
+
 class TaskResult(object):
     def __init__(self):
         self.finetune_acc = None
+        self.finetune_train_acc = None
         self.ratio_to_acc = {}          # the reference's record.txt (pruning ratio -> validation accuracy)
         self.chosen_ratio = 0.0
-        self.needs_growth = False       # reference exit code 2
+        self.needs_growth = False       # reference exit code 2 that could not be served (max width reached is NOT this: see run_task)
         self.no_free_capacity = False   # reference exit code 5
+        self.grown_to = []              # width multipliers tried after the first one
+        self.retrain_kept = None        # task >= 2: did the piggymask retrain beat the pruned model (choose_retrain_or_not.py)
+        self.retrain_acc = None
         self.steps = 0
+
+
+class Snapshot(object):
+    """What the reference keeps in a checkpoint file between two phases: weights + buffers, owner masks, and the per-task
+    side tensors.  Everything is cloned -- later training cannot reach into it."""
+
+    def __init__(self, sess):
+        self.state = {k: v.detach().clone() for k, v in sess.net.state_dict().items()}
+        self.masks = {k: v.clone() for k, v in sess.masks.items()}
+        self.width = sess.width
+        self.datasets = list(sess.net.datasets)
+        self.dataset2num_classes = dict(sess.net.dataset2num_classes)
+        self.shared_layer_info = copy.deepcopy(sess.shared_layer_info)
 
 
 class CPGSession(object):
     """Holds everything the reference passes between processes through checkpoint files."""
 
     def __init__(self, arch='custom_vgg_cifar100', width=1.0, device='cuda', cfg=VGG16_CFG, data_parallel=True,
-                 fused_optimizers=True):
+                 fused_optimizers=True, seed=None):
         self.arch, self.width, self.device = arch, width, torch.device(device)
+        self.cfg = cfg
+        self.seed = seed
         self.fused_optimizers = fused_optimizers      # MaskedSGD / MaskedAdam: gradient routing fused into the optimizer passes
-        kw = dict(dataset_history=[], dataset2num_classes={}, network_width_multiplier=width, shared_layer_info={})
-        build = getattr(models, arch)
-        self.net = build(cfg, **kw) if 'vgg' in arch else build(**kw)
         self.shared_layer_info = {}
         self.masks = {}
         self.model = None
         self.data_parallel = data_parallel
+        self.net = self._build(width, [], {})
+
+    def _build(self, width, datasets, dataset2num_classes):
+        if self.seed is not None:
+            torch.manual_seed(self.seed)
+        kw = dict(dataset_history=datasets, dataset2num_classes=dataset2num_classes, network_width_multiplier=width,
+                  shared_layer_info=self.shared_layer_info)
+        build = getattr(models, self.arch)
+        return build(self.cfg, **kw) if 'vgg' in self.arch else build(**kw)
 
     # -- per-task set-up (CPG_cifar100_main_normal.py:196-290) -------------------------------------------------
     def start_task(self, dataset, num_classes):
@@ -79,12 +120,17 @@ class CPGSession(object):
         if not self.masks:
             for name, module in masked_layers(self.model):
                 self.masks[name] = torch.zeros(module.weight.shape, dtype=torch.uint8, device=self.device)
+        else:
+            ckpt.resize_masks(self.model, self.masks, 'finetune')        # after a growth step (:208-232)
         task_id = self.net.datasets.index(dataset) + 1
         if dataset not in self.shared_layer_info:
             self.shared_layer_info[dataset] = {k: {} for k in ('bias', 'bn_layer_running_mean', 'bn_layer_running_var',
                                                                'bn_layer_weight', 'bn_layer_bias', 'piggymask')}
             if task_id > 1:
                 self._fresh_piggymasks()
+            else:
+                for _, module in masked_layers(self.net):
+                    module.piggymask = None
         self.shared_layer_info[dataset]['network_width_multiplier'] = self.width
         if hasattr(self.model, 'refresh_hooks'):
             self.model.refresh_hooks()
@@ -98,6 +144,8 @@ class CPGSession(object):
             if isinstance(module, (nl.SharableConv2d, nl.SharableLinear)):
                 pm = torch.full_like(self.masks[prefix + name], 0.01, dtype=torch.float32)
                 module.piggymask = Parameter(pm)
+        if hasattr(self.model, 'refresh_hooks'):
+            self.model.refresh_hooks()
 
     def make_optimizers(self, args, pruner=None):
         """Head of the current task + every non-piggymask parameter -> SGD(nesterov); piggymasks -> Adam (:320-346).
@@ -124,17 +172,89 @@ class CPGSession(object):
             opts.add(torch.optim.Adam(adam_params, lr=args.lr_mask), args.lr_mask)
         return opts
 
+    # -- state hand-over between phases (the reference's checkpoint files) ---------------------------------------
+    def snapshot(self):
+        return Snapshot(self)
+
+    def restore(self, snap):
+        """Back to a snapshot taken at the SAME width (the reference: copy that checkpoint over the working one)."""
+        assert snap.width == self.width
+        cur = self.net.state_dict()
+        with torch.no_grad():
+            for k, v in snap.state.items():
+                if k in cur and cur[k].shape == v.shape:
+                    cur[k].copy_(v)
+        for _, module in masked_layers(self.net):           # piggymask Parameters are (re)created per phase, not restored here
+            pass
+        for k, v in snap.masks.items():
+            if self.masks[k].shape == v.shape:
+                self.masks[k].copy_(v)
+            else:
+                self.masks[k] = v.clone()
+
+    def load(self, state):
+        """Resume from a checkpoint dictionary in the reference's format (CPG_cifar100_main_normal.py:155-164 +
+        Manager.load_checkpoint): task history, heads, shared weights (into the top-left corner when this session is
+        wider), owner masks (zero-padded likewise) and the per-task side tensors."""
+        self.shared_layer_info.clear()
+        self.shared_layer_info.update(state['shared_layer_info'])
+        self.net = self._build(self.width, list(state['dataset_history']), dict(state['dataset2num_classes'])).to(self.device)
+        self.model = cdist.DataParallel(self.net) if self.data_parallel else self.net
+        ckpt.load_state(self.model, state['model_state_dict'], for_evaluate=False)
+        if self.net.datasets:
+            self.net.set_dataset(self.net.datasets[-1])
+        self.masks.clear()
+        prefix = 'module.' if hasattr(self.model, 'module') else ''
+        for k, v in state['masks'].items():
+            key = k if k.startswith('module.') or not prefix else prefix + k
+            self.masks[key if prefix else k[len('module.'):] if k.startswith('module.') else k] = v.to(self.device)
+        ckpt.resize_masks(self.model, self.masks, 'finetune')
+
+    def commit_task(self, dataset):
+        """End of a phase: store COPIES of the task's own layers (BatchNorm, biases, PReLU, piggymasks) -- what
+        Manager.save_checkpoint does (utils/manager.py:202-221) when the reference writes the phase's checkpoint."""
+        ckpt.collect_task_layers(self.model, self.shared_layer_info, dataset)
+        self.shared_layer_info[dataset]['network_width_multiplier'] = self.width
+
+    def grow(self, new_width, snap=None):
+        """The reference's exit code 2: bash adds 0.5 to network_width_multiplier and re-runs `--mode finetune` from the
+        PREVIOUS task's checkpoint (experiment1/CPG_cifar100_scratch_mul_1.5.sh:89-94) into a wider model; weights and
+        BatchNorm vectors land in the top-left corner (utils/manager.py:233-264), the new rows / columns keep their fresh
+        initialisation, owner masks are zero-padded = the new slots are free (CPG_cifar100_main_normal.py:208-232)."""
+        datasets = list(snap.datasets) if snap is not None else []
+        d2n = dict(snap.dataset2num_classes) if snap is not None else {}
+        if snap is not None:
+            self.shared_layer_info.clear()
+            self.shared_layer_info.update(copy.deepcopy(snap.shared_layer_info))
+        else:
+            self.shared_layer_info.clear()
+        self.width = new_width
+        self.net = self._build(new_width, datasets, d2n).to(self.device)
+        self.model = cdist.DataParallel(self.net) if self.data_parallel else self.net
+        if snap is not None:
+            ckpt.load_state(self.model, snap.state, for_evaluate=False)
+            self.masks.clear()
+            self.masks.update({k: v.clone() for k, v in snap.masks.items()})
+            ckpt.resize_masks(self.model, self.masks, 'finetune')
+        else:
+            self.masks.clear()
+
     # -- phases ------------------------------------------------------------------------------------------------
     def _manager(self, args, train_loader, val_loader, begin, end):
         return Manager(args, self.model, self.shared_layer_info, self.masks, train_loader, val_loader, begin, end)
 
-    def finetune(self, args, train_loader, val_loader, epochs, lr_drops=(50, 80)):
-        """`--mode finetune` (:386-388, :401-444).  Returns (manager, last train acc, last val acc)."""
+    def finetune(self, args, train_loader, val_loader, epochs, lr_drops=(50, 80), patience=5):
+        """`--mode finetune` (:386-388, :401-444).  Returns (manager, last train acc, last val acc).  With
+        args.finetune_again (the piggymask retrain) the best epoch is kept as a snapshot and training stops after
+        `patience` epochs without improvement (:407-429); `self.last_retrain` = (best val acc, snapshot or None)."""
         args = copy.copy(args)
         args.mode = 'finetune'
         mgr = self._manager(args, train_loader, val_loader, 0, 0)
+        best, best_snap, stale = None, None, 0
         if not args.finetune_again:
             mgr.pruner.make_finetuning_mask()
+        else:
+            best = mgr.validate(-1)
         opts = self.make_optimizers(args, mgr.pruner)
         lrs = list(opts.lrs)
         stop_lr_mask = mgr.pruner.calculate_curr_task_ratio() != 0.0
@@ -143,6 +263,15 @@ class CPGSession(object):
         for epoch in range(epochs):
             tr, step = mgr.train(opts, epoch, lrs, step)
             va = mgr.validate(epoch)
+            if args.finetune_again:
+                if va > best:
+                    best, stale = va, 0
+                    best_snap = (self.snapshot(), {n: m.piggymask.detach().clone() for n, m in masked_layers(self.net)
+                                                   if m.piggymask is not None})
+                else:
+                    stale += 1
+                    if stale == patience:
+                        break
             if epoch + 1 in lr_drops:
                 for g in opts[0].param_groups:
                     g['lr'] *= 0.1
@@ -154,6 +283,7 @@ class CPGSession(object):
                 if stop_lr_mask and epoch + 1 == 70:
                     for g in opts[1].param_groups:
                         g['lr'] *= 0.0
+        self.last_retrain = (best, best_snap)
         return mgr, tr, va
 
     def prune(self, args, train_loader, val_loader, initial, target, epochs):
@@ -161,7 +291,7 @@ class CPGSession(object):
         `pruning_frequency` steps, the remaining epochs retrain at the fixed mask (:308-309, :384, :401-404)."""
         args = copy.copy(args)
         args.mode, args.initial_sparsity, args.target_sparsity = 'prune', initial, target
-        args.lr, args.lr_mask = 1e-3, 0.0
+        args.lr, args.lr_mask = getattr(args, 'prune_lr', 1e-3), 0.0
         steps_per_epoch = len(train_loader)
         mgr = self._manager(args, train_loader, val_loader, 0, args.pruning_interval * steps_per_epoch)
         mgr.validate(-1)
@@ -174,46 +304,118 @@ class CPGSession(object):
             va = mgr.validate(epoch)
         return mgr, tr, va
 
+    def evaluate(self, dataset, val_loader):
+        """`--mode inference` on any task learned so far (CPG_cifar100_main_normal.py:165-166,233-249 +
+        utils/manager.py:266-320): a model of THAT task's width, the shared weights cropped into it, the task's own
+        BatchNorm / bias / PReLU / piggymask tensors attached, owner masks cropped, then Manager.validate (apply_mask with
+        the task's index).  The live training model is not touched.  Returns (accuracy, logits of every batch)."""
+        info = self.shared_layer_info[dataset]
+        width = info.get('network_width_multiplier', self.width)
+        saved_info = self.shared_layer_info
+        net = self._build(width, list(self.net.datasets), dict(self.net.dataset2num_classes)).to(self.device)
+        net.set_dataset(dataset)
+        model = _Plain(net)
+        ckpt.load_state(model, self.net.state_dict(), for_evaluate=True)
+        ckpt.attach_task_layers(model, saved_info, dataset, piggymasks=True)
+        masks = {k: v.clone() for k, v in self.masks.items()}
+        ckpt.resize_masks(model, masks, 'inference')
+        args = default_args(mode='inference', dataset=dataset, network_width_multiplier=width)
+        mgr = Manager(args, model, saved_info, masks, None, val_loader, 0, 0)
+        outs = []
+        h = model.register_forward_hook(lambda m, i, o: outs.append(o.detach() if torch.is_tensor(o) else o))
+        acc = mgr.validate(0)
+        h.remove()
+        return acc, outs
+
     def run_task(self, dataset, num_classes, train_loader, val_loader, accuracy_goal=0.0, finetune_epochs=1,
-                 prune_epochs=1, sparsities=(0.1, 0.2, 0.3), args=None, min_train_acc=0.0, allow_acc_loss=0.0):
-        """finetune -> prune sweep -> choose ratio (tools/choose_appropriate_pruning_ratio_for_next_task.py) ->
-        piggymask retrain for task >= 2.  `accuracy_goal` plays baseline_cifar100_acc.txt's role."""
+                 prune_epochs=1, sparsities=(0.1, 0.2, 0.3), args=None, min_train_acc=0.95, allow_acc_loss=0.0,
+                 max_width=None, width_step=0.5, retrain_epochs=1, total_num_tasks=None):
+        """finetune [-> grow and retry] -> prune sweep -> choose ratio -> (task >= 2) piggymask retrain -> keep the better.
+
+        accuracy_goal plays baseline_cifar100_acc.txt's role, min_train_acc the reference's hard-coded 0.95
+        (CPG_cifar100_main_normal.py:452,469,487), max_width its --max_allowed_network_width_multiplier (None: never grow),
+        total_num_tasks its --total_num_tasks (forced pruning at the width cap, :494-506)."""
         res = TaskResult()
         args = args or default_args()
         args = copy.copy(args)
-        args.dataset, args.network_width_multiplier = dataset, self.width
-        task_id = self.start_task(dataset, num_classes)
-        mgr, tr, va = self.finetune(args, train_loader, val_loader, finetune_epochs)
-        res.finetune_acc = va
-        res.ratio_to_acc[0.0] = round(va, 4)
-        if va < accuracy_goal:
-            res.needs_growth = True                    # reference: sys.exit(2) -> bash widens the network
-            return res
+        args.dataset = dataset
+        before = self.snapshot() if self.model is not None else None      # the previous task's final checkpoint
+        max_width = self.width if max_width is None else max_width
+        while True:
+            args.network_width_multiplier = self.width
+            task_id = self.start_task(dataset, num_classes)
+            mgr, tr, va = self.finetune(args, train_loader, val_loader, finetune_epochs)
+            res.finetune_acc, res.finetune_train_acc = va, tr
+            res.ratio_to_acc = {0.0: round(va, 4)}
+            at_cap = self.width >= max_width
+            if tr > min_train_acc and va >= accuracy_goal:
+                break                                              # capacity is enough
+            if at_cap and va < accuracy_goal:
+                break                                              # exit 0 / 5: carry on at the cap (:474-478)
+            if at_cap:
+                break                                              # (train accuracy below the bar at the cap: the reference exits 2 forever)
+            # exit 2: widen and re-run the finetune from the previous task's checkpoint
+            new_width = min(max_width, self.width + width_step)
+            res.grown_to.append(new_width)
+            self.grow(new_width, before)
+        if va < accuracy_goal and not (self.width >= max_width):
+            res.needs_growth = True
+        self.commit_task(dataset)
         if mgr.pruner.calculate_curr_task_ratio() == 0.0:
-            res.no_free_capacity = True                # reference: sys.exit(5)
+            res.no_free_capacity = True                            # exit 5: nothing of this task's own to prune
             return res
+        # ---- gradual-prune sweep; every stage is a checkpoint the selection below can go back to
+        scratch = self.snapshot()
+        stages = {}
         prev = 0.0
+        must = 0.0
+        if self.width >= max_width and va < accuracy_goal and total_num_tasks:
+            remain = total_num_tasks - len(self.net.datasets)
+            must = 1.0 - round(1.0 / (remain + 1), 1)               # :494-506
         for s in sparsities:
-            snapshot = (copy.deepcopy(self.net.state_dict()), {k: v.clone() for k, v in self.masks.items()})
+            if must and prev >= must:
+                break                                              # exit 6 at the start of a run (:379-380)
             mgr, tr, va = self.prune(args, train_loader, val_loader, prev, s, prune_epochs)
-            if tr < min_train_acc:                     # reference: sys.exit(6), keep the previous sparsity level
-                self.net.load_state_dict(snapshot[0])
-                for k, v in snapshot[1].items():
-                    self.masks[k].copy_(v)
+            if tr <= min_train_acc:                                # exit 6: this run is not recorded, the sweep stops
                 break
             res.ratio_to_acc[s] = round(va, 4)
+            stages[s] = self.snapshot()
             prev = s
-        # sparsest ratio whose accuracy holds the goal (the reference walks the record from the sparsest down)
-        res.chosen_ratio = 0.0
-        for s in sorted((k for k in res.ratio_to_acc if k > 0.0), reverse=True):
-            if res.ratio_to_acc[s] + allow_acc_loss >= accuracy_goal:
-                res.chosen_ratio = s
+            if must and s >= must:
                 break
+        # ---- tools/choose_appropriate_pruning_ratio_for_next_task.py: sparsest recorded ratio that holds the goal
+        forced = self.width >= max_width and res.ratio_to_acc[0.0] < accuracy_goal
+        res.chosen_ratio = choose_ratio(res.ratio_to_acc, accuracy_goal, allow_acc_loss, forced)
+        self.restore(stages[res.chosen_ratio] if res.chosen_ratio else scratch)
+        self.commit_task(dataset)
+        # ---- task >= 2: retrain the piggymasks (and the task's weights); keep it only if it improves (choose_retrain_or_not.py)
         if task_id > 1:
             again = copy.copy(args)
-            again.finetune_again, again.lr_mask = True, 1e-4
+            again.finetune_again, again.lr_mask, again.lr = True, 1e-4, getattr(args, 'prune_lr', 1e-3)
+            pruned = self.snapshot()
+            pruned_pm = {n: m.piggymask.detach().clone() for n, m in masked_layers(self.net) if m.piggymask is not None}
             self._fresh_piggymasks()
+            self.finetune(again, train_loader, val_loader, retrain_epochs)
+            best, best_snap = self.last_retrain
+            res.retrain_acc = best
+            res.retrain_kept = best_snap is not None
+            snap, pms = best_snap if best_snap is not None else (pruned, pruned_pm)
+            self.restore(snap)
+            for n, m in masked_layers(self.net):
+                if n in pms:
+                    m.piggymask = Parameter(pms[n].clone())
             if hasattr(self.model, 'refresh_hooks'):
                 self.model.refresh_hooks()
-            self.finetune(again, train_loader, val_loader, 1)
+            self.commit_task(dataset)
         return res
+
+
+class _Plain(nn.Module):
+    """`.module` wrapper without collectives (keeps the `module.` prefix of the owner-mask keys) for evaluation models."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)

@@ -220,3 +220,76 @@ def test_checkpoint_growth_and_crop():
     bsd = {k: v.clone() for k, v in big.state_dict().items() if not k.startswith('classifiers.')}
     ckpt.load_state(_Wrap(small), bsd, for_evaluate=True)
     assert torch.equal(small.state_dict()['features.45.weight'], bsd['features.45.weight'][:256, :32])
+
+
+def test_task_layer_snapshots_are_copies_and_attach_copies_back():
+    """shared_layer_info[task] must hold COPIES (one process trains the same BatchNorm tensors for the next task), with
+    Parameter-ness kept so a file we write still re-attaches in the reference; attach_task_layers copies values into the
+    live tensors (identity of the live Parameters unchanged) and restores / clears piggymasks."""
+    from cpg_amd.utils import checkpoint as ckpt
+    from torch.nn.parameter import Parameter
+    net = _two_task_vgg(0.0625)
+    model = _Wrap(net)
+    bn = net.features[1]
+    bn.running_mean.fill_(0.25)
+    bn.weight.data.fill_(1.5)
+    info = {}
+    ckpt.collect_task_layers(model, info, 't1')
+    assert info['t1']['piggymask'] == {}
+    snap_w = info['t1']['bn_layer_weight']['features.1']
+    assert isinstance(snap_w, Parameter) and snap_w is not bn.weight and snap_w.data_ptr() != bn.weight.data_ptr()
+    # "task 2" trains on: new BN values and piggymasks
+    bn.running_mean.fill_(-3.0)
+    bn.weight.data.fill_(7.0)
+    for _, m in net.named_modules():
+        if isinstance(m, (nl.SharableConv2d, nl.SharableLinear)):
+            m.piggymask = Parameter(torch.full_like(m.weight.detach(), 0.25))
+    ckpt.collect_task_layers(model, info, 't2')
+    assert float(info['t1']['bn_layer_running_mean']['features.1'][0]) == 0.25          # task 1's snapshot did not move
+    assert float(info['t2']['bn_layer_running_mean']['features.1'][0]) == -3.0
+    live_w = bn.weight
+    ckpt.attach_task_layers(model, info, 't1', piggymasks=True)
+    assert bn.weight is live_w and float(bn.weight.detach()[0]) == 1.5 and float(bn.running_mean[0]) == 0.25
+    assert net.features[0].piggymask is None
+    ckpt.attach_task_layers(model, info, 't2', piggymasks=True)
+    assert float(bn.weight.detach()[0]) == 7.0 and float(net.features[0].piggymask.detach().view(-1)[0]) == 0.25
+    net.features[0].piggymask.data.fill_(9.0)                                            # training the live copy ...
+    assert float(info["t2"]["piggymask"]["features.0"].detach().view(-1)[0]) == 0.25       # ... does not reach the snapshot
+
+
+def test_resize_masks_pad_on_growth_and_crop_for_inference():
+    """CPG_cifar100_main_normal.py:208-249: widen -> zero (free) masks with the old mask in the top-left corner; evaluate an
+    older, narrower task -> crop; anything else is refused."""
+    from cpg_amd.utils import checkpoint as ckpt
+    small, big = _Wrap(_two_task_vgg(0.0625)), _Wrap(_two_task_vgg(0.125))
+    g = torch.Generator().manual_seed(3)
+    masks = {n: torch.randint(1, 3, m.weight.shape, generator=g, dtype=torch.uint8) for n, m in small.named_modules()
+             if isinstance(m, (nl.SharableConv2d, nl.SharableLinear))}
+    old = {k: v.clone() for k, v in masks.items()}
+    assert ckpt.resize_masks(small, masks, 'finetune') is False                           # same width: untouched
+    with pytest.raises(AssertionError):
+        ckpt.resize_masks(big, dict(masks), 'prune')
+    with pytest.raises(AssertionError):
+        ckpt.resize_masks(big, dict(masks), 'inference')
+    assert ckpt.resize_masks(big, masks, 'finetune') is True
+    for n, m in big.named_modules():
+        if isinstance(m, (nl.SharableConv2d, nl.SharableLinear)):
+            o = old[n]
+            assert masks[n].shape == m.weight.shape and masks[n].dtype == torch.uint8
+            corner = masks[n][tuple(slice(0, s) for s in o.shape)]
+            assert torch.equal(corner, o)
+            assert int(masks[n].sum()) == int(o.sum())                                    # everything outside the corner is free (0)
+    assert ckpt.resize_masks(small, masks, 'inference') is True
+    for n in old:
+        assert torch.equal(masks[n], old[n])
+
+
+def test_choose_ratio_table():
+    """The selection rule itself (host logic): walk the record from the sparsest ratio down."""
+    from cpg_amd.driver import choose_ratio
+    rec = {0.0: 0.80, 0.1: 0.81, 0.2: 0.79, 0.3: 0.70}
+    assert choose_ratio(rec, 0.78, 0.0, False) == 0.2
+    assert choose_ratio(rec, 0.78, 0.09, False) == 0.3          # --allow_acc_loss
+    assert choose_ratio(rec, 0.95, 0.0, False) == 0.0           # nothing holds the goal: the pre-prune checkpoint
+    assert choose_ratio(rec, 0.95, 0.0, True) == 0.3            # at the width cap with a missed goal: the sparsest anyway
+    assert choose_ratio({0.0: 0.9}, 0.5, 0.0, False) == 0.0     # the sweep recorded nothing

@@ -1,0 +1,142 @@
+"""The data-parallel composition on the GPU: HIP model + cpg_amd.dist.DataParallel + MaskedSGD + rank prune.
+
+A GPU box handed to the tests has ONE MI355X, so two ranks share it and talk through gloo (RCCL needs one device per
+rank); everything else is the product path: the masked conv / linear HIP kernels, the gradient hooks and
+finish_gradient_sync() inside Manager.train, the fused routing + SGD step, cpg_rank_prune.  Expected:
+
+  * both ranks end with bit-identical weights and owner masks (replicated state, no collective besides the gradients);
+  * they equal ONE process training on the full batch -- BatchNorm is frozen in eval mode here, because per-replica batch
+    statistics (nn.DataParallel semantics, kept on purpose) would make a sharded run differ from a full-batch run.
+"""
+import os
+import socket
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VGG_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+WIDTH, B, STEPS = 0.125, 8, 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _batches():
+    g = torch.Generator().manual_seed(77)
+    return [(torch.randn(B, 3, 32, 32, generator=g), torch.randint(0, 5, (B,), generator=g)) for _ in range(STEPS)]
+
+
+def _run(rank, world, data_parallel):
+    """3 prune-mode steps (rank-prune events after steps 1 and 2) through Manager.train; returns (weights, masks)."""
+    import torch.nn as nn
+    import cpg_amd.models as M
+    from cpg_amd import dist as cdist
+    from cpg_amd.models import layers as nl
+    from cpg_amd.utils import Optimizers
+    from cpg_amd.utils.fused_sgd import MaskedSGD
+    from cpg_amd.utils.manager import Manager
+    dev = 'cuda:0'
+    torch.manual_seed(1)
+    net = M.custom_vgg_cifar100(VGG_CFG, dataset_history=[], dataset2num_classes={}, network_width_multiplier=WIDTH, shared_layer_info={})
+    net.add_dataset('t1', 5)
+    net.set_dataset('t1')
+    net = net.to(dev)
+    for m in net.modules():                       # frozen BatchNorm: .train() from Manager.train must not re-enable batch statistics
+        if isinstance(m, nn.BatchNorm2d):
+            m.eval()
+            m.train = lambda mode=True, _m=m: _m
+    model = cdist.DataParallel(net, large_numel=1 << 12) if data_parallel else _Wrap(net)
+    masks = {n: torch.ones(m.weight.shape, dtype=torch.uint8, device=dev) for n, m in model.named_modules()
+             if isinstance(m, (nl.SharableConv2d, nl.SharableLinear))}
+    args = types.SimpleNamespace(mode='prune', dataset='t1', finetune_again=False, target_sparsity=0.3, initial_sparsity=0.0,
+                                 pruning_frequency=1, weight_decay=4e-5, network_width_multiplier=WIDTH, cuda=True, log_path=None,
+                                 progress=False)
+    loader = []
+    for x, t in _batches():
+        xs, ts = cdist.shard_batch(x, t, rank, world)
+        loader.append((xs.to(dev), ts.to(dev)))
+    mgr = Manager(args, model, {}, masks, loader, None, 0, 2)
+    opts = Optimizers()
+    opts.add(MaskedSGD(list(model.parameters()), pruner=mgr.pruner, lr=1e-2, momentum=0.9, nesterov=True), 1e-2)
+    mgr.train(opts, 0, [1e-2], 0)
+    assert mgr.pruner.prune_events == 2
+    torch.cuda.synchronize()
+    return ({k: v.detach().cpu() for k, v in net.state_dict().items()}, {k: v.cpu() for k, v in masks.items()},
+            bool(getattr(model, '_active', False)))
+
+
+class _Wrap(torch.nn.Module):
+    def __init__(self, m):
+        super().__init__()
+        self.module = m
+
+    def forward(self, x):
+        return self.module(x)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        sd, masks, active = _run(rank, world, True)
+        assert active
+        torch.save({'sd': sd, 'masks': masks}, os.path.join(out_dir, 'rank%d.pt' % rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_hip_model_masked_sgd_prune_match_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'rank0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'rank1.pt'))
+    for k in r0['sd']:
+        assert torch.equal(r0['sd'][k], r1['sd'][k]), 'ranks diverged in %s' % k
+    for k in r0['masks']:
+        assert torch.equal(r0['masks'][k], r1['masks'][k]), 'ranks diverged in mask %s' % k
+    sd, masks, _ = _run(0, 1, False)                       # one process, the full batch
+    for k, v in sd.items():
+        if v.dtype.is_floating_point:
+            a, b = r0['sd'][k].numpy(), v.numpy()
+            np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-6 * (float(np.abs(b).max()) + 1e-30), err_msg=k)
+    mism = sum(int((r0['masks'][k] != masks[k]).sum()) for k in masks)
+    total = sum(v.numel() for v in masks.values())
+    assert mism <= max(2, 1e-4 * total), 'owner masks differ from the single-process run in %d of %d slots' % (mism, total)
+    released = sum(int((v == 0).sum()) for v in masks.values())
+    assert released > 0.05 * total                         # the prune events really released weights
+
+
+def test_bench_self_launches_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` started WITHOUT torch.distributed.run must become two ranks by itself (gloo here: the box
+    has one GPU) and print n_gpus = 2 with the multi_gpu block; a world size that contradicts --gpus is refused."""
+    import json
+    import subprocess
+    env = dict(os.environ, CPG_BENCH_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '4',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 8 and out['config']['parallelism'] == 'dp2'
+    mg = out['multi_gpu']
+    assert mg['backend'] == 'gloo' and len(mg['per_rank_ms_per_step']) == 2 and mg['replicas_identical_after_cycle'] is True
+    assert mg['allreduced_gradient_bytes_per_step'] > 500e6
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'],
+                         env=dict(env, WORLD_SIZE='1', RANK='0'), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and 'WORLD_SIZE' in (bad.stderr + bad.stdout)

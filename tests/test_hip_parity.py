@@ -185,11 +185,15 @@ def test_linear_oracle(B, I, O, pm):
     gy = torch.randn(B, O, generator=g)
     y.backward(gy.to(DEV))
     r = ops.linear_backward(x.numpy(), w.numpy(), gy.numpy(), None if pmv is None else pmv.numpy())
-    close(xd.grad, r['gx'], rtol=1e-4, atol=2e-5, msg='gx')
-    close(layer.weight.grad, r['gw'], rtol=1e-4, atol=2e-5, msg='gw')
+    # absolute floor = 1e-5 of the tensor's scale: an element that is a near-cancelling sum of B (or I) terms carries the
+    # round-off of its addends, not of its own magnitude
+    def floor(a):
+        return max(2e-5, 1e-5 * float(np.abs(a).max()))
+    close(xd.grad, r['gx'], rtol=1e-4, atol=floor(r['gx']), msg='gx')
+    close(layer.weight.grad, r['gw'], rtol=1e-4, atol=floor(r['gw']), msg='gw')
     close(layer.bias.grad, r['gb'], rtol=1e-4, atol=1e-4, msg='gb')
     if pm:
-        close(layer.piggymask.grad, r['gpm'], rtol=1e-4, atol=2e-5, msg='gpm')
+        close(layer.piggymask.grad, r['gpm'], rtol=1e-4, atol=floor(r['gpm']), msg='gpm')
 
 
 # --------------------------------------------------------------------------- pruner pieces vs golden
