@@ -56,6 +56,14 @@ __device__ __forceinline__ f32x4 ld_sv4(const float *sbase, unsigned byte_off) {
 }
 
 
+// Inference-mode BatchNorm (+ ReLU) folded into the forward epilogue: y = [max(0,] (acc + bias - mean) * invstd * gamma + beta [)]
+// with invstd = 1 / sqrt(var + eps) -- the expression of bn_kernels.hip's apply pass.  gamma == nullptr: plain conv.
+struct C3BnEval {
+    const float *gamma, *beta, *mean, *var;
+    float eps;
+    int relu;
+};
+
 struct C3Geom {
     int N, C, H, W, M;        // C: channels of the tensor being read, M: channels being produced
     int Mp;                   // row stride of the packed weights (M rounded up to 128)
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(256) void k_c3_pack(const float *__restrict__ w, co
 template <class Cfg, bool DGRAD, bool STATS = false, bool SPLITK = false>
 __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float *__restrict__ x, const float *__restrict__ wp,
                                                            const float *__restrict__ bias, float *__restrict__ y,
-                                                           float *__restrict__ stats) {
+                                                           float *__restrict__ stats, C3BnEval bn) {
     __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -307,6 +315,23 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
                 for (int e = 0; e < 16; ++e) {
                     const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                     bv[e] = bias[co < g.M ? co : 0];
+                }
+            }
+            if (!DGRAD && !STATS && !SPLITK && bn.gamma != nullptr) {       // eval-mode BatchNorm (+ ReLU) in the epilogue (uniform branch)
+                float ga[16], be[16], mu[16], is[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const int cc = co < g.M ? co : 0;
+                    ga[e] = bn.gamma[cc], be[e] = bn.beta[cc], mu[e] = bn.mean[cc], is[e] = bn.var[cc];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    is[e] = 1.0f / sqrtf(is[e] + bn.eps);
+                    float v = ((acc[fm][fn][e] + bv[e]) - mu[e]) * is[e] * ga[e] + be[e];
+                    if (bn.relu) v = fmaxf(v, 0.0f);
+                    acc[fm][fn][e] = v;
+                    bv[e] = 0.0f;
                 }
             }
 #pragma unroll
@@ -729,7 +754,8 @@ inline size_t pack_bytes(int c_read, int m) { return ((size_t)pad_to(c_read, 4) 
 // dry: only compute it.
 template <class Cfg>
 int launch_fwd(C3Geom g, const float *x, const float *wp, const float *bias, float *y, hipStream_t stream, const char *what,
-               float *stats = nullptr, int *tiles_out = nullptr, bool dry = false) {
+               float *stats = nullptr, int *tiles_out = nullptr, bool dry = false, const C3BnEval *bnp = nullptr) {
+    const C3BnEval bn = bnp ? *bnp : C3BnEval{nullptr, nullptr, nullptr, nullptr, 0.0f, 0};
     g.tiles_x = (g.W + Cfg::TW - 1) / Cfg::TW;
     g.tiles_y = (g.H + Cfg::TH - 1) / Cfg::TH;
     g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
@@ -739,22 +765,22 @@ int launch_fwd(C3Geom g, const float *x, const float *wp, const float *bias, flo
     if (tiles_out) *tiles_out = g.ksplit > 1 ? 0 : (int)(blocks / g.tiles_m);      // no fused statistics on split tiles
     if (dry) return CPG_OK;
     if (g.ksplit > 1) {
-        if (stats != nullptr) return fail(CPG_E_UNSUPPORTED, "conv3x3: no fused statistics on channel-split tiles");
+        if (stats != nullptr || bnp != nullptr) return fail(CPG_E_UNSUPPORTED, "conv3x3: no fused epilogue on channel-split tiles");
         hipError_t e = hipMemsetAsync(y, 0, (size_t)g.N * g.M * g.H * g.W * sizeof(float), stream);
         if (e != hipSuccess) return hip_status(e, what);
         if (g.dgrad)
-            hipLaunchKernelGGL((k_c3_fwd<Cfg, true, false, true>), dim3((unsigned)(blocks * g.ksplit)), dim3(256), 0, stream, g, x, wp, bias, y, nullptr);
+            hipLaunchKernelGGL((k_c3_fwd<Cfg, true, false, true>), dim3((unsigned)(blocks * g.ksplit)), dim3(256), 0, stream, g, x, wp, bias, y, nullptr, bn);
         else
-            hipLaunchKernelGGL((k_c3_fwd<Cfg, false, false, true>), dim3((unsigned)(blocks * g.ksplit)), dim3(256), 0, stream, g, x, wp, bias, y, nullptr);
+            hipLaunchKernelGGL((k_c3_fwd<Cfg, false, false, true>), dim3((unsigned)(blocks * g.ksplit)), dim3(256), 0, stream, g, x, wp, bias, y, nullptr, bn);
         CPG_CHECK_LAUNCH(what);
         return CPG_OK;
     }
     if (g.dgrad)
-        hipLaunchKernelGGL((k_c3_fwd<Cfg, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, nullptr);
+        hipLaunchKernelGGL((k_c3_fwd<Cfg, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, nullptr, bn);
     else if (stats != nullptr)
-        hipLaunchKernelGGL((k_c3_fwd<Cfg, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, stats);
+        hipLaunchKernelGGL((k_c3_fwd<Cfg, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, stats, bn);
     else
-        hipLaunchKernelGGL((k_c3_fwd<Cfg, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, nullptr);
+        hipLaunchKernelGGL((k_c3_fwd<Cfg, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, nullptr, bn);
     CPG_CHECK_LAUNCH(what);
     return CPG_OK;
 }
@@ -762,7 +788,7 @@ int launch_fwd(C3Geom g, const float *x, const float *wp, const float *bias, flo
 // c_read / m: channels contracted over / produced.  w is the layer's [K][C][3][3] weight.
 int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, const float *x, const float *w, const float *pm,
             float thr, const float *bias, float *y, void *ws, size_t ws_bytes, hipStream_t stream, float *stats = nullptr,
-            int *tiles_out = nullptr, bool dry = false) {
+            int *tiles_out = nullptr, bool dry = false, const C3BnEval *bn = nullptr) {
     const char *what = dgrad ? "cpg_conv2d_dgrad(3x3)" : "cpg_conv2d_fwd(3x3)";
     float *wp = (float *)ws;
     const int rows_c = pad_to(c_read, 4), Mp = pad_to(m, 128);
@@ -776,22 +802,22 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
     C3Geom g{N, c_read, H, W, m, Mp, 0, 0, 0, dgrad ? 1 : 0, 1};
     if (const char *f = getenv("CPG_C3_FORCE")) {        // A/B experiments only (tools/conv_bench.py --ab)
         switch (atoi(f)) {
-            case 0: return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
-            case 1: return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
-            case 2: return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
-            case 3: return launch_fwd<CfgD128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
-            case 4: return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
-            case 7: return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
-            case 8: g.ksplit = 2; return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
-            default: if (c_read % 4 == 0) return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+            case 0: return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
+            case 1: return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
+            case 2: return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
+            case 3: return launch_fwd<CfgD128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
+            case 4: return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
+            case 7: return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
+            case 8: g.ksplit = 2; return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
+            default: if (c_read % 4 == 0) return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
         }
     }
-    if (W == 7 && H == 7 && c_read % 4 == 0) return launch_fwd<CfgV7>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+    if (W == 7 && H == 7 && c_read % 4 == 0) return launch_fwd<CfgV7>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
     // 14 x 14 maps: the 14 x 16 single-image tile wastes 1/8 of its MFMAs on two padding columns; the zero-waste virtual-row
     // tile alone measured the same, because its N*14/16 tiles put 3.5 block-equivalents on each CU, which rounds up to 4
     // (at batch 256 the layer is too small for 256 CUs).  Halving the blocks (two per tile, each half of the channel chunks,
     // atomically added into a zeroed y) makes it 7 half-blocks per CU.
-    if (W == 14 && H == 14 && m > 64 && c_read % 8 == 0 && !getenv("CPG_NO_V14")) {
+    if (W == 14 && H == 14 && m > 64 && c_read % 8 == 0 && bn == nullptr && !getenv("CPG_NO_V14")) {
         // ... when that balances: per-CU MFMA time in block-equivalents of either tiling (the split pays a memset, atomics
         // and a second prologue; at 256 channels and batch 256 -- 3.5 half-blocks per CU -- it measured no gain)
         const int tm = (m + 127) / 128;
@@ -799,18 +825,18 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
         const double t_split = std::ceil(2.0 * (((int64_t)N * 14 + 15) / 16) * tm / kCUs) * 0.5 * 1.04;
         if (t_split < 0.9 * t_single) {
             g.ksplit = 2;
-            return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+            return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
         }
     }
-    if (W <= 16 && H <= 16 && m > 64) return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+    if (W <= 16 && H <= 16 && m > 64) return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
     if (W == 28 && H % 4 == 0 && m > 64 && c_read % 4 == 0)
-        return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+        return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
     // 56, 112, 168 ...: a 32-wide tile would waste 12.5 % of the MFMAs.  The 64-channel 8 x 56 tile (2 x 2 waves) measured
     // 1-2 % faster than the 128-channel 4 x 56 tile (4 x 1 waves) on every 56- and 112-wide VGG layer, also for m > 64
     // (interleaved in-process A/B, tools/conv_bench.py --ab CPG_C3_FORCE=3,4).
-    if (W % 56 == 0 && W % 32 != 0) return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
-    if (m <= 64) return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
-    return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry);
+    if (W % 56 == 0 && W % 32 != 0) return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
+    if (m <= 64) return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
+    return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
 }
 
 }  // namespace
@@ -844,6 +870,16 @@ int cpg_conv3x3_fwd_bnstats(const cpg_conv_desc *d, const float *x, const float 
                             float *y, float *stats, void *ws, size_t ws_bytes, hipStream_t stream) {
     CPG_REQUIRE(x && w && y && stats, "cpg_conv2d_fwd_bnstats: null pointer");
     return run_fwd(false, d->N, d->C, d->K, d->H, d->W, d->K, d->C, x, w, pm, thr, bias, y, ws, ws_bytes, stream, stats);
+}
+
+// forward with the inference-mode BatchNorm (+ ReLU) that follows the conv folded into the epilogue (Manager.validate's path)
+int cpg_conv3x3_fwd_bn_eval(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
+                            const float *gamma, const float *beta, const float *mean, const float *var, float eps, int relu, float *y,
+                            void *ws, size_t ws_bytes, hipStream_t stream) {
+    CPG_REQUIRE(x && w && y && gamma && beta && mean && var, "cpg_conv2d_fwd_bn_eval: null pointer");
+    const C3BnEval bn{gamma, beta, mean, var, eps, relu};
+    return run_fwd(false, d->N, d->C, d->K, d->H, d->W, d->K, d->C, x, w, pm, thr, bias, y, ws, ws_bytes, stream, nullptr, nullptr, false,
+                   &bn);
 }
 
 int cpg_conv3x3_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx, void *ws,

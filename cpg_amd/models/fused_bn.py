@@ -259,6 +259,7 @@ class FusedSequential(nn.Sequential):
     fuse = True
     fuse_pool = True
     fuse_stats = True       # conv -> BatchNorm2d: the conv kernel's epilogue produces the batch-statistics partial sums
+    fuse_eval = True        # inference: conv -> BatchNorm2d(eval) -> ReLU as one kernel (BatchNorm folded into the conv epilogue)
 
     def forward(self, input):
         mods = list(self._modules.values())
@@ -283,6 +284,17 @@ class FusedSequential(nn.Sequential):
                 stats = None
                 continue
             nxt = mods[i + 1] if i + 1 < n else None
+            if (self.fuse and self.fuse_eval and ENABLED and not torch.is_grad_enabled() and hasattr(m, 'forward_bn_eval')
+                    and isinstance(nxt, nn.BatchNorm2d) and not nxt.training and nxt.track_running_stats and nxt.affine
+                    and i + 2 < n and isinstance(mods[i + 2], nn.ReLU) and input.is_cuda
+                    and not (self.fuse_pool and i + 3 < n and _is_pool2(mods[i + 3]))):
+                # (a following MaxPool2d keeps the conv + fused BN/ReLU/pool pair: same HBM traffic, and the un-pooled
+                # activation is never written either way)
+                y = m.forward_bn_eval(input, nxt, relu=True)
+                if y is not None:
+                    input, stats = y, None
+                    i += 3
+                    continue
             if (self.fuse and self.fuse_stats and ENABLED and hasattr(m, 'forward_with_bn_stats') and isinstance(nxt, nn.BatchNorm2d)
                     and nxt.training and nxt.track_running_stats and nxt.affine and nxt.momentum is not None and input.is_cuda):
                 input, stats = m.forward_with_bn_stats(input)

@@ -252,6 +252,30 @@ class SharableConv2d(_Sharable):
                                          self.stride, self.padding, self.dilation, self.groups, True)
         return y, (stats if stats.numel() else None)
 
+    def forward_bn_eval(self, input, bn, relu=True):
+        """relu(bn(conv(input))) with `bn` an eval-mode nn.BatchNorm2d, as ONE kernel (cpg_conv2d_fwd_bn_eval): the path of
+        Manager.validate.  Inference only -- call it under torch.no_grad(); returns None when this shape has no fused
+        kernel (the caller then runs the layers one by one)."""
+        if torch.is_grad_enabled() or input.dim() != 4 or input.shape[0] == 0 or input.shape[1] != self.weight.shape[1] * self.groups:
+            return None
+        x = input.contiguous()
+        w = self.weight.contiguous()
+        p = None if self.piggymask is None else self.piggymask.contiguous()
+        d = _conv_desc(x.shape, w.shape, self.stride, self.padding, self.dilation, self.groups)
+        L = _lib.lib()
+        if not L.cpg_conv2d_fwd_bn_eval_supported(ctypes.byref(d)):
+            return None
+        oh, ow = _out_hw(d)
+        y = torch.empty((d.N, d.K, oh, ow), dtype=torch.float32, device=x.device)
+        ws, nbytes = _lib.workspace(L.cpg_conv2d_workspace_bytes(ctypes.byref(d)), x.device)
+        rc = L.cpg_conv2d_fwd_bn_eval(ctypes.byref(d), _lib.dptr(x, name='input'), _lib.dptr(w, name='weight'), _lib.dptr(p, name='piggymask'),
+                                      float(self.info['threshold']), _lib.dptr(self.bias, name='bias'), _lib.dptr(bn.weight, name='bn.weight'),
+                                      _lib.dptr(bn.bias, name='bn.bias'), _lib.dptr(bn.running_mean, name='running_mean'),
+                                      _lib.dptr(bn.running_var, name='running_var'), float(bn.eps), int(bool(relu)), _lib.dptr(y),
+                                      _lib.dptr(ws), nbytes, _lib.stream_ptr())
+        _lib.check('cpg_conv2d_fwd_bn_eval', rc)
+        return y
+
     def extra_repr(self):
         s = '{in_channels}, {out_channels}, kernel_size={kernel_size}, stride={stride}'
         if any(self.padding):

@@ -193,6 +193,17 @@ int cpg_conv2d_fwd_bnstats(const cpg_conv_desc *desc, const float *x, const floa
 int cpg_bn_stats_finalize(const float *stats, int32_t tiles, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
                           float *running_mean, float *running_var, float *mean, float *invstd, void *stream);
 
+/* Inference (Manager.validate, utils/manager.py:103-121: apply_mask, then model.eval() forward): conv -> BatchNorm2d in
+ * eval mode (-> ReLU) of models/vgg.py:137-141 as ONE kernel -- y = [max(0,] (conv(x, W_eff) + bias - running_mean) /
+ * sqrt(running_var + eps) * gamma + beta [)] applied in the conv epilogue, so the raw conv output is never written and no
+ * BatchNorm kernel runs.  cpg_conv2d_fwd_bn_eval_supported(desc) == 0: shape has no fused path (use cpg_conv2d_fwd +
+ * cpg_bn_relu_fwd_eval).  No gradient counterpart: callers use it under torch.no_grad() only. */
+int32_t cpg_conv2d_fwd_bn_eval_supported(const cpg_conv_desc *desc);
+int cpg_conv2d_fwd_bn_eval(const cpg_conv_desc *desc, const float *x, const float *w, const float *piggymask, float threshold,
+                           const float *bias, const float *gamma, const float *beta, const float *running_mean,
+                           const float *running_var, float eps, int32_t relu, float *y, void *workspace, size_t workspace_bytes,
+                           void *stream);
+
 /* y = relu(bn(x) + res): the tail of a residual block (models/resnet.py:69-74 `out = self.bn3(out); out += identity;
  * out = self.relu(out)`).  train != 0: batch statistics (mean / invstd out, running stats updated); train == 0: `mean`
  * / `invstd` are inputs.  Backward = relu mask from y, then cpg_bn_relu_bwd(relu = 0); the residual's gradient is the

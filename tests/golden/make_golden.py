@@ -589,7 +589,9 @@ def gen_net_train_steps():
                                      pruning_frequency=1, weight_decay=4e-5, network_width_multiplier=width)
         pruner = SparsePruner(model, masks, args, 0, 2, 1)
         digest = np.array([[float(p.double().sum()), float(p.double().abs().sum())] for p in net.parameters()])
-        lr = 1e-3
+        # a small step: at lr 1e-3 these un-normalised (SphereNet) / tiny-batch (ResNet) nets move 3-20 % of a weight's scale per
+        # step and the 3-step trajectory is chaotic (the SphereNet loss went 9 -> 71 -> 8); 2e-5 keeps steps 1-2 comparable
+        lr = 2e-5
         opt = optim.SGD(list(model.parameters()), lr=lr, weight_decay=0.0, momentum=0.9, nesterov=True)
         crit = AngleLoss() if dataset == 'face_verification' else nn.CrossEntropyLoss()
         g = torch.Generator().manual_seed(17)
