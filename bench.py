@@ -104,6 +104,8 @@ class KernelClock:
         p.cpg_conv2d_fwd = timed('cpg_conv2d_fwd', conv_kind('conv_fwd'), conv_flops)
         # same contraction as cpg_conv2d_fwd; its epilogue also emits the BatchNorm partial sums
         p.cpg_conv2d_fwd_bnstats = timed('cpg_conv2d_fwd_bnstats', conv_kind('conv_fwd'), conv_flops)
+        # ... and the inference variant with the eval-mode BatchNorm + ReLU folded into the epilogue (validate)
+        p.cpg_conv2d_fwd_bn_eval = timed('cpg_conv2d_fwd_bn_eval', conv_kind('conv_fwd'), conv_flops)
         p.cpg_conv2d_dgrad = timed('cpg_conv2d_dgrad', conv_kind('conv_dgrad'), conv_flops)
         p.cpg_conv2d_wgrad = timed('cpg_conv2d_wgrad', conv_kind('conv_wgrad'), conv_flops)
         p.cpg_linear_fwd = timed('cpg_linear_fwd', lambda a: 'linear_fwd', lin_flops(6))

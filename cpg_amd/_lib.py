@@ -56,6 +56,10 @@ _SIGNATURES = {
     'cpg_apply_mask': (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int64, _vp]),
     'cpg_zero_pruned': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp]),
     'cpg_claim_free': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int64, _vp]),
+    'cpg_owned_num_blocks': (ctypes.c_int64, [ctypes.c_int64]),
+    'cpg_owned_block_counts': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _vp, _vp]),
+    'cpg_pack_owned': (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _vp, _vp, _vp]),
+    'cpg_unpack_owned': (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _vp, _vp, _vp]),
     'cpg_sgd_route_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _vp]),
     'cpg_adam_route_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float,

@@ -7,6 +7,12 @@ only gradients move: each parameter's gradient is all-reduced (mean) as soon as 
 on RCCL's own stream, overlapping the rest of backward; large tensors go out individually (no staging
 copy), small ones (BN, biases, heads) are coalesced into one flat message.
 
+Payload: gradient routing (utils/prune.py:195-211) zeroes, right after the exchange, every weight-gradient slot the current
+task does not own and every piggymask-gradient slot outside the older tasks' weights.  With a pruner attached
+(`set_gradient_filter`, done by Manager) those slots are not sent at all: the surviving slots of a layer are gathered into a
+dense buffer by cpg_pack_owned (ballot / popcount positions, natural order), that buffer is all-reduced and scattered back
+(from task 2 on a task owns only what earlier tasks released, so most of the 537 MB stays home).
+
 Semantics kept from the reference:
   * loss is the mean over the GLOBAL batch  <=> mean over ranks of equal-size shard means;
   * BatchNorm uses per-replica batch statistics; running stats are rank 0's (sync_buffers());
@@ -40,6 +46,10 @@ class DataParallel(nn.Module):
         # Parameters looked "already hooked" and their gradients were silently left un-reduced.)
         self._token = object()
         self.sync_events = None          # list of (start, end) HIP events around finish_gradient_sync() when timing is on
+        self._filter = None              # SparsePruner whose owner masks say which gradient slots survive routing
+        self.compact_below = 0.5         # compact a layer's gradient when at most this share of its slots survives
+        self.last_payload = {'dense_elems': 0, 'sent_elems': 0}     # per step: what a dense exchange would send / what was sent
+        self._step_payload = {'dense_elems': 0, 'sent_elems': 0}
         # RCCL averages inside the collective; gloo (CPU tests) has no AVG, there the sum is scaled afterwards
         self._avg = self._active and dist.get_backend(process_group) == 'nccl'
         if self._active and broadcast_init:
@@ -56,18 +66,84 @@ class DataParallel(nn.Module):
             if p.requires_grad and getattr(p, '_cpg_dp_token', None) is not self._token:
                 p.register_post_accumulate_grad_hook(self._on_grad)
                 p._cpg_dp_token = self._token
+        # which owner mask governs a parameter: (mask key, select) with select 0 = weight, 1 = piggymask
+        for name, m in self.named_modules():
+            if hasattr(m, 'piggymask') and hasattr(m, 'weight'):
+                m.weight._cpg_mask_key = (name, 0)
+                if m.piggymask is not None:
+                    m.piggymask._cpg_mask_key = (name, 1)
 
     refresh_hooks = _install_hooks
+
+    def set_gradient_filter(self, pruner):
+        """Attach (or, with None, detach) the SparsePruner whose owner masks decide which gradient slots are exchanged.
+        Only safe when gradient routing runs after finish_gradient_sync() -- Manager.train does both."""
+        self._filter = pruner
+
+    def _plan(self, p):
+        """None: exchange the whole gradient.  Otherwise (owner, cur, select, block offsets, total): exchange only the
+        `total` slots that survive routing; total == 0: nothing of this gradient survives."""
+        pr = self._filter
+        key = getattr(p, '_cpg_mask_key', None)
+        if pr is None or key is None or not p.is_cuda or p.dtype != torch.float32:
+            return None
+        name, select = key
+        owner = pr.masks.get(name)
+        mode = getattr(pr.args, 'mode', None)
+        if owner is None or owner.numel() != p.numel() or mode not in ('finetune', 'prune'):
+            return None
+        cur = int(pr.current_dataset_idx)
+        if select == 1 and mode == 'prune':
+            return (owner, cur, select, None, 0)                  # routing zeroes every piggymask gradient in prune mode
+        ckey = (id(owner), owner._version, pr._mutations, cur, select)
+        cached = getattr(p, '_cpg_pack_plan', None)
+        if cached is not None and cached[0] == ckey:
+            return cached[1]
+        from . import _lib
+        import ctypes
+        L = _lib.lib()
+        owner = pr._owner(name, p.data)
+        nblk = int(L.cpg_owned_num_blocks(p.numel()))
+        counts = torch.empty(nblk, dtype=torch.int32, device=p.device)
+        rc = L.cpg_owned_block_counts(_lib.dptr(owner, torch.uint8, 'mask'), cur, select, p.numel(), ctypes.c_void_p(counts.data_ptr()),
+                                      _lib.stream_ptr())
+        _lib.check('cpg_owned_block_counts', rc)
+        ends = torch.cumsum(counts, 0, dtype=torch.int64)
+        total = int(ends[-1].item())                              # one read-back per mask mutation, then cached
+        plan = None if total > self.compact_below * p.numel() else (owner, cur, select, (ends - counts).contiguous(), total)
+        p._cpg_pack_plan = (ckey, plan)
+        return plan
 
     def _on_grad(self, p):
         if p.grad is None:
             return
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        plan = self._plan(p) if self._filter is not None else None
+        self._step_payload['dense_elems'] += p.numel()
+        if plan is not None:
+            owner, cur, select, offsets, total = plan
+            if total == 0:
+                return                                            # routing will zero all of it: nothing to exchange
+            from . import _lib
+            import ctypes
+            g = p.grad
+            if not g.is_contiguous():
+                p.grad = g = g.contiguous()
+            buf = torch.empty(total, dtype=torch.float32, device=g.device)
+            L = _lib.lib()
+            rc = L.cpg_pack_owned(_lib.dptr(g, name='grad'), _lib.dptr(owner, torch.uint8, 'mask'), cur, select, g.numel(),
+                                  ctypes.c_void_p(offsets.data_ptr()), _lib.dptr(buf), _lib.stream_ptr())
+            _lib.check('cpg_pack_owned', rc)
+            self._step_payload['sent_elems'] += total
+            work = dist.all_reduce(buf, op=op, group=self.process_group, async_op=True)
+            self._handles.append((work, buf, (g, owner, cur, select, offsets)))
+            return
+        self._step_payload['sent_elems'] += p.numel()
         if p.numel() >= self.large_numel:
             g = p.grad
             if not g.is_contiguous():
                 p.grad = g = g.contiguous()
-            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-            self._handles.append((dist.all_reduce(g, op=op, group=self.process_group, async_op=True), g))
+            self._handles.append((dist.all_reduce(g, op=op, group=self.process_group, async_op=True), g, None))
         else:
             self._small.append(p)
 
@@ -96,11 +172,19 @@ class DataParallel(nn.Module):
             for g, s in zip(grads, _unflatten_dense_tensors(flat, grads)):
                 g.copy_(s)
             self._small = []
-        for work, g in self._handles:
+        for work, g, packed in self._handles:
             work.wait()
             if not self._avg:
                 g.mul_(inv)
+            if packed is not None:                                # scatter the reduced survivors back into the gradient
+                from . import _lib
+                import ctypes
+                grad, owner, cur, select, offsets = packed
+                rc = _lib.lib().cpg_unpack_owned(_lib.dptr(g), _lib.dptr(owner, torch.uint8, 'mask'), cur, select, grad.numel(),
+                                                 ctypes.c_void_p(offsets.data_ptr()), _lib.dptr(grad, name='grad'), _lib.stream_ptr())
+                _lib.check('cpg_unpack_owned', rc)
         self._handles = []
+        self.last_payload, self._step_payload = self._step_payload, {'dense_elems': 0, 'sent_elems': 0}
         if ev is not None:
             ev[1].record()
             self.sync_events.append(ev)

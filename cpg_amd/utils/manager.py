@@ -58,6 +58,9 @@ class Manager(object):
         self.inference_dataset_idx = root.datasets.index(args.dataset) + 1
         self.pruner = SparsePruner(self.model, masks, self.args, begin_prune_step, end_prune_step,
                                    self.inference_dataset_idx)
+        if hasattr(model, 'set_gradient_filter'):
+            # data parallel: exchange only the gradient slots that survive the routing below (it runs right after the sync)
+            model.set_gradient_filter(self.pruner)
         self.train_loader = train_loader
         self.val_loader = val_loader
         self.progress = bool(getattr(args, 'progress', True)) and tqdm is not None

@@ -144,6 +144,21 @@ int cpg_zero_pruned(float *w, const uint8_t *owner, int64_t n, void *stream);
 /* make_finetuning_mask (:233-243): owner[owner == 0] = new_idx */
 int cpg_claim_free(uint8_t *owner, int32_t new_idx, int64_t n, void *stream);
 
+/* ---- data-parallel payload (reference: nn.DataParallel reduces every gradient, CPG_cifar100_main_normal.py:199) ----
+ * Gradient routing (K4e) zeroes every slot the current task does not own right after the all-reduce, so only the surviving
+ * slots need to cross xGMI: select 0 = owner == cur (weight gradients), select 1 = 0 < owner < cur (piggymask gradients,
+ * finetune mode).  cpg_owned_block_counts writes the number of selected slots of every 1024-element block
+ * (cpg_owned_num_blocks(n) int32 values); the caller turns them into EXCLUSIVE prefix sums (int64, device) -- cacheable
+ * until the owner mask mutates -- and cpg_pack_owned gathers g.flatten()[selected] (natural order) into `packed`,
+ * cpg_unpack_owned scatters it back; unselected slots of g are left untouched.  Owner masks are replicated, so packed
+ * buffers are element-aligned across ranks. */
+int64_t cpg_owned_num_blocks(int64_t n);
+int cpg_owned_block_counts(const uint8_t *owner, int32_t cur, int32_t select, int64_t n, int32_t *counts, void *stream);
+int cpg_pack_owned(const float *g, const uint8_t *owner, int32_t cur, int32_t select, int64_t n, const int64_t *block_offsets,
+                   float *packed, void *stream);
+int cpg_unpack_owned(const float *packed, const uint8_t *owner, int32_t cur, int32_t select, int64_t n,
+                     const int64_t *block_offsets, float *g, void *stream);
+
 /* ---- fused masked SGD step, one layer ----
  * do_weight_decay_and_make_grads_zero (utils/prune.py:203-205) + torch.optim.SGD(lr, momentum, nesterov,
  * dampening 0, weight_decay 0) (CPG_cifar100_main_normal.py:339-340) in one pass over w / gw / momentum / owner:

@@ -36,8 +36,11 @@ def _batches():
     return [(torch.randn(B, 3, 32, 32, generator=g), torch.randint(0, 5, (B,), generator=g)) for _ in range(STEPS)]
 
 
-def _run(rank, world, data_parallel):
-    """3 prune-mode steps (rank-prune events after steps 1 and 2) through Manager.train; returns (weights, masks)."""
+def _run(rank, world, data_parallel, scenario='task1_prune'):
+    """scenario 'task1_prune': 3 prune-mode steps (rank-prune events after steps 1 and 2) through Manager.train.
+    scenario 'task2_finetune': task 2 of two -- 70 % of the slots belong to task 1 (frozen, picked through piggymasks), the free
+    ones are claimed and trained; MaskedSGD + MaskedAdam; the data-parallel exchange sends only the slots that survive routing.
+    Returns (weights, masks, wrapper active, payload of the last step)."""
     import torch.nn as nn
     import cpg_amd.models as M
     from cpg_amd import dist as cdist
@@ -56,23 +59,49 @@ def _run(rank, world, data_parallel):
             m.eval()
             m.train = lambda mode=True, _m=m: _m
     model = cdist.DataParallel(net, large_numel=1 << 12) if data_parallel else _Wrap(net)
-    masks = {n: torch.ones(m.weight.shape, dtype=torch.uint8, device=dev) for n, m in model.named_modules()
-             if isinstance(m, (nl.SharableConv2d, nl.SharableLinear))}
-    args = types.SimpleNamespace(mode='prune', dataset='t1', finetune_again=False, target_sparsity=0.3, initial_sparsity=0.0,
-                                 pruning_frequency=1, weight_decay=4e-5, network_width_multiplier=WIDTH, cuda=True, log_path=None,
-                                 progress=False)
     loader = []
     for x, t in _batches():
         xs, ts = cdist.shard_batch(x, t, rank, world)
         loader.append((xs.to(dev), ts.to(dev)))
-    mgr = Manager(args, model, {}, masks, loader, None, 0, 2)
-    opts = Optimizers()
-    opts.add(MaskedSGD(list(model.parameters()), pruner=mgr.pruner, lr=1e-2, momentum=0.9, nesterov=True), 1e-2)
-    mgr.train(opts, 0, [1e-2], 0)
-    assert mgr.pruner.prune_events == 2
+    names = [(n, m) for n, m in model.named_modules() if isinstance(m, (nl.SharableConv2d, nl.SharableLinear))]
+    if scenario == 'task1_prune':
+        masks = {n: torch.ones(m.weight.shape, dtype=torch.uint8, device=dev) for n, m in names}
+        args = types.SimpleNamespace(mode='prune', dataset='t1', finetune_again=False, target_sparsity=0.3, initial_sparsity=0.0,
+                                     pruning_frequency=1, weight_decay=4e-5, network_width_multiplier=WIDTH, cuda=True, log_path=None,
+                                     progress=False)
+        mgr = Manager(args, model, {}, masks, loader, None, 0, 2)
+        opts = Optimizers()
+        opts.add(MaskedSGD(list(model.parameters()), pruner=mgr.pruner, lr=1e-2, momentum=0.9, nesterov=True), 1e-2)
+        mgr.train(opts, 0, [1e-2], 0)
+        assert mgr.pruner.prune_events == 2
+    else:
+        from torch.nn.parameter import Parameter
+        from cpg_amd.utils.fused_sgd import MaskedAdam
+        net.add_dataset('t2', 5)
+        net.set_dataset('t2')
+        net.classifiers.to(dev)
+        g = torch.Generator().manual_seed(5)
+        masks = {n: (torch.rand(m.weight.shape, generator=g) < 0.7).to(torch.uint8).to(dev) for n, m in names}      # 1 = task 1, 0 = free
+        for n, m in names:
+            m.piggymask = Parameter(torch.full_like(m.weight.detach(), 0.01))
+        if hasattr(model, 'refresh_hooks'):
+            model.refresh_hooks()
+            model.compact_below = 0.9                      # also compact the piggymask gradients (70 % of their slots survive)
+        args = types.SimpleNamespace(mode='finetune', dataset='t2', finetune_again=False, target_sparsity=0.3, initial_sparsity=0.0,
+                                     pruning_frequency=1, weight_decay=4e-5, network_width_multiplier=WIDTH, cuda=True, log_path=None,
+                                     progress=False)
+        mgr = Manager(args, model, {}, masks, loader, None, 0, 0)
+        mgr.pruner.make_finetuning_mask()                  # free slots -> task 2
+        assert mgr.pruner.current_dataset_idx == 2
+        sgd = [p for n, p in model.named_parameters() if 'piggymask' not in n and 'classifiers.0.' not in n]
+        adam = [p for n, p in model.named_parameters() if 'piggymask' in n]
+        opts = Optimizers()
+        opts.add(MaskedSGD(sgd, pruner=mgr.pruner, lr=1e-2, momentum=0.9, nesterov=True), 1e-2)
+        opts.add(MaskedAdam(adam, pruner=mgr.pruner, lr=5e-4), 5e-4)
+        mgr.train(opts, 0, [1e-2, 5e-4], 0)
     torch.cuda.synchronize()
     return ({k: v.detach().cpu() for k, v in net.state_dict().items()}, {k: v.cpu() for k, v in masks.items()},
-            bool(getattr(model, '_active', False)))
+            bool(getattr(model, '_active', False)), dict(getattr(model, 'last_payload', {})))
 
 
 class _Wrap(torch.nn.Module):
@@ -84,31 +113,51 @@ class _Wrap(torch.nn.Module):
         return self.module(x)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, scenario):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        sd, masks, active = _run(rank, world, True)
+        sd, masks, active, payload = _run(rank, world, True, scenario)
         assert active
-        torch.save({'sd': sd, 'masks': masks}, os.path.join(out_dir, 'rank%d.pt' % rank))
+        torch.save({'sd': sd, 'masks': masks, 'payload': payload}, os.path.join(out_dir, 'rank%d.pt' % rank))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_hip_model_masked_sgd_prune_match_single_process(tmp_path):
+def _two_ranks(tmp_path, scenario):
     import torch.multiprocessing as mp
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), scenario), nprocs=world, join=True)
     r0 = torch.load(os.path.join(tmp_path, 'rank0.pt'))
     r1 = torch.load(os.path.join(tmp_path, 'rank1.pt'))
     for k in r0['sd']:
         assert torch.equal(r0['sd'][k], r1['sd'][k]), 'ranks diverged in %s' % k
     for k in r0['masks']:
         assert torch.equal(r0['masks'][k], r1['masks'][k]), 'ranks diverged in mask %s' % k
-    sd, masks, _ = _run(0, 1, False)                       # one process, the full batch
+    return r0
+
+
+def test_two_ranks_task2_piggymasks_compacted_gradient_exchange(tmp_path):
+    """Task 2 under data parallelism: only the gradient slots that survive routing are exchanged (cpg_pack_owned), and the
+    result still equals one process on the full batch -- weights of task 1 untouched, task-2 slots and piggymasks trained."""
+    r0 = _two_ranks(tmp_path, 'task2_finetune')
+    pay = r0['payload']
+    assert 0 < pay['sent_elems'] < 0.75 * pay['dense_elems'], pay          # ~30 % of the weight slots + ~70 % of the piggymask slots
+    sd, masks, _, _ = _run(0, 1, False, 'task2_finetune')
+    for k, v in sd.items():
+        if v.dtype.is_floating_point:
+            a, b = r0['sd'][k].numpy(), v.numpy()
+            np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-6 * (float(np.abs(b).max()) + 1e-30), err_msg=k)
+    for k in masks:
+        assert torch.equal(r0['masks'][k], masks[k]), k
+
+
+def test_two_ranks_hip_model_masked_sgd_prune_match_single_process(tmp_path):
+    r0 = _two_ranks(tmp_path, 'task1_prune')
+    sd, masks, _, _ = _run(0, 1, False)                    # one process, the full batch
     for k, v in sd.items():
         if v.dtype.is_floating_point:
             a, b = r0['sd'][k].numpy(), v.numpy()

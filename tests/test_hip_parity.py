@@ -379,6 +379,38 @@ def test_mask_kernels_ragged_sizes_vs_oracle():
         np.testing.assert_array_equal(masks['module.conv'].cpu().numpy(), ops.claim_free(owner.numpy(), 4))
 
 
+@pytest.mark.parametrize('n', [1, 3, 1023, 1024, 1025, 70_001, 3_000_001])
+@pytest.mark.parametrize('select', [0, 1])
+def test_gradient_pack_unpack_equals_boolean_indexing(n, select):
+    """cpg_owned_block_counts / cpg_pack_owned / cpg_unpack_owned (the data-parallel payload compaction): packed ==
+    g[selected] in natural order, the scatter restores exactly the selected slots and leaves the others alone."""
+    import ctypes
+    from cpg_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(n + select)
+    owner = torch.randint(0, 4, (n,), generator=g, dtype=torch.uint8).to(DEV)
+    grad = torch.randn(n, generator=g).to(DEV)
+    cur = 2
+    sel = (owner == cur) if select == 0 else ((owner > 0) & (owner < cur))
+    nblk = int(lib.cpg_owned_num_blocks(n))
+    assert nblk == (n + 1023) // 1024
+    counts = torch.empty(nblk, dtype=torch.int32, device=DEV)
+    s = L.stream_ptr()
+    L.check('counts', lib.cpg_owned_block_counts(L.dptr(owner, torch.uint8), cur, select, n, ctypes.c_void_p(counts.data_ptr()), s))
+    want_counts = torch.nn.functional.pad(sel.int(), (0, nblk * 1024 - n)).view(nblk, 1024).sum(1).int()
+    assert torch.equal(counts, want_counts)
+    ends = torch.cumsum(counts, 0, dtype=torch.int64)
+    offs = (ends - counts).contiguous()
+    total = int(ends[-1])
+    assert total == int(sel.sum())
+    packed = torch.full((max(total, 1),), float('nan'), device=DEV)
+    L.check('pack', lib.cpg_pack_owned(L.dptr(grad), L.dptr(owner, torch.uint8), cur, select, n, ctypes.c_void_p(offs.data_ptr()), L.dptr(packed), s))
+    assert torch.equal(packed[:total], grad[sel])
+    out = torch.full((n,), -7.0, device=DEV)
+    L.check('unpack', lib.cpg_unpack_owned(L.dptr(packed * 2), L.dptr(owner, torch.uint8), cur, select, n, ctypes.c_void_p(offs.data_ptr()), L.dptr(out), s))
+    assert torch.equal(out[sel], grad[sel] * 2) and bool((out[~sel] == -7.0).all())
+
+
 def test_owner_id_uint8_extremes_vs_oracle():
     """Owner ids are uint8 (torch.ByteTensor masks): the last representable task (255) and its neighbours through
     routing, statistics, apply_mask, rank prune and claim -- raw C ABI against the oracle."""
@@ -627,7 +659,10 @@ def test_train_steps_golden(arch):
         out = model(xs[s])
         loss = crit(out, ts[s])
         loss.backward()
-        rt = 1e-4 if s == 0 else 1e-3                        # step 0: identical weights; later: two training runs
+        # step 0: identical weights.  Later steps compare two training runs: SphereNet stays within 1e-3; the ResNet forward
+        # amplifies a relative perturbation ~300x by layer4 (fp32 round-off 6e-8 -> 2e-5 there, measured), so weights that differ
+        # by 1e-5 of their scale after one update (the 0.5 % gradient band above x lr) move the logits by a few 1e-3
+        rt = 1e-4 if s == 0 else (1e-2 if arch == 'resnet50' else 1e-3)
         o1 = out[0] if isinstance(out, tuple) else out
         sc = float(np.abs(g['logits'][s]).max())
         close(o1, g['logits'][s], rtol=rt, atol=rt * sc, msg='%s logits step %d' % (arch, s))
