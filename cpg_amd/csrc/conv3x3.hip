@@ -58,10 +58,17 @@ __device__ __forceinline__ f32x4 ld_sv4(const float *sbase, unsigned byte_off) {
 
 // Inference-mode BatchNorm (+ ReLU) folded into the forward epilogue: y = [max(0,] (acc + bias - mean) * invstd * gamma + beta [)]
 // with invstd = 1 / sqrt(var + eps) -- the expression of bn_kernels.hip's apply pass.  gamma == nullptr: plain conv.
+// `live` (may be null; inference only): liveness of the effective weights, written by k_c3_pack -- live[m] != 0 when output
+// channel m has a non-zero weight, live[Mp] = 1 + the last input channel with a non-zero weight, live[Mp + 1] counts the
+// output tiles that were skipped (diagnostics).  A block whose BM output channels are all dead skips its MFMA loop (their
+// conv output is exactly 0, the epilogue still writes bias / BatchNorm of 0), and every block stops after the last live
+// input-channel chunk.  Whole channels die when a model that was GROWN for later tasks serves an earlier, narrower task
+// after apply_mask (every slot with owner > task is zero): the kernel then does the work of the cropped model.
 struct C3BnEval {
     const float *gamma, *beta, *mean, *var;
     float eps;
     int relu;
+    int *live;
 };
 
 struct C3Geom {
@@ -112,7 +119,8 @@ struct C3Cfg {
 // costs microseconds; rocprof PMC showed the alternative -- gathering W[co][ci][tap] inside the conv
 // kernel -- at 13.4 VALU instructions per MFMA and 57 % MFMA utilisation (profiles/r01c_pmc.md).
 __global__ __launch_bounds__(256) void k_c3_pack(const float *__restrict__ w, const float *__restrict__ pm, float thr,
-                                                 float *__restrict__ out, int K, int C, int rows_c, int Mp, int dgrad) {
+                                                 float *__restrict__ out, int K, int C, int rows_c, int Mp, int dgrad,
+                                                 int *__restrict__ live) {
     // out index o = (c*9 + tp) * Mp + m ; consecutive threads -> consecutive m (coalesced writes)
     const int64_t total = (int64_t)rows_c * 9 * Mp;
     const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
@@ -128,6 +136,15 @@ __global__ __launch_bounds__(256) void k_c3_pack(const float *__restrict__ w, co
             if (pm != nullptr) v *= binarize(pm[off], thr);
         }
         out[o] = v;
+        // liveness (forward flavour, zeroed by the caller): columns are posted by the lanes that hold a non-zero (plain
+        // stores of 1: benign race); rows by ONE lane per wave -- c is non-decreasing in o, so the wave's largest live input
+        // channel belongs to its highest lane with a non-zero (ballot + count-leading-zeros)
+        if (live != nullptr) {
+            const bool nz = v != 0.0f;
+            if (nz) live[m] = 1;
+            const unsigned long long any = __ballot(nz);
+            if (any != 0ull && (int)(threadIdx.x & 63) == 63 - __clzll((long long)any)) atomicMax(&live[Mp], c + 1);
+        }
     }
 }
 
@@ -238,7 +255,15 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[fm][fn][e] = 0.0f;
 
-    const int nch_all = (g.C + Cfg::CK - 1) / Cfg::CK;
+    int nch_all = (g.C + Cfg::CK - 1) / Cfg::CK;
+    if (!DGRAD && !STATS && !SPLITK && bn.live != nullptr) {                      // inference: skip what apply_mask killed
+        int alive = 0;
+        for (int i = lane; i < Cfg::BM; i += 64) alive |= (m0 + i < g.M) ? bn.live[m0 + i] : 0;
+        const bool dead = __ballot(alive != 0) == 0ull;                          // wave-uniform; same answer in all 4 waves
+        const int c_live = bn.live[g.Mp];                                        // 1 + last input channel with a non-zero weight
+        nch_all = dead ? 0 : min(nch_all, (c_live + Cfg::CK - 1) / Cfg::CK);
+        if (dead && tid == 0) atomicAdd(&bn.live[g.Mp + 1], 1);
+    }
     const int per_split = SPLITK ? (nch_all + g.ksplit - 1) / g.ksplit : nch_all;
     const int ch0 = ksp * per_split, nch = min(nch_all, ch0 + per_split);        // this block's chunks: [ch0, nch)
 #pragma unroll
@@ -748,14 +773,16 @@ using CfgP28 = C3Cfg<128, 4, 28, 4, 1, 4, 2, 2>;   // 28-wide maps: a 4 x 28 str
 
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 // packed-weight workspace: [roundup(C_read, 4) * 9 (+ 16 rows of slack the last float4 staging pass may read)][roundup(M, 128)] floats
-inline size_t pack_bytes(int c_read, int m) { return ((size_t)pad_to(c_read, 4) * 9 + 16) * pad_to(m, 128) * sizeof(float); }
+inline size_t pack_floats(int c_read, int m) { return ((size_t)pad_to(c_read, 4) * 9 + 16) * pad_to(m, 128); }
+// ... followed by the liveness words of the inference path: live[Mp], last live input channel + 1, skipped-tile counter, pad
+inline size_t pack_bytes(int c_read, int m) { return (pack_floats(c_read, m) + pad_to(m, 128) + 4) * sizeof(float); }
 
 // stats != nullptr: forward with fused BatchNorm statistics.  tiles_out (optional) receives the number of pixel tiles;
 // dry: only compute it.
 template <class Cfg>
 int launch_fwd(C3Geom g, const float *x, const float *wp, const float *bias, float *y, hipStream_t stream, const char *what,
                float *stats = nullptr, int *tiles_out = nullptr, bool dry = false, const C3BnEval *bnp = nullptr) {
-    const C3BnEval bn = bnp ? *bnp : C3BnEval{nullptr, nullptr, nullptr, nullptr, 0.0f, 0};
+    const C3BnEval bn = bnp ? *bnp : C3BnEval{nullptr, nullptr, nullptr, nullptr, 0.0f, 0, nullptr};
     g.tiles_x = (g.W + Cfg::TW - 1) / Cfg::TW;
     g.tiles_y = (g.H + Cfg::TH - 1) / Cfg::TH;
     g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
@@ -796,8 +823,20 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
         const size_t need = pack_bytes(c_read, m);
         if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
         CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
+        int *live = nullptr;
+        if (bn != nullptr && bn->live != nullptr) {          // (bn->live is only a request flag here; the words live in the workspace)
+            live = reinterpret_cast<int *>(wp + pack_floats(c_read, m));
+            hipError_t e = hipMemsetAsync(live, 0, (size_t)(Mp + 4) * sizeof(int), stream);
+            if (e != hipSuccess) return hip_status(e, what);
+        }
         hipLaunchKernelGGL(k_c3_pack, dim3(stream_grid((int64_t)rows_c * 9 * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, K, C,
-                           rows_c, Mp, dgrad ? 1 : 0);
+                           rows_c, Mp, dgrad ? 1 : 0, live);
+    }
+    C3BnEval bn_local;
+    if (bn != nullptr) {
+        bn_local = *bn;
+        bn_local.live = (bn->live != nullptr && !dry) ? reinterpret_cast<int *>(wp + pack_floats(c_read, m)) : nullptr;
+        bn = &bn_local;
     }
     C3Geom g{N, c_read, H, W, m, Mp, 0, 0, 0, dgrad ? 1 : 0, 1};
     if (const char *f = getenv("CPG_C3_FORCE")) {        // A/B experiments only (tools/conv_bench.py --ab)
@@ -875,11 +914,25 @@ int cpg_conv3x3_fwd_bnstats(const cpg_conv_desc *d, const float *x, const float 
 // forward with the inference-mode BatchNorm (+ ReLU) that follows the conv folded into the epilogue (Manager.validate's path)
 int cpg_conv3x3_fwd_bn_eval(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
                             const float *gamma, const float *beta, const float *mean, const float *var, float eps, int relu, float *y,
-                            void *ws, size_t ws_bytes, hipStream_t stream) {
+                            int32_t *skip_stats, void *ws, size_t ws_bytes, hipStream_t stream) {
     CPG_REQUIRE(x && w && y && gamma && beta && mean && var, "cpg_conv2d_fwd_bn_eval: null pointer");
-    const C3BnEval bn{gamma, beta, mean, var, eps, relu};
-    return run_fwd(false, d->N, d->C, d->K, d->H, d->W, d->K, d->C, x, w, pm, thr, bias, y, ws, ws_bytes, stream, nullptr, nullptr, false,
-                   &bn);
+    static int dummy;
+    const bool skip = getenv("CPG_NO_DEAD_SKIP") == nullptr;
+    const C3BnEval bn{gamma, beta, mean, var, eps, relu, skip ? &dummy : nullptr};
+    int rc = run_fwd(false, d->N, d->C, d->K, d->H, d->W, d->K, d->C, x, w, pm, thr, bias, y, ws, ws_bytes, stream, nullptr, nullptr, false,
+                     &bn);
+    if (rc == CPG_OK && skip_stats != nullptr) {
+        // {1 + last live input channel, output tiles skipped}: device-to-device copy of the two words behind live[Mp]
+        if (skip) {
+            const int *live = reinterpret_cast<const int *>((const float *)ws + pack_floats(d->C, d->K));
+            hipError_t e = hipMemcpyAsync(skip_stats, live + pad_to(d->K, 128), 2 * sizeof(int), hipMemcpyDeviceToDevice, stream);
+            if (e != hipSuccess) return hip_status(e, "cpg_conv2d_fwd_bn_eval");
+        } else {
+            hipError_t e = hipMemsetAsync(skip_stats, 0, 2 * sizeof(int), stream);
+            if (e != hipSuccess) return hip_status(e, "cpg_conv2d_fwd_bn_eval");
+        }
+    }
+    return rc;
 }
 
 int cpg_conv3x3_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx, void *ws,

@@ -525,7 +525,7 @@ int cpg_conv3x3_fwd_bnstats(const cpg_conv_desc *d, const float *x, const float 
                             float *y, float *stats, void *ws, size_t ws_bytes, hipStream_t stream);
 int cpg_conv3x3_fwd_bn_eval(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
                             const float *gamma, const float *beta, const float *mean, const float *var, float eps, int relu, float *y,
-                            void *ws, size_t ws_bytes, hipStream_t stream);
+                            int32_t *skip_stats, void *ws, size_t ws_bytes, hipStream_t stream);
 // ... and the pointwise kernels (pointwise.hip) for 1x1 convolutions (forward and input gradient)
 extern "C" int cpg_conv1x1_supported(const cpg_conv_desc *d);
 size_t cpg_conv1x1_pack_workspace(const cpg_conv_desc *d);
@@ -661,14 +661,14 @@ extern "C" int32_t cpg_conv2d_fwd_bn_eval_supported(const cpg_conv_desc *d) {
 }
 extern "C" int cpg_conv2d_fwd_bn_eval(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr,
                                       const float *bias, const float *gamma, const float *beta, const float *running_mean,
-                                      const float *running_var, float eps, int32_t relu, float *y, void *ws, size_t ws_bytes,
-                                      void *stream) {
+                                      const float *running_var, float eps, int32_t relu, float *y, int32_t *skip_stats, void *ws,
+                                      size_t ws_bytes, void *stream) {
     ConvGeom g;
     int rc = make_geom(d, g);
     if (rc) return rc;
     if (!cpg_conv3x3_supported(d)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_fwd_bn_eval: only the 3x3 s1 p1 kernels fuse the epilogue");
-    return cpg_conv3x3_fwd_bn_eval(d, x, w, pm, thr, bias, gamma, beta, running_mean, running_var, eps, relu, y, ws, ws_bytes,
-                                   (hipStream_t)stream);
+    return cpg_conv3x3_fwd_bn_eval(d, x, w, pm, thr, bias, gamma, beta, running_mean, running_var, eps, relu, y, skip_stats, ws,
+                                   ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int cpg_conv2d_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr,

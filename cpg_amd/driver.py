@@ -304,13 +304,16 @@ class CPGSession(object):
             va = mgr.validate(epoch)
         return mgr, tr, va
 
-    def evaluate(self, dataset, val_loader):
+    def evaluate(self, dataset, val_loader, crop=True):
         """`--mode inference` on any task learned so far (CPG_cifar100_main_normal.py:165-166,233-249 +
         utils/manager.py:266-320): a model of THAT task's width, the shared weights cropped into it, the task's own
         BatchNorm / bias / PReLU / piggymask tensors attached, owner masks cropped, then Manager.validate (apply_mask with
-        the task's index).  The live training model is not touched.  Returns (accuracy, logits of every batch)."""
+        the task's index).  The live training model is not touched.  Returns (accuracy, logits of every batch).
+        crop=False serves the task from a model of the CURRENT (grown) width instead -- what a server that keeps one
+        resident network for all tasks does: apply_mask zeroes every slot of later tasks, the inference conv kernels skip
+        the channels that died with them (cpg_conv2d_fwd_bn_eval), and the head reads the task's own share of the features."""
         info = self.shared_layer_info[dataset]
-        width = info.get('network_width_multiplier', self.width)
+        width = info.get('network_width_multiplier', self.width) if crop else self.width
         saved_info = self.shared_layer_info
         net = self._build(width, list(self.net.datasets), dict(self.net.dataset2num_classes)).to(self.device)
         net.set_dataset(dataset)

@@ -260,6 +260,8 @@ class FusedSequential(nn.Sequential):
     fuse_pool = True
     fuse_stats = True       # conv -> BatchNorm2d: the conv kernel's epilogue produces the batch-statistics partial sums
     fuse_eval = True        # inference: conv -> BatchNorm2d(eval) -> ReLU as one kernel (BatchNorm folded into the conv epilogue)
+    skip_log = None         # diagnostics: set to a list to collect one int32[2] tensor per fused inference conv --
+    #                         {1 + last live input channel, output tiles skipped by the dead-channel test}
 
     def forward(self, input):
         mods = list(self._modules.values())
@@ -290,8 +292,13 @@ class FusedSequential(nn.Sequential):
                     and not (self.fuse_pool and i + 3 < n and _is_pool2(mods[i + 3]))):
                 # (a following MaxPool2d keeps the conv + fused BN/ReLU/pool pair: same HBM traffic, and the un-pooled
                 # activation is never written either way)
-                y = m.forward_bn_eval(input, nxt, relu=True)
+                st = None
+                if self.skip_log is not None:
+                    st = torch.zeros(2, dtype=torch.int32, device=input.device)
+                y = m.forward_bn_eval(input, nxt, relu=True, skip_stats=st)
                 if y is not None:
+                    if st is not None:
+                        self.skip_log.append(st)
                     input, stats = y, None
                     i += 3
                     continue

@@ -252,10 +252,11 @@ class SharableConv2d(_Sharable):
                                          self.stride, self.padding, self.dilation, self.groups, True)
         return y, (stats if stats.numel() else None)
 
-    def forward_bn_eval(self, input, bn, relu=True):
+    def forward_bn_eval(self, input, bn, relu=True, skip_stats=None):
         """relu(bn(conv(input))) with `bn` an eval-mode nn.BatchNorm2d, as ONE kernel (cpg_conv2d_fwd_bn_eval): the path of
         Manager.validate.  Inference only -- call it under torch.no_grad(); returns None when this shape has no fused
-        kernel (the caller then runs the layers one by one)."""
+        kernel (the caller then runs the layers one by one).  skip_stats: optional int32[2] device tensor that receives
+        {1 + last live input channel, output tiles skipped} (dead-channel skip, see include/cpg_hip.h)."""
         if torch.is_grad_enabled() or input.dim() != 4 or input.shape[0] == 0 or input.shape[1] != self.weight.shape[1] * self.groups:
             return None
         x = input.contiguous()
@@ -272,6 +273,7 @@ class SharableConv2d(_Sharable):
                                       float(self.info['threshold']), _lib.dptr(self.bias, name='bias'), _lib.dptr(bn.weight, name='bn.weight'),
                                       _lib.dptr(bn.bias, name='bn.bias'), _lib.dptr(bn.running_mean, name='running_mean'),
                                       _lib.dptr(bn.running_var, name='running_var'), float(bn.eps), int(bool(relu)), _lib.dptr(y),
+                                      None if skip_stats is None else ctypes.c_void_p(skip_stats.data_ptr()),
                                       _lib.dptr(ws), nbytes, _lib.stream_ptr())
         _lib.check('cpg_conv2d_fwd_bn_eval', rc)
         return y

@@ -82,7 +82,13 @@ class VGG(nn.Module):
                     nn.init.normal_(m.weight, 0, 0.01)
 
     def forward(self, x):
-        return self.classifier(self.features(x))
+        f = self.features(x)
+        n_in = getattr(self.classifier, 'in_features', None)
+        if n_in is not None and f.dim() == 2 and f.shape[1] > n_in:
+            # an earlier (narrower) task served from the grown network without cropping it: its head reads the first
+            # 4096 * (its width) features; the rest belong to channels that apply_mask zeroed for this task
+            f = f[:, :n_in]
+        return self.classifier(f)
 
     def _initialize_weights(self):
         # same traversal order and distributions as models/vgg.py:59-70 (RNG parity)

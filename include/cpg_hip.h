@@ -212,12 +212,19 @@ int cpg_bn_stats_finalize(const float *stats, int32_t tiles, int32_t N, int32_t 
  * eval mode (-> ReLU) of models/vgg.py:137-141 as ONE kernel -- y = [max(0,] (conv(x, W_eff) + bias - running_mean) /
  * sqrt(running_var + eps) * gamma + beta [)] applied in the conv epilogue, so the raw conv output is never written and no
  * BatchNorm kernel runs.  cpg_conv2d_fwd_bn_eval_supported(desc) == 0: shape has no fused path (use cpg_conv2d_fwd +
- * cpg_bn_relu_fwd_eval).  No gradient counterpart: callers use it under torch.no_grad() only. */
+ * cpg_bn_relu_fwd_eval).  No gradient counterpart: callers use it under torch.no_grad() only.
+ * Dead channels are skipped: after apply_mask (utils/prune.py:223-231) every slot with owner 0 or > the inference task is
+ * zero, so a network that was GROWN for later tasks (CPG_cifar100_main_normal.py:208-232) carries whole output channels and
+ * trailing input channels that are zero for an earlier task.  The weight-pack pass records per-channel liveness (wave
+ * ballots), a block whose output channels are all dead skips its MFMA loop (conv output exactly 0 -> it writes BatchNorm(bias))
+ * and every block stops after the last live input channel: serving an old task from the resident wide model costs what
+ * the reference's cropped model (CPG_cifar100_main_normal.py:233-249) costs.  skip_stats (device, may be NULL) receives
+ * {1 + last live input channel, number of output tiles skipped}. */
 int32_t cpg_conv2d_fwd_bn_eval_supported(const cpg_conv_desc *desc);
 int cpg_conv2d_fwd_bn_eval(const cpg_conv_desc *desc, const float *x, const float *w, const float *piggymask, float threshold,
                            const float *bias, const float *gamma, const float *beta, const float *running_mean,
-                           const float *running_var, float eps, int32_t relu, float *y, void *workspace, size_t workspace_bytes,
-                           void *stream);
+                           const float *running_var, float eps, int32_t relu, float *y, int32_t *skip_stats, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 /* y = relu(bn(x) + res): the tail of a residual block (models/resnet.py:69-74 `out = self.bn3(out); out += identity;
  * out = self.relu(out)`).  train != 0: batch statistics (mean / invstd out, running stats updated); train == 0: `mean`

@@ -142,3 +142,36 @@ def test_growth_pads_masks_keeps_old_weights_and_old_task_logits(tmp_path):
     assert acc1c == acc1
     for a_, b_ in zip(logits1, logits1c):
         assert torch.equal(a_, b_), 'task-1 logits changed through a checkpoint round trip'
+
+
+def test_serving_old_task_from_grown_network_skips_dead_channels():
+    """One resident wide network for all tasks: task 1 (learnt at width 0.5) evaluated on the network grown to 1.0 for task 2.
+    apply_mask kills every slot of task 2 -> half of every layer's output channels and the trailing half of its input channels
+    are dead; the inference conv kernels skip them (tile / chunk skip counters) and the logits equal the cropped model's."""
+    from cpg_amd.models.fused_bn import FusedSequential
+    sess, args = _session(0.5)
+    tr1, va1 = _loaders(0)
+    sess.run_task('t1', 5, tr1, va1, accuracy_goal=0.0, finetune_epochs=1, prune_epochs=1, sparsities=(0.5,), args=args,
+                  min_train_acc=-1.0)
+    tr2, va2 = _loaders(1)
+    sess.run_task('t2', 5, tr2, va2, accuracy_goal=2.0, finetune_epochs=1, prune_epochs=1, sparsities=(0.3,), args=args,
+                  min_train_acc=-1.0, max_width=1.0, width_step=0.5, retrain_epochs=1, total_num_tasks=2)
+    assert sess.width == 1.0
+    acc_c, logits_c = sess.evaluate('t1', va1)                       # the reference's way: a cropped width-0.5 model
+    FusedSequential.skip_log = []
+    try:
+        acc_w, logits_w = sess.evaluate('t1', va1, crop=False)       # the resident width-1.0 model
+        log = [t.cpu().tolist() for t in FusedSequential.skip_log]
+    finally:
+        FusedSequential.skip_log = None
+    assert acc_w == acc_c
+    for a, b in zip(logits_c, logits_w):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(a.abs().max()))
+    assert log, 'no fused inference conv ran'
+    skipped = sum(s for _, s in log)
+    assert skipped > 0, log                                            # whole output tiles were skipped ...
+    widths = [c for c, _ in log]
+    # ... and every layer after the stem stopped at the last live input channel = the width-0.5 channel count
+    names = [m for m in sess.net.features if hasattr(m, 'piggymask') and getattr(m, 'kernel_size', None) == (3, 3)]
+    per_call = {m.in_channels: None for m in names}
+    assert any(c > 0 and c <= max(per_call) // 2 for c in widths), (widths, sorted(per_call))
