@@ -1,0 +1,289 @@
+// OPT-IN bf16 MFMA path of the masked 3x3 / stride 1 / pad 1 convolution (north_star: "MFMA fp32/bf16 GEMM").
+//
+// Never the default and never the headline number: the reference computes in fp32 and north_star's parity bar (logits
+// within 1e-4) is an fp32 bar, which the fp32 kernels of conv3x3.hip meet.  This path trades it for the 16x higher
+// MFMA rate of v_mfma_f32_32x32x16_bf16: activations and effective weights are ROUNDED TO bf16 (8-bit mantissa, round to
+// nearest even) on their way into LDS, products are exact, accumulation is fp32 -- the arithmetic of torch autocast(bf16)
+// convolutions.  Its own tolerance (tests: 2e-2 of the output scale against the fp32 oracle, 1e-6 against an oracle fed
+// the same bf16-rounded operands) and its own roofline (2.5 PFLOP/s dense bf16) apply; tensors in HBM stay fp32 NCHW, so
+// nothing else in the framework changes and the two paths can be mixed per call.
+//
+// forward + input gradient (one kernel; as in conv3x3.hip only the packed weights differ):
+//   k_c3b_pack writes the effective weights W * bin(piggymask) as bf16 in the order the kernel's LDS wants them,
+//       Wp[chunk of 16 channels][tap][half h][m][8 channels 16*chunk + 8*h ...]      (one uint4 = 8 bf16 per (.., m))
+//   Block = BM output channels x (TH x TW) pixels of one image; loop over input channels in chunks of 16.  Per chunk the
+//   block stages
+//       Ws[9][2][BM]  uint4      a straight copy of the packed rows (global_load_dwordx4 -> ds_write_b128)
+//       Xs[2][PH*PW]  uint4      the zero-padded (TH+2) x (TW+2) patch, channel-last in groups of 8: a thread loads the 8
+//                                channels of one (pixel, half) with range-checked buffer loads (zero padding and the
+//                                channel tail cost no select), converts (v_cvt_pk_bf16_f32) and writes ONE ds_write_b128
+//   into the other LDS stage while the MFMAs of the current chunk run.  One k-step = (tap, 16 channels): lanes 0-31 hold
+//   channels 0-7, lanes 32-63 channels 8-15 of A (row = output channel) and B (column = pixel); both operand reads are one
+//   ds_read_b128 per fragment whose 16 consecutive lanes cover 256 contiguous bytes (conflict free).
+//   Work per staged byte is 16x lower than in the fp32 kernel, so this kernel is bound by L2 / HBM delivery of the patch
+//   and the packed weights on most VGG layers, not by the matrix pipe (DESIGN.md section 4.6 has the measurements).
+#include <algorithm>
+#include "igemm_core.h"
+
+using namespace cpg;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v;
+    v[0] = (__bf16)lo;          // round to nearest even; the compiler pairs the two conversions into one v_cvt_pk_bf16_f32
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+struct B16Geom {
+    int N, C, H, W, M;        // C: channels read, M: channels produced
+    int Mp;                   // M rounded up to 128 (row length of the packed weights, in uint4)
+    int tiles_x, tiles_y, tiles_m, nchunks;
+};
+
+template <int BM_, int TH_, int TW_, int WM_, int WN_, int MINB_>
+struct B16Cfg {
+    static constexpr int BM = BM_, TH = TH_, TW = TW_, WM = WM_, WN = WN_, MINB = MINB_;
+    static constexpr int BN = TH * TW;
+    static_assert(WM * WN == 4 && BN % (32 * WN) == 0 && BM % (32 * WM) == 0, "bad bf16 conv config");
+    static constexpr int FM = BM / 32 / WM, FN = BN / 32 / WN;
+    static constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW;
+    static constexpr int NPIXP = (NPIX + 15) / 16 * 16;       // plane of one channel half, multiple of 256 bytes
+    static constexpr int WQ = 9 * 2 * BM;                     // uint4 per stage: weights
+    static constexpr int XQ = 2 * NPIXP;                      //                  patch
+    static constexpr int STAGEQ = WQ + XQ;
+    static constexpr int NWI = (WQ + 255) / 256;              // weight uint4 per thread per chunk
+    static constexpr int NXI = (2 * NPIX + 255) / 256;        // (pixel, half) items per thread per chunk
+};
+
+// ------------------------------------------------------------------------------ weight pack
+// out[((chunk * 9 + tap') * 2 + h) * Mp + m] = 8 bf16: channels 16 * chunk + 8 * h + j (j = 0..7) of
+//   fwd  : W[co = m][ci = c][tap = tap'] * bin(pm)
+//   dgrad: W[co = c][ci = m][tap = 8 - tap'] * bin(pm)        (conv of gy with the spatially flipped, transposed filter)
+__global__ __launch_bounds__(256) void k_c3b_pack(const float *__restrict__ w, const float *__restrict__ pm, float thr,
+                                                  u32x4 *__restrict__ out, int K, int C, int nchunks, int Mp, int dgrad) {
+    const int64_t total = (int64_t)nchunks * 9 * 2 * Mp;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += nthreads) {
+        const int m = (int)(o % Mp);
+        int r = (int)(o / Mp);
+        const int h = r & 1;
+        r >>= 1;
+        const int tp = r % 9, chunk = r / 9;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = chunk * 16 + h * 8 + j;
+            const int co = dgrad ? c : m, ci = dgrad ? m : c, tap = dgrad ? 8 - tp : tp;
+            v[j] = 0.0f;
+            if (co < K && ci < C) {
+                const int64_t off = ((int64_t)co * C + ci) * 9 + tap;
+                v[j] = w[off];
+                if (pm != nullptr) v[j] *= binarize(pm[off], thr);
+            }
+        }
+        u32x4 q = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        out[o] = q;
+    }
+}
+
+// ------------------------------------------------------------------------------ fwd / dgrad
+template <class Cfg>
+__global__ __launch_bounds__(256, Cfg::MINB) void k_c3b_fwd(B16Geom g, const float *__restrict__ x, const u32x4 *__restrict__ wp,
+                                                            const float *__restrict__ bias, float *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4 *smem = reinterpret_cast<u32x4 *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lb % g.tiles_m; lb /= g.tiles_m;
+    const int tx = lb % g.tiles_x; lb /= g.tiles_x;
+    const int ty = lb % g.tiles_y;
+    const int n = lb / g.tiles_y;
+    const int m0 = tm * Cfg::BM, h0 = ty * Cfg::TH, w0 = tx * Cfg::TW;
+    const int HW = g.H * g.W;
+
+    // ---- staging descriptors (fixed for the life of the block) ----
+    // weights: uint4 item e = tid + 256 i of [9][2][BM]: row (tap, half) = e / BM, column e % BM
+    int wsrc[Cfg::NWI];
+#pragma unroll
+    for (int i = 0; i < Cfg::NWI; ++i) {
+        const int e = min(tid + 256 * i, Cfg::WQ - 1);                 // (clamped duplicates re-write the same value)
+        wsrc[i] = (e / Cfg::BM) * g.Mp + m0 + (e % Cfg::BM);
+    }
+    // patch: item e = tid + 256 i of [2 halves][NPIX]: byte offset of (channel 8 * half, pixel) from the image's channel 0,
+    // or an out-of-range offset for halo positions outside the image (the buffer unit then returns 0)
+    constexpr int kOutOfRange = (int)0x80000000;
+    int xoff[Cfg::NXI], xdst[Cfg::NXI];
+#pragma unroll
+    for (int i = 0; i < Cfg::NXI; ++i) {
+        const int e = tid + 256 * i;
+        const int half = e / Cfg::NPIX, p = e - half * Cfg::NPIX;
+        const int pr = p / Cfg::PW, pc = p - pr * Cfg::PW;
+        const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
+        const bool ok = e < 2 * Cfg::NPIX && (unsigned)gh < (unsigned)g.H && (unsigned)gw < (unsigned)g.W;
+        xoff[i] = ok ? (half * 8 * HW + gh * g.W + gw) * 4 : kOutOfRange;
+        xdst[i] = e < 2 * Cfg::NPIX ? Cfg::WQ + half * Cfg::NPIXP + p : -1;
+    }
+    const __amdgpu_buffer_rsrc_t srd_x =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(x + (int64_t)n * g.C * HW), 0, g.C * HW * 4, 0x00020000);
+
+    u32x4 rw[Cfg::NWI];
+    float rx[Cfg::NXI][8];
+    auto load_chunk = [&](int ch) {
+        const u32x4 *wsrc_ch = wp + (int64_t)ch * 18 * g.Mp;
+#pragma unroll
+        for (int i = 0; i < Cfg::NWI; ++i) rw[i] = wsrc_ch[wsrc[i]];
+        const int cbyte = ch * 16 * HW * 4;
+#pragma unroll
+        for (int i = 0; i < Cfg::NXI; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                // (channel offset in the VECTOR offset: only that one is range-checked, and the check is what zero-fills
+                // channels past C in the last chunk)
+                rx[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, xoff[i] + cbyte + j * HW * 4, 0, 0));
+    };
+    auto store_chunk = [&](u32x4 *stage) {
+#pragma unroll
+        for (int i = 0; i < Cfg::NWI; ++i) stage[min(tid + 256 * i, Cfg::WQ - 1)] = rw[i];
+#pragma unroll
+        for (int i = 0; i < Cfg::NXI; ++i) {
+            if (xdst[i] >= 0) {
+                u32x4 q = {pack2(rx[i][0], rx[i][1]), pack2(rx[i][2], rx[i][3]), pack2(rx[i][4], rx[i][5]), pack2(rx[i][6], rx[i][7])};
+                stage[xdst[i]] = q;
+            }
+        }
+    };
+
+    // ---- operand lane bases (uint4 index inside a stage) ----
+    const int a_base = lh * Cfg::BM + wm * Cfg::FM * 32 + li;                              // + tap * 2 * BM + fm * 32
+    int b_base[Cfg::FN];
+#pragma unroll
+    for (int fn = 0; fn < Cfg::FN; ++fn) {
+        const int t = (wn * Cfg::FN + fn) * 32 + li;
+        b_base[fn] = Cfg::WQ + lh * Cfg::NPIXP + (t / Cfg::TW) * Cfg::PW + (t % Cfg::TW);   // + kh * PW + kw
+    }
+
+    f32x16 acc[Cfg::FM][Cfg::FN];
+#pragma unroll
+    for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < Cfg::FN; ++fn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[fm][fn][e] = 0.0f;
+
+    load_chunk(0);
+    store_chunk(smem);
+    __syncthreads();
+    for (int ch = 0; ch < g.nchunks; ++ch) {
+        const u32x4 *cur = smem + (ch & 1) * Cfg::STAGEQ;
+        u32x4 *other = smem + ((ch + 1) & 1) * Cfg::STAGEQ;
+        const bool more = ch + 1 < g.nchunks;                      // block-uniform
+        if (more) load_chunk(ch + 1);                              // in flight under the MFMAs below
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            bf16x8 a[Cfg::FM], b[Cfg::FN];
+#pragma unroll
+            for (int fm = 0; fm < Cfg::FM; ++fm) a[fm] = __builtin_bit_cast(bf16x8, cur[a_base + tap * 2 * Cfg::BM + fm * 32]);
+#pragma unroll
+            for (int fn = 0; fn < Cfg::FN; ++fn)
+                b[fn] = __builtin_bit_cast(bf16x8, cur[b_base[fn] + (tap / 3) * Cfg::PW + (tap % 3)]);
+#pragma unroll
+            for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < Cfg::FN; ++fn)
+                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fm], b[fn], acc[fm][fn], 0, 0, 0);
+        }
+        if (more) store_chunk(other);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D col = pixel (lane & 31), D row = channel ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) ----
+#pragma unroll
+    for (int fn = 0; fn < Cfg::FN; ++fn) {
+        const int t = (wn * Cfg::FN + fn) * 32 + li;
+        const int oh = h0 + t / Cfg::TW, ow = w0 + t % Cfg::TW;
+        const bool pok = oh < g.H && ow < g.W;
+        float *yout = y + (int64_t)n * g.M * HW + oh * g.W + ow;
+#pragma unroll
+        for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (pok && co < g.M) yout[(int64_t)co * HW] = acc[fm][fn][e] + (bias != nullptr ? bias[co] : 0.0f);
+            }
+    }
+}
+
+inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+inline size_t packb_bytes(int c_read, int m) { return (size_t)((c_read + 15) / 16) * 18 * pad_to(m, 128) * sizeof(u32x4); }
+
+template <class Cfg>
+int launch(B16Geom g, const float *x, const u32x4 *wp, const float *bias, float *y, hipStream_t stream, const char *what) {
+    g.tiles_x = (g.W + Cfg::TW - 1) / Cfg::TW;
+    g.tiles_y = (g.H + Cfg::TH - 1) / Cfg::TH;
+    g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
+    const int64_t blocks = (int64_t)g.N * g.tiles_x * g.tiles_y * g.tiles_m;
+    if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "%s: grid too large", what);
+    constexpr size_t smem = (size_t)2 * Cfg::STAGEQ * sizeof(u32x4);
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_c3b_fwd<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return hip_status(e, what);
+    hipLaunchKernelGGL((k_c3b_fwd<Cfg>), dim3((unsigned)blocks), dim3(256), smem, stream, g, x, wp, bias, y);
+    CPG_CHECK_LAUNCH(what);
+    return CPG_OK;
+}
+
+//                    BM  TH  TW  WM WN MINB
+using B16W128 = B16Cfg<128, 8, 56, 2, 2, 1>;      // 56 / 112 / 224 wide maps, >= 128 channels: 7 pixel fragments, zero tile waste
+using B16W64 = B16Cfg<64, 8, 56, 2, 2, 1>;        // same maps, <= 64 channels
+using B16N128 = B16Cfg<128, 8, 32, 2, 2, 1>;      // everything else (28 / 14 wide maps run with tile waste: this path is a demonstrator)
+using B16N64 = B16Cfg<64, 8, 32, 2, 2, 2>;
+
+int run(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, const float *x, const float *w, const float *pm, float thr,
+        const float *bias, float *y, void *ws, size_t ws_bytes, hipStream_t stream) {
+    const char *what = dgrad ? "cpg_conv2d_dgrad_bf16" : "cpg_conv2d_fwd_bf16";
+    const size_t need = packb_bytes(c_read, m);
+    if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
+    CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
+    u32x4 *wp = (u32x4 *)ws;
+    const int nchunks = (c_read + 15) / 16, Mp = pad_to(m, 128);
+    hipLaunchKernelGGL(k_c3b_pack, dim3(stream_grid((int64_t)nchunks * 18 * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, K, C, nchunks,
+                       Mp, dgrad ? 1 : 0);
+    B16Geom g{N, c_read, H, W, m, Mp, 0, 0, 0, nchunks};
+    const bool wide = W % 56 == 0;
+    if (wide) return m > 64 ? launch<B16W128>(g, x, wp, bias, y, stream, what) : launch<B16W64>(g, x, wp, bias, y, stream, what);
+    return m > 64 ? launch<B16N128>(g, x, wp, bias, y, stream, what) : launch<B16N64>(g, x, wp, bias, y, stream, what);
+}
+
+}  // namespace
+
+extern "C" int cpg_conv3x3_supported(const cpg_conv_desc *d);
+
+extern "C" int32_t cpg_conv2d_bf16_supported(const cpg_conv_desc *d) { return d != nullptr && cpg_conv3x3_supported(d) ? 1 : 0; }
+
+extern "C" size_t cpg_conv2d_bf16_workspace_bytes(const cpg_conv_desc *d) {
+    if (!cpg_conv2d_bf16_supported(d)) return 0;
+    return std::max(packb_bytes(d->C, d->K), packb_bytes(d->K, d->C));
+}
+
+extern "C" int cpg_conv2d_fwd_bf16(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
+                                   float *y, void *ws, size_t ws_bytes, void *stream) {
+    if (!cpg_conv2d_bf16_supported(d)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_fwd_bf16: only 3x3 / stride 1 / pad 1 convolutions");
+    CPG_REQUIRE(x && w && y, "cpg_conv2d_fwd_bf16: null pointer");
+    return run(false, d->N, d->C, d->K, d->H, d->W, d->K, d->C, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int cpg_conv2d_dgrad_bf16(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx,
+                                     void *ws, size_t ws_bytes, void *stream) {
+    if (!cpg_conv2d_bf16_supported(d)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_dgrad_bf16: only 3x3 / stride 1 / pad 1 convolutions");
+    CPG_REQUIRE(gy && w && gx, "cpg_conv2d_dgrad_bf16: null pointer");
+    return run(true, d->N, d->K, d->C, d->H, d->W, d->K, d->C, gy, w, pm, thr, nullptr, gx, ws, ws_bytes, (hipStream_t)stream);
+}

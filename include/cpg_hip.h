@@ -226,6 +226,19 @@ int cpg_conv2d_fwd_bn_eval(const cpg_conv_desc *desc, const float *x, const floa
                            const float *running_var, float eps, int32_t relu, float *y, int32_t *skip_stats, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* ---- OPT-IN bf16 MFMA path (north_star: "MFMA fp32/bf16 GEMM") of the 3x3 / stride 1 / pad 1 convolution ----
+ * Same contraction as cpg_conv2d_fwd / cpg_conv2d_dgrad with the operands (activations, effective weights W * bin(pm))
+ * rounded to bf16 on their way into LDS, exact products, fp32 accumulation (v_mfma_f32_32x32x16_bf16) -- the arithmetic of
+ * an autocast(bf16) convolution.  All tensors in HBM stay fp32 NCHW.  NOT the default: north_star's 1e-4 parity bar is an
+ * fp32 bar; this path has its own tolerance (about 1e-2 of the output scale) and its own roofline (2.5 PFLOP/s).
+ * The weight gradient stays on the fp32 kernel (cpg_conv2d_wgrad). */
+int32_t cpg_conv2d_bf16_supported(const cpg_conv_desc *desc);
+size_t cpg_conv2d_bf16_workspace_bytes(const cpg_conv_desc *desc);
+int cpg_conv2d_fwd_bf16(const cpg_conv_desc *desc, const float *x, const float *w, const float *piggymask, float threshold,
+                        const float *bias, float *y, void *workspace, size_t workspace_bytes, void *stream);
+int cpg_conv2d_dgrad_bf16(const cpg_conv_desc *desc, const float *gy, const float *w, const float *piggymask, float threshold,
+                          float *gx, void *workspace, size_t workspace_bytes, void *stream);
+
 /* y = relu(bn(x) + res): the tail of a residual block (models/resnet.py:69-74 `out = self.bn3(out); out += identity;
  * out = self.relu(out)`).  train != 0: batch statistics (mean / invstd out, running stats updated); train == 0: `mean`
  * / `invstd` are inputs.  Backward = relu mask from y, then cpg_bn_relu_bwd(relu = 0); the residual's gradient is the
