@@ -24,6 +24,19 @@ from .. import _lib
 
 DEFAULT_THRESHOLD = 5e-3      # models/layers.py:9
 
+# Arithmetic of the masked 3x3 convolutions: 'fp32' (default; fp32 MFMA, the reference's precision and north_star's parity
+# bar) or the OPT-IN 'bf16' (operands rounded to bf16 on their way into LDS, fp32 accumulation -- forward and input gradient
+# on v_mfma_f32_32x32x16_bf16; the weight gradient stays fp32).  A layer's own `.math` attribute, when set, wins.
+CONV_MATH = 'fp32'
+
+
+def set_conv_math(math):
+    """Select the arithmetic of every SharableConv2d that has no `.math` of its own: 'fp32' or 'bf16' (opt-in)."""
+    global CONV_MATH
+    if math not in ('fp32', 'bf16'):
+        raise ValueError("conv math must be 'fp32' or 'bf16', got %r" % (math,))
+    CONV_MATH = math
+
 
 class Binarizer(torch.autograd.Function):
     """{0,1} hard threshold with straight-through gradient (models/layers.py:11-23)."""
@@ -63,7 +76,7 @@ class _MaskedConv2dFn(torch.autograd.Function):
     """y = conv2d(x, W * bin(pm), b) and its gradients, all through the C ABI."""
 
     @staticmethod
-    def forward(ctx, x, weight, pm, bias, thr, stride, padding, dilation, groups, bn_stats=False):
+    def forward(ctx, x, weight, pm, bias, thr, stride, padding, dilation, groups, bn_stats=False, math='fp32'):
         """bn_stats: also return the per-(channel, pixel tile) {sum, sum of squares} of y that the kernel accumulates
         in its epilogue (cpg_conv2d_fwd_bnstats) -- a second, non-differentiable output, or None when the shape has
         no fused-statistics kernel."""
@@ -80,8 +93,24 @@ class _MaskedConv2dFn(torch.autograd.Function):
         y = torch.empty((d.N, d.K, oh, ow), dtype=torch.float32, device=x.device)
         L = _lib.lib()
         ctx.empty = d.N == 0
+        ctx.bf16 = False
         if ctx.empty:                   # an empty batch is legal for F.conv2d: empty output, zero parameter gradients
             _lib.dptr(x, name='input'), _lib.dptr(w, name='weight')            # still no CPU / dtype fallback
+            ctx.save_for_backward(x, w, p)
+            ctx.desc, ctx.thr, ctx.has_bias = d, float(thr), bias is not None
+            if not bn_stats:
+                return y
+            stats = torch.empty(0, dtype=torch.float32, device=x.device)
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        ctx.bf16 = math == 'bf16' and bool(L.cpg_conv2d_bf16_supported(ctypes.byref(d)))
+        if ctx.bf16:
+            # opt-in bf16 MFMA forward (no fused BatchNorm statistics on this path: the BatchNorm runs its own pass)
+            ws, nbytes = _lib.workspace(L.cpg_conv2d_bf16_workspace_bytes(ctypes.byref(d)), x.device)
+            rc = L.cpg_conv2d_fwd_bf16(ctypes.byref(d), _lib.dptr(x, name='input'), _lib.dptr(w, name='weight'),
+                                       _lib.dptr(p, name='piggymask'), float(thr), _lib.dptr(bias, name='bias'), _lib.dptr(y),
+                                       _lib.dptr(ws), nbytes, _lib.stream_ptr())
+            _lib.check('cpg_conv2d_fwd_bf16', rc)
             ctx.save_for_backward(x, w, p)
             ctx.desc, ctx.thr, ctx.has_bias = d, float(thr), bias is not None
             if not bn_stats:
@@ -118,13 +147,20 @@ class _MaskedConv2dFn(torch.autograd.Function):
         d, thr = ctx.desc, ctx.thr
         if ctx.empty:
             return (torch.zeros_like(x), torch.zeros_like(w), None if p is None else torch.zeros_like(p),
-                    torch.zeros(d.K, dtype=torch.float32, device=x.device) if ctx.has_bias else None, None, None, None, None, None, None)
+                    torch.zeros(d.K, dtype=torch.float32, device=x.device) if ctx.has_bias else None, None, None, None, None, None, None,
+                    None)
         gy = gy.contiguous()
         L = _lib.lib()
         s = _lib.stream_ptr()
         gx = gw = gpm = gb = None
         ws, nbytes = _lib.workspace(L.cpg_conv2d_workspace_bytes(ctypes.byref(d)), x.device)
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.bf16:
+            gx = torch.empty_like(x)
+            ws16, nb16 = _lib.workspace(L.cpg_conv2d_bf16_workspace_bytes(ctypes.byref(d)), x.device)
+            rc = L.cpg_conv2d_dgrad_bf16(ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr,
+                                         _lib.dptr(gx), _lib.dptr(ws16), nb16, s)
+            _lib.check('cpg_conv2d_dgrad_bf16', rc)
+        elif ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             rc = L.cpg_conv2d_dgrad(ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr,
                                     _lib.dptr(gx), _lib.dptr(ws), nbytes, s)
@@ -136,7 +172,7 @@ class _MaskedConv2dFn(torch.autograd.Function):
             rc = L.cpg_conv2d_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), _lib.dptr(p), thr,
                                     _lib.dptr(gw), _lib.dptr(gpm), _lib.dptr(gb), _lib.dptr(ws), nbytes, s)
             _lib.check('cpg_conv2d_wgrad', rc)
-        return gx, gw, gpm, gb, None, None, None, None, None, None
+        return gx, gw, gpm, gb, None, None, None, None, None, None, None
 
 
 class _MaskedLinearFn(torch.autograd.Function):
@@ -243,13 +279,16 @@ class SharableConv2d(_Sharable):
 
     def forward(self, input, layer_info=None, name=None):
         return _MaskedConv2dFn.apply(input, self.weight, self.piggymask, self.bias, self.info['threshold'],
-                                     self.stride, self.padding, self.dilation, self.groups)
+                                     self.stride, self.padding, self.dilation, self.groups, False, self._math())
+
+    def _math(self):
+        return getattr(self, 'math', None) or CONV_MATH
 
     def forward_with_bn_stats(self, input):
         """(y, stats): forward plus the BatchNorm partial sums of y from the same kernel; stats is None when this shape
         has no fused-statistics kernel.  Used by cpg_amd.models.fused_bn.FusedSequential for conv -> BatchNorm2d runs."""
         y, stats = _MaskedConv2dFn.apply(input, self.weight, self.piggymask, self.bias, self.info['threshold'],
-                                         self.stride, self.padding, self.dilation, self.groups, True)
+                                         self.stride, self.padding, self.dilation, self.groups, True, self._math())
         return y, (stats if stats.numel() else None)
 
     def forward_bn_eval(self, input, bn, relu=True, skip_stats=None):
@@ -257,7 +296,8 @@ class SharableConv2d(_Sharable):
         Manager.validate.  Inference only -- call it under torch.no_grad(); returns None when this shape has no fused
         kernel (the caller then runs the layers one by one).  skip_stats: optional int32[2] device tensor that receives
         {1 + last live input channel, output tiles skipped} (dead-channel skip, see include/cpg_hip.h)."""
-        if torch.is_grad_enabled() or input.dim() != 4 or input.shape[0] == 0 or input.shape[1] != self.weight.shape[1] * self.groups:
+        if (torch.is_grad_enabled() or input.dim() != 4 or input.shape[0] == 0 or input.shape[1] != self.weight.shape[1] * self.groups
+                or self._math() != 'fp32'):
             return None
         x = input.contiguous()
         w = self.weight.contiguous()

@@ -196,6 +196,75 @@ def test_linear_oracle(B, I, O, pm):
         close(layer.piggymask.grad, r['gpm'], rtol=1e-4, atol=floor(r['gpm']), msg='gpm')
 
 
+# --------------------------------------------------------------------------- opt-in bf16 MFMA path
+@pytest.mark.parametrize('N,C,H,W,K,bias,pm', [(2, 5, 9, 11, 7, False, False), (1, 8, 6, 37, 33, True, True), (3, 20, 16, 56, 70, False, True),
+                                               (2, 64, 28, 28, 130, True, False), (2, 3, 40, 112, 64, False, False), (1, 33, 14, 14, 257, False, True),
+                                               (4, 128, 56, 56, 128, False, False)])
+def test_conv_bf16_opt_in_path(N, C, H, W, K, bias, pm):
+    """cpg_conv2d_fwd_bf16 / cpg_conv2d_dgrad_bf16 through SharableConv2d(math='bf16').  Two statements:
+    (1) the kernel does exactly what it says -- operands rounded to bf16 (nearest even), exact products, fp32 accumulation:
+        against an fp64 oracle fed the SAME bf16-rounded operands it agrees to 1e-5 of the output scale;
+    (2) against the fp32 oracle (the reference's arithmetic) the opt-in path is within its own documented tolerance, 2e-2 of
+        the output scale -- NOT north_star's 1e-4, which is why it is never the default.
+    The weight gradient stays on the fp32 kernel and keeps the fp32 tolerance."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(N * 1000 + C * 10 + K)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5
+    b = torch.randn(K, generator=g) * 0.1 if bias else None
+    pmv = torch.rand(K, C, 3, 3, generator=g) * 0.012 if pm else None
+    gy = torch.randn(N, K, H, W, generator=g)
+    layer = nl.SharableConv2d(C, K, 3, padding=1, bias=bias).to(DEV)
+    layer.math = 'bf16'
+    layer.weight.data.copy_(w)
+    if bias:
+        layer.bias.data.copy_(b)
+    if pm:
+        layer.piggymask = nn.Parameter(pmv.to(DEV))
+    xd = x.to(DEV).requires_grad_(True)
+    y = layer(xd)
+    y.backward(gy.to(DEV))
+    w_eff = w * (pmv > 5e-3).float() if pm else w
+    rb = lambda t: t.bfloat16().double()                      # round to nearest even, as v_cvt_pk_bf16_f32
+    y16 = F.conv2d(rb(x), rb(w_eff), None if b is None else b.double(), padding=1)
+    gx16 = F.conv_transpose2d(rb(gy), rb(w_eff), padding=1)
+    y32 = F.conv2d(x.double(), w_eff.double(), None if b is None else b.double(), padding=1)
+    gx32 = F.conv_transpose2d(gy.double(), w_eff.double(), padding=1)
+
+    def rel(a, ref):
+        return float((a.detach().double().cpu() - ref).abs().max() / ref.abs().max())
+    assert rel(y, y16) < 1e-5 and rel(xd.grad, gx16) < 1e-5, (rel(y, y16), rel(xd.grad, gx16))
+    assert rel(y, y32) < 2e-2 and rel(xd.grad, gx32) < 2e-2, (rel(y, y32), rel(xd.grad, gx32))
+    assert rel(y, y32) > 1e-5                                  # ... and it really is the bf16 path that ran
+    r = ops.conv2d_backward(x.numpy(), w.numpy(), gy.numpy(), None if pmv is None else pmv.numpy(), bool(bias), 1, 1, 1)
+    scale = float(np.abs(r['gw']).max())
+    close(layer.weight.grad, r['gw'], rtol=1e-4, atol=1e-5 * max(scale, 1.0), msg='gw (fp32 kernel)')
+
+
+def test_conv_math_switch_is_opt_in():
+    """The default is fp32; set_conv_math flips every layer without its own `.math`; unsupported shapes stay on fp32."""
+    assert nl.CONV_MATH == 'fp32'
+    with pytest.raises(ValueError):
+        nl.set_conv_math('fp16')
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 12, 12, generator=g).to(DEV)
+    c3 = nl.SharableConv2d(8, 16, 3, padding=1, bias=False).to(DEV)
+    c1 = nl.SharableConv2d(8, 16, 1, bias=False).to(DEV)
+    for c in (c3, c1):
+        c.weight.data.copy_(torch.randn(c.weight.shape, generator=g) * 0.2)
+    with torch.no_grad():
+        ref3, ref1 = c3(x), c1(x)
+        nl.set_conv_math('bf16')
+        try:
+            got3, got1 = c3(x), c1(x)
+        finally:
+            nl.set_conv_math('fp32')
+        assert torch.equal(got1, ref1)                         # 1x1: no bf16 kernel, unchanged
+        d = float((got3 - ref3).abs().max() / ref3.abs().max())
+        assert 1e-5 < d < 2e-2, d
+        assert torch.equal(c3(x), ref3)
+
+
 # --------------------------------------------------------------------------- pruner pieces vs golden
 class TinyNet(nn.Module):
     def __init__(self, datasets):

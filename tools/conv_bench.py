@@ -69,6 +69,7 @@ def main():
         d = _conv_desc(x.shape, w.shape, (1, 1), (1, 1), (1, 1), 1)
         nws = L.cpg_conv2d_workspace_bytes(ctypes.byref(d))
         ws, nb = _lib.workspace(nws, dev)
+        ws16, nb16 = _lib.workspace(L.cpg_conv2d_bf16_workspace_bytes(ctypes.byref(d)), dev)       # opt-in bf16 path (fwd16 / dgrad16)
         flops = 2.0 * a.batch * K * H * H * C * 9
         P = _lib.dptr
         tiles = L.cpg_conv2d_bnstats_tiles(ctypes.byref(d))
@@ -76,9 +77,11 @@ def main():
         runs = {'fwdstats': lambda: L.cpg_conv2d_fwd_bnstats(ctypes.byref(d), P(x), P(w), P(pm), 5e-3, None, P(y), P(stats), stats.numel() * 4, P(ws), nb, st),
                 'fwd': lambda: L.cpg_conv2d_fwd(ctypes.byref(d), P(x), P(w), P(pm), 5e-3, None, P(y), P(ws), nb, st),
                 'dgrad': lambda: L.cpg_conv2d_dgrad(ctypes.byref(d), P(gy), P(w), P(pm), 5e-3, P(gx), P(ws), nb, st),
+                'fwd16': lambda: L.cpg_conv2d_fwd_bf16(ctypes.byref(d), P(x), P(w), P(pm), 5e-3, None, P(y), P(ws16), nb16, st),
+                'dgrad16': lambda: L.cpg_conv2d_dgrad_bf16(ctypes.byref(d), P(gy), P(w), P(pm), 5e-3, P(gx), P(ws16), nb16, st),
                 'wgrad': lambda: L.cpg_conv2d_wgrad(ctypes.byref(d), P(x), P(gy), P(w), P(pm), 5e-3, P(gw), P(gpm), None, P(ws), nb, st)}
         for k in a.only.split(','):
-            if k == 'dgrad' and name == 'f0':
+            if k in ('dgrad', 'dgrad16') and name == 'f0':
                 continue
             if a.pmc_pass:
                 for _ in range(mult):
