@@ -244,8 +244,10 @@ int launch(B16Geom g, const float *x, const u32x4 *wp, const float *bias, float 
 //                    BM  TH  TW  WM WN MINB
 using B16W128 = B16Cfg<128, 8, 56, 2, 2, 1>;      // 56 / 112 / 224 wide maps, >= 128 channels: 7 pixel fragments, zero tile waste
 using B16W64 = B16Cfg<64, 8, 56, 2, 2, 1>;        // same maps, <= 64 channels
-using B16N128 = B16Cfg<128, 8, 32, 2, 2, 1>;      // everything else (28 / 14 wide maps run with tile waste: this path is a demonstrator)
+using B16N128 = B16Cfg<128, 8, 32, 2, 2, 1>;      // everything else
 using B16N64 = B16Cfg<64, 8, 32, 2, 2, 2>;
+using B16P28 = B16Cfg<128, 7, 32, 4, 1, 1>;       // 28-high maps: 4 tiles of 7 rows (only the 4 padding columns are wasted)
+using B16S16 = B16Cfg<128, 14, 16, 4, 1, 1>;      // 14 x 14 (<= 16 wide) maps: the whole image, 7 fragments
 
 int run(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, const float *x, const float *w, const float *pm, float thr,
         const float *bias, float *y, void *ws, size_t ws_bytes, hipStream_t stream) {
@@ -260,6 +262,8 @@ int run(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, const 
     B16Geom g{N, c_read, H, W, m, Mp, 0, 0, 0, nchunks};
     const bool wide = W % 56 == 0;
     if (wide) return m > 64 ? launch<B16W128>(g, x, wp, bias, y, stream, what) : launch<B16W64>(g, x, wp, bias, y, stream, what);
+    if (m > 64 && W <= 16 && H <= 14) return launch<B16S16>(g, x, wp, bias, y, stream, what);
+    if (m > 64 && W <= 32 && H % 7 == 0) return launch<B16P28>(g, x, wp, bias, y, stream, what);
     return m > 64 ? launch<B16N128>(g, x, wp, bias, y, stream, what) : launch<B16N64>(g, x, wp, bias, y, stream, what);
 }
 
@@ -267,7 +271,11 @@ int run(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, const 
 
 extern "C" int cpg_conv3x3_supported(const cpg_conv_desc *d);
 
-extern "C" int32_t cpg_conv2d_bf16_supported(const cpg_conv_desc *d) { return d != nullptr && cpg_conv3x3_supported(d) ? 1 : 0; }
+// (fewer than 16 channels on either side -- the 3 -> 64 stem -- would fill most of a 16-channel k-step with zeros and is
+// HBM-bound anyway: it stays on the fp32 kernels)
+extern "C" int32_t cpg_conv2d_bf16_supported(const cpg_conv_desc *d) {
+    return d != nullptr && cpg_conv3x3_supported(d) && d->C >= 16 && d->K >= 16 ? 1 : 0;
+}
 
 extern "C" size_t cpg_conv2d_bf16_workspace_bytes(const cpg_conv_desc *d) {
     if (!cpg_conv2d_bf16_supported(d)) return 0;

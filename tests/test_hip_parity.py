@@ -197,9 +197,9 @@ def test_linear_oracle(B, I, O, pm):
 
 
 # --------------------------------------------------------------------------- opt-in bf16 MFMA path
-@pytest.mark.parametrize('N,C,H,W,K,bias,pm', [(2, 5, 9, 11, 7, False, False), (1, 8, 6, 37, 33, True, True), (3, 20, 16, 56, 70, False, True),
-                                               (2, 64, 28, 28, 130, True, False), (2, 3, 40, 112, 64, False, False), (1, 33, 14, 14, 257, False, True),
-                                               (4, 128, 56, 56, 128, False, False)])
+@pytest.mark.parametrize('N,C,H,W,K,bias,pm', [(2, 16, 9, 11, 17, False, False), (1, 24, 6, 37, 33, True, True), (3, 20, 16, 56, 70, False, True),
+                                               (2, 64, 28, 28, 130, True, False), (2, 19, 40, 112, 64, False, False), (1, 33, 14, 14, 257, False, True),
+                                               (3, 40, 7, 9, 129, True, True), (4, 128, 56, 56, 128, False, False)])
 def test_conv_bf16_opt_in_path(N, C, H, W, K, bias, pm):
     """cpg_conv2d_fwd_bf16 / cpg_conv2d_dgrad_bf16 through SharableConv2d(math='bf16').  Two statements:
     (1) the kernel does exactly what it says -- operands rounded to bf16 (nearest even), exact products, fp32 accumulation:
@@ -247,19 +247,20 @@ def test_conv_math_switch_is_opt_in():
     with pytest.raises(ValueError):
         nl.set_conv_math('fp16')
     g = torch.Generator().manual_seed(3)
-    x = torch.randn(2, 8, 12, 12, generator=g).to(DEV)
-    c3 = nl.SharableConv2d(8, 16, 3, padding=1, bias=False).to(DEV)
-    c1 = nl.SharableConv2d(8, 16, 1, bias=False).to(DEV)
-    for c in (c3, c1):
+    x = torch.randn(2, 16, 12, 12, generator=g).to(DEV)
+    c3 = nl.SharableConv2d(16, 16, 3, padding=1, bias=False).to(DEV)
+    c1 = nl.SharableConv2d(16, 16, 1, bias=False).to(DEV)
+    stem = nl.SharableConv2d(3, 16, 3, padding=1, bias=False).to(DEV)     # < 16 channels: stays on the fp32 kernels
+    for c in (c3, c1, stem):
         c.weight.data.copy_(torch.randn(c.weight.shape, generator=g) * 0.2)
     with torch.no_grad():
-        ref3, ref1 = c3(x), c1(x)
+        ref3, ref1, refs = c3(x), c1(x), stem(x[:, :3].contiguous())
         nl.set_conv_math('bf16')
         try:
-            got3, got1 = c3(x), c1(x)
+            got3, got1, gots = c3(x), c1(x), stem(x[:, :3].contiguous())
         finally:
             nl.set_conv_math('fp32')
-        assert torch.equal(got1, ref1)                         # 1x1: no bf16 kernel, unchanged
+        assert torch.equal(got1, ref1) and torch.equal(gots, refs)     # 1x1 / stem: no bf16 kernel, unchanged
         d = float((got3 - ref3).abs().max() / ref3.abs().max())
         assert 1e-5 < d < 2e-2, d
         assert torch.equal(c3(x), ref3)
