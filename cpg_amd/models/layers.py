@@ -265,6 +265,11 @@ class SharableConv2d(_Sharable):
         super().__init__()
         if in_channels % groups or out_channels % groups:
             raise ValueError('in_channels and out_channels must be divisible by groups')
+        if groups != 1:
+            # the reference forwards `groups` to F.conv2d (models/layers.py:108-109) but no CPG configuration uses it; there is
+            # no grouped HIP kernel, so fail where the layer is built, not at the first forward (resnext*, VGG(groups=...))
+            raise NotImplementedError('SharableConv2d(groups=%d): grouped convolutions are not implemented in cpg_amd '
+                                      '(every CPG configuration uses groups=1)' % groups)
         self.in_channels, self.out_channels, self.groups = in_channels, out_channels, groups
         self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
         self.padding, self.dilation = _pair(padding), _pair(dilation)

@@ -293,3 +293,11 @@ def test_choose_ratio_table():
     assert choose_ratio(rec, 0.95, 0.0, False) == 0.0           # nothing holds the goal: the pre-prune checkpoint
     assert choose_ratio(rec, 0.95, 0.0, True) == 0.3            # at the width cap with a missed goal: the sparsest anyway
     assert choose_ratio({0.0: 0.9}, 0.5, 0.0, False) == 0.0     # the sweep recorded nothing
+
+
+def test_grouped_conv_is_refused_at_construction():
+    """groups != 1 has no HIP kernel: the layer (and the resnext factories built on it) say so when they are constructed."""
+    with pytest.raises(NotImplementedError):
+        nl.SharableConv2d(8, 8, 3, groups=2)
+    with pytest.raises(NotImplementedError):
+        M.resnext50_32x4d(dataset_history=[], dataset2num_classes={}, network_width_multiplier=1.0, shared_layer_info={})
