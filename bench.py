@@ -110,6 +110,7 @@ class KernelClock:
         # the opt-in bf16 MFMA kernels (--math bf16) get their own families: they are measured against the bf16 peak
         p.cpg_conv2d_fwd_bf16 = timed('cpg_conv2d_fwd_bf16', conv_kind('conv_fwd_bf16'), conv_flops)
         p.cpg_conv2d_dgrad_bf16 = timed('cpg_conv2d_dgrad_bf16', conv_kind('conv_dgrad_bf16'), conv_flops)
+        p.cpg_conv2d_wgrad_bf16 = timed('cpg_conv2d_wgrad_bf16', conv_kind('conv_wgrad_bf16'), conv_flops)
         p.cpg_conv2d_dgrad = timed('cpg_conv2d_dgrad', conv_kind('conv_dgrad'), conv_flops)
         p.cpg_conv2d_wgrad = timed('cpg_conv2d_wgrad', conv_kind('conv_wgrad'), conv_flops)
         p.cpg_linear_fwd = timed('cpg_linear_fwd', lambda a: 'linear_fwd', lin_flops(6))

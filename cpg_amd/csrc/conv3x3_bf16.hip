@@ -267,6 +267,233 @@ int run(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, const 
     return m > 64 ? launch<B16N128>(g, x, wp, bias, y, stream, what) : launch<B16N64>(g, x, wp, bias, y, stream, what);
 }
 
+
+// ------------------------------------------------------------------------------ weight gradient
+// D[co][ci](tap) = sum over images and pixels of gy[co][pix] * x[ci][pix + tap offset], k of the MFMA = 16 consecutive pixels
+// of one image row (lanes 0-31: pixels 0-7, lanes 32-63: pixels 8-15 of the k-step).
+//
+// A "unit" is TH rows x TW pixels (TW a multiple of 16) of one image.  LDS holds it channel-fastest in groups of 8 pixels,
+//     Gs[row][TW/8 groups][64 co]      uint4 (8 bf16)         gy
+//     Xs[row + halo][TW/8 + 2 groups][64 ci]   uint4          x, one group of left and right halo per row (w0 - 8 ... w0 + TW + 7)
+// so that an operand is ONE ds_read_b128 with consecutive lanes (channels) 16 bytes apart.  The three horizontal taps of a row
+// need the same 8 pixels shifted by -1 / 0 / +1 pixel: kw = 1 is the group itself, kw = 0 and kw = 2 are assembled in registers
+// from the group and one dword of its left / right neighbour with five v_alignbit (three of them shared by the two shifted
+// fragments).  Each wave owns a 32 co x 32 ci fragment for all 9 taps (9 accumulators); per k-step and row offset kh it issues 3
+// MFMAs against one b128 + two b32 reads.
+// Staging: thread = (channel, group): two 16-byte buffer loads (8 consecutive pixels; groups outside the image get an
+// out-of-range offset and read as 0), four v_cvt_pk_bf16_f32, one ds_write_b128.  The loads of unit u+1 are issued before the
+// MFMAs of unit u and stored into the other LDS stage after them (two stages, one barrier per unit, one block per CU).
+// MASKW: W is not a multiple of 8 (28-wide maps): the group that straddles the right image border is masked per element.
+// Split-K over units exactly like the fp32 kernel (k_c3_wgrad): tap-major partials, reduced (with the autograd epilogue
+// gW = g * bin(pm), gPM = g * W) by k_split_reduce.
+template <int TH_, int TW_, bool MASKW_>
+struct B16WCfg {
+    static constexpr int TH = TH_, TW = TW_;
+    static constexpr bool MASKW = MASKW_;
+    static_assert(TW % 16 == 0, "k-steps are 16 pixels of one row");
+    static constexpr int GG = TW / 8, XG = GG + 2, XR = TH + 2;          // groups per gy row / x row, x rows
+    static constexpr int GQ = TH * GG * 64, XQ = XR * XG * 64, STAGEQ = GQ + XQ;      // uint4 per stage
+    static constexpr int NGI = GQ / 256, NXI = (XQ + 255) / 256;          // staging items (channel, group) per thread
+    static_assert(GQ % 256 == 0, "gy items must fill the block");
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(256, 1) void k_c3b_wgrad(int N, int C, int H, int W, int M, int tiles_x, int tiles_y, int tiles_co,
+                                                      int tiles_ci, int units_per_split, const float *__restrict__ x,
+                                                      const float *__restrict__ gy, float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4 *smem = reinterpret_cast<u32x4 *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wco = wave >> 1, wci = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    // block -> (split, channel tile): all tiles of one split on one XCD, as in k_c3_wgrad
+    const int tiles = tiles_co * tiles_ci;
+    const int xcd = blockIdx.x % kXCDs, j = blockIdx.x / kXCDs;
+    const int split = (j / tiles) * kXCDs + xcd, tile = j % tiles;
+    const int tci = tile % tiles_ci, tco = tile / tiles_ci;
+    const int co0 = tco * 64, ci0 = tci * 64;
+    const int HW = H * W;
+    const int units_per_img = tiles_x * tiles_y;
+    const int total_units = N * units_per_img;
+    const int u0 = min(total_units, split * units_per_split);
+    const int u1 = min(total_units, u0 + units_per_split);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+
+    // ---- staging items: 64-lane blocks of (16 channels x 4 consecutive groups); lane l: channel l % 16, group l / 16 ----
+    // item i of this thread covers block b = wave + 4 i:  channels 16 * (b % 4) ..., groups 4 * (b / 4) ...
+    constexpr int kOutOfRange = (int)0x80000000;
+    int gch[Cfg::NGI], ggrp[Cfg::NGI], xch[Cfg::NXI], xgrp[Cfg::NXI];
+#pragma unroll
+    for (int i = 0; i < Cfg::NGI; ++i) {
+        const int b = wave + 4 * i;
+        gch[i] = 16 * (b & 3) + (lane & 15);
+        ggrp[i] = 4 * (b >> 2) + (lane >> 4);                       // < TH * GG
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::NXI; ++i) {
+        const int b = wave + 4 * i;
+        xch[i] = 16 * (b & 3) + (lane & 15);
+        xgrp[i] = 4 * (b >> 2) + (lane >> 4);                       // may exceed XR * XG in the last item: skipped
+    }
+    auto clamp_g = [&](int c) { return min(c, M - 1 - co0); };       // channels past M / C: duplicates of the last one, they only
+    auto clamp_x = [&](int c) { return min(c, C - 1 - ci0); };       // reach accumulator rows / columns that are never stored
+
+    __amdgpu_buffer_rsrc_t srd_g, srd_x;
+    float rg[Cfg::NGI][8], rx[Cfg::NXI][8];
+    int gnv[Cfg::NGI], xnv[Cfg::NXI];                                // MASKW: number of valid pixels in the group (0..8)
+    auto load_unit = [&](int u) {
+        const int n = u / units_per_img, rr = u - n * units_per_img;
+        const int ty = rr / tiles_x, tx = rr - ty * tiles_x;
+        const int h0 = ty * Cfg::TH, w0 = tx * Cfg::TW;
+        // num_records = what is left of the tensor: a 16-byte load that starts inside the last row never reads past the allocation
+        const int64_t g_left = ((int64_t)(N - n) * M - co0) * HW * 4, x_left = ((int64_t)(N - n) * C - ci0) * HW * 4;
+        srd_g = __builtin_amdgcn_make_buffer_rsrc((void *)(gy + ((int64_t)n * M + co0) * HW), 0, (int)min(g_left, (int64_t)0x7FFFFFFF), 0x00020000);
+        srd_x = __builtin_amdgcn_make_buffer_rsrc((void *)(x + ((int64_t)n * C + ci0) * HW), 0, (int)min(x_left, (int64_t)0x7FFFFFFF), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < Cfg::NGI; ++i) {
+            const int r = ggrp[i] / Cfg::GG, g = ggrp[i] % Cfg::GG;
+            const int gh = h0 + r, gw = w0 + 8 * g;
+            const bool ok = gh < H && gw < W;
+            const int off = ok ? (clamp_g(gch[i]) * HW + gh * W + gw) * 4 : kOutOfRange;
+            if (Cfg::MASKW) gnv[i] = ok ? min(8, W - gw) : 0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_g, off + 16 * q, 0, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rg[i][4 * q + e] = __builtin_bit_cast(float, v[e]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::NXI; ++i) {
+            const int r = xgrp[i] / Cfg::XG, g = xgrp[i] % Cfg::XG;
+            const int gh = h0 - 1 + r, gw = w0 - 8 + 8 * g;
+            const bool ok = xgrp[i] < Cfg::XR * Cfg::XG && (unsigned)gh < (unsigned)H && gw >= 0 && gw < W;
+            const int off = ok ? (clamp_x(xch[i]) * HW + gh * W + gw) * 4 : kOutOfRange;
+            if (Cfg::MASKW) xnv[i] = ok ? min(8, W - gw) : 0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, off + 16 * q, 0, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rx[i][4 * q + e] = __builtin_bit_cast(float, v[e]);
+            }
+        }
+    };
+    auto store_unit = [&](u32x4 *stage) {
+#pragma unroll
+        for (int i = 0; i < Cfg::NGI; ++i) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (Cfg::MASKW && e >= gnv[i]) ? 0.0f : rg[i][e];
+            u32x4 q = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+            stage[ggrp[i] * 64 + gch[i]] = q;
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::NXI; ++i) {
+            if (xgrp[i] < Cfg::XR * Cfg::XG) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (Cfg::MASKW && e >= xnv[i]) ? 0.0f : rx[i][e];
+                u32x4 q = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                stage[Cfg::GQ + xgrp[i] * 64 + xch[i]] = q;
+            }
+        }
+    };
+
+    const int a_lane = wco * 32 + li, b_lane = wci * 32 + li;
+    auto compute = [&](const u32x4 *cur) {
+        const unsigned *cur32 = reinterpret_cast<const unsigned *>(cur);
+#pragma unroll
+        for (int r = 0; r < Cfg::TH; ++r)
+#pragma unroll
+            for (int k = 0; k < Cfg::TW / 16; ++k) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, cur[(r * Cfg::GG + 2 * k + lh) * 64 + a_lane]);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int gi = Cfg::GQ + ((r + kh) * Cfg::XG + 1 + 2 * k + lh) * 64 + b_lane;     // centre group (uint4 index)
+                    const u32x4 c = cur[gi];
+                    const unsigned left = cur32[(gi - 64) * 4 + 3], right = cur32[(gi + 64) * 4 + 0];
+                    const unsigned s01 = __builtin_amdgcn_alignbit(c[1], c[0], 16), s12 = __builtin_amdgcn_alignbit(c[2], c[1], 16),
+                                   s23 = __builtin_amdgcn_alignbit(c[3], c[2], 16);
+                    const u32x4 bl = {__builtin_amdgcn_alignbit(c[0], left, 16), s01, s12, s23};      // pixels p0 - 1 ... p0 + 6
+                    const u32x4 br = {s01, s12, s23, __builtin_amdgcn_alignbit(right, c[3], 16)};     // pixels p0 + 1 ... p0 + 8
+                    acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, bl), acc[kh * 3 + 0], 0, 0, 0);
+                    acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, c), acc[kh * 3 + 1], 0, 0, 0);
+                    acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, br), acc[kh * 3 + 2], 0, 0, 0);
+                }
+            }
+    };
+
+    if (u0 < u1) {
+        load_unit(u0);
+        store_unit(smem);
+        __syncthreads();
+        for (int u = u0; u < u1; ++u) {
+            const int cs = (u - u0) & 1;
+            const bool more = u + 1 < u1;                             // block-uniform
+            if (more) load_unit(u + 1);
+            compute(smem + cs * Cfg::STAGEQ);
+            if (more) store_unit(smem + (cs ^ 1) * Cfg::STAGEQ);
+            __syncthreads();
+        }
+    }
+    float *dst = part + (int64_t)split * M * C * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co0 + wco * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const int ci = ci0 + wci * 32 + li;
+            if (co < M && ci < C) dst[((int64_t)t * M + co) * C + ci] = acc[t][e];
+        }
+}
+
+struct B16WPlan {
+    int tiles_x, tiles_y, tiles_co, tiles_ci, nsplit, units_per_split;
+    size_t ws_bytes;
+};
+template <class Cfg>
+B16WPlan wplan(const cpg_conv_desc *d) {
+    B16WPlan p;
+    p.tiles_x = (d->W + Cfg::TW - 1) / Cfg::TW;
+    p.tiles_y = (d->H + Cfg::TH - 1) / Cfg::TH;
+    p.tiles_co = (d->K + 63) / 64;
+    p.tiles_ci = (d->C + 63) / 64;
+    const int64_t units = (int64_t)d->N * p.tiles_x * p.tiles_y;
+    const int64_t tiles = (int64_t)p.tiles_co * p.tiles_ci;
+    int64_t want = (3 * kCUs + tiles - 1) / tiles;               // ~3 rounds of one block per CU
+    if (want > units) want = units;
+    if (want < 1) want = 1;
+    if (want > 4096) want = 4096;
+    want = (want + kXCDs - 1) / kXCDs * kXCDs;
+    p.units_per_split = (int)((units + want - 1) / want);
+    p.nsplit = (int)want;
+    p.ws_bytes = (size_t)p.nsplit * d->K * d->C * 9 * sizeof(float);
+    return p;
+}
+using B16G64 = B16WCfg<2, 64, false>;       // 56 / 112 / 224 wide maps (W a multiple of 8): 128 pixels per unit
+using B16G32 = B16WCfg<4, 32, true>;        // 28-wide maps: the last group of a row is masked per element
+inline int wpick(const cpg_conv_desc *d) { return d->W % 8 == 0 && d->W >= 56 ? 0 : 1; }
+
+template <class Cfg>
+int wlaunch(const cpg_conv_desc *d, const float *x, const float *gy, const Epilogue &ep, void *ws, size_t ws_bytes, hipStream_t stream) {
+    const B16WPlan p = wplan<Cfg>(d);
+    if (ws == nullptr || ws_bytes < p.ws_bytes) return fail(CPG_E_WORKSPACE, "cpg_conv2d_wgrad_bf16: workspace %zu < %zu bytes", ws_bytes, p.ws_bytes);
+    constexpr size_t smem = (size_t)2 * Cfg::STAGEQ * sizeof(u32x4);
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_c3b_wgrad<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return hip_status(e, "cpg_conv2d_wgrad_bf16");
+    hipLaunchKernelGGL(k_c3b_wgrad<Cfg>, dim3((unsigned)(p.tiles_co * p.tiles_ci * p.nsplit)), dim3(256), smem, stream, d->N, d->C, d->H, d->W,
+                       d->K, p.tiles_x, p.tiles_y, p.tiles_co, p.tiles_ci, p.units_per_split, x, gy, (float *)ws);
+    launch_split_reduce((const float *)ws, p.nsplit, (int64_t)d->K * d->C * 9, (int64_t)d->K * d->C, ep, stream);
+    CPG_CHECK_LAUNCH("cpg_conv2d_wgrad_bf16");
+    return CPG_OK;
+}
+
 }  // namespace
 
 extern "C" int cpg_conv3x3_supported(const cpg_conv_desc *d);
@@ -294,4 +521,25 @@ extern "C" int cpg_conv2d_dgrad_bf16(const cpg_conv_desc *d, const float *gy, co
     if (!cpg_conv2d_bf16_supported(d)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_dgrad_bf16: only 3x3 / stride 1 / pad 1 convolutions");
     CPG_REQUIRE(gy && w && gx, "cpg_conv2d_dgrad_bf16: null pointer");
     return run(true, d->N, d->K, d->C, d->H, d->W, d->K, d->C, gy, w, pm, thr, nullptr, gx, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// weight gradient on bf16 MFMA: supported for 3x3 s1 p1 layers with >= 16 channels on both sides whose width is a multiple of 4
+// and at least 28 (16-byte staging loads need aligned rows; 14 x 14 maps stay on the fp32 kernel)
+extern "C" int32_t cpg_conv2d_wgrad_bf16_supported(const cpg_conv_desc *d) {
+    return cpg_conv2d_bf16_supported(d) && d->W % 4 == 0 && d->W >= 28 && (int64_t)d->H * d->W <= (1ll << 22) ? 1 : 0;
+}
+
+extern "C" size_t cpg_conv2d_wgrad_bf16_workspace_bytes(const cpg_conv_desc *d) {
+    if (!cpg_conv2d_wgrad_bf16_supported(d)) return 0;
+    return wpick(d) == 0 ? wplan<B16G64>(d).ws_bytes : wplan<B16G32>(d).ws_bytes;
+}
+
+extern "C" int cpg_conv2d_wgrad_bf16(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
+                                     float *gw, float *gpm, void *ws, size_t ws_bytes, void *stream) {
+    if (!cpg_conv2d_wgrad_bf16_supported(d)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_wgrad_bf16: shape not supported");
+    CPG_REQUIRE(x && gy && gw && w, "cpg_conv2d_wgrad_bf16: null pointer");
+    CPG_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)gy) & 15) == 0, "cpg_conv2d_wgrad_bf16: activations must be 16-byte aligned");
+    Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
+    if (wpick(d) == 0) return wlaunch<B16G64>(d, x, gy, ep, ws, ws_bytes, (hipStream_t)stream);
+    return wlaunch<B16G32>(d, x, gy, ep, ws, ws_bytes, (hipStream_t)stream);
 }

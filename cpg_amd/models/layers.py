@@ -26,7 +26,7 @@ DEFAULT_THRESHOLD = 5e-3      # models/layers.py:9
 
 # Arithmetic of the masked 3x3 convolutions: 'fp32' (default; fp32 MFMA, the reference's precision and north_star's parity
 # bar) or the OPT-IN 'bf16' (operands rounded to bf16 on their way into LDS, fp32 accumulation -- forward and input gradient
-# on v_mfma_f32_32x32x16_bf16; the weight gradient stays fp32).  A layer's own `.math` attribute, when set, wins.
+# and, where a kernel exists, weight gradient on v_mfma_f32_32x32x16_bf16).  A layer's own `.math` attribute, when set, wins.
 CONV_MATH = 'fp32'
 
 
@@ -169,9 +169,15 @@ class _MaskedConv2dFn(torch.autograd.Function):
             gw = torch.empty_like(w)
             gpm = None if p is None else torch.empty_like(p)
             gb = torch.empty(d.K, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            rc = L.cpg_conv2d_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), _lib.dptr(p), thr,
-                                    _lib.dptr(gw), _lib.dptr(gpm), _lib.dptr(gb), _lib.dptr(ws), nbytes, s)
-            _lib.check('cpg_conv2d_wgrad', rc)
+            if ctx.bf16 and not ctx.has_bias and L.cpg_conv2d_wgrad_bf16_supported(ctypes.byref(d)):
+                wsw, nbw = _lib.workspace(L.cpg_conv2d_wgrad_bf16_workspace_bytes(ctypes.byref(d)), x.device)
+                rc = L.cpg_conv2d_wgrad_bf16(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), _lib.dptr(p), thr,
+                                             _lib.dptr(gw), _lib.dptr(gpm), _lib.dptr(wsw), nbw, s)
+                _lib.check('cpg_conv2d_wgrad_bf16', rc)
+            else:
+                rc = L.cpg_conv2d_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), _lib.dptr(p), thr,
+                                        _lib.dptr(gw), _lib.dptr(gpm), _lib.dptr(gb), _lib.dptr(ws), nbytes, s)
+                _lib.check('cpg_conv2d_wgrad', rc)
         return gx, gw, gpm, gb, None, None, None, None, None, None, None
 
 

@@ -199,7 +199,8 @@ def test_linear_oracle(B, I, O, pm):
 # --------------------------------------------------------------------------- opt-in bf16 MFMA path
 @pytest.mark.parametrize('N,C,H,W,K,bias,pm', [(2, 16, 9, 11, 17, False, False), (1, 24, 6, 37, 33, True, True), (3, 20, 16, 56, 70, False, True),
                                                (2, 64, 28, 28, 130, True, False), (2, 19, 40, 112, 64, False, False), (1, 33, 14, 14, 257, False, True),
-                                               (3, 40, 7, 9, 129, True, True), (4, 128, 56, 56, 128, False, False)])
+                                               (3, 40, 7, 9, 129, True, True), (4, 128, 56, 56, 128, False, False),
+                                               (2, 70, 30, 28, 65, False, True), (2, 64, 11, 224, 64, False, False), (3, 16, 5, 112, 130, False, True)])
 def test_conv_bf16_opt_in_path(N, C, H, W, K, bias, pm):
     """cpg_conv2d_fwd_bf16 / cpg_conv2d_dgrad_bf16 through SharableConv2d(math='bf16').  Two statements:
     (1) the kernel does exactly what it says -- operands rounded to bf16 (nearest even), exact products, fp32 accumulation:
@@ -238,7 +239,21 @@ def test_conv_bf16_opt_in_path(N, C, H, W, K, bias, pm):
     assert rel(y, y32) > 1e-5                                  # ... and it really is the bf16 path that ran
     r = ops.conv2d_backward(x.numpy(), w.numpy(), gy.numpy(), None if pmv is None else pmv.numpy(), bool(bias), 1, 1, 1)
     scale = float(np.abs(r['gw']).max())
-    close(layer.weight.grad, r['gw'], rtol=1e-4, atol=1e-5 * max(scale, 1.0), msg='gw (fp32 kernel)')
+    import ctypes
+    from cpg_amd import _lib as L
+    d = nl._conv_desc(x.shape, w.shape, (1, 1), (1, 1), (1, 1), 1)
+    if not bias and L.lib().cpg_conv2d_wgrad_bf16_supported(ctypes.byref(d)):
+        # the weight gradient ran on bf16 MFMA too: exact against an fp64 contraction of the bf16-rounded x and gy (then the
+        # autograd epilogue gW = g * bin(pm), gPM = g * W in fp32), within the opt-in tolerance of the fp32 oracle
+        w64 = torch.zeros(K, C, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(rb(x), w64, None, padding=1).backward(rb(gy))
+        keep = (pmv > 5e-3).double() if pm else torch.ones_like(w64)
+        assert rel(layer.weight.grad, w64.grad * keep) < 1e-5, rel(layer.weight.grad, w64.grad * keep)
+        assert rel(layer.weight.grad, torch.from_numpy(r['gw']).double()) < 2e-2
+        if pm:
+            assert rel(layer.piggymask.grad, w64.grad * w.double()) < 1e-5
+    else:
+        close(layer.weight.grad, r['gw'], rtol=1e-4, atol=1e-5 * max(scale, 1.0), msg='gw (fp32 kernel)')
 
 
 def test_conv_math_switch_is_opt_in():

@@ -70,6 +70,7 @@ def main():
         nws = L.cpg_conv2d_workspace_bytes(ctypes.byref(d))
         ws, nb = _lib.workspace(nws, dev)
         ws16, nb16 = _lib.workspace(L.cpg_conv2d_bf16_workspace_bytes(ctypes.byref(d)), dev)       # opt-in bf16 path (fwd16 / dgrad16)
+        wsw16, nbw16 = _lib.workspace(L.cpg_conv2d_wgrad_bf16_workspace_bytes(ctypes.byref(d)), dev)
         flops = 2.0 * a.batch * K * H * H * C * 9
         P = _lib.dptr
         tiles = L.cpg_conv2d_bnstats_tiles(ctypes.byref(d))
@@ -79,9 +80,14 @@ def main():
                 'dgrad': lambda: L.cpg_conv2d_dgrad(ctypes.byref(d), P(gy), P(w), P(pm), 5e-3, P(gx), P(ws), nb, st),
                 'fwd16': lambda: L.cpg_conv2d_fwd_bf16(ctypes.byref(d), P(x), P(w), P(pm), 5e-3, None, P(y), P(ws16), nb16, st),
                 'dgrad16': lambda: L.cpg_conv2d_dgrad_bf16(ctypes.byref(d), P(gy), P(w), P(pm), 5e-3, P(gx), P(ws16), nb16, st),
+                'wgrad16': lambda: L.cpg_conv2d_wgrad_bf16(ctypes.byref(d), P(x), P(gy), P(w), P(pm), 5e-3, P(gw), P(gpm), P(wsw16), nbw16, st),
                 'wgrad': lambda: L.cpg_conv2d_wgrad(ctypes.byref(d), P(x), P(gy), P(w), P(pm), 5e-3, P(gw), P(gpm), None, P(ws), nb, st)}
         for k in a.only.split(','):
             if k in ('dgrad', 'dgrad16') and name == 'f0':
+                continue
+            if k == 'wgrad16' and not L.cpg_conv2d_wgrad_bf16_supported(ctypes.byref(d)):
+                continue
+            if k in ('fwd16', 'dgrad16') and not L.cpg_conv2d_bf16_supported(ctypes.byref(d)):
                 continue
             if a.pmc_pass:
                 for _ in range(mult):
