@@ -280,8 +280,10 @@ int run(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, const 
 // from the group and one dword of its left / right neighbour with five v_alignbit (three of them shared by the two shifted
 // fragments).  Each wave owns a 32 co x 32 ci fragment for all 9 taps (9 accumulators); per k-step and row offset kh it issues 3
 // MFMAs against one b128 + two b32 reads.
-// Staging: thread = (channel, group): two 16-byte buffer loads (8 consecutive pixels; groups outside the image get an
-// out-of-range offset and read as 0), four v_cvt_pk_bf16_f32, one ds_write_b128.  The loads of unit u+1 are issued before the
+// Staging: thread = (channel, group): eight range-checked dword buffer loads (8 consecutive pixels = one 32-byte sector; groups
+// outside the image get an out-of-range offset and read as 0; a 16-lane group of a wave covers 16 channels x 4 consecutive
+// groups = one 128-byte line per channel), four v_cvt_pk_bf16_f32, one ds_write_b128.  (buffer_load_dwordx4 through the
+// same raw descriptor returned its first dword four times on gfx950 -- tools/diag_wgrad16.py -- and bought 4 % at best.)  The loads of unit u+1 are issued before the
 // MFMAs of unit u and stored into the other LDS stage after them (two stages, one barrier per unit, one block per CU).
 // MASKW: W is not a multiple of 8 (28-wide maps): the group that straddles the right image border is masked per element.
 // Split-K over units exactly like the fp32 kernel (k_c3_wgrad): tap-major partials, reduced (with the autograd epilogue
@@ -362,11 +364,8 @@ __global__ __launch_bounds__(256, 1) void k_c3b_wgrad(int N, int C, int H, int W
             const int off = ok ? (clamp_g(gch[i]) * HW + gh * W + gw) * 4 : kOutOfRange;
             if (Cfg::MASKW) gnv[i] = ok ? min(8, W - gw) : 0;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_g, off + 16 * q, 0, 0));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rg[i][4 * q + e] = __builtin_bit_cast(float, v[e]);
-            }
+            for (int e = 0; e < 8; ++e)
+                rg[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_g, off + 4 * e, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < Cfg::NXI; ++i) {
@@ -376,11 +375,8 @@ __global__ __launch_bounds__(256, 1) void k_c3b_wgrad(int N, int C, int H, int W
             const int off = ok ? (clamp_x(xch[i]) * HW + gh * W + gw) * 4 : kOutOfRange;
             if (Cfg::MASKW) xnv[i] = ok ? min(8, W - gw) : 0;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, off + 16 * q, 0, 0));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rx[i][4 * q + e] = __builtin_bit_cast(float, v[e]);
-            }
+            for (int e = 0; e < 8; ++e)
+                rx[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, off + 4 * e, 0, 0));
         }
     };
     auto store_unit = [&](u32x4 *stage) {
@@ -476,8 +472,9 @@ B16WPlan wplan(const cpg_conv_desc *d) {
     return p;
 }
 using B16G64 = B16WCfg<2, 64, false>;       // 56 / 112 / 224 wide maps (W a multiple of 8): 128 pixels per unit
-using B16G32 = B16WCfg<4, 32, true>;        // 28-wide maps: the last group of a row is masked per element
-inline int wpick(const cpg_conv_desc *d) { return d->W % 8 == 0 && d->W >= 56 ? 0 : 1; }
+using B16G32 = B16WCfg<4, 32, true>;        // any other width > 16 (28-wide maps): the group at the right border is masked per element
+using B16G16 = B16WCfg<8, 16, true>;        // <= 16 wide maps (14 x 14)
+inline int wpick(const cpg_conv_desc *d) { return d->W % 8 == 0 && d->W >= 56 ? 0 : d->W > 16 ? 1 : 2; }
 
 template <class Cfg>
 int wlaunch(const cpg_conv_desc *d, const float *x, const float *gy, const Epilogue &ep, void *ws, size_t ws_bytes, hipStream_t stream) {
@@ -523,23 +520,28 @@ extern "C" int cpg_conv2d_dgrad_bf16(const cpg_conv_desc *d, const float *gy, co
     return run(true, d->N, d->K, d->C, d->H, d->W, d->K, d->C, gy, w, pm, thr, nullptr, gx, ws, ws_bytes, (hipStream_t)stream);
 }
 
-// weight gradient on bf16 MFMA: supported for 3x3 s1 p1 layers with >= 16 channels on both sides whose width is a multiple of 4
-// and at least 28 (16-byte staging loads need aligned rows; 14 x 14 maps stay on the fp32 kernel)
+// weight gradient on bf16 MFMA: every 3x3 s1 p1 layer with >= 16 channels on both sides (the 3 -> 64 stem stays on fp32)
 extern "C" int32_t cpg_conv2d_wgrad_bf16_supported(const cpg_conv_desc *d) {
-    return cpg_conv2d_bf16_supported(d) && d->W % 4 == 0 && d->W >= 28 && (int64_t)d->H * d->W <= (1ll << 22) ? 1 : 0;
+    return cpg_conv2d_bf16_supported(d) && (int64_t)d->H * d->W <= (1ll << 22) ? 1 : 0;
 }
 
 extern "C" size_t cpg_conv2d_wgrad_bf16_workspace_bytes(const cpg_conv_desc *d) {
     if (!cpg_conv2d_wgrad_bf16_supported(d)) return 0;
-    return wpick(d) == 0 ? wplan<B16G64>(d).ws_bytes : wplan<B16G32>(d).ws_bytes;
+    switch (wpick(d)) {
+        case 0: return wplan<B16G64>(d).ws_bytes;
+        case 1: return wplan<B16G32>(d).ws_bytes;
+        default: return wplan<B16G16>(d).ws_bytes;
+    }
 }
 
 extern "C" int cpg_conv2d_wgrad_bf16(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
                                      float *gw, float *gpm, void *ws, size_t ws_bytes, void *stream) {
     if (!cpg_conv2d_wgrad_bf16_supported(d)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_wgrad_bf16: shape not supported");
     CPG_REQUIRE(x && gy && gw && w, "cpg_conv2d_wgrad_bf16: null pointer");
-    CPG_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)gy) & 15) == 0, "cpg_conv2d_wgrad_bf16: activations must be 16-byte aligned");
     Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
-    if (wpick(d) == 0) return wlaunch<B16G64>(d, x, gy, ep, ws, ws_bytes, (hipStream_t)stream);
-    return wlaunch<B16G32>(d, x, gy, ep, ws, ws_bytes, (hipStream_t)stream);
+    switch (wpick(d)) {
+        case 0: return wlaunch<B16G64>(d, x, gy, ep, ws, ws_bytes, (hipStream_t)stream);
+        case 1: return wlaunch<B16G32>(d, x, gy, ep, ws, ws_bytes, (hipStream_t)stream);
+        default: return wlaunch<B16G16>(d, x, gy, ep, ws, ws_bytes, (hipStream_t)stream);
+    }
 }

@@ -231,9 +231,8 @@ int cpg_conv2d_fwd_bn_eval(const cpg_conv_desc *desc, const float *x, const floa
  * rounded to bf16 on their way into LDS, exact products, fp32 accumulation (v_mfma_f32_32x32x16_bf16) -- the arithmetic of
  * an autocast(bf16) convolution.  All tensors in HBM stay fp32 NCHW.  NOT the default: north_star's 1e-4 parity bar is an
  * fp32 bar; this path has its own tolerance (about 1e-2 of the output scale) and its own roofline (2.5 PFLOP/s).
- * cpg_conv2d_wgrad_bf16 (gW_eff from bf16-rounded x and gy, then the same autograd epilogue as cpg_conv2d_wgrad) exists for
- * maps whose width is a multiple of 4 and >= 28; no bias gradient -- layers with a bias, the 14 x 14 maps and the 3 -> 64 stem
- * use cpg_conv2d_wgrad (fp32). */
+ * cpg_conv2d_wgrad_bf16: gW_eff from bf16-rounded x and gy, then the same autograd epilogue as cpg_conv2d_wgrad; no bias
+ * gradient -- layers with a bias and the 3 -> 64 stem (< 16 channels) use cpg_conv2d_wgrad (fp32). */
 int32_t cpg_conv2d_bf16_supported(const cpg_conv_desc *desc);
 int32_t cpg_conv2d_wgrad_bf16_supported(const cpg_conv_desc *desc);
 size_t cpg_conv2d_wgrad_bf16_workspace_bytes(const cpg_conv_desc *desc);
