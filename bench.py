@@ -110,6 +110,9 @@ class KernelClock:
         # the opt-in bf16 MFMA kernels (--math bf16) get their own families: they are measured against the bf16 peak
         p.cpg_conv2d_fwd_bf16 = timed('cpg_conv2d_fwd_bf16', conv_kind('conv_fwd_bf16'), conv_flops)
         p.cpg_conv2d_dgrad_bf16 = timed('cpg_conv2d_dgrad_bf16', conv_kind('conv_dgrad_bf16'), conv_flops)
+        p.cpg_conv2d_fwd_bf16x3 = timed('cpg_conv2d_fwd_bf16x3', conv_kind('conv_fwd_bf16'), conv_flops)
+        p.cpg_conv2d_dgrad_bf16x3 = timed('cpg_conv2d_dgrad_bf16x3', conv_kind('conv_dgrad_bf16'), conv_flops)
+        p.cpg_conv2d_wgrad_bf16x3 = timed('cpg_conv2d_wgrad_bf16x3', conv_kind('conv_wgrad_bf16'), conv_flops)
         p.cpg_conv2d_wgrad_bf16 = timed('cpg_conv2d_wgrad_bf16', conv_kind('conv_wgrad_bf16'), conv_flops)
         p.cpg_conv2d_dgrad = timed('cpg_conv2d_dgrad', conv_kind('conv_dgrad'), conv_flops)
         p.cpg_conv2d_wgrad = timed('cpg_conv2d_wgrad', conv_kind('conv_wgrad'), conv_flops)
@@ -339,7 +342,7 @@ def main():
     ap.add_argument('--steps', type=int, default=220, help='timed train steps (220 = the full section-8d cycle)')
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (config 2: 256)')
-    ap.add_argument('--math', default='fp32', choices=['fp32', 'bf16'],
+    ap.add_argument('--math', default='fp32', choices=['fp32', 'bf16', 'bf16x3'],
                     help="arithmetic of the 3x3 conv forward / input gradient: 'fp32' (default, the reference's precision) or the "
                          "OPT-IN 'bf16' MFMA path (never the headline: it does not meet north_star's 1e-4 parity bar)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -445,8 +448,9 @@ def main():
                'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
                'ms_per_step': round(1000.0 * dt / a.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
                'vs_baseline': None, 'data': 'synthetic',
-               'dtype': 'f32' if a.math == 'fp32' else 'bf16 operands / f32 accumulate in the 3x3 conv forward + input gradient (OPT-IN, '
-                                                       'not the headline); weight gradient, linear layers, BatchNorm, optimizer f32',
+               'dtype': 'f32' if a.math == 'fp32' else
+               ('bf16 operands' if a.math == 'bf16' else 'bf16x3 (two-term bf16 split of every operand, 3 MFMAs per product)')
+               + ' / f32 accumulate in the 3x3 convolutions (OPT-IN, not the headline); stem, linear layers, BatchNorm, optimizer f32',
                'config': {'workload': 'configs[1]: VGG16-BN custom_vgg 224x224, task-1 CPG cycle (finetune -> prune 0.0->0.1 -> recovery, '
                                       'validate after every 20th train step), batch %d per GPU' % a.batch,
                           'global_batch': global_batch, 'per_gpu_batch': a.batch, 'parallelism': 'dp%d' % world,

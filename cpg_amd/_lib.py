@@ -87,6 +87,9 @@ _SIGNATURES = {
     'cpg_conv2d_wgrad_bf16_supported': (ctypes.c_int32, [ctypes.POINTER(ConvDesc)]),
     'cpg_conv2d_wgrad_bf16_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     'cpg_conv2d_wgrad_bf16': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    'cpg_conv2d_fwd_bf16x3': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    'cpg_conv2d_dgrad_bf16x3': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_size_t, _vp]),
+    'cpg_conv2d_wgrad_bf16x3': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'cpg_conv2d_dgrad_bf16': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_size_t, _vp]),
     'cpg_bn_stats_finalize': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                              ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),

@@ -40,15 +40,20 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, v);
 }
 
+// lo part of the two-term split v = hi + lo (hi = bf16(v), lo = bf16(v - hi)): with NP = 2 planes the kernels accumulate
+// a_hi b_hi + a_hi b_lo + a_lo b_hi ("bf16x3"), which restores ~16 mantissa bits per product
+__device__ __forceinline__ float lo_part(float v) { return v - (float)(__bf16)v; }
+
 struct B16Geom {
     int N, C, H, W, M;        // C: channels read, M: channels produced
     int Mp;                   // M rounded up to 128 (row length of the packed weights, in uint4)
     int tiles_x, tiles_y, tiles_m, nchunks;
 };
 
-template <int BM_, int TH_, int TW_, int WM_, int WN_, int MINB_>
+template <int BM_, int TH_, int TW_, int WM_, int WN_, int MINB_, int NP_ = 1>
 struct B16Cfg {
     static constexpr int BM = BM_, TH = TH_, TW = TW_, WM = WM_, WN = WN_, MINB = MINB_;
+    static constexpr int NP = NP_;                            // operand planes: 1 = bf16, 2 = hi + lo ("bf16x3")
     static constexpr int BN = TH * TW;
     static_assert(WM * WN == 4 && BN % (32 * WN) == 0 && BM % (32 * WM) == 0, "bad bf16 conv config");
     static constexpr int FM = BM / 32 / WM, FN = BN / 32 / WN;
@@ -56,8 +61,9 @@ struct B16Cfg {
     static constexpr int NPIXP = (NPIX + 15) / 16 * 16;       // plane of one channel half, multiple of 256 bytes
     static constexpr int WQ = 9 * 2 * BM;                     // uint4 per stage: weights
     static constexpr int XQ = 2 * NPIXP;                      //                  patch
-    static constexpr int STAGEQ = WQ + XQ;
-    static constexpr int NWI = (WQ + 255) / 256;              // weight uint4 per thread per chunk
+    static constexpr int STAGE1 = WQ + XQ;                    // one plane; the lo plane (NP = 2) repeats the layout behind it
+    static constexpr int STAGEQ = NP * STAGE1;
+    static constexpr int NWI = (WQ + 255) / 256;              // weight uint4 per thread per chunk and plane
     static constexpr int NXI = (2 * NPIX + 255) / 256;        // (pixel, half) items per thread per chunk
 };
 
@@ -65,8 +71,9 @@ struct B16Cfg {
 // out[((chunk * 9 + tap') * 2 + h) * Mp + m] = 8 bf16: channels 16 * chunk + 8 * h + j (j = 0..7) of
 //   fwd  : W[co = m][ci = c][tap = tap'] * bin(pm)
 //   dgrad: W[co = c][ci = m][tap = 8 - tap'] * bin(pm)        (conv of gy with the spatially flipped, transposed filter)
+// np = 2: every chunk holds two such [tap][half][m] blocks, hi then lo.
 __global__ __launch_bounds__(256) void k_c3b_pack(const float *__restrict__ w, const float *__restrict__ pm, float thr,
-                                                  u32x4 *__restrict__ out, int K, int C, int nchunks, int Mp, int dgrad) {
+                                                  u32x4 *__restrict__ out, int K, int C, int nchunks, int Mp, int dgrad, int np) {
     const int64_t total = (int64_t)nchunks * 9 * 2 * Mp;
     const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += nthreads) {
@@ -87,8 +94,15 @@ __global__ __launch_bounds__(256) void k_c3b_pack(const float *__restrict__ w, c
                 if (pm != nullptr) v[j] *= binarize(pm[off], thr);
             }
         }
+        // o = (chunk * 18 + row) * Mp + m  ->  chunk-major with np planes per chunk
+        const int64_t dst = ((int64_t)chunk * np * 18 + (tp * 2 + h)) * Mp + m;
         u32x4 q = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-        out[o] = q;
+        out[dst] = q;
+        if (np == 2) {
+            u32x4 l = {pack2(lo_part(v[0]), lo_part(v[1])), pack2(lo_part(v[2]), lo_part(v[3])), pack2(lo_part(v[4]), lo_part(v[5])),
+                       pack2(lo_part(v[6]), lo_part(v[7]))};
+            out[dst + (int64_t)18 * Mp] = l;
+        }
     }
 }
 
@@ -135,12 +149,15 @@ __global__ __launch_bounds__(256, Cfg::MINB) void k_c3b_fwd(B16Geom g, const flo
     const __amdgpu_buffer_rsrc_t srd_x =
         __builtin_amdgcn_make_buffer_rsrc((void *)(x + (int64_t)n * g.C * HW), 0, g.C * HW * 4, 0x00020000);
 
-    u32x4 rw[Cfg::NWI];
+    u32x4 rw[Cfg::NP][Cfg::NWI];
     float rx[Cfg::NXI][8];
     auto load_chunk = [&](int ch) {
-        const u32x4 *wsrc_ch = wp + (int64_t)ch * 18 * g.Mp;
 #pragma unroll
-        for (int i = 0; i < Cfg::NWI; ++i) rw[i] = wsrc_ch[wsrc[i]];
+        for (int pl = 0; pl < Cfg::NP; ++pl) {
+            const u32x4 *wsrc_ch = wp + ((int64_t)ch * Cfg::NP + pl) * 18 * g.Mp;
+#pragma unroll
+            for (int i = 0; i < Cfg::NWI; ++i) rw[pl][i] = wsrc_ch[wsrc[i]];
+        }
         const int cbyte = ch * 16 * HW * 4;
 #pragma unroll
         for (int i = 0; i < Cfg::NXI; ++i)
@@ -152,12 +169,19 @@ __global__ __launch_bounds__(256, Cfg::MINB) void k_c3b_fwd(B16Geom g, const flo
     };
     auto store_chunk = [&](u32x4 *stage) {
 #pragma unroll
-        for (int i = 0; i < Cfg::NWI; ++i) stage[min(tid + 256 * i, Cfg::WQ - 1)] = rw[i];
+        for (int pl = 0; pl < Cfg::NP; ++pl)
+#pragma unroll
+            for (int i = 0; i < Cfg::NWI; ++i) stage[pl * Cfg::STAGE1 + min(tid + 256 * i, Cfg::WQ - 1)] = rw[pl][i];
 #pragma unroll
         for (int i = 0; i < Cfg::NXI; ++i) {
             if (xdst[i] >= 0) {
                 u32x4 q = {pack2(rx[i][0], rx[i][1]), pack2(rx[i][2], rx[i][3]), pack2(rx[i][4], rx[i][5]), pack2(rx[i][6], rx[i][7])};
                 stage[xdst[i]] = q;
+                if (Cfg::NP == 2) {
+                    u32x4 l = {pack2(lo_part(rx[i][0]), lo_part(rx[i][1])), pack2(lo_part(rx[i][2]), lo_part(rx[i][3])),
+                               pack2(lo_part(rx[i][4]), lo_part(rx[i][5])), pack2(lo_part(rx[i][6]), lo_part(rx[i][7]))};
+                    stage[Cfg::STAGE1 + xdst[i]] = l;
+                }
             }
         }
     };
@@ -189,17 +213,26 @@ __global__ __launch_bounds__(256, Cfg::MINB) void k_c3b_fwd(B16Geom g, const flo
         if (more) load_chunk(ch + 1);                              // in flight under the MFMAs below
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            bf16x8 a[Cfg::FM], b[Cfg::FN];
+            bf16x8 a[Cfg::NP][Cfg::FM], b[Cfg::NP][Cfg::FN];
 #pragma unroll
-            for (int fm = 0; fm < Cfg::FM; ++fm) a[fm] = __builtin_bit_cast(bf16x8, cur[a_base + tap * 2 * Cfg::BM + fm * 32]);
+            for (int pl = 0; pl < Cfg::NP; ++pl) {
 #pragma unroll
-            for (int fn = 0; fn < Cfg::FN; ++fn)
-                b[fn] = __builtin_bit_cast(bf16x8, cur[b_base[fn] + (tap / 3) * Cfg::PW + (tap % 3)]);
+                for (int fm = 0; fm < Cfg::FM; ++fm)
+                    a[pl][fm] = __builtin_bit_cast(bf16x8, cur[pl * Cfg::STAGE1 + a_base + tap * 2 * Cfg::BM + fm * 32]);
+#pragma unroll
+                for (int fn = 0; fn < Cfg::FN; ++fn)
+                    b[pl][fn] = __builtin_bit_cast(bf16x8, cur[pl * Cfg::STAGE1 + b_base[fn] + (tap / 3) * Cfg::PW + (tap % 3)]);
+            }
 #pragma unroll
             for (int fm = 0; fm < Cfg::FM; ++fm)
 #pragma unroll
-                for (int fn = 0; fn < Cfg::FN; ++fn)
-                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fm], b[fn], acc[fm][fn], 0, 0, 0);
+                for (int fn = 0; fn < Cfg::FN; ++fn) {
+                    if (Cfg::NP == 2) {          // small terms first: a_lo b_hi + a_hi b_lo, then a_hi b_hi (a_lo b_lo ~ 2^-16 of it is dropped)
+                        acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[Cfg::NP - 1][fm], b[0][fn], acc[fm][fn], 0, 0, 0);
+                        acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][fm], b[Cfg::NP - 1][fn], acc[fm][fn], 0, 0, 0);
+                    }
+                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][fm], b[0][fn], acc[fm][fn], 0, 0, 0);
+                }
         }
         if (more) store_chunk(other);
         __syncthreads();
@@ -223,7 +256,7 @@ __global__ __launch_bounds__(256, Cfg::MINB) void k_c3b_fwd(B16Geom g, const flo
 }
 
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
-inline size_t packb_bytes(int c_read, int m) { return (size_t)((c_read + 15) / 16) * 18 * pad_to(m, 128) * sizeof(u32x4); }
+inline size_t packb_bytes(int c_read, int m, int np = 2) { return (size_t)((c_read + 15) / 16) * np * 18 * pad_to(m, 128) * sizeof(u32x4); }
 
 template <class Cfg>
 int launch(B16Geom g, const float *x, const u32x4 *wp, const float *bias, float *y, hipStream_t stream, const char *what) {
@@ -248,18 +281,27 @@ using B16N128 = B16Cfg<128, 8, 32, 2, 2, 1>;      // everything else
 using B16N64 = B16Cfg<64, 8, 32, 2, 2, 2>;
 using B16P28 = B16Cfg<128, 7, 32, 4, 1, 1>;       // 28-high maps: 4 tiles of 7 rows (only the 4 padding columns are wasted)
 using B16S16 = B16Cfg<128, 14, 16, 4, 1, 1>;      // 14 x 14 (<= 16 wide) maps: the whole image, 7 fragments
+// two-plane ("bf16x3") variants: twice the LDS per chunk, so 64 output channels per block
+using X3W = B16Cfg<64, 8, 56, 2, 2, 1, 2>;
+using X3N = B16Cfg<64, 8, 32, 2, 2, 1, 2>;
+using X3S = B16Cfg<64, 8, 16, 2, 2, 1, 2>;        // <= 16 wide maps
 
 int run(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, const float *x, const float *w, const float *pm, float thr,
-        const float *bias, float *y, void *ws, size_t ws_bytes, hipStream_t stream) {
+        const float *bias, float *y, void *ws, size_t ws_bytes, hipStream_t stream, int np) {
     const char *what = dgrad ? "cpg_conv2d_dgrad_bf16" : "cpg_conv2d_fwd_bf16";
-    const size_t need = packb_bytes(c_read, m);
+    const size_t need = packb_bytes(c_read, m, np);
     if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
     CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
     u32x4 *wp = (u32x4 *)ws;
     const int nchunks = (c_read + 15) / 16, Mp = pad_to(m, 128);
     hipLaunchKernelGGL(k_c3b_pack, dim3(stream_grid((int64_t)nchunks * 18 * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, K, C, nchunks,
-                       Mp, dgrad ? 1 : 0);
+                       Mp, dgrad ? 1 : 0, np);
     B16Geom g{N, c_read, H, W, m, Mp, 0, 0, 0, nchunks};
+    if (np == 2) {
+        if (W % 56 == 0) return launch<X3W>(g, x, wp, bias, y, stream, what);
+        if (W <= 16) return launch<X3S>(g, x, wp, bias, y, stream, what);
+        return launch<X3N>(g, x, wp, bias, y, stream, what);
+    }
     const bool wide = W % 56 == 0;
     if (wide) return m > 64 ? launch<B16W128>(g, x, wp, bias, y, stream, what) : launch<B16W64>(g, x, wp, bias, y, stream, what);
     if (m > 64 && W <= 16 && H <= 14) return launch<B16S16>(g, x, wp, bias, y, stream, what);
@@ -288,13 +330,14 @@ int run(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, const 
 // MASKW: W is not a multiple of 8 (28-wide maps): the group that straddles the right image border is masked per element.
 // Split-K over units exactly like the fp32 kernel (k_c3_wgrad): tap-major partials, reduced (with the autograd epilogue
 // gW = g * bin(pm), gPM = g * W) by k_split_reduce.
-template <int TH_, int TW_, bool MASKW_>
+template <int TH_, int TW_, bool MASKW_, int NP_ = 1>
 struct B16WCfg {
-    static constexpr int TH = TH_, TW = TW_;
+    static constexpr int TH = TH_, TW = TW_, NP = NP_;
     static constexpr bool MASKW = MASKW_;
     static_assert(TW % 16 == 0, "k-steps are 16 pixels of one row");
     static constexpr int GG = TW / 8, XG = GG + 2, XR = TH + 2;          // groups per gy row / x row, x rows
-    static constexpr int GQ = TH * GG * 64, XQ = XR * XG * 64, STAGEQ = GQ + XQ;      // uint4 per stage
+    static constexpr int GQ = TH * GG * 64, XQ = XR * XG * 64, STAGE1 = GQ + XQ;      // uint4 per plane
+    static constexpr int STAGEQ = NP * STAGE1;                                        // (the lo plane repeats the layout)
     static constexpr int NGI = GQ / 256, NXI = (XQ + 255) / 256;          // staging items (channel, group) per thread
     static_assert(GQ % 256 == 0, "gy items must fill the block");
 };
@@ -379,14 +422,22 @@ __global__ __launch_bounds__(256, 1) void k_c3b_wgrad(int N, int C, int H, int W
                 rx[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, off + 4 * e, 0, 0));
         }
     };
+    auto put = [&](u32x4 *stage, int idx, const float (&v)[8]) {
+        u32x4 q = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        stage[idx] = q;
+        if (Cfg::NP == 2) {
+            u32x4 l = {pack2(lo_part(v[0]), lo_part(v[1])), pack2(lo_part(v[2]), lo_part(v[3])), pack2(lo_part(v[4]), lo_part(v[5])),
+                       pack2(lo_part(v[6]), lo_part(v[7]))};
+            stage[Cfg::STAGE1 + idx] = l;
+        }
+    };
     auto store_unit = [&](u32x4 *stage) {
 #pragma unroll
         for (int i = 0; i < Cfg::NGI; ++i) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (Cfg::MASKW && e >= gnv[i]) ? 0.0f : rg[i][e];
-            u32x4 q = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-            stage[ggrp[i] * 64 + gch[i]] = q;
+            put(stage, ggrp[i] * 64 + gch[i], v);
         }
 #pragma unroll
         for (int i = 0; i < Cfg::NXI; ++i) {
@@ -394,8 +445,7 @@ __global__ __launch_bounds__(256, 1) void k_c3b_wgrad(int N, int C, int H, int W
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (Cfg::MASKW && e >= xnv[i]) ? 0.0f : rx[i][e];
-                u32x4 q = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-                stage[Cfg::GQ + xgrp[i] * 64 + xch[i]] = q;
+                put(stage, Cfg::GQ + xgrp[i] * 64 + xch[i], v);
             }
         }
     };
@@ -407,19 +457,34 @@ __global__ __launch_bounds__(256, 1) void k_c3b_wgrad(int N, int C, int H, int W
         for (int r = 0; r < Cfg::TH; ++r)
 #pragma unroll
             for (int k = 0; k < Cfg::TW / 16; ++k) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, cur[(r * Cfg::GG + 2 * k + lh) * 64 + a_lane]);
+                bf16x8 a[Cfg::NP];
+#pragma unroll
+                for (int pl = 0; pl < Cfg::NP; ++pl)
+                    a[pl] = __builtin_bit_cast(bf16x8, cur[pl * Cfg::STAGE1 + (r * Cfg::GG + 2 * k + lh) * 64 + a_lane]);
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
-                    const int gi = Cfg::GQ + ((r + kh) * Cfg::XG + 1 + 2 * k + lh) * 64 + b_lane;     // centre group (uint4 index)
-                    const u32x4 c = cur[gi];
-                    const unsigned left = cur32[(gi - 64) * 4 + 3], right = cur32[(gi + 64) * 4 + 0];
-                    const unsigned s01 = __builtin_amdgcn_alignbit(c[1], c[0], 16), s12 = __builtin_amdgcn_alignbit(c[2], c[1], 16),
-                                   s23 = __builtin_amdgcn_alignbit(c[3], c[2], 16);
-                    const u32x4 bl = {__builtin_amdgcn_alignbit(c[0], left, 16), s01, s12, s23};      // pixels p0 - 1 ... p0 + 6
-                    const u32x4 br = {s01, s12, s23, __builtin_amdgcn_alignbit(right, c[3], 16)};     // pixels p0 + 1 ... p0 + 8
-                    acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, bl), acc[kh * 3 + 0], 0, 0, 0);
-                    acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, c), acc[kh * 3 + 1], 0, 0, 0);
-                    acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, br), acc[kh * 3 + 2], 0, 0, 0);
+                    bf16x8 b[Cfg::NP][3];                                   // [plane][kw]
+#pragma unroll
+                    for (int pl = 0; pl < Cfg::NP; ++pl) {
+                        const int gi = pl * Cfg::STAGE1 + Cfg::GQ + ((r + kh) * Cfg::XG + 1 + 2 * k + lh) * 64 + b_lane;   // centre group
+                        const u32x4 c = cur[gi];
+                        const unsigned left = cur32[(gi - 64) * 4 + 3], right = cur32[(gi + 64) * 4 + 0];
+                        const unsigned s01 = __builtin_amdgcn_alignbit(c[1], c[0], 16), s12 = __builtin_amdgcn_alignbit(c[2], c[1], 16),
+                                       s23 = __builtin_amdgcn_alignbit(c[3], c[2], 16);
+                        const u32x4 bl = {__builtin_amdgcn_alignbit(c[0], left, 16), s01, s12, s23};      // pixels p0 - 1 ... p0 + 6
+                        const u32x4 br = {s01, s12, s23, __builtin_amdgcn_alignbit(right, c[3], 16)};     // pixels p0 + 1 ... p0 + 8
+                        b[pl][0] = __builtin_bit_cast(bf16x8, bl);
+                        b[pl][1] = __builtin_bit_cast(bf16x8, c);
+                        b[pl][2] = __builtin_bit_cast(bf16x8, br);
+                    }
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        if (Cfg::NP == 2) {
+                            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[Cfg::NP - 1], b[0][kw], acc[kh * 3 + kw], 0, 0, 0);
+                            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[Cfg::NP - 1][kw], acc[kh * 3 + kw], 0, 0, 0);
+                        }
+                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][kw], acc[kh * 3 + kw], 0, 0, 0);
+                    }
                 }
             }
     };
@@ -474,6 +539,10 @@ B16WPlan wplan(const cpg_conv_desc *d) {
 using B16G64 = B16WCfg<2, 64, false>;       // 56 / 112 / 224 wide maps (W a multiple of 8): 128 pixels per unit
 using B16G32 = B16WCfg<4, 32, true>;        // any other width > 16 (28-wide maps): the group at the right border is masked per element
 using B16G16 = B16WCfg<8, 16, true>;        // <= 16 wide maps (14 x 14)
+// two-plane ("bf16x3") variants: half the rows per unit so that two stages still fit in LDS
+using X3G64 = B16WCfg<1, 64, false, 2>;
+using X3G32 = B16WCfg<2, 32, true, 2>;
+using X3G16 = B16WCfg<4, 16, true, 2>;
 inline int wpick(const cpg_conv_desc *d) { return d->W % 8 == 0 && d->W >= 56 ? 0 : d->W > 16 ? 1 : 2; }
 
 template <class Cfg>
@@ -501,23 +570,38 @@ extern "C" int32_t cpg_conv2d_bf16_supported(const cpg_conv_desc *d) {
     return d != nullptr && cpg_conv3x3_supported(d) && d->C >= 16 && d->K >= 16 ? 1 : 0;
 }
 
-extern "C" size_t cpg_conv2d_bf16_workspace_bytes(const cpg_conv_desc *d) {
+extern "C" size_t cpg_conv2d_bf16_workspace_bytes(const cpg_conv_desc *d) {       // (sized for the two-plane variant)
     if (!cpg_conv2d_bf16_supported(d)) return 0;
     return std::max(packb_bytes(d->C, d->K), packb_bytes(d->K, d->C));
 }
 
+static int fwd_any(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias, float *y,
+                   void *ws, size_t ws_bytes, void *stream, int np) {
+    if (!cpg_conv2d_bf16_supported(d)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_fwd_bf16: only 3x3 / stride 1 / pad 1 convolutions with >= 16 channels");
+    CPG_REQUIRE(x && w && y, "cpg_conv2d_fwd_bf16: null pointer");
+    return run(false, d->N, d->C, d->K, d->H, d->W, d->K, d->C, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream, np);
+}
+static int dgrad_any(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx, void *ws,
+                     size_t ws_bytes, void *stream, int np) {
+    if (!cpg_conv2d_bf16_supported(d)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_dgrad_bf16: only 3x3 / stride 1 / pad 1 convolutions with >= 16 channels");
+    CPG_REQUIRE(gy && w && gx, "cpg_conv2d_dgrad_bf16: null pointer");
+    return run(true, d->N, d->K, d->C, d->H, d->W, d->K, d->C, gy, w, pm, thr, nullptr, gx, ws, ws_bytes, (hipStream_t)stream, np);
+}
 extern "C" int cpg_conv2d_fwd_bf16(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
                                    float *y, void *ws, size_t ws_bytes, void *stream) {
-    if (!cpg_conv2d_bf16_supported(d)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_fwd_bf16: only 3x3 / stride 1 / pad 1 convolutions");
-    CPG_REQUIRE(x && w && y, "cpg_conv2d_fwd_bf16: null pointer");
-    return run(false, d->N, d->C, d->K, d->H, d->W, d->K, d->C, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream);
+    return fwd_any(d, x, w, pm, thr, bias, y, ws, ws_bytes, stream, 1);
 }
-
+extern "C" int cpg_conv2d_fwd_bf16x3(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr,
+                                     const float *bias, float *y, void *ws, size_t ws_bytes, void *stream) {
+    return fwd_any(d, x, w, pm, thr, bias, y, ws, ws_bytes, stream, 2);
+}
 extern "C" int cpg_conv2d_dgrad_bf16(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx,
                                      void *ws, size_t ws_bytes, void *stream) {
-    if (!cpg_conv2d_bf16_supported(d)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_dgrad_bf16: only 3x3 / stride 1 / pad 1 convolutions");
-    CPG_REQUIRE(gy && w && gx, "cpg_conv2d_dgrad_bf16: null pointer");
-    return run(true, d->N, d->K, d->C, d->H, d->W, d->K, d->C, gy, w, pm, thr, nullptr, gx, ws, ws_bytes, (hipStream_t)stream);
+    return dgrad_any(d, gy, w, pm, thr, gx, ws, ws_bytes, stream, 1);
+}
+extern "C" int cpg_conv2d_dgrad_bf16x3(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx,
+                                       void *ws, size_t ws_bytes, void *stream) {
+    return dgrad_any(d, gy, w, pm, thr, gx, ws, ws_bytes, stream, 2);
 }
 
 // weight gradient on bf16 MFMA: every 3x3 s1 p1 layer with >= 16 channels on both sides (the 3 -> 64 stem stays on fp32)
@@ -525,23 +609,35 @@ extern "C" int32_t cpg_conv2d_wgrad_bf16_supported(const cpg_conv_desc *d) {
     return cpg_conv2d_bf16_supported(d) && (int64_t)d->H * d->W <= (1ll << 22) ? 1 : 0;
 }
 
-extern "C" size_t cpg_conv2d_wgrad_bf16_workspace_bytes(const cpg_conv_desc *d) {
+extern "C" size_t cpg_conv2d_wgrad_bf16_workspace_bytes(const cpg_conv_desc *d) {  // (the larger of the one- and two-plane plans)
     if (!cpg_conv2d_wgrad_bf16_supported(d)) return 0;
     switch (wpick(d)) {
-        case 0: return wplan<B16G64>(d).ws_bytes;
-        case 1: return wplan<B16G32>(d).ws_bytes;
-        default: return wplan<B16G16>(d).ws_bytes;
+        case 0: return std::max(wplan<B16G64>(d).ws_bytes, wplan<X3G64>(d).ws_bytes);
+        case 1: return std::max(wplan<B16G32>(d).ws_bytes, wplan<X3G32>(d).ws_bytes);
+        default: return std::max(wplan<B16G16>(d).ws_bytes, wplan<X3G16>(d).ws_bytes);
     }
 }
 
-extern "C" int cpg_conv2d_wgrad_bf16(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
-                                     float *gw, float *gpm, void *ws, size_t ws_bytes, void *stream) {
+static int wgrad_any(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr, float *gw,
+                     float *gpm, void *ws, size_t ws_bytes, void *stream, int np) {
     if (!cpg_conv2d_wgrad_bf16_supported(d)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_wgrad_bf16: shape not supported");
     CPG_REQUIRE(x && gy && gw && w, "cpg_conv2d_wgrad_bf16: null pointer");
     Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
-    switch (wpick(d)) {
-        case 0: return wlaunch<B16G64>(d, x, gy, ep, ws, ws_bytes, (hipStream_t)stream);
-        case 1: return wlaunch<B16G32>(d, x, gy, ep, ws, ws_bytes, (hipStream_t)stream);
-        default: return wlaunch<B16G16>(d, x, gy, ep, ws, ws_bytes, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    switch (wpick(d) * 2 + (np == 2)) {
+        case 0: return wlaunch<B16G64>(d, x, gy, ep, ws, ws_bytes, st);
+        case 1: return wlaunch<X3G64>(d, x, gy, ep, ws, ws_bytes, st);
+        case 2: return wlaunch<B16G32>(d, x, gy, ep, ws, ws_bytes, st);
+        case 3: return wlaunch<X3G32>(d, x, gy, ep, ws, ws_bytes, st);
+        case 4: return wlaunch<B16G16>(d, x, gy, ep, ws, ws_bytes, st);
+        default: return wlaunch<X3G16>(d, x, gy, ep, ws, ws_bytes, st);
     }
+}
+extern "C" int cpg_conv2d_wgrad_bf16(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
+                                     float *gw, float *gpm, void *ws, size_t ws_bytes, void *stream) {
+    return wgrad_any(d, x, gy, w, pm, thr, gw, gpm, ws, ws_bytes, stream, 1);
+}
+extern "C" int cpg_conv2d_wgrad_bf16x3(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
+                                       float *gw, float *gpm, void *ws, size_t ws_bytes, void *stream) {
+    return wgrad_any(d, x, gy, w, pm, thr, gw, gpm, ws, ws_bytes, stream, 2);
 }

@@ -25,16 +25,17 @@ from .. import _lib
 DEFAULT_THRESHOLD = 5e-3      # models/layers.py:9
 
 # Arithmetic of the masked 3x3 convolutions: 'fp32' (default; fp32 MFMA, the reference's precision and north_star's parity
-# bar) or the OPT-IN 'bf16' (operands rounded to bf16 on their way into LDS, fp32 accumulation -- forward and input gradient
-# and, where a kernel exists, weight gradient on v_mfma_f32_32x32x16_bf16).  A layer's own `.math` attribute, when set, wins.
+# bar), or OPT-IN: 'bf16' (operands rounded to bf16 on their way into LDS, fp32 accumulation, on v_mfma_f32_32x32x16_bf16)
+# and 'bf16x3' (each operand split into two bf16 terms, three MFMAs per product: ~16 mantissa bits, 5e-6 of the output scale
+# per layer).  A layer's own `.math` attribute, when set, wins.
 CONV_MATH = 'fp32'
 
 
 def set_conv_math(math):
     """Select the arithmetic of every SharableConv2d that has no `.math` of its own: 'fp32' or 'bf16' (opt-in)."""
     global CONV_MATH
-    if math not in ('fp32', 'bf16'):
-        raise ValueError("conv math must be 'fp32' or 'bf16', got %r" % (math,))
+    if math not in ('fp32', 'bf16', 'bf16x3'):
+        raise ValueError("conv math must be 'fp32', 'bf16' or 'bf16x3', got %r" % (math,))
     CONV_MATH = math
 
 
@@ -93,7 +94,7 @@ class _MaskedConv2dFn(torch.autograd.Function):
         y = torch.empty((d.N, d.K, oh, ow), dtype=torch.float32, device=x.device)
         L = _lib.lib()
         ctx.empty = d.N == 0
-        ctx.bf16 = False
+        ctx.bf16 = ctx.x3 = False
         if ctx.empty:                   # an empty batch is legal for F.conv2d: empty output, zero parameter gradients
             _lib.dptr(x, name='input'), _lib.dptr(w, name='weight')            # still no CPU / dtype fallback
             ctx.save_for_backward(x, w, p)
@@ -103,13 +104,15 @@ class _MaskedConv2dFn(torch.autograd.Function):
             stats = torch.empty(0, dtype=torch.float32, device=x.device)
             ctx.mark_non_differentiable(stats)
             return y, stats
-        ctx.bf16 = math == 'bf16' and bool(L.cpg_conv2d_bf16_supported(ctypes.byref(d)))
+        ctx.bf16 = math in ('bf16', 'bf16x3') and bool(L.cpg_conv2d_bf16_supported(ctypes.byref(d)))
+        ctx.x3 = math == 'bf16x3'
         if ctx.bf16:
             # opt-in bf16 MFMA forward (no fused BatchNorm statistics on this path: the BatchNorm runs its own pass)
             ws, nbytes = _lib.workspace(L.cpg_conv2d_bf16_workspace_bytes(ctypes.byref(d)), x.device)
-            rc = L.cpg_conv2d_fwd_bf16(ctypes.byref(d), _lib.dptr(x, name='input'), _lib.dptr(w, name='weight'),
-                                       _lib.dptr(p, name='piggymask'), float(thr), _lib.dptr(bias, name='bias'), _lib.dptr(y),
-                                       _lib.dptr(ws), nbytes, _lib.stream_ptr())
+            fwd = L.cpg_conv2d_fwd_bf16x3 if ctx.x3 else L.cpg_conv2d_fwd_bf16
+            rc = fwd(ctypes.byref(d), _lib.dptr(x, name='input'), _lib.dptr(w, name='weight'),
+                     _lib.dptr(p, name='piggymask'), float(thr), _lib.dptr(bias, name='bias'), _lib.dptr(y),
+                     _lib.dptr(ws), nbytes, _lib.stream_ptr())
             _lib.check('cpg_conv2d_fwd_bf16', rc)
             ctx.save_for_backward(x, w, p)
             ctx.desc, ctx.thr, ctx.has_bias = d, float(thr), bias is not None
@@ -157,8 +160,9 @@ class _MaskedConv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] and ctx.bf16:
             gx = torch.empty_like(x)
             ws16, nb16 = _lib.workspace(L.cpg_conv2d_bf16_workspace_bytes(ctypes.byref(d)), x.device)
-            rc = L.cpg_conv2d_dgrad_bf16(ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr,
-                                         _lib.dptr(gx), _lib.dptr(ws16), nb16, s)
+            dgrad = L.cpg_conv2d_dgrad_bf16x3 if ctx.x3 else L.cpg_conv2d_dgrad_bf16
+            rc = dgrad(ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr,
+                       _lib.dptr(gx), _lib.dptr(ws16), nb16, s)
             _lib.check('cpg_conv2d_dgrad_bf16', rc)
         elif ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
@@ -171,8 +175,9 @@ class _MaskedConv2dFn(torch.autograd.Function):
             gb = torch.empty(d.K, dtype=torch.float32, device=x.device) if ctx.has_bias else None
             if ctx.bf16 and not ctx.has_bias and L.cpg_conv2d_wgrad_bf16_supported(ctypes.byref(d)):
                 wsw, nbw = _lib.workspace(L.cpg_conv2d_wgrad_bf16_workspace_bytes(ctypes.byref(d)), x.device)
-                rc = L.cpg_conv2d_wgrad_bf16(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), _lib.dptr(p), thr,
-                                             _lib.dptr(gw), _lib.dptr(gpm), _lib.dptr(wsw), nbw, s)
+                wgrad = L.cpg_conv2d_wgrad_bf16x3 if ctx.x3 else L.cpg_conv2d_wgrad_bf16
+                rc = wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), _lib.dptr(p), thr,
+                           _lib.dptr(gw), _lib.dptr(gpm), _lib.dptr(wsw), nbw, s)
                 _lib.check('cpg_conv2d_wgrad_bf16', rc)
             else:
                 rc = L.cpg_conv2d_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), _lib.dptr(p), thr,

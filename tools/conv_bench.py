@@ -80,14 +80,17 @@ def main():
                 'dgrad': lambda: L.cpg_conv2d_dgrad(ctypes.byref(d), P(gy), P(w), P(pm), 5e-3, P(gx), P(ws), nb, st),
                 'fwd16': lambda: L.cpg_conv2d_fwd_bf16(ctypes.byref(d), P(x), P(w), P(pm), 5e-3, None, P(y), P(ws16), nb16, st),
                 'dgrad16': lambda: L.cpg_conv2d_dgrad_bf16(ctypes.byref(d), P(gy), P(w), P(pm), 5e-3, P(gx), P(ws16), nb16, st),
+                'fwdx3': lambda: L.cpg_conv2d_fwd_bf16x3(ctypes.byref(d), P(x), P(w), P(pm), 5e-3, None, P(y), P(ws16), nb16, st),
+                'dgradx3': lambda: L.cpg_conv2d_dgrad_bf16x3(ctypes.byref(d), P(gy), P(w), P(pm), 5e-3, P(gx), P(ws16), nb16, st),
+                'wgradx3': lambda: L.cpg_conv2d_wgrad_bf16x3(ctypes.byref(d), P(x), P(gy), P(w), P(pm), 5e-3, P(gw), P(gpm), P(wsw16), nbw16, st),
                 'wgrad16': lambda: L.cpg_conv2d_wgrad_bf16(ctypes.byref(d), P(x), P(gy), P(w), P(pm), 5e-3, P(gw), P(gpm), P(wsw16), nbw16, st),
                 'wgrad': lambda: L.cpg_conv2d_wgrad(ctypes.byref(d), P(x), P(gy), P(w), P(pm), 5e-3, P(gw), P(gpm), None, P(ws), nb, st)}
         for k in a.only.split(','):
-            if k in ('dgrad', 'dgrad16') and name == 'f0':
+            if k in ('dgrad', 'dgrad16', 'dgradx3') and name == 'f0':
                 continue
-            if k == 'wgrad16' and not L.cpg_conv2d_wgrad_bf16_supported(ctypes.byref(d)):
+            if k in ('wgrad16', 'wgradx3') and not L.cpg_conv2d_wgrad_bf16_supported(ctypes.byref(d)):
                 continue
-            if k in ('fwd16', 'dgrad16') and not L.cpg_conv2d_bf16_supported(ctypes.byref(d)):
+            if k in ('fwd16', 'dgrad16', 'fwdx3', 'dgradx3') and not L.cpg_conv2d_bf16_supported(ctypes.byref(d)):
                 continue
             if a.pmc_pass:
                 for _ in range(mult):
