@@ -232,7 +232,7 @@ int cpg_conv2d_fwd_bn_eval(const cpg_conv_desc *desc, const float *x, const floa
  * an autocast(bf16) convolution.  All tensors in HBM stay fp32 NCHW.  NOT the default: north_star's 1e-4 parity bar is an
  * fp32 bar; this path has its own tolerance (about 1e-2 of the output scale) and its own roofline (2.5 PFLOP/s).
  * cpg_conv2d_wgrad_bf16: gW_eff from bf16-rounded x and gy, then the same autograd epilogue as cpg_conv2d_wgrad; no bias
- * gradient -- layers with a bias and the 3 -> 64 stem (< 16 channels) use cpg_conv2d_wgrad (fp32). */
+ * gradient -- layers with a bias and the 3 -> 64 stem (< 16 channels) use cpg_conv2d_wgrad (fp32).
  * The *_bf16x3 entry points run the same kernels with every operand split into two bf16 terms, v = hi + lo (hi = bf16(v),
  * lo = bf16(v - hi)), and accumulate a_hi*b_hi + a_hi*b_lo + a_lo*b_hi in fp32: ~16 mantissa bits per product instead of 8
  * (measured 5e-6 of the output scale per layer against 2.5e-3 for plain bf16 and 2.5e-7 for fp32 MFMA) at 3/16 of the fp32
