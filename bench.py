@@ -278,6 +278,36 @@ def phase_report(marks, model, masks, batch):
     return rep
 
 
+def optin_modes(model, masks, pool, steps, batch):
+    """Train-step time of the same model in the two OPT-IN conv arithmetics (cpg_amd.models.layers.set_conv_math), measured
+    after the timed cycle and reported beside it -- information for the reader, not the metric: 'bf16x3' (two-term bf16 split,
+    3 MFMAs per product) holds north_star's 1e-4 logit bar (tests/test_hip_parity.py::test_first_forward_logits_golden_bf16x3),
+    'bf16' does not (2e-2 of the output scale)."""
+    res = {}
+    for mode in ('bf16x3', 'bf16'):
+        nl.set_conv_math(mode)
+        try:
+            mgr = Manager(make_args('finetune', 1), model, {}, {k: v.clone() for k, v in masks.items()},
+                          [pool[i % len(pool)] for i in range(steps)], None, 0, 0)
+            opt = Optimizers()
+            opt.add(torch.optim.SGD(model.parameters(), lr=0.0, momentum=0.9, nesterov=True), 0.0)
+            mgr.train_loader = [pool[0], pool[1]]
+            mgr.train(opt, 0, [0.0], 0)                        # warm the kernels of this mode
+            mgr.train_loader = [pool[i % len(pool)] for i in range(steps)]
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            s.record()
+            mgr.train(opt, 0, [0.0], 0)
+            e.record()
+            torch.cuda.synchronize()
+            ms = s.elapsed_time(e) / steps
+            res[mode] = {'train_ms_per_step': round(ms, 3), 'train_images_per_sec': round(batch / ms * 1e3, 1),
+                         'meets_1e-4_logit_bar': mode == 'bf16x3'}
+        finally:
+            nl.set_conv_math('fp32')
+    return res
+
+
 def cpu_baseline(budget_s=15.0, steps=220, batch=256, validates=11, prune_events=4, cpu_batch=64):
     """Oracle ("port") of the same cycle on the host cores: a bounded sample of each ingredient -- train steps, one
     rank-prune event over all 15 layers, one validate batch -- extrapolated to the cycle the GPU ACTUALLY ran (K train
@@ -345,6 +375,9 @@ def main():
     ap.add_argument('--math', default='fp32', choices=['fp32', 'bf16', 'bf16x3'],
                     help="arithmetic of the 3x3 conv forward / input gradient: 'fp32' (default, the reference's precision) or the "
                          "OPT-IN 'bf16' MFMA path (never the headline: it does not meet north_star's 1e-4 parity bar)")
+    ap.add_argument('--optin-steps', type=int, default=8,
+                    help='after the timed cycle, also time this many train steps in each opt-in conv arithmetic (reported beside the '
+                         'headline as opt_in_conv_math, never as value); 0 = skip')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-clock', action='store_true')
     a = ap.parse_args()
@@ -493,6 +526,8 @@ def main():
                 out['kernel_detail'] = {k: {'n': v[0], 'ms': round(v[1], 2), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
                                         for k, v in sorted(agg.items())}
         out['phases'] = phase_report(marks, model, masks, a.batch)
+        if a.math == 'fp32' and world == 1 and a.optin_steps > 0:
+            out['opt_in_conv_math'] = optin_modes(model, masks, pool, a.optin_steps, a.batch)
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(steps=a.steps, batch=a.batch, validates=counts['validates'],
                                                prune_events=counts['prune_events'])
