@@ -605,13 +605,19 @@ def test_first_forward_logits_golden(arch, width, fx):
     close(y, g['y'], rtol=1e-4, atol=1e-4 * scale, msg=arch)
 
 
+@pytest.mark.parametrize('math', ['fp32', 'bf16x3'])
 @pytest.mark.parametrize('mode', ['prune', 'finetune'])
-def test_trajectory_golden(mode):
+def test_trajectory_golden(mode, math):
     """12 steps of the Manager.train op order on a narrow VGG16-BN: logits per step, prune ratios,
     sparsities; owner masks compared bit-exact where fp32 round-off cannot flip a rank."""
     g = load_golden('trajectory_' + mode)
     width = float(g['width'])
     net = build('vgg_cifar100', width)
+    # math = 'bf16x3': the same 12-step trajectory with the 3x3 convolutions (>= 16 channels) on the opt-in 3-product bf16 path --
+    # the same bars hold (step 0 at 1e-4, masks, ratios, sparsities)
+    for m_ in net.modules():
+        if isinstance(m_, nl.SharableConv2d):
+            m_.math = math
     sd = net.state_dict()
     for k in sd:                                      # same initial state as the reference run
         np.testing.assert_array_equal(sd[k].numpy(), g['init/' + k], err_msg=k)
@@ -662,7 +668,7 @@ def test_trajectory_golden(mode):
     with torch.no_grad():
         ev = model(xs[0])
     close(ev, g['eval_logits'], rtol=1e-3, atol=1e-4 * float(np.abs(g['eval_logits']).max()), msg='eval logits after 12 steps (drift)')
-    print('trajectory_%s: max logit drift over 12 steps %.2e of the logit scale' % (mode, drift))
+    print('trajectory_%s (%s): max logit drift over 12 steps %.2e of the logit scale' % (mode, math, drift))
 
 
 # --------------------------------------------------------------------------- the reference's own Manager.train / validate
