@@ -59,8 +59,8 @@ __device__ __forceinline__ f32x4 ld_sv4(const float *sbase, unsigned byte_off) {
 // Inference-mode BatchNorm (+ ReLU) folded into the forward epilogue: y = [max(0,] (acc + bias - mean) * invstd * gamma + beta [)]
 // with invstd = 1 / sqrt(var + eps) -- the expression of bn_kernels.hip's apply pass.  gamma == nullptr: plain conv.
 // `live` (may be null; inference only): liveness of the effective weights, written by k_c3_pack -- live[m] != 0 when output
-// channel m has a non-zero weight, live[Mp] = 1 + the last input channel with a non-zero weight, live[Mp + 1] counts the
-// output tiles that were skipped (diagnostics).  A block whose BM output channels are all dead skips its MFMA loop (their
+// channel m has a non-zero weight, live[Mp + 4 + q] != 0 when input-channel chunk q (4 channels) has one; live[Mp] receives
+// 4 * (number of chunks up to the last live one), live[Mp + 1] counts the output tiles that were skipped (diagnostics).  A block whose BM output channels are all dead skips its MFMA loop (their
 // conv output is exactly 0, the epilogue still writes bias / BatchNorm of 0), and every block stops after the last live
 // input-channel chunk.  Whole channels die when a model that was GROWN for later tasks serves an earlier, narrower task
 // after apply_mask (every slot with owner > task is zero): the kernel then does the work of the cropped model.
@@ -136,14 +136,12 @@ __global__ __launch_bounds__(256) void k_c3_pack(const float *__restrict__ w, co
             if (pm != nullptr) v *= binarize(pm[off], thr);
         }
         out[o] = v;
-        // liveness (forward flavour, zeroed by the caller): columns are posted by the lanes that hold a non-zero (plain
-        // stores of 1: benign race); rows by ONE lane per wave -- c is non-decreasing in o, so the wave's largest live input
-        // channel belongs to its highest lane with a non-zero (ballot + count-leading-zeros)
-        if (live != nullptr) {
-            const bool nz = v != 0.0f;
-            if (nz) live[m] = 1;
-            const unsigned long long any = __ballot(nz);
-            if (any != 0ull && (int)(threadIdx.x & 63) == 63 - __clzll((long long)any)) atomicMax(&live[Mp], c + 1);
+        // liveness (forward flavour, zeroed by the caller): plain stores of 1 by the lanes that hold a non-zero -- one flag per
+        // output channel, one per 4-channel input chunk (same-value races are benign; no atomics: a single-address atomicMax
+        // per wave serialised at L2 and cost the validate pass 4 ms)
+        if (live != nullptr && v != 0.0f) {
+            live[m] = 1;
+            live[Mp + 4 + c / 4] = 1;
         }
     }
 }
@@ -260,9 +258,14 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
         int alive = 0;
         for (int i = lane; i < Cfg::BM; i += 64) alive |= (m0 + i < g.M) ? bn.live[m0 + i] : 0;
         const bool dead = __ballot(alive != 0) == 0ull;                          // wave-uniform; same answer in all 4 waves
-        const int c_live = bn.live[g.Mp];                                        // 1 + last input channel with a non-zero weight
-        nch_all = dead ? 0 : min(nch_all, (c_live + Cfg::CK - 1) / Cfg::CK);
-        if (dead && tid == 0) atomicAdd(&bn.live[g.Mp + 1], 1);
+        static_assert(Cfg::CK == 4, "the liveness chunks of k_c3_pack are 4 channels");
+        int last = nch_all;                                                      // trailing dead input chunks (uniform scalar loop:
+        while (last > 0 && bn.live[g.Mp + 4 + last - 1] == 0) --last;            //  one read when nothing is dead)
+        nch_all = dead ? 0 : last;
+        if (tid == 0) {
+            if (dead) atomicAdd(&bn.live[g.Mp + 1], 1);
+            if (blockIdx.x == 0) bn.live[g.Mp] = last * Cfg::CK;
+        }
     }
     const int per_split = SPLITK ? (nch_all + g.ksplit - 1) / g.ksplit : nch_all;
     const int ch0 = ksp * per_split, nch = min(nch_all, ch0 + per_split);        // this block's chunks: [ch0, nch)
@@ -774,8 +777,10 @@ using CfgP28 = C3Cfg<128, 4, 28, 4, 1, 4, 2, 2>;   // 28-wide maps: a 4 x 28 str
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 // packed-weight workspace: [roundup(C_read, 4) * 9 (+ 16 rows of slack the last float4 staging pass may read)][roundup(M, 128)] floats
 inline size_t pack_floats(int c_read, int m) { return ((size_t)pad_to(c_read, 4) * 9 + 16) * pad_to(m, 128); }
-// ... followed by the liveness words of the inference path: live[Mp], last live input channel + 1, skipped-tile counter, pad
-inline size_t pack_bytes(int c_read, int m) { return (pack_floats(c_read, m) + pad_to(m, 128) + 4) * sizeof(float); }
+// ... followed by the liveness words of the inference path: live[Mp] column flags, 4 words (live input channels, skipped-tile
+// counter, pad), one flag per 4-channel input chunk
+inline size_t live_words(int c_read, int m) { return (size_t)pad_to(m, 128) + 4 + pad_to(c_read, 4) / 4; }
+inline size_t pack_bytes(int c_read, int m) { return (pack_floats(c_read, m) + live_words(c_read, m)) * sizeof(float); }
 
 // stats != nullptr: forward with fused BatchNorm statistics.  tiles_out (optional) receives the number of pixel tiles;
 // dry: only compute it.
@@ -826,7 +831,7 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
         int *live = nullptr;
         if (bn != nullptr && bn->live != nullptr) {          // (bn->live is only a request flag here; the words live in the workspace)
             live = reinterpret_cast<int *>(wp + pack_floats(c_read, m));
-            hipError_t e = hipMemsetAsync(live, 0, (size_t)(Mp + 4) * sizeof(int), stream);
+            hipError_t e = hipMemsetAsync(live, 0, live_words(c_read, m) * sizeof(int), stream);
             if (e != hipSuccess) return hip_status(e, what);
         }
         hipLaunchKernelGGL(k_c3_pack, dim3(stream_grid((int64_t)rows_c * 9 * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, K, C,
