@@ -21,9 +21,12 @@ def main():
     ap.add_argument('--arch', default='resnet50')
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--math', default='fp32', choices=['fp32', 'bf16', 'bf16x3'], help='arithmetic of the 3x3 s1 p1 convolutions (opt-in modes)')
     ap.add_argument('--piggymask', action='store_true', help='task >= 2: a piggymask on every masked layer + Adam on them')
     a = ap.parse_args()
     dev = 'cuda:0'
+    from cpg_amd.models import layers as _nl
+    _nl.set_conv_math(a.math)
     torch.manual_seed(1)
     kw = dict(dataset_history=[], dataset2num_classes={}, network_width_multiplier=1.0, shared_layer_info={})
     vgg_cfg = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
@@ -63,8 +66,8 @@ def main():
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / a.steps * 1e3
-    print('%s batch %d: %.1f ms/step, %.0f img/s, %.1f TFLOP/s (conv MACs only)' % (
-        a.arch, a.batch, ms, a.batch / ms * 1e3, a.batch * FLOP_PER_IMG.get(a.arch, 0) / ms / 1e9))
+    print('%s batch %d (%s): %.1f ms/step, %.0f img/s, %.1f TFLOP/s (conv MACs only)' % (
+        a.arch, a.batch, a.math, ms, a.batch / ms * 1e3, a.batch * FLOP_PER_IMG.get(a.arch, 0) / ms / 1e9))
 
 
 if __name__ == '__main__':
