@@ -206,8 +206,8 @@ class CPGSession(object):
         self.masks.clear()
         prefix = 'module.' if hasattr(self.model, 'module') else ''
         for k, v in state['masks'].items():
-            key = k if k.startswith('module.') or not prefix else prefix + k
-            self.masks[key if prefix else k[len('module.'):] if k.startswith('module.') else k] = v.to(self.device)
+            bare = k[len('module.'):] if k.startswith('module.') else k        # the reference keys masks with DataParallel's prefix
+            self.masks[prefix + bare] = v.to(self.device)
         ckpt.resize_masks(self.model, self.masks, 'finetune')
 
     def commit_task(self, dataset):
