@@ -34,7 +34,7 @@ def main():
         for f in glob.glob(os.path.join(root, '**', '*kernel_trace.csv'), recursive=True):
             for r in csv.DictReader(open(f)):
                 dur[short(r['Kernel_Name'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-    kernels = [k for k in per if re.search(r'k_c3_fwd|k_c3_wgrad<|k_pw<|k_pw_wgrad', k)]
+    kernels = [k for k in per if re.search(r'k_c3_fwd|k_c3_wgrad<|k_pw<|k_pw_wgrad|k_c3b_fwd|k_c3b_wgrad', k)]
     kernels.sort()
     print('| kernel | avg us | MFMA util | VALU/MFMA | SALU/MFMA | LDS inst/MFMA | LDS bank-conflict share | wait-any share |')
     print('|---|---:|---:|---:|---:|---:|---:|---:|')
