@@ -91,6 +91,11 @@ _SIGNATURES = {
     'cpg_conv2d_dgrad_bf16x3': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_size_t, _vp]),
     'cpg_conv2d_wgrad_bf16x3': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'cpg_conv2d_dgrad_bf16': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_size_t, _vp]),
+    'cpg_conv2d_dgrad_bnbwd_tiles': (ctypes.c_int32, [ctypes.POINTER(ConvDesc)]),
+    'cpg_conv2d_dgrad_bnbwd': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                              ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
+    'cpg_bn_bwd_from_partials': (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
     'cpg_bn_stats_finalize': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                              ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),
     'cpg_bn_add_relu_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32,

@@ -399,6 +399,51 @@ extern "C" int cpg_bn_stats_finalize(const float *partials, int32_t tiles, int32
     return CPG_OK;
 }
 
+// Backward of y = relu(bn(x)) whose reduction already happened in the epilogue of the NEXT layer's input-gradient kernel
+// (cpg_conv2d_dgrad_bnbwd): gm = g * [y > 0] and partials[c][tile] = {sum gm, sum gm * xhat} in fp32 per pixel tile.  Merge in fp64
+// in a fixed order -> dgamma, dbeta and the two means, then the plain apply pass dx = (gm - mean(gm) - xhat * mean(gm xhat)) *
+// invstd * gamma.  2 reads + 1 write instead of 4 reads + 1 write.
+namespace {
+__global__ __launch_bounds__(kThreads) void k_bn_bwd_finalize_tiles(const float *__restrict__ partials, int tiles, double count,
+                                                                    float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                                    float *__restrict__ coef) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    const float2 *p = reinterpret_cast<const float2 *>(partials) + (int64_t)c * tiles;
+    double s = 0.0, sx = 0.0;
+    for (int t = threadIdx.x; t < tiles; t += kThreads) {
+        const float2 v = p[t];
+        s += (double)v.x;
+        sx += (double)v.y;
+    }
+    const double ts = block_sum(s, red);
+    const double tsx = block_sum(sx, red);
+    if (threadIdx.x == 0) {
+        dbeta[c] = (float)ts;
+        dgamma[c] = (float)tsx;
+        coef[2 * c + 0] = (float)(ts / count);
+        coef[2 * c + 1] = (float)(tsx / count);
+    }
+}
+}  // namespace
+
+extern "C" int cpg_bn_bwd_from_partials(const float *partials, int32_t tiles, const float *x, const float *gm, const float *gamma,
+                                        const float *beta, const float *mean, const float *invstd, float *gx, float *dgamma,
+                                        float *dbeta, int32_t N, int32_t C, int32_t HW, void *ws, size_t ws_bytes, void *stream_v) {
+    BnDims d;
+    int rc = make_dims(N, C, HW, d);
+    if (rc) return rc;
+    CPG_REQUIRE(partials && x && gm && gamma && beta && mean && invstd && gx && dgamma && dbeta && ws, "cpg_bn_bwd_from_partials: null pointer");
+    CPG_REQUIRE(tiles > 0 && (((uintptr_t)partials) & 7) == 0, "cpg_bn_bwd_from_partials: bad partial sums");
+    if (ws_bytes < (size_t)C * 2 * sizeof(float)) return fail(CPG_E_WORKSPACE, "cpg_bn_bwd_from_partials: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_v;
+    float *coef = (float *)ws;
+    hipLaunchKernelGGL(k_bn_bwd_finalize_tiles, dim3(C), dim3(kThreads), 0, stream, partials, tiles, (double)N * HW, dgamma, dbeta, coef);
+    launch_bwd_apply<false, true>(d, x, gm, gx, mean, invstd, gamma, beta, coef, stream);
+    CPG_CHECK_LAUNCH("cpg_bn_bwd_from_partials");
+    return CPG_OK;
+}
+
 // y = relu(bn(x) + res): the tail of a residual block (models/resnet.py: `out = bn3(conv3(out)); out += identity;
 // relu(out)`) in the same two passes as plain BN -- 3 activation passes instead of 8 for the stock bn / add_ / relu_.
 extern "C" int cpg_bn_add_relu_fwd(const float *x, const float *res, const float *gamma, const float *beta, float eps, float momentum,

@@ -71,6 +71,14 @@ struct C3BnEval {
     int *live;
 };
 
+// Input-gradient launches whose result is the gradient w.r.t. a = relu(bn(ypre)) of the PREVIOUS layer can do that BatchNorm's
+// backward reduction in their epilogue (BRED): per element g' = g * [bn(ypre) > 0] is what gets stored, and sum g', sum g' * xhat
+// (xhat = (ypre - mean) * invstd) are accumulated per channel and pixel tile -> partials[channel][tile][2], exactly like the
+// forward statistics (STATS).  The BatchNorm backward then needs no reduction pass over ypre and g (cpg_bn_bwd_from_partials).
+struct C3BnBwd {
+    const float *ypre, *gamma, *beta, *mean, *invstd;
+};
+
 struct C3Geom {
     int N, C, H, W, M;        // C: channels of the tensor being read, M: channels being produced
     int Mp;                   // row stride of the packed weights (M rounded up to 128)
@@ -155,10 +163,11 @@ __global__ __launch_bounds__(256) void k_c3_pack(const float *__restrict__ w, co
 // (cpg_conv2d_fwd_bnstats + cpg_bn_stats_finalize; deterministic: fixed-order merges only).
 // SPLITK: g.ksplit blocks share a tile's channel chunks and atomically add their accumulators into a zeroed y.  Two addends
 // per element commute, so the result does not depend on which block arrives first (0 + a + b = 0 + b + a bitwise).
-template <class Cfg, bool DGRAD, bool STATS = false, bool SPLITK = false>
+template <class Cfg, bool DGRAD, bool STATS = false, bool SPLITK = false, bool BRED = false>
 __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float *__restrict__ x, const float *__restrict__ wp,
                                                            const float *__restrict__ bias, float *__restrict__ y,
-                                                           float *__restrict__ stats, C3BnEval bn) {
+                                                           float *__restrict__ stats, C3BnEval bn, C3BnBwd bb) {
+    static_assert(!BRED || (DGRAD && !STATS && !SPLITK), "the BatchNorm-backward reduction rides in plain input-gradient launches");
     __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -318,8 +327,8 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
     }
 
     // ---- epilogue: D col = pixel (lane & 31), D row = channel ----
-    float s1[STATS ? Cfg::FM : 1][16], s2[STATS ? Cfg::FM : 1][16];
-    if (STATS) {
+    float s1[(STATS || BRED) ? Cfg::FM : 1][16], s2[(STATS || BRED) ? Cfg::FM : 1][16];
+    if (STATS || BRED) {
 #pragma unroll
         for (int fm = 0; fm < Cfg::FM; ++fm)
 #pragma unroll
@@ -362,6 +371,30 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
                     bv[e] = 0.0f;
                 }
             }
+            if (BRED) {
+                // g' = g * [bn(ypre) > 0] (the expression of bn_kernels.hip's bn_affine, so the mask is the forward's), and the two
+                // sums of the BatchNorm backward.  16 loads of ypre per fragment, issued together.
+                float yp[16], mu[16], is[16], ga[16], be[16];
+                const float *ypre = bb.ypre + (int64_t)(n + img) * g.M * HW + poff;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const int cc = co < g.M ? co : 0;
+                    yp[e] = pok ? ypre[(int64_t)cc * HW] : 0.0f;
+                    mu[e] = bb.mean[cc], is[e] = bb.invstd[cc], ga[e] = bb.gamma[cc], be[e] = bb.beta[cc];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float xh = (yp[e] - mu[e]) * is[e];
+                    const bool on = ((yp[e] - mu[e]) * is[e] * ga[e] + be[e]) > 0.0f;
+                    const float gm = on ? acc[fm][fn][e] : 0.0f;
+                    acc[fm][fn][e] = gm;
+                    if (pok) {
+                        s1[fm][e] += gm;
+                        s2[fm][e] += gm * xh;
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -377,7 +410,7 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
             }
         }
     }
-    if (STATS) {
+    if (STATS || BRED) {
         // per channel row: sum over the 32 pixel lanes of this half-wave, then over the WN waves sharing the channels
 #pragma unroll
         for (int fm = 0; fm < Cfg::FM; ++fm)
@@ -786,8 +819,10 @@ inline size_t pack_bytes(int c_read, int m) { return (pack_floats(c_read, m) + l
 // dry: only compute it.
 template <class Cfg>
 int launch_fwd(C3Geom g, const float *x, const float *wp, const float *bias, float *y, hipStream_t stream, const char *what,
-               float *stats = nullptr, int *tiles_out = nullptr, bool dry = false, const C3BnEval *bnp = nullptr) {
+               float *stats = nullptr, int *tiles_out = nullptr, bool dry = false, const C3BnEval *bnp = nullptr,
+               const C3BnBwd *bbp = nullptr) {
     const C3BnEval bn = bnp ? *bnp : C3BnEval{nullptr, nullptr, nullptr, nullptr, 0.0f, 0, nullptr};
+    const C3BnBwd bb = bbp ? *bbp : C3BnBwd{nullptr, nullptr, nullptr, nullptr, nullptr};
     g.tiles_x = (g.W + Cfg::TW - 1) / Cfg::TW;
     g.tiles_y = (g.H + Cfg::TH - 1) / Cfg::TH;
     g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
@@ -797,22 +832,25 @@ int launch_fwd(C3Geom g, const float *x, const float *wp, const float *bias, flo
     if (tiles_out) *tiles_out = g.ksplit > 1 ? 0 : (int)(blocks / g.tiles_m);      // no fused statistics on split tiles
     if (dry) return CPG_OK;
     if (g.ksplit > 1) {
-        if (stats != nullptr || bnp != nullptr) return fail(CPG_E_UNSUPPORTED, "conv3x3: no fused epilogue on channel-split tiles");
+        if (stats != nullptr || bnp != nullptr || bbp != nullptr) return fail(CPG_E_UNSUPPORTED, "conv3x3: no fused epilogue on channel-split tiles");
         hipError_t e = hipMemsetAsync(y, 0, (size_t)g.N * g.M * g.H * g.W * sizeof(float), stream);
         if (e != hipSuccess) return hip_status(e, what);
         if (g.dgrad)
-            hipLaunchKernelGGL((k_c3_fwd<Cfg, true, false, true>), dim3((unsigned)(blocks * g.ksplit)), dim3(256), 0, stream, g, x, wp, bias, y, nullptr, bn);
+            hipLaunchKernelGGL((k_c3_fwd<Cfg, true, false, true>), dim3((unsigned)(blocks * g.ksplit)), dim3(256), 0, stream, g, x, wp, bias, y, nullptr, bn, bb);
         else
-            hipLaunchKernelGGL((k_c3_fwd<Cfg, false, false, true>), dim3((unsigned)(blocks * g.ksplit)), dim3(256), 0, stream, g, x, wp, bias, y, nullptr, bn);
+            hipLaunchKernelGGL((k_c3_fwd<Cfg, false, false, true>), dim3((unsigned)(blocks * g.ksplit)), dim3(256), 0, stream, g, x, wp, bias, y, nullptr, bn, bb);
         CPG_CHECK_LAUNCH(what);
         return CPG_OK;
     }
-    if (g.dgrad)
-        hipLaunchKernelGGL((k_c3_fwd<Cfg, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, nullptr, bn);
+    if (g.dgrad && bbp != nullptr) {
+        if (stats == nullptr) return fail(CPG_E_INVALID, "%s: no buffer for the BatchNorm-backward partial sums", what);
+        hipLaunchKernelGGL((k_c3_fwd<Cfg, true, false, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, stats, bn, bb);
+    } else if (g.dgrad)
+        hipLaunchKernelGGL((k_c3_fwd<Cfg, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, nullptr, bn, bb);
     else if (stats != nullptr)
-        hipLaunchKernelGGL((k_c3_fwd<Cfg, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, stats, bn);
+        hipLaunchKernelGGL((k_c3_fwd<Cfg, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, stats, bn, bb);
     else
-        hipLaunchKernelGGL((k_c3_fwd<Cfg, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, nullptr, bn);
+        hipLaunchKernelGGL((k_c3_fwd<Cfg, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, nullptr, bn, bb);
     CPG_CHECK_LAUNCH(what);
     return CPG_OK;
 }
@@ -820,7 +858,7 @@ int launch_fwd(C3Geom g, const float *x, const float *wp, const float *bias, flo
 // c_read / m: channels contracted over / produced.  w is the layer's [K][C][3][3] weight.
 int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, const float *x, const float *w, const float *pm,
             float thr, const float *bias, float *y, void *ws, size_t ws_bytes, hipStream_t stream, float *stats = nullptr,
-            int *tiles_out = nullptr, bool dry = false, const C3BnEval *bn = nullptr) {
+            int *tiles_out = nullptr, bool dry = false, const C3BnEval *bn = nullptr, const C3BnBwd *bb = nullptr) {
     const char *what = dgrad ? "cpg_conv2d_dgrad(3x3)" : "cpg_conv2d_fwd(3x3)";
     float *wp = (float *)ws;
     const int rows_c = pad_to(c_read, 4), Mp = pad_to(m, 128);
@@ -846,17 +884,17 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
     C3Geom g{N, c_read, H, W, m, Mp, 0, 0, 0, dgrad ? 1 : 0, 1};
     if (const char *f = getenv("CPG_C3_FORCE")) {        // A/B experiments only (tools/conv_bench.py --ab)
         switch (atoi(f)) {
-            case 0: return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
-            case 1: return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
-            case 2: return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
-            case 3: return launch_fwd<CfgD128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
-            case 4: return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
-            case 7: return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
-            case 8: g.ksplit = 2; return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
-            default: if (c_read % 4 == 0) return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
+            case 0: return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
+            case 1: return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
+            case 2: return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
+            case 3: return launch_fwd<CfgD128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
+            case 4: return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
+            case 7: return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
+            case 8: g.ksplit = 2; return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
+            default: if (c_read % 4 == 0) return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
         }
     }
-    if (W == 7 && H == 7 && c_read % 4 == 0) return launch_fwd<CfgV7>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
+    if (W == 7 && H == 7 && c_read % 4 == 0) return launch_fwd<CfgV7>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
     // 14 x 14 maps: the 14 x 16 single-image tile wastes 1/8 of its MFMAs on two padding columns; the zero-waste virtual-row
     // tile alone measured the same, because its N*14/16 tiles put 3.5 block-equivalents on each CU, which rounds up to 4
     // (at batch 256 the layer is too small for 256 CUs).  Halving the blocks (two per tile, each half of the channel chunks,
@@ -869,18 +907,18 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
         const double t_split = std::ceil(2.0 * (((int64_t)N * 14 + 15) / 16) * tm / kCUs) * 0.5 * 1.04;
         if (t_split < 0.9 * t_single) {
             g.ksplit = 2;
-            return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
+            return launch_fwd<CfgV14>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
         }
     }
-    if (W <= 16 && H <= 16 && m > 64) return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
+    if (W <= 16 && H <= 16 && m > 64) return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
     if (W == 28 && H % 4 == 0 && m > 64 && c_read % 4 == 0)
-        return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
+        return launch_fwd<CfgP28>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
     // 56, 112, 168 ...: a 32-wide tile would waste 12.5 % of the MFMAs.  The 64-channel 8 x 56 tile (2 x 2 waves) measured
     // 1-2 % faster than the 128-channel 4 x 56 tile (4 x 1 waves) on every 56- and 112-wide VGG layer, also for m > 64
     // (interleaved in-process A/B, tools/conv_bench.py --ab CPG_C3_FORCE=3,4).
-    if (W % 56 == 0 && W % 32 != 0) return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
-    if (m <= 64) return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
-    return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn);
+    if (W % 56 == 0 && W % 32 != 0) return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
+    if (m <= 64) return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
+    return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
 }
 
 }  // namespace
@@ -945,6 +983,25 @@ int cpg_conv3x3_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, c
     CPG_REQUIRE(gy && w && gx, "cpg_conv2d_dgrad: null pointer");
     // reads gy (K channels), produces gx (C channels)
     return run_fwd(true, d->N, d->K, d->C, d->H, d->W, d->K, d->C, gy, w, pm, thr, nullptr, gx, ws, ws_bytes, stream);
+}
+
+// input gradient whose epilogue also does the BatchNorm-backward reduction of the layer below (see C3BnBwd).  tiles = 0: this
+// shape has no such path (channel-split 14 x 14 tiles).
+int cpg_conv3x3_dgrad_bnbwd_tiles(const cpg_conv_desc *d) {
+    int tiles = 0;
+    const C3BnBwd probe{nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (run_fwd(true, d->N, d->K, d->C, d->H, d->W, d->K, d->C, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                &tiles, true, nullptr, &probe) != CPG_OK)
+        return 0;
+    return tiles;
+}
+int cpg_conv3x3_dgrad_bnbwd(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, const float *ypre,
+                            const float *gamma, const float *beta, const float *mean, const float *invstd, float *gx, float *partials,
+                            void *ws, size_t ws_bytes, hipStream_t stream) {
+    CPG_REQUIRE(gy && w && gx && ypre && gamma && beta && mean && invstd && partials, "cpg_conv2d_dgrad_bnbwd: null pointer");
+    const C3BnBwd bb{ypre, gamma, beta, mean, invstd};
+    return run_fwd(true, d->N, d->K, d->C, d->H, d->W, d->K, d->C, gy, w, pm, thr, nullptr, gx, ws, ws_bytes, stream, partials, nullptr, false,
+                   nullptr, &bb);
 }
 
 // ---- wgrad host side -------------------------------------------------------------------------

@@ -526,6 +526,10 @@ int cpg_conv3x3_fwd_bnstats(const cpg_conv_desc *d, const float *x, const float 
 int cpg_conv3x3_fwd_bn_eval(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
                             const float *gamma, const float *beta, const float *mean, const float *var, float eps, int relu, float *y,
                             int32_t *skip_stats, void *ws, size_t ws_bytes, hipStream_t stream);
+int cpg_conv3x3_dgrad_bnbwd_tiles(const cpg_conv_desc *d);
+int cpg_conv3x3_dgrad_bnbwd(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, const float *ypre,
+                            const float *gamma, const float *beta, const float *mean, const float *invstd, float *gx, float *partials,
+                            void *ws, size_t ws_bytes, hipStream_t stream);
 // ... and the pointwise kernels (pointwise.hip) for 1x1 convolutions (forward and input gradient)
 extern "C" int cpg_conv1x1_supported(const cpg_conv_desc *d);
 size_t cpg_conv1x1_pack_workspace(const cpg_conv_desc *d);
@@ -669,6 +673,24 @@ extern "C" int cpg_conv2d_fwd_bn_eval(const cpg_conv_desc *d, const float *x, co
     if (!cpg_conv3x3_supported(d)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_fwd_bn_eval: only the 3x3 s1 p1 kernels fuse the epilogue");
     return cpg_conv3x3_fwd_bn_eval(d, x, w, pm, thr, bias, gamma, beta, running_mean, running_var, eps, relu, y, skip_stats, ws,
                                    ws_bytes, (hipStream_t)stream);
+}
+
+// input gradient + the BatchNorm-backward reduction of the layer below in its epilogue (3x3 s1 p1 kernels only)
+extern "C" int32_t cpg_conv2d_dgrad_bnbwd_tiles(const cpg_conv_desc *d) {
+    ConvGeom g;
+    if (make_geom(d, g) != CPG_OK || !cpg_conv3x3_supported(d)) return 0;
+    return cpg_conv3x3_dgrad_bnbwd_tiles(d);
+}
+extern "C" int cpg_conv2d_dgrad_bnbwd(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr,
+                                      const float *ypre, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                                      float *gm, float *partials, size_t partial_bytes, void *ws, size_t ws_bytes, void *stream) {
+    ConvGeom g;
+    int rc = make_geom(d, g);
+    if (rc) return rc;
+    const int tiles = cpg_conv2d_dgrad_bnbwd_tiles(d);
+    if (tiles <= 0) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_dgrad_bnbwd: this shape has no fused path");
+    if (partial_bytes < (size_t)d->C * tiles * 2 * sizeof(float)) return fail(CPG_E_WORKSPACE, "cpg_conv2d_dgrad_bnbwd: partial-sum buffer too small");
+    return cpg_conv3x3_dgrad_bnbwd(d, gy, w, pm, thr, ypre, gamma, beta, mean, invstd, gm, partials, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int cpg_conv2d_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr,

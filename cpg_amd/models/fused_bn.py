@@ -14,9 +14,26 @@ import torch.nn as nn
 from .. import _lib
 
 
+class BnBwdHint(object):
+    """Link between a training-mode BatchNorm2d -> ReLU and the masked 3x3 conv that is the ONLY consumer of its output:
+    the conv's input-gradient kernel does the BatchNorm's backward reduction in its epilogue (cpg_conv2d_dgrad_bnbwd) and
+    leaves the partial sums here for _BnReluFn.backward (cpg_bn_bwd_from_partials).  One hint per forward pass."""
+    __slots__ = ('ypre', 'gamma', 'beta', 'mean', 'invstd', 'partials', 'tiles', 'out_shape')
+
+    def __init__(self):
+        self.ypre = self.gamma = self.beta = self.mean = self.invstd = self.partials = self.out_shape = None
+        self.tiles = 0
+
+    def usable(self, x):
+        return self.ypre is not None and tuple(x.shape) == self.out_shape and x.is_cuda
+
+
+ENABLE_BWD_HINT = True      # the BatchNorm backward reduction rides in the next conv's input-gradient epilogue
+
+
 class _BnReluFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, training, relu, stats=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, training, relu, stats=None, hint=None):
         x = x.contiguous()
         N, C = x.shape[0], x.shape[1]
         HW = x.numel() // (N * C)
@@ -46,6 +63,10 @@ class _BnReluFn(torch.autograd.Function):
             _lib.check('cpg_bn_relu_fwd_eval', rc)
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         ctx.cfg = (N, C, HW, bool(relu), bool(training))
+        ctx.hint = None
+        if hint is not None and relu and training:
+            hint.ypre, hint.gamma, hint.beta, hint.mean, hint.invstd, hint.out_shape = x, gamma, beta, mean, invstd, tuple(y.shape)
+            ctx.hint = hint
         return y
 
     @staticmethod
@@ -58,11 +79,20 @@ class _BnReluFn(torch.autograd.Function):
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(beta)
         ws, nb = _lib.workspace(L.cpg_bn_workspace_bytes(N, C, HW), x.device)
+        hint = ctx.hint
+        if hint is not None and hint.partials is not None:
+            # the consumer conv's input-gradient kernel already masked gy by the ReLU and reduced it per (channel, tile)
+            rc = L.cpg_bn_bwd_from_partials(_lib.dptr(hint.partials), hint.tiles, _lib.dptr(x), _lib.dptr(gy, name='grad_output'),
+                                            _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(mean), _lib.dptr(invstd), _lib.dptr(gx),
+                                            _lib.dptr(dgamma), _lib.dptr(dbeta), N, C, HW, _lib.dptr(ws), nb, _lib.stream_ptr())
+            _lib.check('cpg_bn_bwd_from_partials', rc)
+            hint.partials = None
+            return gx, dgamma, dbeta, None, None, None, None, None, None, None, None
         rc = L.cpg_bn_relu_bwd(_lib.dptr(x), _lib.dptr(gy, name='grad_output'), _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(mean),
                                _lib.dptr(invstd), _lib.dptr(gx), _lib.dptr(dgamma), _lib.dptr(dbeta), N, C, HW, int(relu),
                                int(training), _lib.dptr(ws), nb, _lib.stream_ptr())
         _lib.check('cpg_bn_relu_bwd', rc)
-        return gx, dgamma, dbeta, None, None, None, None, None, None, None
+        return gx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def _finalize_stats(stats, N, C, HW, eps, momentum, running_mean, running_var, device):
@@ -187,14 +217,15 @@ def fusable(bn, x):
             and bn.momentum is not None and (bn.track_running_stats or bn.training))
 
 
-def bn_relu(x, bn, relu=True, stats=None):
-    """y = relu(bn(x)) with `bn` an nn.BatchNorm2d module (its buffers are updated as torch would)."""
+def bn_relu(x, bn, relu=True, stats=None, hint=None):
+    """y = relu(bn(x)) with `bn` an nn.BatchNorm2d module (its buffers are updated as torch would).  hint: a BnBwdHint when the
+    caller hands y to exactly one masked 3x3 conv (FusedSequential does)."""
     training = bn.training or not bn.track_running_stats
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return _BnReluFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, training, relu,
-                           stats if (training and rm is not None) else None)
+                           stats if (training and rm is not None) else None, hint if training else None)
 
 
 class _PReluFn(torch.autograd.Function):
@@ -267,6 +298,7 @@ class FusedSequential(nn.Sequential):
         mods = list(self._modules.values())
         i, n = 0, len(mods)
         stats = None            # partial sums of `input`, when the module that produced it was asked for them
+        hint = None             # BnBwdHint for the conv that consumes `input`, when `input` came out of a fused BatchNorm -> ReLU
         while i < n:
             m = mods[i]
             if (self.fuse and ENABLED and i + 1 < n and isinstance(m, nn.BatchNorm2d) and isinstance(mods[i + 1], nn.ReLU)
@@ -275,8 +307,14 @@ class FusedSequential(nn.Sequential):
                         and input.shape[3] % 2 == 0 and m.track_running_stats):
                     input = bn_relu_pool(input, m, stats)
                     i += 3
+                    hint = None
                 else:
-                    input = bn_relu(input, m, relu=True, stats=stats)
+                    # BatchNorm -> ReLU feeding a masked conv directly: let that conv's input-gradient kernel do this
+                    # BatchNorm's backward reduction (only this Sequential knows that nothing else reads the activation)
+                    nxt2 = mods[i + 2] if i + 2 < n else None
+                    hint = BnBwdHint() if (ENABLE_BWD_HINT and m.training and torch.is_grad_enabled()
+                                           and hasattr(nxt2, 'forward_with_bn_stats')) else None
+                    input = bn_relu(input, m, relu=True, stats=stats, hint=hint)
                     i += 2
                 stats = None
                 continue
@@ -304,8 +342,11 @@ class FusedSequential(nn.Sequential):
                     continue
             if (self.fuse and self.fuse_stats and ENABLED and hasattr(m, 'forward_with_bn_stats') and isinstance(nxt, nn.BatchNorm2d)
                     and nxt.training and nxt.track_running_stats and nxt.affine and nxt.momentum is not None and input.is_cuda):
-                input, stats = m.forward_with_bn_stats(input)
+                input, stats = m.forward_with_bn_stats(input, bn_hint=hint)
+            elif hint is not None and hasattr(m, 'forward_with_bn_stats'):
+                input, stats = m(input, bn_hint=hint), None
             else:
                 input, stats = m(input), None
+            hint = None
             i += 1
         return input

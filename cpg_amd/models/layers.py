@@ -77,7 +77,10 @@ class _MaskedConv2dFn(torch.autograd.Function):
     """y = conv2d(x, W * bin(pm), b) and its gradients, all through the C ABI."""
 
     @staticmethod
-    def forward(ctx, x, weight, pm, bias, thr, stride, padding, dilation, groups, bn_stats=False, math='fp32'):
+    def forward(ctx, x, weight, pm, bias, thr, stride, padding, dilation, groups, bn_stats=False, math='fp32', bn_hint=None):
+        # bn_hint (fused_bn.BnBwdHint or None): `x` is relu(bn(ypre)) of the layer below and nothing else consumes it -- the
+        # input-gradient kernel may then do that BatchNorm's backward reduction in its epilogue (cpg_conv2d_dgrad_bnbwd)
+        ctx.bn_hint = bn_hint
         """bn_stats: also return the per-(channel, pixel tile) {sum, sum of squares} of y that the kernel accumulates
         in its epilogue (cpg_conv2d_fwd_bnstats) -- a second, non-differentiable output, or None when the shape has
         no fused-statistics kernel."""
@@ -151,7 +154,7 @@ class _MaskedConv2dFn(torch.autograd.Function):
         if ctx.empty:
             return (torch.zeros_like(x), torch.zeros_like(w), None if p is None else torch.zeros_like(p),
                     torch.zeros(d.K, dtype=torch.float32, device=x.device) if ctx.has_bias else None, None, None, None, None, None, None,
-                    None)
+                    None, None)
         gy = gy.contiguous()
         L = _lib.lib()
         s = _lib.stream_ptr()
@@ -166,9 +169,21 @@ class _MaskedConv2dFn(torch.autograd.Function):
             _lib.check('cpg_conv2d_dgrad_bf16', rc)
         elif ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            rc = L.cpg_conv2d_dgrad(ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr,
-                                    _lib.dptr(gx), _lib.dptr(ws), nbytes, s)
-            _lib.check('cpg_conv2d_dgrad', rc)
+            hint = ctx.bn_hint
+            tiles = L.cpg_conv2d_dgrad_bnbwd_tiles(ctypes.byref(d)) if (hint is not None and hint.usable(x)) else 0
+            if tiles > 0:
+                # gx becomes g * [bn(ypre) > 0] and the BatchNorm's two backward sums come out per (channel, pixel tile)
+                partials = torch.empty((d.C, tiles, 2), dtype=torch.float32, device=x.device)
+                rc = L.cpg_conv2d_dgrad_bnbwd(ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr,
+                                              _lib.dptr(hint.ypre), _lib.dptr(hint.gamma), _lib.dptr(hint.beta), _lib.dptr(hint.mean),
+                                              _lib.dptr(hint.invstd), _lib.dptr(gx), _lib.dptr(partials), partials.numel() * 4,
+                                              _lib.dptr(ws), nbytes, s)
+                _lib.check('cpg_conv2d_dgrad_bnbwd', rc)
+                hint.partials, hint.tiles = partials, tiles
+            else:
+                rc = L.cpg_conv2d_dgrad(ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr,
+                                        _lib.dptr(gx), _lib.dptr(ws), nbytes, s)
+                _lib.check('cpg_conv2d_dgrad', rc)
         if ctx.needs_input_grad[1] or (p is not None and ctx.needs_input_grad[2]) or (ctx.has_bias and ctx.needs_input_grad[3]):
             gw = torch.empty_like(w)
             gpm = None if p is None else torch.empty_like(p)
@@ -183,7 +198,7 @@ class _MaskedConv2dFn(torch.autograd.Function):
                 rc = L.cpg_conv2d_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), _lib.dptr(p), thr,
                                         _lib.dptr(gw), _lib.dptr(gpm), _lib.dptr(gb), _lib.dptr(ws), nbytes, s)
                 _lib.check('cpg_conv2d_wgrad', rc)
-        return gx, gw, gpm, gb, None, None, None, None, None, None, None
+        return gx, gw, gpm, gb, None, None, None, None, None, None, None, None
 
 
 class _MaskedLinearFn(torch.autograd.Function):
@@ -293,18 +308,18 @@ class SharableConv2d(_Sharable):
             self.register_parameter('bias', None)
         self._init_mask_state(mask_init, mask_scale, threshold_fn, threshold)
 
-    def forward(self, input, layer_info=None, name=None):
+    def forward(self, input, layer_info=None, name=None, bn_hint=None):
         return _MaskedConv2dFn.apply(input, self.weight, self.piggymask, self.bias, self.info['threshold'],
-                                     self.stride, self.padding, self.dilation, self.groups, False, self._math())
+                                     self.stride, self.padding, self.dilation, self.groups, False, self._math(), bn_hint)
 
     def _math(self):
         return getattr(self, 'math', None) or CONV_MATH
 
-    def forward_with_bn_stats(self, input):
+    def forward_with_bn_stats(self, input, bn_hint=None):
         """(y, stats): forward plus the BatchNorm partial sums of y from the same kernel; stats is None when this shape
         has no fused-statistics kernel.  Used by cpg_amd.models.fused_bn.FusedSequential for conv -> BatchNorm2d runs."""
         y, stats = _MaskedConv2dFn.apply(input, self.weight, self.piggymask, self.bias, self.info['threshold'],
-                                         self.stride, self.padding, self.dilation, self.groups, True, self._math())
+                                         self.stride, self.padding, self.dilation, self.groups, True, self._math(), bn_hint)
         return y, (stats if stats.numel() else None)
 
     def forward_bn_eval(self, input, bn, relu=True, skip_stats=None):

@@ -254,6 +254,20 @@ int cpg_conv2d_fwd_bf16(const cpg_conv_desc *desc, const float *x, const float *
 int cpg_conv2d_dgrad_bf16(const cpg_conv_desc *desc, const float *gy, const float *w, const float *piggymask, float threshold,
                           float *gx, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The BatchNorm backward reduction riding in the NEXT layer's input-gradient kernel (the backward counterpart of
+ * cpg_conv2d_fwd_bnstats): conv_{L+1}'s dgrad produces g = dL/da with a = relu(bn_L(ypre)); its epilogue reads ypre at the
+ * same positions, stores gm = g * [bn_L(ypre) > 0] instead of g and writes {sum gm, sum gm * xhat} per (channel, pixel tile) ->
+ * partials[C][tiles][2] (fp32), tiles = cpg_conv2d_dgrad_bnbwd_tiles(desc) (0: no fused path for this shape).
+ * cpg_bn_bwd_from_partials merges them (fp64, fixed order) into dgamma / dbeta and runs the one remaining pass
+ * dx = (gm - mean(gm) - xhat * mean(gm * xhat)) * invstd * gamma.  Saves the 2-read reduction pass of cpg_bn_relu_bwd. */
+int32_t cpg_conv2d_dgrad_bnbwd_tiles(const cpg_conv_desc *desc);
+int cpg_conv2d_dgrad_bnbwd(const cpg_conv_desc *desc, const float *gy, const float *w, const float *piggymask, float threshold,
+                           const float *ypre, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                           float *gm, float *partials, size_t partial_bytes, void *workspace, size_t workspace_bytes, void *stream);
+int cpg_bn_bwd_from_partials(const float *partials, int32_t tiles, const float *x, const float *gm, const float *gamma,
+                             const float *beta, const float *mean, const float *invstd, float *gx, float *dgamma, float *dbeta,
+                             int32_t N, int32_t C, int32_t HW, void *workspace, size_t workspace_bytes, void *stream);
+
 /* y = relu(bn(x) + res): the tail of a residual block (models/resnet.py:69-74 `out = self.bn3(out); out += identity;
  * out = self.relu(out)`).  train != 0: batch statistics (mean / invstd out, running stats updated); train == 0: `mean`
  * / `invstd` are inputs.  Backward = relu mask from y, then cpg_bn_relu_bwd(relu = 0); the residual's gradient is the

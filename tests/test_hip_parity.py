@@ -1121,6 +1121,77 @@ def test_fused_sequential_equals_unfused():
         np.testing.assert_allclose(res[True][2][n], res[False][2][n], rtol=1e-4, atol=1e-6, err_msg=n)
 
 
+@pytest.mark.parametrize('width,batch', [(0.25, 16), (0.5, 6)])
+def test_bn_backward_reduction_in_dgrad_epilogue_equals_separate_pass(width, batch):
+    """cpg_conv2d_dgrad_bnbwd + cpg_bn_bwd_from_partials (the BatchNorm backward reduction riding in the next conv's
+    input-gradient epilogue) against the separate reduction pass on a whole VGG16-BN: identical logits, every parameter
+    gradient equal to fp32 round-off (the sums are merged in a different order)."""
+    from cpg_amd.models import fused_bn
+    net = build('vgg_cifar100', width).to(DEV).train()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(batch, 3, 32, 32, generator=g).to(DEV)
+    t = torch.randint(0, 5, (batch,), generator=g).to(DEV)
+    res = {}
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    for on in (True, False):
+        net.load_state_dict(sd)
+        net.zero_grad()
+        fused_bn.ENABLE_BWD_HINT = on
+        try:
+            out = net(x)
+            nn.functional.cross_entropy(out, t).backward()
+        finally:
+            fused_bn.ENABLE_BWD_HINT = True
+        res[on] = (out.detach().cpu().numpy(), {n: p.grad.cpu().numpy() for n, p in net.named_parameters() if p.grad is not None})
+    np.testing.assert_array_equal(res[True][0], res[False][0])                    # the forward is untouched
+    for n in res[False][1]:
+        sc = float(np.abs(res[False][1][n]).max()) + 1e-12
+        np.testing.assert_allclose(res[True][1][n], res[False][1][n], rtol=1e-3, atol=2e-5 * sc, err_msg=n)
+
+
+@pytest.mark.parametrize('N,C,K,H', [(6, 32, 48, 28), (2, 16, 64, 56), (2, 8, 130, 112), (3, 24, 40, 12)])
+def test_bn_backward_hint_is_used_and_matches_fp64(N, C, K, H):
+    """One conv -> BatchNorm -> ReLU -> conv chain at shapes with a fused path: the hint is consumed (partials produced) and
+    dx, dgamma, dbeta agree with an fp64 torch reference of the same chain to 1e-5 of scale."""
+    from cpg_amd.models import fused_bn
+    g = torch.Generator().manual_seed(12 + H)
+    x = torch.randn(N, C, H, H, generator=g)
+    w1 = torch.randn(K, C, 3, 3, generator=g) * 0.08
+    w2 = torch.randn(40, K, 3, 3, generator=g) * 0.06
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
+    gy = torch.randn(N, 40, H, H, generator=g)
+    c1 = nl.SharableConv2d(C, K, 3, padding=1, bias=False).to(DEV)
+    c2 = nl.SharableConv2d(K, 40, 3, padding=1, bias=False).to(DEV)
+    bn = nn.BatchNorm2d(K).to(DEV).train()
+    c1.weight.data.copy_(w1)
+    c2.weight.data.copy_(w2)
+    bn.weight.data.copy_(gamma)
+    bn.bias.data.copy_(beta)
+    seq = fused_bn.FusedSequential(c1, bn, nn.ReLU(inplace=True), c2)
+    xd = x.to(DEV).requires_grad_(True)
+    out = seq(xd)
+    # the hint object travels in the conv's autograd context
+    fn = out.grad_fn
+    assert getattr(fn, 'bn_hint', None) is not None
+    hint = fn.bn_hint
+    out.backward(gy.to(DEV))
+    assert hint.tiles > 0 and hint.partials is None             # produced by the conv backward, consumed by the BatchNorm backward
+    # fp64 reference
+    x64 = x.double().requires_grad_(True)
+    c1r, c2r = w1.double().requires_grad_(True), w2.double().requires_grad_(True)
+    bn64 = nn.BatchNorm2d(K).double().train()
+    bn64.weight.data.copy_(gamma.double())
+    bn64.bias.data.copy_(beta.double())
+    y64 = torch.nn.functional.conv2d(torch.relu(bn64(torch.nn.functional.conv2d(x64, c1r, padding=1))), c2r, padding=1)
+    y64.backward(gy.double())
+
+    def rel(a, b):
+        return float((a.detach().double().cpu() - b).abs().max() / b.abs().max())
+    assert rel(out, y64.detach()) < 1e-5
+    assert rel(xd.grad, x64.grad) < 1e-5 and rel(c1.weight.grad, c1r.grad) < 1e-5 and rel(c2.weight.grad, c2r.grad) < 1e-5
+    assert rel(bn.weight.grad, bn64.weight.grad) < 1e-5 and rel(bn.bias.grad, bn64.bias.grad) < 1e-5
+
+
 # --------------------------------------------------------------------------- configs 4 / 5: whole-net train step
 @pytest.mark.parametrize('arch,width,shape,ncls', [('resnet50', 0.25, (4, 3, 64, 64), 5), ('spherenet20', 0.25, (4, 3, 112, 112), 7)])
 def test_resnet_spherenet_backward_matches_torch_ops(arch, width, shape, ncls, monkeypatch):
