@@ -114,6 +114,8 @@ class KernelClock:
         p.cpg_conv2d_dgrad_bf16x3 = timed('cpg_conv2d_dgrad_bf16x3', conv_kind('conv_dgrad_bf16'), conv_flops)
         p.cpg_conv2d_wgrad_bf16x3 = timed('cpg_conv2d_wgrad_bf16x3', conv_kind('conv_wgrad_bf16'), conv_flops)
         p.cpg_conv2d_wgrad_bf16 = timed('cpg_conv2d_wgrad_bf16', conv_kind('conv_wgrad_bf16'), conv_flops)
+        # (same contraction; its epilogue also does the BatchNorm-backward reduction of the layer below)
+        p.cpg_conv2d_dgrad_bnbwd = timed('cpg_conv2d_dgrad_bnbwd', conv_kind('conv_dgrad'), conv_flops)
         p.cpg_conv2d_dgrad = timed('cpg_conv2d_dgrad', conv_kind('conv_dgrad'), conv_flops)
         p.cpg_conv2d_wgrad = timed('cpg_conv2d_wgrad', conv_kind('conv_wgrad'), conv_flops)
         p.cpg_linear_fwd = timed('cpg_linear_fwd', lambda a: 'linear_fwd', lin_flops(6))

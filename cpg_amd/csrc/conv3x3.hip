@@ -334,8 +334,57 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
 #pragma unroll
             for (int e = 0; e < 16; ++e) s1[fm][e] = s2[fm][e] = 0.0f;
     }
+    if (BRED) {
+        // Input gradient w.r.t. a = relu(bn(ypre)): store g' = g * [bn(ypre) > 0] (bn_kernels.hip's bn_affine expression, so the
+        // mask is the forward's) and accumulate sum g', sum g' * xhat.  Loop order (channel quad, pixel fragment): the 16
+        // per-channel scalars of a quad stay in registers across the FN fragments and only 4 ypre values are in flight, which
+        // keeps the epilogue inside the main loop's register budget (the fragment-major order spilled 250-470 VGPRs).
+        int poffs[Cfg::FN];                                  // element offset of the lane's pixel inside a channel plane, or -1
 #pragma unroll
-    for (int fn = 0; fn < Cfg::FN; ++fn) {
+        for (int fn = 0; fn < Cfg::FN; ++fn) {
+            int img, r, c;
+            pixel((wn * Cfg::FN + fn) * 32 + li, img, r, c);
+            const int oh = h0 + r, ow = w0 + c;
+            const bool pok = oh < g.H && ow < g.W && n + img < g.N;
+            poffs[fn] = pok ? img * g.M * HW + oh * g.W + ow : -1;
+        }
+        const float *ypre = bb.ypre + (int64_t)n * g.M * HW;
+        float *yout = y + (int64_t)n * g.M * HW;
+#pragma unroll
+        for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float mu[4], is[4], ga[4], be[4];
+                int coff[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int co = m0 + (wm * Cfg::FM + fm) * 32 + j + 8 * q + 4 * lh;
+                    const int cc = co < g.M ? co : 0;
+                    mu[j] = bb.mean[cc], is[j] = bb.invstd[cc], ga[j] = bb.gamma[cc], be[j] = bb.beta[cc];
+                    coff[j] = co < g.M ? co * HW : -1;
+                }
+#pragma unroll
+                for (int fn = 0; fn < Cfg::FN; ++fn) {
+                    float yp[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) yp[j] = (poffs[fn] >= 0 && coff[j] >= 0) ? ypre[coff[j] + poffs[fn]] : 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 4 * q + j;
+                        const float xh = (yp[j] - mu[j]) * is[j];
+                        const bool on = ((yp[j] - mu[j]) * is[j] * ga[j] + be[j]) > 0.0f;
+                        const float gm = on ? acc[fm][fn][e] : 0.0f;
+                        if (poffs[fn] >= 0 && coff[j] >= 0) {
+                            yout[coff[j] + poffs[fn]] = gm;
+                            s1[fm][e] += gm;
+                            s2[fm][e] += gm * xh;
+                        }
+                    }
+                }
+            }
+    }
+#pragma unroll
+    for (int fn = 0; fn < (BRED ? 0 : Cfg::FN); ++fn) {
         int img, r, c;
         pixel((wn * Cfg::FN + fn) * 32 + li, img, r, c);
         const int oh = h0 + r, ow = w0 + c;
@@ -369,30 +418,6 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
                     if (bn.relu) v = fmaxf(v, 0.0f);
                     acc[fm][fn][e] = v;
                     bv[e] = 0.0f;
-                }
-            }
-            if (BRED) {
-                // g' = g * [bn(ypre) > 0] (the expression of bn_kernels.hip's bn_affine, so the mask is the forward's), and the two
-                // sums of the BatchNorm backward.  16 loads of ypre per fragment, issued together.
-                float yp[16], mu[16], is[16], ga[16], be[16];
-                const float *ypre = bb.ypre + (int64_t)(n + img) * g.M * HW + poff;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    const int cc = co < g.M ? co : 0;
-                    yp[e] = pok ? ypre[(int64_t)cc * HW] : 0.0f;
-                    mu[e] = bb.mean[cc], is[e] = bb.invstd[cc], ga[e] = bb.gamma[cc], be[e] = bb.beta[cc];
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float xh = (yp[e] - mu[e]) * is[e];
-                    const bool on = ((yp[e] - mu[e]) * is[e] * ga[e] + be[e]) > 0.0f;
-                    const float gm = on ? acc[fm][fn][e] : 0.0f;
-                    acc[fm][fn][e] = gm;
-                    if (pok) {
-                        s1[fm][e] += gm;
-                        s2[fm][e] += gm * xh;
-                    }
                 }
             }
 #pragma unroll

@@ -656,7 +656,8 @@ def test_trajectory_golden(mode, math):
         if s == 0:
             close(out, g['logits'][s], rtol=1e-4, atol=1e-4 * sc, msg='logits step 0')
         else:
-            close(out, g['logits'][s], rtol=1e-3, atol=1e-4 * sc, msg='logits step %d (drift)' % s)
+            # (bf16x3: 5e-6 per layer instead of 2.5e-7 feeds the same drift -- 3e-4 of the logit scale observed after 12 steps)
+            close(out, g['logits'][s], rtol=1e-3, atol=(1e-4 if math == 'fp32' else 5e-4) * sc, msg='logits step %d (drift)' % s)
         drift = max(drift, float(np.abs(out.detach().cpu().numpy() - g['logits'][s]).max()) / sc)
         assert abs(float(loss) - g['losses'][s]) < 1e-5
         assert abs(pruner.calculate_sparsity() - g['sparsities'][s]) < 2e-4, s
@@ -667,7 +668,8 @@ def test_trajectory_golden(mode, math):
     model.eval()
     with torch.no_grad():
         ev = model(xs[0])
-    close(ev, g['eval_logits'], rtol=1e-3, atol=1e-4 * float(np.abs(g['eval_logits']).max()), msg='eval logits after 12 steps (drift)')
+    close(ev, g['eval_logits'], rtol=1e-3, atol=(1e-4 if math == 'fp32' else 5e-4) * float(np.abs(g['eval_logits']).max()),
+          msg='eval logits after 12 steps (drift)')
     print('trajectory_%s (%s): max logit drift over 12 steps %.2e of the logit scale' % (mode, math, drift))
 
 
