@@ -350,38 +350,49 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
         }
         const float *ypre = bb.ypre + (int64_t)n * g.M * HW;
         float *yout = y + (int64_t)n * g.M * HW;
+        // software pipeline over the FM * 4 channel quads: the 4 x FN loads of quad i + 1 are in flight while quad i is processed
+        // (one HBM round trip per quad would otherwise be exposed: 4 * FM of them per block)
+        float yp[2][Cfg::FN][4];
+        auto quad_loads = [&](int idx, float (&dst)[Cfg::FN][4]) {
+            const int fm = idx >> 2, q = idx & 3;
 #pragma unroll
-        for (int fm = 0; fm < Cfg::FM; ++fm)
+            for (int j = 0; j < 4; ++j) {
+                const int co = m0 + (wm * Cfg::FM + fm) * 32 + j + 8 * q + 4 * lh;
+                const int cbase = co < g.M ? co * HW : -1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float mu[4], is[4], ga[4], be[4];
-                int coff[4];
+                for (int fn = 0; fn < Cfg::FN; ++fn) dst[fn][j] = ypre[(poffs[fn] >= 0 && cbase >= 0) ? cbase + poffs[fn] : 0];
+            }
+        };
+        quad_loads(0, yp[0]);
+#pragma unroll
+        for (int idx = 0; idx < Cfg::FM * 4; ++idx) {
+            const int fm = idx >> 2, q = idx & 3;
+            if (idx + 1 < Cfg::FM * 4) quad_loads(idx + 1, yp[(idx + 1) & 1]);
+            float mu[4], is[4], ga[4], be[4];
+            int coff[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = m0 + (wm * Cfg::FM + fm) * 32 + j + 8 * q + 4 * lh;
+                const int cc = co < g.M ? co : 0;
+                mu[j] = bb.mean[cc], is[j] = bb.invstd[cc], ga[j] = bb.gamma[cc], be[j] = bb.beta[cc];
+                coff[j] = co < g.M ? co * HW : -1;
+            }
+#pragma unroll
+            for (int fn = 0; fn < Cfg::FN; ++fn)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int co = m0 + (wm * Cfg::FM + fm) * 32 + j + 8 * q + 4 * lh;
-                    const int cc = co < g.M ? co : 0;
-                    mu[j] = bb.mean[cc], is[j] = bb.invstd[cc], ga[j] = bb.gamma[cc], be[j] = bb.beta[cc];
-                    coff[j] = co < g.M ? co * HW : -1;
-                }
-#pragma unroll
-                for (int fn = 0; fn < Cfg::FN; ++fn) {
-                    float yp[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) yp[j] = (poffs[fn] >= 0 && coff[j] >= 0) ? ypre[coff[j] + poffs[fn]] : 0.0f;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int e = 4 * q + j;
-                        const float xh = (yp[j] - mu[j]) * is[j];
-                        const bool on = ((yp[j] - mu[j]) * is[j] * ga[j] + be[j]) > 0.0f;
-                        const float gm = on ? acc[fm][fn][e] : 0.0f;
-                        if (poffs[fn] >= 0 && coff[j] >= 0) {
-                            yout[coff[j] + poffs[fn]] = gm;
-                            s1[fm][e] += gm;
-                            s2[fm][e] += gm * xh;
-                        }
+                    const int e = 4 * q + j;
+                    const float v = yp[idx & 1][fn][j];
+                    const float xh = (v - mu[j]) * is[j];
+                    const bool on = ((v - mu[j]) * is[j] * ga[j] + be[j]) > 0.0f;
+                    const float gm = on ? acc[fm][fn][e] : 0.0f;
+                    if (poffs[fn] >= 0 && coff[j] >= 0) {
+                        yout[coff[j] + poffs[fn]] = gm;
+                        s1[fm][e] += gm;
+                        s2[fm][e] += gm * xh;
                     }
                 }
-            }
+        }
     }
 #pragma unroll
     for (int fn = 0; fn < (BRED ? 0 : Cfg::FN); ++fn) {
