@@ -211,28 +211,51 @@ __global__ __launch_bounds__(256, Cfg::MINB) void k_c3b_fwd(B16Geom g, const flo
         u32x4 *other = smem + ((ch + 1) & 1) * Cfg::STAGEQ;
         const bool more = ch + 1 < g.nchunks;                      // block-uniform
         if (more) load_chunk(ch + 1);                              // in flight under the MFMAs below
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            bf16x8 a[Cfg::NP][Cfg::FM], b[Cfg::NP][Cfg::FN];
+        // Operands of tap t + 1 are read from LDS while the MFMAs of tap t run (two register sets), and the MFMAs of a tap are
+        // ordered product-major, so consecutive MFMAs never share an accumulator (the compiler's own order was: per fragment
+        // ds_read -> s_waitcnt lgkmcnt(0) -> 3 dependent MFMAs on one accumulator: the pipe idled on both the LDS latency and
+        // the accumulate dependency).  sched_group_barrier pins one LDS read behind each MFMA.
+        bf16x8 a[2][Cfg::NP][Cfg::FM], b[2][Cfg::NP][Cfg::FN];
+        auto lds_operands = [&](int tap, int set) {
 #pragma unroll
             for (int pl = 0; pl < Cfg::NP; ++pl) {
 #pragma unroll
                 for (int fm = 0; fm < Cfg::FM; ++fm)
-                    a[pl][fm] = __builtin_bit_cast(bf16x8, cur[pl * Cfg::STAGE1 + a_base + tap * 2 * Cfg::BM + fm * 32]);
+                    a[set][pl][fm] = __builtin_bit_cast(bf16x8, cur[pl * Cfg::STAGE1 + a_base + tap * 2 * Cfg::BM + fm * 32]);
 #pragma unroll
                 for (int fn = 0; fn < Cfg::FN; ++fn)
-                    b[pl][fn] = __builtin_bit_cast(bf16x8, cur[pl * Cfg::STAGE1 + b_base[fn] + (tap / 3) * Cfg::PW + (tap % 3)]);
+                    b[set][pl][fn] = __builtin_bit_cast(bf16x8, cur[pl * Cfg::STAGE1 + b_base[fn] + (tap / 3) * Cfg::PW + (tap % 3)]);
             }
+        };
+        // (one-plane kernels: measured 5 % slower with the pinned order -- they are bound by L2 delivery of the next chunk, not
+        // by operand latency -- so they keep read-then-multiply per tap and the compiler's schedule)
+        constexpr bool kPipelined = Cfg::NP == 2;
+        if (kPipelined) lds_operands(0, 0);
 #pragma unroll
-            for (int fm = 0; fm < Cfg::FM; ++fm)
+        for (int tap = 0; tap < 9; ++tap) {
+            const int set = kPipelined ? (tap & 1) : 0;
+            if (!kPipelined) lds_operands(tap, 0);
+            else if (tap + 1 < 9) lds_operands(tap + 1, set ^ 1);
+            constexpr int NPROD = Cfg::NP == 2 ? 3 : 1;
 #pragma unroll
-                for (int fn = 0; fn < Cfg::FN; ++fn) {
-                    if (Cfg::NP == 2) {          // small terms first: a_lo b_hi + a_hi b_lo, then a_hi b_hi (a_lo b_lo ~ 2^-16 of it is dropped)
-                        acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[Cfg::NP - 1][fm], b[0][fn], acc[fm][fn], 0, 0, 0);
-                        acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][fm], b[Cfg::NP - 1][fn], acc[fm][fn], 0, 0, 0);
-                    }
-                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][fm], b[0][fn], acc[fm][fn], 0, 0, 0);
+            for (int pr = 0; pr < NPROD; ++pr) {
+                // bf16x3: small terms first (a_lo b_hi, a_hi b_lo), then a_hi b_hi; a_lo b_lo (~2^-16 of it) is dropped
+                const int pa = (Cfg::NP == 2 && pr == 0) ? 1 : 0, pb = (Cfg::NP == 2 && pr == 1) ? 1 : 0;
+#pragma unroll
+                for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+                    for (int fn = 0; fn < Cfg::FN; ++fn)
+                        acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][pa][fm], b[set][pb][fn], acc[fm][fn], 0, 0, 0);
+            }
+            constexpr int NREADS = Cfg::NP * (Cfg::FM + Cfg::FN), NMFMA = NPROD * Cfg::FM * Cfg::FN;
+            if (kPipelined) {
+#pragma unroll
+                for (int i = 0; i < NMFMA; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // one MFMA
+                    if (tap + 1 < 9 && i < NREADS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one LDS read of the next tap
                 }
+                if (tap + 1 < 9 && NREADS > NMFMA) __builtin_amdgcn_sched_group_barrier(0x100, NREADS - NMFMA, 0);
+            }
         }
         if (more) store_chunk(other);
         __syncthreads();
