@@ -403,17 +403,20 @@ __global__ __launch_bounds__(256, 1) void k_c3b_wgrad(int N, int C, int H, int W
     // item i of this thread covers block b = wave + 4 i:  channels 16 * (b % 4) ..., groups 4 * (b / 4) ...
     constexpr int kOutOfRange = (int)0x80000000;
     int gch[Cfg::NGI], ggrp[Cfg::NGI], xch[Cfg::NXI], xgrp[Cfg::NXI];
+    int grow[Cfg::NGI], gcol[Cfg::NGI], xrow[Cfg::NXI], xcol[Cfg::NXI];      // row and first pixel of the item's group inside the unit
 #pragma unroll
     for (int i = 0; i < Cfg::NGI; ++i) {
         const int b = wave + 4 * i;
         gch[i] = 16 * (b & 3) + (lane & 15);
         ggrp[i] = 4 * (b >> 2) + (lane >> 4);                       // < TH * GG
+        grow[i] = ggrp[i] / Cfg::GG, gcol[i] = 8 * (ggrp[i] % Cfg::GG);
     }
 #pragma unroll
     for (int i = 0; i < Cfg::NXI; ++i) {
         const int b = wave + 4 * i;
         xch[i] = 16 * (b & 3) + (lane & 15);
         xgrp[i] = 4 * (b >> 2) + (lane >> 4);                       // may exceed XR * XG in the last item: skipped
+        xrow[i] = xgrp[i] / Cfg::XG - 1, xcol[i] = 8 * (xgrp[i] % Cfg::XG) - 8;
     }
     auto clamp_g = [&](int c) { return min(c, M - 1 - co0); };       // channels past M / C: duplicates of the last one, they only
     auto clamp_x = [&](int c) { return min(c, C - 1 - ci0); };       // reach accumulator rows / columns that are never stored
@@ -431,8 +434,7 @@ __global__ __launch_bounds__(256, 1) void k_c3b_wgrad(int N, int C, int H, int W
         srd_x = __builtin_amdgcn_make_buffer_rsrc((void *)(x + ((int64_t)n * C + ci0) * HW), 0, (int)min(x_left, (int64_t)0x7FFFFFFF), 0x00020000);
 #pragma unroll
         for (int i = 0; i < Cfg::NGI; ++i) {
-            const int r = ggrp[i] / Cfg::GG, g = ggrp[i] % Cfg::GG;
-            const int gh = h0 + r, gw = w0 + 8 * g;
+            const int gh = h0 + grow[i], gw = w0 + gcol[i];
             const bool ok = gh < H && gw < W;
             const int off = ok ? (clamp_g(gch[i]) * HW + gh * W + gw) * 4 : kOutOfRange;
             if (Cfg::MASKW) gnv[i] = ok ? min(8, W - gw) : 0;
@@ -442,8 +444,7 @@ __global__ __launch_bounds__(256, 1) void k_c3b_wgrad(int N, int C, int H, int W
         }
 #pragma unroll
         for (int i = 0; i < Cfg::NXI; ++i) {
-            const int r = xgrp[i] / Cfg::XG, g = xgrp[i] % Cfg::XG;
-            const int gh = h0 - 1 + r, gw = w0 - 8 + 8 * g;
+            const int gh = h0 + xrow[i], gw = w0 + xcol[i];
             const bool ok = xgrp[i] < Cfg::XR * Cfg::XG && (unsigned)gh < (unsigned)H && gw >= 0 && gw < W;
             const int off = ok ? (clamp_x(xch[i]) * HW + gh * W + gw) * 4 : kOutOfRange;
             if (Cfg::MASKW) xnv[i] = ok ? min(8, W - gw) : 0;
@@ -507,13 +508,14 @@ __global__ __launch_bounds__(256, 1) void k_c3b_wgrad(int N, int C, int H, int W
                         b[pl][1] = __builtin_bit_cast(bf16x8, c);
                         b[pl][2] = __builtin_bit_cast(bf16x8, br);
                     }
+                    // product-major: consecutive MFMAs go to different accumulators (small terms first in bf16x3)
+                    constexpr int NPROD = Cfg::NP == 2 ? 3 : 1;
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        if (Cfg::NP == 2) {
-                            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[Cfg::NP - 1], b[0][kw], acc[kh * 3 + kw], 0, 0, 0);
-                            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[Cfg::NP - 1][kw], acc[kh * 3 + kw], 0, 0, 0);
-                        }
-                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][kw], acc[kh * 3 + kw], 0, 0, 0);
+                    for (int pr = 0; pr < NPROD; ++pr) {
+                        const int pa = (Cfg::NP == 2 && pr == 0) ? 1 : 0, pb = (Cfg::NP == 2 && pr == 1) ? 1 : 0;
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw)
+                            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[pb][kw], acc[kh * 3 + kw], 0, 0, 0);
                     }
                 }
             }
