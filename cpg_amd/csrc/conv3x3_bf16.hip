@@ -360,9 +360,9 @@ int run(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, const 
 // MASKW: W is not a multiple of 8 (28-wide maps): the group that straddles the right image border is masked per element.
 // Split-K over units exactly like the fp32 kernel (k_c3_wgrad): tap-major partials, reduced (with the autograd epilogue
 // gW = g * bin(pm), gPM = g * W) by k_split_reduce.
-template <int TH_, int TW_, bool MASKW_, int NP_ = 1>
+template <int TH_, int TW_, bool MASKW_, int NP_ = 1, int NSTAGE_ = 2>
 struct B16WCfg {
-    static constexpr int TH = TH_, TW = TW_, NP = NP_;
+    static constexpr int TH = TH_, TW = TW_, NP = NP_, NSTAGE = NSTAGE_;
     static constexpr bool MASKW = MASKW_;
     static_assert(TW % 16 == 0, "k-steps are 16 pixels of one row");
     static constexpr int GG = TW / 8, XG = GG + 2, XR = TH + 2;          // groups per gy row / x row, x rows
@@ -526,11 +526,12 @@ __global__ __launch_bounds__(256, 1) void k_c3b_wgrad(int N, int C, int H, int W
         store_unit(smem);
         __syncthreads();
         for (int u = u0; u < u1; ++u) {
-            const int cs = (u - u0) & 1;
+            const int cs = Cfg::NSTAGE == 2 ? ((u - u0) & 1) : 0;
             const bool more = u + 1 < u1;                             // block-uniform
             if (more) load_unit(u + 1);
             compute(smem + cs * Cfg::STAGEQ);
-            if (more) store_unit(smem + (cs ^ 1) * Cfg::STAGEQ);
+            if (Cfg::NSTAGE == 1) __syncthreads();                    // one stage: all reads done before it is overwritten
+            if (more) store_unit(smem + (Cfg::NSTAGE == 2 ? (cs ^ 1) : 0) * Cfg::STAGEQ);
             __syncthreads();
         }
     }
@@ -573,6 +574,7 @@ using B16G32 = B16WCfg<4, 32, true>;        // any other width > 16 (28-wide map
 using B16G16 = B16WCfg<8, 16, true>;        // <= 16 wide maps (14 x 14)
 // two-plane ("bf16x3") variants: half the rows per unit so that two stages still fit in LDS
 using X3G64 = B16WCfg<1, 64, false, 2>;
+// (two rows per unit on ONE stage -- 2x instead of 3x re-read of the x rows -- spilled 61 VGPRs and ran at half the speed)
 using X3G32 = B16WCfg<2, 32, true, 2>;
 using X3G16 = B16WCfg<4, 16, true, 2>;
 inline int wpick(const cpg_conv_desc *d) { return d->W % 8 == 0 && d->W >= 56 ? 0 : d->W > 16 ? 1 : 2; }
@@ -581,7 +583,7 @@ template <class Cfg>
 int wlaunch(const cpg_conv_desc *d, const float *x, const float *gy, const Epilogue &ep, void *ws, size_t ws_bytes, hipStream_t stream) {
     const B16WPlan p = wplan<Cfg>(d);
     if (ws == nullptr || ws_bytes < p.ws_bytes) return fail(CPG_E_WORKSPACE, "cpg_conv2d_wgrad_bf16: workspace %zu < %zu bytes", ws_bytes, p.ws_bytes);
-    constexpr size_t smem = (size_t)2 * Cfg::STAGEQ * sizeof(u32x4);
+    constexpr size_t smem = (size_t)Cfg::NSTAGE * Cfg::STAGEQ * sizeof(u32x4);
     static_assert(smem <= 160 * 1024, "LDS budget");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_c3b_wgrad<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return hip_status(e, "cpg_conv2d_wgrad_bf16");

@@ -28,7 +28,10 @@ class BnBwdHint(object):
         return self.ypre is not None and tuple(x.shape) == self.out_shape and x.is_cuda
 
 
-ENABLE_BWD_HINT = True      # the BatchNorm backward reduction rides in the next conv's input-gradient epilogue
+# The BatchNorm backward reduction riding in the next conv's input-gradient epilogue.  OFF by default: it removes the 2-read
+# reduction kernels (-2.4 ms per VGG16 step) but the input-gradient kernels pay the HBM time of the extra reads in an epilogue
+# that nothing hides (+0.28 ms per layer); interleaved in-process A/B (tools/step_ab.py): 184.6 ms with it, 183.8 ms without.
+ENABLE_BWD_HINT = False
 
 
 class _BnReluFn(torch.autograd.Function):
