@@ -64,7 +64,7 @@ class TaskResult(object):
         self.finetune_train_acc = None
         self.ratio_to_acc = {}          # the reference's record.txt (pruning ratio -> validation accuracy)
         self.chosen_ratio = 0.0
-        self.needs_growth = False       # reference exit code 2 that could not be served (max width reached is NOT this: see run_task)
+        self.needs_growth = False       # the accuracy goal was missed even at the width cap (the reference's exit code 2 with nowhere to go)
         self.no_free_capacity = False   # reference exit code 5
         self.grown_to = []              # width multipliers tried after the first one
         self.retrain_kept = None        # task >= 2: did the piggymask retrain beat the pruned model (choose_retrain_or_not.py)
@@ -184,8 +184,6 @@ class CPGSession(object):
             for k, v in snap.state.items():
                 if k in cur and cur[k].shape == v.shape:
                     cur[k].copy_(v)
-        for _, module in masked_layers(self.net):           # piggymask Parameters are (re)created per phase, not restored here
-            pass
         for k, v in snap.masks.items():
             if self.masks[k].shape == v.shape:
                 self.masks[k].copy_(v)
@@ -351,18 +349,15 @@ class CPGSession(object):
             res.finetune_acc, res.finetune_train_acc = va, tr
             res.ratio_to_acc = {0.0: round(va, 4)}
             at_cap = self.width >= max_width
-            if tr > min_train_acc and va >= accuracy_goal:
-                break                                              # capacity is enough
-            if at_cap and va < accuracy_goal:
-                break                                              # exit 0 / 5: carry on at the cap (:474-478)
-            if at_cap:
-                break                                              # (train accuracy below the bar at the cap: the reference exits 2 forever)
+            if (tr > min_train_acc and va >= accuracy_goal) or at_cap:
+                # capacity is enough -- or the width cap is reached, where the reference carries on with what it has
+                # (exit 0 / 5, :474-478; a train accuracy below the bar at the cap would make its bash loop exit 2 forever)
+                break
             # exit 2: widen and re-run the finetune from the previous task's checkpoint
             new_width = min(max_width, self.width + width_step)
             res.grown_to.append(new_width)
             self.grow(new_width, before)
-        if va < accuracy_goal and not (self.width >= max_width):
-            res.needs_growth = True
+        res.needs_growth = va < accuracy_goal                      # the goal was missed at the width cap: more capacity would be needed
         self.commit_task(dataset)
         if mgr.pruner.calculate_curr_task_ratio() == 0.0:
             res.no_free_capacity = True                            # exit 5: nothing of this task's own to prune

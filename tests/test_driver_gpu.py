@@ -52,7 +52,7 @@ def test_run_task_sweep_restores_chosen_stage_and_task2_does_not_forget():
     tr1, va1 = _loaders(0)
     res = sess.run_task('t1', 5, tr1, va1, accuracy_goal=0.0, finetune_epochs=2, prune_epochs=1, sparsities=(0.2, 0.4),
                         args=args, min_train_acc=-1.0)
-    assert set(res.ratio_to_acc) == {0.0, 0.2, 0.4} and res.chosen_ratio == 0.4 and not res.grown_to
+    assert set(res.ratio_to_acc) == {0.0, 0.2, 0.4} and res.chosen_ratio == 0.4 and not res.grown_to and not res.needs_growth
     # the model is left in the 0.4 stage: its last rank-prune event ran at step 3 of a 4-step window, where the cubic
     # schedule (utils/prune.py:55-66) stands at 0.4 - 0.2 / 64
     assert abs(_zero_fraction(sess) - (0.4 - 0.2 / 64)) < 1e-3
@@ -104,7 +104,7 @@ def test_growth_pads_masks_keeps_old_weights_and_old_task_logits(tmp_path):
     tr2, va2 = _loaders(1)
     res2 = sess.run_task('t2', 5, tr2, va2, accuracy_goal=2.0, finetune_epochs=1, prune_epochs=1, sparsities=(0.3,), args=args,
                          min_train_acc=-1.0, max_width=0.25, width_step=0.125, retrain_epochs=1, total_num_tasks=2)
-    assert res2.grown_to == [0.25] and sess.width == 0.25
+    assert res2.grown_to == [0.25] and sess.width == 0.25 and res2.needs_growth      # (goal 2.0 stays missed at the cap)
     assert sess.shared_layer_info['t1']['network_width_multiplier'] == 0.125
     assert sess.shared_layer_info['t2']['network_width_multiplier'] == 0.25
     for name, m in sess.model.named_modules():
