@@ -952,7 +952,9 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
     // 56, 112, 168 ...: a 32-wide tile would waste 12.5 % of the MFMAs.  The 64-channel 8 x 56 tile (2 x 2 waves) measured
     // 1-2 % faster than the 128-channel 4 x 56 tile (4 x 1 waves) on every 56- and 112-wide VGG layer, also for m > 64
     // (interleaved in-process A/B, tools/conv_bench.py --ab CPG_C3_FORCE=3,4).
-    if (W % 56 == 0 && W % 32 != 0) return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
+    // (224-wide maps divide by 32 too; the 8 x 56 tile measured 0.8 % faster there as well -- except for the HBM-bound 3-channel
+    // stem, which prefers the 8 x 32 tile by 9 %)
+    if (W % 56 == 0 && (W % 32 != 0 || c_read >= 16)) return launch_fwd<CfgD64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
     if (m <= 64) return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
     return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
 }
