@@ -11,11 +11,11 @@
 //               Up[k block of 32][channel chunk of 4][p][k][c]  (one contiguous 8 KB record per block and chunk)
 //   k_wg_fwd    block = 4 waves = 32 output channels x 64 tiles (256 output pixels), two blocks per CU.  Wave (tq, ph) owns
 //               tiles tq*32..+31 and positions ph*8..+7: 8 accumulators of 32 x 32.  Per chunk of 4 input channels the
-//               block stages U (two float4 per thread) and V: every thread gathers ONE 4x4 patch (tile = tid / 4,
-//               channel = tid % 4) with 16 range-checked buffer loads (zero padding for free), transforms it in
-//               registers (32 adds) and writes the 16 positions to LDS -- V[p][t][c], consecutive threads to consecutive
-//               words.  Operands are ds_read_b64: lanes 0-31 take channels (0, 1), lanes 32-63 channels (2, 3) of the
-//               chunk -- two k-steps of v_mfma_f32_32x32x2_f32 per read pair.  Two LDS stages, one barrier per chunk.
+//               block stages U (two float4 per thread) and V: every thread gathers ONE 4x4 patch (tile = lane,
+//               channel = wave) with 16 range-checked buffer loads (zero padding for free), transforms it in
+//               registers (32 adds) and writes the 16 positions to LDS -- V[p][c][t], consecutive threads to consecutive
+//               words.  Operand reads: lanes 0-31 take channels (0, 1), lanes 32-63 channels (2, 3) of the chunk
+//               -- two k-steps of v_mfma_f32_32x32x2_f32 per read pair.  Two LDS stages, one barrier per chunk.
 //               Epilogue: the output transform is linear, so each wave reduces its 8 positions to partial 2x2 outputs,
 //               the two waves of a tile swap halves through LDS (row 0 of every tile is finished by ph = 0, row 1 by
 //               ph = 1) and store float2 per lane (256 contiguous bytes per channel row and half-wave).
@@ -27,12 +27,14 @@ using namespace cpg;
 
 namespace {
 
+#ifndef WG_EXP
+#define WG_EXP 0
+#endif
 constexpr int WG_BK = 32;                     // output channels per block
 constexpr int WG_T = 64;                      // tiles per block
 constexpr int WG_CK = 4;                      // input channels per chunk
 constexpr int WG_U = 16 * WG_BK * WG_CK;      // floats of U per chunk
 constexpr int WG_V = 16 * WG_T * WG_CK;
-constexpr int WG_STAGE = WG_U + WG_V;         // 6144 floats = 24 KB
 
 struct WgGeom {
     int N, C, H, W, M;        // C: channels read, M: channels produced
@@ -92,13 +94,30 @@ __global__ __launch_bounds__(256) void k_wg_pack(const float *__restrict__ w, co
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+// LDS map (floats): V[2 stages][16][4][64] | U[3 stages][16][32][4] | raw[2 stages][4 channels][4 rows][66 slots][2]
+constexpr int WG_RAWC = 4 * 66 * 2;                    // raw floats per channel
+constexpr int WG_RAW = WG_CK * WG_RAWC;
+constexpr int WG_OFF_U = 2 * WG_V;
+constexpr int WG_OFF_RAW = WG_OFF_U + 3 * WG_U;
+constexpr int WG_SMEM = WG_OFF_RAW + 2 * WG_RAW;       // 18560 floats = 72.5 KB: two blocks per CU
 
 // ------------------------------------------------------------------------------ forward / input gradient
+// Staging is two-level, because a vector-memory instruction occupies the texture addresser for 16 cycles whatever its width:
+// gathering each tile's 4x4 patch with 16 dword loads made the kernel TA-bound (2300 of the 2048 cycles a chunk pair has).
+//   G  global -> registers: per wave (= channel of the chunk) and patch row ONE buffer_load_dwordx2 -- lane t fetches the
+//      aligned column pair (2 tx, 2 tx + 1) of tile t -- plus one dword load for the two halo columns outside the block's
+//      tile run; U: two float4 per thread.  7 instructions per wave and chunk instead of 18.
+//   W  registers -> LDS raw[c][row][slot 1 + t][2]
+//   T  every thread reads its tile's 4 x 4 patch back (own pair + the neighbours' halves), transforms it, writes V
+//   M  16 MFMAs per wave
+// Iteration `it` of the main loop runs M(it), T(it + 1), W(it + 2), G(it + 5): three register sets, one barrier.
 template <bool DGRAD, bool STATS>
 __global__ __launch_bounds__(256, 2) void k_wg_fwd(WgGeom g, const float *__restrict__ x, const float *__restrict__ up,
                                                    const float *__restrict__ bias, float *__restrict__ y,
                                                    float *__restrict__ stats) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * WG_STAGE];
+    __shared__ __attribute__((aligned(16))) float smem[WG_SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tq = wave & 1, ph = wave >> 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -110,56 +129,121 @@ __global__ __launch_bounds__(256, 2) void k_wg_fwd(WgGeom g, const float *__rest
     const int64_t t0 = (int64_t)tb * WG_T;                  // first tile of the block
     const int n0 = (int)(t0 / g.tiles_img);                 // first image the block touches
 
-    // ---- staging item of this thread: the 4x4 patch of tile (tid / 4), channel (tid % 4) of the chunk ----
+    // ---- G descriptors: tile `lane`, channel `wave` of the chunk ----
     constexpr int kOutOfRange = (int)0x80000000;
-    int xoff[16];
+    int roff[4];                                            // byte offset of (row i, column 2 tx) or out of range (-> zeros)
+    int hoff;                                               // lanes 0-3: column 2 tx - 1 of tile t0 - 1's right neighbour ... see below
+    bool edge_l, edge_r;                                    // the tile touches the left / right image border: that halo column is 0
     {
-        const int64_t tg = t0 + (tid >> 2);
+        const int64_t tg = t0 + lane;
         const bool tv = tg < g.tiles_total;
         const int n = (int)(tg / g.tiles_img), r = (int)(tg % g.tiles_img);
         const int ty = r / g.tw, tx = r % g.tw;
-        const int cbase = ((n - n0) * g.C + (tid & 3)) * HW;
+        const int cbase = ((n - n0) * g.C + wave) * HW;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gh = 2 * ty - 1 + i, gw = 2 * tx - 1 + j;
-                const bool ok = tv && (unsigned)gh < (unsigned)g.H && (unsigned)gw < (unsigned)g.W;
-                xoff[i * 4 + j] = ok ? (cbase + gh * g.W + gw) * 4 : kOutOfRange;
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int gh = 2 * ty - 1 + i;
+            roff[i] = (tv && (unsigned)gh < (unsigned)g.H) ? (cbase + gh * g.W + 2 * tx) * 4 : kOutOfRange;
+        }
+        edge_l = tx == 0, edge_r = tx == g.tw - 1;
+        // halo loads, one instruction: lanes 0-3 fetch row (lane) of the column LEFT of tile t0 (slot 0, element 1), lanes 4-7 row
+        // (lane - 4) of the column RIGHT of tile t0 + 63 (slot 65, element 0); unused when that tile sits on the image border
+        const int side = (lane >> 2) & 1, hi = lane & 3;
+        const int64_t th = side ? t0 + WG_T - 1 : t0;
+        const int nh = (int)(th / g.tiles_img), rh = (int)(th % g.tiles_img);
+        const int tyh = rh / g.tw, txh = rh % g.tw;
+        const int ghh = 2 * tyh - 1 + hi, gwh = side ? 2 * txh + 2 : 2 * txh - 1;
+        const bool okh = lane < 8 && th < g.tiles_total && (unsigned)ghh < (unsigned)g.H && (unsigned)gwh < (unsigned)g.W;
+        hoff = okh ? (((nh - n0) * g.C + wave) * HW + ghh * g.W + gwh) * 4 : kOutOfRange;
     }
     const int nimg_here = min(g.span, g.N - n0);
     const __amdgpu_buffer_rsrc_t srd_x =
         __builtin_amdgcn_make_buffer_rsrc((void *)(x + (int64_t)n0 * g.C * HW), 0, nimg_here * g.C * HW * 4, 0x00020000);
     const float *ubase = up + (int64_t)kb * g.nch * WG_U + tid * 4;
 
-    // two register sets: the loads of chunk ch + 2 are issued at the top of chunk ch and consumed (transformed, written to LDS)
-    // at the bottom of chunk ch + 1 -- a chunk is only 16 MFMAs per wave, one chunk of distance left the HBM / L2 latency exposed
-    f32x4 ru[2][2];
-    float rx[2][16];
-    auto load_chunk = [&](int ch, f32x4 (&u)[2], float (&r)[16]) {
-        u[0] = *reinterpret_cast<const f32x4 *>(ubase + (int64_t)ch * WG_U);
-        u[1] = *reinterpret_cast<const f32x4 *>(ubase + (int64_t)ch * WG_U + 1024);
-        const int soff = ch * WG_CK * HW * 4;
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-            r[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, xoff[e], soff, 0));
+    struct Regs {
+        f32x4 u[2];
+        i32x2 row[4];
+        float halo;
     };
-    auto store_chunk = [&](float *stage, const f32x4 (&u)[2], const float (&r)[16]) {
-        *reinterpret_cast<f32x4 *>(stage + tid * 4) = u[0];
-        *reinterpret_cast<f32x4 *>(stage + tid * 4 + 1024) = u[1];
-        // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-        float t[16];
+    Regs rs[3];
+    auto G = [&](int ch, Regs &r) {
+        r.u[0] = *reinterpret_cast<const f32x4 *>(ubase + (int64_t)ch * WG_U);
+        r.u[1] = *reinterpret_cast<const f32x4 *>(ubase + (int64_t)ch * WG_U + 1024);
+        const int soff = ch * WG_CK * HW * 4;
+#if WG_EXP != 1
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t[0 * 4 + j] = r[0 * 4 + j] - r[2 * 4 + j];
-            t[1 * 4 + j] = r[1 * 4 + j] + r[2 * 4 + j];
-            t[2 * 4 + j] = r[2 * 4 + j] - r[1 * 4 + j];
-            t[3 * 4 + j] = r[1 * 4 + j] - r[3 * 4 + j];
-        }
-        float *v = stage + WG_U + tid;
+        for (int i = 0; i < 4; ++i) r.row[i] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[i], soff, 0);
+        r.halo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, hoff, soff, 0));
+#endif
+    };
+    // raw[c = wave][row][slot][2]: slot 0 = left halo, 1 + t = tile t, 65 = right halo
+    const int raw_w = WG_OFF_RAW + wave * WG_RAWC + (lane + 1) * 2;
+    const int halo_w = WG_OFF_RAW + wave * WG_RAWC + (lane & 3) * 132 + ((lane >> 2) & 1 ? 65 * 2 : 1);
+    auto W = [&](int ch, int ustage, const Regs &r) {
+        float *us = smem + WG_OFF_U + ustage * WG_U;
+        *reinterpret_cast<f32x4 *>(us + tid * 4) = r.u[0];
+        *reinterpret_cast<f32x4 *>(us + tid * 4 + 1024) = r.u[1];
+#if WG_EXP != 4 && WG_EXP != 1
+        float *raw = smem + (ch & 1) * WG_RAW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<i32x2 *>(raw + raw_w + i * 132) = r.row[i];
+        if (lane < 8) raw[halo_w] = r.halo;
+#endif
+    };
+    // T in pieces, so that the main loop can spread it between its MFMAs
+    auto T_read = [&](int ch, float (&d)[16]) {          // 4 x (own pair + the two neighbours' halves); no edge fix yet
+        const float *raw = smem + (ch & 1) * WG_RAW + raw_w;
+#if WG_EXP == 4
+        for (int e = 0; e < 16; ++e) d[e] = (float)(ch + e);
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            const f32x2 own = *reinterpret_cast<const f32x2 *>(raw + i * 132);
+            d[i * 4 + 0] = raw[i * 132 - 1];
+            d[i * 4 + 1] = own[0];
+            d[i * 4 + 2] = own[1];
+            d[i * 4 + 3] = raw[i * 132 + 2];
+        }
+    };
+    auto T_edge = [&](float (&d)[16]) {
+#if WG_EXP == 3
+        return;
+#endif
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            d[i * 4 + 0] = edge_l ? 0.0f : d[i * 4 + 0];
+            d[i * 4 + 3] = edge_r ? 0.0f : d[i * 4 + 3];
+        }
+    };
+    // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: column pass in place (columns j0, j0 + 1) ...
+    auto T_col = [&](float (&d)[16], int j0) {
+#if WG_EXP == 3
+        return;
+#endif
+#pragma unroll
+        for (int j = j0; j < j0 + 2; ++j) {
+            const float d0 = d[0 * 4 + j], d1 = d[1 * 4 + j], d2 = d[2 * 4 + j], d3 = d[3 * 4 + j];
+            d[0 * 4 + j] = d0 - d2;
+            d[1 * 4 + j] = d1 + d2;
+            d[2 * 4 + j] = d2 - d1;
+            d[3 * 4 + j] = d1 - d3;
+        }
+    };
+    // ... row pass of rows i0, i0 + 1 and their 8 positions to V[p][c = wave][t = lane]
+    auto T_row = [&](int ch, const float (&t)[16], int i0) {
+        float *v = smem + (ch & 1) * WG_V + tid;
+#if WG_EXP == 2
+        if (t[0] + t[1] + t[2] + t[3] + t[4] + t[5] + t[6] + t[7] + t[8] + t[9] + t[10] + t[11] + t[12] + t[13] + t[14] + t[15] != 12345.f) return;
+#endif
+#if WG_EXP == 3
+        for (int i = i0; i < i0 + 2; ++i)
+            for (int j = 0; j < 4; ++j) v[(i * 4 + j) * (WG_T * WG_CK)] = t[i * 4 + j];
+        return;
+#endif
+#pragma unroll
+        for (int i = i0; i < i0 + 2; ++i) {
             v[(i * 4 + 0) * (WG_T * WG_CK)] = t[i * 4 + 0] - t[i * 4 + 2];
             v[(i * 4 + 1) * (WG_T * WG_CK)] = t[i * 4 + 1] + t[i * 4 + 2];
             v[(i * 4 + 2) * (WG_T * WG_CK)] = t[i * 4 + 2] - t[i * 4 + 1];
@@ -168,8 +252,17 @@ __global__ __launch_bounds__(256, 2) void k_wg_fwd(WgGeom g, const float *__rest
     };
 
     // operand lane bases (floats): position p = ph * 8 + pp
-    const int a_base = (ph * 8) * (WG_BK * WG_CK) + li * WG_CK + lh * 2;
-    const int b_base = WG_U + (ph * 8) * (WG_T * WG_CK) + (tq * 32 + li) * WG_CK + lh * 2;
+    const int a_base = WG_OFF_U + (ph * 8) * (WG_BK * WG_CK) + li * WG_CK + lh * 2;
+    const int b_base = (ph * 8) * (WG_T * WG_CK) + (2 * lh) * WG_T + tq * 32 + li;
+    struct Ops {
+        f32x2 a;
+        float b0, b1;
+    };
+    auto read_ops = [&](int it, int k, int pp, Ops &o) {
+        o.a = *reinterpret_cast<const f32x2 *>(smem + k * WG_U + a_base + pp * (WG_BK * WG_CK));
+        const float *vs = smem + (it & 1) * WG_V + b_base + pp * (WG_T * WG_CK);
+        o.b0 = vs[0], o.b1 = vs[WG_T];
+    };
 
     f32x16 acc[8];
 #pragma unroll
@@ -178,29 +271,77 @@ __global__ __launch_bounds__(256, 2) void k_wg_fwd(WgGeom g, const float *__rest
         for (int e = 0; e < 16; ++e) acc[pp][e] = 0.0f;
 
     const int last = g.nch - 1;
-    load_chunk(0, ru[0], rx[0]);
-    load_chunk(min(1, last), ru[1], rx[1]);
-    store_chunk(smem, ru[0], rx[0]);
+    auto clampc = [&](int c) { return min(c, last); };
+    float d[16];                       // the raw patch of T(it + 1), read before iteration `it` starts
+    Ops o0;                            // operands of M(it)'s first position, likewise
+    G(0, rs[0]);
+    G(clampc(1), rs[1]);
+    G(clampc(2), rs[2]);
+    W(0, 0, rs[0]);
+    G(clampc(3), rs[0]);
     __syncthreads();
-    // chunk ch computes from stage ch & 1; register set (ch + 1) & 1 holds chunk ch + 1, set ch & 1 receives chunk ch + 2
-    auto chunk = [&](int ch, f32x4 (&u_in)[2], float (&r_in)[16], f32x4 (&u_next)[2], float (&r_next)[16]) {
-        const float *st = smem + (ch & 1) * WG_STAGE;
-        float *other = smem + ((ch + 1) & 1) * WG_STAGE;
-        load_chunk(min(ch + 2, last), u_in, r_in);
-#pragma unroll
-        for (int pp = 0; pp < 8; ++pp) {
-            const f32x2 a = *reinterpret_cast<const f32x2 *>(st + a_base + pp * (WG_BK * WG_CK));
-            const f32x2 b = *reinterpret_cast<const f32x2 *>(st + b_base + pp * (WG_T * WG_CK));
-            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc[pp], 0, 0, 0);
-            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc[pp], 0, 0, 0);
-        }
-        store_chunk(other, u_next, r_next);
+    T_read(0, d);
+    T_edge(d);
+    T_col(d, 0);
+    T_col(d, 2);
+    T_row(0, d, 0);
+    T_row(0, d, 2);
+    W(1, 1, rs[1]);
+    G(clampc(4), rs[1]);
+    __syncthreads();
+    T_read(1, d);
+    read_ops(0, 0, 0, o0);
+    // Iteration `it` (k = it % 3 at compile time): M(it), T(it + 1), W(it + 2), G(it + 5), software-pipelined ACROSS the barrier:
+    // everything the other waves wait for (T's V writes, W) and every LDS read of this chunk's operands is done by position 4;
+    // positions 5-7 run from registers after the barrier while the wave issues G and already reads the next iteration's first
+    // operands and raw patch -- no LDS round trip is exposed at the chunk boundary.  sched_barrier fences keep this order.
+#define WG_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define WG_MMA(pp, o)                                                                        \
+    acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a[0], (o).b0, acc[pp], 0, 0, 0);      \
+    acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a[1], (o).b1, acc[pp], 0, 0, 0)
+    auto iter = [&](int it, int k, Regs &r) {
+        Ops o1, o2, o3, o4, o5, o6, o7;
+        read_ops(it, k, 1, o1);
+        WG_MMA(0, o0);
+        T_edge(d);
+        WG_FENCE();
+        read_ops(it, k, 2, o2);
+        WG_MMA(1, o1);
+        T_col(d, 0);
+        WG_FENCE();
+        read_ops(it, k, 3, o3);
+        WG_MMA(2, o2);
+        T_col(d, 2);
+        WG_FENCE();
+        read_ops(it, k, 4, o4);
+        WG_MMA(3, o3);
+        T_row(it + 1, d, 0);
+        WG_FENCE();
+        read_ops(it, k, 5, o5);
+        read_ops(it, k, 6, o6);
+        read_ops(it, k, 7, o7);
+        WG_MMA(4, o4);
+        T_row(it + 1, d, 2);
+        W(it + 2, (k + 2) % 3, r);
+        WG_FENCE();
         __syncthreads();
+        WG_FENCE();
+        WG_MMA(5, o5);
+        G(clampc(it + 5), r);
+        WG_FENCE();
+        WG_MMA(6, o6);
+        T_read(it + 2, d);
+        WG_FENCE();
+        WG_MMA(7, o7);
+        read_ops(it + 1, (k + 1) % 3, 0, o0);
+        WG_FENCE();
     };
-    for (int ch = 0; ch < g.nch; ch += 2) {
-        chunk(ch, ru[0], rx[0], ru[1], rx[1]);
-        if (ch + 1 < g.nch) chunk(ch + 1, ru[1], rx[1], ru[0], rx[0]);
+    for (int it = 0; it < g.nch; it += 3) {
+        iter(it, 0, rs[2]);
+        if (it + 1 < g.nch) iter(it + 1, 1, rs[0]);
+        if (it + 2 < g.nch) iter(it + 2, 2, rs[1]);
     }
+    __syncthreads();                   // (the trailing prefetch reads are done before the epilogue reuses the LDS)
 
     // ---- epilogue: output transform  Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1];  position p = 4 i + j, this wave holds i = 2 ph, 2 ph + 1
     f32x16 own[2], give[2];                    // [b]: the output row this wave finishes (a = ph) / the other row's partial
