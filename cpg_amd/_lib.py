@@ -75,6 +75,7 @@ _SIGNATURES = {
                                             ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
     'cpg_bn_relu_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                        ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
+    'cpg_conv2d_winograd': (ctypes.c_int32, [ctypes.POINTER(ConvDesc), ctypes.c_int32]),
     'cpg_conv2d_bnstats_tiles': (ctypes.c_int32, [ctypes.POINTER(ConvDesc)]),
     'cpg_conv2d_fwd_bnstats': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, ctypes.c_size_t, _vp,
                                               ctypes.c_size_t, _vp]),

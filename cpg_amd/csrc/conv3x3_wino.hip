@@ -5,20 +5,34 @@
 // 16 multiplies per 2x2 output tile and (c, k) pair instead of 36: the contraction over input channels becomes 16
 // independent GEMMs  M_p[k][t] = sum_c U_p[k][c] * V_p[c][t]  (p = transform-domain position, t = tile), 2.25x fewer MFMAs
 // than the direct kernels of conv3x3.hip for the same result up to fp32 rounding (the transforms only add, subtract and
-// halve).  DESIGN.md section 4.9 has the measurements.
+// halve; measured 1-4e-6 of the output scale against fp64, the direct kernels 0.5-1e-6).  DESIGN.md section 4.9 has the
+// measurements behind the choices below.
 //
 //   k_wg_pack   U = G (W .* bin(piggymask)) G^T per (k, c), written in the order the conv kernel streams it:
-//               Up[k block of 32][channel chunk of 4][p][k][c]  (one contiguous 8 KB record per block and chunk)
-//   k_wg_fwd    block = 4 waves = 32 output channels x 64 tiles (256 output pixels), two blocks per CU.  Wave (tq, ph) owns
-//               tiles tq*32..+31 and positions ph*8..+7: 8 accumulators of 32 x 32.  Per chunk of 4 input channels the
-//               block stages U (two float4 per thread) and V: every thread gathers ONE 4x4 patch (tile = lane,
-//               channel = wave) with 16 range-checked buffer loads (zero padding for free), transforms it in
-//               registers (32 adds) and writes the 16 positions to LDS -- V[p][c][t], consecutive threads to consecutive
-//               words.  Operand reads: lanes 0-31 take channels (0, 1), lanes 32-63 channels (2, 3) of the chunk
-//               -- two k-steps of v_mfma_f32_32x32x2_f32 per read pair.  Two LDS stages, one barrier per chunk.
-//               Epilogue: the output transform is linear, so each wave reduces its 8 positions to partial 2x2 outputs,
-//               the two waves of a tile swap halves through LDS (row 0 of every tile is finished by ph = 0, row 1 by
-//               ph = 1) and store float2 per lane (256 contiguous bytes per channel row and half-wave).
+//               Up[k block of BK][channel chunk of 4][p][k][c]  (one contiguous record per block and chunk)
+//   k_wg_fwd    block = NW waves = BK output channels x 64 tiles (256 output pixels); a tile run is 64 consecutive tiles in
+//               (image, tile row, tile column) order, whatever the map size -- no padding tiles, blocks may straddle rows and
+//               images.  NW = 4 (the default): BK = 32, two blocks per CU; NW = 8: BK = 64, one block per CU (every
+//               transformed input element feeds twice the MFMAs, less staging work per MFMA -- but measured slower, see
+//               wino_nw()).  Wave (tq, ph, kq) owns tiles tq*32..+31, positions ph*8..+7 and
+//               channels kq*32..+31: 8 accumulators of 32 x 32.  Per chunk of 4 input channels:
+//     G  global -> registers.  A vector-memory instruction occupies the texture addresser for 16 cycles whatever its width
+//        (gathering every tile's 4 x 4 patch with 16 dword loads made the kernel TA-bound), so the patch rows are fetched
+//        ONCE, as aligned column pairs: per channel and patch row one buffer_load_dwordx2 (lane t = columns 2 tx, 2 tx + 1 of
+//        tile t; range-checked: rows outside the image read as zeros), plus one dword load for the two halo columns left /
+//        right of the tile run.  U: two float4 per thread.
+//     W  registers -> LDS raw[c][row][slot 1 + t][2]  (slot 0 / 65: halos; their unused halves hold zeros that the tiles on
+//        the image's left / right border read instead of a neighbour)
+//     T  every thread reads a tile's patch back (own pair + the neighbours' halves), transforms it in registers and writes the
+//        positions to LDS V[p][c][t].  NW = 8: two threads share a tile, positions 0-7 (patch rows 0-2) / 8-15 (rows 1-3).
+//     M  16 MFMAs per wave; operands: lanes 0-31 take channels (0, 1), lanes 32-63 channels (2, 3) of the chunk.
+//   Main-loop iteration `it` runs M(it), T(it + 1), W(it + 2), G(it + 5) -- three register sets -- software-pipelined ACROSS its
+//   one barrier: every LDS write the other waves wait for and every LDS read of this chunk's operands is issued by position 3;
+//   positions 4-7 run from registers after the barrier while the wave issues G and already reads the next chunk's first operands
+//   and raw patch.  sched_barrier fences pin that order (left alone, the compiler clumps the MFMAs at the top).
+//   Epilogue: the output transform is linear, so each wave reduces its 8 positions to partial 2x2 outputs, the two waves of a
+//   tile swap halves through LDS (row 0 of every tile is finished by ph = 0, row 1 by ph = 1) and store float2 per lane.
+//   STATS: per-channel sum / sum of squares of the block's outputs for the BatchNorm that follows (as k_c3_fwd<.., STATS>).
 //   dgrad       the same kernel on gy with the filter transposed and spatially flipped (k_wg_pack's dgrad flavour).
 #include <algorithm>
 #include "igemm_core.h"
@@ -27,35 +41,32 @@ using namespace cpg;
 
 namespace {
 
-#ifndef WG_EXP
-#define WG_EXP 0
-#endif
-constexpr int WG_BK = 32;                     // output channels per block
 constexpr int WG_T = 64;                      // tiles per block
 constexpr int WG_CK = 4;                      // input channels per chunk
-constexpr int WG_U = 16 * WG_BK * WG_CK;      // floats of U per chunk
-constexpr int WG_V = 16 * WG_T * WG_CK;
+constexpr int WG_V = 16 * WG_T * WG_CK;       // floats of V per chunk
+constexpr int WG_RAWC = 4 * 66 * 2;           // raw floats per channel: [row][slot][2]
+constexpr int WG_RAW = WG_CK * WG_RAWC;
 
 struct WgGeom {
     int N, C, H, W, M;        // C: channels read, M: channels produced
     int th, tw;               // tiles per image column / row (H / 2, W / 2)
     int tiles_img;            // th * tw
     int64_t tiles_total;      // N * th * tw
-    int nkb, nch;             // blocks of 32 output channels, chunks of 4 input channels
+    int nkb, nch;             // blocks of BK output channels, chunks of 4 input channels
     int span;                 // images a block's 64 consecutive tiles can touch
 };
 
 // ------------------------------------------------------------------------------ weight transform
 __global__ __launch_bounds__(256) void k_wg_pack(const float *__restrict__ w, const float *__restrict__ pm, float thr,
-                                                 float *__restrict__ up, int K, int C, int M, int Cin, int nch, int dgrad) {
-    // one thread per (kb, ch, kl, cl); writes 16 values at stride 128 floats
-    const int64_t total = (int64_t)((M + WG_BK - 1) / WG_BK) * nch * WG_BK * WG_CK;
+                                                 float *__restrict__ up, int K, int C, int M, int Cin, int nch, int dgrad, int BK) {
+    // one thread per (kb, ch, kl, cl); writes 16 values at stride BK * 4 floats
+    const int64_t total = (int64_t)((M + BK - 1) / BK) * nch * BK * WG_CK;
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
         const int cl = (int)(o % WG_CK);
-        const int kl = (int)((o / WG_CK) % WG_BK);
-        const int64_t rec = o / (WG_CK * WG_BK);            // kb * nch + ch
+        const int kl = (int)((o / WG_CK) % BK);
+        const int64_t rec = o / (WG_CK * BK);                // kb * nch + ch
         const int ch = (int)(rec % nch), kb = (int)(rec / nch);
-        const int m = kb * WG_BK + kl, c = ch * WG_CK + cl;  // produced / read channel
+        const int m = kb * BK + kl, c = ch * WG_CK + cl;     // produced / read channel
         float g[3][3];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -82,13 +93,13 @@ __global__ __launch_bounds__(256) void k_wg_pack(const float *__restrict__ w, co
             t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
             t[3][s] = g[2][s];
         }
-        float *dst = up + rec * WG_U + kl * WG_CK + cl;
+        float *dst = up + rec * (16 * BK * WG_CK) + kl * WG_CK + cl;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            dst[(i * 4 + 0) * (WG_BK * WG_CK)] = t[i][0];
-            dst[(i * 4 + 1) * (WG_BK * WG_CK)] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
-            dst[(i * 4 + 2) * (WG_BK * WG_CK)] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
-            dst[(i * 4 + 3) * (WG_BK * WG_CK)] = t[i][2];
+            dst[(i * 4 + 0) * (BK * WG_CK)] = t[i][0];
+            dst[(i * 4 + 1) * (BK * WG_CK)] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+            dst[(i * 4 + 2) * (BK * WG_CK)] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+            dst[(i * 4 + 3) * (BK * WG_CK)] = t[i][2];
         }
     }
 }
@@ -96,32 +107,34 @@ __global__ __launch_bounds__(256) void k_wg_pack(const float *__restrict__ w, co
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 
-// LDS map (floats): V[2 stages][16][4][64] | U[3 stages][16][32][4] | raw[2 stages][4 channels][4 rows][66 slots][2]
-constexpr int WG_RAWC = 4 * 66 * 2;                    // raw floats per channel
-constexpr int WG_RAW = WG_CK * WG_RAWC;
-constexpr int WG_OFF_U = 2 * WG_V;
-constexpr int WG_OFF_RAW = WG_OFF_U + 3 * WG_U;
-constexpr int WG_SMEM = WG_OFF_RAW + 2 * WG_RAW;       // 18560 floats = 72.5 KB: two blocks per CU
+template <int NW_>
+struct WgCfg {
+    static constexpr int NW = NW_, NT = 64 * NW, BK = 8 * NW;
+    static constexpr int U = 16 * BK * WG_CK;              // floats of U per chunk
+    // LDS map (floats): V[2 stages] | U[3 stages] | raw[2 stages]
+    static constexpr int OFF_U = 2 * WG_V, OFF_RAW = OFF_U + 3 * U, SMEM = OFF_RAW + 2 * WG_RAW;   // 72.5 KB (NW = 4) / 96.5 KB (NW = 8)
+    static constexpr int NROW = NW == 4 ? 4 : 2;           // patch rows a wave fetches per chunk
+    static constexpr int ND = NW == 4 ? 16 : 12;           // patch elements a thread transforms (4 or 3 rows)
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+};
 
 // ------------------------------------------------------------------------------ forward / input gradient
-// Staging is two-level, because a vector-memory instruction occupies the texture addresser for 16 cycles whatever its width:
-// gathering each tile's 4x4 patch with 16 dword loads made the kernel TA-bound (2300 of the 2048 cycles a chunk pair has).
-//   G  global -> registers: per wave (= channel of the chunk) and patch row ONE buffer_load_dwordx2 -- lane t fetches the
-//      aligned column pair (2 tx, 2 tx + 1) of tile t -- plus one dword load for the two halo columns outside the block's
-//      tile run; U: two float4 per thread.  7 instructions per wave and chunk instead of 18.
-//   W  registers -> LDS raw[c][row][slot 1 + t][2]
-//   T  every thread reads its tile's 4 x 4 patch back (own pair + the neighbours' halves), transforms it, writes V
-//   M  16 MFMAs per wave
-// Iteration `it` of the main loop runs M(it), T(it + 1), W(it + 2), G(it + 5): three register sets, one barrier.
-template <bool DGRAD, bool STATS>
-__global__ __launch_bounds__(256, 2) void k_wg_fwd(WgGeom g, const float *__restrict__ x, const float *__restrict__ up,
-                                                   const float *__restrict__ bias, float *__restrict__ y,
-                                                   float *__restrict__ stats) {
-    __shared__ __attribute__((aligned(16))) float smem[WG_SMEM];
+template <int NW, bool DGRAD, bool STATS>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_wg_fwd(WgGeom g, const float *__restrict__ x,
+                                                                      const float *__restrict__ up,
+                                                                      const float *__restrict__ bias, float *__restrict__ y,
+                                                                      float *__restrict__ stats) {
+    using Cfg = WgCfg<NW>;
+    constexpr int BK = Cfg::BK;
+    __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tq = wave & 1, ph = wave >> 1;
+    const int tq = wave & 1, ph = (wave >> 1) & 1, kq = wave >> 2;
     const int li = lane & 31, lh = lane >> 5;
     const int HW = g.H * g.W;
+    // staging roles: channel of the chunk, first patch row fetched (G / W), position half transformed (T)
+    const int sc = NW == 4 ? wave : wave >> 1;
+    const int srow = NW == 4 ? 0 : 2 * (wave & 1);
+    const int half = NW == 4 ? 0 : wave & 1;               // NW = 8: positions 8 * half .. + 7 = transform rows 2 * half, + 1
 
     unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
     const int kb = lb % g.nkb;
@@ -129,119 +142,103 @@ __global__ __launch_bounds__(256, 2) void k_wg_fwd(WgGeom g, const float *__rest
     const int64_t t0 = (int64_t)tb * WG_T;                  // first tile of the block
     const int n0 = (int)(t0 / g.tiles_img);                 // first image the block touches
 
-    // ---- G descriptors: tile `lane`, channel `wave` of the chunk ----
+    // ---- G descriptors: tile `lane`, channel `sc` of the chunk ----
     constexpr int kOutOfRange = (int)0x80000000;
-    int roff[4];                                            // byte offset of (row i, column 2 tx) or out of range (-> zeros)
-    int hoff;                                               // lanes 0-3: column 2 tx - 1 of tile t0 - 1's right neighbour ... see below
-    bool edge_l, edge_r;                                    // the tile touches the left / right image border: that halo column is 0
+    int roff[Cfg::NROW];                                    // byte offset of (row, column 2 tx), or out of range (-> zeros)
+    int hoff;
+    int lo, ro;                                             // raw-row float index of the patch's column 0 / 3 (a zero slot on the image border)
     {
         const int64_t tg = t0 + lane;
         const bool tv = tg < g.tiles_total;
         const int n = (int)(tg / g.tiles_img), r = (int)(tg % g.tiles_img);
         const int ty = r / g.tw, tx = r % g.tw;
-        const int cbase = ((n - n0) * g.C + wave) * HW;
+        const int cbase = ((n - n0) * g.C + sc) * HW;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gh = 2 * ty - 1 + i;
+        for (int i = 0; i < Cfg::NROW; ++i) {
+            const int gh = 2 * ty - 1 + srow + i;
             roff[i] = (tv && (unsigned)gh < (unsigned)g.H) ? (cbase + gh * g.W + 2 * tx) * 4 : kOutOfRange;
         }
-        edge_l = tx == 0, edge_r = tx == g.tw - 1;
+        lo = tx == 0 ? 0 : (lane + 1) * 2 - 1;
+        ro = tx == g.tw - 1 ? 65 * 2 + 1 : (lane + 1) * 2 + 2;
         // halo loads, one instruction: lanes 0-3 fetch row (lane) of the column LEFT of tile t0 (slot 0, element 1), lanes 4-7 row
-        // (lane - 4) of the column RIGHT of tile t0 + 63 (slot 65, element 0); unused when that tile sits on the image border
+        // (lane - 4) of the column RIGHT of tile t0 + 63 (slot 65, element 0); out of range when that tile sits on the image border
         const int side = (lane >> 2) & 1, hi = lane & 3;
         const int64_t th = side ? t0 + WG_T - 1 : t0;
         const int nh = (int)(th / g.tiles_img), rh = (int)(th % g.tiles_img);
         const int tyh = rh / g.tw, txh = rh % g.tw;
         const int ghh = 2 * tyh - 1 + hi, gwh = side ? 2 * txh + 2 : 2 * txh - 1;
         const bool okh = lane < 8 && th < g.tiles_total && (unsigned)ghh < (unsigned)g.H && (unsigned)gwh < (unsigned)g.W;
-        hoff = okh ? (((nh - n0) * g.C + wave) * HW + ghh * g.W + gwh) * 4 : kOutOfRange;
+        hoff = okh ? (((nh - n0) * g.C + sc) * HW + ghh * g.W + gwh) * 4 : kOutOfRange;
     }
+    const bool halo_wave = NW == 4 || (wave & 1) == 0;
     const int nimg_here = min(g.span, g.N - n0);
     const __amdgpu_buffer_rsrc_t srd_x =
         __builtin_amdgcn_make_buffer_rsrc((void *)(x + (int64_t)n0 * g.C * HW), 0, nimg_here * g.C * HW * 4, 0x00020000);
-    const float *ubase = up + (int64_t)kb * g.nch * WG_U + tid * 4;
+    const float *ubase = up + (int64_t)kb * g.nch * Cfg::U + tid * 4;
 
     struct Regs {
         f32x4 u[2];
-        i32x2 row[4];
+        i32x2 row[Cfg::NROW];
         float halo;
     };
     Regs rs[3];
     auto G = [&](int ch, Regs &r) {
-        r.u[0] = *reinterpret_cast<const f32x4 *>(ubase + (int64_t)ch * WG_U);
-        r.u[1] = *reinterpret_cast<const f32x4 *>(ubase + (int64_t)ch * WG_U + 1024);
+        r.u[0] = *reinterpret_cast<const f32x4 *>(ubase + (int64_t)ch * Cfg::U);
+        r.u[1] = *reinterpret_cast<const f32x4 *>(ubase + (int64_t)ch * Cfg::U + Cfg::NT * 4);
         const int soff = ch * WG_CK * HW * 4;
-#if WG_EXP != 1
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r.row[i] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[i], soff, 0);
-        r.halo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, hoff, soff, 0));
-#endif
+        for (int i = 0; i < Cfg::NROW; ++i) r.row[i] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[i], soff, 0);
+        if (halo_wave) r.halo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, hoff, soff, 0));
     };
-    // raw[c = wave][row][slot][2]: slot 0 = left halo, 1 + t = tile t, 65 = right halo
-    const int raw_w = WG_OFF_RAW + wave * WG_RAWC + (lane + 1) * 2;
-    const int halo_w = WG_OFF_RAW + wave * WG_RAWC + (lane & 3) * 132 + ((lane >> 2) & 1 ? 65 * 2 : 1);
+    // raw[c][row][slot][2]: slot 0 = left halo, 1 + t = tile t, 65 = right halo
+    const int raw_c = Cfg::OFF_RAW + sc * WG_RAWC;
+    const int raw_w = raw_c + srow * 132 + (lane + 1) * 2;
+    const int halo_w = raw_c + (lane & 3) * 132 + ((lane >> 2) & 1 ? 65 * 2 : 1);
     auto W = [&](int ch, int ustage, const Regs &r) {
-        float *us = smem + WG_OFF_U + ustage * WG_U;
+        float *us = smem + Cfg::OFF_U + ustage * Cfg::U;
         *reinterpret_cast<f32x4 *>(us + tid * 4) = r.u[0];
-        *reinterpret_cast<f32x4 *>(us + tid * 4 + 1024) = r.u[1];
-#if WG_EXP != 4 && WG_EXP != 1
+        *reinterpret_cast<f32x4 *>(us + tid * 4 + Cfg::NT * 4) = r.u[1];
         float *raw = smem + (ch & 1) * WG_RAW;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<i32x2 *>(raw + raw_w + i * 132) = r.row[i];
-        if (lane < 8) raw[halo_w] = r.halo;
-#endif
+        for (int i = 0; i < Cfg::NROW; ++i) *reinterpret_cast<i32x2 *>(raw + raw_w + i * 132) = r.row[i];
+        if (halo_wave && lane < 8) raw[halo_w] = r.halo;
     };
-    // T in pieces, so that the main loop can spread it between its MFMAs
-    auto T_read = [&](int ch, float (&d)[16]) {          // 4 x (own pair + the two neighbours' halves); no edge fix yet
-        const float *raw = smem + (ch & 1) * WG_RAW + raw_w;
-#if WG_EXP == 4
-        for (int e = 0; e < 16; ++e) d[e] = (float)(ch + e);
-        return;
-#endif
+    // T in pieces, so that the main loop can spread it between its MFMAs.  d holds patch rows half .. half + ND / 4 - 1.
+    const int t_row0 = raw_c + half * 132;
+    auto T_read = [&](int ch, float (&d)[Cfg::ND]) {
+        const float *raw = smem + (ch & 1) * WG_RAW + t_row0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x2 own = *reinterpret_cast<const f32x2 *>(raw + i * 132);
-            d[i * 4 + 0] = raw[i * 132 - 1];
+        for (int i = 0; i < Cfg::ND / 4; ++i) {
+            const f32x2 own = *reinterpret_cast<const f32x2 *>(raw + i * 132 + (lane + 1) * 2);
+            d[i * 4 + 0] = raw[i * 132 + lo];
             d[i * 4 + 1] = own[0];
             d[i * 4 + 2] = own[1];
-            d[i * 4 + 3] = raw[i * 132 + 2];
+            d[i * 4 + 3] = raw[i * 132 + ro];
         }
     };
-    auto T_edge = [&](float (&d)[16]) {
-#if WG_EXP == 3
-        return;
-#endif
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            d[i * 4 + 0] = edge_l ? 0.0f : d[i * 4 + 0];
-            d[i * 4 + 3] = edge_r ? 0.0f : d[i * 4 + 3];
-        }
-    };
-    // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: column pass in place (columns j0, j0 + 1) ...
-    auto T_col = [&](float (&d)[16], int j0) {
-#if WG_EXP == 3
-        return;
-#endif
+    // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: column pass of columns j0, j0 + 1, in place.  NW = 4: all four
+    // transform rows; NW = 8: rows 2 * half, 2 * half + 1 land in d[0..3], d[4..7]
+    auto T_col = [&](float (&d)[Cfg::ND], int j0) {
 #pragma unroll
         for (int j = j0; j < j0 + 2; ++j) {
-            const float d0 = d[0 * 4 + j], d1 = d[1 * 4 + j], d2 = d[2 * 4 + j], d3 = d[3 * 4 + j];
-            d[0 * 4 + j] = d0 - d2;
-            d[1 * 4 + j] = d1 + d2;
-            d[2 * 4 + j] = d2 - d1;
-            d[3 * 4 + j] = d1 - d3;
+            if (NW == 4) {
+                const float d0 = d[0 * 4 + j], d1 = d[1 * 4 + j], d2 = d[2 * 4 + j], d3 = d[3 * 4 + j];
+                d[0 * 4 + j] = d0 - d2;
+                d[1 * 4 + j] = d1 + d2;
+                d[2 * 4 + j] = d2 - d1;
+                d[3 * 4 + j] = d1 - d3;
+            } else {
+                const float e0 = d[0 * 4 + j], e1 = d[1 * 4 + j], e2 = d[2 * 4 + j];
+                // half 0 holds patch rows 0, 1, 2: rows 0, 1 of B^T d = d0 - d2, d1 + d2;  half 1 holds 1, 2, 3: rows 2, 3 = d2 - d1, d1 - d3
+                d[0 * 4 + j] = half ? e1 - e0 : e0 - e2;
+                d[1 * 4 + j] = half ? e0 - e2 : e1 + e2;
+            }
         }
     };
-    // ... row pass of rows i0, i0 + 1 and their 8 positions to V[p][c = wave][t = lane]
-    auto T_row = [&](int ch, const float (&t)[16], int i0) {
-        float *v = smem + (ch & 1) * WG_V + tid;
-#if WG_EXP == 2
-        if (t[0] + t[1] + t[2] + t[3] + t[4] + t[5] + t[6] + t[7] + t[8] + t[9] + t[10] + t[11] + t[12] + t[13] + t[14] + t[15] != 12345.f) return;
-#endif
-#if WG_EXP == 3
-        for (int i = i0; i < i0 + 2; ++i)
-            for (int j = 0; j < 4; ++j) v[(i * 4 + j) * (WG_T * WG_CK)] = t[i * 4 + j];
-        return;
-#endif
+    // ... row pass of transform rows i0, i0 + 1 (as stored in d) and their 8 positions to V[p][c][t]
+    const int v_w = (half * 8) * (WG_T * WG_CK) + sc * WG_T + lane;
+    auto T_row = [&](int ch, const float (&t)[Cfg::ND], int i0) {
+        float *v = smem + (ch & 1) * WG_V + v_w;
 #pragma unroll
         for (int i = i0; i < i0 + 2; ++i) {
             v[(i * 4 + 0) * (WG_T * WG_CK)] = t[i * 4 + 0] - t[i * 4 + 2];
@@ -252,14 +249,14 @@ __global__ __launch_bounds__(256, 2) void k_wg_fwd(WgGeom g, const float *__rest
     };
 
     // operand lane bases (floats): position p = ph * 8 + pp
-    const int a_base = WG_OFF_U + (ph * 8) * (WG_BK * WG_CK) + li * WG_CK + lh * 2;
+    const int a_base = Cfg::OFF_U + (ph * 8) * (BK * WG_CK) + (kq * 32 + li) * WG_CK + lh * 2;
     const int b_base = (ph * 8) * (WG_T * WG_CK) + (2 * lh) * WG_T + tq * 32 + li;
     struct Ops {
         f32x2 a;
         float b0, b1;
     };
     auto read_ops = [&](int it, int k, int pp, Ops &o) {
-        o.a = *reinterpret_cast<const f32x2 *>(smem + k * WG_U + a_base + pp * (WG_BK * WG_CK));
+        o.a = *reinterpret_cast<const f32x2 *>(smem + k * Cfg::U + a_base + pp * (BK * WG_CK));
         const float *vs = smem + (it & 1) * WG_V + b_base + pp * (WG_T * WG_CK);
         o.b0 = vs[0], o.b1 = vs[WG_T];
     };
@@ -270,10 +267,13 @@ __global__ __launch_bounds__(256, 2) void k_wg_fwd(WgGeom g, const float *__rest
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[pp][e] = 0.0f;
 
+    // zero slots of the raw rows (never written by W): slot 0 element 0, slot 65 element 1 -- 2 stages x 4 channels x 4 rows x 2
+    if (tid < 64) smem[Cfg::OFF_RAW + (tid >> 1) * 132 + (tid & 1 ? 65 * 2 + 1 : 0)] = 0.0f;
+
     const int last = g.nch - 1;
     auto clampc = [&](int c) { return min(c, last); };
-    float d[16];                       // the raw patch of T(it + 1), read before iteration `it` starts
-    Ops o0;                            // operands of M(it)'s first position, likewise
+    float d[Cfg::ND];                  // the raw patch of T(it + 1), read before iteration `it` starts
+    Ops o0, o1;                        // operands of M(it)'s first two positions, likewise
     G(0, rs[0]);
     G(clampc(1), rs[1]);
     G(clampc(2), rs[2]);
@@ -281,59 +281,55 @@ __global__ __launch_bounds__(256, 2) void k_wg_fwd(WgGeom g, const float *__rest
     G(clampc(3), rs[0]);
     __syncthreads();
     T_read(0, d);
-    T_edge(d);
     T_col(d, 0);
     T_col(d, 2);
     T_row(0, d, 0);
-    T_row(0, d, 2);
+    if (NW == 4) T_row(0, d, 2);
     W(1, 1, rs[1]);
     G(clampc(4), rs[1]);
     __syncthreads();
     T_read(1, d);
     read_ops(0, 0, 0, o0);
-    // Iteration `it` (k = it % 3 at compile time): M(it), T(it + 1), W(it + 2), G(it + 5), software-pipelined ACROSS the barrier:
-    // everything the other waves wait for (T's V writes, W) and every LDS read of this chunk's operands is done by position 4;
-    // positions 5-7 run from registers after the barrier while the wave issues G and already reads the next iteration's first
-    // operands and raw patch -- no LDS round trip is exposed at the chunk boundary.  sched_barrier fences keep this order.
+    read_ops(0, 0, 1, o1);
 #define WG_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define WG_MMA(pp, o)                                                                        \
     acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a[0], (o).b0, acc[pp], 0, 0, 0);      \
     acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a[1], (o).b1, acc[pp], 0, 0, 0)
-    auto iter = [&](int it, int k, Regs &r) {
-        Ops o1, o2, o3, o4, o5, o6, o7;
-        read_ops(it, k, 1, o1);
-        WG_MMA(0, o0);
-        T_edge(d);
-        WG_FENCE();
+    // (operands are read two positions = 256 MFMA cycles before their MFMAs)
+    auto iter = [&](int it, int k, Regs &r) {             // k = it % 3 (compile-time at the three call sites)
+        Ops o2, o3, o4, o5, o6, o7;
         read_ops(it, k, 2, o2);
-        WG_MMA(1, o1);
+        WG_MMA(0, o0);
         T_col(d, 0);
         WG_FENCE();
         read_ops(it, k, 3, o3);
-        WG_MMA(2, o2);
+        WG_MMA(1, o1);
         T_col(d, 2);
         WG_FENCE();
         read_ops(it, k, 4, o4);
-        WG_MMA(3, o3);
+        WG_MMA(2, o2);
         T_row(it + 1, d, 0);
         WG_FENCE();
         read_ops(it, k, 5, o5);
         read_ops(it, k, 6, o6);
         read_ops(it, k, 7, o7);
-        WG_MMA(4, o4);
-        T_row(it + 1, d, 2);
+        WG_MMA(3, o3);
+        if (NW == 4) T_row(it + 1, d, 2);
         W(it + 2, (k + 2) % 3, r);
         WG_FENCE();
         __syncthreads();
         WG_FENCE();
-        WG_MMA(5, o5);
+        WG_MMA(4, o4);
         G(clampc(it + 5), r);
         WG_FENCE();
-        WG_MMA(6, o6);
+        WG_MMA(5, o5);
         T_read(it + 2, d);
         WG_FENCE();
-        WG_MMA(7, o7);
+        WG_MMA(6, o6);
         read_ops(it + 1, (k + 1) % 3, 0, o0);
+        WG_FENCE();
+        WG_MMA(7, o7);
+        read_ops(it + 1, (k + 1) % 3, 1, o1);
         WG_FENCE();
     };
     for (int it = 0; it < g.nch; it += 3) {
@@ -362,17 +358,17 @@ __global__ __launch_bounds__(256, 2) void k_wg_fwd(WgGeom g, const float *__rest
             }
         }
     }
-    // (the main loop's last barrier freed the LDS) exchange buffer [tq][writer ph][b * 16 + e][lane]
+    // exchange buffer [wave][b * 16 + e][lane]; the partner of wave w is w ^ 2
     float *xch = smem;
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) xch[((tq * 2 + ph) * 32 + b * 16 + e) * 64 + lane] = give[b][e];
+        for (int e = 0; e < 16; ++e) xch[(wave * 32 + b * 16 + e) * 64 + lane] = give[b][e];
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) own[b][e] += xch[((tq * 2 + (ph ^ 1)) * 32 + b * 16 + e) * 64 + lane];
+        for (int e = 0; e < 16; ++e) own[b][e] += xch[((wave ^ 2) * 32 + b * 16 + e) * 64 + lane];
 
     const int64_t tg = t0 + tq * 32 + li;
     const bool tv = tg < g.tiles_total;
@@ -382,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void k_wg_fwd(WgGeom g, const float *__rest
     float s1[16], s2[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const int co = kb * WG_BK + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int co = kb * BK + kq * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         float v0 = own[0][e], v1 = own[1][e];
         if (bias != nullptr) {
             const float bv = bias[co < g.M ? co : 0];
@@ -412,20 +408,20 @@ __global__ __launch_bounds__(256, 2) void k_wg_fwd(WgGeom g, const float *__rest
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int cl = (e & 3) + 8 * (e >> 2) + 4 * lh;
-                red[(wave * WG_BK + cl) * 2 + 0] = s1[e];
-                red[(wave * WG_BK + cl) * 2 + 1] = s2[e];
+                red[(wave * 32 + cl) * 2 + 0] = s1[e];
+                red[(wave * 32 + cl) * 2 + 1] = s2[e];
             }
         }
         __syncthreads();
-        if (tid < WG_BK && kb * WG_BK + tid < g.M) {
+        if (tid < BK && kb * BK + tid < g.M) {  // channel tid: waves kq = tid / 32, (tq, ph) = 0..3
             float a = 0.0f, b = 0.0f;
 #pragma unroll
             for (int w2 = 0; w2 < 4; ++w2) {
-                a += red[(w2 * WG_BK + tid) * 2 + 0];
-                b += red[(w2 * WG_BK + tid) * 2 + 1];
+                a += red[(((tid >> 5) * 4 + w2) * 32 + (tid & 31)) * 2 + 0];
+                b += red[(((tid >> 5) * 4 + w2) * 32 + (tid & 31)) * 2 + 1];
             }
             const unsigned ntb = gridDim.x / g.nkb;
-            float *dst = stats + ((int64_t)(kb * WG_BK + tid) * ntb + tb) * 2;
+            float *dst = stats + ((int64_t)(kb * BK + tid) * ntb + tb) * 2;
             dst[0] = a;
             dst[1] = b;
         }
@@ -433,6 +429,28 @@ __global__ __launch_bounds__(256, 2) void k_wg_fwd(WgGeom g, const float *__rest
 }
 
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+// waves per block for a launch.  The 8-wave / 64-channel block does half the staging work per MFMA, but its eight waves run in
+// lock step behind one barrier and it measured 3-4 % SLOWER than two independent 4-wave blocks per CU on every VGG16 layer
+// (DESIGN.md section 4.9), so it is only reachable through CPG_WINO_NW=8 (A/B experiments, tests).
+inline int wino_nw(int c_read, int m) {
+    if (const char *f = getenv("CPG_WINO_NW")) return atoi(f) == 8 ? 8 : 4;
+    return 4;
+}
+
+template <int NW>
+int wino_launch(bool dgrad, const WgGeom &g, int64_t tblocks, const float *x, const float *up, const float *bias, float *y, float *stats,
+                hipStream_t stream) {
+    const int64_t blocks = tblocks * g.nkb;
+    if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "conv3x3 (winograd): grid too large");
+    if (dgrad)
+        hipLaunchKernelGGL((k_wg_fwd<NW, true, false>), dim3((unsigned)blocks), dim3(64 * NW), 0, stream, g, x, up, bias, y, nullptr);
+    else if (stats != nullptr)
+        hipLaunchKernelGGL((k_wg_fwd<NW, false, true>), dim3((unsigned)blocks), dim3(64 * NW), 0, stream, g, x, up, bias, y, stats);
+    else
+        hipLaunchKernelGGL((k_wg_fwd<NW, false, false>), dim3((unsigned)blocks), dim3(64 * NW), 0, stream, g, x, up, bias, y, nullptr);
+    return CPG_OK;
+}
 
 }  // namespace
 
@@ -447,8 +465,8 @@ extern "C" int cpg_conv3x3_wino_ok(int N, int c_read, int m, int H, int W) {
     return (int64_t)span * c_read * H * W * 4 < (1ll << 31);
 }
 
-extern "C" size_t cpg_conv3x3_wino_pack_bytes(int c_read, int m) {
-    return (size_t)pad_to(m, WG_BK) / WG_BK * (pad_to(c_read, WG_CK) / WG_CK) * WG_U * sizeof(float);
+extern "C" size_t cpg_conv3x3_wino_pack_bytes(int c_read, int m) {      // (the 64-channel blocking pads m further: covers both)
+    return (size_t)pad_to(m, 64) * pad_to(c_read, WG_CK) * 16 * sizeof(float);
 }
 
 extern "C" int cpg_conv3x3_wino_tiles(int N, int H, int W) {
@@ -464,23 +482,20 @@ extern "C" int cpg_conv3x3_wino_run(int dgrad, int N, int c_read, int m, int H, 
     const size_t need = cpg_conv3x3_wino_pack_bytes(c_read, m);
     if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
     CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
+    const int nw = wino_nw(c_read, m), BK = 8 * nw;
     WgGeom g;
     g.N = N, g.C = c_read, g.H = H, g.W = W, g.M = m;
     g.th = H / 2, g.tw = W / 2, g.tiles_img = g.th * g.tw;
     g.tiles_total = (int64_t)N * g.tiles_img;
-    g.nkb = pad_to(m, WG_BK) / WG_BK, g.nch = pad_to(c_read, WG_CK) / WG_CK;
+    g.nkb = pad_to(m, BK) / BK, g.nch = pad_to(c_read, WG_CK) / WG_CK;
     g.span = (WG_T + g.tiles_img - 1) / g.tiles_img + 1;
     float *up = (float *)ws;
-    hipLaunchKernelGGL(k_wg_pack, dim3(stream_grid((int64_t)g.nkb * g.nch * WG_BK * WG_CK, 256)), dim3(256), 0, stream, w, pm, thr, up,
-                       K, C, m, c_read, g.nch, dgrad ? 1 : 0);
-    const int64_t blocks = (int64_t)cpg_conv3x3_wino_tiles(N, H, W) * g.nkb;
-    if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "%s: grid too large", what);
-    if (dgrad)
-        hipLaunchKernelGGL((k_wg_fwd<true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, up, bias, y, nullptr);
-    else if (stats != nullptr)
-        hipLaunchKernelGGL((k_wg_fwd<false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, up, bias, y, stats);
-    else
-        hipLaunchKernelGGL((k_wg_fwd<false, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, up, bias, y, nullptr);
+    hipLaunchKernelGGL(k_wg_pack, dim3(stream_grid((int64_t)g.nkb * g.nch * BK * WG_CK, 256)), dim3(256), 0, stream, w, pm, thr, up,
+                       K, C, m, c_read, g.nch, dgrad ? 1 : 0, BK);
+    const int64_t tblocks = cpg_conv3x3_wino_tiles(N, H, W);
+    const int rc = nw == 8 ? wino_launch<8>(dgrad != 0, g, tblocks, x, up, bias, y, stats, stream)
+                           : wino_launch<4>(dgrad != 0, g, tblocks, x, up, bias, y, stats, stream);
+    if (rc != CPG_OK) return rc;
     CPG_CHECK_LAUNCH(what);
     return CPG_OK;
 }

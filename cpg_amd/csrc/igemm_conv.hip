@@ -658,6 +658,13 @@ extern "C" int cpg_conv2d_fwd_bnstats(const cpg_conv_desc *d, const float *x, co
     return cpg_conv3x3_fwd_bnstats(d, x, w, pm, thr, bias, y, stats, ws, ws_bytes, (hipStream_t)stream);
 }
 
+extern "C" int cpg_conv3x3_wino_ok(int N, int c_read, int m, int H, int W);
+extern "C" int32_t cpg_conv2d_winograd(const cpg_conv_desc *d, int32_t dgrad) {
+    ConvGeom g;
+    if (d == nullptr || make_geom(d, g) != CPG_OK || !cpg_conv3x3_supported(d)) return 0;
+    return dgrad ? cpg_conv3x3_wino_ok(d->N, d->K, d->C, d->H, d->W) : cpg_conv3x3_wino_ok(d->N, d->C, d->K, d->H, d->W);
+}
+
 // conv -> eval-mode BatchNorm2d (-> ReLU) in one kernel; 0 from the _supported query: use cpg_conv2d_fwd + cpg_bn_relu_fwd_eval
 extern "C" int32_t cpg_conv2d_fwd_bn_eval_supported(const cpg_conv_desc *d) {
     ConvGeom g;
