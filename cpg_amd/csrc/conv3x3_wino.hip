@@ -194,19 +194,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_wg_fwd(WgGeom g, c
     const int raw_c = Cfg::OFF_RAW + sc * WG_RAWC;
     const int raw_w = raw_c + srow * 132 + (lane + 1) * 2;
     const int halo_w = raw_c + (lane & 3) * 132 + ((lane >> 2) & 1 ? 65 * 2 : 1);
-    auto W = [&](int ch, int ustage, const Regs &r) {
+    // (stage indices are compile-time constants at every call site of the 6-fold unrolled main loop: LDS addresses are a
+    //  per-thread base register + an immediate)
+    auto W = [&](int rstage, int ustage, const Regs &r) {
         float *us = smem + Cfg::OFF_U + ustage * Cfg::U;
         *reinterpret_cast<f32x4 *>(us + tid * 4) = r.u[0];
         *reinterpret_cast<f32x4 *>(us + tid * 4 + Cfg::NT * 4) = r.u[1];
-        float *raw = smem + (ch & 1) * WG_RAW;
+        float *raw = smem + rstage * WG_RAW;
 #pragma unroll
         for (int i = 0; i < Cfg::NROW; ++i) *reinterpret_cast<i32x2 *>(raw + raw_w + i * 132) = r.row[i];
         if (halo_wave && lane < 8) raw[halo_w] = r.halo;
     };
     // T in pieces, so that the main loop can spread it between its MFMAs.  d holds patch rows half .. half + ND / 4 - 1.
     const int t_row0 = raw_c + half * 132;
-    auto T_read = [&](int ch, float (&d)[Cfg::ND]) {
-        const float *raw = smem + (ch & 1) * WG_RAW + t_row0;
+    auto T_read = [&](int rstage, float (&d)[Cfg::ND]) {
+        const float *raw = smem + rstage * WG_RAW + t_row0;
 #pragma unroll
         for (int i = 0; i < Cfg::ND / 4; ++i) {
             const f32x2 own = *reinterpret_cast<const f32x2 *>(raw + i * 132 + (lane + 1) * 2);
@@ -217,7 +219,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_wg_fwd(WgGeom g, c
         }
     };
     // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: column pass of columns j0, j0 + 1, in place.  NW = 4: all four
-    // transform rows; NW = 8: rows 2 * half, 2 * half + 1 land in d[0..3], d[4..7]
+    // transform rows; NW = 8: rows 2 * half, 2 * half + 1 land in d[0..3], d[4..7].  (Written on register pairs to get packed
+    // v_pk_add_f32 the compiler spent more v_mov on forming the pairs than it saved: 110 VALU per chunk instead of 45.)
     auto T_col = [&](float (&d)[Cfg::ND], int j0) {
 #pragma unroll
         for (int j = j0; j < j0 + 2; ++j) {
@@ -237,8 +240,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_wg_fwd(WgGeom g, c
     };
     // ... row pass of transform rows i0, i0 + 1 (as stored in d) and their 8 positions to V[p][c][t]
     const int v_w = (half * 8) * (WG_T * WG_CK) + sc * WG_T + lane;
-    auto T_row = [&](int ch, const float (&t)[Cfg::ND], int i0) {
-        float *v = smem + (ch & 1) * WG_V + v_w;
+    auto T_row = [&](int vstage, const float (&t)[Cfg::ND], int i0) {
+        float *v = smem + vstage * WG_V + v_w;
 #pragma unroll
         for (int i = i0; i < i0 + 2; ++i) {
             v[(i * 4 + 0) * (WG_T * WG_CK)] = t[i * 4 + 0] - t[i * 4 + 2];
@@ -255,9 +258,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_wg_fwd(WgGeom g, c
         f32x2 a;
         float b0, b1;
     };
-    auto read_ops = [&](int it, int k, int pp, Ops &o) {
+    auto read_ops = [&](int vstage, int k, int pp, Ops &o) {
         o.a = *reinterpret_cast<const f32x2 *>(smem + k * Cfg::U + a_base + pp * (BK * WG_CK));
-        const float *vs = smem + (it & 1) * WG_V + b_base + pp * (WG_T * WG_CK);
+        const float *vs = smem + vstage * WG_V + b_base + pp * (WG_T * WG_CK);
         o.b0 = vs[0], o.b1 = vs[WG_T];
     };
 
@@ -295,27 +298,28 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_wg_fwd(WgGeom g, c
 #define WG_MMA(pp, o)                                                                        \
     acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a[0], (o).b0, acc[pp], 0, 0, 0);      \
     acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32((o).a[1], (o).b1, acc[pp], 0, 0, 0)
+    // iteration `it`: k = it % 3 (U stage, register set), p = it & 1 (V / raw stage) -- constants at the six call sites.
     // (operands are read two positions = 256 MFMA cycles before their MFMAs)
-    auto iter = [&](int it, int k, Regs &r) {             // k = it % 3 (compile-time at the three call sites)
+    auto iter = [&](int it, int k, int p, Regs &r) {
         Ops o2, o3, o4, o5, o6, o7;
-        read_ops(it, k, 2, o2);
+        read_ops(p, k, 2, o2);
         WG_MMA(0, o0);
         T_col(d, 0);
         WG_FENCE();
-        read_ops(it, k, 3, o3);
+        read_ops(p, k, 3, o3);
         WG_MMA(1, o1);
         T_col(d, 2);
         WG_FENCE();
-        read_ops(it, k, 4, o4);
+        read_ops(p, k, 4, o4);
         WG_MMA(2, o2);
-        T_row(it + 1, d, 0);
+        T_row(p ^ 1, d, 0);                                // T(it + 1) -> V stage of it + 1
         WG_FENCE();
-        read_ops(it, k, 5, o5);
-        read_ops(it, k, 6, o6);
-        read_ops(it, k, 7, o7);
+        read_ops(p, k, 5, o5);
+        read_ops(p, k, 6, o6);
+        read_ops(p, k, 7, o7);
         WG_MMA(3, o3);
-        if (NW == 4) T_row(it + 1, d, 2);
-        W(it + 2, (k + 2) % 3, r);
+        if (NW == 4) T_row(p ^ 1, d, 2);
+        W(p, (k + 2) % 3, r);                              // W(it + 2) -> raw stage of it + 2, U stage (it + 2) % 3
         WG_FENCE();
         __syncthreads();
         WG_FENCE();
@@ -323,19 +327,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_wg_fwd(WgGeom g, c
         G(clampc(it + 5), r);
         WG_FENCE();
         WG_MMA(5, o5);
-        T_read(it + 2, d);
+        T_read(p, d);                                      // raw patch of T(it + 2)
         WG_FENCE();
         WG_MMA(6, o6);
-        read_ops(it + 1, (k + 1) % 3, 0, o0);
+        read_ops(p ^ 1, (k + 1) % 3, 0, o0);
         WG_FENCE();
         WG_MMA(7, o7);
-        read_ops(it + 1, (k + 1) % 3, 1, o1);
+        read_ops(p ^ 1, (k + 1) % 3, 1, o1);
         WG_FENCE();
     };
-    for (int it = 0; it < g.nch; it += 3) {
-        iter(it, 0, rs[2]);
-        if (it + 1 < g.nch) iter(it + 1, 1, rs[0]);
-        if (it + 2 < g.nch) iter(it + 2, 2, rs[1]);
+    for (int it = 0; it < g.nch; it += 6) {
+        iter(it, 0, 0, rs[2]);
+        if (it + 1 < g.nch) iter(it + 1, 1, 1, rs[0]);
+        if (it + 2 < g.nch) iter(it + 2, 2, 0, rs[1]);
+        if (it + 3 < g.nch) iter(it + 3, 0, 1, rs[2]);
+        if (it + 4 < g.nch) iter(it + 4, 1, 0, rs[0]);
+        if (it + 5 < g.nch) iter(it + 5, 2, 1, rs[1]);
     }
     __syncthreads();                   // (the trailing prefetch reads are done before the epilogue reuses the LDS)
 
