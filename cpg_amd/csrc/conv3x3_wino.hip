@@ -435,6 +435,361 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_wg_fwd(WgGeom g, c
     }
 }
 
+// ------------------------------------------------------------------------------ one wave = one unit ("k_wg1")
+// A wave computes 32 output channels x 32 tiles for ALL 16 positions by itself: 256 accumulator registers (one wave per SIMD, the
+// whole 512-entry register file), no cooperation between waves, hence NO barrier and no V / U staging through LDS:
+//   * lane (li, lh) transforms the patches of tile li for channels 2 lh, 2 lh + 1 of the chunk -- and those 2 x 16 values ARE
+//     its B operands (lanes 0-31 feed k = channel 0 / 1, lanes 32-63 channel 2 / 3 of the two MFMAs of a position);
+//   * the A operands come straight from global memory in per-lane order: Up1[k block][chunk][q][lane][4] (positions 2q, 2q + 1 x
+//     channels 2 lh, 2 lh + 1 of output channel li), 8 float4 per lane and chunk, L1 / L2 resident (the four waves of a block
+//     share the k block);
+//   * only the raw patch rows go through LDS, inside the wave (no synchronisation: a wave's LDS operations complete in order):
+//     8 buffer_load_dwordx2 (4 rows x 2 channels, lane = aligned column pair of its tile) + 1 dword load for the 32 halo values,
+//     written to raw[c][row][slot][2], read back with the neighbours' halves.
+// Per chunk and wave: 32 MFMAs against 17 vector-memory, 25 LDS and ~70 vector-ALU instructions (the 4-wave block: 16 MFMAs
+// against 7 + 33 + 50) -- and nothing to wait for at a barrier.
+constexpr int W1_T = 32;                                  // tiles per wave
+constexpr int W1_ROW = (W1_T + 2) * 2;                    // floats of a raw row: slot 0 = left halo, 1 + t, 33 = right halo
+constexpr int W1_RAW = 4 * 4 * W1_ROW;                    // one stage: [channel][row][slot][2] = 1088 floats
+constexpr int W1_U = 16 * 32 * WG_CK;                     // floats of U per (k block, chunk)
+
+// U in per-lane order (see above); rec = kb * nch + ch
+__global__ __launch_bounds__(256) void k_wg1_pack(const float *__restrict__ w, const float *__restrict__ pm, float thr,
+                                                  float *__restrict__ up, int K, int C, int M, int Cin, int nch, int dgrad) {
+    const int64_t total = (int64_t)((M + 31) / 32) * nch * 32 * WG_CK;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int cl = (int)(o % WG_CK);
+        const int kl = (int)((o / WG_CK) % 32);
+        const int64_t rec = o / (WG_CK * 32);
+        const int ch = (int)(rec % nch), kb = (int)(rec / nch);
+        const int m = kb * 32 + kl, c = ch * WG_CK + cl;
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) g[r][s] = 0.0f;
+        if (m < M && c < Cin) {
+            const int co = dgrad ? c : m, ci = dgrad ? m : c;
+            const int64_t off = ((int64_t)co * C + ci) * 9;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int tap = dgrad ? 8 - (r * 3 + s) : r * 3 + s;
+                    float v = w[off + tap];
+                    if (pm != nullptr) v *= binarize(pm[off + tap], thr);
+                    g[r][s] = v;
+                }
+        }
+        float t[4][3], u[16];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            t[0][s] = g[0][s];
+            t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+            t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+            t[3][s] = g[2][s];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u[i * 4 + 0] = t[i][0];
+            u[i * 4 + 1] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+            u[i * 4 + 2] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+            u[i * 4 + 3] = t[i][2];
+        }
+        // lane = (lh = cl / 2) * 32 + kl; float (p & 1) * 2 + (cl & 1) of float4 q = p / 2
+        float *dst = up + rec * W1_U + ((cl >> 1) * 32 + kl) * 4 + (cl & 1);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) dst[(p >> 1) * 256 + (p & 1) * 2] = u[p];
+    }
+}
+
+template <bool DGRAD, bool STATS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
+           float *__restrict__ y, float *__restrict__ stats) {
+    __shared__ __attribute__((aligned(16))) float smem_all[4 * 2 * W1_RAW];
+    // (readfirstlane: tells the compiler the wave index is wave-uniform, so that everything derived from it -- the tile run, the
+    //  buffer descriptor of its first image -- lives in scalar registers; without it every buffer load became a waterfall loop)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int HW = g.H * g.W;
+    float *smem = smem_all + wave * 2 * W1_RAW;               // this wave's private raw stages
+
+    unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int kb = lb % g.nkb;
+    const int64_t run = (int64_t)(lb / g.nkb) * 4 + wave;     // tile run of 32
+    const int64_t t0 = run * W1_T;
+    if (t0 >= g.tiles_total) return;                          // (no barriers anywhere: a wave may leave)
+    const int n0 = (int)(t0 / g.tiles_img);
+
+    constexpr int kOutOfRange = (int)0x80000000;
+    int roff[4], hoff, lo, ro;
+    {
+        const int64_t tg = t0 + li;
+        const bool tv = tg < g.tiles_total;
+        const int n = (int)(tg / g.tiles_img), r = (int)(tg % g.tiles_img);
+        const int ty = r / g.tw, tx = r % g.tw;
+        const int cbase = ((n - n0) * g.C + 2 * lh) * HW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gh = 2 * ty - 1 + i;
+            roff[i] = (tv && (unsigned)gh < (unsigned)g.H) ? (cbase + gh * g.W + 2 * tx) * 4 : kOutOfRange;
+        }
+        lo = tx == 0 ? 0 : (li + 1) * 2 - 1;
+        ro = tx == g.tw - 1 ? (W1_T + 1) * 2 + 1 : (li + 1) * 2 + 2;
+        // halo: lanes 0-31 = (side, row, channel): the column left of tile t0 / right of tile t0 + 31
+        const int side = (lane >> 4) & 1, hi = (lane >> 2) & 3, hc = lane & 3;
+        const int64_t th = side ? t0 + W1_T - 1 : t0;
+        const int nh = (int)(th / g.tiles_img), rh = (int)(th % g.tiles_img);
+        const int tyh = rh / g.tw, txh = rh % g.tw;
+        const int ghh = 2 * tyh - 1 + hi, gwh = side ? 2 * txh + 2 : 2 * txh - 1;
+        const bool okh = lane < 32 && th < g.tiles_total && (unsigned)ghh < (unsigned)g.H && (unsigned)gwh < (unsigned)g.W;
+        hoff = okh ? (((nh - n0) * g.C + hc) * HW + ghh * g.W + gwh) * 4 : kOutOfRange;
+    }
+    const int span = (W1_T + g.tiles_img - 1) / g.tiles_img + 1;
+    const int nimg_here = min(span, g.N - n0);
+    const __amdgpu_buffer_rsrc_t srd_x =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(x + (int64_t)n0 * g.C * HW), 0, nimg_here * g.C * HW * 4, 0x00020000);
+    const float *ubase = up + (int64_t)kb * g.nch * W1_U + lane * 4;
+
+    // raw[c][row][slot][2] offsets of this lane (channels 2 lh + j)
+    const int raw_own = (2 * lh) * 4 * W1_ROW + (li + 1) * 2;
+    const int halo_w = ((lane & 3) * 4 + ((lane >> 2) & 3)) * W1_ROW + (((lane >> 4) & 1) ? (W1_T + 1) * 2 : 1);
+    // zero slots (never written): slot 0 element 0, slot 33 element 1 of the 2 x 16 rows
+    if (lane < 32) {
+        smem[lane * W1_ROW] = 0.0f;
+        smem[lane * W1_ROW + (W1_T + 1) * 2 + 1] = 0.0f;
+    }
+
+    struct Rows {
+        i32x2 r[2][4];
+        float halo;
+    };
+    auto G_rows = [&](int ch, Rows &q) {
+        const int soff = ch * WG_CK * HW * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q.r[j][i] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[i], soff + j * HW * 4, 0);
+        q.halo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, hoff, soff, 0));
+    };
+    auto W_rows = [&](int stage, const Rows &q) {
+        float *raw = smem + stage * W1_RAW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<i32x2 *>(raw + raw_own + (j * 4 + i) * W1_ROW) = q.r[j][i];
+        if (lane < 32) raw[halo_w] = q.halo;
+    };
+    auto G_u = [&](int ch, f32x4 (&u)[8]) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u[q] = *reinterpret_cast<const f32x4 *>(ubase + (int64_t)ch * W1_U + q * 256);
+    };
+    // patch of (tile li, channel 2 lh + j) -> the 16 transform-domain values, in place
+    auto T_read = [&](int stage, int j, float (&d)[16]) {
+        const float *raw = smem + stage * W1_RAW + (2 * lh + j) * 4 * W1_ROW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 own = *reinterpret_cast<const f32x2 *>(raw + i * W1_ROW + (li + 1) * 2);
+            d[i * 4 + 0] = raw[i * W1_ROW + lo];
+            d[i * 4 + 1] = own[0];
+            d[i * 4 + 2] = own[1];
+            d[i * 4 + 3] = raw[i * W1_ROW + ro];
+        }
+    };
+    auto T_col = [&](float (&d)[16], int j0) {
+#pragma unroll
+        for (int j = j0; j < j0 + 2; ++j) {
+            const float d0 = d[0 * 4 + j], d1 = d[1 * 4 + j], d2 = d[2 * 4 + j], d3 = d[3 * 4 + j];
+            d[0 * 4 + j] = d0 - d2;
+            d[1 * 4 + j] = d1 + d2;
+            d[2 * 4 + j] = d2 - d1;
+            d[3 * 4 + j] = d1 - d3;
+        }
+    };
+    auto T_rowp = [&](float (&d)[16], int i) {
+        const float t0_ = d[i * 4 + 0], t1 = d[i * 4 + 1], t2 = d[i * 4 + 2], t3 = d[i * 4 + 3];
+        d[i * 4 + 0] = t0_ - t2;
+        d[i * 4 + 1] = t1 + t2;
+        d[i * 4 + 2] = t2 - t1;
+        d[i * 4 + 3] = t1 - t3;
+    };
+
+    asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0" : : : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
+    asm volatile("v_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0" : : : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
+    asm volatile("v_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0" : : : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    asm volatile("v_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0" : : : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
+    asm volatile("v_accvgpr_write_b32 a64, 0\n\tv_accvgpr_write_b32 a65, 0\n\tv_accvgpr_write_b32 a66, 0\n\tv_accvgpr_write_b32 a67, 0\n\tv_accvgpr_write_b32 a68, 0\n\tv_accvgpr_write_b32 a69, 0\n\tv_accvgpr_write_b32 a70, 0\n\tv_accvgpr_write_b32 a71, 0\n\tv_accvgpr_write_b32 a72, 0\n\tv_accvgpr_write_b32 a73, 0\n\tv_accvgpr_write_b32 a74, 0\n\tv_accvgpr_write_b32 a75, 0\n\tv_accvgpr_write_b32 a76, 0\n\tv_accvgpr_write_b32 a77, 0\n\tv_accvgpr_write_b32 a78, 0\n\tv_accvgpr_write_b32 a79, 0" : : : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
+    asm volatile("v_accvgpr_write_b32 a80, 0\n\tv_accvgpr_write_b32 a81, 0\n\tv_accvgpr_write_b32 a82, 0\n\tv_accvgpr_write_b32 a83, 0\n\tv_accvgpr_write_b32 a84, 0\n\tv_accvgpr_write_b32 a85, 0\n\tv_accvgpr_write_b32 a86, 0\n\tv_accvgpr_write_b32 a87, 0\n\tv_accvgpr_write_b32 a88, 0\n\tv_accvgpr_write_b32 a89, 0\n\tv_accvgpr_write_b32 a90, 0\n\tv_accvgpr_write_b32 a91, 0\n\tv_accvgpr_write_b32 a92, 0\n\tv_accvgpr_write_b32 a93, 0\n\tv_accvgpr_write_b32 a94, 0\n\tv_accvgpr_write_b32 a95, 0" : : : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
+    asm volatile("v_accvgpr_write_b32 a96, 0\n\tv_accvgpr_write_b32 a97, 0\n\tv_accvgpr_write_b32 a98, 0\n\tv_accvgpr_write_b32 a99, 0\n\tv_accvgpr_write_b32 a100, 0\n\tv_accvgpr_write_b32 a101, 0\n\tv_accvgpr_write_b32 a102, 0\n\tv_accvgpr_write_b32 a103, 0\n\tv_accvgpr_write_b32 a104, 0\n\tv_accvgpr_write_b32 a105, 0\n\tv_accvgpr_write_b32 a106, 0\n\tv_accvgpr_write_b32 a107, 0\n\tv_accvgpr_write_b32 a108, 0\n\tv_accvgpr_write_b32 a109, 0\n\tv_accvgpr_write_b32 a110, 0\n\tv_accvgpr_write_b32 a111, 0" : : : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
+    asm volatile("v_accvgpr_write_b32 a112, 0\n\tv_accvgpr_write_b32 a113, 0\n\tv_accvgpr_write_b32 a114, 0\n\tv_accvgpr_write_b32 a115, 0\n\tv_accvgpr_write_b32 a116, 0\n\tv_accvgpr_write_b32 a117, 0\n\tv_accvgpr_write_b32 a118, 0\n\tv_accvgpr_write_b32 a119, 0\n\tv_accvgpr_write_b32 a120, 0\n\tv_accvgpr_write_b32 a121, 0\n\tv_accvgpr_write_b32 a122, 0\n\tv_accvgpr_write_b32 a123, 0\n\tv_accvgpr_write_b32 a124, 0\n\tv_accvgpr_write_b32 a125, 0\n\tv_accvgpr_write_b32 a126, 0\n\tv_accvgpr_write_b32 a127, 0" : : : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
+    asm volatile("v_accvgpr_write_b32 a128, 0\n\tv_accvgpr_write_b32 a129, 0\n\tv_accvgpr_write_b32 a130, 0\n\tv_accvgpr_write_b32 a131, 0\n\tv_accvgpr_write_b32 a132, 0\n\tv_accvgpr_write_b32 a133, 0\n\tv_accvgpr_write_b32 a134, 0\n\tv_accvgpr_write_b32 a135, 0\n\tv_accvgpr_write_b32 a136, 0\n\tv_accvgpr_write_b32 a137, 0\n\tv_accvgpr_write_b32 a138, 0\n\tv_accvgpr_write_b32 a139, 0\n\tv_accvgpr_write_b32 a140, 0\n\tv_accvgpr_write_b32 a141, 0\n\tv_accvgpr_write_b32 a142, 0\n\tv_accvgpr_write_b32 a143, 0" : : : "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143");
+    asm volatile("v_accvgpr_write_b32 a144, 0\n\tv_accvgpr_write_b32 a145, 0\n\tv_accvgpr_write_b32 a146, 0\n\tv_accvgpr_write_b32 a147, 0\n\tv_accvgpr_write_b32 a148, 0\n\tv_accvgpr_write_b32 a149, 0\n\tv_accvgpr_write_b32 a150, 0\n\tv_accvgpr_write_b32 a151, 0\n\tv_accvgpr_write_b32 a152, 0\n\tv_accvgpr_write_b32 a153, 0\n\tv_accvgpr_write_b32 a154, 0\n\tv_accvgpr_write_b32 a155, 0\n\tv_accvgpr_write_b32 a156, 0\n\tv_accvgpr_write_b32 a157, 0\n\tv_accvgpr_write_b32 a158, 0\n\tv_accvgpr_write_b32 a159, 0" : : : "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159");
+    asm volatile("v_accvgpr_write_b32 a160, 0\n\tv_accvgpr_write_b32 a161, 0\n\tv_accvgpr_write_b32 a162, 0\n\tv_accvgpr_write_b32 a163, 0\n\tv_accvgpr_write_b32 a164, 0\n\tv_accvgpr_write_b32 a165, 0\n\tv_accvgpr_write_b32 a166, 0\n\tv_accvgpr_write_b32 a167, 0\n\tv_accvgpr_write_b32 a168, 0\n\tv_accvgpr_write_b32 a169, 0\n\tv_accvgpr_write_b32 a170, 0\n\tv_accvgpr_write_b32 a171, 0\n\tv_accvgpr_write_b32 a172, 0\n\tv_accvgpr_write_b32 a173, 0\n\tv_accvgpr_write_b32 a174, 0\n\tv_accvgpr_write_b32 a175, 0" : : : "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175");
+    asm volatile("v_accvgpr_write_b32 a176, 0\n\tv_accvgpr_write_b32 a177, 0\n\tv_accvgpr_write_b32 a178, 0\n\tv_accvgpr_write_b32 a179, 0\n\tv_accvgpr_write_b32 a180, 0\n\tv_accvgpr_write_b32 a181, 0\n\tv_accvgpr_write_b32 a182, 0\n\tv_accvgpr_write_b32 a183, 0\n\tv_accvgpr_write_b32 a184, 0\n\tv_accvgpr_write_b32 a185, 0\n\tv_accvgpr_write_b32 a186, 0\n\tv_accvgpr_write_b32 a187, 0\n\tv_accvgpr_write_b32 a188, 0\n\tv_accvgpr_write_b32 a189, 0\n\tv_accvgpr_write_b32 a190, 0\n\tv_accvgpr_write_b32 a191, 0" : : : "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191");
+    asm volatile("v_accvgpr_write_b32 a192, 0\n\tv_accvgpr_write_b32 a193, 0\n\tv_accvgpr_write_b32 a194, 0\n\tv_accvgpr_write_b32 a195, 0\n\tv_accvgpr_write_b32 a196, 0\n\tv_accvgpr_write_b32 a197, 0\n\tv_accvgpr_write_b32 a198, 0\n\tv_accvgpr_write_b32 a199, 0\n\tv_accvgpr_write_b32 a200, 0\n\tv_accvgpr_write_b32 a201, 0\n\tv_accvgpr_write_b32 a202, 0\n\tv_accvgpr_write_b32 a203, 0\n\tv_accvgpr_write_b32 a204, 0\n\tv_accvgpr_write_b32 a205, 0\n\tv_accvgpr_write_b32 a206, 0\n\tv_accvgpr_write_b32 a207, 0" : : : "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207");
+    asm volatile("v_accvgpr_write_b32 a208, 0\n\tv_accvgpr_write_b32 a209, 0\n\tv_accvgpr_write_b32 a210, 0\n\tv_accvgpr_write_b32 a211, 0\n\tv_accvgpr_write_b32 a212, 0\n\tv_accvgpr_write_b32 a213, 0\n\tv_accvgpr_write_b32 a214, 0\n\tv_accvgpr_write_b32 a215, 0\n\tv_accvgpr_write_b32 a216, 0\n\tv_accvgpr_write_b32 a217, 0\n\tv_accvgpr_write_b32 a218, 0\n\tv_accvgpr_write_b32 a219, 0\n\tv_accvgpr_write_b32 a220, 0\n\tv_accvgpr_write_b32 a221, 0\n\tv_accvgpr_write_b32 a222, 0\n\tv_accvgpr_write_b32 a223, 0" : : : "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223");
+    asm volatile("v_accvgpr_write_b32 a224, 0\n\tv_accvgpr_write_b32 a225, 0\n\tv_accvgpr_write_b32 a226, 0\n\tv_accvgpr_write_b32 a227, 0\n\tv_accvgpr_write_b32 a228, 0\n\tv_accvgpr_write_b32 a229, 0\n\tv_accvgpr_write_b32 a230, 0\n\tv_accvgpr_write_b32 a231, 0\n\tv_accvgpr_write_b32 a232, 0\n\tv_accvgpr_write_b32 a233, 0\n\tv_accvgpr_write_b32 a234, 0\n\tv_accvgpr_write_b32 a235, 0\n\tv_accvgpr_write_b32 a236, 0\n\tv_accvgpr_write_b32 a237, 0\n\tv_accvgpr_write_b32 a238, 0\n\tv_accvgpr_write_b32 a239, 0" : : : "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239");
+    asm volatile("v_accvgpr_write_b32 a240, 0\n\tv_accvgpr_write_b32 a241, 0\n\tv_accvgpr_write_b32 a242, 0\n\tv_accvgpr_write_b32 a243, 0\n\tv_accvgpr_write_b32 a244, 0\n\tv_accvgpr_write_b32 a245, 0\n\tv_accvgpr_write_b32 a246, 0\n\tv_accvgpr_write_b32 a247, 0\n\tv_accvgpr_write_b32 a248, 0\n\tv_accvgpr_write_b32 a249, 0\n\tv_accvgpr_write_b32 a250, 0\n\tv_accvgpr_write_b32 a251, 0\n\tv_accvgpr_write_b32 a252, 0\n\tv_accvgpr_write_b32 a253, 0\n\tv_accvgpr_write_b32 a254, 0\n\tv_accvgpr_write_b32 a255, 0" : : : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+
+    const int last = g.nch - 1;
+    auto clampc = [&](int c) { return min(c, last); };
+    f32x4 ua[8], ub[8];                    // U of the current / next chunk
+    float b0[16], b1[16];                  // B operands of the current chunk: V of channels 2 lh, 2 lh + 1
+    float n0v[16], n1v[16];                // ... of the next chunk, transformed while the current chunk's MFMAs run
+    Rows rows;
+    // prologue: chunk 0 operands, chunk 1 raw rows in LDS, chunk 2 rows in flight
+    G_rows(0, rows);
+    G_u(0, ua);
+    W_rows(0, rows);
+    G_rows(clampc(1), rows);
+    T_read(0, 0, b0);
+    T_read(0, 1, b1);
+    T_col(b0, 0); T_col(b0, 2); T_col(b1, 0); T_col(b1, 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { T_rowp(b0, i); T_rowp(b1, i); }
+    W_rows(1, rows);
+    G_rows(clampc(2), rows);
+
+#define W1_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // The 256 accumulators live in FIXED accumulation registers a[16 p : 16 p + 15], named in the asm text and declared as clobbers.
+    // (With the MFMA builtin -- or an "a" constraint on a variable -- the register allocator kept copies of them in VGPRs, shuffled
+    //  v_accvgpr_read / write by the hundred inside the loop and spilled 250 registers.)
+#define W1_MMA_0(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[0:15], %0, %1, a[0:15]\n\tv_mfma_f32_32x32x2_f32 a[0:15], %2, %3, a[0:15]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15")
+#define W1_MMA_1(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[16:31], %0, %1, a[16:31]\n\tv_mfma_f32_32x32x2_f32 a[16:31], %2, %3, a[16:31]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31")
+#define W1_MMA_2(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[32:47], %0, %1, a[32:47]\n\tv_mfma_f32_32x32x2_f32 a[32:47], %2, %3, a[32:47]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47")
+#define W1_MMA_3(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[48:63], %0, %1, a[48:63]\n\tv_mfma_f32_32x32x2_f32 a[48:63], %2, %3, a[48:63]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63")
+#define W1_MMA_4(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[64:79], %0, %1, a[64:79]\n\tv_mfma_f32_32x32x2_f32 a[64:79], %2, %3, a[64:79]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79")
+#define W1_MMA_5(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[80:95], %0, %1, a[80:95]\n\tv_mfma_f32_32x32x2_f32 a[80:95], %2, %3, a[80:95]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95")
+#define W1_MMA_6(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[96:111], %0, %1, a[96:111]\n\tv_mfma_f32_32x32x2_f32 a[96:111], %2, %3, a[96:111]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111")
+#define W1_MMA_7(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[112:127], %0, %1, a[112:127]\n\tv_mfma_f32_32x32x2_f32 a[112:127], %2, %3, a[112:127]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127")
+#define W1_MMA_8(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[128:143], %0, %1, a[128:143]\n\tv_mfma_f32_32x32x2_f32 a[128:143], %2, %3, a[128:143]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143")
+#define W1_MMA_9(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[144:159], %0, %1, a[144:159]\n\tv_mfma_f32_32x32x2_f32 a[144:159], %2, %3, a[144:159]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159")
+#define W1_MMA_10(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[160:175], %0, %1, a[160:175]\n\tv_mfma_f32_32x32x2_f32 a[160:175], %2, %3, a[160:175]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175")
+#define W1_MMA_11(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[176:191], %0, %1, a[176:191]\n\tv_mfma_f32_32x32x2_f32 a[176:191], %2, %3, a[176:191]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191")
+#define W1_MMA_12(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[192:207], %0, %1, a[192:207]\n\tv_mfma_f32_32x32x2_f32 a[192:207], %2, %3, a[192:207]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207")
+#define W1_MMA_13(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[208:223], %0, %1, a[208:223]\n\tv_mfma_f32_32x32x2_f32 a[208:223], %2, %3, a[208:223]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223")
+#define W1_MMA_14(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[224:239], %0, %1, a[224:239]\n\tv_mfma_f32_32x32x2_f32 a[224:239], %2, %3, a[224:239]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239")
+#define W1_MMA_15(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[240:255], %0, %1, a[240:255]\n\tv_mfma_f32_32x32x2_f32 a[240:255], %2, %3, a[240:255]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255")
+#define W1_MMA(p, U, B0, B1) W1_MMA_##p((U)[(p) >> 1][((p) & 1) * 2 + 0], (U)[(p) >> 1][((p) & 1) * 2 + 1], (B0)[p], (B1)[p])
+    // iteration it (par = it & 1): M(it) from (ucur, c0, c1); T(it + 1) from raw stage (it + 1) & 1 into (x0, x1); then W(it + 2)
+    // (rows loaded one iteration earlier) and the loads of rows(it + 3); U(it + 1) is requested at the top
+    auto iter = [&](int it, int par, f32x4 (&ucur)[8], f32x4 (&unext)[8], float (&c0)[16], float (&c1)[16], float (&x0)[16],
+                    float (&x1)[16]) {
+        G_u(clampc(it + 1), unext);
+        W1_FENCE();
+        W1_MMA(0, ucur, c0, c1);  T_read(par ^ 1, 0, x0);                 W1_FENCE();
+        W1_MMA(1, ucur, c0, c1);  T_read(par ^ 1, 1, x1);                 W1_FENCE();
+        W1_MMA(2, ucur, c0, c1);  T_col(x0, 0);                           W1_FENCE();
+        W1_MMA(3, ucur, c0, c1);  T_col(x0, 2);                           W1_FENCE();
+        W1_MMA(4, ucur, c0, c1);  T_col(x1, 0);                           W1_FENCE();
+        W1_MMA(5, ucur, c0, c1);  T_col(x1, 2);                           W1_FENCE();
+        W1_MMA(6, ucur, c0, c1);  T_rowp(x0, 0); T_rowp(x0, 1);           W1_FENCE();
+        W1_MMA(7, ucur, c0, c1);  T_rowp(x0, 2); T_rowp(x0, 3);           W1_FENCE();
+        W1_MMA(8, ucur, c0, c1);  T_rowp(x1, 0); T_rowp(x1, 1);           W1_FENCE();
+        W1_MMA(9, ucur, c0, c1);  T_rowp(x1, 2); T_rowp(x1, 3);           W1_FENCE();
+        W1_MMA(10, ucur, c0, c1); W_rows(par, rows);                      W1_FENCE();     // rows of chunk it + 2 -> raw stage (it + 2) & 1
+        W1_MMA(11, ucur, c0, c1); G_rows(clampc(it + 3), rows);           W1_FENCE();
+        W1_MMA(12, ucur, c0, c1);                                         W1_FENCE();
+        W1_MMA(13, ucur, c0, c1);                                         W1_FENCE();
+        W1_MMA(14, ucur, c0, c1);                                         W1_FENCE();
+        W1_MMA(15, ucur, c0, c1);                                         W1_FENCE();
+    };
+    for (int it = 0; it < g.nch; it += 2) {
+        iter(it, 0, ua, ub, b0, b1, n0v, n1v);
+        if (it + 1 < g.nch) iter(it + 1, 1, ub, ua, n0v, n1v, b0, b1);
+    }
+
+    // ---- epilogue: Y = A^T M A in registers (M[i][j] = acc[4 i + j]),  A^T = [1 1 1 0; 0 1 -1 -1]
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // (the last MFMA's result is read below: the compiler cannot see into the asm)
+    const int64_t tg = t0 + li;
+    const bool tv = tg < g.tiles_total;
+    const int n = (int)(tg / g.tiles_img), r = (int)(tg % g.tiles_img);
+    const int ty = r / g.tw, tx = r % g.tw;
+    float *yout = y + ((int64_t)n * g.M) * HW + (2 * ty) * g.W + 2 * tx;
+#define W1_RD_0(m) asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a16\n\tv_accvgpr_read_b32 %2, a32\n\tv_accvgpr_read_b32 %3, a48\n\tv_accvgpr_read_b32 %4, a64\n\tv_accvgpr_read_b32 %5, a80\n\tv_accvgpr_read_b32 %6, a96\n\tv_accvgpr_read_b32 %7, a112\n\tv_accvgpr_read_b32 %8, a128\n\tv_accvgpr_read_b32 %9, a144\n\tv_accvgpr_read_b32 %10, a160\n\tv_accvgpr_read_b32 %11, a176\n\tv_accvgpr_read_b32 %12, a192\n\tv_accvgpr_read_b32 %13, a208\n\tv_accvgpr_read_b32 %14, a224\n\tv_accvgpr_read_b32 %15, a240" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
+#define W1_RD_1(m) asm volatile("v_accvgpr_read_b32 %0, a1\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a33\n\tv_accvgpr_read_b32 %3, a49\n\tv_accvgpr_read_b32 %4, a65\n\tv_accvgpr_read_b32 %5, a81\n\tv_accvgpr_read_b32 %6, a97\n\tv_accvgpr_read_b32 %7, a113\n\tv_accvgpr_read_b32 %8, a129\n\tv_accvgpr_read_b32 %9, a145\n\tv_accvgpr_read_b32 %10, a161\n\tv_accvgpr_read_b32 %11, a177\n\tv_accvgpr_read_b32 %12, a193\n\tv_accvgpr_read_b32 %13, a209\n\tv_accvgpr_read_b32 %14, a225\n\tv_accvgpr_read_b32 %15, a241" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
+#define W1_RD_2(m) asm volatile("v_accvgpr_read_b32 %0, a2\n\tv_accvgpr_read_b32 %1, a18\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a50\n\tv_accvgpr_read_b32 %4, a66\n\tv_accvgpr_read_b32 %5, a82\n\tv_accvgpr_read_b32 %6, a98\n\tv_accvgpr_read_b32 %7, a114\n\tv_accvgpr_read_b32 %8, a130\n\tv_accvgpr_read_b32 %9, a146\n\tv_accvgpr_read_b32 %10, a162\n\tv_accvgpr_read_b32 %11, a178\n\tv_accvgpr_read_b32 %12, a194\n\tv_accvgpr_read_b32 %13, a210\n\tv_accvgpr_read_b32 %14, a226\n\tv_accvgpr_read_b32 %15, a242" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
+#define W1_RD_3(m) asm volatile("v_accvgpr_read_b32 %0, a3\n\tv_accvgpr_read_b32 %1, a19\n\tv_accvgpr_read_b32 %2, a35\n\tv_accvgpr_read_b32 %3, a51\n\tv_accvgpr_read_b32 %4, a67\n\tv_accvgpr_read_b32 %5, a83\n\tv_accvgpr_read_b32 %6, a99\n\tv_accvgpr_read_b32 %7, a115\n\tv_accvgpr_read_b32 %8, a131\n\tv_accvgpr_read_b32 %9, a147\n\tv_accvgpr_read_b32 %10, a163\n\tv_accvgpr_read_b32 %11, a179\n\tv_accvgpr_read_b32 %12, a195\n\tv_accvgpr_read_b32 %13, a211\n\tv_accvgpr_read_b32 %14, a227\n\tv_accvgpr_read_b32 %15, a243" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
+#define W1_RD_4(m) asm volatile("v_accvgpr_read_b32 %0, a4\n\tv_accvgpr_read_b32 %1, a20\n\tv_accvgpr_read_b32 %2, a36\n\tv_accvgpr_read_b32 %3, a52\n\tv_accvgpr_read_b32 %4, a68\n\tv_accvgpr_read_b32 %5, a84\n\tv_accvgpr_read_b32 %6, a100\n\tv_accvgpr_read_b32 %7, a116\n\tv_accvgpr_read_b32 %8, a132\n\tv_accvgpr_read_b32 %9, a148\n\tv_accvgpr_read_b32 %10, a164\n\tv_accvgpr_read_b32 %11, a180\n\tv_accvgpr_read_b32 %12, a196\n\tv_accvgpr_read_b32 %13, a212\n\tv_accvgpr_read_b32 %14, a228\n\tv_accvgpr_read_b32 %15, a244" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
+#define W1_RD_5(m) asm volatile("v_accvgpr_read_b32 %0, a5\n\tv_accvgpr_read_b32 %1, a21\n\tv_accvgpr_read_b32 %2, a37\n\tv_accvgpr_read_b32 %3, a53\n\tv_accvgpr_read_b32 %4, a69\n\tv_accvgpr_read_b32 %5, a85\n\tv_accvgpr_read_b32 %6, a101\n\tv_accvgpr_read_b32 %7, a117\n\tv_accvgpr_read_b32 %8, a133\n\tv_accvgpr_read_b32 %9, a149\n\tv_accvgpr_read_b32 %10, a165\n\tv_accvgpr_read_b32 %11, a181\n\tv_accvgpr_read_b32 %12, a197\n\tv_accvgpr_read_b32 %13, a213\n\tv_accvgpr_read_b32 %14, a229\n\tv_accvgpr_read_b32 %15, a245" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
+#define W1_RD_6(m) asm volatile("v_accvgpr_read_b32 %0, a6\n\tv_accvgpr_read_b32 %1, a22\n\tv_accvgpr_read_b32 %2, a38\n\tv_accvgpr_read_b32 %3, a54\n\tv_accvgpr_read_b32 %4, a70\n\tv_accvgpr_read_b32 %5, a86\n\tv_accvgpr_read_b32 %6, a102\n\tv_accvgpr_read_b32 %7, a118\n\tv_accvgpr_read_b32 %8, a134\n\tv_accvgpr_read_b32 %9, a150\n\tv_accvgpr_read_b32 %10, a166\n\tv_accvgpr_read_b32 %11, a182\n\tv_accvgpr_read_b32 %12, a198\n\tv_accvgpr_read_b32 %13, a214\n\tv_accvgpr_read_b32 %14, a230\n\tv_accvgpr_read_b32 %15, a246" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
+#define W1_RD_7(m) asm volatile("v_accvgpr_read_b32 %0, a7\n\tv_accvgpr_read_b32 %1, a23\n\tv_accvgpr_read_b32 %2, a39\n\tv_accvgpr_read_b32 %3, a55\n\tv_accvgpr_read_b32 %4, a71\n\tv_accvgpr_read_b32 %5, a87\n\tv_accvgpr_read_b32 %6, a103\n\tv_accvgpr_read_b32 %7, a119\n\tv_accvgpr_read_b32 %8, a135\n\tv_accvgpr_read_b32 %9, a151\n\tv_accvgpr_read_b32 %10, a167\n\tv_accvgpr_read_b32 %11, a183\n\tv_accvgpr_read_b32 %12, a199\n\tv_accvgpr_read_b32 %13, a215\n\tv_accvgpr_read_b32 %14, a231\n\tv_accvgpr_read_b32 %15, a247" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
+#define W1_RD_8(m) asm volatile("v_accvgpr_read_b32 %0, a8\n\tv_accvgpr_read_b32 %1, a24\n\tv_accvgpr_read_b32 %2, a40\n\tv_accvgpr_read_b32 %3, a56\n\tv_accvgpr_read_b32 %4, a72\n\tv_accvgpr_read_b32 %5, a88\n\tv_accvgpr_read_b32 %6, a104\n\tv_accvgpr_read_b32 %7, a120\n\tv_accvgpr_read_b32 %8, a136\n\tv_accvgpr_read_b32 %9, a152\n\tv_accvgpr_read_b32 %10, a168\n\tv_accvgpr_read_b32 %11, a184\n\tv_accvgpr_read_b32 %12, a200\n\tv_accvgpr_read_b32 %13, a216\n\tv_accvgpr_read_b32 %14, a232\n\tv_accvgpr_read_b32 %15, a248" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
+#define W1_RD_9(m) asm volatile("v_accvgpr_read_b32 %0, a9\n\tv_accvgpr_read_b32 %1, a25\n\tv_accvgpr_read_b32 %2, a41\n\tv_accvgpr_read_b32 %3, a57\n\tv_accvgpr_read_b32 %4, a73\n\tv_accvgpr_read_b32 %5, a89\n\tv_accvgpr_read_b32 %6, a105\n\tv_accvgpr_read_b32 %7, a121\n\tv_accvgpr_read_b32 %8, a137\n\tv_accvgpr_read_b32 %9, a153\n\tv_accvgpr_read_b32 %10, a169\n\tv_accvgpr_read_b32 %11, a185\n\tv_accvgpr_read_b32 %12, a201\n\tv_accvgpr_read_b32 %13, a217\n\tv_accvgpr_read_b32 %14, a233\n\tv_accvgpr_read_b32 %15, a249" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
+#define W1_RD_10(m) asm volatile("v_accvgpr_read_b32 %0, a10\n\tv_accvgpr_read_b32 %1, a26\n\tv_accvgpr_read_b32 %2, a42\n\tv_accvgpr_read_b32 %3, a58\n\tv_accvgpr_read_b32 %4, a74\n\tv_accvgpr_read_b32 %5, a90\n\tv_accvgpr_read_b32 %6, a106\n\tv_accvgpr_read_b32 %7, a122\n\tv_accvgpr_read_b32 %8, a138\n\tv_accvgpr_read_b32 %9, a154\n\tv_accvgpr_read_b32 %10, a170\n\tv_accvgpr_read_b32 %11, a186\n\tv_accvgpr_read_b32 %12, a202\n\tv_accvgpr_read_b32 %13, a218\n\tv_accvgpr_read_b32 %14, a234\n\tv_accvgpr_read_b32 %15, a250" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
+#define W1_RD_11(m) asm volatile("v_accvgpr_read_b32 %0, a11\n\tv_accvgpr_read_b32 %1, a27\n\tv_accvgpr_read_b32 %2, a43\n\tv_accvgpr_read_b32 %3, a59\n\tv_accvgpr_read_b32 %4, a75\n\tv_accvgpr_read_b32 %5, a91\n\tv_accvgpr_read_b32 %6, a107\n\tv_accvgpr_read_b32 %7, a123\n\tv_accvgpr_read_b32 %8, a139\n\tv_accvgpr_read_b32 %9, a155\n\tv_accvgpr_read_b32 %10, a171\n\tv_accvgpr_read_b32 %11, a187\n\tv_accvgpr_read_b32 %12, a203\n\tv_accvgpr_read_b32 %13, a219\n\tv_accvgpr_read_b32 %14, a235\n\tv_accvgpr_read_b32 %15, a251" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
+#define W1_RD_12(m) asm volatile("v_accvgpr_read_b32 %0, a12\n\tv_accvgpr_read_b32 %1, a28\n\tv_accvgpr_read_b32 %2, a44\n\tv_accvgpr_read_b32 %3, a60\n\tv_accvgpr_read_b32 %4, a76\n\tv_accvgpr_read_b32 %5, a92\n\tv_accvgpr_read_b32 %6, a108\n\tv_accvgpr_read_b32 %7, a124\n\tv_accvgpr_read_b32 %8, a140\n\tv_accvgpr_read_b32 %9, a156\n\tv_accvgpr_read_b32 %10, a172\n\tv_accvgpr_read_b32 %11, a188\n\tv_accvgpr_read_b32 %12, a204\n\tv_accvgpr_read_b32 %13, a220\n\tv_accvgpr_read_b32 %14, a236\n\tv_accvgpr_read_b32 %15, a252" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
+#define W1_RD_13(m) asm volatile("v_accvgpr_read_b32 %0, a13\n\tv_accvgpr_read_b32 %1, a29\n\tv_accvgpr_read_b32 %2, a45\n\tv_accvgpr_read_b32 %3, a61\n\tv_accvgpr_read_b32 %4, a77\n\tv_accvgpr_read_b32 %5, a93\n\tv_accvgpr_read_b32 %6, a109\n\tv_accvgpr_read_b32 %7, a125\n\tv_accvgpr_read_b32 %8, a141\n\tv_accvgpr_read_b32 %9, a157\n\tv_accvgpr_read_b32 %10, a173\n\tv_accvgpr_read_b32 %11, a189\n\tv_accvgpr_read_b32 %12, a205\n\tv_accvgpr_read_b32 %13, a221\n\tv_accvgpr_read_b32 %14, a237\n\tv_accvgpr_read_b32 %15, a253" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
+#define W1_RD_14(m) asm volatile("v_accvgpr_read_b32 %0, a14\n\tv_accvgpr_read_b32 %1, a30\n\tv_accvgpr_read_b32 %2, a46\n\tv_accvgpr_read_b32 %3, a62\n\tv_accvgpr_read_b32 %4, a78\n\tv_accvgpr_read_b32 %5, a94\n\tv_accvgpr_read_b32 %6, a110\n\tv_accvgpr_read_b32 %7, a126\n\tv_accvgpr_read_b32 %8, a142\n\tv_accvgpr_read_b32 %9, a158\n\tv_accvgpr_read_b32 %10, a174\n\tv_accvgpr_read_b32 %11, a190\n\tv_accvgpr_read_b32 %12, a206\n\tv_accvgpr_read_b32 %13, a222\n\tv_accvgpr_read_b32 %14, a238\n\tv_accvgpr_read_b32 %15, a254" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
+#define W1_RD_15(m) asm volatile("v_accvgpr_read_b32 %0, a15\n\tv_accvgpr_read_b32 %1, a31\n\tv_accvgpr_read_b32 %2, a47\n\tv_accvgpr_read_b32 %3, a63\n\tv_accvgpr_read_b32 %4, a79\n\tv_accvgpr_read_b32 %5, a95\n\tv_accvgpr_read_b32 %6, a111\n\tv_accvgpr_read_b32 %7, a127\n\tv_accvgpr_read_b32 %8, a143\n\tv_accvgpr_read_b32 %9, a159\n\tv_accvgpr_read_b32 %10, a175\n\tv_accvgpr_read_b32 %11, a191\n\tv_accvgpr_read_b32 %12, a207\n\tv_accvgpr_read_b32 %13, a223\n\tv_accvgpr_read_b32 %14, a239\n\tv_accvgpr_read_b32 %15, a255" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
+    float s1[16], s2[16];
+    auto out_e = [&](int e, const float (&m)[16]) {       // m[4 i + j] = M[i][j] of output channel element e
+        float r_[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r_[i][0] = m[i * 4 + 0] + m[i * 4 + 1] + m[i * 4 + 2];
+            r_[i][1] = m[i * 4 + 1] - m[i * 4 + 2] - m[i * 4 + 3];
+        }
+        const int co = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        float bv = 0.0f;
+        if (bias != nullptr) bv = bias[co < g.M ? co : 0];
+        const float v00 = r_[0][0] + r_[1][0] + r_[2][0] + bv, v01 = r_[0][1] + r_[1][1] + r_[2][1] + bv;
+        const float v10 = r_[1][0] - r_[2][0] - r_[3][0] + bv, v11 = r_[1][1] - r_[2][1] - r_[3][1] + bv;
+        if (tv && co < g.M) {
+            f32x2 o;
+            o[0] = v00, o[1] = v01;
+            *reinterpret_cast<f32x2 *>(yout + (int64_t)co * HW) = o;
+            o[0] = v10, o[1] = v11;
+            *reinterpret_cast<f32x2 *>(yout + (int64_t)co * HW + g.W) = o;
+        }
+        if (STATS) {
+            s1[e] = tv ? (v00 + v01) + (v10 + v11) : 0.0f;
+            s2[e] = tv ? (v00 * v00 + v01 * v01) + (v10 * v10 + v11 * v11) : 0.0f;
+        }
+    };
+    {
+        float m[16];
+        W1_RD_0(m); out_e(0, m);
+        W1_RD_1(m); out_e(1, m);
+        W1_RD_2(m); out_e(2, m);
+        W1_RD_3(m); out_e(3, m);
+        W1_RD_4(m); out_e(4, m);
+        W1_RD_5(m); out_e(5, m);
+        W1_RD_6(m); out_e(6, m);
+        W1_RD_7(m); out_e(7, m);
+        W1_RD_8(m); out_e(8, m);
+        W1_RD_9(m); out_e(9, m);
+        W1_RD_10(m); out_e(10, m);
+        W1_RD_11(m); out_e(11, m);
+        W1_RD_12(m); out_e(12, m);
+        W1_RD_13(m); out_e(13, m);
+        W1_RD_14(m); out_e(14, m);
+        W1_RD_15(m); out_e(15, m);
+    }
+    if (STATS) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                s1[e] += __shfl_xor(s1[e], off);
+                s2[e] += __shfl_xor(s2[e], off);
+            }
+        if (li == 0) {
+            const int64_t nruns = (g.tiles_total + W1_T - 1) / W1_T;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (co < g.M) {
+                    float *dst = stats + ((int64_t)co * nruns + run) * 2;
+                    dst[0] = s1[e];
+                    dst[1] = s2[e];
+                }
+            }
+        }
+    }
+}
+
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 
 // waves per block for a launch.  The 8-wave / 64-channel block does half the staging work per MFMA, but its eight waves run in
@@ -476,8 +831,15 @@ extern "C" size_t cpg_conv3x3_wino_pack_bytes(int c_read, int m) {      // (the 
     return (size_t)pad_to(m, 64) * pad_to(c_read, WG_CK) * 16 * sizeof(float);
 }
 
+// CPG_WINO_KERNEL=block selects the 4-wave-block kernel k_wg_fwd (A/B experiments, tests); default: one wave per unit (k_wg1)
+static inline bool wino_one_wave() {
+    const char *f = getenv("CPG_WINO_KERNEL");
+    return !(f && f[0] == 'b');
+}
+
 extern "C" int cpg_conv3x3_wino_tiles(int N, int H, int W) {
-    return (int)(((int64_t)N * (H / 2) * (W / 2) + WG_T - 1) / WG_T);
+    const int per = wino_one_wave() ? W1_T : WG_T;
+    return (int)(((int64_t)N * (H / 2) * (W / 2) + per - 1) / per);
 }
 
 // y[N][m][H][W] = conv3x3(x[N][c_read][H][W], W .* bin(pm)) (+ bias); dgrad: x = gy, the filter transposed and flipped.
@@ -489,6 +851,28 @@ extern "C" int cpg_conv3x3_wino_run(int dgrad, int N, int c_read, int m, int H, 
     const size_t need = cpg_conv3x3_wino_pack_bytes(c_read, m);
     if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
     CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
+    if (wino_one_wave()) {
+        WgGeom g;
+        g.N = N, g.C = c_read, g.H = H, g.W = W, g.M = m;
+        g.th = H / 2, g.tw = W / 2, g.tiles_img = g.th * g.tw;
+        g.tiles_total = (int64_t)N * g.tiles_img;
+        g.nkb = pad_to(m, 32) / 32, g.nch = pad_to(c_read, WG_CK) / WG_CK;
+        g.span = (W1_T + g.tiles_img - 1) / g.tiles_img + 1;
+        float *up = (float *)ws;
+        hipLaunchKernelGGL(k_wg1_pack, dim3(stream_grid((int64_t)g.nkb * g.nch * 32 * WG_CK, 256)), dim3(256), 0, stream, w, pm, thr, up,
+                           K, C, m, c_read, g.nch, dgrad ? 1 : 0);
+        const int64_t runs = (g.tiles_total + W1_T - 1) / W1_T;
+        const int64_t blocks = (runs + 3) / 4 * g.nkb;
+        if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "%s: grid too large", what);
+        if (dgrad)
+            hipLaunchKernelGGL((k_wg1<true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, up, bias, y, nullptr);
+        else if (stats != nullptr)
+            hipLaunchKernelGGL((k_wg1<false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, up, bias, y, stats);
+        else
+            hipLaunchKernelGGL((k_wg1<false, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, up, bias, y, nullptr);
+        CPG_CHECK_LAUNCH(what);
+        return CPG_OK;
+    }
     const int nw = wino_nw(c_read, m), BK = 8 * nw;
     WgGeom g;
     g.N = N, g.C = c_read, g.H = H, g.W = W, g.M = m;
