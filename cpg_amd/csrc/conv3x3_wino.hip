@@ -517,18 +517,20 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
 
     unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
     const int kb = lb % g.nkb;
-    const int64_t run = (int64_t)(lb / g.nkb) * 4 + wave;     // tile run of 32
-    const int64_t t0 = run * W1_T;
-    if (t0 >= g.tiles_total) return;                          // (no barriers anywhere: a wave may leave)
-    const int n0 = (int)(t0 / g.tiles_img);
+    // (32-bit tile arithmetic: the host refuses N * tiles >= 2^31; 64-bit divisions cost the prologue ~1.5 us per wave)
+    const unsigned ttot = (unsigned)g.tiles_total, timg = (unsigned)g.tiles_img, twu = (unsigned)g.tw;
+    const unsigned run = (lb / g.nkb) * 4 + wave;             // tile run of 32
+    const unsigned t0 = run * W1_T;
+    if (t0 >= ttot) return;                                   // (no barriers anywhere: a wave may leave)
+    const int n0 = (int)(t0 / timg);
 
     constexpr int kOutOfRange = (int)0x80000000;
     int roff[4], hoff, lo, ro;
     {
-        const int64_t tg = t0 + li;
-        const bool tv = tg < g.tiles_total;
-        const int n = (int)(tg / g.tiles_img), r = (int)(tg % g.tiles_img);
-        const int ty = r / g.tw, tx = r % g.tw;
+        const unsigned tg = t0 + li;
+        const bool tv = tg < ttot;
+        const int n = (int)(tg / timg), r = (int)(tg % timg);
+        const int ty = (int)((unsigned)r / twu), tx = (int)((unsigned)r % twu);
         const int cbase = ((n - n0) * g.C + 2 * lh) * HW;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -539,11 +541,11 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         ro = tx == g.tw - 1 ? (W1_T + 1) * 2 + 1 : (li + 1) * 2 + 2;
         // halo: lanes 0-31 = (side, row, channel): the column left of tile t0 / right of tile t0 + 31
         const int side = (lane >> 4) & 1, hi = (lane >> 2) & 3, hc = lane & 3;
-        const int64_t th = side ? t0 + W1_T - 1 : t0;
-        const int nh = (int)(th / g.tiles_img), rh = (int)(th % g.tiles_img);
-        const int tyh = rh / g.tw, txh = rh % g.tw;
+        const unsigned th = side ? t0 + W1_T - 1 : t0;
+        const int nh = (int)(th / timg), rh = (int)(th % timg);
+        const int tyh = (int)((unsigned)rh / twu), txh = (int)((unsigned)rh % twu);
         const int ghh = 2 * tyh - 1 + hi, gwh = side ? 2 * txh + 2 : 2 * txh - 1;
-        const bool okh = lane < 32 && th < g.tiles_total && (unsigned)ghh < (unsigned)g.H && (unsigned)gwh < (unsigned)g.W;
+        const bool okh = lane < 32 && th < ttot && (unsigned)ghh < (unsigned)g.H && (unsigned)gwh < (unsigned)g.W;
         hoff = okh ? (((nh - n0) * g.C + hc) * HW + ghh * g.W + gwh) * 4 : kOutOfRange;
     }
     const int span = (W1_T + g.tiles_img - 1) / g.tiles_img + 1;
@@ -565,27 +567,45 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         i32x2 r[2][4];
         float halo;
     };
-    auto G_rows = [&](int ch, Rows &q) {
+    auto G_row1 = [&](int ch, Rows &q, int k) {             // k = 0..7: row k & 3 of channel 2 lh + k / 4;  k = 8: the halo values
         const int soff = ch * WG_CK * HW * 4;
+        if (k < 8)
+            q.r[k >> 2][k & 3] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[k & 3], soff + (k >> 2) * HW * 4, 0);
+        else
+            q.halo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, hoff, soff, 0));
+    };
+    auto G_rows = [&](int ch, Rows &q) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) q.r[j][i] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[i], soff + j * HW * 4, 0);
-        q.halo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, hoff, soff, 0));
+        for (int k = 0; k < 9; ++k) G_row1(ch, q, k);
+    };
+    auto W_row1 = [&](int stage, const Rows &q, int k) {
+        float *raw = smem + stage * W1_RAW;
+        if (k < 8)
+            *reinterpret_cast<i32x2 *>(raw + raw_own + k * W1_ROW) = q.r[k >> 2][k & 3];
+        else if (lane < 32)
+            raw[halo_w] = q.halo;
     };
     auto W_rows = [&](int stage, const Rows &q) {
-        float *raw = smem + stage * W1_RAW;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<i32x2 *>(raw + raw_own + (j * 4 + i) * W1_ROW) = q.r[j][i];
-        if (lane < 32) raw[halo_w] = q.halo;
+        for (int k = 0; k < 9; ++k) W_row1(stage, q, k);
     };
+    auto G_u1 = [&](int ch, f32x4 (&u)[8], int q) { u[q] = *reinterpret_cast<const f32x4 *>(ubase + (int64_t)ch * W1_U + q * 256); };
     auto G_u = [&](int ch, f32x4 (&u)[8]) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) u[q] = *reinterpret_cast<const f32x4 *>(ubase + (int64_t)ch * W1_U + q * 256);
+        for (int q = 0; q < 8; ++q) G_u1(ch, u, q);
     };
     // patch of (tile li, channel 2 lh + j) -> the 16 transform-domain values, in place
+    auto T_read2 = [&](int stage, int j, float (&d)[16], int i0) {       // patch rows i0, i0 + 1
+        const float *raw = smem + stage * W1_RAW + (2 * lh + j) * 4 * W1_ROW;
+#pragma unroll
+        for (int i = i0; i < i0 + 2; ++i) {
+            const f32x2 own = *reinterpret_cast<const f32x2 *>(raw + i * W1_ROW + (li + 1) * 2);
+            d[i * 4 + 0] = raw[i * W1_ROW + lo];
+            d[i * 4 + 1] = own[0];
+            d[i * 4 + 2] = own[1];
+            d[i * 4 + 3] = raw[i * W1_ROW + ro];
+        }
+    };
     auto T_read = [&](int stage, int j, float (&d)[16]) {
         const float *raw = smem + stage * W1_RAW + (2 * lh + j) * 4 * W1_ROW;
 #pragma unroll
@@ -605,14 +625,18 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
             d[1 * 4 + j] = d1 + d2;
             d[2 * 4 + j] = d2 - d1;
             d[3 * 4 + j] = d1 - d3;
+            asm volatile("" : "+v"(d[0 * 4 + j]), "+v"(d[1 * 4 + j]), "+v"(d[2 * 4 + j]), "+v"(d[3 * 4 + j]));
         }
     };
+    // (the asm "uses" pin the results where they are computed: their only consumers are the NEXT iteration's MFMAs, and the
+    //  optimizer otherwise sinks the whole transform -- 64 adds -- in front of them, where nothing runs in its shadow)
     auto T_rowp = [&](float (&d)[16], int i) {
         const float t0_ = d[i * 4 + 0], t1 = d[i * 4 + 1], t2 = d[i * 4 + 2], t3 = d[i * 4 + 3];
         d[i * 4 + 0] = t0_ - t2;
         d[i * 4 + 1] = t1 + t2;
         d[i * 4 + 2] = t2 - t1;
         d[i * 4 + 3] = t1 - t3;
+        asm volatile("" : "+v"(d[i * 4 + 0]), "+v"(d[i * 4 + 1]), "+v"(d[i * 4 + 2]), "+v"(d[i * 4 + 3]));
     };
 
     asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0" : : : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
@@ -634,78 +658,108 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
 
     const int last = g.nch - 1;
     auto clampc = [&](int c) { return min(c, last); };
-    f32x4 ua[8], ub[8];                    // U of the current / next chunk
+    f32x4 u0[8], u1[8], u2[8];             // U of chunks it, it + 1, it + 2 (three rotating sets: requested two iterations ahead)
     float b0[16], b1[16];                  // B operands of the current chunk: V of channels 2 lh, 2 lh + 1
     float n0v[16], n1v[16];                // ... of the next chunk, transformed while the current chunk's MFMAs run
-    Rows rows;
-    // prologue: chunk 0 operands, chunk 1 raw rows in LDS, chunk 2 rows in flight
-    G_rows(0, rows);
-    G_u(0, ua);
-    W_rows(0, rows);
-    G_rows(clampc(1), rows);
+    Rows rw0, rw1;                         // raw rows in flight: chunk c uses set c & 1, requested FOUR iterations before its MFMAs
+    // With one wave per SIMD a wait is an idle MFMA pipe: the loads that miss L2 (the transformed filter of a 512 x 512 layer is
+    // 16 MB, the input's first touch) take longer than one iteration (0.85 us), so everything is requested two iterations early.
+    // prologue: chunk 0 operands, chunks 0 / 1 raw rows in LDS, chunks 2 / 3 rows and U(0), U(1) in flight
+    G_rows(0, rw0);
+    G_rows(clampc(1), rw1);
+    G_u(0, u0);
+    G_u(clampc(1), u1);
+    W_rows(0, rw0);
+    W_rows(1, rw1);
+    G_rows(clampc(2), rw0);
+    G_rows(clampc(3), rw1);
     T_read(0, 0, b0);
     T_read(0, 1, b1);
     T_col(b0, 0); T_col(b0, 2); T_col(b1, 0); T_col(b1, 2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { T_rowp(b0, i); T_rowp(b1, i); }
-    W_rows(1, rows);
-    G_rows(clampc(2), rows);
 
-#define W1_FENCE() __builtin_amdgcn_sched_barrier(0)
     // The 256 accumulators live in FIXED accumulation registers a[16 p : 16 p + 15], named in the asm text and declared as clobbers.
     // (With the MFMA builtin -- or an "a" constraint on a variable -- the register allocator kept copies of them in VGPRs, shuffled
     //  v_accvgpr_read / write by the hundred inside the loop and spilled 250 registers.)
-#define W1_MMA_0(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[0:15], %0, %1, a[0:15]\n\tv_mfma_f32_32x32x2_f32 a[0:15], %2, %3, a[0:15]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15")
-#define W1_MMA_1(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[16:31], %0, %1, a[16:31]\n\tv_mfma_f32_32x32x2_f32 a[16:31], %2, %3, a[16:31]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31")
-#define W1_MMA_2(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[32:47], %0, %1, a[32:47]\n\tv_mfma_f32_32x32x2_f32 a[32:47], %2, %3, a[32:47]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47")
-#define W1_MMA_3(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[48:63], %0, %1, a[48:63]\n\tv_mfma_f32_32x32x2_f32 a[48:63], %2, %3, a[48:63]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63")
-#define W1_MMA_4(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[64:79], %0, %1, a[64:79]\n\tv_mfma_f32_32x32x2_f32 a[64:79], %2, %3, a[64:79]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79")
-#define W1_MMA_5(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[80:95], %0, %1, a[80:95]\n\tv_mfma_f32_32x32x2_f32 a[80:95], %2, %3, a[80:95]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95")
-#define W1_MMA_6(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[96:111], %0, %1, a[96:111]\n\tv_mfma_f32_32x32x2_f32 a[96:111], %2, %3, a[96:111]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111")
-#define W1_MMA_7(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[112:127], %0, %1, a[112:127]\n\tv_mfma_f32_32x32x2_f32 a[112:127], %2, %3, a[112:127]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127")
-#define W1_MMA_8(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[128:143], %0, %1, a[128:143]\n\tv_mfma_f32_32x32x2_f32 a[128:143], %2, %3, a[128:143]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143")
-#define W1_MMA_9(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[144:159], %0, %1, a[144:159]\n\tv_mfma_f32_32x32x2_f32 a[144:159], %2, %3, a[144:159]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159")
-#define W1_MMA_10(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[160:175], %0, %1, a[160:175]\n\tv_mfma_f32_32x32x2_f32 a[160:175], %2, %3, a[160:175]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175")
-#define W1_MMA_11(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[176:191], %0, %1, a[176:191]\n\tv_mfma_f32_32x32x2_f32 a[176:191], %2, %3, a[176:191]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191")
-#define W1_MMA_12(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[192:207], %0, %1, a[192:207]\n\tv_mfma_f32_32x32x2_f32 a[192:207], %2, %3, a[192:207]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207")
-#define W1_MMA_13(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[208:223], %0, %1, a[208:223]\n\tv_mfma_f32_32x32x2_f32 a[208:223], %2, %3, a[208:223]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223")
-#define W1_MMA_14(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[224:239], %0, %1, a[224:239]\n\tv_mfma_f32_32x32x2_f32 a[224:239], %2, %3, a[224:239]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239")
-#define W1_MMA_15(A0, A1, B0, B1) asm volatile("v_mfma_f32_32x32x2_f32 a[240:255], %0, %1, a[240:255]\n\tv_mfma_f32_32x32x2_f32 a[240:255], %2, %3, a[240:255]" : : "v"(A0), "v"(B0), "v"(A1), "v"(B1) : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255")
-#define W1_MMA(p, U, B0, B1) W1_MMA_##p((U)[(p) >> 1][((p) & 1) * 2 + 0], (U)[(p) >> 1][((p) & 1) * 2 + 1], (B0)[p], (B1)[p])
-    // iteration it (par = it & 1): M(it) from (ucur, c0, c1); T(it + 1) from raw stage (it + 1) & 1 into (x0, x1); then W(it + 2)
-    // (rows loaded one iteration earlier) and the loads of rows(it + 3); U(it + 1) is requested at the top
-    auto iter = [&](int it, int par, f32x4 (&ucur)[8], f32x4 (&unext)[8], float (&c0)[16], float (&c1)[16], float (&x0)[16],
-                    float (&x1)[16]) {
-        G_u(clampc(it + 1), unext);
-        W1_FENCE();
-        W1_MMA(0, ucur, c0, c1);  T_read(par ^ 1, 0, x0);                 W1_FENCE();
-        W1_MMA(1, ucur, c0, c1);  T_read(par ^ 1, 1, x1);                 W1_FENCE();
-        W1_MMA(2, ucur, c0, c1);  T_col(x0, 0);                           W1_FENCE();
-        W1_MMA(3, ucur, c0, c1);  T_col(x0, 2);                           W1_FENCE();
-        W1_MMA(4, ucur, c0, c1);  T_col(x1, 0);                           W1_FENCE();
-        W1_MMA(5, ucur, c0, c1);  T_col(x1, 2);                           W1_FENCE();
-        W1_MMA(6, ucur, c0, c1);  T_rowp(x0, 0); T_rowp(x0, 1);           W1_FENCE();
-        W1_MMA(7, ucur, c0, c1);  T_rowp(x0, 2); T_rowp(x0, 3);           W1_FENCE();
-        W1_MMA(8, ucur, c0, c1);  T_rowp(x1, 0); T_rowp(x1, 1);           W1_FENCE();
-        W1_MMA(9, ucur, c0, c1);  T_rowp(x1, 2); T_rowp(x1, 3);           W1_FENCE();
-        W1_MMA(10, ucur, c0, c1); W_rows(par, rows);                      W1_FENCE();     // rows of chunk it + 2 -> raw stage (it + 2) & 1
-        W1_MMA(11, ucur, c0, c1); G_rows(clampc(it + 3), rows);           W1_FENCE();
-        W1_MMA(12, ucur, c0, c1);                                         W1_FENCE();
-        W1_MMA(13, ucur, c0, c1);                                         W1_FENCE();
-        W1_MMA(14, ucur, c0, c1);                                         W1_FENCE();
-        W1_MMA(15, ucur, c0, c1);                                         W1_FENCE();
+#define W1_ONE_0(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[0:15], %0, %1, a[0:15]" : : "v"(A), "v"(B) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15")
+#define W1_ONE_1(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[16:31], %0, %1, a[16:31]" : : "v"(A), "v"(B) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31")
+#define W1_ONE_2(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[32:47], %0, %1, a[32:47]" : : "v"(A), "v"(B) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47")
+#define W1_ONE_3(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[48:63], %0, %1, a[48:63]" : : "v"(A), "v"(B) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63")
+#define W1_ONE_4(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[64:79], %0, %1, a[64:79]" : : "v"(A), "v"(B) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79")
+#define W1_ONE_5(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[80:95], %0, %1, a[80:95]" : : "v"(A), "v"(B) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95")
+#define W1_ONE_6(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[96:111], %0, %1, a[96:111]" : : "v"(A), "v"(B) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111")
+#define W1_ONE_7(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[112:127], %0, %1, a[112:127]" : : "v"(A), "v"(B) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127")
+#define W1_ONE_8(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[128:143], %0, %1, a[128:143]" : : "v"(A), "v"(B) : "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143")
+#define W1_ONE_9(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[144:159], %0, %1, a[144:159]" : : "v"(A), "v"(B) : "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159")
+#define W1_ONE_10(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[160:175], %0, %1, a[160:175]" : : "v"(A), "v"(B) : "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175")
+#define W1_ONE_11(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[176:191], %0, %1, a[176:191]" : : "v"(A), "v"(B) : "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191")
+#define W1_ONE_12(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[192:207], %0, %1, a[192:207]" : : "v"(A), "v"(B) : "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207")
+#define W1_ONE_13(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[208:223], %0, %1, a[208:223]" : : "v"(A), "v"(B) : "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223")
+#define W1_ONE_14(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[224:239], %0, %1, a[224:239]" : : "v"(A), "v"(B) : "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239")
+#define W1_ONE_15(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[240:255], %0, %1, a[240:255]" : : "v"(A), "v"(B) : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255")
+// MFMA h (0: channels 0 / 2 of the chunk, 1: channels 1 / 3) of position p, then a slice of the staging work, then a fence.  ONE
+// MFMA per slot: a wave issues in order, so whatever stands behind an MFMA pair only gets the second one's 64-cycle shadow --
+// with 9 loads or 9 LDS writes in one slot the matrix pipe waited for the memory pipelines' issue
+#define W1_SLOT(p, h, U, B, work)                                                      \
+    W1_ONE_##p((U)[(p) >> 1][((p) & 1) * 2 + (h)], (B)[p]);                            \
+    work;                                                                              \
+    __builtin_amdgcn_sched_barrier(0)
+#define W1_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // iteration it (par = it & 1): M(it) from (ucur, c0, c1); T(it + 1) from raw stage (it + 1) & 1 into (x0, x1); W(it + 2) from
+    // the row set of this parity, which is then re-used for the loads of chunk it + 4; U(it + 2) is requested at the top
+    auto iter = [&](int it, int par, f32x4 (&ucur)[8], f32x4 (&ufar)[8], Rows &rows, float (&c0)[16], float (&c1)[16],
+                    float (&x0)[16], float (&x1)[16]) {
+        const int cu = clampc(it + 2), cr = clampc(it + 4);
+        W1_SLOT(0, 0, ucur, c0, T_read2(par ^ 1, 0, x0, 0));
+        W1_SLOT(0, 1, ucur, c1, T_read2(par ^ 1, 0, x0, 2));
+        W1_SLOT(1, 0, ucur, c0, T_read2(par ^ 1, 1, x1, 0));
+        W1_SLOT(1, 1, ucur, c1, T_read2(par ^ 1, 1, x1, 2));
+        W1_SLOT(2, 0, ucur, c0, T_col(x0, 0));
+        W1_SLOT(2, 1, ucur, c1, T_col(x0, 2));
+        W1_SLOT(3, 0, ucur, c0, T_col(x1, 0));
+        W1_SLOT(3, 1, ucur, c1, T_col(x1, 2));
+        W1_SLOT(4, 0, ucur, c0, T_rowp(x0, 0));
+        W1_SLOT(4, 1, ucur, c1, T_rowp(x0, 1));
+        W1_SLOT(5, 0, ucur, c0, T_rowp(x0, 2));
+        W1_SLOT(5, 1, ucur, c1, T_rowp(x0, 3));
+        W1_SLOT(6, 0, ucur, c0, T_rowp(x1, 0));
+        W1_SLOT(6, 1, ucur, c1, T_rowp(x1, 1));
+        W1_SLOT(7, 0, ucur, c0, T_rowp(x1, 2));
+        W1_SLOT(7, 1, ucur, c1, T_rowp(x1, 3));
+        W1_SLOT(8, 0, ucur, c0, G_u1(cu, ufar, 0));
+        W1_SLOT(8, 1, ucur, c1, G_u1(cu, ufar, 1));
+        W1_SLOT(9, 0, ucur, c0, G_u1(cu, ufar, 2));
+        W1_SLOT(9, 1, ucur, c1, G_u1(cu, ufar, 3));
+        W1_SLOT(10, 0, ucur, c0, G_u1(cu, ufar, 4));
+        W1_SLOT(10, 1, ucur, c1, G_u1(cu, ufar, 5));
+        W1_SLOT(11, 0, ucur, c0, G_u1(cu, ufar, 6));
+        W1_SLOT(11, 1, ucur, c1, G_u1(cu, ufar, 7));
+        // rows of chunk it + 2 -> raw stage (it + 2) & 1, each register pair re-requested for chunk it + 4 right after its store
+        W1_SLOT(12, 0, ucur, c0, W_row1(par, rows, 0); W_row1(par, rows, 1); G_row1(cr, rows, 0));
+        W1_SLOT(12, 1, ucur, c1, W_row1(par, rows, 2); G_row1(cr, rows, 1));
+        W1_SLOT(13, 0, ucur, c0, W_row1(par, rows, 3); G_row1(cr, rows, 2));
+        W1_SLOT(13, 1, ucur, c1, W_row1(par, rows, 4); G_row1(cr, rows, 3));
+        W1_SLOT(14, 0, ucur, c0, W_row1(par, rows, 5); G_row1(cr, rows, 4));
+        W1_SLOT(14, 1, ucur, c1, W_row1(par, rows, 6); G_row1(cr, rows, 5));
+        W1_SLOT(15, 0, ucur, c0, W_row1(par, rows, 7); G_row1(cr, rows, 6));
+        W1_SLOT(15, 1, ucur, c1, W_row1(par, rows, 8); G_row1(cr, rows, 7); G_row1(cr, rows, 8));
     };
-    for (int it = 0; it < g.nch; it += 2) {
-        iter(it, 0, ua, ub, b0, b1, n0v, n1v);
-        if (it + 1 < g.nch) iter(it + 1, 1, ub, ua, n0v, n1v, b0, b1);
+    for (int it = 0; it < g.nch; it += 6) {
+        iter(it, 0, u0, u2, rw0, b0, b1, n0v, n1v);
+        if (it + 1 < g.nch) iter(it + 1, 1, u1, u0, rw1, n0v, n1v, b0, b1);
+        if (it + 2 < g.nch) iter(it + 2, 0, u2, u1, rw0, b0, b1, n0v, n1v);
+        if (it + 3 < g.nch) iter(it + 3, 1, u0, u2, rw1, n0v, n1v, b0, b1);
+        if (it + 4 < g.nch) iter(it + 4, 0, u1, u0, rw0, b0, b1, n0v, n1v);
+        if (it + 5 < g.nch) iter(it + 5, 1, u2, u1, rw1, n0v, n1v, b0, b1);
     }
 
     // ---- epilogue: Y = A^T M A in registers (M[i][j] = acc[4 i + j]),  A^T = [1 1 1 0; 0 1 -1 -1]
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // (the last MFMA's result is read below: the compiler cannot see into the asm)
-    const int64_t tg = t0 + li;
-    const bool tv = tg < g.tiles_total;
-    const int n = (int)(tg / g.tiles_img), r = (int)(tg % g.tiles_img);
-    const int ty = r / g.tw, tx = r % g.tw;
+    const unsigned tg = t0 + li;
+    const bool tv = tg < ttot;
+    const int n = (int)(tg / timg), r = (int)(tg % timg);
+    const int ty = (int)((unsigned)r / twu), tx = (int)((unsigned)r % twu);
     float *yout = y + ((int64_t)n * g.M) * HW + (2 * ty) * g.W + 2 * tx;
 #define W1_RD_0(m) asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a16\n\tv_accvgpr_read_b32 %2, a32\n\tv_accvgpr_read_b32 %3, a48\n\tv_accvgpr_read_b32 %4, a64\n\tv_accvgpr_read_b32 %5, a80\n\tv_accvgpr_read_b32 %6, a96\n\tv_accvgpr_read_b32 %7, a112\n\tv_accvgpr_read_b32 %8, a128\n\tv_accvgpr_read_b32 %9, a144\n\tv_accvgpr_read_b32 %10, a160\n\tv_accvgpr_read_b32 %11, a176\n\tv_accvgpr_read_b32 %12, a192\n\tv_accvgpr_read_b32 %13, a208\n\tv_accvgpr_read_b32 %14, a224\n\tv_accvgpr_read_b32 %15, a240" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
 #define W1_RD_1(m) asm volatile("v_accvgpr_read_b32 %0, a1\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a33\n\tv_accvgpr_read_b32 %3, a49\n\tv_accvgpr_read_b32 %4, a65\n\tv_accvgpr_read_b32 %5, a81\n\tv_accvgpr_read_b32 %6, a97\n\tv_accvgpr_read_b32 %7, a113\n\tv_accvgpr_read_b32 %8, a129\n\tv_accvgpr_read_b32 %9, a145\n\tv_accvgpr_read_b32 %10, a161\n\tv_accvgpr_read_b32 %11, a177\n\tv_accvgpr_read_b32 %12, a193\n\tv_accvgpr_read_b32 %13, a209\n\tv_accvgpr_read_b32 %14, a225\n\tv_accvgpr_read_b32 %15, a241" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
@@ -776,7 +830,7 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
                 s2[e] += __shfl_xor(s2[e], off);
             }
         if (li == 0) {
-            const int64_t nruns = (g.tiles_total + W1_T - 1) / W1_T;
+            const unsigned nruns = (ttot + W1_T - 1) / W1_T;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -824,6 +878,7 @@ extern "C" int cpg_conv3x3_wino_ok(int N, int c_read, int m, int H, int W) {
     if (H % 2 || W % 2 || c_read % 4 || c_read < 16 || m < 16 || N < 1) return 0;
     const int tiles_img = (H / 2) * (W / 2);
     const int span = (WG_T + tiles_img - 1) / tiles_img + 1;
+    if ((int64_t)N * tiles_img + 64 >= (1ll << 31)) return 0;               // 32-bit tile indices in the kernels
     return (int64_t)span * c_read * H * W * 4 < (1ll << 31);
 }
 
