@@ -1,0 +1,271 @@
+// Masked 3x3 / stride 1 / pad 1 convolution: WEIGHT gradient by Winograd F(2x2, 3x3) on fp32 MFMA.
+//
+//   dg = G^T [ sum over tiles (A dY A^T) .* (B^T d B) ] G        (dY: 2x2 tile of gy, d: the 4x4 input patch of that tile)
+//
+// the adjoint of conv3x3_wino.hip's forward: per transform position p one GEMM  M_p[k][c] = sum_t P_p[k][t] * V_p[c][t]  over the
+// tiles t -- 16 multiplies per tile and channel pair instead of 36 -- and a 4x4 -> 3x3 output transform per (k, c) at the end.
+// Same design as k_wg1: ONE WAVE = ONE UNIT (32 output channels x 32 input channels x all 16 positions, 256 accumulators in fixed
+// AGPRs, one wave per SIMD), no barriers.  The MFMA's k dimension is a PAIR OF TILES (lanes 0-31: even tile, 32-63: odd tile):
+// lane (li, lh) transforms the gy tile of output channel li and the input patch of input channel li for its tile of the pair --
+// those 16 + 16 values are its A and B operands.  Channels are lanes here, pixels are what the global loads coalesce over, so
+// the raw rows are transposed through (wave-private) LDS:
+//   stage = 14 consecutive tiles of one tile row (every VGG16 map is a multiple of 14 tiles wide, so a stage never straddles a row
+//           end and the only halo is the one at its two ends): 7 k-steps of 16 MFMAs.
+//   G  global -> registers: 16 byte per lane (two tiles' column pairs), lanes = (8 quads x 8 (channel, row) items): 16 loads for x,
+//      8 for gy, 4 dword loads for the halo columns; all offsets are a per-lane constant + a scalar stage base.
+//   W  registers -> LDS  x_raw[c][row][16 slots][2], gy_raw[k][row][14][2]  (channel strides 130 / 58 words: conflict-free reads)
+//   T  per k-step: lane reads its patch (ds_read_b64 + ds_read2_b32 per row) and gy tile, 32 + 12 adds -> B and A operands
+//   M  16 MFMAs per k-step, one per schedule slot, with one slice of T / W / G behind each (sched_barrier fences).
+// ONE LDS buffer per wave: a wave's LDS operations complete in order, so the last k-step of a stage first stores the next
+// stage's rows (loaded five k-steps earlier) and then reads the next stage's first operands.
+// Split over tile ranges; the partial sums land in part[split][tap][k][c], which k_split_reduce (igemm_core.h) adds up and passes
+// through the autograd epilogue (gW = g * bin(pm), gPM = g * W) exactly as for the direct kernels.
+// The sign of the transform rows / columns with a -1 (A's last row) is applied to M in the epilogue instead of to the operands.
+#include <algorithm>
+#include "igemm_core.h"
+
+using namespace cpg;
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WW_XC = 130, WW_GC = 58;              // channel strides (floats) of the raw rows in LDS
+constexpr int WW_XS = 32 * WW_XC;                   // 4160
+constexpr int WW_STAGE = WW_XS + 32 * WW_GC;        // 6016 floats = 23.5 KB
+
+struct WwGeom {
+    int N, C, K, H, W;
+    int th, tw, nseg;         // tile rows / tiles per row / 14-tile segments per row
+    unsigned nstages;         // N * th * nseg
+    int nkb, ncb, nsplit;
+    unsigned su;              // stages per unit
+    int span;                 // images a unit can touch
+};
+
+@@MMA@@
+@@RD@@
+#define WW_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float smem_all[4 * WW_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    float *smem = smem_all + wave * WW_STAGE;
+    const int HW = g.H * g.W;
+    const unsigned npairs = (unsigned)(g.nkb * g.ncb);
+    const unsigned u = blockIdx.x * 4 + wave;
+    if (u >= npairs * (unsigned)g.nsplit) return;                // (no barriers anywhere: a wave may leave)
+    const unsigned pair = u % npairs, split = u / npairs;
+    const int kb = (int)(pair % (unsigned)g.nkb), cb = (int)(pair / (unsigned)g.nkb);
+    const unsigned s_begin = split * g.su;
+    const int nst = (int)min(g.su, g.nstages - s_begin);
+    // loader coordinates (uniform): the stage whose loads are issued next -> image n, tile row ty, segment tseg
+    const unsigned per_img = (unsigned)(g.th * g.nseg);
+    int n = (int)(s_begin / per_img);
+    const unsigned r0 = s_begin % per_img;
+    int ty = (int)(r0 / (unsigned)g.nseg), tseg = (int)(r0 % (unsigned)g.nseg);
+    const int n0 = n;
+    const int nimg_here = min(g.span, g.N - n0);
+    // x descriptor: base one row and four pixels (16 bytes: the base stays 16-byte aligned for the dwordx4 loads) BELOW the first image, so that the row / column "- 1" of the patch never makes a
+    // per-lane offset negative (only the per-lane part of an offset is range-checked; out-of-image elements get 0x80000000)
+    const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(x + (int64_t)n0 * g.C * HW - (g.W + 4)), 0, nimg_here * g.C * HW * 4 + (g.W + 4) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_g =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(gy + (int64_t)n0 * g.K * HW), 0, nimg_here * g.K * HW * 4, 0x00020000);
+
+    // ---- per-lane constants of G and W ----
+    constexpr int kOOR = (int)0x80000000;
+    // quad (tiles 2 qd, 2 qd + 1) and (channel, row) item of this lane.  Seven quads per 14-tile row: the eighth lane of a group
+    // repeats the seventh (same address, same data -- a dump address would need the per-instruction offset removed again)
+    const int qd = min(lane & 7, 6), rem = lane >> 3;
+    const int xrow = rem & 3;
+    const int vx_const = ((rem >> 2) * HW + xrow * g.W) * 4 + qd * 16 + 16;         // x item (c = 2 j + rem / 4, row = rem % 4)
+    const int vg_const = ((rem >> 1) * HW + (rem & 1) * g.W) * 4 + qd * 16;         // gy item (k = 4 j + rem / 2, row = rem % 2)
+    const int hside = lane & 1, hrow = (lane >> 1) & 3;                             // halo item (c = 8 j + lane / 8, row, side)
+    const int vh_const = ((lane >> 3) * HW + hrow * g.W) * 4 + (hside ? 28 * 4 + 16 : 12);
+    const int xw_addr = (rem >> 2) * WW_XC + xrow * 32 + 2 + 4 * qd;
+    const int gw_addr = WW_XS + (rem >> 1) * WW_GC + (rem & 1) * 28 + 4 * qd;
+    const int hw_addr = (lane >> 3) * WW_XC + hrow * 32 + (hside ? 30 : 1);
+    int sx, sgo, vx, vg, vh;                                     // stage part of the offsets (scalar) / per-lane part with validity
+    auto stage_offsets = [&]() {
+        sx = (((n - n0) * g.C + cb * 32) * HW + 2 * ty * g.W + 28 * tseg) * 4;
+        sgo = (((n - n0) * g.K + kb * 32) * HW + 2 * ty * g.W + 28 * tseg) * 4;
+        const bool top = ty == 0, bot = ty == g.th - 1;
+        vx = ((xrow == 0 && top) || (xrow == 3 && bot)) ? kOOR : vx_const;
+        vg = vg_const;
+        vh = ((hrow == 0 && top) || (hrow == 3 && bot) || (hside == 0 && tseg == 0) || (hside == 1 && tseg == g.nseg - 1)) ? kOOR : vh_const;
+    };
+    auto advance_stage = [&]() {
+        if (++tseg == g.nseg) {
+            tseg = 0;
+            if (++ty == g.th) ty = 0, ++n;
+        }
+        stage_offsets();
+    };
+    i32x4 rx[16], rg[8];
+    float rh[4];
+    auto g_load = [&](int idx, int) {
+        if (idx < 16)
+            rx[idx] = __builtin_amdgcn_raw_buffer_load_b128(srd_x, vx, sx + idx * 2 * HW * 4, 0);
+        else if (idx < 24)
+            rg[idx - 16] = __builtin_amdgcn_raw_buffer_load_b128(srd_g, vg, sgo + (idx - 16) * 4 * HW * 4, 0);
+        else
+            rh[idx - 24] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, vh, sx + (idx - 24) * 8 * HW * 4, 0));
+    };
+    auto w_store = [&](int idx) {
+        if (idx < 16) {
+            i32x2 *d = reinterpret_cast<i32x2 *>(smem + xw_addr + idx * 2 * WW_XC);
+            i32x2 lo, hi;
+            lo[0] = rx[idx][0], lo[1] = rx[idx][1], hi[0] = rx[idx][2], hi[1] = rx[idx][3];
+            d[0] = lo, d[1] = hi;
+        } else if (idx < 24) {
+            i32x2 *d = reinterpret_cast<i32x2 *>(smem + gw_addr + (idx - 16) * 4 * WW_GC);
+            i32x2 lo, hi;
+            lo[0] = rg[idx - 16][0], lo[1] = rg[idx - 16][1], hi[0] = rg[idx - 16][2], hi[1] = rg[idx - 16][3];
+            d[0] = lo, d[1] = hi;
+        } else {
+            smem[hw_addr + (idx - 24) * 8 * WW_XC] = rh[idx - 24];
+        }
+    };
+    // ---- T: operands of k-step ks (tile 2 ks + lh of the stage in LDS), in 14 micro steps ----
+    const int xr_base = li * WW_XC + (lh + 1) * 2, gr_base = WW_XS + li * WW_GC + lh * 2;
+    auto t_micro = [&](int m, int ks, float (&A)[16], float (&B)[16]) {
+        if (m < 4) {                                             // patch row m: own pair + the neighbours' halves
+            const float *r = smem + xr_base + 4 * ks + m * 32;
+            const f32x2 own = *reinterpret_cast<const f32x2 *>(r);
+            B[m * 4 + 0] = r[-1], B[m * 4 + 1] = own[0], B[m * 4 + 2] = own[1], B[m * 4 + 3] = r[2];
+        } else if (m == 4) {                                     // the gy tile: A[0] = y00, A[3] = y01, A[12] = y10, A[15] = y11
+            const f32x2 y0 = *reinterpret_cast<const f32x2 *>(smem + gr_base + 4 * ks);
+            const f32x2 y1 = *reinterpret_cast<const f32x2 *>(smem + gr_base + 4 * ks + 28);
+            A[0] = y0[0], A[3] = y0[1], A[12] = y1[0], A[15] = y1[1];
+        } else if (m < 7) {                                      // V = B^T d B: column pass of columns 2 (m - 5), + 1
+#pragma unroll
+            for (int j = 2 * (m - 5); j < 2 * (m - 5) + 2; ++j) {
+                const float d0 = B[0 * 4 + j], d1 = B[1 * 4 + j], d2 = B[2 * 4 + j], d3 = B[3 * 4 + j];
+                B[0 * 4 + j] = d0 - d2, B[1 * 4 + j] = d1 + d2, B[2 * 4 + j] = d2 - d1, B[3 * 4 + j] = d1 - d3;
+                asm volatile("" : "+v"(B[0 * 4 + j]), "+v"(B[1 * 4 + j]), "+v"(B[2 * 4 + j]), "+v"(B[3 * 4 + j]));
+            }
+        } else if (m < 11) {                                     // ... row pass of row m - 7
+            const int i = m - 7;
+            const float t0 = B[i * 4 + 0], t1 = B[i * 4 + 1], t2 = B[i * 4 + 2], t3 = B[i * 4 + 3];
+            B[i * 4 + 0] = t0 - t2, B[i * 4 + 1] = t1 + t2, B[i * 4 + 2] = t2 - t1, B[i * 4 + 3] = t1 - t3;
+            asm volatile("" : "+v"(B[i * 4 + 0]), "+v"(B[i * 4 + 1]), "+v"(B[i * 4 + 2]), "+v"(B[i * 4 + 3]));
+        } else if (m == 11) {                                    // P' = A dY A^T without the signs: rows 1, 2 of A dY
+            A[4] = A[0] + A[12], A[7] = A[3] + A[15], A[8] = A[0] - A[12], A[11] = A[3] - A[15];
+            asm volatile("" : "+v"(A[4]), "+v"(A[7]), "+v"(A[8]), "+v"(A[11]));
+        } else if (m == 12) {                                    // ... columns 1, 2 of rows 0, 1
+            A[1] = A[0] + A[3], A[2] = A[0] - A[3], A[5] = A[4] + A[7], A[6] = A[4] - A[7];
+            asm volatile("" : "+v"(A[1]), "+v"(A[2]), "+v"(A[5]), "+v"(A[6]));
+        } else if (m == 13) {                                    // ... of rows 2, 3
+            A[9] = A[8] + A[11], A[10] = A[8] - A[11], A[13] = A[12] + A[15], A[14] = A[12] - A[15];
+            asm volatile("" : "+v"(A[9]), "+v"(A[10]), "+v"(A[13]), "+v"(A[14]));
+        }
+    };
+
+@@ZERO@@
+    float A0[16], B0[16], A1[16], B1[16];
+    // prologue: stage 0 into LDS, its first operands, stage 1's coordinates ready
+    stage_offsets();
+#pragma unroll
+    for (int i = 0; i < 28; ++i) g_load(i, 0);
+#pragma unroll
+    for (int i = 0; i < 28; ++i) w_store(i);
+    advance_stage();
+#pragma unroll
+    for (int m = 0; m < 14; ++m) t_micro(m, 0, A0, B0);
+
+    for (int st = 0; st < nst; st += 2) {
+@@BODY@@
+    }
+
+    // ---- epilogue: dg = G^T M G per (k, c); M[i][j] = sigma_i sigma_j acc[4 i + j], sigma = (1, 1, 1, -1) ----
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    float *pout = part + ((int64_t)split * 9 * g.K + kb * 32) * g.C + cb * 32 + li;
+    const int64_t tap_plane = (int64_t)g.K * g.C;
+    auto out_e = [&](int e, float (&m)[16]) {
+        m[3] = -m[3], m[7] = -m[7], m[11] = -m[11], m[12] = -m[12], m[13] = -m[13], m[14] = -m[14];
+        float t[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s = 0.5f * (m[4 + j] + m[8 + j]), d = 0.5f * (m[4 + j] - m[8 + j]);
+            t[0][j] = m[j] + s, t[1][j] = d, t[2][j] = s + m[12 + j];
+        }
+        float *dst = pout + (int64_t)((e & 3) + 8 * (e >> 2) + 4 * lh) * g.C;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float s = 0.5f * (t[r][1] + t[r][2]), d = 0.5f * (t[r][1] - t[r][2]);
+            dst[(r * 3 + 0) * tap_plane] = t[r][0] + s;
+            dst[(r * 3 + 1) * tap_plane] = d;
+            dst[(r * 3 + 2) * tap_plane] = s + t[r][3];
+        }
+    };
+    {
+        float m[16];
+@@OUT@@
+    }
+}
+
+inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+struct WwPlan {
+    WwGeom g;
+    size_t ws_bytes;
+    int64_t blocks;
+};
+
+bool ww_plan(const cpg_conv_desc *d, WwPlan &p) {
+    if (getenv("CPG_NO_WINO") || getenv("CPG_NO_WINO_WGRAD")) return false;
+    if (d->R != 3 || d->S != 3 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 1 || d->pad_w != 1 || d->dil_h != 1 ||
+        d->dil_w != 1 || d->groups != 1)
+        return false;
+    if (d->H % 2 || d->W % 28 || d->C % 32 || d->K % 32 || d->N < 1) return false;
+    WwGeom &g = p.g;
+    g.N = d->N, g.C = d->C, g.K = d->K, g.H = d->H, g.W = d->W;
+    g.th = d->H / 2, g.tw = d->W / 2, g.nseg = g.tw / 14;
+    const int64_t nstages = (int64_t)d->N * g.th * g.nseg;
+    if (nstages >= (1ll << 28)) return false;
+    g.nstages = (unsigned)nstages;
+    g.nkb = d->K / 32, g.ncb = d->C / 32;
+    const int64_t npairs = (int64_t)g.nkb * g.ncb;
+    int64_t want = std::max<int64_t>(1, (6 * 4 * kCUs) / npairs);              // ~6 units per wave slot
+    want = std::min<int64_t>(want, nstages);
+    g.su = (unsigned)((nstages + want - 1) / want);
+    g.nsplit = (int)((nstages + g.su - 1) / g.su);
+    const int64_t per_img = (int64_t)g.th * g.nseg;
+    g.span = (int)((g.su + per_img - 1) / per_img) + 1;
+    const int64_t HW = (int64_t)d->H * d->W;
+    if ((int64_t)g.span * std::max(d->C, d->K) * HW * 4 + (d->W + 4) * 4 >= (1ll << 31)) return false;
+    p.ws_bytes = (size_t)g.nsplit * 9 * d->K * d->C * sizeof(float);
+    p.blocks = (npairs * g.nsplit + 3) / 4;
+    return p.blocks <= 0x7FFFFFFFll;
+}
+
+}  // namespace
+
+extern "C" int cpg_conv3x3_wino_wgrad_ok(const cpg_conv_desc *d) {
+    WwPlan p;
+    return ww_plan(d, p) ? 1 : 0;
+}
+
+extern "C" size_t cpg_conv3x3_wino_wgrad_workspace(const cpg_conv_desc *d) {
+    WwPlan p;
+    return ww_plan(d, p) ? p.ws_bytes : 0;
+}
+
+extern "C" int cpg_conv3x3_wino_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
+                                      float *gw, float *gpm, void *ws, size_t ws_bytes, hipStream_t stream) {
+    WwPlan p;
+    if (!ww_plan(d, p)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_wgrad(winograd): shape not supported");
+    if (ws == nullptr || ws_bytes < p.ws_bytes)
+        return fail(CPG_E_WORKSPACE, "cpg_conv2d_wgrad(winograd): workspace %zu < %zu bytes", ws_bytes, p.ws_bytes);
+    hipLaunchKernelGGL(k_wgw, dim3((unsigned)p.blocks), dim3(256), 0, stream, p.g, x, gy, (float *)ws);
+    Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
+    const int64_t out_elems = (int64_t)d->K * d->C * 9;
+    launch_split_reduce((const float *)ws, p.g.nsplit, out_elems, (int64_t)d->K * d->C, ep, stream);
+    CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(winograd)");
+    return CPG_OK;
+}
