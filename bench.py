@@ -96,6 +96,9 @@ class KernelClock:
         def wino_dgrad(args):
             return bool(lib.cpg_conv2d_winograd(args[0], 1))
 
+        def wino_wgrad(args):
+            return bool(lib.cpg_conv2d_winograd(args[0], 2))
+
         def conv_kind(prefix):
             def k(args):
                 d = args[0]._obj
@@ -126,7 +129,7 @@ class KernelClock:
         # (same contraction; its epilogue also does the BatchNorm-backward reduction of the layer below)
         p.cpg_conv2d_dgrad_bnbwd = timed('cpg_conv2d_dgrad_bnbwd', conv_kind('conv_dgrad'), conv_flops)
         p.cpg_conv2d_dgrad = timed('cpg_conv2d_dgrad', conv_kind('conv_dgrad'), conv_flops, wino_dgrad)
-        p.cpg_conv2d_wgrad = timed('cpg_conv2d_wgrad', conv_kind('conv_wgrad'), conv_flops)
+        p.cpg_conv2d_wgrad = timed('cpg_conv2d_wgrad', conv_kind('conv_wgrad'), conv_flops, wino_wgrad)
         p.cpg_linear_fwd = timed('cpg_linear_fwd', lambda a: 'linear_fwd', lin_flops(6))
         p.cpg_linear_dgrad = timed('cpg_linear_dgrad', lambda a: 'linear_dgrad', lin_flops(5))
         p.cpg_linear_wgrad = timed('cpg_linear_wgrad', lambda a: 'linear_wgrad', lin_flops(8))

@@ -1101,7 +1101,13 @@ inline int w3_pick(const cpg_conv_desc *d) {
 }
 }  // namespace
 
+extern "C" int cpg_conv3x3_wino_wgrad_ok(const cpg_conv_desc *d);
+extern "C" size_t cpg_conv3x3_wino_wgrad_workspace(const cpg_conv_desc *d);
+extern "C" int cpg_conv3x3_wino_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
+                                      float *gw, float *gpm, void *ws, size_t ws_bytes, hipStream_t stream);
+
 size_t cpg_conv3x3_wgrad_workspace(const cpg_conv_desc *d) {
+    if (cpg_conv3x3_wino_wgrad_ok(d)) return cpg_conv3x3_wino_wgrad_workspace(d);
     if (d->C <= 3) {            // stem kernel: same formula as ws_plan() below
         const int tiles = ((d->W + 31) / 32) * ((d->H + 3) / 4);
         const int64_t units = (int64_t)d->N * tiles;
@@ -1157,6 +1163,8 @@ WSPlan ws_plan(const cpg_conv_desc *d) {
 
 int cpg_conv3x3_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
                       float *gw, float *gpm, void *ws, size_t ws_bytes, hipStream_t stream) {
+    // Winograd F(2x2, 3x3) weight gradient (conv3x3_wino_wgrad.hip): maps a multiple of 28 wide, channel counts multiples of 32
+    if (cpg_conv3x3_wino_wgrad_ok(d)) return cpg_conv3x3_wino_wgrad(d, x, gy, w, pm, thr, gw, gpm, ws, ws_bytes, stream);
     Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
     if (d->C <= WSCfg::CMAX) {
         const WSPlan p = ws_plan(d);

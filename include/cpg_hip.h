@@ -195,14 +195,16 @@ int cpg_bn_relu_bwd(const float *x, const float *gy, const float *gamma, const f
                     const float *invstd, float *gx, float *dgamma, float *dbeta, int32_t N, int32_t C,
                     int32_t HW, int32_t relu, int32_t train, void *ws, size_t ws_bytes, void *stream);
 
-/* Which arithmetic a training-time launch of this shape uses.  cpg_conv2d_fwd, cpg_conv2d_fwd_bnstats (dgrad = 0) and
- * cpg_conv2d_dgrad (dgrad = 1) run 3x3 / stride 1 / pad 1 layers on even-sized maps with >= 16 channels on both sides (a multiple
+/* Which arithmetic a training-time launch of this shape uses (pass: 0 forward, 1 input gradient, 2 weight gradient).
+ * cpg_conv2d_fwd, cpg_conv2d_fwd_bnstats (0) and cpg_conv2d_dgrad (1) run 3x3 / stride 1 / pad 1 layers on even-sized maps with >= 16 channels on both sides (a multiple
  * of 4 on the contracted side) by Winograd F(2x2, 3x3): 16 instead of 36 multiplies per 2x2 output tile and channel pair, the
  * same sums in a different association -- 1-4e-6 of the output scale from fp64 where the direct kernels are at 0.5-1e-6; the
  * reference's own F.conv2d (models/layers.py:106-109) takes whichever algorithm cuDNN / MIOpen picks, Winograd included.
  * Returns 1 for such a launch, 0 for the direct / generic kernels.  Setting CPG_NO_WINO in the environment (read per call)
- * forces 0 everywhere.  cpg_conv2d_wgrad, cpg_conv2d_fwd_bn_eval and the bf16 entry points never use it. */
-int32_t cpg_conv2d_winograd(const cpg_conv_desc *desc, int32_t dgrad);
+ * forces 0 everywhere.  cpg_conv2d_wgrad (2) uses the adjoint transform for maps that are a multiple of 28 pixels wide with channel counts that are
+ * multiples of 32 (CPG_NO_WINO_WGRAD forces the direct kernels for this pass only).  cpg_conv2d_fwd_bn_eval and the bf16 entry
+ * points never use it. */
+int32_t cpg_conv2d_winograd(const cpg_conv_desc *desc, int32_t pass);
 
 /* Conv forward fused with the statistics pass of the BatchNorm2d that follows it in every CPG topology
  * (models/vgg.py:137-141 `conv2d, BatchNorm2d, ReLU`): the kernel that produces y also writes, per output channel and

@@ -216,6 +216,51 @@ def test_winograd_matches_direct(N, C, H, W, K, bias, pm, nw, monkeypatch):
     assert not torch.equal(y1, y0) or N * H * W < 64                         # (the two paths really are different kernels)
 
 
+@pytest.mark.parametrize('N,C,H,W,K,pm', [
+    (1, 32, 28, 28, 32, False),        # one 14-tile segment per tile row, 14 stages: every unit is a single stage
+    (5, 96, 28, 28, 64, True),         # odd image count, 3 x 2 channel blocks, piggymask (the reduce kernel's autograd epilogue)
+    (2, 32, 56, 56, 32, False),        # two segments per row: left / right halo between segments and at the image border
+    (3, 64, 2, 28, 32, True),          # a single tile row: the patch's top and bottom rows are both padding
+    (2, 32, 14, 56, 64, False),        # H != W
+    (40, 32, 28, 28, 32, False),       # more stages than units can take one at a time: several stages per unit, stage hand-over
+    (2, 64, 112, 112, 64, False),      # four segments per row
+])
+def test_winograd_wgrad_matches_direct(N, C, H, W, K, pm, monkeypatch):
+    """The Winograd weight-gradient kernel (conv3x3_wino_wgrad.hip: the default for maps a multiple of 28 wide with channel counts
+    that are multiples of 32) against the direct kernel (CPG_NO_WINO_WGRAD=1) and fp64, bit-identical when repeated."""
+    import ctypes
+    from cpg_amd import _lib
+    assert _lib.lib().cpg_conv2d_winograd(ctypes.byref(nl._conv_desc((N, C, H, W), (K, C, 3, 3), (1, 1), (1, 1), (1, 1), 1)), 2) == 1
+    g = torch.Generator().manual_seed(N + C + K + W)
+    x = torch.randn(N, C, H, W, generator=g).relu_()
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.1
+    pmv = torch.rand(K, C, 3, 3, generator=g) * 0.012 if pm else None
+    gy = torch.randn(N, K, H, W, generator=g)
+    layer = nl.SharableConv2d(C, K, 3, padding=1, bias=False).to(DEV)
+    layer.weight.data.copy_(w)
+    if pm:
+        layer.piggymask = nn.Parameter(pmv.to(DEV))
+
+    def run():
+        layer.zero_grad()
+        y = layer(x.to(DEV))
+        y.backward(gy.to(DEV))
+        return layer.weight.grad.cpu().double(), (layer.piggymask.grad.cpu().double() if pm else None)
+    g1, p1 = run()
+    g2, p2 = run()
+    assert torch.equal(g1, g2) and (not pm or torch.equal(p1, p2))
+    monkeypatch.setenv('CPG_NO_WINO_WGRAD', '1')
+    g0, p0 = run()
+    raw = nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), padding=1)
+    ref_w = raw * (pmv > 5e-3).double() if pm else raw
+    sc = float(raw.abs().max())
+    assert float((g1 - ref_w).abs().max()) < 1e-5 * sc and float((g0 - ref_w).abs().max()) < 1e-5 * sc
+    assert not torch.equal(g1, g0)
+    if pm:
+        ref_p = raw * w.double()
+        assert float((p1 - ref_p).abs().max()) < 1e-5 * float(ref_p.abs().max())
+
+
 @pytest.mark.parametrize('B,I,O,pm', [(32, 25088, 512, False), (256, 4096, 4096, True), (7, 513, 129, True), (1, 64, 5, False),
                                       (256, 4096, 4096, False), (100, 1024, 256, False), (48, 260, 384, False),
                                       # features.45 of config 2 at its own shape (89 % of all masked weights), both mask modes,
