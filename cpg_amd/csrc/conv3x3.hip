@@ -857,6 +857,11 @@ inline size_t pack_bytes(int c_read, int m) { return (pack_floats(c_read, m) + l
 extern "C" int cpg_conv3x3_wino_ok(int N, int c_read, int m, int H, int W);
 extern "C" size_t cpg_conv3x3_wino_pack_bytes(int c_read, int m);
 extern "C" int cpg_conv3x3_wino_tiles(int N, int H, int W);
+extern "C" int cpg_conv3x3_wino_eval_ok(int N, int c_read, int m, int H, int W);
+extern "C" int cpg_conv3x3_wino_run_bn_eval(int N, int C, int K, int H, int W, const float *x, const float *w, const float *pm, float thr,
+                                            const float *bias, const float *gamma, const float *beta, const float *mean, const float *var,
+                                            float eps, int relu, int *live, size_t live_words, float *y, void *ws, size_t ws_bytes,
+                                            hipStream_t stream);
 extern "C" int cpg_conv3x3_wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, int C, const float *x, const float *w,
                                     const float *pm, float thr, const float *bias, float *y, float *stats, void *ws, size_t ws_bytes,
                                     hipStream_t stream);
@@ -912,6 +917,15 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
         if (tiles_out) *tiles_out = cpg_conv3x3_wino_tiles(N, H, W);
         if (dry) return CPG_OK;
         return cpg_conv3x3_wino_run(dgrad ? 1 : 0, N, c_read, m, H, W, K, C, x, w, pm, thr, bias, y, stats, ws, ws_bytes, stream);
+    }
+    // ... and the inference forward with the eval-mode BatchNorm epilogue and the dead-channel skip (k_wg1<.., BNE>).  Workspace layout:
+    // [the direct kernels' packed-weight region (unused) | liveness words, where cpg_conv3x3_fwd_bn_eval looks for them | U]
+    if (bn != nullptr && bb == nullptr && !dgrad && stats == nullptr && !dry && cpg_conv3x3_wino_eval_ok(N, c_read, m, H, W)) {
+        const size_t off = (pack_bytes(c_read, m) + 15) / 16 * 16;
+        if (ws == nullptr || ws_bytes < off) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, off);
+        int *live = bn->live != nullptr ? reinterpret_cast<int *>((float *)ws + pack_floats(c_read, m)) : nullptr;
+        return cpg_conv3x3_wino_run_bn_eval(N, c_read, m, H, W, x, w, pm, thr, bias, bn->gamma, bn->beta, bn->mean, bn->var, bn->eps, bn->relu,
+                                            live, live_words(c_read, m), y, (char *)ws + off, ws_bytes - off, stream);
     }
     float *wp = (float *)ws;
     const int rows_c = pad_to(c_read, 4), Mp = pad_to(m, 128);
@@ -988,8 +1002,8 @@ extern "C" int cpg_conv3x3_supported(const cpg_conv_desc *d) {
 }
 
 size_t cpg_conv3x3_pack_workspace(const cpg_conv_desc *d) {
-    return std::max(std::max(pack_bytes(d->C, d->K), pack_bytes(d->K, d->C)),
-                    std::max(cpg_conv3x3_wino_pack_bytes(d->C, d->K), cpg_conv3x3_wino_pack_bytes(d->K, d->C)));
+    return std::max(pack_bytes(d->C, d->K), pack_bytes(d->K, d->C)) + 16 +
+           std::max(cpg_conv3x3_wino_pack_bytes(d->C, d->K), cpg_conv3x3_wino_pack_bytes(d->K, d->C));
 }
 
 int cpg_conv3x3_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,

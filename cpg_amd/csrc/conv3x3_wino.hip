@@ -455,7 +455,8 @@ constexpr int W1_U = 16 * 32 * WG_CK;                     // floats of U per (k 
 
 // U in per-lane order (see above); rec = kb * nch + ch
 __global__ __launch_bounds__(256) void k_wg1_pack(const float *__restrict__ w, const float *__restrict__ pm, float thr,
-                                                  float *__restrict__ up, int K, int C, int M, int Cin, int nch, int dgrad) {
+                                                  float *__restrict__ up, int K, int C, int M, int Cin, int nch, int dgrad,
+                                                  int *__restrict__ live, int Mp) {
     const int64_t total = (int64_t)((M + 31) / 32) * nch * 32 * WG_CK;
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
         const int cl = (int)(o % WG_CK);
@@ -481,6 +482,17 @@ __global__ __launch_bounds__(256) void k_wg1_pack(const float *__restrict__ w, c
                     g[r][s] = v;
                 }
         }
+        if (live != nullptr) {                  // liveness flags (zeroed by the caller): plain stores of 1, same-value races are benign
+            bool nz = false;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) nz |= g[r][s] != 0.0f;
+            if (nz) {
+                live[m] = 1;
+                live[Mp + 4 + c / 4] = 1;
+            }
+        }
         float t[4][3], u[16];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -503,10 +515,22 @@ __global__ __launch_bounds__(256) void k_wg1_pack(const float *__restrict__ w, c
     }
 }
 
-template <bool DGRAD, bool STATS>
+// Inference: eval-mode BatchNorm (+ ReLU) in the epilogue -- the expression of conv3x3.hip's C3BnEval -- and the dead-channel skip:
+// `live` (may be null) are the flags k_wg1_pack wrote, same layout as k_c3_pack's (live[m]: output channel m has a non-zero
+// weight; live[Mp + 4 + q]: input chunk q has one; live[Mp] receives 4 x the chunks up to the last live one, live[Mp + 1] counts
+// the waves that skipped their MFMA loop).
+struct WgBnEval {
+    const float *gamma, *beta, *mean, *var;
+    float eps;
+    int relu;
+    int *live;
+    int Mp;
+};
+
+template <bool DGRAD, bool STATS, bool BNE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
-           float *__restrict__ y, float *__restrict__ stats) {
+           float *__restrict__ y, float *__restrict__ stats, WgBnEval bn) {
     __shared__ __attribute__((aligned(16))) float smem_all[4 * 2 * W1_RAW];
     // (readfirstlane: tells the compiler the wave index is wave-uniform, so that everything derived from it -- the tile run, the
     //  buffer descriptor of its first image -- lives in scalar registers; without it every buffer load became a waterfall loop)
@@ -656,7 +680,19 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     asm volatile("v_accvgpr_write_b32 a224, 0\n\tv_accvgpr_write_b32 a225, 0\n\tv_accvgpr_write_b32 a226, 0\n\tv_accvgpr_write_b32 a227, 0\n\tv_accvgpr_write_b32 a228, 0\n\tv_accvgpr_write_b32 a229, 0\n\tv_accvgpr_write_b32 a230, 0\n\tv_accvgpr_write_b32 a231, 0\n\tv_accvgpr_write_b32 a232, 0\n\tv_accvgpr_write_b32 a233, 0\n\tv_accvgpr_write_b32 a234, 0\n\tv_accvgpr_write_b32 a235, 0\n\tv_accvgpr_write_b32 a236, 0\n\tv_accvgpr_write_b32 a237, 0\n\tv_accvgpr_write_b32 a238, 0\n\tv_accvgpr_write_b32 a239, 0" : : : "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239");
     asm volatile("v_accvgpr_write_b32 a240, 0\n\tv_accvgpr_write_b32 a241, 0\n\tv_accvgpr_write_b32 a242, 0\n\tv_accvgpr_write_b32 a243, 0\n\tv_accvgpr_write_b32 a244, 0\n\tv_accvgpr_write_b32 a245, 0\n\tv_accvgpr_write_b32 a246, 0\n\tv_accvgpr_write_b32 a247, 0\n\tv_accvgpr_write_b32 a248, 0\n\tv_accvgpr_write_b32 a249, 0\n\tv_accvgpr_write_b32 a250, 0\n\tv_accvgpr_write_b32 a251, 0\n\tv_accvgpr_write_b32 a252, 0\n\tv_accvgpr_write_b32 a253, 0\n\tv_accvgpr_write_b32 a254, 0\n\tv_accvgpr_write_b32 a255, 0" : : : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
 
-    const int last = g.nch - 1;
+    int nch = g.nch;
+    if (BNE && bn.live != nullptr) {                          // inference: skip what apply_mask killed (wave-uniform decisions)
+        const int alive = (kb * 32 + li < g.M) ? bn.live[kb * 32 + li] : 0;
+        const bool dead = __ballot(alive != 0) == 0ull;
+        int lastc = g.nch;
+        while (lastc > 0 && bn.live[bn.Mp + 4 + lastc - 1] == 0) --lastc;
+        nch = dead ? 0 : lastc;
+        if (lane == 0) {
+            if (dead) atomicAdd(&bn.live[bn.Mp + 1], 1);
+            if (blockIdx.x == 0 && wave == 0) bn.live[bn.Mp] = lastc * WG_CK;
+        }
+    }
+    const int last = nch - 1;
     auto clampc = [&](int c) { return min(c, last); };
     f32x4 u0[8], u1[8], u2[8];             // U of chunks it, it + 1, it + 2 (three rotating sets: requested two iterations ahead)
     float b0[16], b1[16];                  // B operands of the current chunk: V of channels 2 lh, 2 lh + 1
@@ -665,6 +701,7 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     // With one wave per SIMD a wait is an idle MFMA pipe: the loads that miss L2 (the transformed filter of a 512 x 512 layer is
     // 16 MB, the input's first touch) take longer than one iteration (0.85 us), so everything is requested two iterations early.
     // prologue: chunk 0 operands, chunks 0 / 1 raw rows in LDS, chunks 2 / 3 rows and U(0), U(1) in flight
+    if (nch > 0) {
     G_rows(0, rw0);
     G_rows(clampc(1), rw1);
     G_u(0, u0);
@@ -678,6 +715,7 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     T_col(b0, 0); T_col(b0, 2); T_col(b1, 0); T_col(b1, 2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { T_rowp(b0, i); T_rowp(b1, i); }
+    }
 
     // The 256 accumulators live in FIXED accumulation registers a[16 p : 16 p + 15], named in the asm text and declared as clobbers.
     // (With the MFMA builtin -- or an "a" constraint on a variable -- the register allocator kept copies of them in VGPRs, shuffled
@@ -745,13 +783,13 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         W1_SLOT(15, 0, ucur, c0, W_row1(par, rows, 7); G_row1(cr, rows, 6));
         W1_SLOT(15, 1, ucur, c1, W_row1(par, rows, 8); G_row1(cr, rows, 7); G_row1(cr, rows, 8));
     };
-    for (int it = 0; it < g.nch; it += 6) {
+    for (int it = 0; it < nch; it += 6) {
         iter(it, 0, u0, u2, rw0, b0, b1, n0v, n1v);
-        if (it + 1 < g.nch) iter(it + 1, 1, u1, u0, rw1, n0v, n1v, b0, b1);
-        if (it + 2 < g.nch) iter(it + 2, 0, u2, u1, rw0, b0, b1, n0v, n1v);
-        if (it + 3 < g.nch) iter(it + 3, 1, u0, u2, rw1, n0v, n1v, b0, b1);
-        if (it + 4 < g.nch) iter(it + 4, 0, u1, u0, rw0, b0, b1, n0v, n1v);
-        if (it + 5 < g.nch) iter(it + 5, 1, u2, u1, rw1, n0v, n1v, b0, b1);
+        if (it + 1 < nch) iter(it + 1, 1, u1, u0, rw1, n0v, n1v, b0, b1);
+        if (it + 2 < nch) iter(it + 2, 0, u2, u1, rw0, b0, b1, n0v, n1v);
+        if (it + 3 < nch) iter(it + 3, 1, u0, u2, rw1, n0v, n1v, b0, b1);
+        if (it + 4 < nch) iter(it + 4, 0, u1, u0, rw0, b0, b1, n0v, n1v);
+        if (it + 5 < nch) iter(it + 5, 1, u2, u1, rw1, n0v, n1v, b0, b1);
     }
 
     // ---- epilogue: Y = A^T M A in registers (M[i][j] = acc[4 i + j]),  A^T = [1 1 1 0; 0 1 -1 -1]
@@ -788,8 +826,15 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         const int co = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         float bv = 0.0f;
         if (bias != nullptr) bv = bias[co < g.M ? co : 0];
-        const float v00 = r_[0][0] + r_[1][0] + r_[2][0] + bv, v01 = r_[0][1] + r_[1][1] + r_[2][1] + bv;
-        const float v10 = r_[1][0] - r_[2][0] - r_[3][0] + bv, v11 = r_[1][1] - r_[2][1] - r_[3][1] + bv;
+        float v00 = r_[0][0] + r_[1][0] + r_[2][0] + bv, v01 = r_[0][1] + r_[1][1] + r_[2][1] + bv;
+        float v10 = r_[1][0] - r_[2][0] - r_[3][0] + bv, v11 = r_[1][1] - r_[2][1] - r_[3][1] + bv;
+        if (BNE) {                             // y = [max(0,] (conv + bias - mean) * invstd * gamma + beta [)]
+            const int cc = co < g.M ? co : 0;
+            const float mu = bn.mean[cc], is = 1.0f / sqrtf(bn.var[cc] + bn.eps), ga = bn.gamma[cc], be = bn.beta[cc];
+            v00 = (v00 - mu) * is * ga + be, v01 = (v01 - mu) * is * ga + be;
+            v10 = (v10 - mu) * is * ga + be, v11 = (v11 - mu) * is * ga + be;
+            if (bn.relu) v00 = fmaxf(v00, 0.0f), v01 = fmaxf(v01, 0.0f), v10 = fmaxf(v10, 0.0f), v11 = fmaxf(v11, 0.0f);
+        }
         if (tv && co < g.M) {
             f32x2 o;
             o[0] = v00, o[1] = v01;
@@ -899,9 +944,35 @@ extern "C" int cpg_conv3x3_wino_tiles(int N, int H, int W) {
 
 // y[N][m][H][W] = conv3x3(x[N][c_read][H][W], W .* bin(pm)) (+ bias); dgrad: x = gy, the filter transposed and flipped.
 // w is the layer's [K][C][3][3] weight.  stats (forward only, may be null): [m][tiles][2] partial sums for the BatchNorm.
+static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, int C, const float *x, const float *w, const float *pm,
+                    float thr, const float *bias, float *y, float *stats, void *ws, size_t ws_bytes, hipStream_t stream, const WgBnEval *bne);
+
 extern "C" int cpg_conv3x3_wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, int C, const float *x,
                                     const float *w, const float *pm, float thr, const float *bias, float *y, float *stats,
                                     void *ws, size_t ws_bytes, hipStream_t stream) {
+    return wino_run(dgrad, N, c_read, m, H, W, K, C, x, w, pm, thr, bias, y, stats, ws, ws_bytes, stream, nullptr);
+}
+
+// 1: the inference epilogue is available on the Winograd kernel (the one-wave kernel only)
+extern "C" int cpg_conv3x3_wino_eval_ok(int N, int c_read, int m, int H, int W) {
+    return wino_one_wave() && cpg_conv3x3_wino_ok(N, c_read, m, H, W);
+}
+
+// forward with eval-mode BatchNorm (+ ReLU) in the epilogue; live (may be null): live_words ints, zeroed here, layout of k_c3_pack
+extern "C" int cpg_conv3x3_wino_run_bn_eval(int N, int C, int K, int H, int W, const float *x, const float *w, const float *pm, float thr,
+                                            const float *bias, const float *gamma, const float *beta, const float *mean, const float *var,
+                                            float eps, int relu, int *live, size_t live_words, float *y, void *ws, size_t ws_bytes,
+                                            hipStream_t stream) {
+    if (live != nullptr) {
+        hipError_t e = hipMemsetAsync(live, 0, live_words * sizeof(int), stream);
+        if (e != hipSuccess) return hip_status(e, "cpg_conv2d_fwd_bn_eval(winograd)");
+    }
+    const WgBnEval bne{gamma, beta, mean, var, eps, relu, live, pad_to(K, 128)};
+    return wino_run(0, N, C, K, H, W, K, C, x, w, pm, thr, bias, y, nullptr, ws, ws_bytes, stream, &bne);
+}
+
+static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, int C, const float *x, const float *w, const float *pm,
+                    float thr, const float *bias, float *y, float *stats, void *ws, size_t ws_bytes, hipStream_t stream, const WgBnEval *bne) {
     const char *what = dgrad ? "cpg_conv2d_dgrad(winograd)" : "cpg_conv2d_fwd(winograd)";
     const size_t need = cpg_conv3x3_wino_pack_bytes(c_read, m);
     if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
@@ -914,20 +985,24 @@ extern "C" int cpg_conv3x3_wino_run(int dgrad, int N, int c_read, int m, int H, 
         g.nkb = pad_to(m, 32) / 32, g.nch = pad_to(c_read, WG_CK) / WG_CK;
         g.span = (W1_T + g.tiles_img - 1) / g.tiles_img + 1;
         float *up = (float *)ws;
+        const WgBnEval none{nullptr, nullptr, nullptr, nullptr, 0.0f, 0, nullptr, 0};
         hipLaunchKernelGGL(k_wg1_pack, dim3(stream_grid((int64_t)g.nkb * g.nch * 32 * WG_CK, 256)), dim3(256), 0, stream, w, pm, thr, up,
-                           K, C, m, c_read, g.nch, dgrad ? 1 : 0);
+                           K, C, m, c_read, g.nch, dgrad ? 1 : 0, bne ? bne->live : nullptr, bne ? bne->Mp : 0);
         const int64_t runs = (g.tiles_total + W1_T - 1) / W1_T;
         const int64_t blocks = (runs + 3) / 4 * g.nkb;
         if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "%s: grid too large", what);
-        if (dgrad)
-            hipLaunchKernelGGL((k_wg1<true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, up, bias, y, nullptr);
+        if (bne != nullptr)
+            hipLaunchKernelGGL((k_wg1<false, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, up, bias, y, nullptr, *bne);
+        else if (dgrad)
+            hipLaunchKernelGGL((k_wg1<true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, up, bias, y, nullptr, none);
         else if (stats != nullptr)
-            hipLaunchKernelGGL((k_wg1<false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, up, bias, y, stats);
+            hipLaunchKernelGGL((k_wg1<false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, up, bias, y, stats, none);
         else
-            hipLaunchKernelGGL((k_wg1<false, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, up, bias, y, nullptr);
+            hipLaunchKernelGGL((k_wg1<false, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, up, bias, y, nullptr, none);
         CPG_CHECK_LAUNCH(what);
         return CPG_OK;
     }
+    if (bne != nullptr) return fail(CPG_E_UNSUPPORTED, "%s: the block kernels have no inference epilogue", what);
     const int nw = wino_nw(c_read, m), BK = 8 * nw;
     WgGeom g;
     g.N = N, g.C = c_read, g.H = H, g.W = W, g.M = m;
