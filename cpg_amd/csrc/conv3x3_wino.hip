@@ -889,6 +889,309 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     }
 }
 
+// ------------------------------------------------------------------------------ two waves = one unit ("k_wg2")
+// k_wg1 split over the transform positions, built to test whether a SECOND wave per SIMD would fill the gaps the staging
+// instructions leave in k_wg1's MFMA stream: a block is two waves that share a unit of 32 channels x 32 tiles, wave ph owns the
+// positions of transform rows 2 ph, 2 ph + 1 -- 8 accumulators = 128 AGPRs, so two waves fit a SIMD (four independent blocks per
+// CU).  Per chunk a wave fetches the three patch rows its positions need (ph .. ph + 2), does half of the input transform (16 adds
+// per patch instead of 32: nothing is computed twice) and 16 MFMAs; the two waves meet once, in the epilogue, to swap the halves of
+// the (linear) output transform through LDS.  RESULT: the same speed as k_wg1 within 1 % on every layer (34.5 vs 34.4 ms per VGG16
+// pass) -- the time the other instructions take is not hidden by a second wave either; on this chip an fp32 MFMA and the fp32 vector
+// adds / the memory instructions' register traffic share what they run on (the fp32 matrix and packed-vector peaks are the same
+// number), so the cost is additive: MFMA time + ~4 cycles per vector add + ~8-16 per LDS / vector-memory instruction.  Kept behind
+// CPG_WINO_KERNEL=pair (tested); not the default.
+constexpr int W2_RAW = 4 * 3 * W1_ROW;                    // one stage of one wave: [channel][row 3][slot 34][2] = 816 floats
+
+#define W2_ONE_0(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[0:15], %0, %1, a[0:15]" : : "v"(A), "v"(B) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15")
+#define W2_ONE_1(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[16:31], %0, %1, a[16:31]" : : "v"(A), "v"(B) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31")
+#define W2_ONE_2(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[32:47], %0, %1, a[32:47]" : : "v"(A), "v"(B) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47")
+#define W2_ONE_3(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[48:63], %0, %1, a[48:63]" : : "v"(A), "v"(B) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63")
+#define W2_ONE_4(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[64:79], %0, %1, a[64:79]" : : "v"(A), "v"(B) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79")
+#define W2_ONE_5(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[80:95], %0, %1, a[80:95]" : : "v"(A), "v"(B) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95")
+#define W2_ONE_6(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[96:111], %0, %1, a[96:111]" : : "v"(A), "v"(B) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111")
+#define W2_ONE_7(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[112:127], %0, %1, a[112:127]" : : "v"(A), "v"(B) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127")
+
+#define W2_RD_0(m) asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a16\n\tv_accvgpr_read_b32 %2, a32\n\tv_accvgpr_read_b32 %3, a48\n\tv_accvgpr_read_b32 %4, a64\n\tv_accvgpr_read_b32 %5, a80\n\tv_accvgpr_read_b32 %6, a96\n\tv_accvgpr_read_b32 %7, a112" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W2_RD_1(m) asm volatile("v_accvgpr_read_b32 %0, a1\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a33\n\tv_accvgpr_read_b32 %3, a49\n\tv_accvgpr_read_b32 %4, a65\n\tv_accvgpr_read_b32 %5, a81\n\tv_accvgpr_read_b32 %6, a97\n\tv_accvgpr_read_b32 %7, a113" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W2_RD_2(m) asm volatile("v_accvgpr_read_b32 %0, a2\n\tv_accvgpr_read_b32 %1, a18\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a50\n\tv_accvgpr_read_b32 %4, a66\n\tv_accvgpr_read_b32 %5, a82\n\tv_accvgpr_read_b32 %6, a98\n\tv_accvgpr_read_b32 %7, a114" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W2_RD_3(m) asm volatile("v_accvgpr_read_b32 %0, a3\n\tv_accvgpr_read_b32 %1, a19\n\tv_accvgpr_read_b32 %2, a35\n\tv_accvgpr_read_b32 %3, a51\n\tv_accvgpr_read_b32 %4, a67\n\tv_accvgpr_read_b32 %5, a83\n\tv_accvgpr_read_b32 %6, a99\n\tv_accvgpr_read_b32 %7, a115" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W2_RD_4(m) asm volatile("v_accvgpr_read_b32 %0, a4\n\tv_accvgpr_read_b32 %1, a20\n\tv_accvgpr_read_b32 %2, a36\n\tv_accvgpr_read_b32 %3, a52\n\tv_accvgpr_read_b32 %4, a68\n\tv_accvgpr_read_b32 %5, a84\n\tv_accvgpr_read_b32 %6, a100\n\tv_accvgpr_read_b32 %7, a116" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W2_RD_5(m) asm volatile("v_accvgpr_read_b32 %0, a5\n\tv_accvgpr_read_b32 %1, a21\n\tv_accvgpr_read_b32 %2, a37\n\tv_accvgpr_read_b32 %3, a53\n\tv_accvgpr_read_b32 %4, a69\n\tv_accvgpr_read_b32 %5, a85\n\tv_accvgpr_read_b32 %6, a101\n\tv_accvgpr_read_b32 %7, a117" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W2_RD_6(m) asm volatile("v_accvgpr_read_b32 %0, a6\n\tv_accvgpr_read_b32 %1, a22\n\tv_accvgpr_read_b32 %2, a38\n\tv_accvgpr_read_b32 %3, a54\n\tv_accvgpr_read_b32 %4, a70\n\tv_accvgpr_read_b32 %5, a86\n\tv_accvgpr_read_b32 %6, a102\n\tv_accvgpr_read_b32 %7, a118" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W2_RD_7(m) asm volatile("v_accvgpr_read_b32 %0, a7\n\tv_accvgpr_read_b32 %1, a23\n\tv_accvgpr_read_b32 %2, a39\n\tv_accvgpr_read_b32 %3, a55\n\tv_accvgpr_read_b32 %4, a71\n\tv_accvgpr_read_b32 %5, a87\n\tv_accvgpr_read_b32 %6, a103\n\tv_accvgpr_read_b32 %7, a119" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W2_RD_8(m) asm volatile("v_accvgpr_read_b32 %0, a8\n\tv_accvgpr_read_b32 %1, a24\n\tv_accvgpr_read_b32 %2, a40\n\tv_accvgpr_read_b32 %3, a56\n\tv_accvgpr_read_b32 %4, a72\n\tv_accvgpr_read_b32 %5, a88\n\tv_accvgpr_read_b32 %6, a104\n\tv_accvgpr_read_b32 %7, a120" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W2_RD_9(m) asm volatile("v_accvgpr_read_b32 %0, a9\n\tv_accvgpr_read_b32 %1, a25\n\tv_accvgpr_read_b32 %2, a41\n\tv_accvgpr_read_b32 %3, a57\n\tv_accvgpr_read_b32 %4, a73\n\tv_accvgpr_read_b32 %5, a89\n\tv_accvgpr_read_b32 %6, a105\n\tv_accvgpr_read_b32 %7, a121" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W2_RD_10(m) asm volatile("v_accvgpr_read_b32 %0, a10\n\tv_accvgpr_read_b32 %1, a26\n\tv_accvgpr_read_b32 %2, a42\n\tv_accvgpr_read_b32 %3, a58\n\tv_accvgpr_read_b32 %4, a74\n\tv_accvgpr_read_b32 %5, a90\n\tv_accvgpr_read_b32 %6, a106\n\tv_accvgpr_read_b32 %7, a122" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W2_RD_11(m) asm volatile("v_accvgpr_read_b32 %0, a11\n\tv_accvgpr_read_b32 %1, a27\n\tv_accvgpr_read_b32 %2, a43\n\tv_accvgpr_read_b32 %3, a59\n\tv_accvgpr_read_b32 %4, a75\n\tv_accvgpr_read_b32 %5, a91\n\tv_accvgpr_read_b32 %6, a107\n\tv_accvgpr_read_b32 %7, a123" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W2_RD_12(m) asm volatile("v_accvgpr_read_b32 %0, a12\n\tv_accvgpr_read_b32 %1, a28\n\tv_accvgpr_read_b32 %2, a44\n\tv_accvgpr_read_b32 %3, a60\n\tv_accvgpr_read_b32 %4, a76\n\tv_accvgpr_read_b32 %5, a92\n\tv_accvgpr_read_b32 %6, a108\n\tv_accvgpr_read_b32 %7, a124" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W2_RD_13(m) asm volatile("v_accvgpr_read_b32 %0, a13\n\tv_accvgpr_read_b32 %1, a29\n\tv_accvgpr_read_b32 %2, a45\n\tv_accvgpr_read_b32 %3, a61\n\tv_accvgpr_read_b32 %4, a77\n\tv_accvgpr_read_b32 %5, a93\n\tv_accvgpr_read_b32 %6, a109\n\tv_accvgpr_read_b32 %7, a125" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W2_RD_14(m) asm volatile("v_accvgpr_read_b32 %0, a14\n\tv_accvgpr_read_b32 %1, a30\n\tv_accvgpr_read_b32 %2, a46\n\tv_accvgpr_read_b32 %3, a62\n\tv_accvgpr_read_b32 %4, a78\n\tv_accvgpr_read_b32 %5, a94\n\tv_accvgpr_read_b32 %6, a110\n\tv_accvgpr_read_b32 %7, a126" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W2_RD_15(m) asm volatile("v_accvgpr_read_b32 %0, a15\n\tv_accvgpr_read_b32 %1, a31\n\tv_accvgpr_read_b32 %2, a47\n\tv_accvgpr_read_b32 %3, a63\n\tv_accvgpr_read_b32 %4, a79\n\tv_accvgpr_read_b32 %5, a95\n\tv_accvgpr_read_b32 %6, a111\n\tv_accvgpr_read_b32 %7, a127" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+
+template <bool DGRAD, bool STATS, bool BNE = false>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_wg2(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
+           float *__restrict__ y, float *__restrict__ stats, WgBnEval bn) {
+    __shared__ __attribute__((aligned(16))) float smem_all[2 * 32 * 64];       // 2 x 2 raw stages (3264 floats) / the exchange buffer
+    const int tid = threadIdx.x, lane = tid & 63, ph = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int HW = g.H * g.W;
+    float *smem = smem_all + ph * 2 * W2_RAW;                 // this wave's private raw stages
+
+    unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int kb = lb % g.nkb;
+    const unsigned ttot = (unsigned)g.tiles_total, timg = (unsigned)g.tiles_img, twu = (unsigned)g.tw;
+    const unsigned run = lb / g.nkb;                          // tile run of 32
+    const unsigned t0 = run * W1_T;
+    if (t0 >= ttot) return;                                   // (uniform for the block)
+    const int n0 = (int)(t0 / timg);
+
+    constexpr int kOutOfRange = (int)0x80000000;
+    int roff[3], hoff, lo, ro;
+    {
+        const unsigned tg = t0 + li;
+        const bool tv = tg < ttot;
+        const int n = (int)(tg / timg), r = (int)(tg % timg);
+        const int ty = (int)((unsigned)r / twu), tx = (int)((unsigned)r % twu);
+        const int cbase = ((n - n0) * g.C + 2 * lh) * HW;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int gh = 2 * ty - 1 + ph + i;
+            roff[i] = (tv && (unsigned)gh < (unsigned)g.H) ? (cbase + gh * g.W + 2 * tx) * 4 : kOutOfRange;
+        }
+        lo = tx == 0 ? 0 : (li + 1) * 2 - 1;
+        ro = tx == g.tw - 1 ? (W1_T + 1) * 2 + 1 : (li + 1) * 2 + 2;
+        // halo: lanes 0-23 = (side, row, channel): the column left of tile t0 / right of tile t0 + 31
+        const int side = lane >= 12 ? 1 : 0, hl = lane - 12 * side, hi = hl >> 2, hc = hl & 3;
+        const unsigned th = side ? t0 + W1_T - 1 : t0;
+        const int nh = (int)(th / timg), rh = (int)(th % timg);
+        const int tyh = (int)((unsigned)rh / twu), txh = (int)((unsigned)rh % twu);
+        const int ghh = 2 * tyh - 1 + ph + hi, gwh = side ? 2 * txh + 2 : 2 * txh - 1;
+        const bool okh = lane < 24 && th < ttot && (unsigned)ghh < (unsigned)g.H && (unsigned)gwh < (unsigned)g.W;
+        hoff = okh ? (((nh - n0) * g.C + hc) * HW + ghh * g.W + gwh) * 4 : kOutOfRange;
+    }
+    const int span = (W1_T + g.tiles_img - 1) / g.tiles_img + 1;
+    const int nimg_here = min(span, g.N - n0);
+    const __amdgpu_buffer_rsrc_t srd_x =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(x + (int64_t)n0 * g.C * HW), 0, nimg_here * g.C * HW * 4, 0x00020000);
+    const float *ubase = up + (int64_t)kb * g.nch * W1_U + ph * 1024 + lane * 4;     // this wave's four float4 of a chunk: q = 4 ph .. + 3
+
+    // raw[c][row][slot][2] offsets of this lane (channels 2 lh + j)
+    const int raw_own = (2 * lh) * 3 * W1_ROW + (li + 1) * 2;
+    const int hside = lane >= 12 ? 1 : 0, hrem = lane - 12 * hside;
+    const int halo_w = ((hrem & 3) * 3 + (hrem >> 2)) * W1_ROW + (hside ? (W1_T + 1) * 2 : 1);
+    if (lane < 24) {                                          // zero slots of the 2 x 12 rows (never written)
+        smem[lane * W1_ROW] = 0.0f;
+        smem[lane * W1_ROW + (W1_T + 1) * 2 + 1] = 0.0f;
+    }
+
+    struct Rows {
+        i32x2 r[2][3];
+        float halo;
+    };
+    auto G_row1 = [&](int ch, Rows &q, int k) {             // k = 0..5: row k % 3 of channel 2 lh + k / 3;  k = 6: the halo values
+        const int soff = ch * WG_CK * HW * 4;
+        if (k < 6)
+            q.r[k / 3][k % 3] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[k % 3], soff + (k / 3) * HW * 4, 0);
+        else
+            q.halo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, hoff, soff, 0));
+    };
+    auto W_row1 = [&](int stage, const Rows &q, int k) {
+        float *raw = smem + stage * W2_RAW;
+        if (k < 6)
+            *reinterpret_cast<i32x2 *>(raw + raw_own + k * W1_ROW) = q.r[k / 3][k % 3];
+        else if (lane < 24)
+            raw[halo_w] = q.halo;
+    };
+    auto G_u1 = [&](int ch, f32x4 (&u)[4], int q) { u[q] = *reinterpret_cast<const f32x4 *>(ubase + (int64_t)ch * W1_U + q * 256); };
+    // half patch of (tile li, channel 2 lh + j): rows ph .. ph + 2 -> the 8 values of transform rows 2 ph, 2 ph + 1 in d[0..7]
+    auto T_read1 = [&](int stage, int j, float (&d)[12], int i) {
+        const float *raw = smem + stage * W2_RAW + ((2 * lh + j) * 3 + i) * W1_ROW;
+        const f32x2 own = *reinterpret_cast<const f32x2 *>(raw + (li + 1) * 2);
+        d[i * 4 + 0] = raw[lo], d[i * 4 + 1] = own[0], d[i * 4 + 2] = own[1], d[i * 4 + 3] = raw[ro];
+    };
+    // B^T d: ph = 0 holds patch rows 0, 1, 2 -> rows 0, 1 = d0 - d2, d1 + d2;  ph = 1 holds 1, 2, 3 -> rows 2, 3 = d2 - d1, d1 - d3
+    auto T_col = [&](float (&d)[12], int j0) {
+#pragma unroll
+        for (int j = j0; j < j0 + 2; ++j) {
+            const float e0 = d[0 * 4 + j], e1 = d[1 * 4 + j], e2 = d[2 * 4 + j];
+            d[0 * 4 + j] = ph ? e1 - e0 : e0 - e2;
+            d[1 * 4 + j] = ph ? e0 - e2 : e1 + e2;
+            asm volatile("" : "+v"(d[0 * 4 + j]), "+v"(d[1 * 4 + j]));
+        }
+    };
+    auto T_rowp = [&](float (&d)[12], int i) {
+        const float t0_ = d[i * 4 + 0], t1 = d[i * 4 + 1], t2 = d[i * 4 + 2], t3 = d[i * 4 + 3];
+        d[i * 4 + 0] = t0_ - t2, d[i * 4 + 1] = t1 + t2, d[i * 4 + 2] = t2 - t1, d[i * 4 + 3] = t1 - t3;
+        asm volatile("" : "+v"(d[i * 4 + 0]), "+v"(d[i * 4 + 1]), "+v"(d[i * 4 + 2]), "+v"(d[i * 4 + 3]));
+    };
+
+    asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0" : : : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
+    asm volatile("v_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0" : : : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
+    asm volatile("v_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0" : : : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    asm volatile("v_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0" : : : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
+    asm volatile("v_accvgpr_write_b32 a64, 0\n\tv_accvgpr_write_b32 a65, 0\n\tv_accvgpr_write_b32 a66, 0\n\tv_accvgpr_write_b32 a67, 0\n\tv_accvgpr_write_b32 a68, 0\n\tv_accvgpr_write_b32 a69, 0\n\tv_accvgpr_write_b32 a70, 0\n\tv_accvgpr_write_b32 a71, 0\n\tv_accvgpr_write_b32 a72, 0\n\tv_accvgpr_write_b32 a73, 0\n\tv_accvgpr_write_b32 a74, 0\n\tv_accvgpr_write_b32 a75, 0\n\tv_accvgpr_write_b32 a76, 0\n\tv_accvgpr_write_b32 a77, 0\n\tv_accvgpr_write_b32 a78, 0\n\tv_accvgpr_write_b32 a79, 0" : : : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
+    asm volatile("v_accvgpr_write_b32 a80, 0\n\tv_accvgpr_write_b32 a81, 0\n\tv_accvgpr_write_b32 a82, 0\n\tv_accvgpr_write_b32 a83, 0\n\tv_accvgpr_write_b32 a84, 0\n\tv_accvgpr_write_b32 a85, 0\n\tv_accvgpr_write_b32 a86, 0\n\tv_accvgpr_write_b32 a87, 0\n\tv_accvgpr_write_b32 a88, 0\n\tv_accvgpr_write_b32 a89, 0\n\tv_accvgpr_write_b32 a90, 0\n\tv_accvgpr_write_b32 a91, 0\n\tv_accvgpr_write_b32 a92, 0\n\tv_accvgpr_write_b32 a93, 0\n\tv_accvgpr_write_b32 a94, 0\n\tv_accvgpr_write_b32 a95, 0" : : : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
+    asm volatile("v_accvgpr_write_b32 a96, 0\n\tv_accvgpr_write_b32 a97, 0\n\tv_accvgpr_write_b32 a98, 0\n\tv_accvgpr_write_b32 a99, 0\n\tv_accvgpr_write_b32 a100, 0\n\tv_accvgpr_write_b32 a101, 0\n\tv_accvgpr_write_b32 a102, 0\n\tv_accvgpr_write_b32 a103, 0\n\tv_accvgpr_write_b32 a104, 0\n\tv_accvgpr_write_b32 a105, 0\n\tv_accvgpr_write_b32 a106, 0\n\tv_accvgpr_write_b32 a107, 0\n\tv_accvgpr_write_b32 a108, 0\n\tv_accvgpr_write_b32 a109, 0\n\tv_accvgpr_write_b32 a110, 0\n\tv_accvgpr_write_b32 a111, 0" : : : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
+    asm volatile("v_accvgpr_write_b32 a112, 0\n\tv_accvgpr_write_b32 a113, 0\n\tv_accvgpr_write_b32 a114, 0\n\tv_accvgpr_write_b32 a115, 0\n\tv_accvgpr_write_b32 a116, 0\n\tv_accvgpr_write_b32 a117, 0\n\tv_accvgpr_write_b32 a118, 0\n\tv_accvgpr_write_b32 a119, 0\n\tv_accvgpr_write_b32 a120, 0\n\tv_accvgpr_write_b32 a121, 0\n\tv_accvgpr_write_b32 a122, 0\n\tv_accvgpr_write_b32 a123, 0\n\tv_accvgpr_write_b32 a124, 0\n\tv_accvgpr_write_b32 a125, 0\n\tv_accvgpr_write_b32 a126, 0\n\tv_accvgpr_write_b32 a127, 0" : : : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
+
+    int nch = g.nch;
+    if (BNE && bn.live != nullptr) {                          // inference: skip what apply_mask killed (wave-uniform decisions)
+        const int alive = (kb * 32 + li < g.M) ? bn.live[kb * 32 + li] : 0;
+        const bool dead = __ballot(alive != 0) == 0ull;
+        int lastc = g.nch;
+        while (lastc > 0 && bn.live[bn.Mp + 4 + lastc - 1] == 0) --lastc;
+        nch = dead ? 0 : lastc;
+        if (lane == 0 && ph == 0) {
+            if (dead) atomicAdd(&bn.live[bn.Mp + 1], 1);
+            if (blockIdx.x == 0) bn.live[bn.Mp] = lastc * WG_CK;
+        }
+    }
+    const int last = nch - 1;
+    auto clampc = [&](int c) { return min(c, last); };
+    f32x4 ua[4], ub[4];                    // U of the current / next chunk
+    float c0[12], c1[12], x0[12], x1[12];  // B operands ([0..7]) of the current chunk for channels 2 lh, 2 lh + 1 / the next chunk's, being transformed
+    Rows rows;
+    if (nch > 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) G_row1(0, rows, k);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) G_u1(0, ua, q);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) W_row1(0, rows, k);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) G_row1(clampc(1), rows, k);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { T_read1(0, 0, c0, i); T_read1(0, 1, c1, i); }
+        T_col(c0, 0); T_col(c0, 2); T_col(c1, 0); T_col(c1, 2);
+        T_rowp(c0, 0); T_rowp(c0, 1); T_rowp(c1, 0); T_rowp(c1, 1);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) W_row1(1, rows, k);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) G_row1(clampc(2), rows, k);
+    }
+#define W2_SLOT(p, h, U, B, work)                                                      \
+    W2_ONE_##p((U)[(p) >> 1][((p) & 1) * 2 + (h)], (B)[p]);                            \
+    work;                                                                              \
+    __builtin_amdgcn_sched_barrier(0)
+    // iteration it (par = it & 1): M(it); T(it + 1) from raw stage (it + 1) & 1; U(it + 1) requested; W(it + 2) stores the rows
+    // requested one iteration ago, whose registers then take the loads of chunk it + 3
+    auto iter = [&](int it, int par, f32x4 (&ucur)[4], f32x4 (&unext)[4], float (&b0)[12], float (&b1)[12], float (&n0v)[12], float (&n1v)[12]) {
+        const int cu = clampc(it + 1), cr = clampc(it + 3);
+        W2_SLOT(0, 0, ucur, b0, T_read1(par ^ 1, 0, n0v, 0); T_read1(par ^ 1, 0, n0v, 1));
+        W2_SLOT(0, 1, ucur, b1, T_read1(par ^ 1, 0, n0v, 2); T_read1(par ^ 1, 1, n1v, 0));
+        W2_SLOT(1, 0, ucur, b0, T_read1(par ^ 1, 1, n1v, 1); T_read1(par ^ 1, 1, n1v, 2));
+        W2_SLOT(1, 1, ucur, b1, G_u1(cu, unext, 0));
+        W2_SLOT(2, 0, ucur, b0, T_col(n0v, 0); G_u1(cu, unext, 1));
+        W2_SLOT(2, 1, ucur, b1, T_col(n0v, 2); G_u1(cu, unext, 2));
+        W2_SLOT(3, 0, ucur, b0, T_col(n1v, 0); G_u1(cu, unext, 3));
+        W2_SLOT(3, 1, ucur, b1, T_col(n1v, 2));
+        W2_SLOT(4, 0, ucur, b0, T_rowp(n0v, 0));
+        W2_SLOT(4, 1, ucur, b1, T_rowp(n0v, 1));
+        W2_SLOT(5, 0, ucur, b0, T_rowp(n1v, 0));
+        W2_SLOT(5, 1, ucur, b1, T_rowp(n1v, 1));
+        W2_SLOT(6, 0, ucur, b0, W_row1(par, rows, 0); W_row1(par, rows, 1); G_row1(cr, rows, 0));
+        W2_SLOT(6, 1, ucur, b1, W_row1(par, rows, 2); W_row1(par, rows, 3); G_row1(cr, rows, 1); G_row1(cr, rows, 2));
+        W2_SLOT(7, 0, ucur, b0, W_row1(par, rows, 4); W_row1(par, rows, 5); G_row1(cr, rows, 3); G_row1(cr, rows, 4));
+        W2_SLOT(7, 1, ucur, b1, W_row1(par, rows, 6); G_row1(cr, rows, 5); G_row1(cr, rows, 6));
+    };
+    for (int it = 0; it < nch; it += 2) {
+        iter(it, 0, ua, ub, c0, c1, x0, x1);
+        if (it + 1 < nch) iter(it + 1, 1, ub, ua, x0, x1, c0, c1);
+    }
+
+    // ---- epilogue: this wave's 8 positions (transform rows i = 2 ph, 2 ph + 1) -> partial 2x2 outputs; the output transform is linear
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    float own0[16], own1[16];                  // the output row this wave finishes (a = ph), columns 0 / 1, per accumulator element
+    __syncthreads();                           // both waves are done with their raw stages: the LDS becomes the exchange buffer
+    float *xch = smem_all;
+    auto part_e = [&](int e, const float (&m)[8]) {
+        const float r00 = m[0] + m[1] + m[2], r01 = m[1] - m[2] - m[3];       // R[il][b] = sum_j A^T[b][j] M[i][j]
+        const float r10 = m[4] + m[5] + m[6], r11 = m[5] - m[6] - m[7];
+        float g0, g1;
+        if (ph == 0) {                         // i = 0, 1:  Y0 += R0 + R1 (own),  Y1 += R1 (given to the other wave)
+            own0[e] = r00 + r10, own1[e] = r01 + r11, g0 = r10, g1 = r11;
+        } else {                               // i = 2, 3:  Y1 += -R2 - R3 (own),  Y0 += R2 (given)
+            own0[e] = -r00 - r10, own1[e] = -r01 - r11, g0 = r00, g1 = r01;
+        }
+        xch[((ph * 2 + 0) * 16 + e) * 64 + lane] = g0;
+        xch[((ph * 2 + 1) * 16 + e) * 64 + lane] = g1;
+    };
+    {
+        float m[8];
+        W2_RD_0(m); part_e(0, m);
+        W2_RD_1(m); part_e(1, m);
+        W2_RD_2(m); part_e(2, m);
+        W2_RD_3(m); part_e(3, m);
+        W2_RD_4(m); part_e(4, m);
+        W2_RD_5(m); part_e(5, m);
+        W2_RD_6(m); part_e(6, m);
+        W2_RD_7(m); part_e(7, m);
+        W2_RD_8(m); part_e(8, m);
+        W2_RD_9(m); part_e(9, m);
+        W2_RD_10(m); part_e(10, m);
+        W2_RD_11(m); part_e(11, m);
+        W2_RD_12(m); part_e(12, m);
+        W2_RD_13(m); part_e(13, m);
+        W2_RD_14(m); part_e(14, m);
+        W2_RD_15(m); part_e(15, m);
+
+    }
+    __syncthreads();
+    const unsigned tg = t0 + li;
+    const bool tv = tg < ttot;
+    const int n = (int)(tg / timg), r = (int)(tg % timg);
+    const int ty = (int)((unsigned)r / twu), tx = (int)((unsigned)r % twu);
+    float *yout = y + ((int64_t)n * g.M) * HW + (2 * ty + ph) * g.W + 2 * tx;
+    float s1[16], s2[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int co = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        float v0 = own0[e] + xch[(((ph ^ 1) * 2 + 0) * 16 + e) * 64 + lane];
+        float v1 = own1[e] + xch[(((ph ^ 1) * 2 + 1) * 16 + e) * 64 + lane];
+        if (bias != nullptr) {
+            const float bv = bias[co < g.M ? co : 0];
+            v0 += bv, v1 += bv;
+        }
+        if (BNE) {                             // y = [max(0,] (conv + bias - mean) * invstd * gamma + beta [)]
+            const int cc = co < g.M ? co : 0;
+            const float mu = bn.mean[cc], is = 1.0f / sqrtf(bn.var[cc] + bn.eps), ga = bn.gamma[cc], be = bn.beta[cc];
+            v0 = (v0 - mu) * is * ga + be, v1 = (v1 - mu) * is * ga + be;
+            if (bn.relu) v0 = fmaxf(v0, 0.0f), v1 = fmaxf(v1, 0.0f);
+        }
+        if (tv && co < g.M) {
+            f32x2 o;
+            o[0] = v0, o[1] = v1;
+            *reinterpret_cast<f32x2 *>(yout + (int64_t)co * HW) = o;
+        }
+        if (STATS) {
+            s1[e] = tv ? v0 + v1 : 0.0f;
+            s2[e] = tv ? v0 * v0 + v1 * v1 : 0.0f;
+        }
+    }
+    if (STATS) {                               // every wave is its own statistics tile: stats[k][2 run + ph][2]
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                s1[e] += __shfl_xor(s1[e], off);
+                s2[e] += __shfl_xor(s2[e], off);
+            }
+        if (li == 0) {
+            const unsigned ntile = 2 * ((ttot + W1_T - 1) / W1_T);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (co < g.M) {
+                    float *dst = stats + ((int64_t)co * ntile + 2 * run + ph) * 2;
+                    dst[0] = s1[e];
+                    dst[1] = s2[e];
+                }
+            }
+        }
+    }
+}
+
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 
 // waves per block for a launch.  The 8-wave / 64-channel block does half the staging work per MFMA, but its eight waves run in
@@ -931,15 +1234,22 @@ extern "C" size_t cpg_conv3x3_wino_pack_bytes(int c_read, int m) {      // (the 
     return (size_t)pad_to(m, 64) * pad_to(c_read, WG_CK) * 16 * sizeof(float);
 }
 
-// CPG_WINO_KERNEL=block selects the 4-wave-block kernel k_wg_fwd (A/B experiments, tests); default: one wave per unit (k_wg1)
-static inline bool wino_one_wave() {
+// Default: one wave per unit (k_wg1).  CPG_WINO_KERNEL = pair: two waves per unit (k_wg2, measured the same); = block: the cooperative
+// 4- / 8-wave block kernel k_wg_fwd (measured slower).  (A/B experiments and tests.)
+static inline bool wino_one_wave() {          // k_wg1 or k_wg2: the kernels with the inference epilogue and U in per-lane order
     const char *f = getenv("CPG_WINO_KERNEL");
     return !(f && f[0] == 'b');
 }
+static inline bool wino_pair() {
+    const char *f = getenv("CPG_WINO_KERNEL");
+    return f && f[0] == 'p';
+}
 
 extern "C" int cpg_conv3x3_wino_tiles(int N, int H, int W) {
+    const int64_t tiles = (int64_t)N * (H / 2) * (W / 2);
+    if (wino_pair()) return (int)(2 * ((tiles + W1_T - 1) / W1_T));          // every wave of a pair is its own statistics tile
     const int per = wino_one_wave() ? W1_T : WG_T;
-    return (int)(((int64_t)N * (H / 2) * (W / 2) + per - 1) / per);
+    return (int)((tiles + per - 1) / per);
 }
 
 // y[N][m][H][W] = conv3x3(x[N][c_read][H][W], W .* bin(pm)) (+ bias); dgrad: x = gy, the filter transposed and flipped.
@@ -989,6 +1299,20 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
         hipLaunchKernelGGL(k_wg1_pack, dim3(stream_grid((int64_t)g.nkb * g.nch * 32 * WG_CK, 256)), dim3(256), 0, stream, w, pm, thr, up,
                            K, C, m, c_read, g.nch, dgrad ? 1 : 0, bne ? bne->live : nullptr, bne ? bne->Mp : 0);
         const int64_t runs = (g.tiles_total + W1_T - 1) / W1_T;
+        if (wino_pair()) {
+            const int64_t blocks = runs * g.nkb;
+            if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "%s: grid too large", what);
+            if (bne != nullptr)
+                hipLaunchKernelGGL((k_wg2<false, false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, *bne);
+            else if (dgrad)
+                hipLaunchKernelGGL((k_wg2<true, false>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, none);
+            else if (stats != nullptr)
+                hipLaunchKernelGGL((k_wg2<false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, stats, none);
+            else
+                hipLaunchKernelGGL((k_wg2<false, false>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, none);
+            CPG_CHECK_LAUNCH(what);
+            return CPG_OK;
+        }
         const int64_t blocks = (runs + 3) / 4 * g.nkb;
         if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "%s: grid too large", what);
         if (bne != nullptr)
