@@ -856,7 +856,7 @@ inline size_t pack_bytes(int c_read, int m) { return (pack_floats(c_read, m) + l
 }  // namespace
 extern "C" int cpg_conv3x3_wino_ok(int N, int c_read, int m, int H, int W);
 extern "C" size_t cpg_conv3x3_wino_pack_bytes(int c_read, int m);
-extern "C" int cpg_conv3x3_wino_tiles(int N, int H, int W);
+extern "C" int cpg_conv3x3_wino_tiles(int N, int c_read, int m, int H, int W);
 extern "C" int cpg_conv3x3_wino_eval_ok(int N, int c_read, int m, int H, int W);
 extern "C" int cpg_conv3x3_wino_run_bn_eval(int N, int C, int K, int H, int W, const float *x, const float *w, const float *pm, float thr,
                                             const float *bias, const float *gamma, const float *beta, const float *mean, const float *var,
@@ -914,7 +914,7 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
     // input gradient of every even-sized map with >= 16 channels on both sides: 2.25x fewer MFMAs, 1.36-1.47x the speed of the
     // direct kernels below.  The inference epilogues (eval BatchNorm, dead-channel skip) and BRED stay on the direct kernels.
     if (bn == nullptr && bb == nullptr && cpg_conv3x3_wino_ok(N, c_read, m, H, W)) {
-        if (tiles_out) *tiles_out = cpg_conv3x3_wino_tiles(N, H, W);
+        if (tiles_out) *tiles_out = cpg_conv3x3_wino_tiles(N, c_read, m, H, W);
         if (dry) return CPG_OK;
         return cpg_conv3x3_wino_run(dgrad ? 1 : 0, N, c_read, m, H, W, K, C, x, w, pm, thr, bias, y, stats, ws, ws_bytes, stream);
     }

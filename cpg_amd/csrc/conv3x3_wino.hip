@@ -1192,6 +1192,370 @@ void k_wg2(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     }
 }
 
+// ------------------------------------------------------------------------------ two waves = one unit of 64 channels ("k_wg3")
+// k_wg2 with 64 output channels per wave: the transformed input (whose adds and LDS round trip are paid in MFMA time, see k_wg2) feeds
+// twice the MFMAs.  Wave ph owns the positions of transform rows 2 ph, 2 ph + 1 for the channel halves kq = 0, 1: 16 accumulators =
+// 256 AGPRs, one wave per SIMD, two 2-wave blocks per CU.  Per chunk: 32 MFMAs against 32 (not 64) transform adds, 7 (not 9) row
+// loads and 8 float4 of U.
+#define W3_ONE_0(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[0:15], %0, %1, a[0:15]" : : "v"(A), "v"(B) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15")
+#define W3_ONE_1(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[16:31], %0, %1, a[16:31]" : : "v"(A), "v"(B) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31")
+#define W3_ONE_2(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[32:47], %0, %1, a[32:47]" : : "v"(A), "v"(B) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47")
+#define W3_ONE_3(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[48:63], %0, %1, a[48:63]" : : "v"(A), "v"(B) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63")
+#define W3_ONE_4(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[64:79], %0, %1, a[64:79]" : : "v"(A), "v"(B) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79")
+#define W3_ONE_5(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[80:95], %0, %1, a[80:95]" : : "v"(A), "v"(B) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95")
+#define W3_ONE_6(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[96:111], %0, %1, a[96:111]" : : "v"(A), "v"(B) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111")
+#define W3_ONE_7(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[112:127], %0, %1, a[112:127]" : : "v"(A), "v"(B) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127")
+#define W3_ONE_8(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[128:143], %0, %1, a[128:143]" : : "v"(A), "v"(B) : "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143")
+#define W3_ONE_9(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[144:159], %0, %1, a[144:159]" : : "v"(A), "v"(B) : "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159")
+#define W3_ONE_10(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[160:175], %0, %1, a[160:175]" : : "v"(A), "v"(B) : "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175")
+#define W3_ONE_11(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[176:191], %0, %1, a[176:191]" : : "v"(A), "v"(B) : "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191")
+#define W3_ONE_12(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[192:207], %0, %1, a[192:207]" : : "v"(A), "v"(B) : "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207")
+#define W3_ONE_13(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[208:223], %0, %1, a[208:223]" : : "v"(A), "v"(B) : "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223")
+#define W3_ONE_14(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[224:239], %0, %1, a[224:239]" : : "v"(A), "v"(B) : "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239")
+#define W3_ONE_15(A, B) asm volatile("v_mfma_f32_32x32x2_f32 a[240:255], %0, %1, a[240:255]" : : "v"(A), "v"(B) : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255")
+
+#define W3_RD_0_0(m) asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a16\n\tv_accvgpr_read_b32 %2, a32\n\tv_accvgpr_read_b32 %3, a48\n\tv_accvgpr_read_b32 %4, a64\n\tv_accvgpr_read_b32 %5, a80\n\tv_accvgpr_read_b32 %6, a96\n\tv_accvgpr_read_b32 %7, a112" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_0_1(m) asm volatile("v_accvgpr_read_b32 %0, a1\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a33\n\tv_accvgpr_read_b32 %3, a49\n\tv_accvgpr_read_b32 %4, a65\n\tv_accvgpr_read_b32 %5, a81\n\tv_accvgpr_read_b32 %6, a97\n\tv_accvgpr_read_b32 %7, a113" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_0_2(m) asm volatile("v_accvgpr_read_b32 %0, a2\n\tv_accvgpr_read_b32 %1, a18\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a50\n\tv_accvgpr_read_b32 %4, a66\n\tv_accvgpr_read_b32 %5, a82\n\tv_accvgpr_read_b32 %6, a98\n\tv_accvgpr_read_b32 %7, a114" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_0_3(m) asm volatile("v_accvgpr_read_b32 %0, a3\n\tv_accvgpr_read_b32 %1, a19\n\tv_accvgpr_read_b32 %2, a35\n\tv_accvgpr_read_b32 %3, a51\n\tv_accvgpr_read_b32 %4, a67\n\tv_accvgpr_read_b32 %5, a83\n\tv_accvgpr_read_b32 %6, a99\n\tv_accvgpr_read_b32 %7, a115" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_0_4(m) asm volatile("v_accvgpr_read_b32 %0, a4\n\tv_accvgpr_read_b32 %1, a20\n\tv_accvgpr_read_b32 %2, a36\n\tv_accvgpr_read_b32 %3, a52\n\tv_accvgpr_read_b32 %4, a68\n\tv_accvgpr_read_b32 %5, a84\n\tv_accvgpr_read_b32 %6, a100\n\tv_accvgpr_read_b32 %7, a116" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_0_5(m) asm volatile("v_accvgpr_read_b32 %0, a5\n\tv_accvgpr_read_b32 %1, a21\n\tv_accvgpr_read_b32 %2, a37\n\tv_accvgpr_read_b32 %3, a53\n\tv_accvgpr_read_b32 %4, a69\n\tv_accvgpr_read_b32 %5, a85\n\tv_accvgpr_read_b32 %6, a101\n\tv_accvgpr_read_b32 %7, a117" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_0_6(m) asm volatile("v_accvgpr_read_b32 %0, a6\n\tv_accvgpr_read_b32 %1, a22\n\tv_accvgpr_read_b32 %2, a38\n\tv_accvgpr_read_b32 %3, a54\n\tv_accvgpr_read_b32 %4, a70\n\tv_accvgpr_read_b32 %5, a86\n\tv_accvgpr_read_b32 %6, a102\n\tv_accvgpr_read_b32 %7, a118" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_0_7(m) asm volatile("v_accvgpr_read_b32 %0, a7\n\tv_accvgpr_read_b32 %1, a23\n\tv_accvgpr_read_b32 %2, a39\n\tv_accvgpr_read_b32 %3, a55\n\tv_accvgpr_read_b32 %4, a71\n\tv_accvgpr_read_b32 %5, a87\n\tv_accvgpr_read_b32 %6, a103\n\tv_accvgpr_read_b32 %7, a119" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_0_8(m) asm volatile("v_accvgpr_read_b32 %0, a8\n\tv_accvgpr_read_b32 %1, a24\n\tv_accvgpr_read_b32 %2, a40\n\tv_accvgpr_read_b32 %3, a56\n\tv_accvgpr_read_b32 %4, a72\n\tv_accvgpr_read_b32 %5, a88\n\tv_accvgpr_read_b32 %6, a104\n\tv_accvgpr_read_b32 %7, a120" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_0_9(m) asm volatile("v_accvgpr_read_b32 %0, a9\n\tv_accvgpr_read_b32 %1, a25\n\tv_accvgpr_read_b32 %2, a41\n\tv_accvgpr_read_b32 %3, a57\n\tv_accvgpr_read_b32 %4, a73\n\tv_accvgpr_read_b32 %5, a89\n\tv_accvgpr_read_b32 %6, a105\n\tv_accvgpr_read_b32 %7, a121" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_0_10(m) asm volatile("v_accvgpr_read_b32 %0, a10\n\tv_accvgpr_read_b32 %1, a26\n\tv_accvgpr_read_b32 %2, a42\n\tv_accvgpr_read_b32 %3, a58\n\tv_accvgpr_read_b32 %4, a74\n\tv_accvgpr_read_b32 %5, a90\n\tv_accvgpr_read_b32 %6, a106\n\tv_accvgpr_read_b32 %7, a122" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_0_11(m) asm volatile("v_accvgpr_read_b32 %0, a11\n\tv_accvgpr_read_b32 %1, a27\n\tv_accvgpr_read_b32 %2, a43\n\tv_accvgpr_read_b32 %3, a59\n\tv_accvgpr_read_b32 %4, a75\n\tv_accvgpr_read_b32 %5, a91\n\tv_accvgpr_read_b32 %6, a107\n\tv_accvgpr_read_b32 %7, a123" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_0_12(m) asm volatile("v_accvgpr_read_b32 %0, a12\n\tv_accvgpr_read_b32 %1, a28\n\tv_accvgpr_read_b32 %2, a44\n\tv_accvgpr_read_b32 %3, a60\n\tv_accvgpr_read_b32 %4, a76\n\tv_accvgpr_read_b32 %5, a92\n\tv_accvgpr_read_b32 %6, a108\n\tv_accvgpr_read_b32 %7, a124" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_0_13(m) asm volatile("v_accvgpr_read_b32 %0, a13\n\tv_accvgpr_read_b32 %1, a29\n\tv_accvgpr_read_b32 %2, a45\n\tv_accvgpr_read_b32 %3, a61\n\tv_accvgpr_read_b32 %4, a77\n\tv_accvgpr_read_b32 %5, a93\n\tv_accvgpr_read_b32 %6, a109\n\tv_accvgpr_read_b32 %7, a125" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_0_14(m) asm volatile("v_accvgpr_read_b32 %0, a14\n\tv_accvgpr_read_b32 %1, a30\n\tv_accvgpr_read_b32 %2, a46\n\tv_accvgpr_read_b32 %3, a62\n\tv_accvgpr_read_b32 %4, a78\n\tv_accvgpr_read_b32 %5, a94\n\tv_accvgpr_read_b32 %6, a110\n\tv_accvgpr_read_b32 %7, a126" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_0_15(m) asm volatile("v_accvgpr_read_b32 %0, a15\n\tv_accvgpr_read_b32 %1, a31\n\tv_accvgpr_read_b32 %2, a47\n\tv_accvgpr_read_b32 %3, a63\n\tv_accvgpr_read_b32 %4, a79\n\tv_accvgpr_read_b32 %5, a95\n\tv_accvgpr_read_b32 %6, a111\n\tv_accvgpr_read_b32 %7, a127" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_1_0(m) asm volatile("v_accvgpr_read_b32 %0, a128\n\tv_accvgpr_read_b32 %1, a144\n\tv_accvgpr_read_b32 %2, a160\n\tv_accvgpr_read_b32 %3, a176\n\tv_accvgpr_read_b32 %4, a192\n\tv_accvgpr_read_b32 %5, a208\n\tv_accvgpr_read_b32 %6, a224\n\tv_accvgpr_read_b32 %7, a240" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_1_1(m) asm volatile("v_accvgpr_read_b32 %0, a129\n\tv_accvgpr_read_b32 %1, a145\n\tv_accvgpr_read_b32 %2, a161\n\tv_accvgpr_read_b32 %3, a177\n\tv_accvgpr_read_b32 %4, a193\n\tv_accvgpr_read_b32 %5, a209\n\tv_accvgpr_read_b32 %6, a225\n\tv_accvgpr_read_b32 %7, a241" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_1_2(m) asm volatile("v_accvgpr_read_b32 %0, a130\n\tv_accvgpr_read_b32 %1, a146\n\tv_accvgpr_read_b32 %2, a162\n\tv_accvgpr_read_b32 %3, a178\n\tv_accvgpr_read_b32 %4, a194\n\tv_accvgpr_read_b32 %5, a210\n\tv_accvgpr_read_b32 %6, a226\n\tv_accvgpr_read_b32 %7, a242" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_1_3(m) asm volatile("v_accvgpr_read_b32 %0, a131\n\tv_accvgpr_read_b32 %1, a147\n\tv_accvgpr_read_b32 %2, a163\n\tv_accvgpr_read_b32 %3, a179\n\tv_accvgpr_read_b32 %4, a195\n\tv_accvgpr_read_b32 %5, a211\n\tv_accvgpr_read_b32 %6, a227\n\tv_accvgpr_read_b32 %7, a243" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_1_4(m) asm volatile("v_accvgpr_read_b32 %0, a132\n\tv_accvgpr_read_b32 %1, a148\n\tv_accvgpr_read_b32 %2, a164\n\tv_accvgpr_read_b32 %3, a180\n\tv_accvgpr_read_b32 %4, a196\n\tv_accvgpr_read_b32 %5, a212\n\tv_accvgpr_read_b32 %6, a228\n\tv_accvgpr_read_b32 %7, a244" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_1_5(m) asm volatile("v_accvgpr_read_b32 %0, a133\n\tv_accvgpr_read_b32 %1, a149\n\tv_accvgpr_read_b32 %2, a165\n\tv_accvgpr_read_b32 %3, a181\n\tv_accvgpr_read_b32 %4, a197\n\tv_accvgpr_read_b32 %5, a213\n\tv_accvgpr_read_b32 %6, a229\n\tv_accvgpr_read_b32 %7, a245" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_1_6(m) asm volatile("v_accvgpr_read_b32 %0, a134\n\tv_accvgpr_read_b32 %1, a150\n\tv_accvgpr_read_b32 %2, a166\n\tv_accvgpr_read_b32 %3, a182\n\tv_accvgpr_read_b32 %4, a198\n\tv_accvgpr_read_b32 %5, a214\n\tv_accvgpr_read_b32 %6, a230\n\tv_accvgpr_read_b32 %7, a246" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_1_7(m) asm volatile("v_accvgpr_read_b32 %0, a135\n\tv_accvgpr_read_b32 %1, a151\n\tv_accvgpr_read_b32 %2, a167\n\tv_accvgpr_read_b32 %3, a183\n\tv_accvgpr_read_b32 %4, a199\n\tv_accvgpr_read_b32 %5, a215\n\tv_accvgpr_read_b32 %6, a231\n\tv_accvgpr_read_b32 %7, a247" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_1_8(m) asm volatile("v_accvgpr_read_b32 %0, a136\n\tv_accvgpr_read_b32 %1, a152\n\tv_accvgpr_read_b32 %2, a168\n\tv_accvgpr_read_b32 %3, a184\n\tv_accvgpr_read_b32 %4, a200\n\tv_accvgpr_read_b32 %5, a216\n\tv_accvgpr_read_b32 %6, a232\n\tv_accvgpr_read_b32 %7, a248" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_1_9(m) asm volatile("v_accvgpr_read_b32 %0, a137\n\tv_accvgpr_read_b32 %1, a153\n\tv_accvgpr_read_b32 %2, a169\n\tv_accvgpr_read_b32 %3, a185\n\tv_accvgpr_read_b32 %4, a201\n\tv_accvgpr_read_b32 %5, a217\n\tv_accvgpr_read_b32 %6, a233\n\tv_accvgpr_read_b32 %7, a249" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_1_10(m) asm volatile("v_accvgpr_read_b32 %0, a138\n\tv_accvgpr_read_b32 %1, a154\n\tv_accvgpr_read_b32 %2, a170\n\tv_accvgpr_read_b32 %3, a186\n\tv_accvgpr_read_b32 %4, a202\n\tv_accvgpr_read_b32 %5, a218\n\tv_accvgpr_read_b32 %6, a234\n\tv_accvgpr_read_b32 %7, a250" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_1_11(m) asm volatile("v_accvgpr_read_b32 %0, a139\n\tv_accvgpr_read_b32 %1, a155\n\tv_accvgpr_read_b32 %2, a171\n\tv_accvgpr_read_b32 %3, a187\n\tv_accvgpr_read_b32 %4, a203\n\tv_accvgpr_read_b32 %5, a219\n\tv_accvgpr_read_b32 %6, a235\n\tv_accvgpr_read_b32 %7, a251" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_1_12(m) asm volatile("v_accvgpr_read_b32 %0, a140\n\tv_accvgpr_read_b32 %1, a156\n\tv_accvgpr_read_b32 %2, a172\n\tv_accvgpr_read_b32 %3, a188\n\tv_accvgpr_read_b32 %4, a204\n\tv_accvgpr_read_b32 %5, a220\n\tv_accvgpr_read_b32 %6, a236\n\tv_accvgpr_read_b32 %7, a252" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_1_13(m) asm volatile("v_accvgpr_read_b32 %0, a141\n\tv_accvgpr_read_b32 %1, a157\n\tv_accvgpr_read_b32 %2, a173\n\tv_accvgpr_read_b32 %3, a189\n\tv_accvgpr_read_b32 %4, a205\n\tv_accvgpr_read_b32 %5, a221\n\tv_accvgpr_read_b32 %6, a237\n\tv_accvgpr_read_b32 %7, a253" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_1_14(m) asm volatile("v_accvgpr_read_b32 %0, a142\n\tv_accvgpr_read_b32 %1, a158\n\tv_accvgpr_read_b32 %2, a174\n\tv_accvgpr_read_b32 %3, a190\n\tv_accvgpr_read_b32 %4, a206\n\tv_accvgpr_read_b32 %5, a222\n\tv_accvgpr_read_b32 %6, a238\n\tv_accvgpr_read_b32 %7, a254" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+#define W3_RD_1_15(m) asm volatile("v_accvgpr_read_b32 %0, a143\n\tv_accvgpr_read_b32 %1, a159\n\tv_accvgpr_read_b32 %2, a175\n\tv_accvgpr_read_b32 %3, a191\n\tv_accvgpr_read_b32 %4, a207\n\tv_accvgpr_read_b32 %5, a223\n\tv_accvgpr_read_b32 %6, a239\n\tv_accvgpr_read_b32 %7, a255" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
+
+template <bool DGRAD, bool STATS, bool BNE = false>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
+           float *__restrict__ y, float *__restrict__ stats, WgBnEval bn) {
+    __shared__ __attribute__((aligned(16))) float smem_all[2 * 64 * 64];       // 2 x 2 raw stages (3264 floats) / the exchange buffer (32 KB)
+    const int tid = threadIdx.x, lane = tid & 63, ph = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int HW = g.H * g.W;
+    float *smem = smem_all + ph * 2 * W2_RAW;                 // this wave's private raw stages
+
+    unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int nkb64 = (g.nkb + 1) / 2;                        // (g.nkb counts blocks of 32 channels)
+    const int kb = lb % nkb64;                                // block of 64 output channels
+    const unsigned ttot = (unsigned)g.tiles_total, timg = (unsigned)g.tiles_img, twu = (unsigned)g.tw;
+    const unsigned run = lb / nkb64;                          // tile run of 32
+    const unsigned t0 = run * W1_T;
+    if (t0 >= ttot) return;                                   // (uniform for the block)
+    const int n0 = (int)(t0 / timg);
+
+    constexpr int kOutOfRange = (int)0x80000000;
+    int roff[3], hoff, lo, ro;
+    {
+        const unsigned tg = t0 + li;
+        const bool tv = tg < ttot;
+        const int n = (int)(tg / timg), r = (int)(tg % timg);
+        const int ty = (int)((unsigned)r / twu), tx = (int)((unsigned)r % twu);
+        const int cbase = ((n - n0) * g.C + 2 * lh) * HW;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int gh = 2 * ty - 1 + ph + i;
+            roff[i] = (tv && (unsigned)gh < (unsigned)g.H) ? (cbase + gh * g.W + 2 * tx) * 4 : kOutOfRange;
+        }
+        lo = tx == 0 ? 0 : (li + 1) * 2 - 1;
+        ro = tx == g.tw - 1 ? (W1_T + 1) * 2 + 1 : (li + 1) * 2 + 2;
+        // halo: lanes 0-23 = (side, row, channel): the column left of tile t0 / right of tile t0 + 31
+        const int side = lane >= 12 ? 1 : 0, hl = lane - 12 * side, hi = hl >> 2, hc = hl & 3;
+        const unsigned th = side ? t0 + W1_T - 1 : t0;
+        const int nh = (int)(th / timg), rh = (int)(th % timg);
+        const int tyh = (int)((unsigned)rh / twu), txh = (int)((unsigned)rh % twu);
+        const int ghh = 2 * tyh - 1 + ph + hi, gwh = side ? 2 * txh + 2 : 2 * txh - 1;
+        const bool okh = lane < 24 && th < ttot && (unsigned)ghh < (unsigned)g.H && (unsigned)gwh < (unsigned)g.W;
+        hoff = okh ? (((nh - n0) * g.C + hc) * HW + ghh * g.W + gwh) * 4 : kOutOfRange;
+    }
+    const int span = (W1_T + g.tiles_img - 1) / g.tiles_img + 1;
+    const int nimg_here = min(span, g.N - n0);
+    const __amdgpu_buffer_rsrc_t srd_x =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(x + (int64_t)n0 * g.C * HW), 0, nimg_here * g.C * HW * 4, 0x00020000);
+    // U records are per block of 32 channels: this wave reads float4 q = 4 ph .. + 3 of the records of blocks 2 kb, 2 kb + 1
+    const float *ubase = up + (int64_t)(2 * kb) * g.nch * W1_U + ph * 1024 + lane * 4;
+    const int64_t ukq = (int64_t)g.nch * W1_U;
+
+    // raw[c][row][slot][2] offsets of this lane (channels 2 lh + j)
+    const int raw_own = (2 * lh) * 3 * W1_ROW + (li + 1) * 2;
+    const int hside = lane >= 12 ? 1 : 0, hrem = lane - 12 * hside;
+    const int halo_w = ((hrem & 3) * 3 + (hrem >> 2)) * W1_ROW + (hside ? (W1_T + 1) * 2 : 1);
+    if (lane < 24) {                                          // zero slots of the 2 x 12 rows (never written)
+        smem[lane * W1_ROW] = 0.0f;
+        smem[lane * W1_ROW + (W1_T + 1) * 2 + 1] = 0.0f;
+    }
+
+    struct Rows {
+        i32x2 r[2][3];
+        float halo;
+    };
+    auto G_row1 = [&](int ch, Rows &q, int k) {             // k = 0..5: row k % 3 of channel 2 lh + k / 3;  k = 6: the halo values
+        const int soff = ch * WG_CK * HW * 4;
+        if (k < 6)
+            q.r[k / 3][k % 3] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[k % 3], soff + (k / 3) * HW * 4, 0);
+        else
+            q.halo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, hoff, soff, 0));
+    };
+    auto W_row1 = [&](int stage, const Rows &q, int k) {
+        float *raw = smem + stage * W2_RAW;
+        if (k < 6)
+            *reinterpret_cast<i32x2 *>(raw + raw_own + k * W1_ROW) = q.r[k / 3][k % 3];
+        else if (lane < 24)
+            raw[halo_w] = q.halo;
+    };
+    auto G_u1 = [&](int ch, f32x4 (&u)[8], int q) { u[q] = *reinterpret_cast<const f32x4 *>(ubase + (q >> 2) * ukq + (int64_t)ch * W1_U + (q & 3) * 256); };
+    // half patch of (tile li, channel 2 lh + j): rows ph .. ph + 2 -> the 8 values of transform rows 2 ph, 2 ph + 1 in d[0..7]
+    auto T_read1 = [&](int stage, int j, float (&d)[12], int i) {
+        const float *raw = smem + stage * W2_RAW + ((2 * lh + j) * 3 + i) * W1_ROW;
+        const f32x2 own = *reinterpret_cast<const f32x2 *>(raw + (li + 1) * 2);
+        d[i * 4 + 0] = raw[lo], d[i * 4 + 1] = own[0], d[i * 4 + 2] = own[1], d[i * 4 + 3] = raw[ro];
+    };
+    // B^T d: ph = 0 holds patch rows 0, 1, 2 -> rows 0, 1 = d0 - d2, d1 + d2;  ph = 1 holds 1, 2, 3 -> rows 2, 3 = d2 - d1, d1 - d3
+    auto T_col = [&](float (&d)[12], int j0) {
+#pragma unroll
+        for (int j = j0; j < j0 + 2; ++j) {
+            const float e0 = d[0 * 4 + j], e1 = d[1 * 4 + j], e2 = d[2 * 4 + j];
+            d[0 * 4 + j] = ph ? e1 - e0 : e0 - e2;
+            d[1 * 4 + j] = ph ? e0 - e2 : e1 + e2;
+            asm volatile("" : "+v"(d[0 * 4 + j]), "+v"(d[1 * 4 + j]));
+        }
+    };
+    auto T_rowp = [&](float (&d)[12], int i) {
+        const float t0_ = d[i * 4 + 0], t1 = d[i * 4 + 1], t2 = d[i * 4 + 2], t3 = d[i * 4 + 3];
+        d[i * 4 + 0] = t0_ - t2, d[i * 4 + 1] = t1 + t2, d[i * 4 + 2] = t2 - t1, d[i * 4 + 3] = t1 - t3;
+        asm volatile("" : "+v"(d[i * 4 + 0]), "+v"(d[i * 4 + 1]), "+v"(d[i * 4 + 2]), "+v"(d[i * 4 + 3]));
+    };
+
+    asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0" : : : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
+    asm volatile("v_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0" : : : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
+    asm volatile("v_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0" : : : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+    asm volatile("v_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0" : : : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
+    asm volatile("v_accvgpr_write_b32 a64, 0\n\tv_accvgpr_write_b32 a65, 0\n\tv_accvgpr_write_b32 a66, 0\n\tv_accvgpr_write_b32 a67, 0\n\tv_accvgpr_write_b32 a68, 0\n\tv_accvgpr_write_b32 a69, 0\n\tv_accvgpr_write_b32 a70, 0\n\tv_accvgpr_write_b32 a71, 0\n\tv_accvgpr_write_b32 a72, 0\n\tv_accvgpr_write_b32 a73, 0\n\tv_accvgpr_write_b32 a74, 0\n\tv_accvgpr_write_b32 a75, 0\n\tv_accvgpr_write_b32 a76, 0\n\tv_accvgpr_write_b32 a77, 0\n\tv_accvgpr_write_b32 a78, 0\n\tv_accvgpr_write_b32 a79, 0" : : : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
+    asm volatile("v_accvgpr_write_b32 a80, 0\n\tv_accvgpr_write_b32 a81, 0\n\tv_accvgpr_write_b32 a82, 0\n\tv_accvgpr_write_b32 a83, 0\n\tv_accvgpr_write_b32 a84, 0\n\tv_accvgpr_write_b32 a85, 0\n\tv_accvgpr_write_b32 a86, 0\n\tv_accvgpr_write_b32 a87, 0\n\tv_accvgpr_write_b32 a88, 0\n\tv_accvgpr_write_b32 a89, 0\n\tv_accvgpr_write_b32 a90, 0\n\tv_accvgpr_write_b32 a91, 0\n\tv_accvgpr_write_b32 a92, 0\n\tv_accvgpr_write_b32 a93, 0\n\tv_accvgpr_write_b32 a94, 0\n\tv_accvgpr_write_b32 a95, 0" : : : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
+    asm volatile("v_accvgpr_write_b32 a96, 0\n\tv_accvgpr_write_b32 a97, 0\n\tv_accvgpr_write_b32 a98, 0\n\tv_accvgpr_write_b32 a99, 0\n\tv_accvgpr_write_b32 a100, 0\n\tv_accvgpr_write_b32 a101, 0\n\tv_accvgpr_write_b32 a102, 0\n\tv_accvgpr_write_b32 a103, 0\n\tv_accvgpr_write_b32 a104, 0\n\tv_accvgpr_write_b32 a105, 0\n\tv_accvgpr_write_b32 a106, 0\n\tv_accvgpr_write_b32 a107, 0\n\tv_accvgpr_write_b32 a108, 0\n\tv_accvgpr_write_b32 a109, 0\n\tv_accvgpr_write_b32 a110, 0\n\tv_accvgpr_write_b32 a111, 0" : : : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
+    asm volatile("v_accvgpr_write_b32 a112, 0\n\tv_accvgpr_write_b32 a113, 0\n\tv_accvgpr_write_b32 a114, 0\n\tv_accvgpr_write_b32 a115, 0\n\tv_accvgpr_write_b32 a116, 0\n\tv_accvgpr_write_b32 a117, 0\n\tv_accvgpr_write_b32 a118, 0\n\tv_accvgpr_write_b32 a119, 0\n\tv_accvgpr_write_b32 a120, 0\n\tv_accvgpr_write_b32 a121, 0\n\tv_accvgpr_write_b32 a122, 0\n\tv_accvgpr_write_b32 a123, 0\n\tv_accvgpr_write_b32 a124, 0\n\tv_accvgpr_write_b32 a125, 0\n\tv_accvgpr_write_b32 a126, 0\n\tv_accvgpr_write_b32 a127, 0" : : : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
+    asm volatile("v_accvgpr_write_b32 a128, 0\n\tv_accvgpr_write_b32 a129, 0\n\tv_accvgpr_write_b32 a130, 0\n\tv_accvgpr_write_b32 a131, 0\n\tv_accvgpr_write_b32 a132, 0\n\tv_accvgpr_write_b32 a133, 0\n\tv_accvgpr_write_b32 a134, 0\n\tv_accvgpr_write_b32 a135, 0\n\tv_accvgpr_write_b32 a136, 0\n\tv_accvgpr_write_b32 a137, 0\n\tv_accvgpr_write_b32 a138, 0\n\tv_accvgpr_write_b32 a139, 0\n\tv_accvgpr_write_b32 a140, 0\n\tv_accvgpr_write_b32 a141, 0\n\tv_accvgpr_write_b32 a142, 0\n\tv_accvgpr_write_b32 a143, 0" : : : "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143");
+    asm volatile("v_accvgpr_write_b32 a144, 0\n\tv_accvgpr_write_b32 a145, 0\n\tv_accvgpr_write_b32 a146, 0\n\tv_accvgpr_write_b32 a147, 0\n\tv_accvgpr_write_b32 a148, 0\n\tv_accvgpr_write_b32 a149, 0\n\tv_accvgpr_write_b32 a150, 0\n\tv_accvgpr_write_b32 a151, 0\n\tv_accvgpr_write_b32 a152, 0\n\tv_accvgpr_write_b32 a153, 0\n\tv_accvgpr_write_b32 a154, 0\n\tv_accvgpr_write_b32 a155, 0\n\tv_accvgpr_write_b32 a156, 0\n\tv_accvgpr_write_b32 a157, 0\n\tv_accvgpr_write_b32 a158, 0\n\tv_accvgpr_write_b32 a159, 0" : : : "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159");
+    asm volatile("v_accvgpr_write_b32 a160, 0\n\tv_accvgpr_write_b32 a161, 0\n\tv_accvgpr_write_b32 a162, 0\n\tv_accvgpr_write_b32 a163, 0\n\tv_accvgpr_write_b32 a164, 0\n\tv_accvgpr_write_b32 a165, 0\n\tv_accvgpr_write_b32 a166, 0\n\tv_accvgpr_write_b32 a167, 0\n\tv_accvgpr_write_b32 a168, 0\n\tv_accvgpr_write_b32 a169, 0\n\tv_accvgpr_write_b32 a170, 0\n\tv_accvgpr_write_b32 a171, 0\n\tv_accvgpr_write_b32 a172, 0\n\tv_accvgpr_write_b32 a173, 0\n\tv_accvgpr_write_b32 a174, 0\n\tv_accvgpr_write_b32 a175, 0" : : : "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175");
+    asm volatile("v_accvgpr_write_b32 a176, 0\n\tv_accvgpr_write_b32 a177, 0\n\tv_accvgpr_write_b32 a178, 0\n\tv_accvgpr_write_b32 a179, 0\n\tv_accvgpr_write_b32 a180, 0\n\tv_accvgpr_write_b32 a181, 0\n\tv_accvgpr_write_b32 a182, 0\n\tv_accvgpr_write_b32 a183, 0\n\tv_accvgpr_write_b32 a184, 0\n\tv_accvgpr_write_b32 a185, 0\n\tv_accvgpr_write_b32 a186, 0\n\tv_accvgpr_write_b32 a187, 0\n\tv_accvgpr_write_b32 a188, 0\n\tv_accvgpr_write_b32 a189, 0\n\tv_accvgpr_write_b32 a190, 0\n\tv_accvgpr_write_b32 a191, 0" : : : "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191");
+    asm volatile("v_accvgpr_write_b32 a192, 0\n\tv_accvgpr_write_b32 a193, 0\n\tv_accvgpr_write_b32 a194, 0\n\tv_accvgpr_write_b32 a195, 0\n\tv_accvgpr_write_b32 a196, 0\n\tv_accvgpr_write_b32 a197, 0\n\tv_accvgpr_write_b32 a198, 0\n\tv_accvgpr_write_b32 a199, 0\n\tv_accvgpr_write_b32 a200, 0\n\tv_accvgpr_write_b32 a201, 0\n\tv_accvgpr_write_b32 a202, 0\n\tv_accvgpr_write_b32 a203, 0\n\tv_accvgpr_write_b32 a204, 0\n\tv_accvgpr_write_b32 a205, 0\n\tv_accvgpr_write_b32 a206, 0\n\tv_accvgpr_write_b32 a207, 0" : : : "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207");
+    asm volatile("v_accvgpr_write_b32 a208, 0\n\tv_accvgpr_write_b32 a209, 0\n\tv_accvgpr_write_b32 a210, 0\n\tv_accvgpr_write_b32 a211, 0\n\tv_accvgpr_write_b32 a212, 0\n\tv_accvgpr_write_b32 a213, 0\n\tv_accvgpr_write_b32 a214, 0\n\tv_accvgpr_write_b32 a215, 0\n\tv_accvgpr_write_b32 a216, 0\n\tv_accvgpr_write_b32 a217, 0\n\tv_accvgpr_write_b32 a218, 0\n\tv_accvgpr_write_b32 a219, 0\n\tv_accvgpr_write_b32 a220, 0\n\tv_accvgpr_write_b32 a221, 0\n\tv_accvgpr_write_b32 a222, 0\n\tv_accvgpr_write_b32 a223, 0" : : : "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223");
+    asm volatile("v_accvgpr_write_b32 a224, 0\n\tv_accvgpr_write_b32 a225, 0\n\tv_accvgpr_write_b32 a226, 0\n\tv_accvgpr_write_b32 a227, 0\n\tv_accvgpr_write_b32 a228, 0\n\tv_accvgpr_write_b32 a229, 0\n\tv_accvgpr_write_b32 a230, 0\n\tv_accvgpr_write_b32 a231, 0\n\tv_accvgpr_write_b32 a232, 0\n\tv_accvgpr_write_b32 a233, 0\n\tv_accvgpr_write_b32 a234, 0\n\tv_accvgpr_write_b32 a235, 0\n\tv_accvgpr_write_b32 a236, 0\n\tv_accvgpr_write_b32 a237, 0\n\tv_accvgpr_write_b32 a238, 0\n\tv_accvgpr_write_b32 a239, 0" : : : "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239");
+    asm volatile("v_accvgpr_write_b32 a240, 0\n\tv_accvgpr_write_b32 a241, 0\n\tv_accvgpr_write_b32 a242, 0\n\tv_accvgpr_write_b32 a243, 0\n\tv_accvgpr_write_b32 a244, 0\n\tv_accvgpr_write_b32 a245, 0\n\tv_accvgpr_write_b32 a246, 0\n\tv_accvgpr_write_b32 a247, 0\n\tv_accvgpr_write_b32 a248, 0\n\tv_accvgpr_write_b32 a249, 0\n\tv_accvgpr_write_b32 a250, 0\n\tv_accvgpr_write_b32 a251, 0\n\tv_accvgpr_write_b32 a252, 0\n\tv_accvgpr_write_b32 a253, 0\n\tv_accvgpr_write_b32 a254, 0\n\tv_accvgpr_write_b32 a255, 0" : : : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+
+    int nch = g.nch;
+    if (BNE && bn.live != nullptr) {                          // inference: skip what apply_mask killed (wave-uniform decisions)
+        const int alive = (kb * 64 + lane < g.M) ? bn.live[kb * 64 + lane] : 0;
+        const bool dead = __ballot(alive != 0) == 0ull;
+        int lastc = g.nch;
+        while (lastc > 0 && bn.live[bn.Mp + 4 + lastc - 1] == 0) --lastc;
+        nch = dead ? 0 : lastc;
+        if (lane == 0 && ph == 0) {
+            if (dead) atomicAdd(&bn.live[bn.Mp + 1], 1);
+            if (blockIdx.x == 0) bn.live[bn.Mp] = lastc * WG_CK;
+        }
+    }
+    const int last = nch - 1;
+    auto clampc = [&](int c) { return min(c, last); };
+    f32x4 ua[8], ub[8];                    // U of the current / next chunk: [kq * 4 + q]
+    float c0[12], c1[12], x0[12], x1[12];  // B operands ([0..7]) of the current chunk for channels 2 lh, 2 lh + 1 / the next chunk's, being transformed
+    Rows rows;
+    if (nch > 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) G_row1(0, rows, k);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) G_u1(0, ua, q);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) W_row1(0, rows, k);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) G_row1(clampc(1), rows, k);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { T_read1(0, 0, c0, i); T_read1(0, 1, c1, i); }
+        T_col(c0, 0); T_col(c0, 2); T_col(c1, 0); T_col(c1, 2);
+        T_rowp(c0, 0); T_rowp(c0, 1); T_rowp(c1, 0); T_rowp(c1, 1);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) W_row1(1, rows, k);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) G_row1(clampc(2), rows, k);
+    }
+// accumulator a = kq * 8 + pp (channel half kq, local position pp)
+#define W3_SLOT(a, h, U, B, work)                                                                  \
+    W3_ONE_##a((U)[((a) >> 3) * 4 + (((a) & 7) >> 1)][((a) & 1) * 2 + (h)], (B)[(a) & 7]);         \
+    work;                                                                                          \
+    __builtin_amdgcn_sched_barrier(0)
+    // iteration it (par = it & 1): M(it); T(it + 1) from raw stage (it + 1) & 1; U(it + 1) requested; W(it + 2) stores the rows
+    // requested one iteration ago, whose registers then take the loads of chunk it + 3
+    auto iter = [&](int it, int par, f32x4 (&ucur)[8], f32x4 (&unext)[8], float (&b0)[12], float (&b1)[12], float (&n0v)[12], float (&n1v)[12]) {
+        const int cu = clampc(it + 1), cr = clampc(it + 3);
+        W3_SLOT(0, 0, ucur, b0, T_read1(par ^ 1, 0, n0v, 0));
+        W3_SLOT(0, 1, ucur, b1, T_read1(par ^ 1, 0, n0v, 1));
+        W3_SLOT(8, 0, ucur, b0, T_read1(par ^ 1, 0, n0v, 2));
+        W3_SLOT(8, 1, ucur, b1, T_read1(par ^ 1, 1, n1v, 0));
+        W3_SLOT(1, 0, ucur, b0, T_read1(par ^ 1, 1, n1v, 1));
+        W3_SLOT(1, 1, ucur, b1, T_read1(par ^ 1, 1, n1v, 2));
+        W3_SLOT(9, 0, ucur, b0, G_u1(cu, unext, 0));
+        W3_SLOT(9, 1, ucur, b1, G_u1(cu, unext, 1));
+        W3_SLOT(2, 0, ucur, b0, T_col(n0v, 0));
+        W3_SLOT(2, 1, ucur, b1, G_u1(cu, unext, 2));
+        W3_SLOT(10, 0, ucur, b0, T_col(n0v, 2));
+        W3_SLOT(10, 1, ucur, b1, G_u1(cu, unext, 3));
+        W3_SLOT(3, 0, ucur, b0, T_col(n1v, 0));
+        W3_SLOT(3, 1, ucur, b1, G_u1(cu, unext, 4));
+        W3_SLOT(11, 0, ucur, b0, T_col(n1v, 2));
+        W3_SLOT(11, 1, ucur, b1, G_u1(cu, unext, 5));
+        W3_SLOT(4, 0, ucur, b0, T_rowp(n0v, 0));
+        W3_SLOT(4, 1, ucur, b1, G_u1(cu, unext, 6));
+        W3_SLOT(12, 0, ucur, b0, T_rowp(n0v, 1));
+        W3_SLOT(12, 1, ucur, b1, G_u1(cu, unext, 7));
+        W3_SLOT(5, 0, ucur, b0, T_rowp(n1v, 0));
+        W3_SLOT(5, 1, ucur, b1, T_rowp(n1v, 1));
+        W3_SLOT(13, 0, ucur, b0, W_row1(par, rows, 0); G_row1(cr, rows, 0));
+        W3_SLOT(13, 1, ucur, b1, W_row1(par, rows, 1); G_row1(cr, rows, 1));
+        W3_SLOT(6, 0, ucur, b0, W_row1(par, rows, 2); G_row1(cr, rows, 2));
+        W3_SLOT(6, 1, ucur, b1, W_row1(par, rows, 3); G_row1(cr, rows, 3));
+        W3_SLOT(14, 0, ucur, b0, W_row1(par, rows, 4); G_row1(cr, rows, 4));
+        W3_SLOT(14, 1, ucur, b1, W_row1(par, rows, 5); G_row1(cr, rows, 5));
+        W3_SLOT(7, 0, ucur, b0, W_row1(par, rows, 6); G_row1(cr, rows, 6));
+        W3_SLOT(7, 1, ucur, b1, );
+        W3_SLOT(15, 0, ucur, b0, );
+        W3_SLOT(15, 1, ucur, b1, );
+    };
+    for (int it = 0; it < nch; it += 2) {
+        iter(it, 0, ua, ub, c0, c1, x0, x1);
+        if (it + 1 < nch) iter(it + 1, 1, ub, ua, x0, x1, c0, c1);
+    }
+
+    // ---- epilogue: this wave's 8 positions (transform rows i = 2 ph, 2 ph + 1) -> partial 2x2 outputs; the output transform is linear
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    float own0[32], own1[32];                  // the output row this wave finishes (a = ph), columns 0 / 1, per channel half and accumulator element
+    __syncthreads();                           // both waves are done with their raw stages: the LDS becomes the exchange buffer
+    float *xch = smem_all;
+    auto part_e = [&](int kq, int e, const float (&m)[8]) {
+        const float r00 = m[0] + m[1] + m[2], r01 = m[1] - m[2] - m[3];       // R[il][b] = sum_j A^T[b][j] M[i][j]
+        const float r10 = m[4] + m[5] + m[6], r11 = m[5] - m[6] - m[7];
+        float g0, g1;
+        if (ph == 0) {                         // i = 0, 1:  Y0 += R0 + R1 (own),  Y1 += R1 (given to the other wave)
+            own0[kq * 16 + e] = r00 + r10, own1[kq * 16 + e] = r01 + r11, g0 = r10, g1 = r11;
+        } else {                               // i = 2, 3:  Y1 += -R2 - R3 (own),  Y0 += R2 (given)
+            own0[kq * 16 + e] = -r00 - r10, own1[kq * 16 + e] = -r01 - r11, g0 = r00, g1 = r01;
+        }
+        xch[(((ph * 2 + kq) * 2 + 0) * 16 + e) * 64 + lane] = g0;
+        xch[(((ph * 2 + kq) * 2 + 1) * 16 + e) * 64 + lane] = g1;
+    };
+    {
+        float m[8];
+        W3_RD_0_0(m); part_e(0, 0, m);
+        W3_RD_0_1(m); part_e(0, 1, m);
+        W3_RD_0_2(m); part_e(0, 2, m);
+        W3_RD_0_3(m); part_e(0, 3, m);
+        W3_RD_0_4(m); part_e(0, 4, m);
+        W3_RD_0_5(m); part_e(0, 5, m);
+        W3_RD_0_6(m); part_e(0, 6, m);
+        W3_RD_0_7(m); part_e(0, 7, m);
+        W3_RD_0_8(m); part_e(0, 8, m);
+        W3_RD_0_9(m); part_e(0, 9, m);
+        W3_RD_0_10(m); part_e(0, 10, m);
+        W3_RD_0_11(m); part_e(0, 11, m);
+        W3_RD_0_12(m); part_e(0, 12, m);
+        W3_RD_0_13(m); part_e(0, 13, m);
+        W3_RD_0_14(m); part_e(0, 14, m);
+        W3_RD_0_15(m); part_e(0, 15, m);
+        W3_RD_1_0(m); part_e(1, 0, m);
+        W3_RD_1_1(m); part_e(1, 1, m);
+        W3_RD_1_2(m); part_e(1, 2, m);
+        W3_RD_1_3(m); part_e(1, 3, m);
+        W3_RD_1_4(m); part_e(1, 4, m);
+        W3_RD_1_5(m); part_e(1, 5, m);
+        W3_RD_1_6(m); part_e(1, 6, m);
+        W3_RD_1_7(m); part_e(1, 7, m);
+        W3_RD_1_8(m); part_e(1, 8, m);
+        W3_RD_1_9(m); part_e(1, 9, m);
+        W3_RD_1_10(m); part_e(1, 10, m);
+        W3_RD_1_11(m); part_e(1, 11, m);
+        W3_RD_1_12(m); part_e(1, 12, m);
+        W3_RD_1_13(m); part_e(1, 13, m);
+        W3_RD_1_14(m); part_e(1, 14, m);
+        W3_RD_1_15(m); part_e(1, 15, m);
+
+    }
+    __syncthreads();
+    const unsigned tg = t0 + li;
+    const bool tv = tg < ttot;
+    const int n = (int)(tg / timg), r = (int)(tg % timg);
+    const int ty = (int)((unsigned)r / twu), tx = (int)((unsigned)r % twu);
+    float *yout = y + ((int64_t)n * g.M) * HW + (2 * ty + ph) * g.W + 2 * tx;
+    float s1[32], s2[32];
+#pragma unroll
+    for (int ke = 0; ke < 32; ++ke) {
+        const int kq = ke >> 4, e = ke & 15;
+        const int co = kb * 64 + kq * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        float v0 = own0[ke] + xch[((((ph ^ 1) * 2 + kq) * 2 + 0) * 16 + e) * 64 + lane];
+        float v1 = own1[ke] + xch[((((ph ^ 1) * 2 + kq) * 2 + 1) * 16 + e) * 64 + lane];
+        if (bias != nullptr) {
+            const float bv = bias[co < g.M ? co : 0];
+            v0 += bv, v1 += bv;
+        }
+        if (BNE) {                             // y = [max(0,] (conv + bias - mean) * invstd * gamma + beta [)]
+            const int cc = co < g.M ? co : 0;
+            const float mu = bn.mean[cc], is = 1.0f / sqrtf(bn.var[cc] + bn.eps), ga = bn.gamma[cc], be = bn.beta[cc];
+            v0 = (v0 - mu) * is * ga + be, v1 = (v1 - mu) * is * ga + be;
+            if (bn.relu) v0 = fmaxf(v0, 0.0f), v1 = fmaxf(v1, 0.0f);
+        }
+        if (tv && co < g.M) {
+            f32x2 o;
+            o[0] = v0, o[1] = v1;
+            *reinterpret_cast<f32x2 *>(yout + (int64_t)co * HW) = o;
+        }
+        if (STATS) {
+            s1[ke] = tv ? v0 + v1 : 0.0f;
+            s2[ke] = tv ? v0 * v0 + v1 * v1 : 0.0f;
+        }
+    }
+    if (STATS) {                               // every wave is its own statistics tile: stats[k][2 run + ph][2]
+#pragma unroll
+        for (int ke = 0; ke < 32; ++ke)
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                s1[ke] += __shfl_xor(s1[ke], off);
+                s2[ke] += __shfl_xor(s2[ke], off);
+            }
+        if (li == 0) {
+            const unsigned ntile = 2 * ((ttot + W1_T - 1) / W1_T);
+#pragma unroll
+            for (int ke = 0; ke < 32; ++ke) {
+                const int co = kb * 64 + (ke >> 4) * 32 + (ke & 3) + 8 * ((ke & 15) >> 2) + 4 * lh;
+                if (co < g.M) {
+                    float *dst = stats + ((int64_t)co * ntile + 2 * run + ph) * 2;
+                    dst[0] = s1[ke];
+                    dst[1] = s2[ke];
+                }
+            }
+        }
+    }
+}
+
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 
 // waves per block for a launch.  The 8-wave / 64-channel block does half the staging work per MFMA, but its eight waves run in
@@ -1234,21 +1598,27 @@ extern "C" size_t cpg_conv3x3_wino_pack_bytes(int c_read, int m) {      // (the 
     return (size_t)pad_to(m, 64) * pad_to(c_read, WG_CK) * 16 * sizeof(float);
 }
 
-// Default: one wave per unit (k_wg1).  CPG_WINO_KERNEL = pair: two waves per unit (k_wg2, measured the same); = block: the cooperative
-// 4- / 8-wave block kernel k_wg_fwd (measured slower).  (A/B experiments and tests.)
-static inline bool wino_one_wave() {          // k_wg1 or k_wg2: the kernels with the inference epilogue and U in per-lane order
-    const char *f = getenv("CPG_WINO_KERNEL");
-    return !(f && f[0] == 'b');
-}
-static inline bool wino_pair() {
-    const char *f = getenv("CPG_WINO_KERNEL");
-    return f && f[0] == 'p';
+// Which Winograd forward / input-gradient kernel a launch uses.  Default: k_wg3 (two waves per unit, 64 output channels each) when the
+// channel loop is long (>= 128 channels read) and there are at least 64 channels to produce -- 4 % faster there --, else k_wg1 (one
+// wave per unit): for 64-channel layers the shorter loop makes k_wg3's heavier epilogue (and its statistics) cost more than it saves.
+// CPG_WINO_KERNEL = wave | pair | 64 | block forces k_wg1 / k_wg2 / k_wg3 / the cooperative block kernel (A/B experiments, tests).
+enum { WV_BLOCK = 0, WV_WAVE = 1, WV_PAIR = 2, WV_PAIR64 = 3 };
+static inline int wino_variant(int c_read, int m) {
+    if (const char *f = getenv("CPG_WINO_KERNEL")) {
+        if (f[0] == 'b') return WV_BLOCK;
+        if (f[0] == 'p') return WV_PAIR;
+        if (f[0] == '6') return WV_PAIR64;
+        return WV_WAVE;
+    }
+    return (c_read >= 128 && m >= 64) ? WV_PAIR64 : WV_WAVE;
 }
 
-extern "C" int cpg_conv3x3_wino_tiles(int N, int H, int W) {
+// number of BatchNorm-statistics tiles per channel of a forward launch (stats[m][tiles][2])
+extern "C" int cpg_conv3x3_wino_tiles(int N, int c_read, int m, int H, int W) {
     const int64_t tiles = (int64_t)N * (H / 2) * (W / 2);
-    if (wino_pair()) return (int)(2 * ((tiles + W1_T - 1) / W1_T));          // every wave of a pair is its own statistics tile
-    const int per = wino_one_wave() ? W1_T : WG_T;
+    const int v = wino_variant(c_read, m);
+    if (v == WV_PAIR || v == WV_PAIR64) return (int)(2 * ((tiles + W1_T - 1) / W1_T));     // every wave of a pair is its own tile
+    const int per = v == WV_WAVE ? W1_T : WG_T;
     return (int)((tiles + per - 1) / per);
 }
 
@@ -1265,7 +1635,7 @@ extern "C" int cpg_conv3x3_wino_run(int dgrad, int N, int c_read, int m, int H, 
 
 // 1: the inference epilogue is available on the Winograd kernel (the one-wave kernel only)
 extern "C" int cpg_conv3x3_wino_eval_ok(int N, int c_read, int m, int H, int W) {
-    return wino_one_wave() && cpg_conv3x3_wino_ok(N, c_read, m, H, W);
+    return wino_variant(c_read, m) != WV_BLOCK && cpg_conv3x3_wino_ok(N, c_read, m, H, W);
 }
 
 // forward with eval-mode BatchNorm (+ ReLU) in the epilogue; live (may be null): live_words ints, zeroed here, layout of k_c3_pack
@@ -1287,7 +1657,8 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
     const size_t need = cpg_conv3x3_wino_pack_bytes(c_read, m);
     if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
     CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
-    if (wino_one_wave()) {
+    const int variant = wino_variant(c_read, m);
+    if (variant != WV_BLOCK) {
         WgGeom g;
         g.N = N, g.C = c_read, g.H = H, g.W = W, g.M = m;
         g.th = H / 2, g.tw = W / 2, g.tiles_img = g.th * g.tw;
@@ -1299,7 +1670,21 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
         hipLaunchKernelGGL(k_wg1_pack, dim3(stream_grid((int64_t)g.nkb * g.nch * 32 * WG_CK, 256)), dim3(256), 0, stream, w, pm, thr, up,
                            K, C, m, c_read, g.nch, dgrad ? 1 : 0, bne ? bne->live : nullptr, bne ? bne->Mp : 0);
         const int64_t runs = (g.tiles_total + W1_T - 1) / W1_T;
-        if (wino_pair()) {
+        if (variant == WV_PAIR64) {
+            const int64_t blocks = runs * ((g.nkb + 1) / 2);
+            if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "%s: grid too large", what);
+            if (bne != nullptr)
+                hipLaunchKernelGGL((k_wg3<false, false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, *bne);
+            else if (dgrad)
+                hipLaunchKernelGGL((k_wg3<true, false>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, none);
+            else if (stats != nullptr)
+                hipLaunchKernelGGL((k_wg3<false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, stats, none);
+            else
+                hipLaunchKernelGGL((k_wg3<false, false>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, none);
+            CPG_CHECK_LAUNCH(what);
+            return CPG_OK;
+        }
+        if (variant == WV_PAIR) {
             const int64_t blocks = runs * g.nkb;
             if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "%s: grid too large", what);
             if (bne != nullptr)
@@ -1337,7 +1722,7 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
     float *up = (float *)ws;
     hipLaunchKernelGGL(k_wg_pack, dim3(stream_grid((int64_t)g.nkb * g.nch * BK * WG_CK, 256)), dim3(256), 0, stream, w, pm, thr, up,
                        K, C, m, c_read, g.nch, dgrad ? 1 : 0, BK);
-    const int64_t tblocks = cpg_conv3x3_wino_tiles(N, H, W);
+    const int64_t tblocks = cpg_conv3x3_wino_tiles(N, c_read, m, H, W);
     const int rc = nw == 8 ? wino_launch<8>(dgrad != 0, g, tblocks, x, up, bias, y, stats, stream)
                            : wino_launch<4>(dgrad != 0, g, tblocks, x, up, bias, y, stats, stream);
     if (rc != CPG_OK) return rc;

@@ -173,15 +173,19 @@ def test_conv_oracle(N, C, H, W, K, k, s, p, bias, pm):
     (7, 128, 28, 28, 96, False, False),    # 196 tiles per image
     (2, 64, 112, 112, 64, False, False),   # 56-tile rows, block halos inside a row
 ])
-@pytest.mark.parametrize('nw', [1, 2, 4, 8])
+@pytest.mark.parametrize('nw', [0, 1, 2, 3, 4, 8])
 def test_winograd_matches_direct(N, C, H, W, K, bias, pm, nw, monkeypatch):
     """The Winograd F(2x2, 3x3) forward / input-gradient kernels (conv3x3_wino.hip, the default for even maps with >= 16 channels)
     against the direct kernels (CPG_NO_WINO=1) and against fp64: same result to a few fp32 roundings of the output scale, bit-identical
     when repeated; shapes chosen for the tile enumeration's edge cases (the oracle comparisons of test_conv_oracle run through
     the same dispatch)."""
-    if nw == 2:                                         # 1: the default one-wave-per-unit kernel k_wg1
+    if nw == 1:                                         # 0: the library's own choice per shape (k_wg1 or k_wg3)
+        monkeypatch.setenv('CPG_WINO_KERNEL', 'wave')    # one wave per unit (k_wg1)
+    elif nw == 2:
         monkeypatch.setenv('CPG_WINO_KERNEL', 'pair')    # two waves per unit, the transform positions split between them (k_wg2)
-    elif nw != 1:
+    elif nw == 3:
+        monkeypatch.setenv('CPG_WINO_KERNEL', '64')      # ... with 64 output channels per wave (k_wg3)
+    elif nw != 0:
         monkeypatch.setenv('CPG_WINO_KERNEL', 'block')   # the cooperative 4- / 8-wave block kernels (not the default: measured slower)
         monkeypatch.setenv('CPG_WINO_NW', str(nw))
     g = torch.Generator().manual_seed(N + C + K + H)

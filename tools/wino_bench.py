@@ -29,7 +29,7 @@ def main():
     raw.cpg_conv3x3_wino_pack_bytes.restype = ctypes.c_size_t
     raw.cpg_conv3x3_wino_pack_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     raw.cpg_conv3x3_wino_tiles.restype = ctypes.c_int
-    raw.cpg_conv3x3_wino_tiles.argtypes = [ctypes.c_int] * 3
+    raw.cpg_conv3x3_wino_tiles.argtypes = [ctypes.c_int] * 5
     raw.cpg_conv3x3_wino_run.restype = ctypes.c_int
     raw.cpg_conv3x3_wino_run.argtypes = [ctypes.c_int] * 8 + [ctypes.c_void_p] * 3 + [ctypes.c_float] + [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p]
     dev = 'cuda:0'
@@ -51,7 +51,7 @@ def main():
         ws, nb = _lib.workspace(L.cpg_conv2d_workspace_bytes(ctypes.byref(d)), dev)
         nbw = max(raw.cpg_conv3x3_wino_pack_bytes(C, K), raw.cpg_conv3x3_wino_pack_bytes(K, C))
         wsw = torch.empty(nbw // 4 + 64, device=dev)
-        tiles = raw.cpg_conv3x3_wino_tiles(a.batch, H, H)
+        tiles = raw.cpg_conv3x3_wino_tiles(a.batch, C, K, H, H)
         stats = torch.zeros(K * tiles * 2, device=dev)
         flops = 2.0 * a.batch * K * H * H * C * 9
         cp = ctypes.c_void_p
