@@ -1603,14 +1603,15 @@ extern "C" size_t cpg_conv3x3_wino_pack_bytes(int c_read, int m) {      // (the 
 // wave per unit): for 64-channel layers the shorter loop makes k_wg3's heavier epilogue (and its statistics) cost more than it saves.
 // CPG_WINO_KERNEL = wave | pair | 64 | block forces k_wg1 / k_wg2 / k_wg3 / the cooperative block kernel (A/B experiments, tests).
 enum { WV_BLOCK = 0, WV_WAVE = 1, WV_PAIR = 2, WV_PAIR64 = 3 };
-static inline int wino_variant(int c_read, int m) {
+static inline int wino_variant(int c_read, int m, bool stats = true) {
     if (const char *f = getenv("CPG_WINO_KERNEL")) {
         if (f[0] == 'b') return WV_BLOCK;
         if (f[0] == 'p') return WV_PAIR;
         if (f[0] == '6') return WV_PAIR64;
         return WV_WAVE;
     }
-    return (c_read >= 128 && m >= 64) ? WV_PAIR64 : WV_WAVE;
+    // (without the statistics epilogue k_wg3 already pays off at 64 channels: 64 -> 64 @224 4.89 vs 5.13 ms)
+    return (c_read >= (stats ? 128 : 64) && m >= 64) ? WV_PAIR64 : WV_WAVE;
 }
 
 // number of BatchNorm-statistics tiles per channel of a forward launch (stats[m][tiles][2])
@@ -1657,7 +1658,7 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
     const size_t need = cpg_conv3x3_wino_pack_bytes(c_read, m);
     if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
     CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
-    const int variant = wino_variant(c_read, m);
+    const int variant = wino_variant(c_read, m, stats != nullptr);
     if (variant != WV_BLOCK) {
         WgGeom g;
         g.N = N, g.C = c_read, g.H = H, g.W = W, g.M = m;
