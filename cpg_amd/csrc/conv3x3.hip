@@ -1177,7 +1177,7 @@ WSPlan ws_plan(const cpg_conv_desc *d) {
 
 int cpg_conv3x3_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
                       float *gw, float *gpm, void *ws, size_t ws_bytes, hipStream_t stream) {
-    // Winograd F(2x2, 3x3) weight gradient (conv3x3_wino_wgrad.hip): maps a multiple of 28 wide, channel counts multiples of 32
+    // Winograd F(2x2, 3x3) weight gradient (conv3x3_wino_wgrad.hip): maps 14 or a multiple of 28 wide, channel counts multiples of 32
     if (cpg_conv3x3_wino_wgrad_ok(d)) return cpg_conv3x3_wino_wgrad(d, x, gy, w, pm, thr, gw, gpm, ws, ws_bytes, stream);
     Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
     if (d->C <= WSCfg::CMAX) {

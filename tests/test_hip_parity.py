@@ -230,10 +230,15 @@ def test_winograd_matches_direct(N, C, H, W, K, bias, pm, nw, monkeypatch):
     (2, 32, 14, 56, 64, False),        # H != W
     (40, 32, 28, 28, 32, False),       # more stages than units can take one at a time: several stages per unit, stage hand-over
     (2, 64, 112, 112, 64, False),      # four segments per row
+    (2, 32, 14, 14, 32, False),        # maps 14 wide (the narrow variant: a stage = one tile row of an image PAIR): one pair
+    (5, 64, 14, 14, 96, True),         # ... odd image count (the last stage has one image), 2 x 3 channel blocks, piggymask
+    (64, 32, 14, 14, 32, False),       # ... several stages per unit, units starting in the middle of an image pair's rows
+    (3, 32, 2, 14, 32, False),         # ... a single tile row
+    (4, 32, 28, 14, 64, True),         # ... H != W
 ])
 def test_winograd_wgrad_matches_direct(N, C, H, W, K, pm, monkeypatch):
-    """The Winograd weight-gradient kernel (conv3x3_wino_wgrad.hip: the default for maps a multiple of 28 wide with channel counts
-    that are multiples of 32) against the direct kernel (CPG_NO_WINO_WGRAD=1) and fp64, bit-identical when repeated."""
+    """The Winograd weight-gradient kernel (conv3x3_wino_wgrad.hip: the default for maps 14 or a multiple of 28 wide with channel
+    counts that are multiples of 32) against the direct kernel (CPG_NO_WINO_WGRAD=1) and fp64, bit-identical when repeated."""
     import ctypes
     from cpg_amd import _lib
     assert _lib.lib().cpg_conv2d_winograd(ctypes.byref(nl._conv_desc((N, C, H, W), (K, C, 3, 3), (1, 1), (1, 1), (1, 1), 1)), 2) == 1

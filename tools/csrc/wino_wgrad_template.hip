@@ -13,9 +13,11 @@
 //           end and the only halo is the one at its two ends): 7 k-steps of 16 MFMAs.
 //   G  global -> registers: 16 byte per lane (two tiles' column pairs), lanes = (8 quads x 8 (channel, row) items): 16 loads for x,
 //      8 for gy, 4 dword loads for the halo columns; all offsets are a per-lane constant + a scalar stage base.
-//   W  registers -> LDS  x_raw[c][row][16 slots][2], gy_raw[k][row][14][2]  (channel strides 130 / 58 words: conflict-free reads)
-//   T  per k-step: lane reads its patch (ds_read_b64 + ds_read2_b32 per row) and gy tile, 32 + 12 adds -> B and A operands
+//   W  registers -> LDS  x_raw[c][row][16 slots][2], gy_raw[k][row][14][2]  (row / channel strides chosen for the LDS banks, see WW_XR)
+//   T  per k-step: lane reads its patch (three 8-byte reads per row) and gy tile, 32 + 12 adds -> B and A operands
 //   M  16 MFMAs per k-step, one per schedule slot, with one slice of T / W / G behind each (sched_barrier fences).
+// Maps 14 pixels wide (VGG16's last block) run the NARROW instance: a stage is tile row ty of TWO images, 7 + 7 tiles, the two
+// halves of the wave take one image each; everything after the staging loads is the same code with other address constants.
 // ONE LDS buffer per wave: a wave's LDS operations complete in order, so the last k-step of a stage first stores the next
 // stage's rows (loaded five k-steps earlier) and then reads the next stage's first operands.
 // Split over tile ranges; the partial sums land in part[split][tap][k][c], which k_split_reduce (igemm_core.h) adds up and passes
@@ -32,9 +34,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int WW_XC = 130, WW_GC = 58;              // channel strides (floats) of the raw rows in LDS
-constexpr int WW_XS = 32 * WW_XC;                   // 4160
-constexpr int WW_STAGE = WW_XS + 32 * WW_GC;        // 6016 floats = 23.5 KB
+// LDS layout of one stage (floats).  x_raw: 32 channels x 4 rows of 32 floats, row stride 34, channel stride 138; gy_raw: 32 channels
+// x 2 rows of 28, row stride 30, channel stride 62.  The strides are what the LDS banking wants (MI355X guide, LDS table):
+// ds_write_b64 goes out in groups of 16 lanes over 32 banks, and 16 lanes are two rows x 8 quads here, so the second row must
+// sit 2 banks off the first (34 = 2, 30 = -2 mod 32) for the two to interleave; the b64 reads of a half-wave have the channel as
+// the lane index, and 138 / 62 step through all the even banks.  With 32 / 130 / 28 / 58 the stores were 2-way conflicted and
+// the kernel 3% slower (profiles/r02j_pmc_wino.md: 44% of the LDS cycles were conflict cycles).
+constexpr int WW_XR = 34, WW_XC = 138, WW_GR = 30, WW_GC = 62;
+constexpr int WW_XS = 32 * WW_XC;
+constexpr int WW_STAGE = WW_XS + 32 * WW_GC;        // 6400 floats = 25 KB per wave
 
 struct WwGeom {
     int N, C, K, H, W;
@@ -49,6 +57,7 @@ struct WwGeom {
 @@RD@@
 #define WW_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+template <bool NARROW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ part) {
     __shared__ __attribute__((aligned(16))) float smem_all[4 * WW_STAGE];
@@ -64,8 +73,9 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
     const unsigned s_begin = split * g.su;
     const int nst = (int)min(g.su, g.nstages - s_begin);
     // loader coordinates (uniform): the stage whose loads are issued next -> image n, tile row ty, segment tseg
+    // (NARROW: image PAIR n, n + 1 and tile row ty -- see below)
     const unsigned per_img = (unsigned)(g.th * g.nseg);
-    int n = (int)(s_begin / per_img);
+    int n = (int)(s_begin / per_img) * (NARROW ? 2 : 1);
     const unsigned r0 = s_begin % per_img;
     int ty = (int)(r0 / (unsigned)g.nseg), tseg = (int)(r0 % (unsigned)g.nseg);
     const int n0 = n;
@@ -82,42 +92,88 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
     // quad (tiles 2 qd, 2 qd + 1) and (channel, row) item of this lane.  Seven quads per 14-tile row: the eighth lane of a group
     // repeats the seventh (same address, same data -- a dump address would need the per-instruction offset removed again)
     const int qd = min(lane & 7, 6), rem = lane >> 3;
-    const int xrow = rem & 3;
-    const int vx_const = ((rem >> 2) * HW + xrow * g.W) * 4 + qd * 16 + 16;         // x item (c = 2 j + rem / 4, row = rem % 4)
-    const int vg_const = ((rem >> 1) * HW + (rem & 1) * g.W) * 4 + qd * 16;         // gy item (k = 4 j + rem / 2, row = rem % 2)
+    // NARROW (maps 14 pixels = 7 tiles wide): the stage is tile row ty of TWO images, 7 + 7 tiles (half h = lh of the k-step's tile
+    // pair); an LDS row holds both halves side by side, x: [0 0 | 14 px of image n | 0 0 | 14 px of image n + 1 | 0 0] (the zeros
+    // are the left / right padding of the image: written once, there are no halo loads), gy: [14 | 14].  A row is 7 column PAIRS:
+    // 8-byte loads, lanes = (8 pairs x 8 items), item = (row, half) for x -> one channel per load (32 loads), (channel, row, half)
+    // for gy (16 loads).  The half is the low bit of the item so that the 16 lanes of a ds_write_b64 group fill 28 different banks.
+    const int xrow = NARROW ? rem >> 1 : rem & 3, half = rem & 1;
+    const int vx_const = NARROW ? (half * g.C * HW + xrow * g.W) * 4 + qd * 8 + 16
+                                : ((rem >> 2) * HW + xrow * g.W) * 4 + qd * 16 + 16;   // x item (c = 2 j + rem / 4, row = rem % 4)
+    const int vg_const = NARROW ? ((rem >> 2) * HW + half * g.K * HW + ((rem >> 1) & 1) * g.W) * 4 + qd * 8
+                                : ((rem >> 1) * HW + (rem & 1) * g.W) * 4 + qd * 16;   // gy item (k = 4 j + rem / 2, row = rem % 2)
     const int hside = lane & 1, hrow = (lane >> 1) & 3;                             // halo item (c = 8 j + lane / 8, row, side)
     const int vh_const = ((lane >> 3) * HW + hrow * g.W) * 4 + (hside ? 28 * 4 + 16 : 12);
-    const int xw_addr = (rem >> 2) * WW_XC + xrow * 32 + 2 + 4 * qd;
-    const int gw_addr = WW_XS + (rem >> 1) * WW_GC + (rem & 1) * 28 + 4 * qd;
-    const int hw_addr = (lane >> 3) * WW_XC + hrow * 32 + (hside ? 30 : 1);
+    const int xw_addr = NARROW ? xrow * WW_XR + 16 * half + 2 + 2 * qd : (rem >> 2) * WW_XC + xrow * WW_XR + 2 + 4 * qd;
+    const int gw_addr = NARROW ? WW_XS + (rem >> 2) * WW_GC + ((rem >> 1) & 1) * WW_GR + 14 * half + 2 * qd
+                               : WW_XS + (rem >> 1) * WW_GC + (rem & 1) * WW_GR + 4 * qd;
+    const int hw_addr = (lane >> 3) * WW_XC + hrow * WW_XR + (hside ? 30 : 1);
+    if constexpr (NARROW) {                                      // the padding columns 0, 1, 16, 17, 32, 33 of every x row
+        for (int i = lane; i < 32 * 4 * 6; i += 64) {
+            const int rowi = i / 6, col = i % 6;
+            smem[(rowi >> 2) * WW_XC + (rowi & 3) * WW_XR + (col >> 1) * 16 + (col & 1)] = 0.0f;
+        }
+    }
     int sx, sgo, vx, vg, vh;                                     // stage part of the offsets (scalar) / per-lane part with validity
     auto stage_offsets = [&]() {
-        sx = (((n - n0) * g.C + cb * 32) * HW + 2 * ty * g.W + 28 * tseg) * 4;
-        sgo = (((n - n0) * g.K + kb * 32) * HW + 2 * ty * g.W + 28 * tseg) * 4;
         const bool top = ty == 0, bot = ty == g.th - 1;
-        vx = ((xrow == 0 && top) || (xrow == 3 && bot)) ? kOOR : vx_const;
-        vg = vg_const;
-        vh = ((hrow == 0 && top) || (hrow == 3 && bot) || (hside == 0 && tseg == 0) || (hside == 1 && tseg == g.nseg - 1)) ? kOOR : vh_const;
+        if constexpr (NARROW) {
+            sx = (((n - n0) * g.C + cb * 32) * HW + 2 * ty * g.W) * 4;
+            sgo = (((n - n0) * g.K + kb * 32) * HW + 2 * ty * g.W) * 4;
+            const bool gone = half && n + 1 >= g.N;              // an odd batch: the last stage has one image only
+            vx = ((xrow == 0 && top) || (xrow == 3 && bot) || gone) ? kOOR : vx_const;
+            vg = gone ? kOOR : vg_const;
+            vh = kOOR;
+        } else {
+            sx = (((n - n0) * g.C + cb * 32) * HW + 2 * ty * g.W + 28 * tseg) * 4;
+            sgo = (((n - n0) * g.K + kb * 32) * HW + 2 * ty * g.W + 28 * tseg) * 4;
+            vx = ((xrow == 0 && top) || (xrow == 3 && bot)) ? kOOR : vx_const;
+            vg = vg_const;
+            vh = ((hrow == 0 && top) || (hrow == 3 && bot) || (hside == 0 && tseg == 0) || (hside == 1 && tseg == g.nseg - 1)) ? kOOR : vh_const;
+        }
     };
     auto advance_stage = [&]() {
         if (++tseg == g.nseg) {
             tseg = 0;
-            if (++ty == g.th) ty = 0, ++n;
+            if (++ty == g.th) ty = 0, n += NARROW ? 2 : 1;
         }
         stage_offsets();
     };
+    // staging registers: 16 + 8 quads (+ 4 halo words), or NARROW 32 + 16 pairs: 96 registers either way
     i32x4 rx[16], rg[8];
     float rh[4];
     auto g_load = [&](int idx, int) {
-        if (idx < 16)
-            rx[idx] = __builtin_amdgcn_raw_buffer_load_b128(srd_x, vx, sx + idx * 2 * HW * 4, 0);
-        else if (idx < 24)
-            rg[idx - 16] = __builtin_amdgcn_raw_buffer_load_b128(srd_g, vg, sgo + (idx - 16) * 4 * HW * 4, 0);
-        else
-            rh[idx - 24] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, vh, sx + (idx - 24) * 8 * HW * 4, 0));
+        if constexpr (NARROW) {
+            i32x2 v;
+            if (idx < 32)
+                v = __builtin_amdgcn_raw_buffer_load_b64(srd_x, vx, sx + idx * HW * 4, 0);
+            else
+                v = __builtin_amdgcn_raw_buffer_load_b64(srd_g, vg, sgo + (idx - 32) * 2 * HW * 4, 0);
+            if (idx < 32)
+                rx[idx >> 1][2 * (idx & 1)] = v[0], rx[idx >> 1][2 * (idx & 1) + 1] = v[1];
+            else
+                rg[(idx - 32) >> 1][2 * (idx & 1)] = v[0], rg[(idx - 32) >> 1][2 * (idx & 1) + 1] = v[1];
+        } else {
+            if (idx < 16)
+                rx[idx] = __builtin_amdgcn_raw_buffer_load_b128(srd_x, vx, sx + idx * 2 * HW * 4, 0);
+            else if (idx < 24)
+                rg[idx - 16] = __builtin_amdgcn_raw_buffer_load_b128(srd_g, vg, sgo + (idx - 16) * 4 * HW * 4, 0);
+            else
+                rh[idx - 24] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, vh, sx + (idx - 24) * 8 * HW * 4, 0));
+        }
     };
     auto w_store = [&](int idx) {
-        if (idx < 16) {
+        if constexpr (NARROW) {
+            if (idx < 32) {
+                i32x2 v;
+                v[0] = rx[idx >> 1][2 * (idx & 1)], v[1] = rx[idx >> 1][2 * (idx & 1) + 1];
+                *reinterpret_cast<i32x2 *>(smem + xw_addr + idx * WW_XC) = v;
+            } else if (idx < 48) {
+                i32x2 v;
+                v[0] = rg[(idx - 32) >> 1][2 * (idx & 1)], v[1] = rg[(idx - 32) >> 1][2 * (idx & 1) + 1];
+                *reinterpret_cast<i32x2 *>(smem + gw_addr + (idx - 32) * 2 * WW_GC) = v;
+            }
+        } else if (idx < 16) {
             i32x2 *d = reinterpret_cast<i32x2 *>(smem + xw_addr + idx * 2 * WW_XC);
             i32x2 lo, hi;
             lo[0] = rx[idx][0], lo[1] = rx[idx][1], hi[0] = rx[idx][2], hi[1] = rx[idx][3];
@@ -127,20 +183,24 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
             i32x2 lo, hi;
             lo[0] = rg[idx - 16][0], lo[1] = rg[idx - 16][1], hi[0] = rg[idx - 16][2], hi[1] = rg[idx - 16][3];
             d[0] = lo, d[1] = hi;
-        } else {
+        } else if (idx < 28) {
             smem[hw_addr + (idx - 24) * 8 * WW_XC] = rh[idx - 24];
         }
     };
     // ---- T: operands of k-step ks (tile 2 ks + lh of the stage in LDS), in 14 micro steps ----
-    const int xr_base = li * WW_XC + (lh + 1) * 2, gr_base = WW_XS + li * WW_GC + lh * 2;
+    // tile of (k-step ks, half-wave lh): wide 2 ks + lh of the 14-tile segment, NARROW tile ks of image n + lh
+    constexpr int kLhX = NARROW ? 16 : 2, kLhG = NARROW ? 14 : 2, kKs = NARROW ? 2 : 4;
+    const int xr_base = li * WW_XC + 2 + lh * kLhX, gr_base = WW_XS + li * WW_GC + lh * kLhG;
     auto t_micro = [&](int m, int ks, float (&A)[16], float (&B)[16]) {
         if (m < 4) {                                             // patch row m: own pair + the neighbours' halves
-            const float *r = smem + xr_base + 4 * ks + m * 32;
+            const float *r = smem + xr_base + kKs * ks + m * WW_XR;
             const f32x2 own = *reinterpret_cast<const f32x2 *>(r);
-            B[m * 4 + 0] = r[-1], B[m * 4 + 1] = own[0], B[m * 4 + 2] = own[1], B[m * 4 + 3] = r[2];
+            // the neighbours' halves as 8-byte reads too: a 4-byte read of 32 lanes at an even channel stride is 2-way conflicted
+            const f32x2 lo = *reinterpret_cast<const f32x2 *>(r - 2), hi = *reinterpret_cast<const f32x2 *>(r + 2);
+            B[m * 4 + 0] = lo[1], B[m * 4 + 1] = own[0], B[m * 4 + 2] = own[1], B[m * 4 + 3] = hi[0];
         } else if (m == 4) {                                     // the gy tile: A[0] = y00, A[3] = y01, A[12] = y10, A[15] = y11
-            const f32x2 y0 = *reinterpret_cast<const f32x2 *>(smem + gr_base + 4 * ks);
-            const f32x2 y1 = *reinterpret_cast<const f32x2 *>(smem + gr_base + 4 * ks + 28);
+            const f32x2 y0 = *reinterpret_cast<const f32x2 *>(smem + gr_base + kKs * ks);
+            const f32x2 y1 = *reinterpret_cast<const f32x2 *>(smem + gr_base + kKs * ks + WW_GR);
             A[0] = y0[0], A[3] = y0[1], A[12] = y1[0], A[15] = y1[1];
         } else if (m < 7) {                                      // V = B^T d B: column pass of columns 2 (m - 5), + 1
 #pragma unroll
@@ -171,15 +231,19 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
     // prologue: stage 0 into LDS, its first operands, stage 1's coordinates ready
     stage_offsets();
 #pragma unroll
-    for (int i = 0; i < 28; ++i) g_load(i, 0);
+    for (int i = 0; i < (NARROW ? 48 : 28); ++i) g_load(i, 0);
 #pragma unroll
-    for (int i = 0; i < 28; ++i) w_store(i);
+    for (int i = 0; i < (NARROW ? 48 : 28); ++i) w_store(i);
     advance_stage();
 #pragma unroll
     for (int m = 0; m < 14; ++m) t_micro(m, 0, A0, B0);
 
     for (int st = 0; st < nst; st += 2) {
+        if constexpr (NARROW) {
+@@BODY_N@@
+        } else {
 @@BODY@@
+        }
     }
 
     // ---- epilogue: dg = G^T M G per (k, c); M[i][j] = sigma_i sigma_j acc[4 i + j], sigma = (1, 1, 1, -1) ----
@@ -215,6 +279,7 @@ struct WwPlan {
     WwGeom g;
     size_t ws_bytes;
     int64_t blocks;
+    bool narrow;              // maps 14 pixels wide: a stage is one tile row of two images
 };
 
 bool ww_plan(const cpg_conv_desc *d, WwPlan &p) {
@@ -222,11 +287,12 @@ bool ww_plan(const cpg_conv_desc *d, WwPlan &p) {
     if (d->R != 3 || d->S != 3 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 1 || d->pad_w != 1 || d->dil_h != 1 ||
         d->dil_w != 1 || d->groups != 1)
         return false;
-    if (d->H % 2 || d->W % 28 || d->C % 32 || d->K % 32 || d->N < 1) return false;
+    p.narrow = d->W == 14;
+    if (d->H % 2 || (d->W % 28 && !p.narrow) || d->C % 32 || d->K % 32 || d->N < 1) return false;
     WwGeom &g = p.g;
     g.N = d->N, g.C = d->C, g.K = d->K, g.H = d->H, g.W = d->W;
-    g.th = d->H / 2, g.tw = d->W / 2, g.nseg = g.tw / 14;
-    const int64_t nstages = (int64_t)d->N * g.th * g.nseg;
+    g.th = d->H / 2, g.tw = d->W / 2, g.nseg = p.narrow ? 1 : g.tw / 14;
+    const int64_t nstages = (int64_t)(p.narrow ? (d->N + 1) / 2 : d->N) * g.th * g.nseg;
     if (nstages >= (1ll << 28)) return false;
     g.nstages = (unsigned)nstages;
     g.nkb = d->K / 32, g.ncb = d->C / 32;
@@ -236,7 +302,7 @@ bool ww_plan(const cpg_conv_desc *d, WwPlan &p) {
     g.su = (unsigned)((nstages + want - 1) / want);
     g.nsplit = (int)((nstages + g.su - 1) / g.su);
     const int64_t per_img = (int64_t)g.th * g.nseg;
-    g.span = (int)((g.su + per_img - 1) / per_img) + 1;
+    g.span = ((int)((g.su + per_img - 1) / per_img) + 1) * (p.narrow ? 2 : 1);
     const int64_t HW = (int64_t)d->H * d->W;
     if ((int64_t)g.span * std::max(d->C, d->K) * HW * 4 + (d->W + 4) * 4 >= (1ll << 31)) return false;
     p.ws_bytes = (size_t)g.nsplit * 9 * d->K * d->C * sizeof(float);
@@ -262,7 +328,10 @@ extern "C" int cpg_conv3x3_wino_wgrad(const cpg_conv_desc *d, const float *x, co
     if (!ww_plan(d, p)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_wgrad(winograd): shape not supported");
     if (ws == nullptr || ws_bytes < p.ws_bytes)
         return fail(CPG_E_WORKSPACE, "cpg_conv2d_wgrad(winograd): workspace %zu < %zu bytes", ws_bytes, p.ws_bytes);
-    hipLaunchKernelGGL(k_wgw, dim3((unsigned)p.blocks), dim3(256), 0, stream, p.g, x, gy, (float *)ws);
+    if (p.narrow)
+        hipLaunchKernelGGL(k_wgw<true>, dim3((unsigned)p.blocks), dim3(256), 0, stream, p.g, x, gy, (float *)ws);
+    else
+        hipLaunchKernelGGL(k_wgw<false>, dim3((unsigned)p.blocks), dim3(256), 0, stream, p.g, x, gy, (float *)ws);
     Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
     const int64_t out_elems = (int64_t)d->K * d->C * 9;
     launch_split_reduce((const float *)ws, p.g.nsplit, out_elems, (int64_t)d->K * d->C, ep, stream);
