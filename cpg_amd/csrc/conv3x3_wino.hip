@@ -35,6 +35,7 @@
 //   STATS: per-channel sum / sum of squares of the block's outputs for the BatchNorm that follows (as k_c3_fwd<.., STATS>).
 //   dgrad       the same kernel on gy with the filter transposed and spatially flipped (k_wg_pack's dgrad flavour).
 #include <algorithm>
+#include <type_traits>
 #include "igemm_core.h"
 
 using namespace cpg;
@@ -527,6 +528,14 @@ struct WgBnEval {
     int Mp;
 };
 
+// -DWG_TIMING (development builds only, tools/diag_wg_timing.py): every wave of k_wg1 leaves the constant-clock time of its
+// entry / prologue start / main loop start / epilogue start / exit and its hardware slot in wg_dbg.
+#ifdef WG_TIMING
+__device__ unsigned long long wg_dbg[65536 * 8];
+#define WG_STAMP(i) do { if (lane == 0 && dbg_u < 65536) wg_dbg[dbg_u * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define WG_STAMP(i)
+#endif
 template <bool DGRAD, bool STATS, bool BNE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
@@ -538,6 +547,11 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     const int li = lane & 31, lh = lane >> 5;
     const int HW = g.H * g.W;
     float *smem = smem_all + wave * 2 * W1_RAW;               // this wave's private raw stages
+#ifdef WG_TIMING
+    const unsigned dbg_u = blockIdx.x * 4 + wave;
+    WG_STAMP(0);
+    if (lane == 0 && dbg_u < 65536) wg_dbg[dbg_u * 8 + 6] = __builtin_amdgcn_s_getreg(63492), wg_dbg[dbg_u * 8 + 7] = __builtin_amdgcn_s_getreg(63508);
+#endif
 
     unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
     const int kb = lb % g.nkb;
@@ -700,6 +714,7 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     Rows rw0, rw1;                         // raw rows in flight: chunk c uses set c & 1, requested FOUR iterations before its MFMAs
     // With one wave per SIMD a wait is an idle MFMA pipe: the loads that miss L2 (the transformed filter of a 512 x 512 layer is
     // 16 MB, the input's first touch) take longer than one iteration (0.85 us), so everything is requested two iterations early.
+    WG_STAMP(1);
     // prologue: chunk 0 operands, chunks 0 / 1 raw rows in LDS, chunks 2 / 3 rows and U(0), U(1) in flight
     if (nch > 0) {
     G_rows(0, rw0);
@@ -783,6 +798,7 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         W1_SLOT(15, 0, ucur, c0, W_row1(par, rows, 7); G_row1(cr, rows, 6));
         W1_SLOT(15, 1, ucur, c1, W_row1(par, rows, 8); G_row1(cr, rows, 7); G_row1(cr, rows, 8));
     };
+    WG_STAMP(2);
     for (int it = 0; it < nch; it += 6) {
         iter(it, 0, u0, u2, rw0, b0, b1, n0v, n1v);
         if (it + 1 < nch) iter(it + 1, 1, u1, u0, rw1, n0v, n1v, b0, b1);
@@ -792,6 +808,7 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         if (it + 5 < nch) iter(it + 5, 1, u2, u1, rw1, n0v, n1v, b0, b1);
     }
 
+    WG_STAMP(3);
     // ---- epilogue: Y = A^T M A in registers (M[i][j] = acc[4 i + j]),  A^T = [1 1 1 0; 0 1 -1 -1]
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // (the last MFMA's result is read below: the compiler cannot see into the asm)
     const unsigned tg = t0 + li;
@@ -816,7 +833,11 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
 #define W1_RD_14(m) asm volatile("v_accvgpr_read_b32 %0, a14\n\tv_accvgpr_read_b32 %1, a30\n\tv_accvgpr_read_b32 %2, a46\n\tv_accvgpr_read_b32 %3, a62\n\tv_accvgpr_read_b32 %4, a78\n\tv_accvgpr_read_b32 %5, a94\n\tv_accvgpr_read_b32 %6, a110\n\tv_accvgpr_read_b32 %7, a126\n\tv_accvgpr_read_b32 %8, a142\n\tv_accvgpr_read_b32 %9, a158\n\tv_accvgpr_read_b32 %10, a174\n\tv_accvgpr_read_b32 %11, a190\n\tv_accvgpr_read_b32 %12, a206\n\tv_accvgpr_read_b32 %13, a222\n\tv_accvgpr_read_b32 %14, a238\n\tv_accvgpr_read_b32 %15, a254" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
 #define W1_RD_15(m) asm volatile("v_accvgpr_read_b32 %0, a15\n\tv_accvgpr_read_b32 %1, a31\n\tv_accvgpr_read_b32 %2, a47\n\tv_accvgpr_read_b32 %3, a63\n\tv_accvgpr_read_b32 %4, a79\n\tv_accvgpr_read_b32 %5, a95\n\tv_accvgpr_read_b32 %6, a111\n\tv_accvgpr_read_b32 %7, a127\n\tv_accvgpr_read_b32 %8, a143\n\tv_accvgpr_read_b32 %9, a159\n\tv_accvgpr_read_b32 %10, a175\n\tv_accvgpr_read_b32 %11, a191\n\tv_accvgpr_read_b32 %12, a207\n\tv_accvgpr_read_b32 %13, a223\n\tv_accvgpr_read_b32 %14, a239\n\tv_accvgpr_read_b32 %15, a255" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]), "=v"(m[8]), "=v"(m[9]), "=v"(m[10]), "=v"(m[11]), "=v"(m[12]), "=v"(m[13]), "=v"(m[14]), "=v"(m[15]))
     float s1[16], s2[16];
-    auto out_e = [&](int e, const float (&m)[16]) {       // m[4 i + j] = M[i][j] of output channel element e
+    // hb: with / without a conv bias, decided ONCE outside (the two epilogues are separate code).  With the bias load behind a
+    // branch inside the per-channel code the compiler's s_waitcnt vmcnt(0) for it sat in the common path: every channel waited for
+    // the previous channel's stores to be acknowledged, 16 round trips = 3.9 us of a 29 us unit on the 64-channel layers
+    // (tools/diag_wg_timing.py); without it 2.7 us.
+    auto out_e = [&](auto hb, int e, const float (&m)[16]) {       // m[4 i + j] = M[i][j] of output channel element e
         float r_[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -825,7 +846,7 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         }
         const int co = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         float bv = 0.0f;
-        if (bias != nullptr) bv = bias[co < g.M ? co : 0];
+        if constexpr (decltype(hb)::value) bv = bias[co < g.M ? co : 0];
         float v00 = r_[0][0] + r_[1][0] + r_[2][0] + bv, v01 = r_[0][1] + r_[1][1] + r_[2][1] + bv;
         float v10 = r_[1][0] - r_[2][0] - r_[3][0] + bv, v11 = r_[1][1] - r_[2][1] - r_[3][1] + bv;
         if (BNE) {                             // y = [max(0,] (conv + bias - mean) * invstd * gamma + beta [)]
@@ -847,25 +868,26 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
             s2[e] = tv ? (v00 * v00 + v01 * v01) + (v10 * v10 + v11 * v11) : 0.0f;
         }
     };
-    {
+    auto out_all = [&](auto hb) {
         float m[16];
-        W1_RD_0(m); out_e(0, m);
-        W1_RD_1(m); out_e(1, m);
-        W1_RD_2(m); out_e(2, m);
-        W1_RD_3(m); out_e(3, m);
-        W1_RD_4(m); out_e(4, m);
-        W1_RD_5(m); out_e(5, m);
-        W1_RD_6(m); out_e(6, m);
-        W1_RD_7(m); out_e(7, m);
-        W1_RD_8(m); out_e(8, m);
-        W1_RD_9(m); out_e(9, m);
-        W1_RD_10(m); out_e(10, m);
-        W1_RD_11(m); out_e(11, m);
-        W1_RD_12(m); out_e(12, m);
-        W1_RD_13(m); out_e(13, m);
-        W1_RD_14(m); out_e(14, m);
-        W1_RD_15(m); out_e(15, m);
-    }
+        W1_RD_0(m); out_e(hb, 0, m);
+        W1_RD_1(m); out_e(hb, 1, m);
+        W1_RD_2(m); out_e(hb, 2, m);
+        W1_RD_3(m); out_e(hb, 3, m);
+        W1_RD_4(m); out_e(hb, 4, m);
+        W1_RD_5(m); out_e(hb, 5, m);
+        W1_RD_6(m); out_e(hb, 6, m);
+        W1_RD_7(m); out_e(hb, 7, m);
+        W1_RD_8(m); out_e(hb, 8, m);
+        W1_RD_9(m); out_e(hb, 9, m);
+        W1_RD_10(m); out_e(hb, 10, m);
+        W1_RD_11(m); out_e(hb, 11, m);
+        W1_RD_12(m); out_e(hb, 12, m);
+        W1_RD_13(m); out_e(hb, 13, m);
+        W1_RD_14(m); out_e(hb, 14, m);
+        W1_RD_15(m); out_e(hb, 15, m);
+    };
+    if (bias != nullptr) out_all(std::true_type{}); else out_all(std::false_type{});
     if (STATS) {
 #pragma unroll
         for (int e = 0; e < 16; ++e)
@@ -887,6 +909,7 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
             }
         }
     }
+    WG_STAMP(4);
 }
 
 // ------------------------------------------------------------------------------ two waves = one unit ("k_wg2")
@@ -1144,12 +1167,13 @@ void k_wg2(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     const int ty = (int)((unsigned)r / twu), tx = (int)((unsigned)r % twu);
     float *yout = y + ((int64_t)n * g.M) * HW + (2 * ty + ph) * g.W + 2 * tx;
     float s1[16], s2[16];
+    auto out_all = [&](auto hb) {                // (hb: with / without a conv bias -- two separate epilogues, see k_wg1)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int co = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         float v0 = own0[e] + xch[(((ph ^ 1) * 2 + 0) * 16 + e) * 64 + lane];
         float v1 = own1[e] + xch[(((ph ^ 1) * 2 + 1) * 16 + e) * 64 + lane];
-        if (bias != nullptr) {
+        if constexpr (decltype(hb)::value) {
             const float bv = bias[co < g.M ? co : 0];
             v0 += bv, v1 += bv;
         }
@@ -1169,6 +1193,8 @@ void k_wg2(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
             s2[e] = tv ? v0 * v0 + v1 * v1 : 0.0f;
         }
     }
+    };
+    if (bias != nullptr) out_all(std::true_type{}); else out_all(std::false_type{});
     if (STATS) {                               // every wave is its own statistics tile: stats[k][2 run + ph][2]
 #pragma unroll
         for (int e = 0; e < 16; ++e)
@@ -1507,13 +1533,14 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     const int ty = (int)((unsigned)r / twu), tx = (int)((unsigned)r % twu);
     float *yout = y + ((int64_t)n * g.M) * HW + (2 * ty + ph) * g.W + 2 * tx;
     float s1[32], s2[32];
+    auto out_all = [&](auto hb) {                // (hb: with / without a conv bias -- two separate epilogues, see k_wg1)
 #pragma unroll
     for (int ke = 0; ke < 32; ++ke) {
         const int kq = ke >> 4, e = ke & 15;
         const int co = kb * 64 + kq * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         float v0 = own0[ke] + xch[((((ph ^ 1) * 2 + kq) * 2 + 0) * 16 + e) * 64 + lane];
         float v1 = own1[ke] + xch[((((ph ^ 1) * 2 + kq) * 2 + 1) * 16 + e) * 64 + lane];
-        if (bias != nullptr) {
+        if constexpr (decltype(hb)::value) {
             const float bv = bias[co < g.M ? co : 0];
             v0 += bv, v1 += bv;
         }
@@ -1533,6 +1560,8 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
             s2[ke] = tv ? v0 * v0 + v1 * v1 : 0.0f;
         }
     }
+    };
+    if (bias != nullptr) out_all(std::true_type{}); else out_all(std::false_type{});
     if (STATS) {                               // every wave is its own statistics tile: stats[k][2 run + ph][2]
 #pragma unroll
         for (int ke = 0; ke < 32; ++ke)
@@ -1614,6 +1643,11 @@ static inline int wino_variant(int c_read, int m, bool stats = true) {
     return (c_read >= (stats ? 128 : 64) && m >= 64) ? WV_PAIR64 : WV_WAVE;
 }
 
+#ifdef WG_TIMING
+extern "C" int cpg_debug_wg_timing(unsigned long long *dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wg_dbg), (size_t)n * 8 * sizeof(unsigned long long));
+}
+#endif
 // number of BatchNorm-statistics tiles per channel of a forward launch (stats[m][tiles][2])
 extern "C" int cpg_conv3x3_wino_tiles(int N, int c_read, int m, int H, int W) {
     const int64_t tiles = (int64_t)N * (H / 2) * (W / 2);

@@ -202,8 +202,8 @@ int cpg_bn_relu_bwd(const float *x, const float *gy, const float *gamma, const f
  * reference's own F.conv2d (models/layers.py:106-109) takes whichever algorithm cuDNN / MIOpen picks, Winograd included.
  * Returns 1 for such a launch, 0 for the direct / generic kernels.  Setting CPG_NO_WINO in the environment (read per call)
  * forces 0 everywhere.  cpg_conv2d_wgrad (2) uses the adjoint transform for maps that are 14 or a multiple of 28 pixels wide with channel counts that are
- * multiples of 32 (CPG_NO_WINO_WGRAD forces the direct kernels for this pass only).  cpg_conv2d_fwd_bn_eval and the bf16 entry
- * points never use it. */
+ * multiples of 32 (CPG_NO_WINO_WGRAD forces the direct kernels for this pass only).  cpg_conv2d_fwd_bn_eval uses it on the
+ * same shapes as the forward pass when there is no conv bias and no skip statistics are asked for; the bf16 entry points never do. */
 int32_t cpg_conv2d_winograd(const cpg_conv_desc *desc, int32_t pass);
 
 /* Conv forward fused with the statistics pass of the BatchNorm2d that follows it in every CPG topology

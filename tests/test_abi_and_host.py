@@ -301,3 +301,32 @@ def test_grouped_conv_is_refused_at_construction():
         nl.SharableConv2d(8, 8, 3, groups=2)
     with pytest.raises(NotImplementedError):
         M.resnext50_32x4d(dataset_history=[], dataset2num_classes={}, network_width_multiplier=1.0, shared_layer_info={})
+
+
+@pytest.mark.parametrize('src,names,agprs', [('conv3x3_wino.hip', r'k_wg[123]I', (128, 256)), ('conv3x3_wino_wgrad.hip', r'k_wgwI', (256,))])
+def test_winograd_kernels_keep_their_accumulators_to_themselves(src, names, agprs, tmp_path):
+    """The Winograd kernels hold their accumulators in accumulation registers that only the inline asm names (clobber lists), so the
+    register allocator believes those registers are free between the asm statements: if a kernel runs out of vector registers it
+    parks values there and silently overwrites an accumulator (it did, once, in an epilogue).  Checked on the compiled code: every
+    v_accvgpr_write is one of the zero-fills, there are as many zero-fills as accumulators, and nothing spills to scratch."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    out = tmp_path / 'k.s'
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-gpu-rdc', '-x', 'hip', '-S', '--cuda-device-only',
+                    os.path.join(ROOT, 'cpg_amd', 'csrc', src), '-o', str(out)], check=True, capture_output=True, timeout=600)
+    txt = out.read_text()
+    found = 0
+    for m in re.finditer(r'^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end', txt, re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        if not re.search(names, name):
+            continue
+        found += 1
+        zero = len(re.findall(r'v_accvgpr_write_b32 a\d+, 0\b', body))
+        other = len(re.findall(r'v_accvgpr_write', body)) - zero
+        assert zero in agprs and other == 0, (name, zero, other)
+        assert 'scratch_' not in body, name
+        assert len(re.findall(r'v_accvgpr_read', body)) % zero == 0, name
+    assert found >= 2
