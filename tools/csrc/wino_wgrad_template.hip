@@ -57,6 +57,15 @@ struct WwGeom {
 @@RD@@
 #define WW_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// -DWG_TIMING (development builds, tools/diag_wg_timing.py --wgrad): per-wave constant-clock stamps, as in conv3x3_wino.hip
+#ifdef WG_TIMING
+__device__ unsigned long long ww_dbg[65536 * 8];
+#define WW_STAMP(i) do { if (lane == 0 && u < 65536) ww_dbg[u * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define WW_STAMP(i)
+#endif
+// (blocks of one or two waves and an XCD-contiguous unit order were measured: within 0.5 % on every layer, a single wave without the
+//  reorder 6 % slower on the 64-channel layers)
 template <bool NARROW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ part) {
@@ -72,6 +81,10 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
     const int kb = (int)(pair % (unsigned)g.nkb), cb = (int)(pair / (unsigned)g.nkb);
     const unsigned s_begin = split * g.su;
     const int nst = (int)min(g.su, g.nstages - s_begin);
+    WW_STAMP(0);
+#ifdef WG_TIMING
+    if (lane == 0 && u < 65536) ww_dbg[u * 8 + 6] = __builtin_amdgcn_s_getreg(63492), ww_dbg[u * 8 + 7] = __builtin_amdgcn_s_getreg(63508);
+#endif
     // loader coordinates (uniform): the stage whose loads are issued next -> image n, tile row ty, segment tseg
     // (NARROW: image PAIR n, n + 1 and tile row ty -- see below)
     const unsigned per_img = (unsigned)(g.th * g.nseg);
@@ -226,6 +239,7 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
         }
     };
 
+    WW_STAMP(1);
 @@ZERO@@
     float A0[16], B0[16], A1[16], B1[16];
     // prologue: stage 0 into LDS, its first operands, stage 1's coordinates ready
@@ -238,6 +252,7 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
 #pragma unroll
     for (int m = 0; m < 14; ++m) t_micro(m, 0, A0, B0);
 
+    WW_STAMP(2);
     for (int st = 0; st < nst; st += 2) {
         if constexpr (NARROW) {
 @@BODY_N@@
@@ -246,6 +261,7 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
         }
     }
 
+    WW_STAMP(3);
     // ---- epilogue: dg = G^T M G per (k, c); M[i][j] = sigma_i sigma_j acc[4 i + j], sigma = (1, 1, 1, -1) ----
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     float *pout = part + ((int64_t)split * 9 * g.K + kb * 32) * g.C + cb * 32 + li;
@@ -271,6 +287,7 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
         float m[16];
 @@OUT@@
     }
+    WW_STAMP(4);
 }
 
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
@@ -312,6 +329,11 @@ bool ww_plan(const cpg_conv_desc *d, WwPlan &p) {
 
 }  // namespace
 
+#ifdef WG_TIMING
+extern "C" int cpg_debug_ww_timing(unsigned long long *dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(ww_dbg), (size_t)n * 8 * sizeof(unsigned long long));
+}
+#endif
 extern "C" int cpg_conv3x3_wino_wgrad_ok(const cpg_conv_desc *d) {
     WwPlan p;
     return ww_plan(d, p) ? 1 : 0;

@@ -10,20 +10,28 @@ from cpg_amd import _lib
 from cpg_amd.models.layers import _conv_desc
 
 def main():
-    N, C, K, H = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else '16,64,64,224').split(',')]
+    wgrad = '--wgrad' in sys.argv
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    N, C, K, H = [int(v) for v in (args[0] if args else '16,64,64,224').split(',')]
     L = _lib.lib(); raw = ctypes.CDLL(_lib.LIB_PATH)
     dev = 'cuda:0'
     x = torch.randn(N, C, H, H, device=dev).relu_(); w = torch.randn(K, C, 3, 3, device=dev) * 0.05
     y = torch.empty(N, K, H, H, device=dev)
     d = _conv_desc(x.shape, w.shape, (1, 1), (1, 1), (1, 1), 1)
     ws, nb = _lib.workspace(L.cpg_conv2d_workspace_bytes(ctypes.byref(d)), dev)
-    for _ in range(2):
+    if wgrad:
+        gy = torch.randn(N, K, H, H, device=dev); gw = torch.empty_like(w)
+        for _ in range(2):
+            rc = L.cpg_conv2d_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), None, ctypes.c_float(0), _lib.dptr(gw), None, None,
+                                    _lib.dptr(ws), nb, _lib.stream_ptr())
+            assert rc == 0, L.cpg_last_error()
+    for _ in range(0 if wgrad else 2):
         rc = L.cpg_conv2d_fwd(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w), None, ctypes.c_float(0), None, _lib.dptr(y), _lib.dptr(ws), nb, _lib.stream_ptr())
         assert rc == 0, L.cpg_last_error()
     torch.cuda.synchronize()
-    units = min(65536, N * (H // 2) * (H // 2) // 32 * ((K + 31) // 32))
+    units = 65536 if wgrad else min(65536, N * (H // 2) * (H // 2) // 32 * ((K + 31) // 32))
     buf = np.zeros((units, 8), dtype=np.uint64)
-    assert raw.cpg_debug_wg_timing(buf.ctypes.data_as(ctypes.c_void_p), units) == 0
+    assert (raw.cpg_debug_ww_timing if wgrad else raw.cpg_debug_wg_timing)(buf.ctypes.data_as(ctypes.c_void_p), units) == 0
     t = buf[:, :5].astype(np.int64)
     ok = t[:, 4] > 0
     t = t[ok]; hw = buf[ok, 6]; xcc = buf[ok, 7]
