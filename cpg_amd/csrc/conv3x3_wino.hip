@@ -437,6 +437,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_wg_fwd(WgGeom g, c
     }
 }
 
+// Sum over the 32 lanes of each half-wave by DPP (quad swaps, half-row / row mirrors, then lane 15 of rows 0 / 2 into rows 1 / 3):
+// five v_add_f32_dpp per value, the result valid in lanes 16-31 and 48-63.  The ds_bpermute butterfly this replaces cost the
+// statistics epilogue of k_wg3 4.7 us per unit (tools/diag_wg_timing.py --stats): 320 LDS-crossbar round trips.  Eight values per
+// asm block, step by step across the eight: a DPP operand must not be read within two instructions of the VALU write that produced
+// it, and neither the assembler nor the compiler looks into inline asm for that.
+#define WG_DPP8(OP)                                                                                                                \
+    "v_add_f32_dpp %0, %0, %0 " OP "\n\tv_add_f32_dpp %1, %1, %1 " OP "\n\tv_add_f32_dpp %2, %2, %2 " OP "\n\tv_add_f32_dpp %3, %3, %3 " OP "\n\t" \
+    "v_add_f32_dpp %4, %4, %4 " OP "\n\tv_add_f32_dpp %5, %5, %5 " OP "\n\tv_add_f32_dpp %6, %6, %6 " OP "\n\tv_add_f32_dpp %7, %7, %7 " OP "\n\t"
+__device__ __forceinline__ void wg_half_sum8(float *v) {
+    asm volatile("s_nop 1\n\t"                                         // (the values may have been written just before)
+                 WG_DPP8("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 WG_DPP8("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 WG_DPP8("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 WG_DPP8("row_mirror row_mask:0xf bank_mask:0xf")      // every lane of a 16-lane row holds the row's sum
+                 WG_DPP8("row_bcast:15 row_mask:0xa bank_mask:0xf")    // rows 1 / 3 += lane 15 of rows 0 / 2
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+constexpr int kWgSumLane = 16;       // li of a lane that holds wg_half_sum's result
+
 // ------------------------------------------------------------------------------ one wave = one unit ("k_wg1")
 // A wave computes 32 output channels x 32 tiles for ALL 16 positions by itself: 256 accumulator registers (one wave per SIMD, the
 // whole 512-entry register file), no cooperation between waves, hence NO barrier and no V / U staging through LDS:
@@ -901,21 +920,17 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     if (bias != nullptr) out_all(std::true_type{}); else out_all(std::false_type{});
     if (STATS) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) {
-                s1[e] += __shfl_xor(s1[e], off);
-                s2[e] += __shfl_xor(s2[e], off);
-            }
-        if (li == 0) {
+        for (int e = 0; e < 16; e += 8) wg_half_sum8(s1 + e), wg_half_sum8(s2 + e);
+        if (li == kWgSumLane) {
             const unsigned nruns = (ttot + W1_T - 1) / W1_T;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (co < g.M) {
                     float *dst = stats + ((int64_t)co * nruns + run) * 2;
-                    dst[0] = s1[e];
-                    dst[1] = s2[e];
+                    f32x2 o;
+                    o[0] = s1[e], o[1] = s2[e];
+                    *reinterpret_cast<f32x2 *>(dst) = o;
                 }
             }
         }
@@ -1209,21 +1224,17 @@ void k_wg2(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     if (bias != nullptr) out_all(std::true_type{}); else out_all(std::false_type{});
     if (STATS) {                               // every wave is its own statistics tile: stats[k][2 run + ph][2]
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) {
-                s1[e] += __shfl_xor(s1[e], off);
-                s2[e] += __shfl_xor(s2[e], off);
-            }
-        if (li == 0) {
+        for (int e = 0; e < 16; e += 8) wg_half_sum8(s1 + e), wg_half_sum8(s2 + e);
+        if (li == kWgSumLane) {
             const unsigned ntile = 2 * ((ttot + W1_T - 1) / W1_T);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (co < g.M) {
                     float *dst = stats + ((int64_t)co * ntile + 2 * run + ph) * 2;
-                    dst[0] = s1[e];
-                    dst[1] = s2[e];
+                    f32x2 o;
+                    o[0] = s1[e], o[1] = s2[e];
+                    *reinterpret_cast<f32x2 *>(dst) = o;
                 }
             }
         }
@@ -1306,6 +1317,11 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     const unsigned run = lb / nkb64;                          // tile run of 32
     const unsigned t0 = run * W1_T;
     if (t0 >= ttot) continue;                                 // (uniform for the block)
+#ifdef WG_TIMING
+    const unsigned dbg_u = lb * 2 + ph;
+    WG_STAMP(0);
+    if (lane == 0 && dbg_u < 65536) wg_dbg[dbg_u * 8 + 6] = __builtin_amdgcn_s_getreg(63492), wg_dbg[dbg_u * 8 + 7] = __builtin_amdgcn_s_getreg(63508);
+#endif
     const int n0 = (int)(t0 / timg);
 
     constexpr int kOutOfRange = (int)0x80000000;
@@ -1391,6 +1407,7 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     };
 
 
+    WG_STAMP(1);
     int nch = g.nch;
     if (BNE && bn.live != nullptr) {                          // inference: skip what apply_mask killed (wave-uniform decisions)
         const int alive = (kb * 64 + lane < g.M) ? bn.live[kb * 64 + lane] : 0;
@@ -1489,11 +1506,13 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         W3_SLOT(15, 0, ucur, b0, );
         W3_SLOT(15, 1, ucur, b1, );
     };
+    WG_STAMP(2);
     for (int it = 0; it < nch; it += 2) {
         iter(it, 0, ua, ub, c0, c1, x0, x1);
         if (it + 1 < nch) iter(it + 1, 1, ub, ua, x0, x1, c0, c1);
     }
 
+    WG_STAMP(3);
     // ---- epilogue: this wave's 8 positions (transform rows i = 2 ph, 2 ph + 1) -> partial 2x2 outputs; the output transform is linear
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     float own0[32], own1[32];                  // the output row this wave finishes (a = ph), columns 0 / 1, per channel half and accumulator element
@@ -1585,25 +1604,22 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     if (bias != nullptr) out_all(std::true_type{}); else out_all(std::false_type{});
     if (STATS) {                               // every wave is its own statistics tile: stats[k][2 run + ph][2]
 #pragma unroll
-        for (int ke = 0; ke < 32; ++ke)
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) {
-                s1[ke] += __shfl_xor(s1[ke], off);
-                s2[ke] += __shfl_xor(s2[ke], off);
-            }
-        if (li == 0) {
+        for (int ke = 0; ke < 32; ke += 8) wg_half_sum8(s1 + ke), wg_half_sum8(s2 + ke);
+        if (li == kWgSumLane) {
             const unsigned ntile = 2 * ((ttot + W1_T - 1) / W1_T);
 #pragma unroll
             for (int ke = 0; ke < 32; ++ke) {
                 const int co = kb * 64 + (ke >> 4) * 32 + (ke & 3) + 8 * ((ke & 15) >> 2) + 4 * lh;
                 if (co < g.M) {
                     float *dst = stats + ((int64_t)co * ntile + 2 * run + ph) * 2;
-                    dst[0] = s1[ke];
-                    dst[1] = s2[ke];
+                    f32x2 o;
+                    o[0] = s1[ke], o[1] = s2[ke];
+                    *reinterpret_cast<f32x2 *>(dst) = o;
                 }
             }
         }
     }
+    WG_STAMP(4);
     __syncthreads();                           // the exchange buffer becomes the next unit's raw stages
     }   // next logical block
 }

@@ -11,6 +11,7 @@ from cpg_amd.models.layers import _conv_desc
 
 def main():
     wgrad = '--wgrad' in sys.argv
+    stats = '--stats' in sys.argv
     args = [a for a in sys.argv[1:] if not a.startswith('--')]
     N, C, K, H = [int(v) for v in (args[0] if args else '16,64,64,224').split(',')]
     L = _lib.lib(); raw = ctypes.CDLL(_lib.LIB_PATH)
@@ -25,11 +26,15 @@ def main():
             rc = L.cpg_conv2d_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), None, ctypes.c_float(0), _lib.dptr(gw), None, None,
                                     _lib.dptr(ws), nb, _lib.stream_ptr())
             assert rc == 0, L.cpg_last_error()
-    for _ in range(0 if wgrad else 2):
+    if stats:
+        import cpg_amd.models.layers as nl
+        for _ in range(2):
+            nl._MaskedConv2dFn.apply(x, w, None, None, 5e-3, (1, 1), (1, 1), (1, 1), 1, True)
+    for _ in range(0 if (wgrad or stats) else 2):
         rc = L.cpg_conv2d_fwd(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w), None, ctypes.c_float(0), None, _lib.dptr(y), _lib.dptr(ws), nb, _lib.stream_ptr())
         assert rc == 0, L.cpg_last_error()
     torch.cuda.synchronize()
-    units = 65536 if wgrad else min(65536, N * (H // 2) * (H // 2) // 32 * ((K + 31) // 32))
+    units = 65536 if wgrad else min(65536, N * (H // 2) * (H // 2) // 32 * ((K + 31) // 32) * 2)
     buf = np.zeros((units, 8), dtype=np.uint64)
     assert (raw.cpg_debug_ww_timing if wgrad else raw.cpg_debug_wg_timing)(buf.ctypes.data_as(ctypes.c_void_p), units) == 0
     t = buf[:, :5].astype(np.int64)
