@@ -1383,20 +1383,27 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         else if (lane < 24)
             raw[halo_w] = q.halo;
     };
-    auto G_u1 = [&](int ch, f32x4 (&u)[8], int q) { u[q] = *reinterpret_cast<const f32x4 *>(ubase + (q >> 2) * ukq + (int64_t)ch * W1_U + (q & 3) * 256); };
+    // Wave ph = 1 keeps its two transform rows in REVERSE order (local row 0 = row 3, local row 1 = row 2): then local row 0 of
+    // B^T d is e0 - e2 for both waves (rows held: 0 1 2 / 1 2 3) and only local row 1 differs -- 3 instead of 5 vector
+    // instructions per column pair in the loop -- and the row a wave GIVES the other in the epilogue is local row 1 for both.
+    const int urow = ph * 512;                                // float4 q ^ 2 of the wave's four: + 512 floats for q = 0, 1, - 512 for q = 2, 3
+    auto G_u1 = [&](int ch, f32x4 (&u)[8], int q) {
+        u[q] = *reinterpret_cast<const f32x4 *>(ubase + ((q & 2) ? -urow : urow) + (q >> 2) * ukq + (int64_t)ch * W1_U + (q & 3) * 256);
+    };
     // half patch of (tile li, channel 2 lh + j): rows ph .. ph + 2 -> the 8 values of transform rows 2 ph, 2 ph + 1 in d[0..7]
     auto T_read1 = [&](int stage, int j, float (&d)[12], int i) {
         const float *raw = smem + stage * W2_RAW + ((2 * lh + j) * 3 + i) * W1_ROW;
         const f32x2 own = *reinterpret_cast<const f32x2 *>(raw + (li + 1) * 2);
         d[i * 4 + 0] = raw[lo], d[i * 4 + 1] = own[0], d[i * 4 + 2] = own[1], d[i * 4 + 3] = raw[ro];
     };
-    // B^T d: ph = 0 holds patch rows 0, 1, 2 -> rows 0, 1 = d0 - d2, d1 + d2;  ph = 1 holds 1, 2, 3 -> rows 2, 3 = d2 - d1, d1 - d3
+    // B^T d: ph = 0 holds patch rows 0, 1, 2 -> local rows (0, 1) = rows (0, 1) = d0 - d2, d1 + d2;
+    //        ph = 1 holds 1, 2, 3 -> local rows (0, 1) = rows (3, 2) = d1 - d3, d2 - d1
     auto T_col = [&](float (&d)[12], int j0) {
 #pragma unroll
         for (int j = j0; j < j0 + 2; ++j) {
             const float e0 = d[0 * 4 + j], e1 = d[1 * 4 + j], e2 = d[2 * 4 + j];
-            d[0 * 4 + j] = ph ? e1 - e0 : e0 - e2;
-            d[1 * 4 + j] = ph ? e0 - e2 : e1 + e2;
+            d[0 * 4 + j] = e0 - e2;
+            d[1 * 4 + j] = e1 + (ph ? -e0 : e2);
             asm volatile("" : "+v"(d[0 * 4 + j]), "+v"(d[1 * 4 + j]));
         }
     };
@@ -1518,17 +1525,15 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     float own0[32], own1[32];                  // the output row this wave finishes (a = ph), columns 0 / 1, per channel half and accumulator element
     __syncthreads();                           // both waves are done with their raw stages: the LDS becomes the exchange buffer
     float *xch = smem_all;
+    // local rows: wave 0 holds R0, R1, wave 1 holds R3, R2 (reversed).  Y0 = R0 + R1 + R2, Y1 = R1 - R2 - R3: a wave owns
+    // +-(its two rows) and gives its local row 1 (R1 to Y1, R2 to Y0) to the other wave; the sign is applied when the two meet.
     auto part_e = [&](int kq, int e, const float (&m)[8]) {
         const float r00 = m[0] + m[1] + m[2], r01 = m[1] - m[2] - m[3];       // R[il][b] = sum_j A^T[b][j] M[i][j]
         const float r10 = m[4] + m[5] + m[6], r11 = m[5] - m[6] - m[7];
-        float g0, g1;
-        if (ph == 0) {                         // i = 0, 1:  Y0 += R0 + R1 (own),  Y1 += R1 (given to the other wave)
-            own0[kq * 16 + e] = r00 + r10, own1[kq * 16 + e] = r01 + r11, g0 = r10, g1 = r11;
-        } else {                               // i = 2, 3:  Y1 += -R2 - R3 (own),  Y0 += R2 (given)
-            own0[kq * 16 + e] = -r00 - r10, own1[kq * 16 + e] = -r01 - r11, g0 = r00, g1 = r01;
-        }
-        xch[(((ph * 2 + kq) * 2 + 0) * 16 + e) * 64 + lane] = g0;
-        xch[(((ph * 2 + kq) * 2 + 1) * 16 + e) * 64 + lane] = g1;
+        own0[kq * 16 + e] = r00 + r10, own1[kq * 16 + e] = r01 + r11;
+        f32x2 gv;                              // (one 8-byte LDS store / load per channel: xch[wave][kq][e][lane][2])
+        gv[0] = r10, gv[1] = r11;
+        *reinterpret_cast<f32x2 *>(xch + (((ph * 2 + kq) * 16 + e) * 64 + lane) * 2) = gv;
     };
     {
         float m[8];
@@ -1573,13 +1578,15 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     const int ty = (int)((unsigned)r / twu), tx = (int)((unsigned)r % twu);
     float *yout = y + ((int64_t)n * g.M) * HW + (2 * ty + ph) * g.W + 2 * tx;
     float s1[32], s2[32];
+    const float sgn = ph ? -1.0f : 1.0f;
     auto out_all = [&](auto hb) {                // (hb: with / without a conv bias -- two separate epilogues, see k_wg1)
 #pragma unroll
     for (int ke = 0; ke < 32; ++ke) {
         const int kq = ke >> 4, e = ke & 15;
         const int co = kb * 64 + kq * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        float v0 = own0[ke] + xch[((((ph ^ 1) * 2 + kq) * 2 + 0) * 16 + e) * 64 + lane];
-        float v1 = own1[ke] + xch[((((ph ^ 1) * 2 + kq) * 2 + 1) * 16 + e) * 64 + lane];
+        const f32x2 got = *reinterpret_cast<const f32x2 *>(xch + ((((ph ^ 1) * 2 + kq) * 16 + e) * 64 + lane) * 2);
+        float v0 = fmaf(own0[ke], sgn, got[0]);             // (+- own + got, exactly)
+        float v1 = fmaf(own1[ke], sgn, got[1]);
         if constexpr (decltype(hb)::value) {
             const float bv = bias[co < g.M ? co : 0];
             v0 += bv, v1 += bv;
