@@ -437,25 +437,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_wg_fwd(WgGeom g, c
     }
 }
 
-// Sum over the 32 lanes of each half-wave by DPP (quad swaps, half-row / row mirrors, then lane 15 of rows 0 / 2 into rows 1 / 3):
-// five v_add_f32_dpp per value, the result valid in lanes 16-31 and 48-63.  The ds_bpermute butterfly this replaces cost the
-// statistics epilogue of k_wg3 4.7 us per unit (tools/diag_wg_timing.py --stats): 320 LDS-crossbar round trips.  Eight values per
-// asm block, step by step across the eight: a DPP operand must not be read within two instructions of the VALU write that produced
-// it, and neither the assembler nor the compiler looks into inline asm for that.
-#define WG_DPP8(OP)                                                                                                                \
-    "v_add_f32_dpp %0, %0, %0 " OP "\n\tv_add_f32_dpp %1, %1, %1 " OP "\n\tv_add_f32_dpp %2, %2, %2 " OP "\n\tv_add_f32_dpp %3, %3, %3 " OP "\n\t" \
-    "v_add_f32_dpp %4, %4, %4 " OP "\n\tv_add_f32_dpp %5, %5, %5 " OP "\n\tv_add_f32_dpp %6, %6, %6 " OP "\n\tv_add_f32_dpp %7, %7, %7 " OP "\n\t"
-__device__ __forceinline__ void wg_half_sum8(float *v) {
-    asm volatile("s_nop 1\n\t"                                         // (the values may have been written just before)
-                 WG_DPP8("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-                 WG_DPP8("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-                 WG_DPP8("row_half_mirror row_mask:0xf bank_mask:0xf")
-                 WG_DPP8("row_mirror row_mask:0xf bank_mask:0xf")      // every lane of a 16-lane row holds the row's sum
-                 WG_DPP8("row_bcast:15 row_mask:0xa bank_mask:0xf")    // rows 1 / 3 += lane 15 of rows 0 / 2
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
-}
-constexpr int kWgSumLane = 16;       // li of a lane that holds wg_half_sum's result
-
 // ------------------------------------------------------------------------------ one wave = one unit ("k_wg1")
 // A wave computes 32 output channels x 32 tiles for ALL 16 positions by itself: 256 accumulator registers (one wave per SIMD, the
 // whole 512-entry register file), no cooperation between waves, hence NO barrier and no V / U staging through LDS:
@@ -920,8 +901,8 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     if (bias != nullptr) out_all(std::true_type{}); else out_all(std::false_type{});
     if (STATS) {
 #pragma unroll
-        for (int e = 0; e < 16; e += 8) wg_half_sum8(s1 + e), wg_half_sum8(s2 + e);
-        if (li == kWgSumLane) {
+        for (int e = 0; e < 16; e += 8) half_wave_sum8(s1 + e), half_wave_sum8(s2 + e);
+        if (li == kHalfSumLane) {
             const unsigned nruns = (ttot + W1_T - 1) / W1_T;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -1224,8 +1205,8 @@ void k_wg2(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     if (bias != nullptr) out_all(std::true_type{}); else out_all(std::false_type{});
     if (STATS) {                               // every wave is its own statistics tile: stats[k][2 run + ph][2]
 #pragma unroll
-        for (int e = 0; e < 16; e += 8) wg_half_sum8(s1 + e), wg_half_sum8(s2 + e);
-        if (li == kWgSumLane) {
+        for (int e = 0; e < 16; e += 8) half_wave_sum8(s1 + e), half_wave_sum8(s2 + e);
+        if (li == kHalfSumLane) {
             const unsigned ntile = 2 * ((ttot + W1_T - 1) / W1_T);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -1611,8 +1592,8 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     if (bias != nullptr) out_all(std::true_type{}); else out_all(std::false_type{});
     if (STATS) {                               // every wave is its own statistics tile: stats[k][2 run + ph][2]
 #pragma unroll
-        for (int ke = 0; ke < 32; ke += 8) wg_half_sum8(s1 + ke), wg_half_sum8(s2 + ke);
-        if (li == kWgSumLane) {
+        for (int ke = 0; ke < 32; ke += 8) half_wave_sum8(s1 + ke), half_wave_sum8(s2 + ke);
+        if (li == kHalfSumLane) {
             const unsigned ntile = 2 * ((ttot + W1_T - 1) / W1_T);
 #pragma unroll
             for (int ke = 0; ke < 32; ++ke) {

@@ -46,6 +46,25 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
     return base + idx;
 }
 
+// Sum over the 32 lanes of each half-wave by DPP (quad swaps, half-row / row mirrors, then lane 15 of rows 0 / 2 into rows 1 / 3):
+// five v_add_f32_dpp per value, the result valid in lanes 16-31 and 48-63.  The ds_bpermute butterfly this replaces cost the
+// statistics epilogue of the Winograd kernel k_wg3 4.7 us per unit (tools/diag_wg_timing.py --stats): 320 LDS-crossbar round trips.  Eight values per
+// asm block, step by step across the eight: a DPP operand must not be read within two instructions of the VALU write that produced
+// it, and neither the assembler nor the compiler looks into inline asm for that.
+#define CPG_DPP8(OP)                                                                                                                \
+    "v_add_f32_dpp %0, %0, %0 " OP "\n\tv_add_f32_dpp %1, %1, %1 " OP "\n\tv_add_f32_dpp %2, %2, %2 " OP "\n\tv_add_f32_dpp %3, %3, %3 " OP "\n\t" \
+    "v_add_f32_dpp %4, %4, %4 " OP "\n\tv_add_f32_dpp %5, %5, %5 " OP "\n\tv_add_f32_dpp %6, %6, %6 " OP "\n\tv_add_f32_dpp %7, %7, %7 " OP "\n\t"
+__device__ __forceinline__ void half_wave_sum8(float *v) {
+    asm volatile("s_nop 1\n\t"                                         // (the values may have been written just before)
+                 CPG_DPP8("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 CPG_DPP8("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 CPG_DPP8("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 CPG_DPP8("row_mirror row_mask:0xf bank_mask:0xf")      // every lane of a 16-lane row holds the row's sum
+                 CPG_DPP8("row_bcast:15 row_mask:0xa bank_mask:0xf")    // rows 1 / 3 += lane 15 of rows 0 / 2
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+constexpr int kHalfSumLane = 16;       // li of a lane that holds wg_half_sum's result
+
 template <class Cfg>
 __device__ __forceinline__ void mma_stage(const float *__restrict__ As, const float *__restrict__ Bs,
                                           f32x16 (&acc)[Cfg::FM][Cfg::FN], int a_off, int b_off) {
