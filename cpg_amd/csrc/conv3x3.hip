@@ -855,6 +855,10 @@ inline size_t pack_bytes(int c_read, int m) { return (pack_floats(c_read, m) + l
 // dry: only compute it.
 }  // namespace
 extern "C" int cpg_conv3x3_wino_ok(int N, int c_read, int m, int H, int W);
+extern "C" int cpg_conv3x3_stem_ok(int N, int C, int K, int H, int W);
+extern "C" int cpg_conv3x3_stem_tiles(int N, int C, int K, int H, int W);
+extern "C" int cpg_conv3x3_stem_run(int N, int C, int K, int H, int W, const float *x, const float *w, const float *pm, float thr,
+                                    const float *bias, float *y, float *stats, hipStream_t stream);
 extern "C" size_t cpg_conv3x3_wino_pack_bytes(int c_read, int m);
 extern "C" int cpg_conv3x3_wino_tiles(int N, int c_read, int m, int H, int W);
 extern "C" int cpg_conv3x3_wino_eval_ok(int N, int c_read, int m, int H, int W);
@@ -926,6 +930,12 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
         int *live = bn->live != nullptr ? reinterpret_cast<int *>((float *)ws + pack_floats(c_read, m)) : nullptr;
         return cpg_conv3x3_wino_run_bn_eval(N, c_read, m, H, W, x, w, pm, thr, bias, bn->gamma, bn->beta, bn->mean, bn->var, bn->eps, bn->relu,
                                             live, live_words(c_read, m), y, (char *)ws + off, ws_bytes - off, stream);
+    }
+    // the <= 3-channel stem (conv3x3_stem.hip: one persistent wave per tile, weights in registers, HBM-bound)
+    if (!dgrad && bn == nullptr && bb == nullptr && cpg_conv3x3_stem_ok(N, c_read, m, H, W)) {
+        if (tiles_out) *tiles_out = cpg_conv3x3_stem_tiles(N, c_read, m, H, W);
+        if (dry) return CPG_OK;
+        return cpg_conv3x3_stem_run(N, c_read, m, H, W, x, w, pm, thr, bias, y, stats, stream);
     }
     float *wp = (float *)ws;
     const int rows_c = pad_to(c_read, 4), Mp = pad_to(m, 128);

@@ -1,0 +1,235 @@
+// Masked 3x3 / stride 1 / pad 1 convolution of an image-like input (<= 3 channels) to 64 channels: the network stem
+// (VGG16 features.0, models/vgg.py:131-141 of the reference; SharableConv2d.forward, models/layers.py:98-109).
+//
+// The layer is HBM-bound: 27 multiplies per output against 4 bytes written -- batch 256 @ 224 x 224 writes 3.29 GB and reads 0.15 GB,
+// 0.45 ms at the 7.3 TB/s the streaming kernels of this library reach; the MFMA work is 0.3 ms.  The general direct kernel
+// (conv3x3.hip, 8 x 32 tile) took 1.23 ms: one block per tile, so each tile pays a prologue (operand staging, a barrier), an
+// epilogue of 64 dword stores per lane and the dispatch of the next block, with only 72 MFMAs per wave in between.
+//
+// Here ONE WAVE = ONE TILE (8 rows x 32 columns x all output channels), persistent, no barriers:
+//   * k of the MFMA runs over (channel, tap): 27 values padded to 28 = 14 steps of v_mfma_f32_32x32x2_f32.  The A operands
+//     (W .* bin(pm), 2 blocks of 32 output channels x 14 steps) stay in 28 registers for the whole launch -- no weight pack kernel;
+//   * the B operand of step t and output row j is one ds_read_b32 from the wave's private patch (3 channels x 10 rows x 34 columns):
+//     per-lane base address of (channel, tap) + an immediate row offset;
+//   * the next tile's patch is requested before the current tile's MFMAs (16 loads per tile, range-checked to zero outside the image);
+//   * per output row: 28 MFMAs, 32 stores of 2 x 128 contiguous bytes; the BatchNorm statistics (STATS) are summed per lane over the
+//     tile's 8 rows and reduced once per tile with DPP adds -> stats[k][tile][2], the layout of the other forward kernels.
+#include <algorithm>
+#include <type_traits>
+#include "igemm_core.h"
+
+using namespace cpg;
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int ST_R = 8, ST_W = 32;              // output rows / columns of a tile
+constexpr int ST_PW = 36;                       // row stride of the patch in LDS (34 used)
+constexpr int ST_ROWS = ST_R + 2;
+constexpr int ST_CMAX = 3, ST_KS = 14;          // channels, MFMA steps (2 k each)
+constexpr int ST_PATCH = ST_CMAX * ST_ROWS * ST_PW;
+
+struct StemGeom {
+    int N, C, K, H, W;
+    int tiles_x, tiles_y;
+    unsigned ntiles;
+};
+
+// (STATS: 64 more registers for the sums -- one block per CU instead of two)
+template <bool STATS>
+__global__ __launch_bounds__(256, STATS ? 1 : 2)
+void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ pm, float thr,
+                const float *__restrict__ bias, float *__restrict__ y, float *__restrict__ stats) {
+    __shared__ float smem_all[4 * ST_PATCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    float *smem = smem_all + wave * ST_PATCH;
+    const int HW = g.H * g.W, CK = g.C * 9;
+
+    // A operands: W_eff[co = 32 mb + li][k = 2 t + lh], zero beyond the layer's channels / taps
+    float A[2][ST_KS];
+    int boff[ST_KS];                             // B operand: float index of (channel, tap) of k = 2 t + lh in the patch, + li
+#pragma unroll
+    for (int t = 0; t < ST_KS; ++t) {
+        const int k = 2 * t + lh;
+        const bool kv = k < CK;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int co = mb * 32 + li;
+            float v = 0.0f;
+            if (kv && co < g.K) {
+                v = w[co * CK + k];
+                if (pm != nullptr) v *= binarize(pm[co * CK + k], thr);
+            }
+            A[mb][t] = v;
+        }
+        const int kk = kv ? k : 0;               // (padding taps: a zero weight against any finite patch element)
+        const int c = kk / 9, r = (kk % 9) / 3, s = kk % 3;
+        boff[t] = (c * ST_ROWS + r) * ST_PW + s + li;
+    }
+    float bv[2][16];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            bv[mb][e] = (bias != nullptr && co < g.K) ? bias[co] : 0.0f;
+        }
+
+    const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, g.N * g.C * HW * 4, 0x00020000);
+    constexpr int kOOR = (int)0x80000000;
+    // staging items: item = channel * 10 + patch row; centre columns: two items per load (half-waves), 15 loads; halo columns: one load
+    const int hw_half = lane >> 5, hcol = lane & 31;
+    float pc[15], ph;
+    auto tile_coords = [&](unsigned tile, int &n, int &y0, int &x0) {
+        const unsigned per_img = (unsigned)(g.tiles_x * g.tiles_y);
+        n = (int)(tile / per_img);
+        const unsigned r = tile % per_img;
+        y0 = (int)(r / (unsigned)g.tiles_x) * ST_R, x0 = (int)(r % (unsigned)g.tiles_x) * ST_W;
+    };
+    auto issue_loads = [&](unsigned tile) {
+        int n, y0, x0;
+        tile_coords(tile, n, y0, x0);
+#pragma unroll
+        for (int q = 0; q < 15; ++q) {
+            const int item = 2 * q + hw_half, c = item / ST_ROWS, r = item % ST_ROWS;
+            const int row = y0 - 1 + r, col = x0 + hcol;
+            const bool ok = c < g.C && (unsigned)row < (unsigned)g.H && col < g.W;
+            const int off = ok ? (((n * g.C + c) * g.H + row) * g.W + col) * 4 : kOOR;
+            pc[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, off, 0, 0));
+        }
+        {
+            const int item = lane >> 1, side = lane & 1, c = item / ST_ROWS, r = item % ST_ROWS;
+            const int row = y0 - 1 + r, col = side ? x0 + ST_W : x0 - 1;
+            const bool ok = item < ST_CMAX * ST_ROWS && c < g.C && (unsigned)row < (unsigned)g.H && (unsigned)col < (unsigned)g.W;
+            const int off = ok ? (((n * g.C + c) * g.H + row) * g.W + col) * 4 : kOOR;
+            ph = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, off, 0, 0));
+        }
+    };
+    auto write_patch = [&]() {
+#pragma unroll
+        for (int q = 0; q < 15; ++q) smem[(2 * q + hw_half) * ST_PW + 1 + hcol] = pc[q];
+        if (lane < 2 * ST_CMAX * ST_ROWS) smem[(lane >> 1) * ST_PW + ((lane & 1) ? ST_W + 1 : 0)] = ph;
+    };
+
+    const unsigned nwaves = gridDim.x * 4, wid = blockIdx.x * 4 + wave;
+    if (wid >= g.ntiles) return;                 // (no barriers anywhere: a wave may leave)
+    const int HW4 = HW * 4;
+    issue_loads(wid);
+    for (unsigned tile = wid; tile < g.ntiles; tile += nwaves) {
+        int n, y0, x0;
+        tile_coords(tile, n, y0, x0);
+        write_patch();
+        if (tile + nwaves < g.ntiles) issue_loads(tile + nwaves);
+        float s1[2][16], s2[2][16];
+        if (STATS) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s1[mb][e] = s2[mb][e] = 0.0f;
+        }
+        // y of this image through a buffer descriptor: the lane part of a store's address (pixel, + 4 channels for the upper
+        // half-wave) is a 32-bit offset that is out of range for pixels outside the image (the store is dropped), the uniform
+        // part of the channel is the instruction's scalar offset (K = 64: every channel of the two blocks exists)
+        const __amdgpu_buffer_rsrc_t srd_y = __builtin_amdgcn_make_buffer_rsrc((void *)(y + (int64_t)n * g.K * HW), 0, g.K * HW4, 0x00020000);
+        const bool cok = x0 + li < g.W;
+        const int pix0 = (y0 * g.W + x0 + li) * 4 + lh * 4 * HW4;
+        // (a tile inside the image needs no per-pixel masks: `full` is wave-uniform)
+        const bool full = x0 + ST_W <= g.W && y0 + ST_R <= g.H;
+        auto row = [&](int j, auto fullc) {
+            constexpr bool FULL = decltype(fullc)::value;
+            f32x16 acc[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mb][e] = 0.0f;
+            const float *prow = smem + j * ST_PW;
+#pragma unroll
+            for (int t = 0; t < ST_KS; ++t) {
+                const float b = prow[boff[t]];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][t], b, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][t], b, acc[1], 0, 0, 0);
+            }
+            const bool pok = FULL || (cok && y0 + j < g.H);
+            const int voff = pok ? pix0 + j * g.W * 4 : kOOR;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int cu = mb * 32 + (e & 3) + 8 * (e >> 2);       // + 4 lh: in voff
+                    const float v = acc[mb][e] + bv[mb][e];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), srd_y, voff, cu * HW4, 0);
+                    if (STATS) {
+                        const float vm = (FULL || pok) ? v : 0.0f;
+                        s1[mb][e] += vm;
+                        s2[mb][e] = fmaf(vm, vm, s2[mb][e]);
+                    }
+                }
+        };
+        if (full) {
+#pragma unroll 1
+            for (int j = 0; j < ST_R; ++j) row(j, std::true_type{});
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < ST_R; ++j) row(j, std::false_type{});
+        }
+        if (STATS) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int e = 0; e < 16; e += 8) half_wave_sum8(s1[mb] + e), half_wave_sum8(s2[mb] + e);
+            if (li == kHalfSumLane) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int co = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        f32x2 o;
+                        o[0] = s1[mb][e], o[1] = s2[mb][e];
+                        *reinterpret_cast<f32x2 *>(stats + ((int64_t)co * g.ntiles + tile) * 2) = o;
+                    }
+            }
+        }
+    }
+}
+
+bool stem_geom(int N, int C, int K, int H, int W, StemGeom &g) {
+    if (const char *f = getenv("CPG_NO_STEM")) {                 // (A/B experiments, tests: any value but "0" disables)
+        if (f[0] != '0') return false;
+    }
+    if (N < 1 || C < 1 || C > ST_CMAX || K != 64 || H < 1 || W < 1) return false;
+    if ((int64_t)N * C * H * W * 4 >= (1ll << 31) || (int64_t)K * H * W >= (1ll << 31)) return false;
+    g.N = N, g.C = C, g.K = K, g.H = H, g.W = W;
+    g.tiles_x = (W + ST_W - 1) / ST_W, g.tiles_y = (H + ST_R - 1) / ST_R;
+    const int64_t nt = (int64_t)N * g.tiles_x * g.tiles_y;
+    if (nt >= (1ll << 31)) return false;
+    g.ntiles = (unsigned)nt;
+    return true;
+}
+
+}  // namespace
+
+// 1: cpg_conv2d_fwd / cpg_conv2d_fwd_bnstats run this layer on the stem kernel (CPG_NO_STEM in the environment: never)
+extern "C" int cpg_conv3x3_stem_ok(int N, int C, int K, int H, int W) {
+    StemGeom g;
+    return stem_geom(N, C, K, H, W, g) ? 1 : 0;
+}
+
+// BatchNorm-statistics tiles per channel (stats[K][tiles][2])
+extern "C" int cpg_conv3x3_stem_tiles(int N, int C, int K, int H, int W) {
+    StemGeom g;
+    return stem_geom(N, C, K, H, W, g) ? (int)g.ntiles : 0;
+}
+
+extern "C" int cpg_conv3x3_stem_run(int N, int C, int K, int H, int W, const float *x, const float *w, const float *pm, float thr,
+                                    const float *bias, float *y, float *stats, hipStream_t stream) {
+    StemGeom g;
+    if (!stem_geom(N, C, K, H, W, g)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_fwd(stem): shape not supported");
+    const unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)g.ntiles + 3) / 4, 2 * kCUs);
+    if (stats != nullptr)
+        hipLaunchKernelGGL(k_stem_fwd<true>, dim3(blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y, stats);
+    else
+        hipLaunchKernelGGL(k_stem_fwd<false>, dim3(blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y, nullptr);
+    CPG_CHECK_LAUNCH("cpg_conv2d_fwd(stem)");
+    return CPG_OK;
+}

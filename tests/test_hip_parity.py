@@ -222,6 +222,44 @@ def test_winograd_matches_direct(N, C, H, W, K, bias, pm, nw, monkeypatch):
     assert not torch.equal(y1, y0) or N * H * W < 64                         # (the two paths really are different kernels)
 
 
+@pytest.mark.parametrize('N,C,H,W,bias,pm', [
+    (2, 3, 224, 224, False, False),    # the VGG16 stem at its own map size: every tile inside the image
+    (3, 3, 20, 45, True, True),        # ragged: 20 = 2 x 8 + 4 rows, 45 = 32 + 13 columns; conv bias; piggymask
+    (1, 1, 9, 33, False, False),       # one channel (18 of the 27 taps are padding), one pixel in the second tile column
+    (2, 2, 8, 32, True, False),        # exactly one tile per image
+    (70, 3, 16, 64, False, True),      # more tiles than waves of a small launch can take one at a time
+])
+def test_stem_kernel_matches_general_kernel(N, C, H, W, bias, pm, monkeypatch):
+    """conv3x3_stem.hip (<= 3 input channels, 64 output channels: one persistent wave per 8 x 32 tile, weights in registers)
+    against the general direct kernel (CPG_NO_STEM=1) and fp64: output and the BatchNorm statistics tiles' totals."""
+    g = torch.Generator().manual_seed(N + H + W)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(64, C, 3, 3, generator=g) * 0.3
+    b = torch.randn(64, generator=g) if bias else None
+    pmv = torch.rand(64, C, 3, 3, generator=g) * 0.012 if pm else None
+    xd, wd = x.to(DEV), w.to(DEV)
+    bd, pd = (b.to(DEV) if bias else None), (pmv.to(DEV) if pm else None)
+
+    def run():
+        y0 = nl._MaskedConv2dFn.apply(xd, wd, pd, bd, 5e-3, (1, 1), (1, 1), (1, 1), 1)
+        y1, st = nl._MaskedConv2dFn.apply(xd, wd, pd, bd, 5e-3, (1, 1), (1, 1), (1, 1), 1, True)
+        return y0.cpu(), y1.cpu(), st.cpu().double()
+    y0, y1, st = run()
+    y0b, y1b, stb = run()
+    assert torch.equal(y0, y0b) and torch.equal(y1, y1b) and torch.equal(st, stb)
+    monkeypatch.setenv('CPG_NO_STEM', '1')
+    g0, g1, gst = run()
+    weff = w.double() * ((pmv > 5e-3).double() if pm else 1.0)
+    ref = torch.nn.functional.conv2d(x.double(), weff, b.double() if bias else None, padding=1)
+    sc = float(ref.abs().max())
+    assert torch.equal(y0, y1)
+    assert float((y0.double() - ref).abs().max()) < 2e-6 * sc and float((g0.double() - ref).abs().max()) < 2e-6 * sc
+    # statistics: per channel sum / sum of squares over all tiles (the two kernels tile differently)
+    tot, ref_tot = st.sum(1), torch.stack([ref.sum((0, 2, 3)), (ref * ref).sum((0, 2, 3))], 1)
+    assert st.shape[0] == 64 and float((tot - ref_tot).abs().max()) < 1e-5 * float(ref_tot.abs().max())
+    assert float((gst.sum(1) - ref_tot).abs().max()) < 1e-5 * float(ref_tot.abs().max())
+
+
 @pytest.mark.parametrize('N,C,H,W,K,pm', [
     (1, 32, 28, 28, 32, False),        # one 14-tile segment per tile row, 14 stages: every unit is a single stage
     (5, 96, 28, 28, 64, True),         # odd image count, 3 x 2 channel blocks, piggymask (the reduce kernel's autograd epilogue)
