@@ -28,7 +28,7 @@ def main():
     # the families bench.py reports (its HIP-event clock brackets the whole library call: + k_c3_pack for fwd / dgrad,
     # + k_c3_wgrad_reduce for wgrad)
     # (k_pw / k_pw_wgrad serve the 1x1 convs AND the un-masked linear layers, so they get their own row)
-    fams = [('conv_fwd', r'k_c3_fwd<.*>, false(, (true|false))*>|k_conv_fwd|k_wg_fwd<\d, false|k_wg[13]<false'),
+    fams = [('conv_fwd', r'k_c3_fwd<.*>, false(, (true|false))*>|k_conv_fwd|k_wg_fwd<\d, false|k_wg[13]<false|k_stem_fwd'),
             ('conv_dgrad', r'k_c3_fwd<.*>, true(, (true|false))*>|k_conv_dgrad|k_wg_fwd<\d, true|k_wg[13]<true'),
             ('conv_wgrad', r'k_c3_wgrad<|k_c3_wgrad_smallc|k_conv_wgrad|k_wgw'),
             ('pointwise conv / linear GEMM', r'k_pw<|k_pw_wgrad|k_gemm<')]
