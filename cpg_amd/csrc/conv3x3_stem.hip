@@ -35,9 +35,8 @@ struct StemGeom {
     unsigned ntiles;
 };
 
-// (STATS: 64 more registers for the sums -- one block per CU instead of two)
 template <bool STATS>
-__global__ __launch_bounds__(256, STATS ? 1 : 2)
+__global__ __launch_bounds__(256, 2)
 void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ pm, float thr,
                 const float *__restrict__ bias, float *__restrict__ y, float *__restrict__ stats) {
     __shared__ float smem_all[4 * ST_PATCH];
@@ -136,24 +135,27 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
         const int pix0 = (y0 * g.W + x0 + li) * 4 + lh * 4 * HW4;
         // (a tile inside the image needs no per-pixel masks: `full` is wave-uniform)
         const bool full = x0 + ST_W <= g.W && y0 + ST_R <= g.H;
-        auto row = [&](int j, auto fullc) {
+        // STATS: the two blocks of 32 output channels in two passes over the patch (the 64 sums of one pass would cost the second
+        // resident block its registers: 0.81 instead of 0.68 ms); plain: both blocks share every B operand read
+        auto row = [&](int j, auto fullc, auto mbsel) {
             constexpr bool FULL = decltype(fullc)::value;
+            constexpr int MB0 = decltype(mbsel)::value < 0 ? 0 : decltype(mbsel)::value, MB1 = decltype(mbsel)::value < 0 ? 2 : MB0 + 1;
             f32x16 acc[2];
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+            for (int mb = MB0; mb < MB1; ++mb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mb][e] = 0.0f;
             const float *prow = smem + j * ST_PW;
 #pragma unroll
             for (int t = 0; t < ST_KS; ++t) {
                 const float b = prow[boff[t]];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][t], b, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][t], b, acc[1], 0, 0, 0);
+#pragma unroll
+                for (int mb = MB0; mb < MB1; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[mb][t], b, acc[mb], 0, 0, 0);
             }
             const bool pok = FULL || (cok && y0 + j < g.H);
             const int voff = pok ? pix0 + j * g.W * 4 : kOOR;
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+            for (int mb = MB0; mb < MB1; ++mb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int cu = mb * 32 + (e & 3) + 8 * (e >> 2);       // + 4 lh: in voff
@@ -166,29 +168,35 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
                     }
                 }
         };
-        if (full) {
+        auto rows = [&](auto mbsel) {
+            if (full) {
 #pragma unroll 1
-            for (int j = 0; j < ST_R; ++j) row(j, std::true_type{});
-        } else {
+                for (int j = 0; j < ST_R; ++j) row(j, std::true_type{}, mbsel);
+            } else {
 #pragma unroll 1
-            for (int j = 0; j < ST_R; ++j) row(j, std::false_type{});
-        }
-        if (STATS) {
+                for (int j = 0; j < ST_R; ++j) row(j, std::false_type{}, mbsel);
+            }
+        };
+        auto stats_out = [&](int mb) {
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int e = 0; e < 16; e += 8) half_wave_sum8(s1[mb] + e), half_wave_sum8(s2[mb] + e);
+            for (int e = 0; e < 16; e += 8) half_wave_sum8(s1[mb] + e), half_wave_sum8(s2[mb] + e);
             if (li == kHalfSumLane) {
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int co = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                        f32x2 o;
-                        o[0] = s1[mb][e], o[1] = s2[mb][e];
-                        *reinterpret_cast<f32x2 *>(stats + ((int64_t)co * g.ntiles + tile) * 2) = o;
-                    }
+                for (int e = 0; e < 16; ++e) {
+                    const int co = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    f32x2 o;
+                    o[0] = s1[mb][e], o[1] = s2[mb][e];
+                    *reinterpret_cast<f32x2 *>(stats + ((int64_t)co * g.ntiles + tile) * 2) = o;
+                }
             }
+        };
+        if (STATS) {
+            rows(std::integral_constant<int, 0>{});
+            stats_out(0);
+            rows(std::integral_constant<int, 1>{});
+            stats_out(1);
+        } else {
+            rows(std::integral_constant<int, -1>{});
         }
     }
 }
