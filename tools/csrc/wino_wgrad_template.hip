@@ -314,7 +314,12 @@ bool ww_plan(const cpg_conv_desc *d, WwPlan &p) {
     g.nstages = (unsigned)nstages;
     g.nkb = d->K / 32, g.ncb = d->C / 32;
     const int64_t npairs = (int64_t)g.nkb * g.ncb;
-    int64_t want = std::max<int64_t>(1, (6 * 4 * kCUs) / npairs);              // ~6 units per wave slot
+    // units per wave slot: 2.  Every unit costs a prologue / epilogue and a 9 x 32 x 32 partial sum that k_split_reduce has to read;
+    // 6 (the first choice, for load balance) measured 35.25 ms per VGG16 pass against 34.2-34.3 ms for 1 or 2 (the units of a
+    // launch are equally long: there is little to balance), with a third of the workspace.  CPG_WW_UNITS overrides (A/B).
+    int upw = 2;
+    if (const char *f = getenv("CPG_WW_UNITS")) upw = std::max(1, atoi(f));
+    int64_t want = std::max<int64_t>(1, ((int64_t)upw * 4 * kCUs) / npairs);
     want = std::min<int64_t>(want, nstages);
     g.su = (unsigned)((nstages + want - 1) / want);
     g.nsplit = (int)((nstages + g.su - 1) / g.su);

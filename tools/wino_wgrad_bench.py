@@ -54,7 +54,11 @@ def main():
         if not raw.cpg_conv3x3_wino_wgrad_ok(ctypes.byref(d)):
             print('%-5s not eligible' % name)
             continue
-        ws, nb = _lib.workspace(L.cpg_conv2d_workspace_bytes(ctypes.byref(d)), dev)
+        need = L.cpg_conv2d_workspace_bytes(ctypes.byref(d))
+        os.environ['CPG_NO_WINO_WGRAD'] = '1'                 # (the direct kernel's partial sums may need more)
+        need = max(need, L.cpg_conv2d_workspace_bytes(ctypes.byref(d)))
+        os.environ.pop('CPG_NO_WINO_WGRAD')
+        ws, nb = _lib.workspace(need, dev)
         nbw = raw.cpg_conv3x3_wino_wgrad_workspace(ctypes.byref(d))
         wsw = torch.empty(nbw // 4 + 64, device=dev)
         flops = 2.0 * N * K * H * H * C * 9
