@@ -550,11 +550,14 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     float *smem = smem_all + wave * 2 * W1_RAW;               // this wave's private raw stages
     // PERSISTENT blocks: the grid is at most one block per CU (all a CU can hold: 512 registers per wave) and every wave walks
     // over the logical blocks base + blockIdx, base += gridDim -- no dispatch gap between units (0.6 us of 27 on the 64-channel
-    // layers), the kernel arguments and the code stay where they are.  Within a round the XCDs take contiguous ranges.
+    // layers), the kernel arguments and the code stay where they are.
     for (unsigned base = 0; base < g.nblocks; base += gridDim.x) {
-    const unsigned round_n = min(gridDim.x, g.nblocks - base);
-    if (blockIdx.x >= round_n) break;
-    const unsigned lb = base + xcd_remap(blockIdx.x, round_n);
+    // (virtual block v runs on XCD v % 8 = blockIdx % 8 -- the grid is a multiple of 8 blocks whenever there is more than one
+    //  round -- and XCD x owns the x-th eighth of ALL logical blocks, walking through it round after round: consecutive tile runs,
+    //  which share half of their input rows, stay in one XCD's L2 as with one block per logical block)
+    const unsigned v = base + blockIdx.x;
+    if (v >= g.nblocks) break;
+    const unsigned lb = xcd_remap(v, g.nblocks);
     const int kb = lb % g.nkb;
     // (32-bit tile arithmetic: the host refuses N * tiles >= 2^31; 64-bit divisions cost the prologue ~1.5 us per wave)
     const unsigned ttot = (unsigned)g.tiles_total, timg = (unsigned)g.tiles_img, twu = (unsigned)g.tw;
@@ -1289,9 +1292,12 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
 
     // persistent blocks, as in k_wg1 (two blocks of two waves per CU)
     for (unsigned base = 0; base < g.nblocks; base += gridDim.x) {
-    const unsigned round_n = min(gridDim.x, g.nblocks - base);
-    if (blockIdx.x >= round_n) break;
-    const unsigned lb = base + xcd_remap(blockIdx.x, round_n);
+    // (virtual block v runs on XCD v % 8 = blockIdx % 8 -- the grid is a multiple of 8 blocks whenever there is more than one
+    //  round -- and XCD x owns the x-th eighth of ALL logical blocks, walking through it round after round: consecutive tile runs,
+    //  which share half of their input rows, stay in one XCD's L2 as with one block per logical block)
+    const unsigned v = base + blockIdx.x;
+    if (v >= g.nblocks) break;
+    const unsigned lb = xcd_remap(v, g.nblocks);
     const int nkb64 = (g.nkb + 1) / 2;                        // (g.nkb counts blocks of 32 channels)
     const int kb = lb % nkb64;                                // block of 64 output channels
     const unsigned ttot = (unsigned)g.tiles_total, timg = (unsigned)g.tiles_img, twu = (unsigned)g.tw;
