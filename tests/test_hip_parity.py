@@ -172,6 +172,8 @@ def test_conv_oracle(N, C, H, W, K, k, s, p, bias, pm):
     (2, 24, 12, 30, 40, True, True),       # 15-tile rows: a block's tile run wraps rows several times
     (7, 128, 28, 28, 96, False, False),    # 196 tiles per image
     (2, 64, 112, 112, 64, False, False),   # 56-tile rows, block halos inside a row
+    (8, 32, 96, 96, 64, True, False),      # 288 logical k_wg1 blocks: more than the persistent grid holds (256), a ragged second round
+    (4, 128, 96, 96, 128, False, True),    # 576 logical k_wg3 blocks against a grid of 512
 ])
 @pytest.mark.parametrize('nw', [0, 1, 2, 3, 4, 8])
 def test_winograd_matches_direct(N, C, H, W, K, bias, pm, nw, monkeypatch):
@@ -1495,7 +1497,9 @@ def test_prelu_backward_matches_torch(N, C, H, W, shared):
 @pytest.mark.parametrize('N,C,K,H,W,pool', [(4, 16, 64, 56, 56, False), (6, 64, 128, 28, 28, True), (5, 32, 160, 14, 14, True),
                                           (3, 3, 64, 64, 64, False), (2, 8, 24, 10, 12, True), (7, 16, 40, 7, 7, False),
                                           # small even maps on the Winograd kernels: 1 / 4 / 16 tiles per image, one partly filled block
-                                          (16, 128, 128, 2, 2, False), (16, 64, 128, 4, 4, True), (16, 32, 64, 8, 8, True), (3, 16, 16, 2, 2, False)])
+                                          (16, 128, 128, 2, 2, False), (16, 64, 128, 4, 4, True), (16, 32, 64, 8, 8, True), (3, 16, 16, 2, 2, False),
+                                          # more logical blocks than the persistent Winograd grids hold: k_wg1 (288 of 256) and k_wg3 (576 of 512)
+                                          (8, 32, 64, 96, 96, False), (4, 128, 128, 96, 96, True)])
 def test_conv_epilogue_bn_statistics(N, C, K, H, W, pool):
     """conv -> BatchNorm2d -> ReLU (-> MaxPool) in train mode with the statistics accumulated in the conv epilogue
     (cpg_conv2d_fwd_bnstats + cpg_bn_stats_finalize) against the separate statistics pass: output, running statistics,
