@@ -229,7 +229,8 @@ def test_winograd_matches_direct(N, C, H, W, K, bias, pm, nw, monkeypatch):
     (3, 3, 20, 45, True, True),        # ragged: 20 = 2 x 8 + 4 rows, 45 = 32 + 13 columns; conv bias; piggymask
     (1, 1, 9, 33, False, False),       # one channel (18 of the 27 taps are padding), one pixel in the second tile column
     (2, 2, 8, 32, True, False),        # exactly one tile per image
-    (70, 3, 16, 64, False, True),      # more tiles than waves of a small launch can take one at a time
+    (70, 3, 16, 64, False, True),      # 280 tiles
+    (12, 3, 224, 224, False, False),   # 2352 tiles for the 2048 persistent waves: a wave's second tile, the ragged last round
 ])
 def test_stem_kernel_matches_general_kernel(N, C, H, W, bias, pm, monkeypatch):
     """conv3x3_stem.hip (<= 3 input channels, 64 output channels: one persistent wave per 8 x 32 tile, weights in registers)
