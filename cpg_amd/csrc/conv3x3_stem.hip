@@ -206,7 +206,7 @@ bool stem_geom(int N, int C, int K, int H, int W, StemGeom &g) {
         if (f[0] != '0') return false;
     }
     if (N < 1 || C < 1 || C > ST_CMAX || K != 64 || H < 1 || W < 1) return false;
-    if ((int64_t)N * C * H * W * 4 >= (1ll << 31) || (int64_t)K * H * W >= (1ll << 31)) return false;
+    if ((int64_t)N * C * H * W * 4 >= (1ll << 31) || (int64_t)K * H * W * 4 >= (1ll << 31)) return false;   // (32-bit byte offsets into x and into one image of y)
     g.N = N, g.C = C, g.K = K, g.H = H, g.W = W;
     g.tiles_x = (W + ST_W - 1) / ST_W, g.tiles_y = (H + ST_R - 1) / ST_R;
     const int64_t nt = (int64_t)N * g.tiles_x * g.tiles_y;
