@@ -6,7 +6,7 @@
 // (conv3x3.hip, 8 x 32 tile) took 1.23 ms: one block per tile, so each tile pays a prologue (operand staging, a barrier), an
 // epilogue of 64 dword stores per lane and the dispatch of the next block, with only 72 MFMAs per wave in between.
 //
-// Here ONE WAVE = ONE TILE (8 rows x 32 columns x all output channels), persistent, no barriers:
+// Here ONE WAVE = ONE TILE (8 rows x 32 columns x all output channels) at a time, a dozen tiles per wave at batch 256, no barriers:
 //   * k of the MFMA runs over (channel, tap): 27 values padded to 28 = 14 steps of v_mfma_f32_32x32x2_f32.  The A operands
 //     (W .* bin(pm), 2 blocks of 32 output channels x 14 steps) stay in 28 registers for the whole launch -- no weight pack kernel;
 //   * the B operand of step t and output row j is one ds_read_b32 from the wave's private patch (3 channels x 10 rows x 34 columns):
@@ -233,7 +233,11 @@ extern "C" int cpg_conv3x3_stem_run(int N, int C, int K, int H, int W, const flo
                                     const float *bias, float *y, float *stats, hipStream_t stream) {
     StemGeom g;
     if (!stem_geom(N, C, K, H, W, g)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_fwd(stem): shape not supported");
-    const unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)g.ntiles + 3) / 4, 2 * kCUs);
+    // Two resident grids' worth of blocks (4 per CU; a CU holds 2): measured the same as exactly one grid (0.776 vs 0.778 ms,
+    // 12 vs 24 tiles per wave), 3-10 % faster than 3, 6 or 12 grids (the weights are re-fetched by every wave) -- and when another
+    // stream (RCCL) holds some CUs, an exactly-resident grid would have to wait for its last blocks.  CPG_STEM_BLOCKS overrides (A/B).
+    unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)g.ntiles + 3) / 4, 4 * kCUs);
+    if (const char *f = getenv("CPG_STEM_BLOCKS")) blocks = (unsigned)std::max(1, atoi(f));
     if (stats != nullptr)
         hipLaunchKernelGGL(k_stem_fwd<true>, dim3(blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y, stats);
     else

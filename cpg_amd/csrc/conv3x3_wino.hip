@@ -548,9 +548,9 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     const int li = lane & 31, lh = lane >> 5;
     const int HW = g.H * g.W;
     float *smem = smem_all + wave * 2 * W1_RAW;               // this wave's private raw stages
-    // PERSISTENT blocks: the grid is at most one block per CU (all a CU can hold: 512 registers per wave) and every wave walks
-    // over the logical blocks base + blockIdx, base += gridDim -- no dispatch gap between units (0.6 us of 27 on the 64-channel
-    // layers), the kernel arguments and the code stay where they are.
+    // PERSISTENT blocks: the grid is at most a few times what the chip holds (one block per CU: 512 registers per wave; see
+    // wino_grids) and every wave walks over the logical blocks base + blockIdx, base += gridDim -- no dispatch gap between
+    // units (0.6 us of 27 on the 64-channel layers), the kernel arguments and the code stay where they are.
     for (unsigned base = 0; base < g.nblocks; base += gridDim.x) {
     // (virtual block v runs on XCD v % 8 = blockIdx % 8 -- the grid is a multiple of 8 blocks whenever there is more than one
     //  round -- and XCD x owns the x-th eighth of ALL logical blocks, walking through it round after round: consecutive tile runs,
@@ -1290,7 +1290,7 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     const int HW = g.H * g.W;
     float *smem = smem_all + ph * 2 * W2_RAW;                 // this wave's private raw stages
 
-    // persistent blocks, as in k_wg1 (two blocks of two waves per CU)
+    // persistent blocks, as in k_wg1 (two blocks of two waves per CU are resident)
     for (unsigned base = 0; base < g.nblocks; base += gridDim.x) {
     // (virtual block v runs on XCD v % 8 = blockIdx % 8 -- the grid is a multiple of 8 blocks whenever there is more than one
     //  round -- and XCD x owns the x-th eighth of ALL logical blocks, walking through it round after round: consecutive tile runs,
@@ -1687,6 +1687,16 @@ static inline bool wino_persist() {
     return f == nullptr || f[0] != '0';
 }
 
+// How many resident grids' worth of persistent blocks a launch gets: 8.  One grid (every block resident from the start, ~200 units
+// per wave on the big layers) and 4, 8 or 16 grids measured the same within 0.5 % on every VGG16 layer -- a block that runs a
+// dozen units has amortised its dispatch --, but with one exactly-resident grid a launch that finds some CUs taken (RCCL's
+// kernels on the communication stream) would run its last blocks alone afterwards; with 8 the dispatcher balances whatever
+// share of the chip is free to within 1/8 of a round.  CPG_WINO_GRIDS overrides (A/B experiments).
+static inline int wino_grids() {
+    if (const char *f = getenv("CPG_WINO_GRIDS")) return std::max(1, atoi(f));
+    return 8;
+}
+
 // number of BatchNorm-statistics tiles per channel of a forward launch (stats[m][tiles][2])
 extern "C" int cpg_conv3x3_wino_tiles(int N, int c_read, int m, int H, int W) {
     const int64_t tiles = (int64_t)N * (H / 2) * (W / 2);
@@ -1749,7 +1759,7 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
             int64_t blocks = runs * ((g.nkb + 1) / 2);
             if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "%s: grid too large", what);
             g.nblocks = (unsigned)blocks;
-            if (persist) blocks = std::min<int64_t>(blocks, 2 * kCUs);
+            if (persist) blocks = std::min<int64_t>(blocks, (int64_t)wino_grids() * 2 * kCUs);
             if (bne != nullptr)
                 hipLaunchKernelGGL((k_wg3<false, false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, *bne);
             else if (dgrad)
@@ -1778,7 +1788,7 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
         int64_t blocks = (runs + 3) / 4 * g.nkb;
         if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "%s: grid too large", what);
         g.nblocks = (unsigned)blocks;
-        if (persist) blocks = std::min<int64_t>(blocks, kCUs);
+        if (persist) blocks = std::min<int64_t>(blocks, (int64_t)wino_grids() * kCUs);
         if (bne != nullptr)
             hipLaunchKernelGGL((k_wg1<false, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, up, bias, y, nullptr, *bne);
         else if (dgrad)

@@ -39,6 +39,10 @@ class DataParallel(nn.Module):
         self._active = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size(process_group) > 1 or os.environ.get('CPG_DP_FORCE') == '1')
         self._world = dist.get_world_size(process_group) if self._active else 1
+        if self._active and self._world > 1:
+            # the gradient all-reduce runs on RCCL's stream beside the backward kernels and holds some CUs: the Winograd weight
+            # gradient then wants more, shorter units per wave slot (a launch is `units` rounds of blocks; conv3x3_wino_wgrad.hip)
+            os.environ.setdefault('CPG_WW_UNITS', '8')
         self._handles = []
         self._small = []
         # marks the Parameters this wrapper has hooked: an attribute on the Parameter itself, which dies with it.  (A set of
