@@ -2,7 +2,7 @@
 // (VGG16 features.0, models/vgg.py:131-141 of the reference; SharableConv2d.forward, models/layers.py:98-109).
 //
 // The layer is HBM-bound: 27 multiplies per output against 4 bytes written -- batch 256 @ 224 x 224 writes 3.29 GB and reads 0.15 GB,
-// 0.45 ms at the 7.3 TB/s the streaming kernels of this library reach; the MFMA work is 0.3 ms.  The general direct kernel
+// 0.55 ms at the 6.3 TB/s a float4 copy reaches on this part; the MFMA work is 0.3 ms.  The general direct kernel
 // (conv3x3.hip, 8 x 32 tile) took 1.23 ms: one block per tile, so each tile pays a prologue (operand staging, a barrier), an
 // epilogue of 64 dword stores per lane and the dispatch of the next block, with only 72 MFMAs per wave in between.
 //
