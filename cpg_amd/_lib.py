@@ -39,6 +39,7 @@ assert PRUNE_RESULT_BYTES == 32
 # name -> (restype, argtypes); mirrors include/cpg_hip.h one to one
 _SIGNATURES = {
     'cpg_version': (ctypes.c_int, []),
+    'cpg_set_shared_chip_hint': (ctypes.c_int, [ctypes.c_int32]),
     'cpg_last_error': (ctypes.c_char_p, []),
     'cpg_binarize_mask_weight': (ctypes.c_int, [_vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, _vp]),
     'cpg_conv2d_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),

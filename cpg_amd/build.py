@@ -31,6 +31,33 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def export_map():
+    """Linker version script: the shared library exports exactly the functions include/cpg_hip.h declares (cross-file helpers
+    such as cpg_conv3x3_wino_run stay internal).  CPG_EXPORT_ALL=1 builds without it -- the kernel A/B tools under tools/ that
+    drive single kernels (wino_bench.py, wino_wgrad_bench.py, diag_wino_*.py) need those helpers."""
+    import re
+    header = open(os.path.join(CSRC, '..', '..', 'include', 'cpg_hip.h')).read()
+    names = sorted(set(re.findall(r'\b(cpg_[a-z0-9_]+)\s*\(', header)))
+    path = os.path.join(LIBDIR, 'exports.map')
+    text = '{\n  global:\n' + ''.join('    %s;\n' % n for n in names) + '  local: *;\n};\n'
+    if not os.path.exists(path) or open(path).read() != text:
+        with open(path, 'w') as f:
+            f.write(text)
+    return path
+
+
+def _export_mode_changed(restricted):
+    """True when the existing library was linked in the other export mode (CPG_EXPORT_ALL toggled)."""
+    stamp = os.path.join(LIBDIR, 'export_mode')
+    mode = 'restricted' if restricted else 'all'
+    old = open(stamp).read() if os.path.exists(stamp) else None
+    if old != mode:
+        with open(stamp, 'w') as f:
+            f.write(mode)
+        return True
+    return False
+
+
 def build_lib(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
@@ -56,8 +83,14 @@ def build_lib(force=False, verbose=True):
             print('FAILED:', src)
     if failed:
         raise RuntimeError('hipcc failed')
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    link_deps = list(objs)
+    link_flags = []
+    if os.environ.get('CPG_EXPORT_ALL') != '1':
+        vs = export_map()
+        link_deps.append(vs)
+        link_flags = ['-Wl,--version-script=' + vs]
+    if force or procs or _stale(LIB, link_deps) or _export_mode_changed(bool(link_flags)):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + link_flags + ['-o', LIB] + objs
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

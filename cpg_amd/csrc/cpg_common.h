@@ -10,6 +10,8 @@ namespace cpg {
 // thread-local last-error text (no global mutable state shared between host threads)
 char *err_buf();
 int fail(int code, const char *fmt, ...);
+// cpg_set_shared_chip_hint() of the calling host thread (thread-local; never changes results, only split counts / grids)
+int shared_chip_hint();
 
 inline int hip_status(hipError_t e, const char *what) {
     if (e == hipSuccess) return CPG_OK;

@@ -660,10 +660,12 @@ extern "C" int cpg_conv2d_fwd_bnstats(const cpg_conv_desc *d, const float *x, co
 
 extern "C" int cpg_conv3x3_wino_ok(int N, int c_read, int m, int H, int W);
 extern "C" int cpg_conv3x3_wino_wgrad_ok(const cpg_conv_desc *d);
+extern "C" int cpg_conv3x3_wino_eval_ok(int N, int c_read, int m, int H, int W);
 extern "C" int32_t cpg_conv2d_winograd(const cpg_conv_desc *d, int32_t dgrad) {
     ConvGeom g;
     if (d == nullptr || make_geom(d, g) != CPG_OK || !cpg_conv3x3_supported(d)) return 0;
     if (dgrad == 2) return use_c3_wgrad(d) ? cpg_conv3x3_wino_wgrad_ok(d) : 0;
+    if (dgrad == 3) return cpg_conv3x3_wino_eval_ok(d->N, d->C, d->K, d->H, d->W);      // the dispatch rule of run_fwd(bn != nullptr)
     return dgrad ? cpg_conv3x3_wino_ok(d->N, d->K, d->C, d->H, d->W) : cpg_conv3x3_wino_ok(d->N, d->C, d->K, d->H, d->W);
 }
 

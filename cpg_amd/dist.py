@@ -39,10 +39,12 @@ class DataParallel(nn.Module):
         self._active = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size(process_group) > 1 or os.environ.get('CPG_DP_FORCE') == '1')
         self._world = dist.get_world_size(process_group) if self._active else 1
-        if self._active and self._world > 1:
-            # the gradient all-reduce runs on RCCL's stream beside the backward kernels and holds some CUs: the Winograd weight
-            # gradient then wants more, shorter units per wave slot (a launch is `units` rounds of blocks; conv3x3_wino_wgrad.hip)
-            os.environ.setdefault('CPG_WW_UNITS', '8')
+        if self._active and self._world > 1 and any(p.is_cuda for p in module.parameters()):
+            # the gradient all-reduce runs on RCCL's stream beside the backward kernels and holds some CUs: tell the library
+            # (a thread-local hint of its C ABI, not a process-wide environment variable) -- the Winograd weight gradient then
+            # uses more, shorter units per wave slot (a launch is `units` rounds of blocks; conv3x3_wino_wgrad.hip)
+            from . import _lib
+            _lib.lib().cpg_set_shared_chip_hint(1)
         self._handles = []
         self._small = []
         # marks the Parameters this wrapper has hooked: an attribute on the Parameter itself, which dies with it.  (A set of
@@ -83,6 +85,9 @@ class DataParallel(nn.Module):
         """Attach (or, with None, detach) the SparsePruner whose owner masks decide which gradient slots are exchanged.
         Only safe when gradient routing runs after finish_gradient_sync() -- Manager.train does both."""
         self._filter = pruner
+        for p in self.module.parameters():          # a new pruner restarts its mutation counter: never reuse the old one's plans
+            if hasattr(p, '_cpg_pack_plan'):
+                del p._cpg_pack_plan
 
     def _plan(self, p):
         """None: exchange the whole gradient.  Otherwise (owner, cur, select, block offsets, total): exchange only the
@@ -99,7 +104,7 @@ class DataParallel(nn.Module):
         cur = int(pr.current_dataset_idx)
         if select == 1 and mode == 'prune':
             return (owner, cur, select, None, 0)                  # routing zeroes every piggymask gradient in prune mode
-        ckey = (id(owner), owner._version, pr._mutations, cur, select)
+        ckey = (pr._epoch, id(owner), owner._version, pr._mutations, cur, select)
         cached = getattr(p, '_cpg_pack_plan', None)
         if cached is not None and cached[0] == ckey:
             return cached[1]

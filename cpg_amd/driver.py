@@ -98,15 +98,25 @@ class CPGSession(object):
         self.masks = {}
         self.model = None
         self.data_parallel = data_parallel
-        self.net = self._build(width, [], {})
+        self.net = self._build(width, [], {}, reseed=True)
 
-    def _build(self, width, datasets, dataset2num_classes):
-        if self.seed is not None:
-            torch.manual_seed(self.seed)
+    def _build(self, width, datasets, dataset2num_classes, reseed=False):
+        """A fresh network of the session's topology.  reseed=True (construction, growth): the global generator is seeded, as
+        the reference's main() does once per process (CPG_cifar100_main_normal.py:135-137).  Otherwise (load, evaluate: the
+        initial values are overwritten anyway) the construction draws from a FORKED generator, so evaluating an old task in the
+        middle of a session does not rewind the Dropout / shuffling stream -- nor the per-rank seeds of cdist.seed_per_rank."""
         kw = dict(dataset_history=datasets, dataset2num_classes=dataset2num_classes, network_width_multiplier=width,
                   shared_layer_info=self.shared_layer_info)
         build = getattr(models, self.arch)
-        return build(self.cfg, **kw) if 'vgg' in self.arch else build(**kw)
+
+        def make():
+            if self.seed is not None:
+                torch.manual_seed(self.seed)
+            return build(self.cfg, **kw) if 'vgg' in self.arch else build(**kw)
+        if reseed or self.seed is None:
+            return make()
+        with torch.random.fork_rng(devices=[self.device] if self.device.type == 'cuda' else []):
+            return make()
 
     # -- per-task set-up (CPG_cifar100_main_normal.py:196-290) -------------------------------------------------
     def start_task(self, dataset, num_classes):
@@ -227,7 +237,7 @@ class CPGSession(object):
         else:
             self.shared_layer_info.clear()
         self.width = new_width
-        self.net = self._build(new_width, datasets, d2n).to(self.device)
+        self.net = self._build(new_width, datasets, d2n, reseed=True).to(self.device)
         self.model = cdist.DataParallel(self.net) if self.data_parallel else self.net
         if snap is not None:
             ckpt.load_state(self.model, snap.state, for_evaluate=False)

@@ -82,7 +82,9 @@ class _BnReluFn(torch.autograd.Function):
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(beta)
         ws, nb = _lib.workspace(L.cpg_bn_workspace_bytes(N, C, HW), x.device)
-        hint = ctx.hint
+        hint, ctx.hint = ctx.hint, None                  # (the hint only lives for one backward pass: drop its tensors afterwards)
+        if hint is not None:
+            hint.ypre = hint.gamma = hint.beta = hint.mean = hint.invstd = hint.out_shape = None
         if hint is not None and hint.partials is not None:
             # the consumer conv's input-gradient kernel already masked gy by the ReLU and reduced it per (channel, tile)
             rc = L.cpg_bn_bwd_from_partials(_lib.dptr(hint.partials), hint.tiles, _lib.dptr(x), _lib.dptr(gy, name='grad_output'),

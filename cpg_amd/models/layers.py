@@ -169,7 +169,7 @@ class _MaskedConv2dFn(torch.autograd.Function):
             _lib.check('cpg_conv2d_dgrad_bf16', rc)
         elif ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            hint = ctx.bn_hint
+            hint, ctx.bn_hint = ctx.bn_hint, None
             tiles = L.cpg_conv2d_dgrad_bnbwd_tiles(ctypes.byref(d)) if (hint is not None and hint.usable(x)) else 0
             if tiles > 0:
                 # gx becomes g * [bn(ypre) > 0] and the BatchNorm's two backward sums come out per (channel, pixel tile)

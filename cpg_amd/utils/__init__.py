@@ -52,6 +52,20 @@ class Metric(object):
     def avg(self):
         return self.sum / self.n
 
+    def all_reduce_(self, group=None):
+        """Sum the running totals over the ranks of a data-parallel run: `avg` then is the mean over the GLOBAL batches, what the
+        reference's single-process nn.DataParallel computes on the gathered output (utils/manager.py:60-62) -- and identical on
+        every rank, so decisions taken on it (grow, stop the sweep, early stop) cannot diverge between ranks."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return self
+        both = torch.stack([self.sum.float().reshape(()), self.n.float().reshape(())])
+        if dist.get_backend(group) == 'nccl' and not both.is_cuda:
+            both = both.cuda()
+        dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
+        self.sum, self.n = both[0], both[1]
+        return self
+
 
 def classification_accuracy(output, target):
     """Top-1 accuracy of a batch (utils/__init__.py:46-49); stays on the device (no .cpu() stall)."""

@@ -122,6 +122,11 @@ class Manager(object):
                                    'sparsity': self.last_stats['sparsity'],
                                    'network_width_mpl': self.args.network_width_multiplier})
                 t.update(1)
+        if getattr(self.model, '_world', 1) > 1:        # data parallel: metrics of the GLOBAL batches, the same on every rank
+            pg = getattr(self.model, 'process_group', None)
+            train_loss.all_reduce_(pg)
+            if self.args.dataset != 'face_verification':
+                train_accuracy.all_reduce_(pg)
         summary = {'loss': '{:.3f}'.format(train_loss.avg.item()),
                    'accuracy': '{:.2f}'.format(100. * train_accuracy.avg.item()),
                    'lr': curr_lrs[0],
@@ -167,6 +172,10 @@ class Manager(object):
                         post['mpl'] = self.args.network_width_multiplier
                         t.set_postfix(post)
                     t.update(1)
+        if getattr(self.model, '_world', 1) > 1:        # data parallel: every rank returns the same accuracy (sharded or replicated loader)
+            pg = getattr(self.model, 'process_group', None)
+            val_loss.all_reduce_(pg)
+            val_accuracy.all_reduce_(pg)
         summary = {'loss': '{:.3f}'.format(val_loss.avg.item()),
                    'accuracy': '{:.2f}'.format(100. * val_accuracy.avg.item()),
                    'sparsity': '{:.3f}'.format(self.pruner.calculate_sparsity()),

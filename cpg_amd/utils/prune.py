@@ -31,6 +31,7 @@ def _masked(module):
 
 class SparsePruner(object):
     """Performs pruning on the given model (utils/prune.py:6-28)."""
+    _epochs = 0
 
     def __init__(self, model, masks, args, begin_prune_step, end_prune_step, inference_dataset_idx):
         self.model = model
@@ -52,6 +53,8 @@ class SparsePruner(object):
         self.inference_dataset_idx = inference_dataset_idx
         self.fused_weight_step = False   # set by utils.fused_sgd.MaskedSGD: it routes masked-weight grads itself
         self.fused_piggymask_step = False   # set by utils.fused_sgd.MaskedAdam: it routes piggymask grads itself
+        SparsePruner._epochs += 1
+        self._epoch = SparsePruner._epochs      # distinguishes this pruner's mutation counter from an earlier pruner's (plan caches)
         self._mutations = 0          # bumped whenever a kernel of ours rewrites a mask in place
         self._pm_mutations = 0       # bumped when a kernel of ours rewrites a piggymask through its raw pointer (MaskedAdam)
         self._hist_key = None

@@ -75,6 +75,12 @@ typedef struct cpg_prune_result {
 } cpg_prune_result;
 
 int cpg_version(void);
+/* Scheduling hint of the CALLING HOST THREAD (thread-local, default 0): 1 = other streams' kernels share the chip with this
+ * thread's launches (a data-parallel run: RCCL's all-reduce kernels hold some CUs during the backward pass).  Never changes a
+ * result bit; the Winograd weight gradient then splits into 8 instead of 4 units per wave slot so that a launch that finds
+ * CUs taken is still balanced by the dispatcher.  Set it before the workspace query of the calls it should affect.
+ * Replaces nn.DataParallel's implicit "all GPUs are mine" (CPG_cifar100_main_normal.py:199-200). */
+int cpg_set_shared_chip_hint(int32_t shared);
 /* human-readable text for the last non-zero status returned on THIS thread */
 const char *cpg_last_error(void);
 
@@ -195,15 +201,17 @@ int cpg_bn_relu_bwd(const float *x, const float *gy, const float *gamma, const f
                     const float *invstd, float *gx, float *dgamma, float *dbeta, int32_t N, int32_t C,
                     int32_t HW, int32_t relu, int32_t train, void *ws, size_t ws_bytes, void *stream);
 
-/* Which arithmetic a training-time launch of this shape uses (pass: 0 forward, 1 input gradient, 2 weight gradient).
+/* Which arithmetic a launch of this shape uses (pass: 0 forward, 1 input gradient, 2 weight gradient, 3 the inference entry
+ * cpg_conv2d_fwd_bn_eval).
  * cpg_conv2d_fwd, cpg_conv2d_fwd_bnstats (0) and cpg_conv2d_dgrad (1) run 3x3 / stride 1 / pad 1 layers on even-sized maps with >= 16 channels on both sides (a multiple
  * of 4 on the contracted side) by Winograd F(2x2, 3x3): 16 instead of 36 multiplies per 2x2 output tile and channel pair, the
  * same sums in a different association -- 1-4e-6 of the output scale from fp64 where the direct kernels are at 0.5-1e-6; the
  * reference's own F.conv2d (models/layers.py:106-109) takes whichever algorithm cuDNN / MIOpen picks, Winograd included.
  * Returns 1 for such a launch, 0 for the direct / generic kernels.  Setting CPG_NO_WINO in the environment (read per call)
  * forces 0 everywhere.  cpg_conv2d_wgrad (2) uses the adjoint transform for maps that are 14 or a multiple of 28 pixels wide with channel counts that are
- * multiples of 32 (CPG_NO_WINO_WGRAD forces the direct kernels for this pass only).  cpg_conv2d_fwd_bn_eval uses it on the
- * same shapes as the forward pass when there is no conv bias and no skip statistics are asked for; the bf16 entry points never do. */
+ * multiples of 32 (CPG_NO_WINO_WGRAD forces the direct kernels for this pass only).  cpg_conv2d_fwd_bn_eval (3) uses it on the
+ * same shapes as the forward pass, with or without a conv bias and the skip statistics (the Winograd kernel's epilogue applies
+ * the same expression and honours the same liveness words); the bf16 entry points never do. */
 int32_t cpg_conv2d_winograd(const cpg_conv_desc *desc, int32_t pass);
 
 /* Conv forward fused with the statistics pass of the BatchNorm2d that follows it in every CPG topology

@@ -138,6 +138,35 @@ def test_gloo_world2_recreated_piggymasks_stay_hooked(tmp_path):
             assert torch.equal(r0[rnd][n], r1[rnd][n]), 'round %d: piggymask gradient of %s was not all-reduced' % (rnd, n)
 
 
+def _worker_metrics(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from cpg_amd.utils import Metric
+    m = Metric('train_accuracy')
+    # rank 0 sees an easy shard, rank 1 a hard one: the local means straddle the driver's 0.95 bar
+    for acc, num in ((0.99, 4), (0.97, 4)) if rank == 0 else ((0.90, 4), (0.92, 2)):
+        m.update(torch.tensor(acc), num)
+    local = float(m.avg)
+    m.all_reduce_()
+    torch.save({'local': local, 'global': float(m.avg), 'n': float(m.n)}, os.path.join(out_dir, 'metric_rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_metrics_are_global_and_rank_identical(tmp_path):
+    """CPGSession.run_task decides grow / stop-the-sweep on the train accuracy Manager.train returns; under data
+    parallelism that must be the accuracy over the GLOBAL batches (nn.DataParallel's gathered output, utils/manager.py:60),
+    bit-identical on every rank, or the ranks take different branches and their collectives mismatch."""
+    world, port = 2, _free_port()
+    mp.spawn(_worker_metrics, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'metric_rank0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'metric_rank1.pt'))
+    assert r0['local'] > 0.95 > r1['local']                       # local decisions WOULD differ
+    assert r0['global'] == r1['global'] and r0['n'] == r1['n'] == 14.0
+    np.testing.assert_allclose(r0['global'], (0.99 * 4 + 0.97 * 4 + 0.90 * 4 + 0.92 * 2) / 14, rtol=1e-6)
+
+
 def test_seed_per_rank_differs():
     sys.path.insert(0, ROOT)
     from cpg_amd import dist as cdist

@@ -318,8 +318,8 @@ bool ww_plan(const cpg_conv_desc *d, WwPlan &p) {
     // 6 (the first choice) measured 35.25 ms per VGG16 pass against 34.0-34.3 ms for 1, 2 or 4 (the units of a launch are equally
     // long: there is little to balance on an otherwise idle chip).  Not fewer than 4: a launch is only (units per slot) rounds of
     // blocks, and when another stream's kernels (RCCL) hold some CUs a 2-round launch would grow by a whole round.  cpg_amd.dist
-    // asks for 8 when it wraps a model for more than one rank.  CPG_WW_UNITS overrides.
-    int upw = 4;
+    // asks for 8 when it wraps a model for more than one rank (cpg_set_shared_chip_hint).  CPG_WW_UNITS overrides.
+    int upw = shared_chip_hint() ? 8 : 4;
     if (const char *f = getenv("CPG_WW_UNITS")) upw = std::max(1, atoi(f));
     int64_t want = std::max<int64_t>(1, ((int64_t)upw * 4 * kCUs) / npairs);
     want = std::min<int64_t>(want, nstages);
