@@ -83,12 +83,20 @@ struct C3Geom {
     int N, C, H, W, M;        // C: channels of the tensor being read, M: channels being produced
     int Mp;                   // row stride of the packed weights (M rounded up to 128)
     int tiles_x, tiles_y, tiles_m;
+    int OH, OW;               // output map (= H, W for the stride-1 tiles; the strided forward: (H - 1) / 2 + 1)
     int dgrad;                // host side only: which instantiation to launch
     int ksplit;               // 1, or 2: the channel chunks of a tile are shared by two blocks that atomically add into a zeroed y
 };
 
-template <int BM_, int TH_, int TW_, int WM_, int WN_, int CK_, int MINW_, int NIMG_ = 1, int VROWS_ = 0>
+// S2 = 1: the STRIDE-2 forward (3x3, pad 1: ResNet's conv2 of a down-sampling block, SphereNet's conv{s}_1).  TH x TW is the tile of
+// the OUTPUT map; its input patch is (2 TH + 1) x (2 TW + 1), staged with the columns de-interleaved -- a patch row holds its
+// TW + 1 even columns, then its TW odd ones -- so that the B operand of a tap is 32 CONSECUTIVE words for 32 consecutive output
+// columns (a stride-2 read would put two lanes on every LDS bank): tap column s = 0 / 1 / 2 of output column c is slot c,
+// TW + 1 + c, c + 1.  Everything else (weights, k order, MFMA loop, epilogues) is the stride-1 kernel's.
+template <int BM_, int TH_, int TW_, int WM_, int WN_, int CK_, int MINW_, int NIMG_ = 1, int VROWS_ = 0, int S2_ = 0>
 struct C3Cfg {
+    static constexpr int S2 = S2_;
+    static_assert(S2_ == 0 || VROWS_ == 0, "no virtual-row tiles for the strided forward");
     // VROWS > 0 ("virtual rows", for maps that are exactly TH x TW -- smaller than any sensible tile): the rows of ALL images
     // are numbered consecutively (R = n * TH + h) and a tile is VROWS consecutive rows, straddling images.  7 x 7 maps: 32
     // virtual rows x 7 columns = 224 pixels = 7 fragments exactly, where the 14 x 16 single-image tile wastes 78 %.
@@ -101,7 +109,10 @@ struct C3Cfg {
     static constexpr int BN = VROWS ? VROWS * TW : NIMG * TPIX;
     static_assert(WM * WN == 4 && BN % (32 * WN) == 0 && BM % (32 * WM) == 0 && CK % 2 == 0, "bad conv3x3 config");
     static constexpr int FM = BM / 32 / WM, FN = BN / 32 / WN;
-    static constexpr int PH = TH + 2, PW = TW + 2, IPLANE = PH * PW, PLANE = NIMG * IPLANE;
+    static constexpr int PH = S2 ? 2 * TH + 1 : TH + 2, PW = S2 ? 2 * TW + 1 : TW + 2, IPLANE = PH * PW, PLANE = NIMG * IPLANE;
+    static constexpr int RSTEP = S2 ? 2 : 1;                // patch rows per output row
+    // patch offset of tap (r, s) relative to the lane's output pixel
+    static constexpr int tap_off(int tap) { return (tap / 3) * PW + (S2 ? (tap % 3 == 0 ? 0 : tap % 3 == 1 ? TW + 1 : 1) : tap % 3); }
     static constexpr int LDW = BM + 4;                      // +4: rows stay 16-byte aligned for ds_write_b128
     static constexpr int KC = CK * 9;                       // k extent of one chunk
     static constexpr int W4 = BM / 4;                       // float4 per weight row
@@ -115,7 +126,10 @@ struct C3Cfg {
     static constexpr int SMEM_FLOATS = 2 * STAGE;
     static constexpr int NS = CK / 2 * 9;                   // k-steps (of 2 channels x 1 tap) per chunk
     static constexpr int NITEMS = NW4 + NXL;                // staging loads (= staging stores) per thread per chunk
-    static_assert(NITEMS <= NS, "one staging load and one store per k-step at most");
+    // staging items per k-step: 1 for every stride-1 tile; the strided forward's patch is 4x the pixels per output and rides 2 per step
+    static constexpr int IPS = (NITEMS + NS - 1) / NS;
+    static constexpr int LSTEPS = (NITEMS + IPS - 1) / IPS; // k-steps that carry loads (the first LSTEPS) / stores (the last LSTEPS)
+    static_assert(IPS <= 2 && LSTEPS <= NS, "at most two staging loads and two stores per k-step");
 };
 
 // ------------------------------------------------------------------------------ weight pack
@@ -168,6 +182,7 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
                                                            const float *__restrict__ bias, float *__restrict__ y,
                                                            float *__restrict__ stats, C3BnEval bn, C3BnBwd bb) {
     static_assert(!BRED || (DGRAD && !STATS && !SPLITK), "the BatchNorm-backward reduction rides in plain input-gradient launches");
+    static_assert(!Cfg::S2 || (!DGRAD && !SPLITK && !BRED), "the strided tiles are forward-only (its input gradient is k_c3s2_dgrad)");
     __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -217,8 +232,10 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
         const int e = tid + 256 * i;
         const int cl = e / Cfg::PLANE, rem0 = e - cl * Cfg::PLANE;
         const int img = rem0 / Cfg::IPLANE, rem = rem0 - img * Cfg::IPLANE;
-        const int pr = rem / Cfg::PW, pc = rem - pr * Cfg::PW;
-        const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
+        const int pr = rem / Cfg::PW, slot = rem - pr * Cfg::PW;
+        // strided forward: slots 0..TW of a patch row are its even columns, slots TW+1..2TW the odd ones (see C3Cfg)
+        const int pc = Cfg::S2 ? (slot <= Cfg::TW ? 2 * slot : 2 * (slot - Cfg::TW - 1) + 1) : slot;
+        const int gh = Cfg::RSTEP * h0 - 1 + pr, gw = Cfg::RSTEP * w0 - 1 + pc;
         const bool ok = e < Cfg::X_ELEMS && n + img < g.N && (unsigned)gh < (unsigned)g.H && (unsigned)gw < (unsigned)g.W;
         xbyte[i] = ok ? ((img * g.C + cl) * HW + gh * g.W + gw) * 4 : kOutOfRange;
     }
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
     for (int fn = 0; fn < Cfg::FN; ++fn) {
         int img, r, c;
         pixel((wn * Cfg::FN + fn) * 32 + li, img, r, c);
-        b_base[fn] = lh * Cfg::PLANE + img * Cfg::IPLANE + r * Cfg::PW + c;
+        b_base[fn] = lh * Cfg::PLANE + img * Cfg::IPLANE + Cfg::RSTEP * r * Cfg::PW + c;
     }
 
     f32x16 acc[Cfg::FM][Cfg::FN];
@@ -302,7 +319,7 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
             for (int fm = 0; fm < Cfg::FM; ++fm) a[set][fm] = ws[a_base + (2 * p * 9 + tap) * Cfg::LDW + fm * 32];
 #pragma unroll
             for (int fn = 0; fn < Cfg::FN; ++fn)
-                b[set][fn] = xs[b_base[fn] + 2 * p * Cfg::PLANE + (tap / 3) * Cfg::PW + (tap % 3)];
+                b[set][fn] = xs[b_base[fn] + 2 * p * Cfg::PLANE + Cfg::tap_off(tap)];
         };
         lds_operands(0, 0);
 #pragma unroll
@@ -313,20 +330,25 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
 #pragma unroll
                 for (int fn = 0; fn < Cfg::FN; ++fn)
                     acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][fm], b[st & 1][fn], acc[fm][fn], 0, 0, 0);
-            if (st < Cfg::NITEMS) load_item(st, c_next);
-            if (st >= Cfg::NS - Cfg::NITEMS) store_item(st - (Cfg::NS - Cfg::NITEMS), other);
+#pragma unroll
+            for (int j = 0; j < Cfg::IPS; ++j) {
+                const int kl = st * Cfg::IPS + j, ks = (st - (Cfg::NS - Cfg::LSTEPS)) * Cfg::IPS + j;
+                if (st < Cfg::LSTEPS && kl < Cfg::NITEMS) load_item(kl, c_next);
+                if (st >= Cfg::NS - Cfg::LSTEPS && ks < Cfg::NITEMS) store_item(ks, other);
+            }
 #pragma unroll
             for (int i = 0; i < Cfg::FM * Cfg::FN; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                if (i == 1 && st < Cfg::NITEMS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                if (i == 1 && st >= Cfg::NS - Cfg::NITEMS) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                if (i >= 1 && i <= Cfg::IPS && st < Cfg::LSTEPS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (i >= 1 && i <= Cfg::IPS && st >= Cfg::NS - Cfg::LSTEPS) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
         }
         __syncthreads();
     }
 
     // ---- epilogue: D col = pixel (lane & 31), D row = channel ----
+    const int HWo = g.OH * g.OW;                         // (the map being written; = HW except for the strided forward)
     float s1[(STATS || BRED) ? Cfg::FM : 1][16], s2[(STATS || BRED) ? Cfg::FM : 1][16];
     if (STATS || BRED) {
 #pragma unroll
@@ -399,9 +421,9 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
         int img, r, c;
         pixel((wn * Cfg::FN + fn) * 32 + li, img, r, c);
         const int oh = h0 + r, ow = w0 + c;
-        const bool pok = oh < g.H && ow < g.W && n + img < g.N;
-        const int poff = oh * g.W + ow;
-        float *yout = y + (int64_t)(n + img) * g.M * HW;
+        const bool pok = oh < g.OH && ow < g.OW && n + img < g.N;
+        const int poff = oh * g.OW + ow;
+        float *yout = y + (int64_t)(n + img) * g.M * HWo;
 #pragma unroll
         for (int fm = 0; fm < Cfg::FM; ++fm) {
             float bv[16];
@@ -436,8 +458,8 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
                 const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 const float v = acc[fm][fn][e] + bv[e];
                 if (pok && co < g.M) {
-                    if (SPLITK) atomicAdd(&yout[(int64_t)co * HW + poff], v);
-                    else yout[(int64_t)co * HW + poff] = v;
+                    if (SPLITK) atomicAdd(&yout[(int64_t)co * HWo + poff], v);
+                    else yout[(int64_t)co * HWo + poff] = v;
                 }
                 if (STATS && pok) {
                     s1[fm][e] += v;
@@ -484,6 +506,162 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
     }
 }
 
+
+// ------------------------------------------------------------------------------ input gradient of the 3x3 / stride 2 / pad 1 conv
+// gx[n][ci][h][w] = sum_{co, r, s : h = 2 oh + r - 1, w = 2 ow + s - 1} W[co][ci][r][s] * gy[n][co][oh][ow]
+// A position (h, w) = (2 i + a, 2 j + b) only receives the taps with r odd-ness = !a, s odd-ness = !b: class (0,0) one tap, (0,1) and
+// (1,0) two, (1,1) four -- nine taps per 2 x 2 group of gx, the forward's multiply-adds and not one more.  (The generic kernel ran one
+// gather launch per class: 26-43 TFLOP/s.)  Here ONE block computes all four classes of a tile of (i, j): its gy patch
+// (TH + 1) x (TW + 1) (rows i .. i + TH, no flip: tap r = 0 reads row i + 1, r = 1 and r = 2 read row i) is staged once per chunk
+// of CK output channels exactly like k_c3_fwd's, a k-step is (channel pair, tap) and the tap picks which of the lane's four
+// accumulators the MFMA adds to.  The B operand only depends on (r == 0, s == 0): 4 LDS reads serve the 9 taps.  Weights: k_c3_pack's
+// input-gradient layout Wp[(co * 9 + 8 - tap)][ci].  Epilogue: classes (a, 0) and (a, 1) of a lane are neighbours in memory -> one
+// 8-byte store per row.
+template <int BM_, int WM_, int WN_, int TH_, int TW_, int NIMG_>
+struct D2Cfg {
+    static constexpr int BM = BM_, WM = WM_, WN = WN_, TH = TH_, TW = TW_, NIMG = NIMG_, CK = 4;
+    static constexpr int TPIX = TH * TW, BN = NIMG * TPIX;
+    static_assert(WM * WN == 4 && BM == 32 * WM && BN % (32 * WN) == 0, "bad strided-dgrad config");
+    static constexpr int FN = BN / 32 / WN;
+    static constexpr int PH = TH + 1, PW = TW + 1, IPLANE = PH * PW, PLANE = NIMG * IPLANE;
+    static constexpr int LDW = BM + 4, KC = CK * 9, W4 = BM / 4, WROWS = 256 / W4, NW4 = (KC + WROWS - 1) / WROWS;
+    static constexpr int X_ELEMS = CK * PLANE, NXL = (X_ELEMS + 255) / 256;
+    static constexpr int W_ELEMS = NW4 * WROWS * LDW, XS_ELEMS = NXL * 256, STAGE = W_ELEMS + XS_ELEMS, SMEM_FLOATS = 2 * STAGE;
+    static constexpr int NITEMS = NW4 + NXL;
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(256, 2) void k_c3s2_dgrad(C3Geom g, const float *__restrict__ gy, const float *__restrict__ wp,
+                                                       float *__restrict__ gx) {
+    // g: N, C = channels of gy (contracted), H x W = the gy map, M = channels of gx, OH x OW = the gx map
+    __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int li = lane & 31, lh = lane >> 5;
+    unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lb % g.tiles_m; lb /= g.tiles_m;
+    const int tx = lb % g.tiles_x; lb /= g.tiles_x;
+    const int ty = lb % g.tiles_y;
+    const int n = (int)(lb / g.tiles_y) * Cfg::NIMG;
+    const int m0 = tm * Cfg::BM, i0 = ty * Cfg::TH, j0 = tx * Cfg::TW;
+    const int HW = g.H * g.W;
+
+    const int wcol = (tid % Cfg::W4) * 4, wrow0 = tid / Cfg::W4;
+    const int wdst = wrow0 * Cfg::LDW + wcol;
+    const unsigned wbyte = (unsigned)(wrow0 * g.Mp + m0 + wcol) * 4u;
+    constexpr int kOutOfRange = (int)0x80000000;
+    int xbyte[Cfg::NXL];
+#pragma unroll
+    for (int i = 0; i < Cfg::NXL; ++i) {
+        const int e = tid + 256 * i;
+        const int cl = e / Cfg::PLANE, rem0 = e - cl * Cfg::PLANE;
+        const int img = rem0 / Cfg::IPLANE, rem = rem0 - img * Cfg::IPLANE;
+        const int pr = rem / Cfg::PW, pc = rem - pr * Cfg::PW;
+        const int gh = i0 + pr, gw = j0 + pc;
+        const bool ok = e < Cfg::X_ELEMS && n + img < g.N && gh < g.H && gw < g.W;
+        xbyte[i] = ok ? ((img * g.C + cl) * HW + gh * g.W + gw) * 4 : kOutOfRange;
+    }
+    const int nimg_here = min(Cfg::NIMG, g.N - n);
+    const __amdgpu_buffer_rsrc_t srd_x =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(gy + (int64_t)n * g.C * HW), 0, nimg_here * g.C * HW * 4, 0x00020000);
+    f32x4 rw[Cfg::NW4];
+    float rx[Cfg::NXL];
+    auto load_item = [&](int k, int c0) {
+        if (k < Cfg::NW4)
+            rw[k] = ld_sv4(wp + ((int64_t)c0 * 9 + Cfg::WROWS * k) * g.Mp, wbyte);
+        else
+            rx[k - Cfg::NW4] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, xbyte[k - Cfg::NW4] + c0 * HW * 4, 0, 0));
+    };
+    auto store_item = [&](int k, float *stage) {
+        if (k < Cfg::NW4)
+            *reinterpret_cast<f32x4 *>(stage + wdst + Cfg::WROWS * k * Cfg::LDW) = rw[k];
+        else
+            stage[Cfg::W_ELEMS + tid + 256 * (k - Cfg::NW4)] = rx[k - Cfg::NW4];
+    };
+
+    const int a_base = lh * 9 * Cfg::LDW + wm * 32 + li;
+    int b_base[Cfg::FN];
+#pragma unroll
+    for (int fn = 0; fn < Cfg::FN; ++fn) {
+        const int t = (wn * Cfg::FN + fn) * 32 + li;
+        const int img = t / Cfg::TPIX, tt = t % Cfg::TPIX;
+        b_base[fn] = lh * Cfg::PLANE + img * Cfg::IPLANE + (tt / Cfg::TW) * Cfg::PW + tt % Cfg::TW;
+    }
+    f32x16 acc[4][Cfg::FN];                               // [class 2 a + b][pixel fragment]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int fn = 0; fn < Cfg::FN; ++fn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[c][fn][e] = 0.0f;
+
+    const int nch = (g.C + Cfg::CK - 1) / Cfg::CK;
+#pragma unroll
+    for (int k = 0; k < Cfg::NITEMS; ++k) load_item(k, 0);
+#pragma unroll
+    for (int k = 0; k < Cfg::NITEMS; ++k) store_item(k, smem);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const float *ws = smem + (ch & 1) * Cfg::STAGE;
+        const float *xs = ws + Cfg::W_ELEMS;
+        float *other = smem + ((ch + 1) & 1) * Cfg::STAGE;
+        const int c_next = min(ch + 1, nch - 1) * Cfg::CK;
+#pragma unroll
+        for (int k = 0; k < Cfg::NITEMS; ++k) load_item(k, c_next);
+#pragma unroll
+        for (int p = 0; p < Cfg::CK / 2; ++p) {
+            float b[4][Cfg::FN];                           // [2 * (r == 0) + (s == 0)]
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int fn = 0; fn < Cfg::FN; ++fn) b[v][fn] = xs[b_base[fn] + 2 * p * Cfg::PLANE + (v >> 1) * Cfg::PW + (v & 1)];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int tap = 8 - tp, r = tap / 3, q = tap % 3;
+                const int cls = 2 * (r != 1) + (q != 1), v = 2 * (r == 0) + (q == 0);
+                const float a = ws[a_base + (2 * p * 9 + tp) * Cfg::LDW];
+#pragma unroll
+                for (int fn = 0; fn < Cfg::FN; ++fn)
+                    acc[cls][fn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[v][fn], acc[cls][fn], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < Cfg::NITEMS; ++k) store_item(k, other);
+        __syncthreads();
+    }
+
+    // epilogue: lane li = pixel (i, j) of the class grid, rows of D = channels; classes (a, 0) / (a, 1) -> gx[2 i + a][2 j], [2 j + 1]
+    const int HWo = g.OH * g.OW;
+#pragma unroll
+    for (int fn = 0; fn < Cfg::FN; ++fn) {
+        const int t = (wn * Cfg::FN + fn) * 32 + li;
+        const int img = t / Cfg::TPIX, tt = t % Cfg::TPIX;
+        const int i = i0 + tt / Cfg::TW, j = j0 + tt % Cfg::TW;
+        float *out = gx + (int64_t)(n + img) * g.M * HWo;
+        const bool iok = n + img < g.N;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int h = 2 * i + a, w = 2 * j;
+            const bool ok0 = iok && h < g.OH && w < g.OW, ok1 = ok0 && w + 1 < g.OW;
+            const bool pair = ok1 && (g.OW % 2 == 0);      // 8-byte aligned pair
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ci = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (ci >= g.M) continue;
+                float *dst = out + (int64_t)ci * HWo + h * g.OW + w;
+                const float v0 = acc[2 * a + 0][fn][e], v1 = acc[2 * a + 1][fn][e];
+                if (pair) {
+                    *reinterpret_cast<float2 *>(dst) = make_float2(v0, v1);
+                } else {
+                    if (ok0) dst[0] = v0;
+                    if (ok1) dst[1] = v1;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ wgrad
 // D[co][ci](tap) += sum_pix gy[co][pix] * x[ci][pix + tap offset]
 //
@@ -502,15 +680,19 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_c3_fwd(C3Geom g, const float
 // The loads and LDS writes are spread between the MFMAs of a unit (sched_group_barrier), so the chip never sees a
 // staging-only phase: before this, with the block's two waves per SIMD in lock step, wgrad ran at 74-77 % MFMA
 // utilisation against 95 % for the same loop with staging removed (profiles/r01j_*.md).
-template <int TH_, int TW_, bool DB_ = false>
+// S2 = 1: the weight gradient of the 3x3 / STRIDE 2 / pad 1 conv.  TH x TW tiles the gy map (OH x OW); the x patch of a unit is
+// (2 TH + 1) x (2 TW + 1), pixel (r, c) of the tile pairs with patch element (2 r + kh, 2 c + kw): no sliding window (consecutive
+// pixel pairs share no column), nine LDS reads of x per nine MFMAs instead of six.
+template <int TH_, int TW_, bool DB_ = false, int S2_ = 0>
 struct W3Cfg {
     static constexpr bool DB = DB_;                             // two LDS stages: one barrier per unit instead of two
+    static constexpr int S2 = S2_, SS = S2_ ? 2 : 1;
     static constexpr int TH = TH_, TW = TW_, NPIX = TH * TW;
     static_assert(TW % 2 == 0, "pixel pairs must not straddle rows");
     static constexpr int BMC = 64, BCI = 64;                    // block tile: 64 co x 64 ci, 2 x 2 waves
-    static constexpr int PH = TH + 2, PW = TW + 2, PHW = PH * PW;
-    static_assert(PHW % 2 == 0, "the patch plane needs a padding column");
-    static constexpr int PLANE = PHW + 1;                       // odd strides: conflict-free lane = channel reads,
+    static constexpr int PH = S2 ? 2 * TH + 1 : TH + 2, PW = S2 ? 2 * TW + 1 : TW + 2, PHW = PH * PW;
+    static_assert(S2 || PHW % 2 == 0, "the patch plane needs a padding column");
+    static constexpr int PLANE = PHW + 1 + (PHW % 2);           // odd strides: conflict-free lane = channel reads,
     static constexpr int LDG = NPIX + 1;                        // and one padding column per row
     static_assert(PLANE % 2 == 1 && LDG % 2 == 1, "row strides must be odd");
     static constexpr int G_ELEMS = BMC * LDG, X_ELEMS = BCI * PLANE;
@@ -522,8 +704,9 @@ struct W3Cfg {
     static constexpr int NC = TW / 2, NSTEP = TH * NC;                      // pixel-pair steps per row / per unit
 };
 
+// (OH x OW: the gy map -- = H x W for the stride-1 tiles)
 template <class Cfg>
-__global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W, int M, int tiles_x, int tiles_y, int tiles_co,
+__global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W, int M, int OH, int OW, int tiles_x, int tiles_y, int tiles_co,
                                                      int tiles_ci, int units_per_split, const float *__restrict__ x,
                                                      const float *__restrict__ gy, float *__restrict__ part) {
     __shared__ float smem[Cfg::SMEM_FLOATS];
@@ -540,7 +723,7 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
     const int split = (j / tiles) * kXCDs + xcd, tile = j % tiles;
     const int tci = tile % tiles_ci, tco = tile / tiles_ci;
     const int co0 = tco * Cfg::BMC, ci0 = tci * Cfg::BCI;
-    const int HW = H * W;
+    const int HW = H * W, HWg = OH * OW;
     const int units_per_img = tiles_x * tiles_y;
     const int total_units = N * units_per_img;
     const int u0 = min(total_units, split * units_per_split);
@@ -560,7 +743,7 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
     for (int g = 0; g < Cfg::GP; ++g) {
         const int pix = lane + 64 * g, r = pix / Cfg::TW, c = pix % Cfg::TW;
         const bool has = pix < Cfg::NPIX;
-        g_fix[g] = 4 * (r * W + c);                                       // bytes from the tile origin
+        g_fix[g] = 4 * (r * OW + c);                                      // bytes from the tile origin
         g_rc[g] = has ? (unsigned)((r << 8) | c) : 0xFFFFu;
         g_dst[g] = sub * Cfg::LDG + (has ? pix : Cfg::NPIX);              // LDS float index (padding column if none)
     }
@@ -573,7 +756,7 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
         x_dst[g] = Cfg::G_ELEMS + sub * Cfg::PLANE + (has ? q : Cfg::PHW);
     }
     // channel plane offsets (bytes, wave-uniform), clamped to the last channel of the tensor
-    auto g_chan = [&](int i) { return min(sub + 4 * i, M - 1 - co0) * HW * 4; };
+    auto g_chan = [&](int i) { return min(sub + 4 * i, M - 1 - co0) * HWg * 4; };
     auto x_chan = [&](int i) { return min(sub + 4 * i, C - 1 - ci0) * HW * 4; };
 
     // ---- descriptor of the unit being loaded: two buffer resources + per-group byte offsets ----
@@ -583,19 +766,19 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
         const int n = u / units_per_img, rr = u - n * units_per_img;
         const int ty = rr / tiles_x, tx = rr - ty * tiles_x;
         const int h0 = ty * Cfg::TH, w0 = tx * Cfg::TW;
-        srd_g = __builtin_amdgcn_make_buffer_rsrc((void *)(gy + ((int64_t)n * M + co0) * HW), 0, 0x7FFFFFFF, 0x00020000);
+        srd_g = __builtin_amdgcn_make_buffer_rsrc((void *)(gy + ((int64_t)n * M + co0) * HWg), 0, 0x7FFFFFFF, 0x00020000);
         srd_x = __builtin_amdgcn_make_buffer_rsrc((void *)(x + ((int64_t)n * C + ci0) * HW), 0, 0x7FFFFFFF, 0x00020000);
-        const int go = 4 * (h0 * W + w0), xo = 4 * ((h0 - 1) * W + (w0 - 1));
+        const int go = 4 * (h0 * OW + w0), xo = 4 * ((Cfg::SS * h0 - 1) * W + (Cfg::SS * w0 - 1));
 #pragma unroll
         for (int g = 0; g < Cfg::GP; ++g) {
             const int r = g_rc[g] >> 8, c = g_rc[g] & 255;
-            const bool pv = g_rc[g] != 0xFFFFu && h0 + r < H && w0 + c < W;
+            const bool pv = g_rc[g] != 0xFFFFu && h0 + r < OH && w0 + c < OW;
             gv[g] = pv ? go + g_fix[g] : kOutOfRange;
         }
 #pragma unroll
         for (int g = 0; g < Cfg::XP; ++g) {
             const int r = x_rc[g] >> 8, c = x_rc[g] & 255;
-            const int gh = h0 - 1 + r, gw = w0 - 1 + c;
+            const int gh = Cfg::SS * h0 - 1 + r, gw = Cfg::SS * w0 - 1 + c;
             const bool pv = x_rc[g] != 0xFFFFu && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
             xv[g] = pv ? xo + x_fix[g] : kOutOfRange;
         }
@@ -618,13 +801,49 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
     };
 
     const int a_base = (wco * 32 + li) * Cfg::LDG + lh;                                  // gy[co][pix], pix = 2s + lh
-    const int b_base = Cfg::G_ELEMS + (wci * 32 + li) * Cfg::PLANE + lh;                 // x[ci][(r+kh)*PW + c + kw]
+    const int b_base = Cfg::G_ELEMS + (wci * 32 + li) * Cfg::PLANE + Cfg::SS * lh;       // x[ci][(S r + kh) * PW + S c + kw]
 
     // One unit: NSTEP steps of 9 MFMAs.  Sliding window along a row: step c2 needs patch columns 2*c2 + lh + {0,1,2};
     // column +2 of one step is column +0 of the next, so a step reads 1 + 6 new LDS values, one step ahead of the
     // MFMAs that consume them.  Each step also carries its share of the unit's staging: element k's LDS write (two
     // stages: into the other stage; the value was loaded one unit ago) and the buffer load that refills its register.
-    auto unit = [&](const float *cur, float *other, bool stage_writes) {
+    auto unit_s2 = [&](const float *cur, float *other, bool stage_writes) {
+        float a[2], bs[2][3][3];
+        auto rd = [&](int q, int set) {
+            const int r = q / Cfg::NC, c2 = q % Cfg::NC;
+            a[set] = cur[a_base + r * Cfg::TW + 2 * c2];
+            const float *xb = cur + b_base + 2 * r * Cfg::PW + 4 * c2;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) bs[set][kh][kw] = xb[kh * Cfg::PW + kw];
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int q = 0; q < Cfg::NSTEP; ++q) {
+            const int set = q & 1;
+            if (q + 1 < Cfg::NSTEP) rd(q + 1, set ^ 1);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set], bs[set][t / 3][t % 3], acc[t], 0, 0, 0);
+            const int k0 = q * Cfg::NITEMS / Cfg::NSTEP, k1 = (q + 1) * Cfg::NITEMS / Cfg::NSTEP;
+#pragma unroll
+            for (int k = k0; k < k1; ++k) {
+                if (stage_writes) write_item(k, other);
+                load_item(k);
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                if (i < k1 - k0) {
+                    if (stage_writes) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+        }
+    };
+    auto unit_s1 = [&](const float *cur, float *other, bool stage_writes) {
         float a[2], bn[2][3][2], b0[3], b0n[3];
         auto rd = [&](int q, int set) {
             const int r = q / Cfg::NC, c2 = q % Cfg::NC;
@@ -671,6 +890,10 @@ __global__ __launch_bounds__(256, 2) void k_c3_wgrad(int N, int C, int H, int W,
         }
     };
 
+    auto unit = [&](const float *cur, float *other, bool stage_writes) {
+        if constexpr (Cfg::S2) unit_s2(cur, other, stage_writes);
+        else unit_s1(cur, other, stage_writes);
+    };
     if (u0 < u1) {      // (an empty trailing split just writes zeros)
         describe(u0);
 #pragma unroll
@@ -877,8 +1100,8 @@ int launch_fwd(C3Geom g, const float *x, const float *wp, const float *bias, flo
                const C3BnBwd *bbp = nullptr) {
     const C3BnEval bn = bnp ? *bnp : C3BnEval{nullptr, nullptr, nullptr, nullptr, 0.0f, 0, nullptr};
     const C3BnBwd bb = bbp ? *bbp : C3BnBwd{nullptr, nullptr, nullptr, nullptr, nullptr};
-    g.tiles_x = (g.W + Cfg::TW - 1) / Cfg::TW;
-    g.tiles_y = (g.H + Cfg::TH - 1) / Cfg::TH;
+    g.tiles_x = (g.OW + Cfg::TW - 1) / Cfg::TW;           // (tiles cover the OUTPUT map; = the input map for the stride-1 tiles)
+    g.tiles_y = (g.OH + Cfg::TH - 1) / Cfg::TH;
     g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
     const int64_t blocks = Cfg::VROWS ? (int64_t)(((int64_t)g.N * Cfg::TH + Cfg::VROWS - 1) / Cfg::VROWS) * g.tiles_m
                                       : (int64_t)((g.N + Cfg::NIMG - 1) / Cfg::NIMG) * g.tiles_x * g.tiles_y * g.tiles_m;
@@ -887,7 +1110,7 @@ int launch_fwd(C3Geom g, const float *x, const float *wp, const float *bias, flo
     if (dry) return CPG_OK;
     if (g.ksplit > 1) {
         if (stats != nullptr || bnp != nullptr || bbp != nullptr) return fail(CPG_E_UNSUPPORTED, "conv3x3: no fused epilogue on channel-split tiles");
-        hipError_t e = hipMemsetAsync(y, 0, (size_t)g.N * g.M * g.H * g.W * sizeof(float), stream);
+        hipError_t e = hipMemsetAsync(y, 0, (size_t)g.N * g.M * g.OH * g.OW * sizeof(float), stream);
         if (e != hipSuccess) return hip_status(e, what);
         if (g.dgrad)
             hipLaunchKernelGGL((k_c3_fwd<Cfg, true, false, true>), dim3((unsigned)(blocks * g.ksplit)), dim3(256), 0, stream, g, x, wp, bias, y, nullptr, bn, bb);
@@ -958,7 +1181,7 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
         bn_local.live = (bn->live != nullptr && !dry) ? reinterpret_cast<int *>(wp + pack_floats(c_read, m)) : nullptr;
         bn = &bn_local;
     }
-    C3Geom g{N, c_read, H, W, m, Mp, 0, 0, 0, dgrad ? 1 : 0, 1};
+    C3Geom g{N, c_read, H, W, m, Mp, 0, 0, 0, H, W, dgrad ? 1 : 0, 1};
     if (const char *f = getenv("CPG_C3_FORCE")) {        // A/B experiments only (tools/conv_bench.py --ab)
         switch (atoi(f)) {
             case 0: return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
@@ -1095,8 +1318,9 @@ struct W3Plan {
 template <class Cfg>
 W3Plan w3_plan(const cpg_conv_desc *d) {
     W3Plan p;
-    p.tiles_x = (d->W + Cfg::TW - 1) / Cfg::TW;
-    p.tiles_y = (d->H + Cfg::TH - 1) / Cfg::TH;
+    const int OH = (d->H + 2 * d->pad_h - 3) / d->stride_h + 1, OW = (d->W + 2 * d->pad_w - 3) / d->stride_w + 1;   // the gy map
+    p.tiles_x = (OW + Cfg::TW - 1) / Cfg::TW;
+    p.tiles_y = (OH + Cfg::TH - 1) / Cfg::TH;
     p.tiles_co = (d->K + Cfg::BMC - 1) / Cfg::BMC;
     p.tiles_ci = (d->C + Cfg::BCI - 1) / Cfg::BCI;
     const int64_t units = (int64_t)d->N * p.tiles_x * p.tiles_y;
@@ -1156,8 +1380,9 @@ static int w3_launch(const cpg_conv_desc *d, const float *x, const float *gy, co
                      hipStream_t stream) {
     const W3Plan p = w3_plan<Cfg>(d);
     if (ws_bytes < p.ws_bytes) return fail(CPG_E_WORKSPACE, "cpg_conv2d_wgrad(3x3): workspace %zu < %zu bytes", ws_bytes, p.ws_bytes);
+    const int OH = (d->H + 2 * d->pad_h - 3) / d->stride_h + 1, OW = (d->W + 2 * d->pad_w - 3) / d->stride_w + 1;
     hipLaunchKernelGGL(k_c3_wgrad<Cfg>, dim3((unsigned)(p.tiles_co * p.tiles_ci * p.nsplit)), dim3(256), 0, stream, d->N, d->C, d->H,
-                       d->W, d->K, p.tiles_x, p.tiles_y, p.tiles_co, p.tiles_ci, p.units_per_split, x, gy, (float *)ws);
+                       d->W, d->K, OH, OW, p.tiles_x, p.tiles_y, p.tiles_co, p.tiles_ci, p.units_per_split, x, gy, (float *)ws);
     const int64_t out_elems = (int64_t)d->K * d->C * 9;
     launch_split_reduce((const float *)ws, p.nsplit, out_elems, (int64_t)d->K * d->C, ep, stream);
     CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(3x3)");
@@ -1207,4 +1432,130 @@ int cpg_conv3x3_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, c
         case 4: return w3_launch<W3Sev>(d, x, gy, ep, ws, ws_bytes, stream);
         default: return w3_launch<W3Wide>(d, x, gy, ep, ws, ws_bytes, stream);
     }
+}
+
+// ---- the 3x3 / stride 2 / pad 1 class (ResNet: conv2 of the first block of layer2-4; SphereNet: conv{2,3,4}_1) -------------------
+namespace {
+using S2P28 = C3Cfg<128, 4, 28, 4, 1, 4, 2, 2, 0, 1>;   // 28-wide outputs: a 4 x 28 strip of two images, 7 fragments, zero waste
+using S2S16 = C3Cfg<128, 14, 16, 4, 1, 4, 2, 1, 0, 1>;  // <= 16-wide outputs (14 x 14): one image
+using S2M8 = C3Cfg<128, 8, 8, 4, 1, 4, 2, 2, 0, 1>;     // <= 8-wide outputs (7 x 7): two images of 8 x 8 = 4 fragments (four would not leave LDS for a second block)
+using S2G128 = C3Cfg<128, 4, 32, 2, 2, 4, 2, 1, 0, 1>;  // anything else
+using S2G64 = C3Cfg<64, 8, 32, 1, 4, 4, 2, 1, 0, 1>;    // ... with <= 64 output channels
+
+template <class Cfg>
+int launch_fwd_s2(C3Geom g, const float *x, const float *wp, const float *bias, float *y, hipStream_t stream, float *stats,
+                  int *tiles_out, bool dry, const C3BnEval *bnp) {
+    const C3BnEval bn = bnp ? *bnp : C3BnEval{nullptr, nullptr, nullptr, nullptr, 0.0f, 0, nullptr};
+    const C3BnBwd bb{nullptr, nullptr, nullptr, nullptr, nullptr};
+    g.tiles_x = (g.OW + Cfg::TW - 1) / Cfg::TW;
+    g.tiles_y = (g.OH + Cfg::TH - 1) / Cfg::TH;
+    g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
+    const int64_t blocks = (int64_t)((g.N + Cfg::NIMG - 1) / Cfg::NIMG) * g.tiles_x * g.tiles_y * g.tiles_m;
+    if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "conv3x3 s2: grid too large");
+    if (tiles_out) *tiles_out = (int)(blocks / g.tiles_m);
+    if (dry) return CPG_OK;
+    if (stats != nullptr)
+        hipLaunchKernelGGL((k_c3_fwd<Cfg, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, stats, bn, bb);
+    else
+        hipLaunchKernelGGL((k_c3_fwd<Cfg, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, nullptr, bn, bb);
+    CPG_CHECK_LAUNCH("cpg_conv2d_fwd(3x3 s2)");
+    return CPG_OK;
+}
+
+inline int s2_out(int v) { return (v - 1) / 2 + 1; }
+
+int run_fwd_s2(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias, float *y, void *ws,
+               size_t ws_bytes, hipStream_t stream, float *stats, int *tiles_out, bool dry) {
+    const char *what = "cpg_conv2d_fwd(3x3 s2)";
+    const int OH = s2_out(d->H), OW = s2_out(d->W);
+    float *wp = (float *)ws;
+    const int rows_c = pad_to(d->C, 4), Mp = pad_to(d->K, 128);
+    if (!dry) {
+        const size_t need = pack_bytes(d->C, d->K);
+        if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
+        CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
+        hipLaunchKernelGGL(k_c3_pack, dim3(stream_grid((int64_t)rows_c * 9 * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, d->K, d->C,
+                           rows_c, Mp, 0, (int *)nullptr);
+    }
+    C3Geom g{d->N, d->C, d->H, d->W, d->K, Mp, 0, 0, 0, OH, OW, 0, 1};
+    if (OW == 28 && OH % 4 == 0 && d->K > 64) return launch_fwd_s2<S2P28>(g, x, wp, bias, y, stream, stats, tiles_out, dry, nullptr);
+    if (OW <= 8 && OH <= 8 && d->K > 64) return launch_fwd_s2<S2M8>(g, x, wp, bias, y, stream, stats, tiles_out, dry, nullptr);
+    if (OW <= 16 && OH <= 16 && d->K > 64) return launch_fwd_s2<S2S16>(g, x, wp, bias, y, stream, stats, tiles_out, dry, nullptr);
+    if (d->K <= 64) return launch_fwd_s2<S2G64>(g, x, wp, bias, y, stream, stats, tiles_out, dry, nullptr);
+    return launch_fwd_s2<S2G128>(g, x, wp, bias, y, stream, stats, tiles_out, dry, nullptr);
+}
+
+//                  BM  WM WN TH TW NIMG
+using D2a = D2Cfg<128, 4, 1, 4, 16, 1>;      // class grids >= 17 wide (gx 56 x 56 -> 28 x 28 classes)
+using D2b = D2Cfg<128, 4, 1, 2, 16, 2>;      // class grids <= 16 wide (gx 28 x 28 -> 14 x 14): two rows of two images, no row waste
+using D2c = D2Cfg<128, 4, 1, 1, 8, 8>;       // class grids <= 8 wide (gx 14 x 14 -> 7 x 7): one row of eight images
+using D2a64 = D2Cfg<64, 2, 2, 4, 16, 1>;     // the same for <= 64 input channels
+using D2b64 = D2Cfg<64, 2, 2, 2, 16, 2>;
+using D2c64 = D2Cfg<64, 2, 2, 1, 8, 8>;
+
+template <class Cfg>
+int launch_dgrad_s2(C3Geom g, const float *gy, const float *wp, float *gx, hipStream_t stream) {
+    const int GH = (g.OH + 1) / 2, GW = (g.OW + 1) / 2;           // the class grid (i, j) = (h >> 1, w >> 1)
+    g.tiles_x = (GW + Cfg::TW - 1) / Cfg::TW;
+    g.tiles_y = (GH + Cfg::TH - 1) / Cfg::TH;
+    g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
+    const int64_t blocks = (int64_t)((g.N + Cfg::NIMG - 1) / Cfg::NIMG) * g.tiles_x * g.tiles_y * g.tiles_m;
+    if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "conv3x3 s2 dgrad: grid too large");
+    hipLaunchKernelGGL(k_c3s2_dgrad<Cfg>, dim3((unsigned)blocks), dim3(256), 0, stream, g, gy, wp, gx);
+    CPG_CHECK_LAUNCH("cpg_conv2d_dgrad(3x3 s2)");
+    return CPG_OK;
+}
+
+using W3S2a = W3Cfg<2, 14, false, 1>;        // gy maps 14 / 28 / 56 wide
+using W3S2b = W3Cfg<4, 8, false, 1>;         // everything else (7 x 7: 8-wide tiles)
+}  // namespace
+
+extern "C" int cpg_conv3x3s2_supported(const cpg_conv_desc *d) {
+    if (getenv("CPG_DISABLE_CONV3X3") || getenv("CPG_NO_S2")) return 0;
+    return d->R == 3 && d->S == 3 && d->stride_h == 2 && d->stride_w == 2 && d->pad_h == 1 && d->pad_w == 1 && d->dil_h == 1 &&
+           d->dil_w == 1 && d->groups == 1 && d->N > 0 && d->C >= 16 && d->K >= 16 && d->H > 1 && d->W > 1 &&
+           (int64_t)d->C * d->H * d->W < (1ll << 27) && (int64_t)d->K * d->H * d->W < (1ll << 27) && (int64_t)d->H * d->W <= (1ll << 22);
+}
+size_t cpg_conv3x3s2_pack_workspace(const cpg_conv_desc *d) { return std::max(pack_bytes(d->C, d->K), pack_bytes(d->K, d->C)) + 16; }
+int cpg_conv3x3s2_bnstats_tiles(const cpg_conv_desc *d) {
+    int tiles = 0;
+    if (run_fwd_s2(d, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, 0, nullptr, nullptr, &tiles, true) != CPG_OK) return 0;
+    return tiles;
+}
+int cpg_conv3x3s2_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias, float *y,
+                      float *stats, void *ws, size_t ws_bytes, hipStream_t stream) {
+    CPG_REQUIRE(x && w && y, "cpg_conv2d_fwd: null pointer");
+    return run_fwd_s2(d, x, w, pm, thr, bias, y, ws, ws_bytes, stream, stats, nullptr, false);
+}
+int cpg_conv3x3s2_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx, void *ws,
+                        size_t ws_bytes, hipStream_t stream) {
+    CPG_REQUIRE(gy && w && gx, "cpg_conv2d_dgrad: null pointer");
+    const char *what = "cpg_conv2d_dgrad(3x3 s2)";
+    const int OH = s2_out(d->H), OW = s2_out(d->W);
+    float *wp = (float *)ws;
+    const int rows_c = pad_to(d->K, 4), Mp = pad_to(d->C, 128);
+    const size_t need = pack_bytes(d->K, d->C);
+    if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
+    hipLaunchKernelGGL(k_c3_pack, dim3(stream_grid((int64_t)rows_c * 9 * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, d->K, d->C,
+                       rows_c, Mp, 1, (int *)nullptr);
+    // reads gy (K channels, OH x OW), produces gx (C channels, H x W)
+    C3Geom g{d->N, d->K, OH, OW, d->C, Mp, 0, 0, 0, d->H, d->W, 1, 1};
+    const int GW = (d->W + 1) / 2;
+    if (d->C <= 64) {
+        if (GW <= 8) return launch_dgrad_s2<D2c64>(g, gy, wp, gx, stream);
+        if (GW <= 16) return launch_dgrad_s2<D2b64>(g, gy, wp, gx, stream);
+        return launch_dgrad_s2<D2a64>(g, gy, wp, gx, stream);
+    }
+    if (GW <= 8) return launch_dgrad_s2<D2c>(g, gy, wp, gx, stream);
+    if (GW <= 16) return launch_dgrad_s2<D2b>(g, gy, wp, gx, stream);
+    return launch_dgrad_s2<D2a>(g, gy, wp, gx, stream);
+}
+static inline bool s2_wide(const cpg_conv_desc *d) { return s2_out(d->W) % 14 == 0; }
+size_t cpg_conv3x3s2_wgrad_workspace(const cpg_conv_desc *d) {
+    return s2_wide(d) ? w3_plan<W3S2a>(d).ws_bytes : w3_plan<W3S2b>(d).ws_bytes;
+}
+int cpg_conv3x3s2_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr, float *gw,
+                        float *gpm, void *ws, size_t ws_bytes, hipStream_t stream) {
+    Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
+    return s2_wide(d) ? w3_launch<W3S2a>(d, x, gy, ep, ws, ws_bytes, stream) : w3_launch<W3S2b>(d, x, gy, ep, ws, ws_bytes, stream);
 }

@@ -541,6 +541,17 @@ extern "C" int cpg_conv1x1_wgrad_supported(const cpg_conv_desc *d);
 size_t cpg_conv1x1_wgrad_workspace(const cpg_conv_desc *d);
 int cpg_conv1x1_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
                       float *gw, float *gpm, void *ws, size_t ws_bytes, hipStream_t stream);
+// ... the 3x3 / stride 2 / pad 1 class (conv3x3.hip: k_c3_fwd's strided tiles, k_c3s2_dgrad, k_c3_wgrad's strided units)
+extern "C" int cpg_conv3x3s2_supported(const cpg_conv_desc *d);
+size_t cpg_conv3x3s2_pack_workspace(const cpg_conv_desc *d);
+int cpg_conv3x3s2_bnstats_tiles(const cpg_conv_desc *d);
+int cpg_conv3x3s2_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias, float *y,
+                      float *stats, void *ws, size_t ws_bytes, hipStream_t stream);
+int cpg_conv3x3s2_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx, void *ws,
+                        size_t ws_bytes, hipStream_t stream);
+size_t cpg_conv3x3s2_wgrad_workspace(const cpg_conv_desc *d);
+int cpg_conv3x3s2_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr, float *gw,
+                        float *gpm, void *ws, size_t ws_bytes, hipStream_t stream);
 static inline bool use_c3_wgrad(const cpg_conv_desc *d) { return cpg_conv3x3_supported(d) && (d->C >= 16 || d->C <= 3); }
 
 extern "C" size_t cpg_conv2d_workspace_bytes(const cpg_conv_desc *d) {
@@ -549,6 +560,7 @@ extern "C" size_t cpg_conv2d_workspace_bytes(const cpg_conv_desc *d) {
     size_t pack = cpg_conv3x3_supported(d) ? cpg_conv3x3_pack_workspace(d) : cpg_conv1x1_supported(d) ? cpg_conv1x1_pack_workspace(d) : 0;
     pack = std::max(pack, bias_ws_bytes(g.N, g.K));          // the bias gradient's partial sums reuse the workspace
     if (use_c3_wgrad(d)) return std::max(pack, cpg_conv3x3_wgrad_workspace(d));
+    if (cpg_conv3x3s2_supported(d)) return std::max(std::max(pack, cpg_conv3x3s2_pack_workspace(d)), cpg_conv3x3s2_wgrad_workspace(d));
     if (cpg_conv1x1_wgrad_supported(d)) return std::max(pack, cpg_conv1x1_wgrad_workspace(d));
     int tm, tn, nsplit, per;
     conv_wgrad_tiles<CfgA>(g, tm, tn);
@@ -640,11 +652,13 @@ extern "C" int cpg_conv2d_fwd(const cpg_conv_desc *d, const float *x, const floa
                               const float *bias, float *y, void *ws, size_t ws_bytes, void *stream) {
     if (d && cpg_conv3x3_supported(d)) return cpg_conv3x3_fwd(d, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream);
     if (d && cpg_conv1x1_supported(d)) return cpg_conv1x1_fwd(d, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream);
+    if (d && cpg_conv3x3s2_supported(d)) return cpg_conv3x3s2_fwd(d, x, w, pm, thr, bias, y, nullptr, ws, ws_bytes, (hipStream_t)stream);
     return cpg_conv2d_fwd_generic(d, x, w, pm, thr, bias, y, stream);
 }
 
 // Forward that also emits the BatchNorm partial sums of its output (3x3 s1 p1 shapes; 0 tiles = not available).
 extern "C" int32_t cpg_conv2d_bnstats_tiles(const cpg_conv_desc *d) {
+    if (d && cpg_conv3x3s2_supported(d)) return cpg_conv3x3s2_bnstats_tiles(d);
     return (d && cpg_conv3x3_supported(d)) ? cpg_conv3x3_bnstats_tiles(d) : 0;
 }
 extern "C" int cpg_conv2d_fwd_bnstats(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr,
@@ -655,6 +669,7 @@ extern "C" int cpg_conv2d_fwd_bnstats(const cpg_conv_desc *d, const float *x, co
     const size_t need = (size_t)d->K * tiles * 2 * sizeof(float);
     if (stats == nullptr || stats_bytes < need)
         return fail(CPG_E_WORKSPACE, "cpg_conv2d_fwd_bnstats: statistics buffer %zu < %zu bytes", stats_bytes, need);
+    if (cpg_conv3x3s2_supported(d)) return cpg_conv3x3s2_fwd(d, x, w, pm, thr, bias, y, stats, ws, ws_bytes, (hipStream_t)stream);
     return cpg_conv3x3_fwd_bnstats(d, x, w, pm, thr, bias, y, stats, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -708,6 +723,7 @@ extern "C" int cpg_conv2d_dgrad(const cpg_conv_desc *d, const float *gy, const f
                                 float *gx, void *ws, size_t ws_bytes, void *stream) {
     if (d && cpg_conv3x3_supported(d)) return cpg_conv3x3_dgrad(d, gy, w, pm, thr, gx, ws, ws_bytes, (hipStream_t)stream);
     if (d && cpg_conv1x1_supported(d)) return cpg_conv1x1_dgrad(d, gy, w, pm, thr, gx, ws, ws_bytes, (hipStream_t)stream);
+    if (d && cpg_conv3x3s2_supported(d)) return cpg_conv3x3s2_dgrad(d, gy, w, pm, thr, gx, ws, ws_bytes, (hipStream_t)stream);
     return cpg_conv2d_dgrad_generic(d, gy, w, pm, thr, gx, stream);
 }
 
@@ -724,6 +740,13 @@ extern "C" int cpg_conv2d_wgrad(const cpg_conv_desc *d, const float *x, const fl
     hipStream_t stream = (hipStream_t)stream_v;
     if (use_c3_wgrad(d)) {
         rc = cpg_conv3x3_wgrad(d, x, gy, w, pm, thr, gw, gpm, ws, ws_bytes, stream);
+        if (rc) return rc;
+        if (gb) launch_conv_bias_grad(gy, gb, g.N, g.K, g.OH * g.OW, ws, stream);
+        CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(bias)");
+        return CPG_OK;
+    }
+    if (cpg_conv3x3s2_supported(d)) {
+        rc = cpg_conv3x3s2_wgrad(d, x, gy, w, pm, thr, gw, gpm, ws, ws_bytes, stream);
         if (rc) return rc;
         if (gb) launch_conv_bias_grad(gy, gb, g.N, g.K, g.OH * g.OW, ws, stream);
         CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(bias)");

@@ -133,7 +133,13 @@ def test_linear_golden(name):
     (1, 8, 20, 20, 8, 5, 3, 2, True, False),         # stride 3, 5x5: nine residue classes with 1..4 taps
     (2, 8, 9, 9, 8, 1, 2, 0, False, False),          # 1x1 s2 on the generic kernel: three classes have no taps (zero fill)
     (2, 130, 12, 12, 70, 3, 2, 1, False, False),     # strided dgrad, > 64 input channels (128-wide tile), ragged channels
-    (2, 64, 56, 56, 64, 3, 2, 1, True, False),       # SphereNet stride-2 with bias
+    (2, 64, 56, 56, 64, 3, 2, 1, True, False),       # SphereNet stride-2 with bias: <= 64-channel strided tiles, 28-wide class grid
+    (3, 128, 56, 56, 128, 3, 2, 1, False, True),     # ResNet layer2 stride-2: two-image 4x28 output strips (odd image count), piggymask
+    (5, 96, 28, 28, 136, 3, 2, 1, True, False),      # 14x14 outputs: whole-image strided tile, two-image class-grid tiles, bias
+    (9, 64, 14, 14, 160, 3, 2, 1, False, True),      # 7x7 outputs: two-image 8x8 tiles; class grid: one row of eight images (9 images)
+    (3, 160, 14, 14, 72, 3, 2, 1, False, False),     # the same with > 64 input channels in the input gradient
+    (2, 32, 33, 70, 200, 3, 2, 1, True, True),       # odd map, 35-wide outputs: the general strided tiles
+    (1, 16, 2, 2, 16, 3, 2, 1, False, False),        # 2x2 -> 1x1
 ])
 def test_conv_oracle(N, C, H, W, K, k, s, p, bias, pm):
     g = torch.Generator().manual_seed(N * 1000 + C + K)
@@ -1505,9 +1511,19 @@ def test_conv_epilogue_bn_statistics(N, C, K, H, W, pool):
     """conv -> BatchNorm2d -> ReLU (-> MaxPool) in train mode with the statistics accumulated in the conv epilogue
     (cpg_conv2d_fwd_bnstats + cpg_bn_stats_finalize) against the separate statistics pass: output, running statistics,
     input and parameter gradients; every tile configuration of the forward kernel."""
+    _bn_statistics_case(N, C, K, H, W, pool, 1)
+
+
+@pytest.mark.parametrize('N,C,K,H,W', [(3, 128, 128, 56, 56), (5, 96, 136, 28, 28), (5, 64, 160, 14, 14), (2, 32, 48, 33, 70), (2, 32, 200, 33, 70)])
+def test_strided_conv_epilogue_bn_statistics(N, C, K, H, W):
+    """the same for the 3x3 / stride 2 forward tiles (ResNet: conv2 -> bn2 of a down-sampling block, models/resnet.py:9,88-90)"""
+    _bn_statistics_case(N, C, K, H, W, False, 2)
+
+
+def _bn_statistics_case(N, C, K, H, W, pool, stride):
     from cpg_amd.models import fused_bn
     torch.manual_seed(N * 10 + K)
-    mods = [nl.SharableConv2d(C, K, 3, padding=1, bias=False), nn.BatchNorm2d(K), nn.ReLU(inplace=True)]
+    mods = [nl.SharableConv2d(C, K, 3, stride=stride, padding=1, bias=False), nn.BatchNorm2d(K), nn.ReLU(inplace=True)]
     if pool:
         mods.append(nn.MaxPool2d(2, 2))
     seq = fused_bn.FusedSequential(*mods)
