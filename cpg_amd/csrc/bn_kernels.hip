@@ -180,11 +180,15 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const float *__restrict__
 }
 
 // grid (C, slices): partial[c][slice] = {sum g, sum g*xhat}
-template <bool RELU>
+// MASKY (the tail of a residual block, out = relu(bn(x) + identity)): the ReLU mask cannot be recomputed from x alone, so it is
+// taken from the saved output (`out > 0`), and the masked gradient gz = g * [out > 0] -- which is also the identity branch's
+// gradient -- is WRITTEN here, so that neither a separate threshold pass nor a second read of `out` in the apply pass is needed.
+template <bool RELU, bool MASKY = false>
 __global__ __launch_bounds__(kThreads) void k_bn_bwd_reduce(const float *__restrict__ x, const float *__restrict__ gy, BnDims d,
                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                            double *__restrict__ partial) {
+                                                            double *__restrict__ partial, const float *__restrict__ out = nullptr,
+                                                            float *__restrict__ gz = nullptr) {
     __shared__ double red[4];
     const int c = blockIdx.x, s = blockIdx.y;
     const int n0 = s * d.imgs_per_slice, n1 = min(d.N, n0 + d.imgs_per_slice);
@@ -200,7 +204,27 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_reduce(const float *__restr
     auto flush = [&]() {
         dsg += (double)sg; dsgx += (double)sgx; sg = 0.f; sgx = 0.f;
     };
-    if (vec)
+    if (MASKY) {
+        const bool vec3 = vec && (((uintptr_t)out) & 15) == 0 && (((uintptr_t)gz) & 15) == 0;
+        if (vec3)
+            walk_planes(d.HW >> 2, n0, n1, [&](int n, int j) {
+                const int64_t off = ((int64_t)n * d.C + c) * d.HW + 4 * j;
+                const float4 xv = *reinterpret_cast<const float4 *>(x + off);
+                float4 gv = *reinterpret_cast<const float4 *>(gy + off);
+                const float4 ov = *reinterpret_cast<const float4 *>(out + off);
+                gv.x = ov.x > 0.f ? gv.x : 0.f; gv.y = ov.y > 0.f ? gv.y : 0.f;
+                gv.z = ov.z > 0.f ? gv.z : 0.f; gv.w = ov.w > 0.f ? gv.w : 0.f;
+                *reinterpret_cast<float4 *>(gz + off) = gv;
+                visit(xv.x, gv.x); visit(xv.y, gv.y); visit(xv.z, gv.z); visit(xv.w, gv.w);
+            }, flush);
+        else
+            walk_planes(d.HW, n0, n1, [&](int n, int j) {
+                const int64_t off = ((int64_t)n * d.C + c) * d.HW + j;
+                const float gv = out[off] > 0.f ? gy[off] : 0.f;
+                gz[off] = gv;
+                visit(x[off], gv);
+            }, flush);
+    } else if (vec)
         walk_planes(d.HW >> 2, n0, n1, [&](int n, int j) {
             const int64_t off = ((int64_t)n * d.C + c) * d.HW + 4 * j;
             const float4 xv = *reinterpret_cast<const float4 *>(x + off);
@@ -490,6 +514,30 @@ extern "C" int cpg_bn_relu_bwd(const float *x, const float *gy, const float *gam
     else if (train) launch_bwd_apply<false, true>(d, x, gy, gx, mean, invstd, gamma, beta, coef, stream);
     else launch_bwd_apply<false, false>(d, x, gy, gx, mean, invstd, gamma, beta, coef, stream);
     CPG_CHECK_LAUNCH("cpg_bn_relu_bwd");
+    return CPG_OK;
+}
+
+// backward of out = relu(bn(x) + res) (cpg_bn_add_relu_fwd; models/resnet.py:62-71,96-104): gz = gy * [out > 0] is the gradient of
+// the residual branch AND of bn(x); one pass reads x, gy, out, writes gz and reduces {sum gz, sum gz * xhat}, the second applies
+// the BatchNorm gradient from x and gz -- 7 activation passes where threshold_backward + cpg_bn_relu_bwd made 8 (and one launch
+// of a stock elementwise kernel less).  gz may alias gy.
+extern "C" int cpg_bn_add_relu_bwd(const float *x, const float *out, const float *gy, const float *gamma, const float *beta,
+                                   const float *mean, const float *invstd, float *gx, float *gz, float *dgamma, float *dbeta, int32_t N,
+                                   int32_t C, int32_t HW, int32_t train, void *ws, size_t ws_bytes, void *stream_v) {
+    BnDims d;
+    int rc = make_dims(N, C, HW, d);
+    if (rc) return rc;
+    CPG_REQUIRE(x && out && gy && gamma && beta && mean && invstd && gx && gz && dgamma && dbeta && ws, "cpg_bn_add_relu_bwd: null pointer");
+    if (ws_bytes < cpg_bn_workspace_bytes(N, C, HW)) return fail(CPG_E_WORKSPACE, "cpg_bn_add_relu_bwd: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_v;
+    double *partial = (double *)ws;
+    float *coef = (float *)(partial + (size_t)C * d.slices * 2);
+    hipLaunchKernelGGL((k_bn_bwd_reduce<false, true>), dim3(C, d.slices), dim3(kThreads), 0, stream, x, gy, d, mean, invstd, gamma, beta,
+                       partial, out, gz);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 63) / 64), dim3(64), 0, stream, partial, d, dgamma, dbeta, coef);
+    if (train) launch_bwd_apply<false, true>(d, x, gz, gx, mean, invstd, gamma, beta, coef, stream);
+    else launch_bwd_apply<false, false>(d, x, gz, gx, mean, invstd, gamma, beta, coef, stream);
+    CPG_CHECK_LAUNCH("cpg_bn_add_relu_bwd");
     return CPG_OK;
 }
 

@@ -534,7 +534,8 @@ int cpg_conv3x3_dgrad_bnbwd(const cpg_conv_desc *d, const float *gy, const float
 extern "C" int cpg_conv1x1_supported(const cpg_conv_desc *d);
 size_t cpg_conv1x1_pack_workspace(const cpg_conv_desc *d);
 int cpg_conv1x1_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
-                    float *y, void *ws, size_t ws_bytes, hipStream_t stream);
+                    float *y, void *ws, size_t ws_bytes, hipStream_t stream, float *stats = nullptr);
+int cpg_conv1x1_bnstats_tiles(const cpg_conv_desc *d);
 int cpg_conv1x1_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx, void *ws,
                       size_t ws_bytes, hipStream_t stream);
 extern "C" int cpg_conv1x1_wgrad_supported(const cpg_conv_desc *d);
@@ -659,6 +660,7 @@ extern "C" int cpg_conv2d_fwd(const cpg_conv_desc *d, const float *x, const floa
 // Forward that also emits the BatchNorm partial sums of its output (3x3 s1 p1 shapes; 0 tiles = not available).
 extern "C" int32_t cpg_conv2d_bnstats_tiles(const cpg_conv_desc *d) {
     if (d && cpg_conv3x3s2_supported(d)) return cpg_conv3x3s2_bnstats_tiles(d);
+    if (d && !cpg_conv3x3_supported(d) && cpg_conv1x1_supported(d)) return cpg_conv1x1_bnstats_tiles(d);
     return (d && cpg_conv3x3_supported(d)) ? cpg_conv3x3_bnstats_tiles(d) : 0;
 }
 extern "C" int cpg_conv2d_fwd_bnstats(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr,
@@ -670,6 +672,7 @@ extern "C" int cpg_conv2d_fwd_bnstats(const cpg_conv_desc *d, const float *x, co
     if (stats == nullptr || stats_bytes < need)
         return fail(CPG_E_WORKSPACE, "cpg_conv2d_fwd_bnstats: statistics buffer %zu < %zu bytes", stats_bytes, need);
     if (cpg_conv3x3s2_supported(d)) return cpg_conv3x3s2_fwd(d, x, w, pm, thr, bias, y, stats, ws, ws_bytes, (hipStream_t)stream);
+    if (!cpg_conv3x3_supported(d)) return cpg_conv1x1_fwd(d, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream, stats);
     return cpg_conv3x3_fwd_bnstats(d, x, w, pm, thr, bias, y, stats, ws, ws_bytes, (hipStream_t)stream);
 }
 

@@ -82,9 +82,14 @@ __global__ __launch_bounds__(256) void k_pw_pack(const float *__restrict__ w, co
     }
 }
 
-template <class Cfg, bool DGRAD>
+// STATS (forward only): the block also writes, per output channel, the sum and the sum of squares of its 224 outputs ->
+// stats[channel][pixel tile][2], the partial sums of the training-mode BatchNorm2d that follows every pointwise conv of the
+// ResNet topologies (models/resnet.py:86-98) -- cpg_bn_stats_finalize merges them, no statistics pass over y (cf. k_c3_fwd).
+template <class Cfg, bool DGRAD, bool STATS = false>
 __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__restrict__ x, const float *__restrict__ wp,
-                                                       const float *__restrict__ bias, float *__restrict__ y) {
+                                                       const float *__restrict__ bias, float *__restrict__ y,
+                                                       float *__restrict__ stats = nullptr) {
+    static_assert(!STATS || (!DGRAD && Cfg::WN == 1), "statistics ride in forward launches whose waves own whole channel rows");
     __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -203,6 +208,13 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
     }
 
     // ---- epilogue: D col = grid position (lane & 31), D row = channel ----
+    float s1[STATS ? Cfg::FM : 1][16], s2[STATS ? Cfg::FM : 1][16];
+    if (STATS) {
+#pragma unroll
+        for (int fm = 0; fm < Cfg::FM; ++fm)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s1[fm][e] = s2[fm][e] = 0.0f;
+    }
 #pragma unroll
     for (int fn = 0; fn < Cfg::FN; ++fn) {
         const long long gg = g0 + (wn * Cfg::FN + fn) * 32 + li;
@@ -224,7 +236,34 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (pok && co < g.M) yout[(int64_t)co * g.out_plane] = acc[fm][fn][e] + bv[e];
+                const float v = acc[fm][fn][e] + bv[e];
+                if (pok && co < g.M) yout[(int64_t)co * g.out_plane] = v;
+                if (STATS && pok) {
+                    s1[fm][e] += v;
+                    s2[fm][e] += v * v;
+                }
+            }
+        }
+    }
+    if (STATS) {
+        // sum over the 32 pixel lanes of each half-wave (DPP adds; valid in lanes 16-31 / 48-63); WN == 1: the wave owns its rows
+        const unsigned ntiles = gridDim.x / g.tiles_m, tile_n = xcd_remap(blockIdx.x, gridDim.x) / g.tiles_m;
+#pragma unroll
+        for (int fm = 0; fm < Cfg::FM; ++fm) {
+            half_wave_sum8(&s1[fm][0]);
+            half_wave_sum8(&s1[fm][8]);
+            half_wave_sum8(&s2[fm][0]);
+            half_wave_sum8(&s2[fm][8]);
+            if (li == 31) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (co < g.M) {
+                        float *dst = stats + ((int64_t)co * ntiles + tile_n) * 2;
+                        dst[0] = s1[fm][e];
+                        dst[1] = s2[fm][e];
+                    }
+                }
             }
         }
     }
@@ -420,11 +459,19 @@ inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 inline size_t pack_bytes(int c_read, int m) { return ((size_t)pad_to(c_read, 16) + 16) * pad_to(m, 128) * sizeof(float); }
 
 template <class Cfg, bool DGRAD>
-int launch(PwGeom g, const float *x, const float *wp, const float *bias, float *y, hipStream_t stream, const char *what) {
+int launch(PwGeom g, const float *x, const float *wp, const float *bias, float *y, hipStream_t stream, const char *what,
+           float *stats = nullptr) {
     g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
     const int64_t blocks = (g.G + Cfg::BN - 1) / Cfg::BN * g.tiles_m;
     if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "conv1x1: grid too large");
-    hipLaunchKernelGGL((k_pw<Cfg, DGRAD>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y);
+    if constexpr (!DGRAD) {
+        if (stats != nullptr) {
+            hipLaunchKernelGGL((k_pw<Cfg, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, stats);
+            CPG_CHECK_LAUNCH(what);
+            return CPG_OK;
+        }
+    }
+    hipLaunchKernelGGL((k_pw<Cfg, DGRAD>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, (float *)nullptr);
     CPG_CHECK_LAUNCH(what);
     return CPG_OK;
 }
@@ -445,8 +492,14 @@ extern "C" int cpg_conv1x1_supported(const cpg_conv_desc *d) {
 
 size_t cpg_conv1x1_pack_workspace(const cpg_conv_desc *d) { return std::max(pack_bytes(d->C, d->K), pack_bytes(d->K, d->C)); }
 
+// pixel tiles of the forward launch = rows of the [K][tiles][2] statistics buffer of cpg_conv2d_fwd_bnstats
+int cpg_conv1x1_bnstats_tiles(const cpg_conv_desc *d) {
+    const int OH = (d->H - 1) / d->stride_h + 1, OW = (d->W - 1) / d->stride_w + 1;
+    return (int)(((int64_t)d->N * OH * OW + PwV::BN - 1) / PwV::BN);
+}
+
 int cpg_conv1x1_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
-                    float *y, void *ws, size_t ws_bytes, hipStream_t stream) {
+                    float *y, void *ws, size_t ws_bytes, hipStream_t stream, float *stats) {
     const char *what = "cpg_conv2d_fwd(1x1)";
     CPG_REQUIRE(x && w && y, "%s: null pointer", what);
     const size_t need = pack_bytes(d->C, d->K);
@@ -458,8 +511,9 @@ int cpg_conv1x1_fwd(const cpg_conv_desc *d, const float *x, const float *w, cons
     const int OH = (d->H - 1) / d->stride_h + 1, OW = (d->W - 1) / d->stride_w + 1;
     PwGeom g{d->N, d->C, d->K, Mp, OW, OH * OW, d->H * d->W, d->stride_h * d->W, d->stride_w, OH * OW, OW, 1, 0, (long long)d->N * OH * OW};
     const bool dense = d->stride_h == 1 && d->stride_w == 1;
-    if (dense && (OH * OW) % 4 == 0 && (((uintptr_t)x) & 15) == 0) return launch<PwV, false>(g, x, wp, bias, y, stream, what);
-    return launch<PwS, false>(g, x, wp, bias, y, stream, what);
+    static_assert(PwV::BN == PwS::BN, "cpg_conv1x1_bnstats_tiles counts tiles of either configuration");
+    if (dense && (OH * OW) % 4 == 0 && (((uintptr_t)x) & 15) == 0) return launch<PwV, false>(g, x, wp, bias, y, stream, what, stats);
+    return launch<PwS, false>(g, x, wp, bias, y, stream, what, stats);
 }
 
 int cpg_conv1x1_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx, void *ws,

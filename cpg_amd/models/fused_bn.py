@@ -117,13 +117,19 @@ class _BnAddReluFn(torch.autograd.Function):
     BN backward kernels, and the masked gradient itself for the residual."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, eps, momentum, training):
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, eps, momentum, training, stats=None):
         x, res = x.contiguous(), res.contiguous()
         N, C = x.shape[0], x.shape[1]
         HW = x.numel() // (N * C)
         L = _lib.lib()
         y = torch.empty_like(x)
-        if training:
+        apply_only = not training
+        if training and stats is not None:
+            # the producing conv's epilogue already accumulated the partial sums (cpg_conv2d_fwd_bnstats): finalize + apply pass
+            mean, invstd = _finalize_stats(stats, N, C, HW, eps, momentum, running_mean, running_var, x.device)
+            ws, nb = None, 0
+            apply_only = True
+        elif training:
             mean = torch.empty(C, dtype=torch.float32, device=x.device)
             invstd = torch.empty(C, dtype=torch.float32, device=x.device)
             ws, nb = _lib.workspace(L.cpg_bn_workspace_bytes(N, C, HW), x.device)
@@ -131,9 +137,9 @@ class _BnAddReluFn(torch.autograd.Function):
             mean, invstd = running_mean, torch.rsqrt(running_var + eps)
             ws, nb = None, 0
         rc = L.cpg_bn_add_relu_fwd(_lib.dptr(x, name='input'), _lib.dptr(res, name='residual'), _lib.dptr(gamma), _lib.dptr(beta),
-                                   float(eps), float(momentum), _lib.dptr(running_mean if training else None),
-                                   _lib.dptr(running_var if training else None), _lib.dptr(mean), _lib.dptr(invstd), _lib.dptr(y),
-                                   N, C, HW, int(training), _lib.dptr(ws), nb, _lib.stream_ptr())
+                                   float(eps), float(momentum), _lib.dptr(None if apply_only else running_mean),
+                                   _lib.dptr(None if apply_only else running_var), _lib.dptr(mean), _lib.dptr(invstd), _lib.dptr(y),
+                                   N, C, HW, int(not apply_only), _lib.dptr(ws), nb, _lib.stream_ptr())
         _lib.check('cpg_bn_add_relu_fwd', rc)
         ctx.save_for_backward(x, y, gamma, beta, mean, invstd)
         ctx.cfg = (N, C, HW, bool(training))
@@ -143,16 +149,17 @@ class _BnAddReluFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, y, gamma, beta, mean, invstd = ctx.saved_tensors
         N, C, HW, training = ctx.cfg
-        gz = torch.ops.aten.threshold_backward(gy.contiguous(), y, 0.0)
+        gy = gy.contiguous()
         L = _lib.lib()
         gx = torch.empty_like(x)
+        gz = torch.empty_like(x)                       # gy * [y > 0]: the residual branch's gradient, written by the reduction pass
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
         ws, nb = _lib.workspace(L.cpg_bn_workspace_bytes(N, C, HW), x.device)
-        rc = L.cpg_bn_relu_bwd(_lib.dptr(x), _lib.dptr(gz, name='grad_output'), _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(mean),
-                               _lib.dptr(invstd), _lib.dptr(gx), _lib.dptr(dgamma), _lib.dptr(dbeta), N, C, HW, 0, int(training),
-                               _lib.dptr(ws), nb, _lib.stream_ptr())
-        _lib.check('cpg_bn_relu_bwd', rc)
-        return gx, gz, dgamma, dbeta, None, None, None, None, None
+        rc = L.cpg_bn_add_relu_bwd(_lib.dptr(x), _lib.dptr(y), _lib.dptr(gy, name='grad_output'), _lib.dptr(gamma), _lib.dptr(beta),
+                                   _lib.dptr(mean), _lib.dptr(invstd), _lib.dptr(gx), _lib.dptr(gz), _lib.dptr(dgamma), _lib.dptr(dbeta),
+                                   N, C, HW, int(training), _lib.dptr(ws), nb, _lib.stream_ptr())
+        _lib.check('cpg_bn_add_relu_bwd', rc)
+        return gx, gz, dgamma, dbeta, None, None, None, None, None, None
 
 
 class _BnReluPoolFn(torch.autograd.Function):
@@ -276,16 +283,41 @@ def bn_act(bn, act, x):
     return y if act is None else act(y)
 
 
-def bn_add_act(bn, act, x, res):
-    """act(bn(x) + res), the tail of a residual block; fused when `act` is a plain nn.ReLU and `bn` qualifies."""
+def bn_add_act(bn, act, x, res, stats=None):
+    """act(bn(x) + res), the tail of a residual block; fused when `act` is a plain nn.ReLU and `bn` qualifies.  stats: partial sums
+    of x from the conv that produced it (conv_bn_add_act)."""
     if ENABLED and type(act) is nn.ReLU and fusable(bn, x) and bn.track_running_stats and res.shape == x.shape:
         training = bn.training
         if training and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
-        return _BnAddReluFn.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, training)
+        return _BnAddReluFn.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, training,
+                                  stats if training else None)
     out = bn(x)
     out = out + res
     return act(out)
+
+
+def _conv_with_stats(conv, bn, x):
+    """(conv(x), partial sums for `bn` or None): the conv's epilogue accumulates the BatchNorm statistics when the pair qualifies
+    (a masked conv with a fused-statistics kernel feeding a training-mode, stat-tracking BatchNorm2d)."""
+    if (ENABLED and FusedSequential.fuse_stats and hasattr(conv, 'forward_with_bn_stats') and isinstance(bn, nn.BatchNorm2d) and bn.training
+            and bn.track_running_stats and bn.affine and bn.momentum is not None and x.is_cuda and torch.is_grad_enabled()):
+        return conv.forward_with_bn_stats(x)
+    return conv(x), None
+
+
+def conv_bn_act(conv, bn, act, x):
+    """act(bn(conv(x))) for the residual topologies (models/resnet.py:86-93): bn_act with the statistics pass folded into the conv."""
+    y, stats = _conv_with_stats(conv, bn, x)
+    if stats is not None and (act is None or type(act) is nn.ReLU) and fusable(bn, y):
+        return bn_relu(y, bn, relu=act is not None, stats=stats)
+    return bn_act(bn, act, y)
+
+
+def conv_bn_add_act(conv, bn, act, x, res):
+    """act(bn(conv(x)) + res): the block tail (models/resnet.py:94-104) with the statistics from the conv's epilogue."""
+    y, stats = _conv_with_stats(conv, bn, x)
+    return bn_add_act(bn, act, y, res, stats)
 
 
 class FusedSequential(nn.Sequential):

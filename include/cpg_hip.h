@@ -294,6 +294,13 @@ int cpg_bn_bwd_from_partials(const float *partials, int32_t tiles, const float *
 int cpg_bn_add_relu_fwd(const float *x, const float *res, const float *gamma, const float *beta, float eps,
                         float momentum, float *running_mean, float *running_var, float *mean, float *invstd, float *y,
                         int32_t N, int32_t C, int32_t HW, int32_t train, void *ws, size_t ws_bytes, void *stream);
+/* Backward of cpg_bn_add_relu_fwd (out = relu(bn(x) + residual), the tail of a residual block, models/resnet.py:62-71,96-104 --
+ * stock torch: threshold_backward, then the BatchNorm backward, 8 passes): gz = gy * [out > 0] (the residual branch's gradient, may
+ * alias gy) is written by the reduction pass that also needs it, gx is the BatchNorm input gradient.  7 passes. */
+int cpg_bn_add_relu_bwd(const float *x, const float *out, const float *gy, const float *gamma, const float *beta,
+                        const float *mean, const float *invstd, float *gx, float *gz, float *dgamma, float *dbeta,
+                        int32_t N, int32_t C, int32_t HW, int32_t train, void *workspace, size_t workspace_bytes,
+                        void *stream);
 
 /* BatchNorm2d -> ReLU -> MaxPool2d(2, 2) fused (the 5 VGG blocks that end in 'M', models/vgg.py:131-141).
  * y_pooled / g_pooled: [N][C][H/2][W/2]; H and W even.  train != 0: batch statistics are computed (and

@@ -57,7 +57,8 @@ def save(name, **arrays):
         out[k] = np.asarray(v)
     out['_torch_version'] = np.asarray(torch.__version__)
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
-    print('wrote', name, {k: getattr(v, 'shape', None) for k, v in out.items() if not k.startswith('_')})
+    shapes = {k: getattr(v, 'shape', None) for k, v in out.items() if not k.startswith('_')}
+    print('wrote', name, shapes if len(shapes) <= 40 else '%d arrays' % len(shapes))
 
 
 # --------------------------------------------------------------------------
@@ -639,6 +640,81 @@ def gen_net_train_steps():
         save('train_steps_' + arch, **arrs)
 
 
+# --------------------------------------------------------------------------
+# 13b. config 4's backward pinned at 1e-4 (round 3): the whole narrow ResNet-50 backward chain (7x7 s2 stem, 1x1 s1 / s2, 3x3 s1 / s2,
+#      residual adds, max-pool, BatchNorm backward) on inputs for which two correct fp32 implementations MUST agree.
+#      What makes train_steps_resnet50.npz a sanity band only: a ReLU whose input lies inside the forward round-off takes different
+#      sides in two implementations, and ONE flipped element moves every weight-gradient entry it touches by ~1/sqrt(N H W) of its
+#      value (0.3 % of the tensor's scale on a 16 x 16 plane) -- measured here: the reference's own fp32 and fp64 train-mode runs
+#      differ in 3-17 ReLU elements of layer3 / layer4 for every one of 180 input seeds at batch 32.  Train-mode BatchNorm over few
+#      samples amplifies the round-off ~300x (tools/diag_train_steps.py), so this fixture takes BatchNorm in EVAL mode (running
+#      statistics populated by one train-mode pass over another batch; the train-mode BatchNorm kernels are pinned against fp64 in
+#      test_fused_bn_small_planes_fp64) and the input seed, of 120 candidates, whose smallest |ReLU input| / rms(layer) in the fp64
+#      run is largest -- no knife-edge activation exists, so every gradient is held to 1e-4 of its scale.
+# --------------------------------------------------------------------------
+def gen_resnet_backward_wc():
+    import copy
+    width, ncls, shape = 0.25, 5, (2, 3, 64, 64)
+    net = build_ref('resnet50', width, num_classes=ncls, dataset='t1')
+    reinit_resnet(net, 2)
+    digest = np.array([[float(p.double().sum()), float(p.double().abs().sum())] for p in net.parameters()])
+    # non-trivial affine parameters and running statistics
+    torch.manual_seed(3)
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            nn.init.uniform_(m.weight, 0.5, 1.5)
+            nn.init.uniform_(m.bias, -0.3, 0.3)
+    net.train()
+    with torch.no_grad():
+        net(torch.randn(16, 3, 64, 64, generator=torch.Generator().manual_seed(5)))
+    net.eval()
+    net64 = copy.deepcopy(net).double().eval()
+
+    def margin(x):
+        worst = [1e9]
+
+        def hook(mod, inp):                 # PRE-hook: the reference's ReLUs are in-place
+            v = inp[0]
+            worst[0] = min(worst[0], float(v.abs().min() / v.pow(2).mean().sqrt()))
+        hooks = [m.register_forward_pre_hook(hook) for m in net64.modules() if isinstance(m, nn.ReLU)]
+        with torch.no_grad():
+            net64(x.double())
+        for h in hooks:
+            h.remove()
+        return worst[0]
+
+    best = (-1.0, None)
+    for cand in range(120):
+        g = torch.Generator().manual_seed(1000 + cand)
+        x = quant(torch.randn(*shape, generator=g))
+        mg = margin(x)
+        if mg > best[0]:
+            best = (mg, 1000 + cand)
+    print('chosen input seed', best[1], 'smallest |ReLU input| / rms =', best[0], flush=True)
+    seed = best[1]
+    g = torch.Generator().manual_seed(seed)
+    x = quant(torch.randn(*shape, generator=g))
+    t = torch.randint(0, ncls, (shape[0],), generator=torch.Generator().manual_seed(seed + 1))
+    model = nn.DataParallel(net)
+    model.eval()
+    out = model(x)
+    loss = nn.CrossEntropyLoss()(out, t)
+    loss.backward()
+    names = [n for n, m in net.named_modules() if isinstance(m, nl.SharableConv2d)]
+    arrs = dict(width=width, num_classes=ncls, x=x, t=t, seed=seed, relu_margin=best[0], param_digest=digest, logits=out.detach().clone(),
+                loss=float(loss), conv_names=np.array(names))
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            arrs['grad/' + n] = p.grad.detach().clone()                 # EVERY parameter gradient (the narrow net is 1.5 M weights)
+    for n, b in net.named_buffers():
+        if b.dtype.is_floating_point:
+            arrs['buf/' + n] = b.detach().clone()                        # running statistics the eval-mode pass used
+    for n, p in net.named_parameters():
+        if p.dim() == 1:
+            arrs['param/' + n] = p.detach().clone()                      # BatchNorm affine parameters / head bias drawn above
+    save('backward_resnet50_wc', **arrs)
+
+
 def gen_angle():
     """A-Softmax head of config 5 (models/spherenet.py:24-98): AngleLinear output pair and AngleLoss over 3 calls
     (the loss is stateful: lambda anneals with the call count)."""
@@ -698,6 +774,7 @@ if __name__ == '__main__':
     gen_one_shot()
     gen_manager_trajectory()
     gen_net_train_steps()
+    gen_resnet_backward_wc()
     gen_checkpoint()
     gen_angle()
     gen_binarizer()

