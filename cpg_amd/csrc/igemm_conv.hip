@@ -553,6 +553,14 @@ int cpg_conv3x3s2_dgrad(const cpg_conv_desc *d, const float *gy, const float *w,
 size_t cpg_conv3x3s2_wgrad_workspace(const cpg_conv_desc *d);
 int cpg_conv3x3s2_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr, float *gw,
                         float *gpm, void *ws, size_t ws_bytes, hipStream_t stream);
+// ... and the strided image stems (conv_stem_s2.hip: 7x7 s2 p3 and 3x3 s2 p1 from <= 3 channels to 64)
+extern "C" int cpg_conv_stem2_ok(const cpg_conv_desc *d);
+int cpg_conv_stem2_tiles(const cpg_conv_desc *d);
+int cpg_conv_stem2_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias, float *y,
+                       float *stats, hipStream_t stream);
+size_t cpg_conv_stem2_wgrad_workspace(const cpg_conv_desc *d);
+int cpg_conv_stem2_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr, float *gw,
+                         float *gpm, void *ws, size_t ws_bytes, hipStream_t stream);
 static inline bool use_c3_wgrad(const cpg_conv_desc *d) { return cpg_conv3x3_supported(d) && (d->C >= 16 || d->C <= 3); }
 
 extern "C" size_t cpg_conv2d_workspace_bytes(const cpg_conv_desc *d) {
@@ -562,6 +570,7 @@ extern "C" size_t cpg_conv2d_workspace_bytes(const cpg_conv_desc *d) {
     pack = std::max(pack, bias_ws_bytes(g.N, g.K));          // the bias gradient's partial sums reuse the workspace
     if (use_c3_wgrad(d)) return std::max(pack, cpg_conv3x3_wgrad_workspace(d));
     if (cpg_conv3x3s2_supported(d)) return std::max(std::max(pack, cpg_conv3x3s2_pack_workspace(d)), cpg_conv3x3s2_wgrad_workspace(d));
+    if (cpg_conv_stem2_ok(d)) return std::max(pack, cpg_conv_stem2_wgrad_workspace(d));
     if (cpg_conv1x1_wgrad_supported(d)) return std::max(pack, cpg_conv1x1_wgrad_workspace(d));
     int tm, tn, nsplit, per;
     conv_wgrad_tiles<CfgA>(g, tm, tn);
@@ -654,12 +663,14 @@ extern "C" int cpg_conv2d_fwd(const cpg_conv_desc *d, const float *x, const floa
     if (d && cpg_conv3x3_supported(d)) return cpg_conv3x3_fwd(d, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream);
     if (d && cpg_conv1x1_supported(d)) return cpg_conv1x1_fwd(d, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream);
     if (d && cpg_conv3x3s2_supported(d)) return cpg_conv3x3s2_fwd(d, x, w, pm, thr, bias, y, nullptr, ws, ws_bytes, (hipStream_t)stream);
+    if (d && cpg_conv_stem2_ok(d)) return cpg_conv_stem2_fwd(d, x, w, pm, thr, bias, y, nullptr, (hipStream_t)stream);
     return cpg_conv2d_fwd_generic(d, x, w, pm, thr, bias, y, stream);
 }
 
 // Forward that also emits the BatchNorm partial sums of its output (3x3 s1 p1 shapes; 0 tiles = not available).
 extern "C" int32_t cpg_conv2d_bnstats_tiles(const cpg_conv_desc *d) {
     if (d && cpg_conv3x3s2_supported(d)) return cpg_conv3x3s2_bnstats_tiles(d);
+    if (d && cpg_conv_stem2_ok(d)) return cpg_conv_stem2_tiles(d);
     if (d && !cpg_conv3x3_supported(d) && cpg_conv1x1_supported(d)) return cpg_conv1x1_bnstats_tiles(d);
     return (d && cpg_conv3x3_supported(d)) ? cpg_conv3x3_bnstats_tiles(d) : 0;
 }
@@ -672,6 +683,7 @@ extern "C" int cpg_conv2d_fwd_bnstats(const cpg_conv_desc *d, const float *x, co
     if (stats == nullptr || stats_bytes < need)
         return fail(CPG_E_WORKSPACE, "cpg_conv2d_fwd_bnstats: statistics buffer %zu < %zu bytes", stats_bytes, need);
     if (cpg_conv3x3s2_supported(d)) return cpg_conv3x3s2_fwd(d, x, w, pm, thr, bias, y, stats, ws, ws_bytes, (hipStream_t)stream);
+    if (cpg_conv_stem2_ok(d)) return cpg_conv_stem2_fwd(d, x, w, pm, thr, bias, y, stats, (hipStream_t)stream);
     if (!cpg_conv3x3_supported(d)) return cpg_conv1x1_fwd(d, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream, stats);
     return cpg_conv3x3_fwd_bnstats(d, x, w, pm, thr, bias, y, stats, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -743,6 +755,13 @@ extern "C" int cpg_conv2d_wgrad(const cpg_conv_desc *d, const float *x, const fl
     hipStream_t stream = (hipStream_t)stream_v;
     if (use_c3_wgrad(d)) {
         rc = cpg_conv3x3_wgrad(d, x, gy, w, pm, thr, gw, gpm, ws, ws_bytes, stream);
+        if (rc) return rc;
+        if (gb) launch_conv_bias_grad(gy, gb, g.N, g.K, g.OH * g.OW, ws, stream);
+        CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(bias)");
+        return CPG_OK;
+    }
+    if (cpg_conv_stem2_ok(d)) {
+        rc = cpg_conv_stem2_wgrad(d, x, gy, w, pm, thr, gw, gpm, ws, ws_bytes, stream);
         if (rc) return rc;
         if (gb) launch_conv_bias_grad(gy, gb, g.N, g.K, g.OH * g.OW, ws, stream);
         CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(bias)");

@@ -140,6 +140,11 @@ def test_linear_golden(name):
     (3, 160, 14, 14, 72, 3, 2, 1, False, False),     # the same with > 64 input channels in the input gradient
     (2, 32, 33, 70, 200, 3, 2, 1, True, True),       # odd map, 35-wide outputs: the general strided tiles
     (1, 16, 2, 2, 16, 3, 2, 1, False, False),        # 2x2 -> 1x1
+    (3, 3, 64, 70, 64, 7, 2, 3, False, True),        # ResNet stem on the strided stem kernels: ragged tiles, piggymask
+    (2, 3, 37, 45, 64, 7, 2, 3, True, False),        # ... odd map, bias
+    (5, 3, 30, 64, 64, 3, 2, 1, True, False),        # SphereNet stem (3x3 s2 from 3 channels, bias)
+    (2, 2, 16, 18, 64, 3, 2, 1, False, True),        # ... two input channels
+    (1, 3, 224, 224, 64, 7, 2, 3, False, False),     # the ResNet stem's own map: 4 x 32 tiles, several tiles per wave
 ])
 def test_conv_oracle(N, C, H, W, K, k, s, p, bias, pm):
     g = torch.Generator().manual_seed(N * 1000 + C + K)
@@ -1149,6 +1154,78 @@ def test_conv_full_size_properties(C, K, H):
         assert abs(float(layer.piggymask.grad[k, c, r, t]) - want * float(w[k, c, r, t])) <= tol + 1e-4 * abs(want * float(w[k, c, r, t]))
 
 
+@pytest.mark.parametrize('C,K,H,k,s,p,bias', [
+    (256, 64, 56, 1, 1, 0, False),      # ResNet-50 layer1 conv1 (pointwise, models/resnet.py:86)
+    (256, 512, 56, 1, 2, 0, False),     # ResNet-50 layer2 downsample (pointwise stride 2, models/resnet.py:189-193)
+    (128, 128, 56, 3, 2, 1, False),     # ResNet-50 layer2.0.conv2 (3x3 stride 2, models/resnet.py:9,88)
+    (3, 64, 224, 7, 2, 3, False),       # ResNet-50 stem (models/resnet.py:126)
+    (64, 64, 56, 3, 1, 1, True),        # SphereNet-20 conv1_2 (3x3 s1 with bias, models/spherenet.py:205)
+    (3, 64, 112, 3, 2, 1, True),        # SphereNet-20 conv1_1 (3x3 s2 with bias from 3 channels, models/spherenet.py:203)
+    (512, 512, 7, 3, 1, 1, True),       # SphereNet-20 conv4_2 / ResNet-50 layer4 conv2: 7x7 maps
+    (512, 2048, 7, 1, 1, 0, False),     # ResNet-50 layer4 conv3: pointwise on 49-pixel planes
+])
+def test_conv_full_size_properties_other_nets(C, K, H, k, s, p, bias):
+    """The conv shape classes of configs 4 / 5 (ResNet-50, SphereNet-20) at their full size, batch 256, through the layer class:
+    adjoint identities tie forward, input gradient and weight gradient to one another, sampled entries of all three (and of the bias
+    gradient) are recomputed from the definition in fp64 -- no CPU reference needed at this size."""
+    N = 256
+    OH = (H + 2 * p - k) // s + 1
+    g = torch.Generator(device=DEV).manual_seed(C * 7 + H + k)
+    x = torch.randn(N, C, H, H, generator=g, device=DEV)
+    w = torch.randn(K, C, k, k, generator=g, device=DEV) * (2.0 / (C * k * k)) ** 0.5
+    pm = torch.rand(K, C, k, k, generator=g, device=DEV) * 0.012
+    layer = nl.SharableConv2d(C, K, k, stride=s, padding=p, bias=bias).to(DEV)
+    layer.weight.data.copy_(w)
+    if bias:
+        layer.bias.data.copy_(torch.randn(K, generator=g, device=DEV) * 0.1)
+    layer.piggymask = nn.Parameter(pm.clone())
+    xd = x.clone().requires_grad_(True)
+    y = layer(xd)
+    assert tuple(y.shape) == (N, K, OH, OH)
+    gy = torch.randn(y.shape, generator=g, device=DEV)
+    y.backward(gy)
+    w_eff = (w * (pm > 5e-3).float()).double()
+    bvec = layer.bias.detach().double() if bias else torch.zeros(K, dtype=torch.float64, device=DEV)
+
+    def dot(a, b):
+        return float((a.double() * b.double()).sum())
+    y0 = y.detach().double() - bvec.view(1, K, 1, 1)                          # the linear part
+    lhs = float((y0 * gy.double()).sum())
+    scale = float(y0.norm() * gy.double().norm())
+    assert abs(lhs - dot(x, xd.grad)) <= 1e-6 * scale                          # fwd vs dgrad
+    assert abs(lhs - dot(w, layer.weight.grad)) <= 1e-6 * scale                # fwd vs wgrad (bin(pm) is 0/1)
+    if bias:
+        want = gy.double().sum(dim=(0, 2, 3))
+        assert float((layer.bias.grad.double() - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    rs = np.random.RandomState(H + C + k)
+    xp = torch.nn.functional.pad(x, (p, p, p, p)).double()
+    for _ in range(24):
+        n, ko, c = rs.randint(N), rs.randint(K), rs.randint(C)
+        oh, ow = rs.randint(OH), rs.randint(OH)
+        if rs.rand() < 0.5:
+            oh, ow = rs.choice([0, OH - 1]), rs.choice([0, OH - 1])            # corners: zero padding / the strided map's last row
+        want = float((xp[n, :, oh * s:oh * s + k, ow * s:ow * s + k] * w_eff[ko]).sum() + bvec[ko])
+        assert abs(float(y.detach()[n, ko, oh, ow]) - want) <= 1e-4 * abs(want) + 2e-5
+        # gx[n, c, h, w] = sum over (k, r, q) with h = oh s + r - p, w = ow s + q - p of gy[n, k, oh, ow] W_eff[k, c, r, q]
+        h, ww = rs.randint(H), rs.randint(H)
+        if rs.rand() < 0.5:
+            h, ww = rs.choice([0, H - 1]), rs.choice([0, H - 1])
+        want = 0.0
+        for r in range(k):
+            for q in range(k):
+                a, b = h + p - r, ww + p - q
+                if a % s == 0 and b % s == 0 and 0 <= a // s < OH and 0 <= b // s < OH:
+                    want += float((gy[n, :, a // s, b // s].double() * w_eff[:, c, r, q]).sum())
+        assert abs(float(xd.grad[n, c, h, ww]) - want) <= 1e-4 * abs(want) + 2e-5, ('gx', n, c, h, ww)
+    for _ in range(6):
+        ko, c, r, q = rs.randint(K), rs.randint(C), rs.randint(k), rs.randint(k)
+        want = float((xp[:, c, r:r + (OH - 1) * s + 1:s, q:q + (OH - 1) * s + 1:s] * gy[:, ko].double()).sum())
+        b = float(pm[ko, c, r, q] > 5e-3)
+        tol = 1e-4 * abs(want) + 1e-5 * float(layer.weight.grad.abs().max())
+        assert abs(float(layer.weight.grad[ko, c, r, q]) - want * b) <= tol
+        assert abs(float(layer.piggymask.grad[ko, c, r, q]) - want * float(w[ko, c, r, q])) <= tol + 1e-4 * abs(want * float(w[ko, c, r, q]))
+
+
 @pytest.mark.parametrize('B,I,O', [(256, 25088, 4096), (256, 4096, 4096)])
 @pytest.mark.parametrize('pm_on', [False, True])
 def test_linear_full_size_properties(B, I, O, pm_on):
@@ -1566,10 +1643,18 @@ def test_strided_conv_epilogue_bn_statistics(N, C, K, H, W):
     _bn_statistics_case(N, C, K, H, W, False, 2)
 
 
-def _bn_statistics_case(N, C, K, H, W, pool, stride):
+@pytest.mark.parametrize('N,C,K,H,W,k,s', [(3, 3, 64, 64, 70, 7, 2), (2, 3, 64, 224, 224, 7, 2), (4, 64, 256, 28, 28, 1, 1), (5, 32, 48, 7, 7, 1, 1),
+                                         (3, 64, 128, 30, 30, 1, 2)])
+def test_stem_and_pointwise_conv_epilogue_bn_statistics(N, C, K, H, W, k, s):
+    """... for the strided stem kernel (ResNet conv1 -> bn1, models/resnet.py:126-127) and the pointwise kernels (conv1 / conv3 /
+    downsample -> BatchNorm, models/resnet.py:86-98,189-193): float4 and scalar staging, tiles that span images"""
+    _bn_statistics_case(N, C, K, H, W, False, s, k)
+
+
+def _bn_statistics_case(N, C, K, H, W, pool, stride, k=3):
     from cpg_amd.models import fused_bn
     torch.manual_seed(N * 10 + K)
-    mods = [nl.SharableConv2d(C, K, 3, stride=stride, padding=1, bias=False), nn.BatchNorm2d(K), nn.ReLU(inplace=True)]
+    mods = [nl.SharableConv2d(C, K, k, stride=stride, padding=k // 2, bias=False), nn.BatchNorm2d(K), nn.ReLU(inplace=True)]
     if pool:
         mods.append(nn.MaxPool2d(2, 2))
     seq = fused_bn.FusedSequential(*mods)
