@@ -287,10 +287,17 @@ struct PwWCfg {
     static constexpr int NITEMS = NA + NB, NS = PIX / 2;
 };
 
-template <class Cfg>
+// SCALAR: every staged pixel is fetched on its own (four dword loads instead of one dwordx4 per item) -- planes whose size is not
+// a multiple of 4 (ResNet layer4's 7 x 7 maps: a float4 would straddle images and lose its alignment) and STRIDED layers (the 1x1 s2
+// downsample shortcuts, models/resnet.py:189-193), where pixel q of the output grid pairs with x at (s q / OW, s (q % OW)).
+// xg = {x plane size, OW, row pitch, column pitch} of the tensor read as x (SCALAR only).
+struct PwWX {
+    int plane, OW, sy, sx;
+};
+template <class Cfg, bool SCALAR = false>
 __global__ __launch_bounds__(256, 2) void k_pw_wgrad(int M, int C, int HWo, long long G, int tiles_co, int tiles_ci,
                                                      int units_per_split, const float *__restrict__ x,
-                                                     const float *__restrict__ gy, float *__restrict__ part) {
+                                                     const float *__restrict__ gy, float *__restrict__ part, PwWX xg = PwWX{0, 0, 0, 0}) {
     __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -323,18 +330,39 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(int M, int C, int HWo, long
 #pragma unroll
     for (int i = 0; i < Cfg::NA; ++i) a_chan[i] = min(co0 + chl + 32 * i, M - 1) * HWo * 4;
 #pragma unroll
-    for (int i = 0; i < Cfg::NB; ++i) b_chan[i] = min(ci0 + chl + 32 * i, C - 1) * HWo * 4;
+    for (int i = 0; i < Cfg::NB; ++i) b_chan[i] = min(ci0 + chl + 32 * i, C - 1) * (SCALAR ? xg.plane : HWo) * 4;
     const int dst = chl * Cfg::LD + 4 * j4;
     int pos_g = kOutOfRange, pos_x = kOutOfRange;       // byte offset of (image, pixel) in gy / x for the unit being loaded
+    int pgs[SCALAR ? 4 : 1], pxs[SCALAR ? 4 : 1];       // SCALAR: one position per pixel of the float4
     auto describe = [&](long long u) {      // G < 2^29 (host check): 32-bit arithmetic
         const int g = (int)u * Cfg::PIX + 4 * j4;
-        const int n = g / HWo, q = g - n * HWo;
+        int n = g / HWo, q = g - n * HWo;
+        if (SCALAR) {
+            int oy = q / xg.OW, ox = q - oy * xg.OW;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = g + e < (int)G;
+                pgs[e] = ok ? (n * M * HWo + q) * 4 : kOutOfRange;
+                pxs[e] = ok ? (n * C * xg.plane + oy * xg.sy + ox * xg.sx) * 4 : kOutOfRange;
+                ++q, ++ox;                                       // next pixel: carry into the row / the image
+                if (ox == xg.OW) ox = 0, ++oy;
+                if (q == HWo) q = 0, oy = 0, ++n;
+            }
+            return;
+        }
         const bool ok = g < (int)G;
         pos_g = ok ? (n * M * HWo + q) * 4 : kOutOfRange;
         pos_x = ok ? (n * C * HWo + q) * 4 : kOutOfRange;
     };
     f32x4 st[Cfg::NITEMS];
     auto load_item = [&](int k) {
+        if (SCALAR) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                st[k][e] = __builtin_bit_cast(float, k < Cfg::NA ? __builtin_amdgcn_raw_buffer_load_b32(srd_g, pgs[e] + a_chan[k], 0, 0)
+                                                                 : __builtin_amdgcn_raw_buffer_load_b32(srd_x, pxs[e] + b_chan[k - Cfg::NA], 0, 0));
+            return;
+        }
         if (k < Cfg::NA)
             st[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_g, pos_g + a_chan[k], 0, 0));
         else
@@ -392,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(int M, int C, int HWo, long
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     if (i < k1 - k0) {
                         __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, SCALAR ? 4 : 1, 0);
                     }
                 }
             }
@@ -422,7 +450,8 @@ PwWPlan pw_wgrad_plan(const cpg_conv_desc *d) {
     PwWPlan p;
     p.tiles_co = (d->K + Cfg::BCO - 1) / Cfg::BCO;
     p.tiles_ci = (d->C + Cfg::BCI - 1) / Cfg::BCI;
-    const int64_t units = ((int64_t)d->N * d->H * d->W + Cfg::PIX - 1) / Cfg::PIX;
+    const int OH = (d->H - 1) / d->stride_h + 1, OW = (d->W - 1) / d->stride_w + 1;       // the gy grid
+    const int64_t units = ((int64_t)d->N * OH * OW + Cfg::PIX - 1) / Cfg::PIX;
     const int64_t tiles = (int64_t)p.tiles_co * p.tiles_ci;
     int64_t want = (4 * kCUs + tiles - 1) / tiles;              // ~2 rounds of 2 blocks per CU
     want = std::max<int64_t>(1, std::min<int64_t>(want, (units + 7) / 8));      // at least 8 units per split
@@ -444,8 +473,15 @@ int pw_wgrad_launch(const cpg_conv_desc *d, const float *x, const float *gy, con
     const PwWPlan p = pw_wgrad_plan<Cfg>(d);
     if (ws == nullptr || ws_bytes < p.ws_bytes)
         return fail(CPG_E_WORKSPACE, "cpg_conv2d_wgrad(1x1): workspace %zu < %zu bytes", ws_bytes, p.ws_bytes);
-    hipLaunchKernelGGL(k_pw_wgrad<Cfg>, dim3((unsigned)(p.tiles_co * p.tiles_ci * p.nsplit)), dim3(256), 0, stream, d->K, d->C,
-                       d->H * d->W, (long long)d->N * d->H * d->W, p.tiles_co, p.tiles_ci, p.units_per_split, x, gy, (float *)ws);
+    const int OH = (d->H - 1) / d->stride_h + 1, OW = (d->W - 1) / d->stride_w + 1;
+    const bool vec = d->stride_h == 1 && d->stride_w == 1 && (OH * OW) % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)gy) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL((k_pw_wgrad<Cfg, false>), dim3((unsigned)(p.tiles_co * p.tiles_ci * p.nsplit)), dim3(256), 0, stream, d->K, d->C,
+                           OH * OW, (long long)d->N * OH * OW, p.tiles_co, p.tiles_ci, p.units_per_split, x, gy, (float *)ws, PwWX{0, 0, 0, 0});
+    else
+        hipLaunchKernelGGL((k_pw_wgrad<Cfg, true>), dim3((unsigned)(p.tiles_co * p.tiles_ci * p.nsplit)), dim3(256), 0, stream, d->K, d->C,
+                           OH * OW, (long long)d->N * OH * OW, p.tiles_co, p.tiles_ci, p.units_per_split, x, gy, (float *)ws,
+                           PwWX{d->H * d->W, OW, d->stride_h * d->W, d->stride_w});
     launch_split_reduce((const float *)ws, p.nsplit, (int64_t)d->K * d->C, 0, ep, stream);
     CPG_CHECK_LAUNCH("cpg_conv2d_wgrad(1x1)");
     return CPG_OK;
@@ -542,7 +578,8 @@ int cpg_conv1x1_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, c
 extern "C" int cpg_conv1x1_wgrad_supported(const cpg_conv_desc *d) {
     if (getenv("CPG_DISABLE_CONV1X1_WGRAD") || !cpg_conv1x1_supported(d)) return 0;
     const int64_t hw = (int64_t)d->H * d->W;
-    return d->stride_h == 1 && d->stride_w == 1 && hw % 4 == 0 && (int64_t)d->N * std::max(d->C, d->K) * hw * 4 < (1ll << 31);
+    // (strided layers and planes that are not multiples of 4 pixels take the kernel's per-pixel staging)
+    return (int64_t)d->N * std::max(d->C, d->K) * hw * 4 < (1ll << 31) && (int64_t)d->N * hw < (1ll << 29);
 }
 
 size_t cpg_conv1x1_wgrad_workspace(const cpg_conv_desc *d) {
@@ -556,7 +593,6 @@ size_t cpg_conv1x1_wgrad_workspace(const cpg_conv_desc *d) {
 
 int cpg_conv1x1_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
                       float *gw, float *gpm, void *ws, size_t ws_bytes, hipStream_t stream) {
-    CPG_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)gy) & 15) == 0, "cpg_conv2d_wgrad(1x1): tensors must be 16-byte aligned");
     Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
     switch (pw_wgrad_pick(d)) {
         case 1: return pw_wgrad_launch<PwW64o>(d, x, gy, ep, ws, ws_bytes, stream);
