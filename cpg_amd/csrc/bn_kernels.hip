@@ -737,6 +737,268 @@ extern "C" int cpg_bn_relu_pool_bwd(const float *x, const float *g_pooled, const
     return CPG_OK;
 }
 
+
+// =====================================================================================================
+// BatchNorm2d -> ReLU -> MaxPool2d(kernel 3, stride 2, padding 1): the ResNet stem's tail (models/resnet.py:127-129,208-211),
+// the largest activation of the network (64 x 112 x 112 per image).  Stock torch: BN apply (2 passes), max-pool forward with an
+// int64 index tensor, max_pool_backward (1.6 ms at batch 256: a gather over the indices), then the BatchNorm backward (5 passes).
+// Here a block owns a strip of one (n, c) plane at a time: its rows go through LDS as z = relu(bn(x)) (windows overlap, so neighbours are
+// needed), the pooled maxima are written; backward recomputes z the same way, finds every window's arg-max (first maximum in
+// row-major order = torch's rule; padding never wins: z >= 0 and every window has a valid element), routes the pooled gradient to
+// it without atomics (each element looks at the <= 4 windows that contain it), masks by z > 0 and continues with the BatchNorm
+// gradient -- a reduction launch and an apply launch that each read x and the pooled gradient once.
+// Work unit = a strip of 8 window rows of one (n, c) plane (19 input rows in LDS: a dozen blocks per CU).
+// =====================================================================================================
+namespace {
+
+struct Pool3Dims {
+    int H, W, OH, OW;
+    int strips;                 // strips of kPool3SR window rows per plane
+};
+constexpr int kPool3SR = 8;     // window (= quad) rows per work unit; a unit stages 2 SR + 3 input rows and SR + 1 window rows
+
+// LDS layout of a unit: zs[(2 SR + 3) * W] = relu(bn(x)) of input rows 2 r0 - 1 ... 2 r0 + 2 SR + 1 (r0 = first window row of the
+// strip; rows outside the plane are never read), idx[(SR + 1) * OW] = arg-max (flat plane index) of window rows r0 ... r0 + SR
+__device__ __forceinline__ void pool3_stage(const float *__restrict__ plane, float *zs, const Pool3Dims &p, int r0, int nrows, float m,
+                                            float is, float ga, float be) {
+    const int h0 = 2 * r0 - 1;                                   // input row of LDS row 0
+    const int lo = max(h0, 0), hi = min(h0 + nrows, p.H);        // valid input rows [lo, hi)
+    const float *src = plane + lo * p.W;
+    float *dst = zs + (lo - h0) * p.W;
+    const int n = (hi - lo) * p.W;
+    if ((n & 3) == 0 && (((uintptr_t)src) & 15) == 0 && (((lo - h0) * p.W) & 3) == 0) {
+        for (int i = threadIdx.x; i < n / 4; i += kThreads) {
+            float4 v = reinterpret_cast<const float4 *>(src)[i];
+            v.x = fmaxf(bn_affine(v.x, m, is, ga, be), 0.f); v.y = fmaxf(bn_affine(v.y, m, is, ga, be), 0.f);
+            v.z = fmaxf(bn_affine(v.z, m, is, ga, be), 0.f); v.w = fmaxf(bn_affine(v.w, m, is, ga, be), 0.f);
+            reinterpret_cast<float4 *>(dst)[i] = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += kThreads) dst[i] = fmaxf(bn_affine(src[i], m, is, ga, be), 0.f);
+    }
+}
+
+// arg-max of window (ph, pw): flat PLANE index h * W + w of the first maximum (row-major scan over the valid positions; padding never
+// takes part, as in torch); zs row 0 = input row h0
+__device__ __forceinline__ int pool3_argmax(const float *zs, const Pool3Dims &p, int h0, int ph, int pw, float *best_out = nullptr) {
+    float best = -1.0f;
+    int arg = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int h = 2 * ph - 1 + r;
+        if ((unsigned)h >= (unsigned)p.H) continue;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int w = 2 * pw - 1 + q;
+            if ((unsigned)w >= (unsigned)p.W) continue;
+            const float v = zs[(h - h0) * p.W + w];
+            if (v > best) best = v, arg = h * p.W + w;
+        }
+    }
+    if (best_out) *best_out = best;
+    return arg;
+}
+
+__global__ __launch_bounds__(kThreads) void k_bnp3_apply(const float *__restrict__ x, float *__restrict__ y, BnDims d, Pool3Dims p,
+                                                         const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                         const float *__restrict__ gamma, const float *__restrict__ beta) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    float *zs = dyn;
+    const int64_t units = (int64_t)d.N * d.C * p.strips;
+    const int wins = p.OH * p.OW;
+    for (int64_t u = blockIdx.x; u < units; u += gridDim.x) {
+        const int64_t pl = u / p.strips;
+        const int r0 = (int)(u % p.strips) * kPool3SR, r1 = min(p.OH, r0 + kPool3SR);
+        const int c = (int)(pl % d.C);
+        __syncthreads();
+        pool3_stage(x + pl * d.HW, zs, p, r0, 2 * (r1 - r0) + 1, mean[c], invstd[c], gamma[c], beta[c]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < (r1 - r0) * p.OW; i += kThreads) {
+            float best;
+            pool3_argmax(zs, p, 2 * r0 - 1, r0 + i / p.OW, i % p.OW, &best);
+            y[pl * wins + r0 * p.OW + i] = best;
+        }
+    }
+}
+
+// One thread = one 2 x 2 QUAD of the plane, quad (a, b) = elements (2a + dy, 2b + dx): element (0,0) lies in window (a, b) only,
+// (0,1) in (a, b) and (a, b+1), (1,0) in (a, b) and (a+1, b), (1,1) in all four -- so the four windows' arg-max entries and pooled
+// gradients are fetched once per quad (pooled gradients straight from global memory: consecutive quads read consecutive words).
+// dz[2 dy + dx] = the pooled gradients routed to the element, masked by z > 0 (elements past the plane's edge get 0).
+__device__ __forceinline__ void pool3_quad(const float *zs, const int *idx, const float *__restrict__ gp, const Pool3Dims &p, int r0, int a,
+                                           int b, float (&dz)[4]) {
+    const int h0 = 2 * r0 - 1;
+    const int *ix = idx + (a - r0) * p.OW + b;
+    const float *g = gp + a * p.OW + b;
+    const bool hb = b + 1 < p.OW, ha = a + 1 < p.OH;
+    const int i00 = ix[0], i01 = hb ? ix[1] : -1, i10 = ha ? ix[p.OW] : -1, i11 = (ha && hb) ? ix[p.OW + 1] : -1;
+    const float g00 = g[0], g01 = hb ? g[1] : 0.f, g10 = ha ? g[p.OW] : 0.f, g11 = (ha && hb) ? g[p.OW + 1] : 0.f;
+    const int e00 = 2 * a * p.W + 2 * b;
+    const float *z = zs + (2 * a - h0) * p.W + 2 * b;
+    const bool hx = 2 * b + 1 < p.W, hy = 2 * a + 1 < p.H;
+    dz[0] = z[0] > 0.f ? (i00 == e00 ? g00 : 0.f) : 0.f;
+    dz[1] = (hx && z[1] > 0.f) ? (i00 == e00 + 1 ? g00 : 0.f) + (i01 == e00 + 1 ? g01 : 0.f) : 0.f;
+    dz[2] = (hy && z[p.W] > 0.f) ? (i00 == e00 + p.W ? g00 : 0.f) + (i10 == e00 + p.W ? g10 : 0.f) : 0.f;
+    const int e11 = e00 + p.W + 1;
+    dz[3] = (hx && hy && z[p.W + 1] > 0.f)
+                ? ((i00 == e11 ? g00 : 0.f) + (i01 == e11 ? g01 : 0.f)) + ((i10 == e11 ? g10 : 0.f) + (i11 == e11 ? g11 : 0.f))
+                : 0.f;
+}
+
+// stage a strip for the backward kernels: z rows and the arg-max table of window rows r0 ... min(OH, r1 + 1) - 1
+__device__ __forceinline__ void pool3_stage_bwd(const float *__restrict__ plane, float *zs, int *idx, const Pool3Dims &p, int r0, int r1,
+                                                float m, float is, float ga, float be) {
+    const int wr = min(p.OH, r1 + 1) - r0;                       // window rows needed (one past the strip for its last quads)
+    __syncthreads();
+    pool3_stage(plane, zs, p, r0, 2 * wr + 1, m, is, ga, be);
+    __syncthreads();
+    for (int i = threadIdx.x; i < wr * p.OW; i += kThreads) idx[i] = pool3_argmax(zs, p, 2 * r0 - 1, r0 + i / p.OW, i % p.OW);
+    __syncthreads();
+}
+
+// grid (C, slices): partial[c][slice] = {sum dz, sum dz * xhat}
+__global__ __launch_bounds__(kThreads) void k_bnp3_bwd_reduce(const float *__restrict__ x, const float *__restrict__ gp, BnDims d, Pool3Dims p,
+                                                              const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                              double *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    __shared__ double red[4];
+    float *zs = dyn;
+    int *idx = reinterpret_cast<int *>(dyn + (2 * kPool3SR + 3) * p.W);
+    const int c = blockIdx.x, s = blockIdx.y;
+    const int n0 = s * d.imgs_per_slice, n1 = min(d.N, n0 + d.imgs_per_slice);
+    const float m = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+    const int wins = p.OH * p.OW;
+    double dsg = 0.0, dsgx = 0.0;
+    for (int n = n0; n < n1; ++n) {
+        const int64_t pl = (int64_t)n * d.C + c;
+        const float *src = x + pl * d.HW;
+        float sg = 0.f, sgx = 0.f;
+        for (int st = 0; st < p.strips; ++st) {
+            const int r0 = st * kPool3SR, r1 = min(p.OH, r0 + kPool3SR);
+            pool3_stage_bwd(src, zs, idx, p, r0, r1, m, is, ga, be);
+            for (int i = threadIdx.x; i < (r1 - r0) * p.OW; i += kThreads) {
+                const int a = r0 + i / p.OW, b = i % p.OW;
+                float dz[4];
+                pool3_quad(zs, idx, gp + pl * wins, p, r0, a, b, dz);
+                const int e00 = 2 * a * p.W + 2 * b;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (dz[k] != 0.f) {                              // (non-zero for at most one element in nine)
+                        sg += dz[k];
+                        sgx += dz[k] * ((src[e00 + (k >> 1) * p.W + (k & 1)] - m) * is);
+                    }
+            }
+        }
+        dsg += (double)sg;
+        dsgx += (double)sgx;
+    }
+    const double t0 = block_sum(dsg, red);
+    const double t1 = block_sum(dsgx, red);
+    if (threadIdx.x == 0) {
+        partial[((int64_t)c * d.slices + s) * 2 + 0] = t0;
+        partial[((int64_t)c * d.slices + s) * 2 + 1] = t1;
+    }
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(kThreads) void k_bnp3_bwd_apply(const float *__restrict__ x, const float *__restrict__ gp, float *__restrict__ gx,
+                                                             BnDims d, Pool3Dims p, const float *__restrict__ mean,
+                                                             const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, const float *__restrict__ coef) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    float *zs = dyn;
+    int *idx = reinterpret_cast<int *>(dyn + (2 * kPool3SR + 3) * p.W);
+    const int64_t units = (int64_t)d.N * d.C * p.strips;
+    const int wins = p.OH * p.OW;
+    for (int64_t u = blockIdx.x; u < units; u += gridDim.x) {
+        const int64_t pl = u / p.strips;
+        const int r0 = (int)(u % p.strips) * kPool3SR, r1 = min(p.OH, r0 + kPool3SR);
+        const int c = (int)(pl % d.C);
+        const float m = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+        const float mg = TRAIN ? coef[2 * c] : 0.f, mgx = TRAIN ? coef[2 * c + 1] : 0.f, scale = is * ga;
+        const float *src = x + pl * d.HW;
+        float *dst = gx + pl * d.HW;
+        pool3_stage_bwd(src, zs, idx, p, r0, r1, m, is, ga, be);
+        const bool pairs = (p.W & 1) == 0 && (((uintptr_t)src) & 7) == 0 && (((uintptr_t)dst) & 7) == 0;   // rows as 8-byte pairs
+        auto out = [&](float xv, float g) { return TRAIN ? (g - mg - ((xv - m) * is) * mgx) * scale : g * scale; };
+        for (int i = threadIdx.x; i < (r1 - r0) * p.OW; i += kThreads) {
+            const int a = r0 + i / p.OW, b = i % p.OW;
+            float dz[4];
+            pool3_quad(zs, idx, gp + pl * wins, p, r0, a, b, dz);
+            const int e0 = 2 * a * p.W + 2 * b;
+            const bool hx = 2 * b + 1 < p.W, hy = 2 * a + 1 < p.H;
+            if (pairs) {
+                const float2 x0 = *reinterpret_cast<const float2 *>(src + e0);
+                *reinterpret_cast<float2 *>(dst + e0) = make_float2(out(x0.x, dz[0]), out(x0.y, dz[1]));
+                if (hy) {
+                    const float2 x1 = *reinterpret_cast<const float2 *>(src + e0 + p.W);
+                    *reinterpret_cast<float2 *>(dst + e0 + p.W) = make_float2(out(x1.x, dz[2]), out(x1.y, dz[3]));
+                }
+            } else {
+                dst[e0] = out(src[e0], dz[0]);
+                if (hx) dst[e0 + 1] = out(src[e0 + 1], dz[1]);
+                if (hy) dst[e0 + p.W] = out(src[e0 + p.W], dz[2]);
+                if (hx && hy) dst[e0 + p.W + 1] = out(src[e0 + p.W + 1], dz[3]);
+            }
+        }
+    }
+}
+
+bool make_pool3(int H, int W, Pool3Dims &p) {
+    if (H < 1 || W < 1 || W > 512) return false;                 // (a strip of 2 SR + 3 rows must fit LDS)
+    p.H = H, p.W = W, p.OH = (H - 1) / 2 + 1, p.OW = (W - 1) / 2 + 1;
+    p.strips = (p.OH + kPool3SR - 1) / kPool3SR;
+    return true;
+}
+inline size_t pool3_lds(const Pool3Dims &p) { return ((size_t)(2 * kPool3SR + 3) * p.W + (size_t)(kPool3SR + 1) * p.OW) * sizeof(float); }
+
+}  // namespace
+
+extern "C" int32_t cpg_bn_relu_pool3_supported(int32_t H, int32_t W) {
+    Pool3Dims p;
+    return make_pool3(H, W, p) ? 1 : 0;
+}
+
+// statistics (mean / invstd) are given: from cpg_bn_stats_finalize (training, after cpg_conv2d_fwd_bnstats) or the running ones
+extern "C" int cpg_bn_relu_pool3_fwd(const float *x, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                                     float *y_pooled, int32_t N, int32_t C, int32_t H, int32_t W, void *stream_v) {
+    BnDims d;
+    Pool3Dims p;
+    int rc = make_dims(N, C, H * W, d);
+    if (rc) return rc;
+    if (!make_pool3(H, W, p)) return fail(CPG_E_UNSUPPORTED, "cpg_bn_relu_pool3_fwd: plane %d x %d does not fit", H, W);
+    CPG_REQUIRE(x && gamma && beta && mean && invstd && y_pooled, "cpg_bn_relu_pool3_fwd: null pointer");
+    const int64_t units = (int64_t)N * C * p.strips;
+    hipLaunchKernelGGL(k_bnp3_apply, dim3((unsigned)std::min<int64_t>(units, (int64_t)kCUs * 32)), dim3(kThreads), pool3_lds(p),
+                       (hipStream_t)stream_v, x, y_pooled, d, p, mean, invstd, gamma, beta);
+    CPG_CHECK_LAUNCH("cpg_bn_relu_pool3_fwd");
+    return CPG_OK;
+}
+
+extern "C" int cpg_bn_relu_pool3_bwd(const float *x, const float *g_pooled, const float *gamma, const float *beta, const float *mean,
+                                     const float *invstd, float *gx, float *dgamma, float *dbeta, int32_t N, int32_t C, int32_t H, int32_t W,
+                                     int32_t train, void *ws, size_t ws_bytes, void *stream_v) {
+    BnDims d;
+    Pool3Dims p;
+    int rc = make_dims(N, C, H * W, d);
+    if (rc) return rc;
+    if (!make_pool3(H, W, p)) return fail(CPG_E_UNSUPPORTED, "cpg_bn_relu_pool3_bwd: plane %d x %d does not fit", H, W);
+    CPG_REQUIRE(x && g_pooled && gamma && beta && mean && invstd && gx && dgamma && dbeta && ws, "cpg_bn_relu_pool3_bwd: null pointer");
+    if (ws_bytes < cpg_bn_workspace_bytes(N, C, H * W)) return fail(CPG_E_WORKSPACE, "cpg_bn_relu_pool3_bwd: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_v;
+    double *partial = (double *)ws;
+    float *coef = (float *)(partial + (size_t)C * d.slices * 2);
+    const size_t lds = pool3_lds(p);
+    hipLaunchKernelGGL(k_bnp3_bwd_reduce, dim3(C, d.slices), dim3(kThreads), lds, stream, x, g_pooled, d, p, mean, invstd, gamma, beta, partial);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 63) / 64), dim3(64), 0, stream, partial, d, dgamma, dbeta, coef);
+    const dim3 grid((unsigned)std::min<int64_t>((int64_t)N * C * p.strips, (int64_t)kCUs * 32));
+    if (train) hipLaunchKernelGGL(k_bnp3_bwd_apply<true>, grid, dim3(kThreads), lds, stream, x, g_pooled, gx, d, p, mean, invstd, gamma, beta, coef);
+    else hipLaunchKernelGGL(k_bnp3_bwd_apply<false>, grid, dim3(kThreads), lds, stream, x, g_pooled, gx, d, p, mean, invstd, gamma, beta, coef);
+    CPG_CHECK_LAUNCH("cpg_bn_relu_pool3_bwd");
+    return CPG_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // PReLU backward (SphereNet-20's activation, models/spherenet.py: nn.PReLU(channels) after every conv).
 //   gx = x > 0 ? g : a[c] * g          ga[c] = sum over (n, pixels) of (x > 0 ? 0 : g * x)

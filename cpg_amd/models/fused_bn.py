@@ -205,6 +205,76 @@ class _BnReluPoolFn(torch.autograd.Function):
         return gx, dgamma, dbeta, None, None, None, None, None, None
 
 
+class _BnReluPool3Fn(torch.autograd.Function):
+    """BatchNorm2d -> ReLU -> MaxPool2d(3, 2, 1) (the ResNet stem's tail); only the pooled tensor is written."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, training, stats):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        L = _lib.lib()
+        if training and stats is not None:
+            mean, invstd = _finalize_stats(stats, N, C, H * W, eps, momentum, running_mean, running_var, x.device)
+        elif training:
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+            # (the producing conv has no fused-statistics kernel -- narrow test nets: torch's own reduction for the statistics)
+            var, mu = torch.var_mean(x, dim=(0, 2, 3), unbiased=False)
+            mean.copy_(mu)
+            invstd.copy_(torch.rsqrt(var + eps))
+            n = x.numel() // C
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mu, alpha=momentum)
+                running_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
+        else:
+            mean, invstd = running_mean, torch.rsqrt(running_var + eps)
+        y = torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+        rc = L.cpg_bn_relu_pool3_fwd(_lib.dptr(x, name='input'), _lib.dptr(gamma, name='bn.weight'), _lib.dptr(beta, name='bn.bias'),
+                                     _lib.dptr(mean), _lib.dptr(invstd), _lib.dptr(y), N, C, H, W, _lib.stream_ptr())
+        _lib.check('cpg_bn_relu_pool3_fwd', rc)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.training = bool(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, gp):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        gp = gp.contiguous()
+        L = _lib.lib()
+        gx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        ws, nb = _lib.workspace(L.cpg_bn_workspace_bytes(N, C, H * W), x.device)
+        rc = L.cpg_bn_relu_pool3_bwd(_lib.dptr(x), _lib.dptr(gp, name='grad_output'), _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(mean),
+                                     _lib.dptr(invstd), _lib.dptr(gx), _lib.dptr(dgamma), _lib.dptr(dbeta), N, C, H, W,
+                                     int(ctx.training), _lib.dptr(ws), nb, _lib.stream_ptr())
+        _lib.check('cpg_bn_relu_pool3_bwd', rc)
+        return gx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def _is_pool3(m):
+    def pair(v):
+        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    return (isinstance(m, nn.MaxPool2d) and pair(m.kernel_size) == (3, 3) and pair(m.stride) == (2, 2) and pair(m.padding) == (1, 1)
+            and pair(m.dilation) == (1, 1) and not m.ceil_mode and not m.return_indices)
+
+
+def conv_bn_act_pool(conv, bn, act, pool, x):
+    """pool(act(bn(conv(x)))): the ResNet stem (models/resnet.py:208-211).  conv -> BatchNorm statistics in the conv epilogue,
+    BatchNorm -> ReLU -> MaxPool2d(3, 2, 1) as one forward kernel and two backward kernels when the plane fits LDS."""
+    y, stats = _conv_with_stats(conv, bn, x)
+    if (ENABLED and FusedSequential.fuse_pool and type(act) is nn.ReLU and _is_pool3(pool) and fusable(bn, y) and bn.track_running_stats
+            and _lib.lib().cpg_bn_relu_pool3_supported(int(y.shape[2]), int(y.shape[3]))):
+        training = bn.training
+        if training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        return _BnReluPool3Fn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, training,
+                                    stats if training else None)
+    if stats is not None and type(act) is nn.ReLU and fusable(bn, y):
+        return pool(bn_relu(y, bn, relu=True, stats=stats))
+    return pool(bn_act(bn, act, y))
+
+
 def _is_pool2(m):
     def pair(v):
         return tuple(v) if isinstance(v, (tuple, list)) else (v, v)

@@ -8,7 +8,7 @@ network_width_multiplier with the reference's int() placement; heads are per-tas
 import torch.nn as nn
 
 from . import layers as nl
-from .fused_bn import FusedSequential, conv_bn_act, conv_bn_add_act
+from .fused_bn import FusedSequential, conv_bn_act, conv_bn_act_pool, conv_bn_add_act
 
 __all__ = ['ResNet', 'BasicBlock', 'Bottleneck', 'resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152',
            'resnext50_32x4d', 'resnext101_32x8d']
@@ -152,7 +152,7 @@ class ResNet(nn.Module):
         self.classifier = self.classifiers[self.datasets.index(dataset)]
 
     def forward(self, x):
-        x = self.maxpool(conv_bn_act(self.conv1, self.bn1, self.relu, x))
+        x = conv_bn_act_pool(self.conv1, self.bn1, self.relu, self.maxpool, x)
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = self.avgpool(x)
         return self.classifier(x.view(x.size(0), -1))

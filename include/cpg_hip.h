@@ -315,6 +315,18 @@ int cpg_bn_relu_pool_bwd(const float *x, const float *g_pooled, const float *gam
                          int32_t N, int32_t C, int32_t H, int32_t W, int32_t train, void *ws, size_t ws_bytes,
                          void *stream);
 
+/* BatchNorm2d -> ReLU -> MaxPool2d(3, stride 2, padding 1): the ResNet stem's tail (models/resnet.py:127-129,208-211 -- stock torch:
+ * BatchNorm apply, max_pool2d with an int64 index tensor, max_pool2d backward, BatchNorm backward).  mean / invstd are given
+ * (cpg_bn_stats_finalize after cpg_conv2d_fwd_bnstats in training, or the running statistics); the un-pooled activation is never
+ * written; backward recomputes it plane by plane in LDS, routes the pooled gradient to each window's first maximum (torch's rule)
+ * and applies the BatchNorm gradient (train != 0: batch statistics).  cpg_bn_relu_pool3_supported: rows of at most 512 pixels. */
+int32_t cpg_bn_relu_pool3_supported(int32_t H, int32_t W);
+int cpg_bn_relu_pool3_fwd(const float *x, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                          float *y_pooled, int32_t N, int32_t C, int32_t H, int32_t W, void *stream);
+int cpg_bn_relu_pool3_bwd(const float *x, const float *g_pooled, const float *gamma, const float *beta, const float *mean,
+                          const float *invstd, float *gx, float *dgamma, float *dbeta, int32_t N, int32_t C, int32_t H,
+                          int32_t W, int32_t train, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Backward of nn.PReLU on an NCHW tensor (SphereNet-20's activation after every masked conv,
  * models/spherenet.py:126-166 `relu{stage}_{i} = nn.PReLU(channels)`):
  *   gx = x > 0 ? gy : slope[c] * gy,   gslope[c] = sum_{n,hw} (x > 0 ? 0 : gy * x)

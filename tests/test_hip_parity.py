@@ -1335,6 +1335,43 @@ def test_fused_bn_relu_pool_matches_torch(N, C, H, W, training):
     close(bn.running_var, ref_bn.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6, msg='running_var')
 
 
+@pytest.mark.parametrize('N,C,H,W', [(4, 16, 56, 56), (2, 64, 112, 112), (3, 5, 7, 9), (2, 3, 1, 1), (2, 8, 16, 15)])
+@pytest.mark.parametrize('training', [True, False])
+def test_fused_bn_relu_pool3_matches_torch(N, C, H, W, training):
+    """BatchNorm2d -> ReLU -> MaxPool2d(3, 2, 1) (the ResNet stem's tail, models/resnet.py:127-129) as one forward and two backward
+    kernels against the stock modules: pooled output, input gradient (arg-max routing with torch's first-maximum rule, also among
+    the zeros ReLU produces), BatchNorm parameter gradients and running statistics."""
+    from cpg_amd.models import fused_bn
+    torch.manual_seed(N + C + H)
+    bn_a, bn_b = nn.BatchNorm2d(C).to(DEV), nn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bn_a.weight.uniform_(0.5, 1.5)
+        bn_a.bias.uniform_(-0.5, 0.5)
+        bn_a.running_mean.normal_(0, 0.3)
+        bn_a.running_var.uniform_(0.5, 2.0)
+    bn_b.load_state_dict(bn_a.state_dict())
+    bn_a.train(training)
+    bn_b.train(training)
+    pool, relu = nn.MaxPool2d(3, 2, 1), nn.ReLU(inplace=True)
+    x0 = torch.randn(N, C, H, W, device=DEV) * 1.5 + 0.2
+    xa, xb = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+    assert fused_bn._is_pool3(pool)
+    ya = fused_bn.conv_bn_act_pool(lambda t: t, bn_a, relu, pool, xa)
+    assert ya.grad_fn is not None and 'Pool3' in type(ya.grad_fn).__name__
+    yb = pool(relu(bn_b(xb)))
+    np.testing.assert_allclose(ya.detach().cpu().numpy(), yb.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    gy = torch.randn_like(yb)
+    ya.backward(gy)
+    yb.backward(gy)
+    sc = float(xb.grad.abs().max()) + 1e-12
+    np.testing.assert_allclose(xa.grad.cpu().numpy(), xb.grad.cpu().numpy(), rtol=1e-4, atol=2e-5 * sc + 2e-6)
+    for pa, pb in ((bn_a.weight, bn_b.weight), (bn_a.bias, bn_b.bias)):
+        sc = float(pb.grad.abs().max()) + 1e-12
+        np.testing.assert_allclose(pa.grad.cpu().numpy(), pb.grad.cpu().numpy(), rtol=1e-4, atol=1e-5 * sc)
+    np.testing.assert_allclose(bn_a.running_mean.cpu().numpy(), bn_b.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn_a.running_var.cpu().numpy(), bn_b.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize('N,C,H,W,relu,add', [(4, 128, 4, 4, 1, 0), (4, 64, 4, 4, 1, 0), (4, 128, 2, 2, 1, 0), (4, 16, 16, 16, 1, 0),
                                                (4, 32, 8, 8, 1, 0), (4, 256, 4, 4, 0, 0), (4, 256, 4, 4, 0, 1), (4, 512, 2, 2, 0, 1),
                                                (8, 64, 56, 56, 1, 0)])
