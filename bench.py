@@ -432,6 +432,32 @@ def cpu_baseline(budget_s=45.0, steps=220, batch=256, validates=11, prune_events
                          prune_s, val_s, b, steps, prune_events, validates)}
 
 
+# ---- 8-GPU prediction: what a SCALE run should show, so that a first hardware run can be judged in one read
+XGMI_LINK_GBS = 153.0                # MI355X_MICROARCH / task statement: 7 links x ~153 GB/s per GPU, point to point
+RCCL_ALLREDUCE_BUSBW_GBS = 310.0     # assumed large-message bus bandwidth of an 8-GPU RCCL all-reduce over xGMI (two links' worth)
+OVERLAP_SLOWDOWN = 1.17              # conv kernels beside 16 busy CUs' worth of other streams' kernels (tools/diag_interference.py)
+SINGLE_GPU_MS_PER_STEP = {'vgg16': 125.0, 'resnet50': 78.0, 'spherenet20': 22.3}   # batch 256, this repository's round-3 measurements
+
+
+def predict_step_ms(arch, world, buckets, measured_single_gpu_ms=None):
+    """Weak scaling (256 images per GPU): step = single-GPU step + what the gradient exchange adds.  All but the LAST messages
+    run under the remaining backward kernels (which slow down by OVERLAP_SLOWDOWN while RCCL holds CUs); the last message -- the
+    coalesced small tensors, issued after backward -- is exposed."""
+    t1 = measured_single_gpu_ms or SINGLE_GPU_MS_PER_STEP[arch]
+    if world <= 1:
+        return {'predicted_ms_per_step': t1, 'allreduce_ms_total': 0.0, 'exposed_ms': 0.0}
+    algbw = RCCL_ALLREDUCE_BUSBW_GBS * world / (2.0 * (world - 1))                  # GB/s of payload
+    per_msg_latency_ms = 0.03
+    total_ms = sum(b / 1e9 / algbw * 1e3 + per_msg_latency_ms for _, b in buckets)
+    last_ms = (buckets[-1][1] / 1e9 / algbw * 1e3 + per_msg_latency_ms) if buckets else 0.0
+    hidden = total_ms - last_ms
+    return {'predicted_ms_per_step': round(t1 + hidden * (OVERLAP_SLOWDOWN - 1.0) + last_ms, 3), 'allreduce_ms_total': round(total_ms, 3),
+            'exposed_ms': round(last_ms + hidden * (OVERLAP_SLOWDOWN - 1.0), 3), 'assumed_algbw_GBs': round(algbw, 1),
+            'assumed_busbw_GBs': RCCL_ALLREDUCE_BUSBW_GBS, 'single_gpu_ms_per_step': t1,
+            'model': 'step(N) = step(1) + (overlapped all-reduce time) x (%.2f - 1) + last message; messages priced at payload / algbw + 30 us'
+                     % OVERLAP_SLOWDOWN}
+
+
 def _free_port():
     import socket
     sk = socket.socket()
@@ -583,6 +609,12 @@ def main():
                                 'exposed_allreduce_ms_per_step': round(sync_ms / max(1, len(ev)), 3),
                                 'allreduced_gradient_bytes_per_step': int(sum(p.numel() for p in net.parameters() if p.requires_grad) * 4),
                                 'dropout_seed_rank0': dropout_seed, 'replicas_identical_after_cycle': replicas_identical}
+            # the messages of one train step in launch order (kind, bytes): 'chunk' = a row block of a very large linear weight
+            # handed over while its producer still runs, 'tensor' = one large gradient, 'packed' = the surviving slots of a
+            # layer, 'coalesced' = all small tensors (BatchNorm, biases, head) in one message after backward
+            buckets = list(model.last_bucket_log)
+            out['multi_gpu']['buckets'] = [{'kind': k, 'bytes': b} for k, b in buckets]
+            out['multi_gpu'].update(predict_step_ms(a.arch, world, buckets))
         agg = clock.summary()
         if agg:
             tot_ms = sum(v[1] for v in agg.values())

@@ -29,12 +29,45 @@ import torch.nn as nn
 from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
 
 
+class _ChunkedGradient(object):
+    """Hand-off between a masked linear layer's weight-gradient kernels and the gradient exchange for ONE very large weight
+    (VGG16 features.45: 4096 x 25088 = 411 MB): SharableLinear's backward computes the gradient in `nchunks` blocks of output rows
+    (independent GEMMs, each writes its rows of `buffer`) and calls ready() after launching each block, which starts that block's
+    all-reduce -- a single 411 MB message could only start after the whole weight-gradient kernel and could not overlap its own
+    producer; with 4 blocks, 3/4 of the exchange runs under the producer's remaining kernels.  Bits are unchanged: every output
+    row is computed by the same instruction sequence whichever block it is launched in."""
+
+    def __init__(self, owner, param, nchunks):
+        self.owner, self.param, self.nchunks = owner, param, int(nchunks)
+        self._buf = None
+        self.pending = []           # [(work, rows tensor)] of the current backward pass
+
+    def active(self):
+        """Chunk this step?  Not when the surviving slots are exchanged as a packed buffer (task >= 2: the payload is small)."""
+        o = self.owner
+        return o._active and (o._filter is None or o._plan(self.param) is None)
+
+    def buffer(self, like):
+        if self._buf is None or self._buf.shape != like.shape or self._buf.device != like.device:
+            self._buf = torch.empty_like(like)
+        return self._buf
+
+    def ready(self, rows):
+        o = self.owner
+        op = dist.ReduceOp.AVG if o._avg else dist.ReduceOp.SUM
+        self.pending.append((dist.all_reduce(rows, op=op, group=o.process_group, async_op=True), rows))
+        o.bucket_log.append(('chunk', rows.numel() * 4))
+
+
 class DataParallel(nn.Module):
-    def __init__(self, module, process_group=None, large_numel=1 << 20, broadcast_init=True):
+    def __init__(self, module, process_group=None, large_numel=1 << 20, broadcast_init=True, chunk_numel=1 << 26, nchunks=4):
         super().__init__()
         self.module = module
         self.process_group = process_group
         self.large_numel = int(large_numel)
+        self.chunk_numel, self.nchunks = int(chunk_numel), int(nchunks)       # weights at least this large go out in `nchunks` row blocks
+        self.bucket_log = []             # (kind, bytes) of every message of the current step, in launch order (bench.py reports it)
+        self.last_bucket_log = []
         # CPG_DP_FORCE=1: run the hooks / collectives even at world size 1 (functional test of the RCCL path on one GPU)
         self._active = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size(process_group) > 1 or os.environ.get('CPG_DP_FORCE') == '1')
@@ -47,6 +80,7 @@ class DataParallel(nn.Module):
             _lib.lib().cpg_set_shared_chip_hint(1)
         self._handles = []
         self._small = []
+        self._chunked = []               # [(param, _ChunkedGradient)] whose row blocks are in flight
         # marks the Parameters this wrapper has hooked: an attribute on the Parameter itself, which dies with it.  (A set of
         # id()s does not work: piggymasks are re-created between phases and CPython reuses the ids of the freed ones, so new
         # Parameters looked "already hooked" and their gradients were silently left un-reduced.)
@@ -78,6 +112,10 @@ class DataParallel(nn.Module):
                 m.weight._cpg_mask_key = (name, 0)
                 if m.piggymask is not None:
                     m.piggymask._cpg_mask_key = (name, 1)
+                # a very large linear weight: its backward hands the gradient over in row blocks (see _ChunkedGradient)
+                if (m.weight.dim() == 2 and m.weight.numel() >= self.chunk_numel and m.weight.shape[0] % self.nchunks == 0
+                        and getattr(m.weight, '_cpg_dp_chunk', None) is None):
+                    m.weight._cpg_dp_chunk = _ChunkedGradient(self, m.weight, self.nchunks)
 
     refresh_hooks = _install_hooks
 
@@ -126,6 +164,13 @@ class DataParallel(nn.Module):
     def _on_grad(self, p):
         if p.grad is None:
             return
+        ch = getattr(p, '_cpg_dp_chunk', None)
+        if ch is not None and ch.pending:
+            # already on the wire, block by block, since the weight-gradient kernels were launched; finish_gradient_sync() joins
+            self._step_payload['dense_elems'] += p.numel()
+            self._step_payload['sent_elems'] += p.numel()
+            self._chunked.append((p, ch))
+            return
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         plan = self._plan(p) if self._filter is not None else None
         self._step_payload['dense_elems'] += p.numel()
@@ -144,6 +189,7 @@ class DataParallel(nn.Module):
                                   ctypes.c_void_p(offsets.data_ptr()), _lib.dptr(buf), _lib.stream_ptr())
             _lib.check('cpg_pack_owned', rc)
             self._step_payload['sent_elems'] += total
+            self.bucket_log.append(('packed', total * 4))
             work = dist.all_reduce(buf, op=op, group=self.process_group, async_op=True)
             self._handles.append((work, buf, (g, owner, cur, select, offsets)))
             return
@@ -152,6 +198,7 @@ class DataParallel(nn.Module):
             g = p.grad
             if not g.is_contiguous():
                 p.grad = g = g.contiguous()
+            self.bucket_log.append(('tensor', g.numel() * 4))
             self._handles.append((dist.all_reduce(g, op=op, group=self.process_group, async_op=True), g, None))
         else:
             self._small.append(p)
@@ -173,6 +220,7 @@ class DataParallel(nn.Module):
         if self._small:
             grads = [p.grad for p in self._small]
             flat = _flatten_dense_tensors(grads)
+            self.bucket_log.append(('coalesced', flat.numel() * 4))
             if self._avg:
                 dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.process_group)
             else:
@@ -193,6 +241,16 @@ class DataParallel(nn.Module):
                                                  ctypes.c_void_p(offsets.data_ptr()), _lib.dptr(grad, name='grad'), _lib.stream_ptr())
                 _lib.check('cpg_unpack_owned', rc)
         self._handles = []
+        for p, ch in self._chunked:
+            for work, rows in ch.pending:
+                work.wait()
+                if not self._avg:
+                    rows.mul_(inv)
+            ch.pending = []
+            if p.grad.data_ptr() != ch._buf.data_ptr():          # (autograd copied instead of adopting the buffer)
+                p.grad.copy_(ch._buf)
+        self._chunked = []
+        self.last_bucket_log, self.bucket_log = self.bucket_log, []
         self.last_payload, self._step_payload = self._step_payload, {'dense_elems': 0, 'sent_elems': 0}
         if ev is not None:
             ev[1].record()

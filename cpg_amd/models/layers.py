@@ -230,6 +230,8 @@ class _MaskedLinearFn(torch.autograd.Function):
         _lib.check('cpg_linear_fwd', rc)
         ctx.save_for_backward(x2, w, p)
         ctx.thr, ctx.has_bias, ctx.lead = float(thr), bias is not None, lead
+        # data parallel: a very large weight hands its gradient to the exchange in row blocks (cpg_amd.dist._ChunkedGradient)
+        ctx.dp_chunk = getattr(weight, '_cpg_dp_chunk', None)
         return y
 
     @staticmethod
@@ -252,12 +254,27 @@ class _MaskedLinearFn(torch.autograd.Function):
                                     batch, fin, fout, _lib.dptr(ws), nbytes, s)
             _lib.check('cpg_linear_dgrad', rc)
         if ctx.needs_input_grad[1] or (p is not None and ctx.needs_input_grad[2]) or (ctx.has_bias and ctx.needs_input_grad[3]):
-            gw = torch.empty_like(w)
             gpm = None if p is None else torch.empty_like(p)
             gb = torch.empty(fout, dtype=torch.float32, device=x2.device) if ctx.has_bias else None
-            rc = L.cpg_linear_wgrad(_lib.dptr(x2), _lib.dptr(gy2), _lib.dptr(w), _lib.dptr(p), thr, _lib.dptr(gw),
-                                    _lib.dptr(gpm), _lib.dptr(gb), batch, fin, fout, _lib.dptr(ws), nbytes, s)
-            _lib.check('cpg_linear_wgrad', rc)
+            ch = getattr(ctx, 'dp_chunk', None)
+            if ch is not None and ch.active() and fout % ch.nchunks == 0:
+                # the same GEMM in blocks of output rows, each block's all-reduce started as soon as its kernels are launched
+                gw = ch.buffer(w)
+                rows = fout // ch.nchunks
+                wsc, nbc = _lib.workspace(L.cpg_linear_workspace_bytes(batch, fin, rows), x2.device)
+                for i in range(ch.nchunks):
+                    r0, r1 = i * rows, (i + 1) * rows
+                    gyc = gy2[:, r0:r1].contiguous()
+                    rc = L.cpg_linear_wgrad(_lib.dptr(x2), _lib.dptr(gyc), _lib.dptr(w[r0:r1]), _lib.dptr(None if p is None else p[r0:r1]), thr,
+                                            _lib.dptr(gw[r0:r1]), _lib.dptr(None if gpm is None else gpm[r0:r1]),
+                                            _lib.dptr(None if gb is None else gb[r0:r1]), batch, fin, rows, _lib.dptr(wsc), nbc, s)
+                    _lib.check('cpg_linear_wgrad', rc)
+                    ch.ready(gw[r0:r1])
+            else:
+                gw = torch.empty_like(w)
+                rc = L.cpg_linear_wgrad(_lib.dptr(x2), _lib.dptr(gy2), _lib.dptr(w), _lib.dptr(p), thr, _lib.dptr(gw),
+                                        _lib.dptr(gpm), _lib.dptr(gb), batch, fin, fout, _lib.dptr(ws), nbytes, s)
+                _lib.check('cpg_linear_wgrad', rc)
         return gx, gw, gpm, gb, None
 
 

@@ -186,6 +186,12 @@ def test_bench_self_launches_two_ranks(tmp_path):
     mg = out['multi_gpu']
     assert mg['backend'] == 'gloo' and len(mg['per_rank_ms_per_step']) == 2 and mg['replicas_identical_after_cycle'] is True
     assert mg['allreduced_gradient_bytes_per_step'] > 500e6
+    # the messages of a step in launch order and the step time a hardware run should show
+    kinds = [b['kind'] for b in mg['buckets']]
+    assert kinds.count('chunk') == 4 and kinds[-1] == 'coalesced', kinds       # features.45 goes out in 4 row blocks; small tensors last
+    assert kinds.index('chunk') < kinds.index('tensor') or 'tensor' in kinds[:2]  # (backward order: the classifier's layers first)
+    assert abs(sum(b['bytes'] for b in mg['buckets']) - mg['allreduced_gradient_bytes_per_step']) < 1e6
+    assert mg['predicted_ms_per_step'] > mg['single_gpu_ms_per_step'] > 0 and 0 < mg['exposed_ms'] < 5.0
     bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'],
                          env=dict(env, WORLD_SIZE='1', RANK='0'), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and 'WORLD_SIZE' in (bad.stderr + bad.stdout)

@@ -2012,5 +2012,34 @@ def test_data_parallel_wrapper_over_rccl_world1(monkeypatch):
         for n, p in net.named_parameters():
             if n in want:
                 np.testing.assert_allclose(p.grad.cpu().numpy(), want[n].cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=n)
+        # ---- the chunked exchange of a very large linear weight (VGG16 features.45 = 411 MB: cpg_amd.dist._ChunkedGradient): the
+        # weight gradient computed and handed to RCCL in 4 blocks of output rows must equal the one-piece gradient BIT FOR BIT
+        for pm_on in (False, True):
+            torch.manual_seed(11)
+            lin = nl.SharableLinear(640, 512).to(DEV)
+            nn.init.normal_(lin.weight, 0, 0.05)
+            nn.init.normal_(lin.bias, 0, 0.1)
+            if pm_on:
+                lin.piggymask = nn.Parameter(torch.rand(512, 640, device=DEV) * 0.012)
+            xin = torch.randn(48, 640, device=DEV)
+            gout = torch.randn(48, 512, device=DEV)
+            res = {}
+            for chunked in (False, True):
+                lin.zero_grad(set_to_none=True)
+                for prm in lin.parameters():
+                    for attr in ('_cpg_dp_chunk', '_cpg_dp_token'):
+                        if hasattr(prm, attr):
+                            delattr(prm, attr)
+                dp = cdist.DataParallel(lin, large_numel=1 << 10, chunk_numel=(1 << 12) if chunked else (1 << 40), nchunks=4)
+                assert (getattr(lin.weight, '_cpg_dp_chunk', None) is not None) == chunked
+                xi = xin.clone().requires_grad_(True)
+                dp(xi).backward(gout)
+                dp.finish_gradient_sync()
+                torch.cuda.synchronize()
+                kinds = [k for k, _ in dp.last_bucket_log]
+                assert (kinds.count('chunk') == 4) == chunked, kinds
+                res[chunked] = [xi.grad.clone()] + [prm.grad.clone() for prm in lin.parameters()]
+            for a, b in zip(res[False], res[True]):
+                assert torch.equal(a, b), 'chunked and one-piece gradients differ (piggymask %s)' % pm_on
     finally:
         dist.destroy_process_group()
