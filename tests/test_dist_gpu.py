@@ -169,6 +169,57 @@ def test_two_ranks_hip_model_masked_sgd_prune_match_single_process(tmp_path):
     assert released > 0.05 * total                         # the prune events really released weights
 
 
+def _driver_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from cpg_amd.driver import CPGSession, default_args
+        dev = 'cuda:0'
+
+        def data(seed, n=8):
+            g = torch.Generator().manual_seed(seed)
+            t = torch.randint(0, 5, (n,), generator=g)
+            x = 0.5 * torch.randn(n, 3, 32, 32, generator=g)
+            for i in range(n):
+                c = int(t[i])
+                x[i, c % 3, (c * 5) % 16:(c * 5) % 16 + 12, (c * 6) % 20:(c * 6) % 20 + 12] += 2.0
+            return x.to(dev), t.to(dev)
+        # every rank its OWN shard of the training batches (rank-dependent seeds): the local train accuracies differ
+        train = [data(100 + 10 * i + rank) for i in range(4)]
+        val = [data(900 + i) for i in range(2)]
+        sess = CPGSession('custom_vgg_cifar100', 0.125, device=dev, seed=1)
+        args = default_args(lr=5e-2, lr_mask=5e-4, pruning_frequency=1, pruning_interval=1, prune_lr=1e-2)
+        # an unreachable goal at the first width forces the grow branch; min_train_acc sits where shard accuracies can straddle it
+        res = sess.run_task('t1', 5, train, val, accuracy_goal=2.0, finetune_epochs=1, prune_epochs=1, sparsities=(0.2, 0.4), args=args,
+                            min_train_acc=0.3, max_width=0.25, width_step=0.125)
+        torch.cuda.synchronize()
+        torch.save({'res': {'grown_to': res.grown_to, 'ratio_to_acc': res.ratio_to_acc, 'chosen_ratio': res.chosen_ratio,
+                            'finetune_train_acc': res.finetune_train_acc, 'finetune_acc': res.finetune_acc},
+                    'sd': {k: v.detach().cpu() for k, v in sess.net.state_dict().items()},
+                    'masks': {k: v.cpu() for k, v in sess.masks.items()}}, os.path.join(out_dir, 'drv_rank%d.pt' % rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_driver_decisions_are_rank_identical(tmp_path):
+    """CPGSession.run_task branches on the train / validation accuracies (grow, stop the sweep, choose the ratio).
+    Under data parallelism every rank must take the SAME branch -- Manager returns metrics over the global batches -- or the ranks'
+    collectives mismatch (a hang) and their networks get different widths.  Two ranks with different shards run a task that grows."""
+    import torch.multiprocessing as mp
+    mp.spawn(_driver_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'drv_rank0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'drv_rank1.pt'))
+    assert r0['res'] == r1['res'], (r0['res'], r1['res'])
+    assert r0['res']['grown_to'] == [0.25]                      # the goal was missed at width 0.125: both ranks widened once
+    for k in r0['sd']:
+        assert torch.equal(r0['sd'][k], r1['sd'][k]), 'ranks diverged in %s' % k
+    for k in r0['masks']:
+        assert torch.equal(r0['masks'][k], r1['masks'][k]), 'ranks diverged in mask %s' % k
+
+
 def test_bench_self_launches_two_ranks(tmp_path):
     """`python bench.py --gpus 2` started WITHOUT torch.distributed.run must become two ranks by itself (gloo here: the box
     has one GPU) and print n_gpus = 2 with the multi_gpu block; a world size that contradicts --gpus is refused."""
