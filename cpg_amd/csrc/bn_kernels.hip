@@ -1081,3 +1081,56 @@ extern "C" int cpg_prelu_bwd(const float *x, const float *gy, const float *slope
     CPG_CHECK_LAUNCH("cpg_prelu_bwd");
     return CPG_OK;
 }
+
+// PReLU forward with the residual add of SphereNet's units folded in (models/spherenet.py:219-247: x = x + relu_b(conv_b(relu_a(conv_a(x))))):
+// y = res + (v > 0 ? v : a[c] v), res may be null.  One pass (stock: prelu kernel, then an add kernel).
+namespace {
+template <int GROUP>
+__global__ __launch_bounds__(kThreads) void k_prelu_fwd(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ slope,
+                                                        float *__restrict__ y, BnDims d, int per_channel) {
+    const int64_t planes = (int64_t)d.N * d.C;
+    const bool vec = (d.HW & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 15) == 0 && (((uintptr_t)res) & 15) == 0;
+    const int gl = threadIdx.x % GROUP;
+    const int64_t g0 = (int64_t)blockIdx.x * (kThreads / GROUP) + threadIdx.x / GROUP;
+    const int64_t gstride = (int64_t)gridDim.x * (kThreads / GROUP);
+    for (int64_t pl = g0; pl < planes; pl += gstride) {
+        const float a = slope[per_channel ? (int)(pl % d.C) : 0];
+        const float *p = x + pl * d.HW;
+        const float *r = res ? res + pl * d.HW : nullptr;
+        float *q = y + pl * d.HW;
+        if (vec) {
+            for (int i = gl; i < d.HW / 4; i += GROUP) {
+                float4 v = reinterpret_cast<const float4 *>(p)[i];
+                v.x = v.x > 0.f ? v.x : a * v.x; v.y = v.y > 0.f ? v.y : a * v.y;
+                v.z = v.z > 0.f ? v.z : a * v.z; v.w = v.w > 0.f ? v.w : a * v.w;
+                if (r != nullptr) {
+                    const float4 t = reinterpret_cast<const float4 *>(r)[i];
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                reinterpret_cast<float4 *>(q)[i] = v;
+            }
+        } else {
+            for (int i = gl; i < d.HW; i += GROUP) {
+                const float v = p[i];
+                q[i] = (v > 0.f ? v : a * v) + (r ? r[i] : 0.f);
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int cpg_prelu_fwd(const float *x, const float *res, const float *slope, float *y, int32_t N, int32_t C, int32_t HW,
+                             int32_t n_slopes, void *stream_v) {
+    BnDims d;
+    int rc = make_dims(N, C, HW, d);
+    if (rc) return rc;
+    CPG_REQUIRE(x && slope && y, "cpg_prelu_fwd: null pointer");
+    CPG_REQUIRE(n_slopes == C || n_slopes == 1, "cpg_prelu_fwd: n_slopes must be C or 1");
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (wave_planes(d))
+        hipLaunchKernelGGL(k_prelu_fwd<64>, dim3(plane_grid(d)), dim3(kThreads), 0, stream, x, res, slope, y, d, n_slopes == C ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_prelu_fwd<256>, dim3(plane_grid(d)), dim3(kThreads), 0, stream, x, res, slope, y, d, n_slopes == C ? 1 : 0);
+    CPG_CHECK_LAUNCH("cpg_prelu_fwd");
+    return CPG_OK;
+}

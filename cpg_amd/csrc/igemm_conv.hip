@@ -537,7 +537,7 @@ int cpg_conv1x1_fwd(const cpg_conv_desc *d, const float *x, const float *w, cons
                     float *y, void *ws, size_t ws_bytes, hipStream_t stream, float *stats = nullptr);
 int cpg_conv1x1_bnstats_tiles(const cpg_conv_desc *d);
 int cpg_conv1x1_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx, void *ws,
-                      size_t ws_bytes, hipStream_t stream);
+                      size_t ws_bytes, hipStream_t stream, const float *addend = nullptr);
 extern "C" int cpg_conv1x1_wgrad_supported(const cpg_conv_desc *d);
 size_t cpg_conv1x1_wgrad_workspace(const cpg_conv_desc *d);
 int cpg_conv1x1_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm, float thr,
@@ -740,6 +740,17 @@ extern "C" int cpg_conv2d_dgrad(const cpg_conv_desc *d, const float *gy, const f
     if (d && cpg_conv1x1_supported(d)) return cpg_conv1x1_dgrad(d, gy, w, pm, thr, gx, ws, ws_bytes, (hipStream_t)stream);
     if (d && cpg_conv3x3s2_supported(d)) return cpg_conv3x3s2_dgrad(d, gy, w, pm, thr, gx, ws, ws_bytes, (hipStream_t)stream);
     return cpg_conv2d_dgrad_generic(d, gy, w, pm, thr, gx, stream);
+}
+
+// input gradient + addend (the gradient of the input's other consumer): dense pointwise layers only
+extern "C" int32_t cpg_conv2d_dgrad_add_supported(const cpg_conv_desc *d) {
+    return d && !cpg_conv3x3_supported(d) && cpg_conv1x1_supported(d) && d->stride_h == 1 && d->stride_w == 1 ? 1 : 0;
+}
+extern "C" int cpg_conv2d_dgrad_add(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, const float *addend,
+                                    float *gx, void *ws, size_t ws_bytes, void *stream) {
+    if (!cpg_conv2d_dgrad_add_supported(d)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_dgrad_add: only dense 1x1 layers fuse the addend");
+    CPG_REQUIRE(addend != nullptr, "cpg_conv2d_dgrad_add: null addend");
+    return cpg_conv1x1_dgrad(d, gy, w, pm, thr, gx, ws, ws_bytes, (hipStream_t)stream, addend);
 }
 
 extern "C" int cpg_conv2d_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm,

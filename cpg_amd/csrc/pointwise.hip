@@ -85,10 +85,14 @@ __global__ __launch_bounds__(256) void k_pw_pack(const float *__restrict__ w, co
 // STATS (forward only): the block also writes, per output channel, the sum and the sum of squares of its 224 outputs ->
 // stats[channel][pixel tile][2], the partial sums of the training-mode BatchNorm2d that follows every pointwise conv of the
 // ResNet topologies (models/resnet.py:86-98) -- cpg_bn_stats_finalize merges them, no statistics pass over y (cf. k_c3_fwd).
-template <class Cfg, bool DGRAD, bool STATS = false>
+// ADD (input-gradient launches): y = result + addend, elementwise at the stored positions -- the gradient of the OTHER consumer of the
+// conv's input (a residual block's identity branch, models/resnet.py:84,104: `out += identity`), which autograd would otherwise add
+// in a separate 3-pass kernel.
+template <class Cfg, bool DGRAD, bool STATS = false, bool ADD = false>
 __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__restrict__ x, const float *__restrict__ wp,
                                                        const float *__restrict__ bias, float *__restrict__ y,
-                                                       float *__restrict__ stats = nullptr) {
+                                                       float *__restrict__ stats = nullptr, const float *__restrict__ addend = nullptr) {
+    static_assert(!ADD || (DGRAD && !STATS), "the addend rides in plain input-gradient launches");
     static_assert(!STATS || (!DGRAD && Cfg::WN == 1), "statistics ride in forward launches whose waves own whole channel rows");
     __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -220,12 +224,20 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
         const long long gg = g0 + (wn * Cfg::FN + fn) * 32 + li;
         const bool pok = gg < g.G;
         const int n = pok ? (int)(gg / g.HWo) : 0, q = pok ? (int)(gg % g.HWo) : 0;
-        float *yout = y + (int64_t)n * g.M * g.out_plane + (q / g.OW) * g.out_sy + (q % g.OW) * g.out_sx;
+        const int64_t yoff = (int64_t)n * g.M * g.out_plane + (q / g.OW) * g.out_sy + (q % g.OW) * g.out_sx;
+        float *yout = y + yoff;
 #pragma unroll
         for (int fm = 0; fm < Cfg::FM; ++fm) {
             float bv[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) bv[e] = 0.0f;
+            if (ADD) {                       // 16 loads issued together, consumed by the stores below
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    bv[e] = (pok && co < g.M) ? addend[yoff + (int64_t)co * g.out_plane] : 0.0f;
+                }
+            }
             if (bias != nullptr) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -496,18 +508,25 @@ inline size_t pack_bytes(int c_read, int m) { return ((size_t)pad_to(c_read, 16)
 
 template <class Cfg, bool DGRAD>
 int launch(PwGeom g, const float *x, const float *wp, const float *bias, float *y, hipStream_t stream, const char *what,
-           float *stats = nullptr) {
+           float *stats = nullptr, const float *addend = nullptr) {
     g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
     const int64_t blocks = (g.G + Cfg::BN - 1) / Cfg::BN * g.tiles_m;
     if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "conv1x1: grid too large");
     if constexpr (!DGRAD) {
         if (stats != nullptr) {
-            hipLaunchKernelGGL((k_pw<Cfg, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, stats);
+            hipLaunchKernelGGL((k_pw<Cfg, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, stats, (const float *)nullptr);
             CPG_CHECK_LAUNCH(what);
             return CPG_OK;
         }
     }
-    hipLaunchKernelGGL((k_pw<Cfg, DGRAD>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, (float *)nullptr);
+    if constexpr (DGRAD) {
+        if (addend != nullptr) {
+            hipLaunchKernelGGL((k_pw<Cfg, true, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, (float *)nullptr, addend);
+            CPG_CHECK_LAUNCH(what);
+            return CPG_OK;
+        }
+    }
+    hipLaunchKernelGGL((k_pw<Cfg, DGRAD>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, (float *)nullptr, (const float *)nullptr);
     CPG_CHECK_LAUNCH(what);
     return CPG_OK;
 }
@@ -553,7 +572,7 @@ int cpg_conv1x1_fwd(const cpg_conv_desc *d, const float *x, const float *w, cons
 }
 
 int cpg_conv1x1_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, float *gx, void *ws,
-                      size_t ws_bytes, hipStream_t stream) {
+                      size_t ws_bytes, hipStream_t stream, const float *addend) {
     const char *what = "cpg_conv2d_dgrad(1x1)";
     CPG_REQUIRE(gy && w && gx, "%s: null pointer", what);
     const size_t need = pack_bytes(d->K, d->C);
@@ -570,8 +589,9 @@ int cpg_conv1x1_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, c
     }
     // reads gy (K channels, dense over the output grid), produces gx (C channels) at the strided positions
     PwGeom g{d->N, d->K, d->C, Mp, OW, OH * OW, OH * OW, OW, 1, d->H * d->W, d->stride_h * d->W, d->stride_w, 0, (long long)d->N * OH * OW};
-    if ((OH * OW) % 4 == 0 && (((uintptr_t)gy) & 15) == 0) return launch<PwV, true>(g, gy, wp, nullptr, gx, stream, what);
-    return launch<PwS, true>(g, gy, wp, nullptr, gx, stream, what);
+    if (addend != nullptr && !dense) return fail(CPG_E_UNSUPPORTED, "%s: the fused addend needs a dense (stride 1) layer", what);
+    if ((OH * OW) % 4 == 0 && (((uintptr_t)gy) & 15) == 0) return launch<PwV, true>(g, gy, wp, nullptr, gx, stream, what, nullptr, addend);
+    return launch<PwS, true>(g, gy, wp, nullptr, gx, stream, what, nullptr, addend);
 }
 
 // dense pointwise layers whose activations can be staged as aligned float4 and addressed with 31-bit byte offsets

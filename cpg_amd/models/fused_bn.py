@@ -311,17 +311,28 @@ def bn_relu(x, bn, relu=True, stats=None, hint=None):
 
 
 class _PReluFn(torch.autograd.Function):
-    """nn.PReLU with the stock forward and a one-pass HIP backward (cpg_prelu_bwd)."""
+    """nn.PReLU (+ an optional residual added to its output: SphereNet's `x + relu(conv(y))`) as one forward pass (cpg_prelu_fwd)
+    and a one-pass backward (cpg_prelu_bwd); the residual's gradient is the incoming gradient itself."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, res=None):
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // max(N * C, 1)
+        y = torch.empty_like(x)
+        if x.numel():
+            rc = _lib.lib().cpg_prelu_fwd(_lib.dptr(x, name='input'), _lib.dptr(res, name='residual'), _lib.dptr(weight, name='prelu.weight'),
+                                          _lib.dptr(y), N, C, HW, weight.numel(), _lib.stream_ptr())
+            _lib.check('cpg_prelu_fwd', rc)
         ctx.save_for_backward(x, weight)
-        return torch.nn.functional.prelu(x, weight)
+        ctx.has_res = res is not None
+        return y
 
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
+        if not x.numel():
+            return torch.zeros_like(x), torch.zeros_like(weight), (gy if ctx.has_res else None)
         N, C = x.shape[0], x.shape[1]
         HW = x.numel() // (N * C)
         L = _lib.lib()
@@ -330,15 +341,17 @@ class _PReluFn(torch.autograd.Function):
         gw = torch.empty_like(weight)
         _lib.check('cpg_prelu_bwd', L.cpg_prelu_bwd(_lib.dptr(x), _lib.dptr(gy), _lib.dptr(weight), _lib.dptr(gx), _lib.dptr(gw),
                                                     N, C, HW, weight.numel(), _lib.dptr(ws), nb, _lib.stream_ptr()))
-        return gx, gw
+        return gx, gw, (gy if ctx.has_res else None)
 
 
-def prelu(mod, x):
-    """mod(x) for an nn.PReLU module (models/spherenet.py); HIP backward when the tensor qualifies."""
+def prelu(mod, x, res=None):
+    """mod(x) [+ res] for an nn.PReLU module (models/spherenet.py); HIP kernels when the tensor qualifies."""
     if (ENABLED and type(mod) is nn.PReLU and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
-            and mod.weight.numel() in (1, x.shape[1])):
-        return _PReluFn.apply(x, mod.weight)
-    return mod(x)
+            and mod.weight.numel() in (1, x.shape[1]) and (res is None or (res.shape == x.shape and res.is_contiguous()
+                                                                            and res.dtype == torch.float32 and res.is_cuda))):
+        return _PReluFn.apply(x, mod.weight, res)
+    y = mod(x)
+    return y if res is None else res + y
 
 
 ENABLED = True      # module-wide switch (tests compare the fused against the stock evaluation)
@@ -382,6 +395,25 @@ def conv_bn_act(conv, bn, act, x):
     if stats is not None and (act is None or type(act) is nn.ReLU) and fusable(bn, y):
         return bn_relu(y, bn, relu=act is not None, stats=stats)
     return bn_act(bn, act, y)
+
+
+FUSE_SKIP_ADD = True       # residual blocks: the identity branch's gradient is added in conv1's input-gradient epilogue
+
+
+def conv_bn_act_skip(conv, bn, act, x):
+    """(act(bn(conv(x))), x for the identity branch): conv_bn_act for the first conv of a residual block WITHOUT a downsample path
+    (models/resnet.py:84-104).  When the conv's input gradient can take an addend (dense 1x1 layers), x is routed through the conv's
+    autograd node, which then receives both of x's gradients and sums them in its kernel's epilogue."""
+    if (ENABLED and FUSE_SKIP_ADD and hasattr(conv, 'forward_with_skip') and x.is_cuda and torch.is_grad_enabled() and x.requires_grad
+            and conv._math() == 'fp32' and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.in_channels % 16 == 0
+            and conv.out_channels % 16 == 0):
+        y, stats, skip = conv.forward_with_skip(x)
+        use_stats = (stats is not None and FusedSequential.fuse_stats and isinstance(bn, nn.BatchNorm2d) and bn.training and bn.track_running_stats
+                     and bn.affine and bn.momentum is not None)
+        if use_stats and (act is None or type(act) is nn.ReLU) and fusable(bn, y):
+            return bn_relu(y, bn, relu=act is not None, stats=stats), skip
+        return bn_act(bn, act, y), skip
+    return conv_bn_act(conv, bn, act, x), x
 
 
 def conv_bn_add_act(conv, bn, act, x, res):

@@ -148,7 +148,9 @@ class _MaskedConv2dFn(torch.autograd.Function):
         return y, stats
 
     @staticmethod
-    def backward(ctx, gy, _gstats=None):
+    def backward(ctx, gy, _gstats=None, addend=None):
+        """addend (only from _MaskedConv2dSkipFn): a tensor shaped like the input gradient that is added to it -- in the kernel's
+        epilogue where the shape class has that (cpg_conv2d_dgrad_add), by one add otherwise."""
         x, w, p = ctx.saved_tensors
         d, thr = ctx.desc, ctx.thr
         if ctx.empty:
@@ -180,10 +182,18 @@ class _MaskedConv2dFn(torch.autograd.Function):
                                               _lib.dptr(ws), nbytes, s)
                 _lib.check('cpg_conv2d_dgrad_bnbwd', rc)
                 hint.partials, hint.tiles = partials, tiles
+            elif addend is not None and L.cpg_conv2d_dgrad_add_supported(ctypes.byref(d)) and addend.shape == x.shape:
+                addend = addend.contiguous()
+                rc = L.cpg_conv2d_dgrad_add(ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr,
+                                            _lib.dptr(addend, name='skip gradient'), _lib.dptr(gx), _lib.dptr(ws), nbytes, s)
+                _lib.check('cpg_conv2d_dgrad_add', rc)
+                addend = None
             else:
                 rc = L.cpg_conv2d_dgrad(ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr,
                                         _lib.dptr(gx), _lib.dptr(ws), nbytes, s)
                 _lib.check('cpg_conv2d_dgrad', rc)
+        if addend is not None:                  # (no fused path for this launch)
+            gx = addend.clone() if gx is None else gx.add_(addend)
         if ctx.needs_input_grad[1] or (p is not None and ctx.needs_input_grad[2]) or (ctx.has_bias and ctx.needs_input_grad[3]):
             gw = torch.empty_like(w)
             gpm = None if p is None else torch.empty_like(p)
@@ -199,6 +209,24 @@ class _MaskedConv2dFn(torch.autograd.Function):
                                         _lib.dptr(gw), _lib.dptr(gpm), _lib.dptr(gb), _lib.dptr(ws), nbytes, s)
                 _lib.check('cpg_conv2d_wgrad', rc)
         return gx, gw, gpm, gb, None, None, None, None, None, None, None, None
+
+
+class _MaskedConv2dSkipFn(torch.autograd.Function):
+    """(y, stats, skip) = conv2d(x), its BatchNorm partial sums (or an empty tensor) and x itself, for a residual block whose input
+    feeds this conv AND the identity branch (models/resnet.py:84-104).  Being the input's only consumer, the Function receives both
+    gradients and folds their sum into the input-gradient kernel's epilogue instead of leaving it to a separate add kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, pm, bias, thr, stride, padding, dilation, groups, math):
+        y, stats = _MaskedConv2dFn.forward(ctx, x, weight, pm, bias, thr, stride, padding, dilation, groups, True, math, None)
+        return y, stats, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, _gstats, gskip):
+        if gy is None:                           # the conv branch is unused: only the skip gradient flows
+            return (gskip,) + (None,) * 9
+        r = _MaskedConv2dFn.backward(ctx, gy, None, addend=gskip)
+        return r[:4] + (None,) * 6
 
 
 class _MaskedLinearFn(torch.autograd.Function):
@@ -338,6 +366,13 @@ class SharableConv2d(_Sharable):
         y, stats = _MaskedConv2dFn.apply(input, self.weight, self.piggymask, self.bias, self.info['threshold'],
                                          self.stride, self.padding, self.dilation, self.groups, True, self._math(), bn_hint)
         return y, (stats if stats.numel() else None)
+
+    def forward_with_skip(self, input):
+        """(y, stats or None, skip): forward (+ BatchNorm partial sums where the shape has them) and the input handed back for the
+        residual branch; the two gradients of the input are summed inside the input-gradient kernel (_MaskedConv2dSkipFn)."""
+        y, stats, skip = _MaskedConv2dSkipFn.apply(input, self.weight, self.piggymask, self.bias, self.info['threshold'],
+                                                   self.stride, self.padding, self.dilation, self.groups, self._math())
+        return y, (stats if stats.numel() else None), skip
 
     def forward_bn_eval(self, input, bn, relu=True, skip_stats=None):
         """relu(bn(conv(input))) with `bn` an eval-mode nn.BatchNorm2d, as ONE kernel (cpg_conv2d_fwd_bn_eval): the path of

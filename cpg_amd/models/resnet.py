@@ -8,7 +8,7 @@ network_width_multiplier with the reference's int() placement; heads are per-tas
 import torch.nn as nn
 
 from . import layers as nl
-from .fused_bn import FusedSequential, conv_bn_act, conv_bn_act_pool, conv_bn_add_act
+from .fused_bn import FusedSequential, conv_bn_act, conv_bn_act_pool, conv_bn_act_skip, conv_bn_add_act
 
 __all__ = ['ResNet', 'BasicBlock', 'Bottleneck', 'resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152',
            'resnext50_32x4d', 'resnext101_32x8d']
@@ -66,9 +66,12 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = conv_bn_act(self.conv1, self.bn1, self.relu, x)
+        if self.downsample is None:
+            out, identity = conv_bn_act_skip(self.conv1, self.bn1, self.relu, x)
+        else:
+            out, identity = conv_bn_act(self.conv1, self.bn1, self.relu, x), self.downsample(x)
         out = conv_bn_act(self.conv2, self.bn2, self.relu, out)
-        return conv_bn_add_act(self.conv3, self.bn3, self.relu, out, x if self.downsample is None else self.downsample(x))
+        return conv_bn_add_act(self.conv3, self.bn3, self.relu, out, identity)
 
 
 class ResNet(nn.Module):

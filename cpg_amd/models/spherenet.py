@@ -105,7 +105,7 @@ class SphereNet(nn.Module):
             for u in range(units):
                 a, b = 2 * u + 2, 2 * u + 3
                 y = prelu(getattr(self, 'relu%d_%d' % (stage, a)), getattr(self, 'conv%d_%d' % (stage, a))(x))
-                x = x + prelu(getattr(self, 'relu%d_%d' % (stage, b)), getattr(self, 'conv%d_%d' % (stage, b))(y))
+                x = prelu(getattr(self, 'relu%d_%d' % (stage, b)), getattr(self, 'conv%d_%d' % (stage, b))(y), res=x)
         return self.flatten(x)
 
     def forward(self, x):

@@ -103,6 +103,12 @@ int cpg_conv2d_fwd(const cpg_conv_desc *d, const float *x, const float *w, const
                    float thr, const float *bias, float *y, void *ws, size_t ws_bytes, void *stream);
 int cpg_conv2d_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm,
                      float thr, float *gx, void *ws, size_t ws_bytes, void *stream);
+/* Input gradient with the gradient of the input's OTHER consumer added in the epilogue: gx = dgrad(gy) + addend.  A residual block's
+ * input feeds conv1 and the identity branch (models/resnet.py:84-104); autograd would sum the two gradients in a separate 3-pass
+ * kernel.  Dense 1x1 layers only (cpg_conv2d_dgrad_add_supported); addend is shaped like gx and may not alias it. */
+int32_t cpg_conv2d_dgrad_add_supported(const cpg_conv_desc *desc);
+int cpg_conv2d_dgrad_add(const cpg_conv_desc *desc, const float *gy, const float *w, const float *piggymask, float threshold,
+                         const float *addend, float *gx, void *workspace, size_t workspace_bytes, void *stream);
 int cpg_conv2d_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w,
                      const float *pm, float thr, float *gw, float *gpm, float *gb,
                      void *ws, size_t ws_bytes, void *stream);
@@ -334,6 +340,10 @@ int cpg_bn_relu_pool3_bwd(const float *x, const float *g_pooled, const float *ga
 size_t cpg_prelu_workspace_bytes(int32_t N, int32_t C, int32_t HW);
 int cpg_prelu_bwd(const float *x, const float *gy, const float *slope, float *gx, float *gslope, int32_t N,
                   int32_t C, int32_t HW, int32_t n_slopes, void *ws, size_t ws_bytes, void *stream);
+/* PReLU forward with the residual add of a SphereNet unit folded in (models/spherenet.py:219-247: x + relu(conv(.))):
+ * y = residual + (x > 0 ? x : slope[c] x); residual may be NULL.  One pass instead of torch's prelu + add kernels. */
+int cpg_prelu_fwd(const float *x, const float *residual, const float *slope, float *y, int32_t N, int32_t C, int32_t HW,
+                  int32_t n_slopes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1634,6 +1634,53 @@ def test_resnet_block_fused_bn_equals_stock_bn(block, stride):
         assert float(np.abs(g1[n] - g0[n]).max()) <= 1e-3 * sc, n
 
 
+@pytest.mark.parametrize('N,C,K,H', [(6, 64, 16, 28), (3, 256, 64, 14), (5, 32, 16, 7)])
+def test_skip_gradient_in_the_input_gradient_epilogue(N, C, K, H):
+    """A residual block without a downsample path: its input feeds conv1 (1x1) and the identity branch.  Routed through
+    SharableConv2d.forward_with_skip the two gradients of the input meet inside conv1's input-gradient kernel (cpg_conv2d_dgrad_add)
+    instead of a separate add -- same values as the plain composition, and the fused entry point is really the one that runs."""
+    from cpg_amd import _lib
+    torch.manual_seed(C + K)
+    conv = nl.SharableConv2d(C, K, 1, bias=False).to(DEV)
+    nn.init.kaiming_normal_(conv.weight, mode='fan_out', nonlinearity='relu')
+    conv.piggymask = nn.Parameter(torch.rand(K, C, 1, 1, device=DEV) * 0.012)
+    x0 = torch.randn(N, C, H, H, device=DEV)
+    gy, gs = torch.randn(N, K, H, H, device=DEV), torch.randn(N, C, H, H, device=DEV)
+    calls = []
+    L = _lib.lib()
+    raw = L.cpg_conv2d_dgrad_add
+
+    class Spy(object):
+        def __getattr__(self, name):
+            if name == 'cpg_conv2d_dgrad_add':
+                def f(*a):
+                    calls.append(1)
+                    return raw(*a)
+                return f
+            return getattr(L, name)
+    res = {}
+    for fused in (True, False):
+        conv.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        if fused:
+            old, _lib._lib = _lib._lib, Spy()
+            try:
+                y, stats, skip = conv.forward_with_skip(x)
+                (y * gy).sum().backward(retain_graph=True, inputs=[conv.weight])       # conv branch alone first: no addend yet
+                conv.zero_grad()
+                ((y * gy).sum() + (skip * gs).sum()).backward()
+            finally:
+                _lib._lib = old
+        else:
+            y = conv(x)
+            ((y * gy).sum() + (x * gs).sum()).backward()
+        res[fused] = (y.detach().clone(), x.grad.clone(), conv.weight.grad.clone(), conv.piggymask.grad.clone())
+    assert calls, 'the fused input-gradient entry point did not run'
+    for a, b in zip(res[True], res[False]):
+        sc = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-6 * sc
+
+
 @pytest.mark.parametrize('N,C,H,W,shared', [(8, 64, 56, 56, False), (5, 12, 7, 9, False), (3, 16, 28, 28, True), (2, 3, 1, 1, False)])
 def test_prelu_backward_matches_torch(N, C, H, W, shared):
     """cpg_prelu_bwd (one pass, deterministic slope reduction) against torch's PReLU backward."""
@@ -1644,21 +1691,27 @@ def test_prelu_backward_matches_torch(N, C, H, W, shared):
     mod = nn.PReLU(1 if shared else C).to(DEV)
     with torch.no_grad():
         mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) - 0.3)
-    out = {}
-    for enabled in (True, False):
-        fused_bn.ENABLED = enabled
-        try:
-            xi = x.clone().requires_grad_(True)
-            mod.zero_grad()
-            y = fused_bn.prelu(mod, xi)
-            y.backward(gy)
-        finally:
-            fused_bn.ENABLED = True
-        out[enabled] = (y.detach().cpu().numpy(), xi.grad.cpu().numpy(), mod.weight.grad.cpu().numpy())
-    np.testing.assert_array_equal(out[True][0], out[False][0])
-    np.testing.assert_array_equal(out[True][1], out[False][1])
-    sc = float(np.abs(out[False][2]).max()) + 1e-12
-    np.testing.assert_allclose(out[True][2], out[False][2], rtol=1e-4, atol=1e-5 * sc)
+    res0 = torch.randn(N, C, H, W, generator=g).to(DEV)
+    for with_res in (False, True):          # with_res: SphereNet's `x + relu(conv(y))` -- the residual add folded into the forward pass
+        out = {}
+        for enabled in (True, False):
+            fused_bn.ENABLED = enabled
+            try:
+                xi = x.clone().requires_grad_(True)
+                ri = res0.clone().requires_grad_(True)
+                mod.zero_grad()
+                y = fused_bn.prelu(mod, xi, res=ri if with_res else None)
+                y.backward(gy)
+            finally:
+                fused_bn.ENABLED = True
+            out[enabled] = (y.detach().cpu().numpy(), xi.grad.cpu().numpy(), mod.weight.grad.cpu().numpy(),
+                            ri.grad.cpu().numpy() if with_res else None)
+        np.testing.assert_allclose(out[True][0], out[False][0], rtol=0, atol=0 if not with_res else 1e-6)
+        np.testing.assert_array_equal(out[True][1], out[False][1])
+        sc = float(np.abs(out[False][2]).max()) + 1e-12
+        np.testing.assert_allclose(out[True][2], out[False][2], rtol=1e-4, atol=1e-5 * sc)
+        if with_res:
+            np.testing.assert_array_equal(out[True][3], out[False][3])
 
 
 @pytest.mark.parametrize('N,C,K,H,W,pool', [(4, 16, 64, 56, 56, False), (6, 64, 128, 28, 28, True), (5, 32, 160, 14, 14, True),
