@@ -1007,6 +1007,9 @@ extern "C" int cpg_bn_relu_pool3_bwd(const float *x, const float *g_pooled, cons
 // full-size per-element slope gradient and reduces it afterwards: 1.2 ms per layer, 36 % of a SphereNet-20 step.
 // ------------------------------------------------------------------------------------------
 namespace {
+// BIAS: also sum gx per channel -- x is the output of a conv WITH bias (every SphereNet conv, models/spherenet.py:203-217), gx is that
+// conv's output gradient, and its per-channel sum is the conv's bias gradient: no separate reduction pass over gx (k_conv_bias_*).
+template <bool BIAS>
 __global__ __launch_bounds__(kThreads) void k_prelu_bwd(const float *__restrict__ x, const float *__restrict__ g,
                                                         const float *__restrict__ slope, float *__restrict__ gx, BnDims d,
                                                         int slope_stride, double *__restrict__ partial) {
@@ -1014,16 +1017,18 @@ __global__ __launch_bounds__(kThreads) void k_prelu_bwd(const float *__restrict_
     const int c = blockIdx.x, s = blockIdx.y;
     const int n0 = s * d.imgs_per_slice, n1 = min(d.N, n0 + d.imgs_per_slice);
     const float a = slope[c * slope_stride];
-    double dacc = 0.0;
-    float acc = 0.f;
+    double dacc = 0.0, dbias = 0.0;
+    float acc = 0.f, accb = 0.f;
     const bool vec = (d.HW & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)g) & 15) == 0 && (((uintptr_t)gx) & 15) == 0;
     auto flush = [&]() {
         dacc += (double)acc; acc = 0.f;
+        if (BIAS) dbias += (double)accb, accb = 0.f;
     };
     auto one = [&](float xv, float gv, float &out) {
         const bool pos = xv > 0.f;
         out = pos ? gv : a * gv;
         acc += pos ? 0.f : gv * xv;
+        if (BIAS) accb += out;
     };
     if (vec)
         walk_planes(d.HW >> 2, n0, n1, [&](int n, int j) {
@@ -1043,8 +1048,21 @@ __global__ __launch_bounds__(kThreads) void k_prelu_bwd(const float *__restrict_
         }, flush);
     const double t = block_sum(dacc, red);
     if (threadIdx.x == 0) partial[(int64_t)c * d.slices + s] = t;
+    if (BIAS) {
+        const double tb = block_sum(dbias, red);
+        if (threadIdx.x == 0) partial[(int64_t)d.C * d.slices + (int64_t)c * d.slices + s] = tb;
+    }
 }
-__global__ void k_prelu_bwd_finalize(const double *__restrict__ partial, BnDims d, int per_channel, float *__restrict__ gslope) {
+__global__ void k_prelu_bwd_finalize(const double *__restrict__ partial, BnDims d, int per_channel, float *__restrict__ gslope,
+                                     float *__restrict__ gbias) {
+    if (gbias != nullptr) {                                   // bias gradient of the conv below: per channel, fixed-order merge
+        const int c = blockIdx.x * blockDim.x + threadIdx.x;
+        if (c < d.C) {
+            double s = 0.0;
+            for (int k = 0; k < d.slices; ++k) s += partial[(int64_t)d.C * d.slices + (int64_t)c * d.slices + k];
+            gbias[c] = (float)s;
+        }
+    }
     if (per_channel) {
         const int c = blockIdx.x * blockDim.x + threadIdx.x;
         if (c >= d.C) return;
@@ -1062,24 +1080,36 @@ __global__ void k_prelu_bwd_finalize(const double *__restrict__ partial, BnDims 
 extern "C" size_t cpg_prelu_workspace_bytes(int32_t N, int32_t C, int32_t HW) {
     BnDims d;
     if (make_dims(N, C, HW, d) != CPG_OK) return 0;
-    return (size_t)C * d.slices * sizeof(double);
+    return (size_t)2 * C * d.slices * sizeof(double);        // slope-gradient partials, then (cpg_prelu_bwd_bias) the bias-gradient ones
 }
 
-// n_slopes: C (one slope per channel) or 1 (shared)
-extern "C" int cpg_prelu_bwd(const float *x, const float *gy, const float *slope, float *gx, float *gslope, int32_t N, int32_t C,
-                             int32_t HW, int32_t n_slopes, void *ws, size_t ws_bytes, void *stream_v) {
+// n_slopes: C (one slope per channel) or 1 (shared).  gbias (cpg_prelu_bwd_bias; may be NULL): per-channel sum of gx
+static int prelu_bwd(const float *x, const float *gy, const float *slope, float *gx, float *gslope, float *gbias, int32_t N, int32_t C,
+                     int32_t HW, int32_t n_slopes, void *ws, size_t ws_bytes, void *stream_v, const char *what) {
     BnDims d;
     int rc = make_dims(N, C, HW, d);
     if (rc) return rc;
-    CPG_REQUIRE(x && gy && slope && gx && gslope && ws, "cpg_prelu_bwd: null pointer");
-    CPG_REQUIRE(n_slopes == C || n_slopes == 1, "cpg_prelu_bwd: n_slopes must be C or 1");
-    if (ws_bytes < cpg_prelu_workspace_bytes(N, C, HW)) return fail(CPG_E_WORKSPACE, "cpg_prelu_bwd: workspace too small");
+    CPG_REQUIRE(x && gy && slope && gx && gslope && ws, "%s: null pointer", what);
+    CPG_REQUIRE(n_slopes == C || n_slopes == 1, "%s: n_slopes must be C or 1", what);
+    if (ws_bytes < cpg_prelu_workspace_bytes(N, C, HW)) return fail(CPG_E_WORKSPACE, "%s: workspace too small", what);
     hipStream_t stream = (hipStream_t)stream_v;
     double *partial = (double *)ws;
-    hipLaunchKernelGGL(k_prelu_bwd, dim3(C, d.slices), dim3(kThreads), 0, stream, x, gy, slope, gx, d, n_slopes == C ? 1 : 0, partial);
-    hipLaunchKernelGGL(k_prelu_bwd_finalize, dim3((C + 63) / 64), dim3(64), 0, stream, partial, d, n_slopes == C ? 1 : 0, gslope);
-    CPG_CHECK_LAUNCH("cpg_prelu_bwd");
+    if (gbias != nullptr)
+        hipLaunchKernelGGL(k_prelu_bwd<true>, dim3(C, d.slices), dim3(kThreads), 0, stream, x, gy, slope, gx, d, n_slopes == C ? 1 : 0, partial);
+    else
+        hipLaunchKernelGGL(k_prelu_bwd<false>, dim3(C, d.slices), dim3(kThreads), 0, stream, x, gy, slope, gx, d, n_slopes == C ? 1 : 0, partial);
+    hipLaunchKernelGGL(k_prelu_bwd_finalize, dim3((C + 63) / 64), dim3(64), 0, stream, partial, d, n_slopes == C ? 1 : 0, gslope, gbias);
+    CPG_CHECK_LAUNCH(what);
     return CPG_OK;
+}
+extern "C" int cpg_prelu_bwd(const float *x, const float *gy, const float *slope, float *gx, float *gslope, int32_t N, int32_t C,
+                             int32_t HW, int32_t n_slopes, void *ws, size_t ws_bytes, void *stream_v) {
+    return prelu_bwd(x, gy, slope, gx, gslope, nullptr, N, C, HW, n_slopes, ws, ws_bytes, stream_v, "cpg_prelu_bwd");
+}
+extern "C" int cpg_prelu_bwd_bias(const float *x, const float *gy, const float *slope, float *gx, float *gslope, float *gbias, int32_t N,
+                                  int32_t C, int32_t HW, int32_t n_slopes, void *ws, size_t ws_bytes, void *stream_v) {
+    CPG_REQUIRE(gbias != nullptr, "cpg_prelu_bwd_bias: null bias-gradient pointer");
+    return prelu_bwd(x, gy, slope, gx, gslope, gbias, N, C, HW, n_slopes, ws, ws_bytes, stream_v, "cpg_prelu_bwd_bias");
 }
 
 // PReLU forward with the residual add of SphereNet's units folded in (models/spherenet.py:219-247: x = x + relu_b(conv_b(relu_a(conv_a(x))))):

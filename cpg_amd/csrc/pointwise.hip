@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
                                                        const float *__restrict__ bias, float *__restrict__ y,
                                                        float *__restrict__ stats = nullptr, const float *__restrict__ addend = nullptr) {
     static_assert(!ADD || (DGRAD && !STATS), "the addend rides in plain input-gradient launches");
-    static_assert(!STATS || (!DGRAD && Cfg::WN == 1), "statistics ride in forward launches whose waves own whole channel rows");
+    static_assert(!STATS || !DGRAD, "statistics ride in forward launches");
     __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -258,8 +258,9 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
         }
     }
     if (STATS) {
-        // sum over the 32 pixel lanes of each half-wave (DPP adds; valid in lanes 16-31 / 48-63); WN == 1: the wave owns its rows
+        // sum over the 32 pixel lanes of each half-wave (DPP adds; valid in lanes 16-31 / 48-63)
         const unsigned ntiles = gridDim.x / g.tiles_m, tile_n = xcd_remap(blockIdx.x, gridDim.x) / g.tiles_m;
+        float *red = smem;                               // WN > 1: [WN][BM][2] (the main loop's last barrier freed the LDS)
 #pragma unroll
         for (int fm = 0; fm < Cfg::FM; ++fm) {
             half_wave_sum8(&s1[fm][0]);
@@ -269,13 +270,32 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
             if (li == 31) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    if (co < g.M) {
-                        float *dst = stats + ((int64_t)co * ntiles + tile_n) * 2;
-                        dst[0] = s1[fm][e];
-                        dst[1] = s2[fm][e];
+                    const int ch = (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (Cfg::WN == 1) {                  // the wave owns its channel rows
+                        if (m0 + ch < g.M) {
+                            float *dst = stats + ((int64_t)(m0 + ch) * ntiles + tile_n) * 2;
+                            dst[0] = s1[fm][e];
+                            dst[1] = s2[fm][e];
+                        }
+                    } else {
+                        red[(wn * Cfg::BM + ch) * 2 + 0] = s1[fm][e];
+                        red[(wn * Cfg::BM + ch) * 2 + 1] = s2[fm][e];
                     }
                 }
+            }
+        }
+        if (Cfg::WN > 1) {                               // fixed-order merge of the WN waves that share the channels
+            __syncthreads();
+            if (tid < Cfg::BM && m0 + tid < g.M) {
+                float a = 0.0f, b = 0.0f;
+#pragma unroll
+                for (int w2 = 0; w2 < Cfg::WN; ++w2) {
+                    a += red[(w2 * Cfg::BM + tid) * 2 + 0];
+                    b += red[(w2 * Cfg::BM + tid) * 2 + 1];
+                }
+                float *dst = stats + ((int64_t)(m0 + tid) * ntiles + tile_n) * 2;
+                dst[0] = a;
+                dst[1] = b;
             }
         }
     }
@@ -502,6 +522,10 @@ int pw_wgrad_launch(const cpg_conv_desc *d, const float *x, const float *gy, con
 //                BM  WM WN FN CK  VEC  MINW
 using PwV = PwCfg<128, 4, 1, 7, 16, true, 3>;       // dense reads, 4 | pixels per image: float4 staging
 using PwS = PwCfg<128, 4, 1, 7, 16, false, 2>;      // strided reads (1x1 s2 forward) or odd plane sizes (7x7 maps)
+// <= 64 channels produced (ResNet layer1: conv1 forward, conv3 input gradient): a 128-row tile would run half of its MFMAs on
+// rows that do not exist.  64 rows x 256 flattened pixels (2 x 2 waves, 4 fragments each); 56 x 56 maps x any batch divide by 256.
+using PwV64 = PwCfg<64, 2, 2, 4, 16, true, 3>;
+using PwS64 = PwCfg<64, 2, 2, 4, 16, false, 3>;
 
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 inline size_t pack_bytes(int c_read, int m) { return ((size_t)pad_to(c_read, 16) + 16) * pad_to(m, 128) * sizeof(float); }
@@ -541,7 +565,7 @@ extern "C" int cpg_conv1x1_supported(const cpg_conv_desc *d) {
     const int OH = (d->H - 1) / d->stride_h + 1, OW = (d->W - 1) / d->stride_w + 1;
     // whole 16-channel chunks on both sides (forward contracts over C, the input gradient over K); a tile's images are
     // addressed with 31-bit byte offsets
-    const int64_t span = (int64_t)(224 / (OH * OW) + 2) * std::max(d->C, d->K) * d->H * d->W * 4;
+    const int64_t span = (int64_t)(256 / (OH * OW) + 2) * std::max(d->C, d->K) * d->H * d->W * 4;
     return d->C % 16 == 0 && d->K % 16 == 0 && span < (1ll << 31) && (int64_t)std::max(d->C, d->K) * d->H * d->W < (1ll << 28);
 }
 
@@ -550,7 +574,8 @@ size_t cpg_conv1x1_pack_workspace(const cpg_conv_desc *d) { return std::max(pack
 // pixel tiles of the forward launch = rows of the [K][tiles][2] statistics buffer of cpg_conv2d_fwd_bnstats
 int cpg_conv1x1_bnstats_tiles(const cpg_conv_desc *d) {
     const int OH = (d->H - 1) / d->stride_h + 1, OW = (d->W - 1) / d->stride_w + 1;
-    return (int)(((int64_t)d->N * OH * OW + PwV::BN - 1) / PwV::BN);
+    const int bn = d->K <= 64 ? PwV64::BN : PwV::BN;
+    return (int)(((int64_t)d->N * OH * OW + bn - 1) / bn);
 }
 
 int cpg_conv1x1_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
@@ -566,8 +591,10 @@ int cpg_conv1x1_fwd(const cpg_conv_desc *d, const float *x, const float *w, cons
     const int OH = (d->H - 1) / d->stride_h + 1, OW = (d->W - 1) / d->stride_w + 1;
     PwGeom g{d->N, d->C, d->K, Mp, OW, OH * OW, d->H * d->W, d->stride_h * d->W, d->stride_w, OH * OW, OW, 1, 0, (long long)d->N * OH * OW};
     const bool dense = d->stride_h == 1 && d->stride_w == 1;
-    static_assert(PwV::BN == PwS::BN, "cpg_conv1x1_bnstats_tiles counts tiles of either configuration");
-    if (dense && (OH * OW) % 4 == 0 && (((uintptr_t)x) & 15) == 0) return launch<PwV, false>(g, x, wp, bias, y, stream, what, stats);
+    static_assert(PwV::BN == PwS::BN && PwV64::BN == PwS64::BN, "cpg_conv1x1_bnstats_tiles counts tiles of either staging flavour");
+    const bool vec = dense && (OH * OW) % 4 == 0 && (((uintptr_t)x) & 15) == 0;
+    if (d->K <= 64) return vec ? launch<PwV64, false>(g, x, wp, bias, y, stream, what, stats) : launch<PwS64, false>(g, x, wp, bias, y, stream, what, stats);
+    if (vec) return launch<PwV, false>(g, x, wp, bias, y, stream, what, stats);
     return launch<PwS, false>(g, x, wp, bias, y, stream, what, stats);
 }
 
@@ -590,7 +617,9 @@ int cpg_conv1x1_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, c
     // reads gy (K channels, dense over the output grid), produces gx (C channels) at the strided positions
     PwGeom g{d->N, d->K, d->C, Mp, OW, OH * OW, OH * OW, OW, 1, d->H * d->W, d->stride_h * d->W, d->stride_w, 0, (long long)d->N * OH * OW};
     if (addend != nullptr && !dense) return fail(CPG_E_UNSUPPORTED, "%s: the fused addend needs a dense (stride 1) layer", what);
-    if ((OH * OW) % 4 == 0 && (((uintptr_t)gy) & 15) == 0) return launch<PwV, true>(g, gy, wp, nullptr, gx, stream, what, nullptr, addend);
+    const bool vec = (OH * OW) % 4 == 0 && (((uintptr_t)gy) & 15) == 0;
+    if (d->C <= 64) return vec ? launch<PwV64, true>(g, gy, wp, nullptr, gx, stream, what, nullptr, addend) : launch<PwS64, true>(g, gy, wp, nullptr, gx, stream, what, nullptr, addend);
+    if (vec) return launch<PwV, true>(g, gy, wp, nullptr, gx, stream, what, nullptr, addend);
     return launch<PwS, true>(g, gy, wp, nullptr, gx, stream, what, nullptr, addend);
 }
 

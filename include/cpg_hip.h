@@ -340,6 +340,11 @@ int cpg_bn_relu_pool3_bwd(const float *x, const float *g_pooled, const float *ga
 size_t cpg_prelu_workspace_bytes(int32_t N, int32_t C, int32_t HW);
 int cpg_prelu_bwd(const float *x, const float *gy, const float *slope, float *gx, float *gslope, int32_t N,
                   int32_t C, int32_t HW, int32_t n_slopes, void *ws, size_t ws_bytes, void *stream);
+/* ... and, when x is the output of a conv WITH bias that only this PReLU consumes (every SphereNet conv, models/spherenet.py:203-217),
+ * also gbias[c] = sum over (n, pixels) of gx -- the conv's bias gradient, so that cpg_conv2d_wgrad is called with gb = NULL and no
+ * separate reduction pass over gx runs. */
+int cpg_prelu_bwd_bias(const float *x, const float *gy, const float *slope, float *gx, float *gslope, float *gbias, int32_t N,
+                       int32_t C, int32_t HW, int32_t n_slopes, void *workspace, size_t workspace_bytes, void *stream);
 /* PReLU forward with the residual add of a SphereNet unit folded in (models/spherenet.py:219-247: x + relu(conv(.))):
  * y = residual + (x > 0 ? x : slope[c] x); residual may be NULL.  One pass instead of torch's prelu + add kernels. */
 int cpg_prelu_fwd(const float *x, const float *residual, const float *slope, float *y, int32_t N, int32_t C, int32_t HW,

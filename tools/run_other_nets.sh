@@ -10,5 +10,5 @@ for a in resnet50 spherenet20; do
   rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_$a -o run -- python $R/tools/net_bench.py --arch $a --steps 5 > $R/gpurun_out/prof_${TAG}_$a.log 2>&1
   db=$(find $R/gpurun_out/prof_${TAG}_$a -name '*.db' | head -1)
   python $R/tools/rocprof_summary.py $db 45 > $R/gpurun_out/summary_${TAG}_$a.md 2>&1
-  find $R/gpurun_out/prof_${TAG}_$a -type f ! -name '*.db' -size +2M -delete
+  rm -rf $R/gpurun_out/prof_${TAG}_$a
 done
