@@ -315,7 +315,8 @@ class _PReluFn(torch.autograd.Function):
     and a one-pass backward (cpg_prelu_bwd); the residual's gradient is the incoming gradient itself."""
 
     @staticmethod
-    def forward(ctx, x, weight, res=None):
+    def forward(ctx, x, weight, res=None, bias_sink=None):
+        ctx.bias_sink = bias_sink        # layers.BiasGradSink of the biased conv that produced x (its only consumer is this PReLU)
         N, C = x.shape[0], x.shape[1]
         HW = x.numel() // max(N * C, 1)
         y = torch.empty_like(x)
@@ -331,17 +332,38 @@ class _PReluFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
+        sink, ctx.bias_sink = ctx.bias_sink, None
         if not x.numel():
-            return torch.zeros_like(x), torch.zeros_like(weight), (gy if ctx.has_res else None)
+            return torch.zeros_like(x), torch.zeros_like(weight), (gy if ctx.has_res else None), None
         N, C = x.shape[0], x.shape[1]
         HW = x.numel() // (N * C)
         L = _lib.lib()
         ws, nb = _lib.workspace(L.cpg_prelu_workspace_bytes(N, C, HW), x.device)
         gx = torch.empty_like(x)
         gw = torch.empty_like(weight)
-        _lib.check('cpg_prelu_bwd', L.cpg_prelu_bwd(_lib.dptr(x), _lib.dptr(gy), _lib.dptr(weight), _lib.dptr(gx), _lib.dptr(gw),
-                                                    N, C, HW, weight.numel(), _lib.dptr(ws), nb, _lib.stream_ptr()))
-        return gx, gw, (gy if ctx.has_res else None)
+        if sink is not None:
+            gbias = torch.empty(C, dtype=torch.float32, device=x.device)
+            _lib.check('cpg_prelu_bwd_bias', L.cpg_prelu_bwd_bias(_lib.dptr(x), _lib.dptr(gy), _lib.dptr(weight), _lib.dptr(gx), _lib.dptr(gw),
+                                                                  _lib.dptr(gbias), N, C, HW, weight.numel(), _lib.dptr(ws), nb, _lib.stream_ptr()))
+            sink.gb = gbias
+        else:
+            _lib.check('cpg_prelu_bwd', L.cpg_prelu_bwd(_lib.dptr(x), _lib.dptr(gy), _lib.dptr(weight), _lib.dptr(gx), _lib.dptr(gw),
+                                                        N, C, HW, weight.numel(), _lib.dptr(ws), nb, _lib.stream_ptr()))
+        return gx, gw, (gy if ctx.has_res else None), None
+
+
+def conv_prelu(conv, mod, x, res=None):
+    """mod(conv(x)) [+ res] for SphereNet's biased conv -> PReLU pairs (models/spherenet.py:203-247): the PReLU's backward pass also
+    delivers the conv's bias gradient (the per-channel sum of the gradient it writes), so the conv's backward runs no bias reduction."""
+    from .layers import BiasGradSink
+    if (ENABLED and type(mod) is nn.PReLU and x.is_cuda and getattr(conv, 'bias', None) is not None and torch.is_grad_enabled()
+            and mod.weight.numel() in (1, conv.out_channels) and conv._math() == 'fp32'):
+        sink = BiasGradSink()
+        y = conv(x, bias_sink=sink)
+        if y.dtype == torch.float32 and y.dim() == 4 and y.is_contiguous() and (res is None or (res.shape == y.shape and res.is_contiguous())):
+            return _PReluFn.apply(y, mod.weight, res, sink)
+        return prelu(mod, y, res)
+    return prelu(mod, conv(x), res)
 
 
 def prelu(mod, x, res=None):

@@ -73,14 +73,25 @@ def _out_hw(d):
     return oh, ow
 
 
+class BiasGradSink(object):
+    """Hand-off from the PReLU that is the ONLY consumer of a biased conv's output (SphereNet, models/spherenet.py:203-247) to that
+    conv's backward: the PReLU's one-pass backward sums its input gradient per channel while it writes it -- that sum IS the conv's bias
+    gradient --, so the conv asks its weight-gradient call for no bias gradient (no extra reduction pass over gy).  One sink per forward."""
+    __slots__ = ('gb',)
+
+    def __init__(self):
+        self.gb = None
+
+
 class _MaskedConv2dFn(torch.autograd.Function):
     """y = conv2d(x, W * bin(pm), b) and its gradients, all through the C ABI."""
 
     @staticmethod
-    def forward(ctx, x, weight, pm, bias, thr, stride, padding, dilation, groups, bn_stats=False, math='fp32', bn_hint=None):
+    def forward(ctx, x, weight, pm, bias, thr, stride, padding, dilation, groups, bn_stats=False, math='fp32', bn_hint=None, bias_sink=None):
         # bn_hint (fused_bn.BnBwdHint or None): `x` is relu(bn(ypre)) of the layer below and nothing else consumes it -- the
         # input-gradient kernel may then do that BatchNorm's backward reduction in its epilogue (cpg_conv2d_dgrad_bnbwd)
         ctx.bn_hint = bn_hint
+        ctx.bias_sink = bias_sink if bias is not None else None     # BiasGradSink: the activation behind this conv delivers the bias gradient
         """bn_stats: also return the per-(channel, pixel tile) {sum, sum of squares} of y that the kernel accumulates
         in its epilogue (cpg_conv2d_fwd_bnstats) -- a second, non-differentiable output, or None when the shape has
         no fused-statistics kernel."""
@@ -156,7 +167,7 @@ class _MaskedConv2dFn(torch.autograd.Function):
         if ctx.empty:
             return (torch.zeros_like(x), torch.zeros_like(w), None if p is None else torch.zeros_like(p),
                     torch.zeros(d.K, dtype=torch.float32, device=x.device) if ctx.has_bias else None, None, None, None, None, None, None,
-                    None, None)
+                    None, None, None)
         gy = gy.contiguous()
         L = _lib.lib()
         s = _lib.stream_ptr()
@@ -198,6 +209,10 @@ class _MaskedConv2dFn(torch.autograd.Function):
             gw = torch.empty_like(w)
             gpm = None if p is None else torch.empty_like(p)
             gb = torch.empty(d.K, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            sink, ctx.bias_sink = getattr(ctx, 'bias_sink', None), None
+            given = sink.gb if sink is not None else None
+            if given is not None:                # the PReLU behind this conv already summed gy per channel (cpg_prelu_bwd_bias)
+                sink.gb, gb = None, None
             if ctx.bf16 and not ctx.has_bias and L.cpg_conv2d_wgrad_bf16_supported(ctypes.byref(d)):
                 wsw, nbw = _lib.workspace(L.cpg_conv2d_wgrad_bf16_workspace_bytes(ctypes.byref(d)), x.device)
                 wgrad = L.cpg_conv2d_wgrad_bf16x3 if ctx.x3 else L.cpg_conv2d_wgrad_bf16
@@ -208,7 +223,9 @@ class _MaskedConv2dFn(torch.autograd.Function):
                 rc = L.cpg_conv2d_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), _lib.dptr(p), thr,
                                         _lib.dptr(gw), _lib.dptr(gpm), _lib.dptr(gb), _lib.dptr(ws), nbytes, s)
                 _lib.check('cpg_conv2d_wgrad', rc)
-        return gx, gw, gpm, gb, None, None, None, None, None, None, None, None
+            if given is not None:
+                gb = given
+        return gx, gw, gpm, gb, None, None, None, None, None, None, None, None, None
 
 
 class _MaskedConv2dSkipFn(torch.autograd.Function):
@@ -353,9 +370,9 @@ class SharableConv2d(_Sharable):
             self.register_parameter('bias', None)
         self._init_mask_state(mask_init, mask_scale, threshold_fn, threshold)
 
-    def forward(self, input, layer_info=None, name=None, bn_hint=None):
+    def forward(self, input, layer_info=None, name=None, bn_hint=None, bias_sink=None):
         return _MaskedConv2dFn.apply(input, self.weight, self.piggymask, self.bias, self.info['threshold'],
-                                     self.stride, self.padding, self.dilation, self.groups, False, self._math(), bn_hint)
+                                     self.stride, self.padding, self.dilation, self.groups, False, self._math(), bn_hint, bias_sink)
 
     def _math(self):
         return getattr(self, 'math', None) or CONV_MATH

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
 from . import layers as nl
-from .fused_bn import prelu
+from .fused_bn import conv_prelu
 from .vgg import View
 
 __all__ = ['SphereNet', 'spherenet20', 'AngleLoss', 'AngleLinear']
@@ -101,11 +101,11 @@ class SphereNet(nn.Module):
 
     def _trunk(self, x):
         for stage, _, units in _STAGES:
-            x = prelu(getattr(self, 'relu%d_1' % stage), getattr(self, 'conv%d_1' % stage)(x))
+            x = conv_prelu(getattr(self, 'conv%d_1' % stage), getattr(self, 'relu%d_1' % stage), x)
             for u in range(units):
                 a, b = 2 * u + 2, 2 * u + 3
-                y = prelu(getattr(self, 'relu%d_%d' % (stage, a)), getattr(self, 'conv%d_%d' % (stage, a))(x))
-                x = prelu(getattr(self, 'relu%d_%d' % (stage, b)), getattr(self, 'conv%d_%d' % (stage, b))(y), res=x)
+                y = conv_prelu(getattr(self, 'conv%d_%d' % (stage, a)), getattr(self, 'relu%d_%d' % (stage, a)), x)
+                x = conv_prelu(getattr(self, 'conv%d_%d' % (stage, b)), getattr(self, 'relu%d_%d' % (stage, b)), y, res=x)
         return self.flatten(x)
 
     def forward(self, x):

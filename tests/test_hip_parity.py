@@ -1569,8 +1569,12 @@ def test_resnet_spherenet_backward_matches_torch_ops(arch, width, shape, ncls, m
 
     out_hip, g_hip = run()
     monkeypatch.setattr(nl.SharableConv2d, 'forward',
-                        lambda self, input, layer_info=None, name=None: F.conv2d(input, self.weight, self.bias, self.stride,
+                        lambda self, input, layer_info=None, name=None, **kw: F.conv2d(input, self.weight, self.bias, self.stride,
                                                                                  self.padding, self.dilation, self.groups))
+    # (the residual blocks' first conv goes through forward_with_skip: the reference run must not take the HIP path there either)
+    monkeypatch.setattr(nl.SharableConv2d, 'forward_with_skip',
+                        lambda self, input: (F.conv2d(input, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups),
+                                             None, input))
     out_ref, g_ref = run()
     np.testing.assert_allclose(out_hip, out_ref, rtol=1e-3, atol=1e-4 * float(np.abs(out_ref).max()))
     assert set(g_hip) == set(g_ref)
@@ -1632,6 +1636,35 @@ def test_resnet_block_fused_bn_equals_stock_bn(block, stride):
     for n in g0:
         sc = float(np.abs(g0[n]).max()) + 1e-20
         assert float(np.abs(g1[n] - g0[n]).max()) <= 1e-3 * sc, n
+
+
+def test_conv_prelu_bias_gradient_from_the_prelu_backward():
+    """SphereNet's biased conv -> PReLU pair (models/spherenet.py:203-247): the conv's bias gradient comes out of the PReLU's backward
+    pass (cpg_prelu_bwd_bias) instead of a reduction pass over the conv's output gradient -- same gradients as the plain composition."""
+    from cpg_amd.models import fused_bn
+    torch.manual_seed(3)
+    conv = nl.SharableConv2d(32, 48, 3, stride=1, padding=1, bias=True).to(DEV)
+    nn.init.kaiming_normal_(conv.weight, mode='fan_out')
+    nn.init.normal_(conv.bias, 0, 0.2)
+    act = nn.PReLU(48).to(DEV)
+    with torch.no_grad():
+        act.weight.uniform_(0.1, 0.4)
+    x0 = torch.randn(5, 32, 14, 14, device=DEV)
+    r0 = torch.randn(5, 48, 14, 14, device=DEV)
+    gy = torch.randn(5, 48, 14, 14, device=DEV)
+    res = {}
+    for fused in (True, False):
+        conv.zero_grad()
+        act.zero_grad()
+        x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        y = fused_bn.conv_prelu(conv, act, x, res=r) if fused else r + act(conv(x))
+        if fused:
+            assert 'PRelu' in type(y.grad_fn).__name__
+        y.backward(gy)
+        res[fused] = [y.detach().clone(), x.grad.clone(), r.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone(), act.weight.grad.clone()]
+    for a, b in zip(res[True], res[False]):
+        sc = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-5 * sc + 1e-7
 
 
 @pytest.mark.parametrize('N,C,K,H', [(6, 64, 16, 28), (3, 256, 64, 14), (5, 32, 16, 7)])
