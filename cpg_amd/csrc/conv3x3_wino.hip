@@ -1280,7 +1280,12 @@ void k_wg2(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
 #define W3_RD_1_14(m) asm volatile("v_accvgpr_read_b32 %0, a142\n\tv_accvgpr_read_b32 %1, a158\n\tv_accvgpr_read_b32 %2, a174\n\tv_accvgpr_read_b32 %3, a190\n\tv_accvgpr_read_b32 %4, a206\n\tv_accvgpr_read_b32 %5, a222\n\tv_accvgpr_read_b32 %6, a238\n\tv_accvgpr_read_b32 %7, a254" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
 #define W3_RD_1_15(m) asm volatile("v_accvgpr_read_b32 %0, a143\n\tv_accvgpr_read_b32 %1, a159\n\tv_accvgpr_read_b32 %2, a175\n\tv_accvgpr_read_b32 %3, a191\n\tv_accvgpr_read_b32 %4, a207\n\tv_accvgpr_read_b32 %5, a223\n\tv_accvgpr_read_b32 %6, a239\n\tv_accvgpr_read_b32 %7, a255" : "=v"(m[0]), "=v"(m[1]), "=v"(m[2]), "=v"(m[3]), "=v"(m[4]), "=v"(m[5]), "=v"(m[6]), "=v"(m[7]))
 
-template <bool DGRAD, bool STATS, bool BNE = false>
+// ODD: maps with an odd height and / or width (7 x 7: ResNet-50 layer4, SphereNet conv4_x) as ceil(H/2) x ceil(W/2) tiles -- the last tile
+// row / column hangs over the edge by one pixel.  Rows past the map are range-checked to zero as ever; a tile in the last column of an
+// odd-width map fetches the pair (W-2, W-1) instead of (W-1, W) -- nothing past the tensor is touched -- and stores (x[W-1], 0); its
+// outputs past the edge are not stored (one dword instead of the pair; the odd row of the last tile row not at all) and stay out of
+// the BatchNorm statistics.
+template <bool DGRAD, bool STATS, bool BNE = false, bool ODD = false>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
            float *__restrict__ y, float *__restrict__ stats, WgBnEval bn) {
@@ -1313,16 +1318,18 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
 
     constexpr int kOutOfRange = (int)0x80000000;
     int roff[3], hoff, lo, ro;
+    bool oddcol = false;                                     // ODD: this lane's tile hangs over the right edge of an odd-width map
     {
         const unsigned tg = t0 + li;
         const bool tv = tg < ttot;
         const int n = (int)(tg / timg), r = (int)(tg % timg);
         const int ty = (int)((unsigned)r / twu), tx = (int)((unsigned)r % twu);
         const int cbase = ((n - n0) * g.C + 2 * lh) * HW;
+        if (ODD) oddcol = (g.W & 1) && tx == g.tw - 1;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int gh = 2 * ty - 1 + ph + i;
-            roff[i] = (tv && (unsigned)gh < (unsigned)g.H) ? (cbase + gh * g.W + 2 * tx) * 4 : kOutOfRange;
+            roff[i] = (tv && (unsigned)gh < (unsigned)g.H) ? (cbase + gh * g.W + 2 * tx - (oddcol ? 1 : 0)) * 4 : kOutOfRange;
         }
         lo = tx == 0 ? 0 : (li + 1) * 2 - 1;
         ro = tx == g.tw - 1 ? (W1_T + 1) * 2 + 1 : (li + 1) * 2 + 2;
@@ -1365,9 +1372,14 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     };
     auto W_row1 = [&](int stage, const Rows &q, int k) {
         float *raw = smem + stage * W2_RAW;
-        if (k < 6)
-            *reinterpret_cast<i32x2 *>(raw + raw_own + k * W1_ROW) = q.r[k / 3][k % 3];
-        else if (lane < 24)
+        if (k < 6) {
+            i32x2 v = q.r[k / 3][k % 3];
+            if (ODD) {                                       // the pair fetched was (W-2, W-1): keep x[W-1], the column past the edge is 0
+                v[0] = oddcol ? v[1] : v[0];
+                v[1] = oddcol ? 0 : v[1];
+            }
+            *reinterpret_cast<i32x2 *>(raw + raw_own + k * W1_ROW) = v;
+        } else if (lane < 24)
             raw[halo_w] = q.halo;
     };
     // Wave ph = 1 keeps its two transform rows in REVERSE order (local row 0 = row 3, local row 1 = row 2): then local row 0 of
@@ -1560,9 +1572,10 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     }
     __syncthreads();
     const unsigned tg = t0 + li;
-    const bool tv = tg < ttot;
     const int n = (int)(tg / timg), r = (int)(tg % timg);
     const int ty = (int)((unsigned)r / twu), tx = (int)((unsigned)r % twu);
+    // (ODD: the odd row of the last tile row of an odd-height map does not exist -- the wave that owns it stores nothing for that tile)
+    const bool tv = tg < ttot && (!ODD || 2 * ty + ph < g.H);
     float *yout = y + ((int64_t)n * g.M) * HW + (2 * ty + ph) * g.W + 2 * tx;
     float s1[32], s2[32];
     const float sgn = ph ? -1.0f : 1.0f;
@@ -1584,7 +1597,10 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
             v0 = (v0 - mu) * is * ga + be, v1 = (v1 - mu) * is * ga + be;
             if (bn.relu) v0 = fmaxf(v0, 0.0f), v1 = fmaxf(v1, 0.0f);
         }
-        if (tv && co < g.M) {
+        if (ODD && oddcol) {                   // the second column is past the edge: one dword, and it stays out of the statistics
+            if (tv && co < g.M) yout[(int64_t)co * HW] = v0;
+            v1 = 0.0f;
+        } else if (tv && co < g.M) {
             f32x2 o;
             o[0] = v0, o[1] = v1;
             *reinterpret_cast<f32x2 *>(yout + (int64_t)co * HW) = o;
@@ -1647,10 +1663,16 @@ int wino_launch(bool dgrad, const WgGeom &g, int64_t tblocks, const float *x, co
 // ---- host side ---------------------------------------------------------------------------------------------------
 // eligibility of one launch (c_read channels contracted, m produced): even maps, channel chunks of 4, the staging offsets of
 // the images a block can touch fit 31 bits
+// odd maps (7 x 7: ResNet-50 layer4, SphereNet conv4_x): only the two-wave kernel k_wg3 has the edge handling (its ODD instances), and it
+// only pays with a long channel loop -- >= 128 channels read, >= 64 produced, no forced kernel choice
+static inline bool wino_odd_ok(int c_read, int m, int H, int W) {
+    return ((H | W) & 1) && H >= 3 && W >= 3 && c_read >= 128 && m >= 64 && getenv("CPG_WINO_KERNEL") == nullptr && getenv("CPG_NO_WINO_ODD") == nullptr;
+}
 extern "C" int cpg_conv3x3_wino_ok(int N, int c_read, int m, int H, int W) {
     if (getenv("CPG_NO_WINO")) return 0;
-    if (H % 2 || W % 2 || c_read % 4 || c_read < 16 || m < 16 || N < 1) return 0;
-    const int tiles_img = (H / 2) * (W / 2);
+    if (c_read % 4 || c_read < 16 || m < 16 || N < 1) return 0;
+    if (((H | W) & 1) && !wino_odd_ok(c_read, m, H, W)) return 0;
+    const int tiles_img = ((H + 1) / 2) * ((W + 1) / 2);
     const int span = (WG_T + tiles_img - 1) / tiles_img + 1;
     if ((int64_t)N * tiles_img + 64 >= (1ll << 31)) return 0;               // 32-bit tile indices in the kernels
     return (int64_t)span * c_read * H * W * 4 < (1ll << 31);
@@ -1699,8 +1721,8 @@ static inline int wino_grids() {
 
 // number of BatchNorm-statistics tiles per channel of a forward launch (stats[m][tiles][2])
 extern "C" int cpg_conv3x3_wino_tiles(int N, int c_read, int m, int H, int W) {
-    const int64_t tiles = (int64_t)N * (H / 2) * (W / 2);
-    const int v = wino_variant(c_read, m);
+    const int64_t tiles = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2);
+    const int v = ((H | W) & 1) ? WV_PAIR64 : wino_variant(c_read, m);
     if (v == WV_PAIR || v == WV_PAIR64) return (int)(2 * ((tiles + W1_T - 1) / W1_T));     // every wave of a pair is its own tile
     const int per = v == WV_WAVE ? W1_T : WG_T;
     return (int)((tiles + per - 1) / per);
@@ -1741,11 +1763,12 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
     const size_t need = cpg_conv3x3_wino_pack_bytes(c_read, m);
     if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
     CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
-    const int variant = wino_variant(c_read, m, stats != nullptr);
+    const bool odd = ((H | W) & 1) != 0;
+    const int variant = odd ? WV_PAIR64 : wino_variant(c_read, m, stats != nullptr);
     if (variant != WV_BLOCK) {
         WgGeom g;
         g.N = N, g.C = c_read, g.H = H, g.W = W, g.M = m;
-        g.th = H / 2, g.tw = W / 2, g.tiles_img = g.th * g.tw;
+        g.th = (H + 1) / 2, g.tw = (W + 1) / 2, g.tiles_img = g.th * g.tw;
         g.tiles_total = (int64_t)N * g.tiles_img;
         g.nkb = pad_to(m, 32) / 32, g.nch = pad_to(c_read, WG_CK) / WG_CK;
         g.span = (W1_T + g.tiles_img - 1) / g.tiles_img + 1;
@@ -1760,6 +1783,18 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
             if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "%s: grid too large", what);
             g.nblocks = (unsigned)blocks;
             if (persist) blocks = std::min<int64_t>(blocks, (int64_t)wino_grids() * 2 * kCUs);
+            if (odd) {
+                if (bne != nullptr)
+                    hipLaunchKernelGGL((k_wg3<false, false, true, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, *bne);
+                else if (dgrad)
+                    hipLaunchKernelGGL((k_wg3<true, false, false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, none);
+                else if (stats != nullptr)
+                    hipLaunchKernelGGL((k_wg3<false, true, false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, stats, none);
+                else
+                    hipLaunchKernelGGL((k_wg3<false, false, false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, none);
+                CPG_CHECK_LAUNCH(what);
+                return CPG_OK;
+            }
             if (bne != nullptr)
                 hipLaunchKernelGGL((k_wg3<false, false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, *bne);
             else if (dgrad)

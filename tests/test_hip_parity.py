@@ -235,6 +235,93 @@ def test_winograd_matches_direct(N, C, H, W, K, bias, pm, nw, monkeypatch):
     assert not torch.equal(y1, y0) or N * H * W < 64                         # (the two paths really are different kernels)
 
 
+@pytest.mark.parametrize('N,C,H,W,K,bias,pm', [
+    (6, 128, 7, 7, 64, False, False),      # ResNet-50 layer4 / SphereNet conv4_x: 7 x 7 maps = 4 x 4 tiles, one row and one column over the edge
+    (37, 128, 7, 7, 160, True, True),      # tile runs that straddle images, ragged last run, bias, piggymask, channel tail
+    (3, 256, 9, 7, 128, True, False),      # odd height and width of different sizes
+    (2, 128, 8, 7, 64, False, True),       # only the width is odd
+    (2, 128, 13, 14, 72, True, False),     # only the height is odd
+    (2, 128, 3, 3, 64, False, False),      # the smallest odd map
+])
+def test_winograd_on_odd_maps(N, C, H, W, K, bias, pm, monkeypatch):
+    """Winograd F(2x2, 3x3) on maps with an odd height / width (k_wg3<..., ODD>: ceil(H/2) x ceil(W/2) tiles, the overhang never loaded
+    past the tensor, never stored, never in the BatchNorm statistics): forward, input gradient and the fused statistics against the
+    direct kernels and fp64; the launch really is a Winograd one (cpg_conv2d_winograd) and writes nothing outside its tensors."""
+    import ctypes
+    from cpg_amd import _lib
+    from cpg_amd.models.layers import _conv_desc
+    g = torch.Generator().manual_seed(N + C + K + H + W)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5
+    b = torch.randn(K, generator=g) * 0.1 if bias else None
+    pmv = torch.rand(K, C, 3, 3, generator=g) * 0.012 if pm else None
+    gy = torch.randn(N, K, H, W, generator=g)
+    layer = nl.SharableConv2d(C, K, 3, padding=1, bias=bias).to(DEV)
+    layer.weight.data.copy_(w)
+    if bias:
+        layer.bias.data.copy_(b)
+    if pm:
+        layer.piggymask = nn.Parameter(pmv.to(DEV))
+    d = _conv_desc((N, C, H, W), (K, C, 3, 3), (1, 1), (1, 1), (1, 1), 1)
+    L = _lib.lib()
+    assert L.cpg_conv2d_winograd(ctypes.byref(d), 0) == 1
+    # (the input gradient contracts over K: it runs the odd-map Winograd kernel when K >= 128, the direct kernel otherwise)
+    assert L.cpg_conv2d_winograd(ctypes.byref(d), 1) == (1 if K >= 128 else 0)
+
+    def run(stats):
+        xd = x.to(DEV).requires_grad_(True)
+        if stats:
+            y, st = layer.forward_with_bn_stats(xd)
+        else:
+            y, st = layer(xd), None
+        y.backward(gy.to(DEV))
+        return y.detach().cpu().double(), xd.grad.cpu().double(), None if st is None else st.sum(dim=1).cpu().double()
+    y1, gx1, _ = run(False)
+    y1s, _, st = run(True)
+    assert torch.equal(y1, y1s)
+    monkeypatch.setenv('CPG_NO_WINO', '1')
+    assert L.cpg_conv2d_winograd(ctypes.byref(d), 0) == 0
+    y0, gx0, _ = run(False)
+    weff = w.double() * ((pmv > 5e-3).double() if pm else 1.0)
+    y64 = nn.functional.conv2d(x.double(), weff, None if b is None else b.double(), padding=1)
+    gx64 = nn.functional.conv_transpose2d(gy.double(), weff, padding=1)
+    for name, a, dd, r in (('y', y1, y0, y64), ('gx', gx1, gx0, gx64)):
+        sc = float(r.abs().max())
+        assert float((a - r).abs().max()) < 1e-5 * sc, name
+        assert float((a - dd).abs().max()) < 1e-5 * sc, name
+    # BatchNorm partial sums: sum y and sum y^2 per channel over the VALID outputs only
+    want = torch.stack([y64.sum(dim=(0, 2, 3)), (y64 * y64).sum(dim=(0, 2, 3))], dim=1)
+    assert float((st - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+@pytest.mark.parametrize('N,C,K,H,W,bias', [(4, 64, 64, 28, 28, False), (3, 128, 128, 14, 14, True), (5, 128, 64, 7, 7, False), (2, 256, 128, 9, 7, True),
+                                           (2, 3, 16, 12, 12, False)])
+def test_inference_epilogue_matches_unfused(N, C, K, H, W, bias):
+    """Manager.validate's path: conv -> BatchNorm2d(eval) -> ReLU as ONE kernel (cpg_conv2d_fwd_bn_eval: the Winograd kernels' BNE
+    epilogue on even maps, its ODD instance on 7 x 7 maps, the direct kernel otherwise) against the three modules run one by one."""
+    from cpg_amd.models import fused_bn
+    torch.manual_seed(N + C + K)
+    seq = fused_bn.FusedSequential(nl.SharableConv2d(C, K, 3, padding=1, bias=bias), nn.BatchNorm2d(K), nn.ReLU(inplace=True))
+    nn.init.kaiming_normal_(seq[0].weight, mode='fan_out', nonlinearity='relu')
+    if bias:
+        nn.init.normal_(seq[0].bias, 0, 0.2)
+    with torch.no_grad():
+        seq[1].weight.uniform_(0.5, 1.5)
+        seq[1].bias.uniform_(-0.5, 0.5)
+        seq[1].running_mean.normal_(0, 0.3)
+        seq[1].running_var.uniform_(0.5, 2.0)
+    seq = seq.to(DEV).eval()
+    x = torch.randn(N, C, H, W, device=DEV)
+    out = {}
+    with torch.no_grad():
+        for fused in (True, False):
+            seq.fuse_eval = fused
+            out[fused] = seq(x).clone()
+    seq.fuse_eval = True
+    sc = float(out[False].abs().max())
+    assert float((out[True] - out[False]).abs().max()) <= 2e-5 * sc
+
+
 @pytest.mark.parametrize('N,C,H,W,bias,pm', [
     (2, 3, 224, 224, False, False),    # the VGG16 stem at its own map size: every tile inside the image
     (3, 3, 20, 45, True, True),        # ragged: 20 = 2 x 8 + 4 rows, 45 = 32 + 13 columns; conv bias; piggymask
