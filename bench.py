@@ -72,14 +72,15 @@ class KernelClock:
     recorded on torch's current stream, the stream the C ABI launches on)."""
 
     def __init__(self):
-        self.records = []           # (kind, algorithmic flops, start_event, end_event, executed flops)
+        self.records = []           # (kind, algorithmic flops, start_event, end_event, executed flops, algorithmic bytes)
         self.enabled = False
 
     def wrap(self, lib):
         clock = self
 
-        def timed(name, kind, flops_fn, wino=None):
+        def timed(name, kind, flops_fn, wino=None, bytes_fn=None):
             raw = getattr(lib, name)
+            bytes_fn = bytes_fn or (conv_bytes if flops_fn is conv_flops else None)
 
             def call(*args):
                 if not clock.enabled:
@@ -89,7 +90,8 @@ class KernelClock:
                 rc = raw(*args)
                 e.record()
                 fl = flops_fn(args)
-                clock.records.append((kind(args), fl, s, e, fl / 2.25 if wino is not None and wino(args) else fl))
+                clock.records.append((kind(args), fl, s, e, fl / 2.25 if wino is not None and wino(args) else fl,
+                                      bytes_fn(args) if bytes_fn else 0.0))
                 return rc
             return call
 
@@ -98,6 +100,12 @@ class KernelClock:
             oh = (d.H + 2 * d.pad_h - d.dil_h * (d.R - 1) - 1) // d.stride_h + 1
             ow = (d.W + 2 * d.pad_w - d.dil_w * (d.S - 1) - 1) // d.stride_w + 1
             return 2.0 * d.N * d.K * oh * ow * d.C * d.R * d.S
+
+        def conv_bytes(args):           # each pass reads two of {x, y or gy, W} once and writes the third once
+            d = args[0]._obj
+            oh = (d.H + 2 * d.pad_h - d.dil_h * (d.R - 1) - 1) // d.stride_h + 1
+            ow = (d.W + 2 * d.pad_w - d.dil_w * (d.S - 1) - 1) // d.stride_w + 1
+            return 4.0 * (d.N * d.C * d.H * d.W + d.N * d.K * oh * ow + d.K * d.C * d.R * d.S)
 
         # Launches that run Winograd F(2x2, 3x3) (cpg_conv2d_winograd: the library's own dispatch rule) execute 16 / 36 of the
         # algorithmic multiply-adds: reported beside the algorithmic rate, never instead of it
@@ -122,6 +130,9 @@ class KernelClock:
         def lin_flops(bi):
             return lambda a: 2.0 * a[bi] * a[bi + 1] * a[bi + 2]
 
+        def lin_bytes(bi):
+            return lambda a: 4.0 * (a[bi] * a[bi + 1] + a[bi + 1] * a[bi + 2] + a[bi] * a[bi + 2])
+
         class Proxy(object):
             pass
         p = Proxy()
@@ -144,35 +155,50 @@ class KernelClock:
         p.cpg_conv2d_dgrad_bnbwd = timed('cpg_conv2d_dgrad_bnbwd', conv_kind('conv_dgrad'), conv_flops)
         p.cpg_conv2d_dgrad = timed('cpg_conv2d_dgrad', conv_kind('conv_dgrad'), conv_flops, wino_dgrad)
         p.cpg_conv2d_wgrad = timed('cpg_conv2d_wgrad', conv_kind('conv_wgrad'), conv_flops, wino_wgrad)
-        p.cpg_linear_fwd = timed('cpg_linear_fwd', lambda a: 'linear_fwd', lin_flops(6))
-        p.cpg_linear_dgrad = timed('cpg_linear_dgrad', lambda a: 'linear_dgrad', lin_flops(5))
-        p.cpg_linear_wgrad = timed('cpg_linear_wgrad', lambda a: 'linear_wgrad', lin_flops(8))
+        p.cpg_linear_fwd = timed('cpg_linear_fwd', lambda a: 'linear_fwd', lin_flops(6), None, lin_bytes(6))
+        p.cpg_linear_dgrad = timed('cpg_linear_dgrad', lambda a: 'linear_dgrad', lin_flops(5), None, lin_bytes(5))
+        p.cpg_linear_wgrad = timed('cpg_linear_wgrad', lambda a: 'linear_wgrad', lin_flops(8), None, lin_bytes(8))
         return p
 
     def summary(self):
         agg = {}
-        for kind, flops, s, e, executed in self.records:
+        for kind, flops, s, e, executed, nbytes in self.records:
             ms = s.elapsed_time(e)
-            a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
+            a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += ms
             a[2] += flops
             a[3] += executed
+            a[4] += nbytes
         return agg
 
 
-def pmc_traffic(family, batch):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE collected separately, gfx950 correction 2 x FETCH_SIZE + WRITE_SIZE; profiles/r02_traffic.json (r01 when absent),
-    measured at batch 256, average over the 13 convs of a VGG16 pass).  None when no measurement applies."""
+def pmc_traffic(arch, family, batch):
+    """HBM bytes per launch of a kernel family from committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
+    passes, gfx950 correction 2 x FETCH_SIZE + WRITE_SIZE).  First choice: profiles/r03_traffic_bench.json -- the passes ran over
+    THIS command (bench.py --arch A --steps 20), so the launch mix is the bench's own (tools/bench_traffic.py); otherwise, for
+    VGG16, the round-2 passes over one launch of each conv of a pass (profiles/r02_traffic.json).  None when neither applies."""
+    if batch != 256:                 # every committed pass ran at the bench's default batch
+        return None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r03_traffic_bench.json')) as f:
+            fam = json.load(f)['archs'][arch]['families'][family]
+        return {'hbm_bytes_per_launch': round(fam['hbm_bytes_per_launch_corrected']),
+                'fetch_size_bytes_per_launch': round(fam['fetch_size_bytes_per_launch']),
+                'write_size_bytes_per_launch': round(fam['write_size_bytes_per_launch']),
+                'launches_counted': fam['launches'], 'source': 'profiles/r03_traffic_bench.json'}
+    except (OSError, KeyError, ValueError):
+        pass
+    if arch != 'vgg16':
+        return None
     for name in ('r02_traffic.json', 'r01_traffic.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 fam = json.load(f)['families'].get(family)
-            if fam is None or batch != 256:
+            if fam is None:
                 return None
             return {'hbm_bytes_per_launch': round(fam['hbm_bytes_per_launch_corrected']),
-                    'algorithmic_bytes_per_launch': round(fam['algorithmic_bytes_per_launch']), 'source': 'profiles/' + name}
+                    'algorithmic_bytes_per_launch_of_that_pass': round(fam['algorithmic_bytes_per_launch']), 'source': 'profiles/' + name}
         except (OSError, KeyError, ValueError):
             continue
     return None
@@ -619,17 +645,18 @@ def main():
         if agg:
             tot_ms = sum(v[1] for v in agg.values())
             fam = {}
-            for kind, (cnt, ms, fl, ex) in agg.items():
-                fk = fam.setdefault(kind.split(' ')[0], [0, 0.0, 0.0, 0.0])
+            for kind, (cnt, ms, fl, ex, nb) in agg.items():
+                fk = fam.setdefault(kind.split(' ')[0], [0, 0.0, 0.0, 0.0, 0.0])
                 fk[0] += cnt
                 fk[1] += ms
                 fk[2] += fl
                 fk[3] += ex
+                fk[4] += nb
             dom = max(fam, key=lambda k: fam[k][1])
-            cnt, ms, fl, ex = fam[dom]
+            cnt, ms, fl, ex, nb = fam[dom]
             ach = fl / (ms * 1e-3) / 1e12                      # algorithmic flops (SURVEY 8d units) per second
             exe = ex / (ms * 1e-3) / 1e12                      # multiply-adds the MFMA pipe really executed, as flops per second
-            traffic = pmc_traffic(dom, a.batch) if a.arch == 'vgg16' else None
+            traffic = pmc_traffic(a.arch, dom, a.batch)
             dense = PEAK_BF16_MFMA_TFLOPS if dom.endswith('_bf16') else PEAK_FP32_MFMA_TFLOPS
             # The ceiling of THIS launch mix: a launch that runs Winograd F(2x2,3x3) needs 16/36 of its algorithmic multiply-adds,
             # so its algorithmic ceiling is 2.25 x the dense MFMA peak; a direct launch's is the dense peak.  Weighted by MFMA
@@ -646,6 +673,9 @@ def main():
                                'traffic_source': 'static: %s (rocprofv3 --pmc passes of this workload, committed; not collected in this run)'
                                                  % traffic['source'] if traffic else None,
                                'traffic_detail': traffic,
+                               # SURVEY 8d's bytes: each launch reads two of {x, y or gy, W} once and writes the third once
+                               'algorithmic_bytes_per_launch': round(nb / cnt),
+                               'traffic_over_algorithmic': round(traffic['hbm_bytes_per_launch'] * cnt / nb, 3) if traffic else None,
                                'launches': cnt, 'avg_launch_ms': round(ms / cnt, 4),
                                'share_of_masked_kernel_time': round(ms / tot_ms, 3)}
             # the whole timed region against the dense peak, in executed multiply-adds (every masked launch, train + validate)

@@ -877,17 +877,25 @@ __global__ __launch_bounds__(kThreads) void k_bnp3_bwd_reduce(const float *__res
         for (int st = 0; st < p.strips; ++st) {
             const int r0 = st * kPool3SR, r1 = min(p.OH, r0 + kPool3SR);
             pool3_stage_bwd(src, zs, idx, p, r0, r1, m, is, ga, be);
+            // x of the quad is read again unconditionally (the strip was staged a moment ago: L2 hits, coalesced 8-byte pairs) --
+            // a load under "dz != 0" is four divergent round trips per quad
+            const bool pairs = (p.W & 1) == 0 && (((uintptr_t)src) & 7) == 0;
             for (int i = threadIdx.x; i < (r1 - r0) * p.OW; i += kThreads) {
                 const int a = r0 + i / p.OW, b = i % p.OW;
+                const int e00 = 2 * a * p.W + 2 * b;
+                const bool hx = 2 * b + 1 < p.W, hy = 2 * a + 1 < p.H;
+                float2 x0, x1 = make_float2(m, m);
+                if (pairs) {
+                    x0 = *reinterpret_cast<const float2 *>(src + e00);
+                    if (hy) x1 = *reinterpret_cast<const float2 *>(src + e00 + p.W);
+                } else {
+                    x0 = make_float2(src[e00], hx ? src[e00 + 1] : m);
+                    if (hy) x1 = make_float2(src[e00 + p.W], hx ? src[e00 + p.W + 1] : m);
+                }
                 float dz[4];
                 pool3_quad(zs, idx, gp + pl * wins, p, r0, a, b, dz);
-                const int e00 = 2 * a * p.W + 2 * b;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (dz[k] != 0.f) {                              // (non-zero for at most one element in nine)
-                        sg += dz[k];
-                        sgx += dz[k] * ((src[e00 + (k >> 1) * p.W + (k & 1)] - m) * is);
-                    }
+                sg += (dz[0] + dz[1]) + (dz[2] + dz[3]);
+                sgx += (dz[0] * ((x0.x - m) * is) + dz[1] * ((x0.y - m) * is)) + (dz[2] * ((x1.x - m) * is) + dz[3] * ((x1.y - m) * is));
             }
         }
         dsg += (double)sg;

@@ -15,6 +15,15 @@ def short(name):
     return m.group(1).strip()
 
 
+# the families bench.py reports (its HIP-event clock brackets the whole library call: + k_c3_pack for fwd / dgrad,
+# + k_c3_wgrad_reduce for wgrad); k_pw / k_pw_wgrad serve the 1x1 convs AND the un-masked linear layers
+FAMS = [('conv_fwd', r'k_c3_fwd<.*>, false(, (true|false))*>|k_conv_fwd|k_wg_fwd<\d, false|k_wg[13]<false|k_stem_fwd|k_stem2_fwd|k_pw<.*>, false'),
+        ('conv_dgrad', r'k_c3_fwd<.*>, true(, (true|false))*>|k_conv_dgrad|k_wg_fwd<\d, true|k_wg[13]<true|k_c3s2_dgrad|k_pw<.*>, true'),
+        ('conv_wgrad', r'k_c3_wgrad<|k_c3_wgrad_smallc|k_conv_wgrad|k_wgw|k_stem2_wgrad|k_pw_wgrad'),
+        ('fused BatchNorm / ReLU / pool / PReLU', r'k_bn|k_prelu'),
+        ('stock torch elementwise / pooling', r'at::native')]
+
+
 def main():
     db = sqlite3.connect(sys.argv[1])
     top_n = int(sys.argv[2]) if len(sys.argv) > 2 else 25
@@ -28,11 +37,7 @@ def main():
     # the families bench.py reports (its HIP-event clock brackets the whole library call: + k_c3_pack for fwd / dgrad,
     # + k_c3_wgrad_reduce for wgrad)
     # (k_pw / k_pw_wgrad serve the 1x1 convs AND the un-masked linear layers, so they get their own row)
-    fams = [('conv_fwd', r'k_c3_fwd<.*>, false(, (true|false))*>|k_conv_fwd|k_wg_fwd<\d, false|k_wg[13]<false|k_stem_fwd|k_stem2_fwd|k_pw<.*>, false'),
-            ('conv_dgrad', r'k_c3_fwd<.*>, true(, (true|false))*>|k_conv_dgrad|k_wg_fwd<\d, true|k_wg[13]<true|k_c3s2_dgrad|k_pw<.*>, true'),
-            ('conv_wgrad', r'k_c3_wgrad<|k_c3_wgrad_smallc|k_conv_wgrad|k_wgw|k_stem2_wgrad|k_pw_wgrad'),
-            ('fused BatchNorm / ReLU / pool / PReLU', r'k_bn|k_prelu'),
-            ('stock torch elementwise / pooling', r'at::native')]
+    fams = FAMS
     print('\n| family (main kernels only) | calls | total ms | avg ms |\n|---|---:|---:|---:|')
     for fam, pat in fams:
         sel = [r for r in rows if re.search(pat, r[0])]

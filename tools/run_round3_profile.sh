@@ -20,3 +20,11 @@ for a in vgg16 resnet50 spherenet20; do
   python $R/tools/rocprof_summary.py $db 50 > $R/gpurun_out/summary_${TAG}_$a.md 2>&1
   rm -rf $R/gpurun_out/prof_${TAG}_$a
 done
+# HBM traffic of the bench's own launch mix: FETCH_SIZE and WRITE_SIZE in separate counter passes (kernel trace only)
+for a in vgg16 resnet50 spherenet20; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/btraffic/${a}_$c -o run --output-format csv -- python $R/bench.py --arch $a --steps 20 --warmup 1 --no-cpu-baseline --optin-steps 0 > $R/gpurun_out/btraffic_${a}_$c.log 2>&1
+  done
+done
+python $R/tools/bench_traffic.py $R/gpurun_out/btraffic > $R/gpurun_out/traffic_${TAG}.json 2> $R/gpurun_out/traffic_${TAG}.err
+rm -rf $R/gpurun_out/btraffic
