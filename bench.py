@@ -689,6 +689,7 @@ def main():
                                  'note': 'all masked conv / linear launches of the timed region (train steps and validates) over the wall time'}
             out['kernel_families'] = {k: dict({'launches': v[0], 'ms': round(v[1], 2), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2),
                                                'mfma_tflops_executed': round(v[3] / (v[1] * 1e-3) / 1e12, 2),
+                                               'algorithmic_bytes_per_launch': round(v[4] / v[0]),
                                                'frac_of_dense_peak_executed': round(v[3] / (v[1] * 1e-3) / 1e12 /
                                                                                     (PEAK_BF16_MFMA_TFLOPS if k.endswith('_bf16') else PEAK_FP32_MFMA_TFLOPS), 4)})
                                       for k, v in sorted(fam.items())}

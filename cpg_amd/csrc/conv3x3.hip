@@ -1325,7 +1325,9 @@ W3Plan w3_plan(const cpg_conv_desc *d) {
     p.tiles_ci = (d->C + Cfg::BCI - 1) / Cfg::BCI;
     const int64_t units = (int64_t)d->N * p.tiles_x * p.tiles_y;
     const int64_t tiles = (int64_t)p.tiles_co * p.tiles_ci;
-    int64_t want = (2 * kCUs * 2 + tiles - 1) / tiles;         // ~2 rounds of 2 blocks per CU
+    int bpc = 4;                                               // ~2 rounds of 2 blocks per CU
+    if (const char *f = getenv("CPG_C3W_BPC")) bpc = std::max(1, atoi(f));
+    int64_t want = ((int64_t)bpc * kCUs + tiles - 1) / tiles;
     if (want > units) want = units;
     if (want < 1) want = 1;
     if (want > 4096) want = 4096;

@@ -423,9 +423,9 @@ FUSE_SKIP_ADD = True       # residual blocks: the identity branch's gradient is 
 
 
 def conv_bn_act_skip(conv, bn, act, x):
-    """(act(bn(conv(x))), x for the identity branch): conv_bn_act for the first conv of a residual block WITHOUT a downsample path
-    (models/resnet.py:84-104).  When the conv's input gradient can take an addend (dense 1x1 layers), x is routed through the conv's
-    autograd node, which then receives both of x's gradients and sums them in its kernel's epilogue."""
+    """(act(bn(conv(x))), x for the block's second branch -- the identity or the downsample conv): conv_bn_act for the first conv of
+    a residual block (models/resnet.py:84-104).  When the conv's input gradient can take an addend (dense 1x1 layers), x is routed
+    through the conv's autograd node, which then receives both of x's gradients and sums them in its kernel's epilogue."""
     if (ENABLED and FUSE_SKIP_ADD and hasattr(conv, 'forward_with_skip') and x.is_cuda and torch.is_grad_enabled() and x.requires_grad
             and conv._math() == 'fp32' and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.in_channels % 16 == 0
             and conv.out_channels % 16 == 0):

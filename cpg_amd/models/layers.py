@@ -91,6 +91,7 @@ class _MaskedConv2dFn(torch.autograd.Function):
         # bn_hint (fused_bn.BnBwdHint or None): `x` is relu(bn(ypre)) of the layer below and nothing else consumes it -- the
         # input-gradient kernel may then do that BatchNorm's backward reduction in its epilogue (cpg_conv2d_dgrad_bnbwd)
         ctx.bn_hint = bn_hint
+        ctx.set_materialize_grads(False)         # (no zero-filled "gradient" tensor for the statistics output on every backward)
         ctx.bias_sink = bias_sink if bias is not None else None     # BiasGradSink: the activation behind this conv delivers the bias gradient
         """bn_stats: also return the per-(channel, pixel tile) {sum, sum of squares} of y that the kernel accumulates
         in its epilogue (cpg_conv2d_fwd_bnstats) -- a second, non-differentiable output, or None when the shape has
@@ -162,6 +163,8 @@ class _MaskedConv2dFn(torch.autograd.Function):
     def backward(ctx, gy, _gstats=None, addend=None):
         """addend (only from _MaskedConv2dSkipFn): a tensor shaped like the input gradient that is added to it -- in the kernel's
         epilogue where the shape class has that (cpg_conv2d_dgrad_add), by one add otherwise."""
+        if gy is None:                           # the conv's output is unused: only a skip gradient (if any) flows
+            return (addend,) + (None,) * 12
         x, w, p = ctx.saved_tensors
         d, thr = ctx.desc, ctx.thr
         if ctx.empty:
@@ -240,8 +243,6 @@ class _MaskedConv2dSkipFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _gstats, gskip):
-        if gy is None:                           # the conv branch is unused: only the skip gradient flows
-            return (gskip,) + (None,) * 9
         r = _MaskedConv2dFn.backward(ctx, gy, None, addend=gskip)
         return r[:4] + (None,) * 6
 

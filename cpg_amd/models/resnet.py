@@ -66,10 +66,10 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        if self.downsample is None:
-            out, identity = conv_bn_act_skip(self.conv1, self.bn1, self.relu, x)
-        else:
-            out, identity = conv_bn_act(self.conv1, self.bn1, self.relu, x), self.downsample(x)
+        # the block input feeds conv1 and the second branch (identity or downsample conv): routed through conv1's autograd node, which
+        # then adds the second branch's gradient in its own input-gradient epilogue (no separate add pass)
+        out, skip = conv_bn_act_skip(self.conv1, self.bn1, self.relu, x)
+        identity = skip if self.downsample is None else self.downsample(skip)
         out = conv_bn_act(self.conv2, self.bn2, self.relu, out)
         return conv_bn_add_act(self.conv3, self.bn3, self.relu, out, identity)
 

@@ -17,7 +17,8 @@ SHAPES = [('r50 stem 7x7s2', 3, 64, 224, 7, 2, 3), ('r50 1x1 64>256 @56', 64, 25
           ('r50 1x1 256>128 @56', 256, 128, 56, 1, 1, 0), ('r50 3x3s2 128 @56', 128, 128, 56, 3, 2, 1), ('r50 1x1 128>512 @28', 128, 512, 28, 1, 1, 0),
           ('r50 1x1 512>128 @28', 512, 128, 28, 1, 1, 0), ('r50 ds 1x1s2 256>512', 256, 512, 56, 1, 2, 0), ('r50 1x1 256>1024 @14', 256, 1024, 14, 1, 1, 0),
           ('r50 1x1 1024>256 @14', 1024, 256, 14, 1, 1, 0), ('r50 1x1 512>2048 @7', 512, 2048, 7, 1, 1, 0), ('r50 1x1 2048>512 @7', 2048, 512, 7, 1, 1, 0),
-          ('sph 3x3s2 3>64 @112', 3, 64, 112, 3, 2, 1), ('sph 3x3s2 64>128 @56', 64, 128, 56, 3, 2, 1), ('sph 3x3s2 256>512 @14', 256, 512, 14, 3, 2, 1)]
+          ('sph 3x3s2 3>64 @112', 3, 64, 112, 3, 2, 1), ('sph 3x3s2 64>128 @56', 64, 128, 56, 3, 2, 1), ('sph 3x3s2 256>512 @14', 256, 512, 14, 3, 2, 1),
+          ('3x3 512>512 @7 (odd map)', 512, 512, 7, 3, 1, 1), ('sph 3x3 64>64 @56', 64, 64, 56, 3, 1, 1), ('sph 3x3 256>256 @14', 256, 256, 14, 3, 1, 1)]
 
 
 def timeit(fn, iters):

@@ -53,6 +53,32 @@ def fam_table(d):
     return '\n'.join(rows)
 
 
+def traffic_table():
+    """HBM bytes per launch (PMC passes over the bench itself, profiles/r03_traffic_bench.json) beside the algorithmic bytes the bench counts."""
+    try:
+        t = json.load(open(os.path.join(P, 'r03_traffic_bench.json')))['archs']
+    except (OSError, KeyError, ValueError):
+        return ''
+    benches = {'vgg16': b20, 'resnet50': others['resnet50'], 'spherenet20': others['spherenet20']}
+    rows = ['## HBM traffic of the bench\'s own launch mix (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --arch A --steps 20`; '
+            '2 x FETCH_SIZE + WRITE_SIZE, per library call; profiles/r03_traffic_bench.json)\n',
+            '| topology | family | launches counted | HBM MB / launch | algorithmic MB / launch (two operands read once, the third written once) | ratio | split-reduce / pack share of the bytes |',
+            '|---|---|---:|---:|---:|---:|---:|']
+    for a, fams in t.items():
+        kd = benches[a].get('kernel_families', {})
+        for fam, v in fams['families'].items():
+            alg = None
+            r = benches[a]['roofline']
+            if kd.get(fam, {}).get('algorithmic_bytes_per_launch'):
+                alg = kd[fam]['algorithmic_bytes_per_launch']
+            elif r['kernel'] == fam and r.get('algorithmic_bytes_per_launch'):
+                alg = r['algorithmic_bytes_per_launch']
+            rows.append('| %s | %s | %d | %.0f | %s | %s | %.3f |' % (a, fam, v['launches'], v['hbm_bytes_per_launch_corrected'] / 1e6,
+                                                                 '%.0f' % (alg / 1e6) if alg else '(not in this bench line)',
+                                                                 '%.2f' % (v['hbm_bytes_per_launch_corrected'] / alg) if alg else '', v['helper_kernels_share_of_bytes']))
+    return '\n'.join(rows) + '\n\n'
+
+
 def roof(d):
     r = d['roofline']
     return ('`roofline`: %s, achieved %.1f TFLOP/s algorithmic (%.1f executed), peak %.1f (launch-mix ceiling; dense %.1f), **frac %.4f**; '
@@ -78,6 +104,7 @@ with open(os.path.join(P, '%s_final.md' % out), 'w') as f:
     w('* `cpu_baseline`: %s\n\n' % json.dumps({k: v for k, v in b20['cpu_baseline'].items() if k != 'sample'}))
     w('## bench.py, K = 20 (HIP events around every C-ABI launch of the timed region)\n\n%s\n\n' % fam_table(b20))
     w('phases: `%s`\n\n' % json.dumps(b20['phases']))
+    w(traffic_table())
     w('## rocprofv3 --kernel-trace --stats of the same command (25 train + 4 eval passes incl. warm-up)\n\n')
     w(read(os.path.join(G, 'summary_%s_vgg16.md' % tag)))
     w('\n')
@@ -93,14 +120,10 @@ with open(os.path.join(P, '%s_other_nets.md' % out), 'w') as f:
         w('        %-12s %.1f img/s, %.3f ms/step -> profiles/%s_bench_%s.json\n' % (a, d['value'], d['ms_per_step'], out, a))
     w('    python tools/generic_bench.py --iters 5  (per shape class through the C ABI, TFLOP/s algorithmic; ms)\n\n')
     w('```\n' + read(os.path.join(G, 'generic_%s.txt' % tag)).strip() + '\n```\n\n')
-    mac = {'resnet50': (4.087, 1.2716, 'layer1-3 conv2 (11 layers)'), 'spherenet20': (2.029, 1.619, 'the 14 layers on 56 / 28 / 14-wide maps')}
     for a, d in others.items():
-        tot, wino, which = mac[a]
-        ceil = 157.3 * tot / (tot - wino * 20.0 / 36.0)
         w('## %s\n\n' % a)
-        w('Winograd F(2x2,3x3) runs the 3x3 s1 layers on even maps: %s = %.3f of %.3f G MACs / image -> launch-mix ceiling of a train step '
-          '157.3 x %.3f / %.3f = %.1f TFLOP/s algorithmic (the wgrad of a layer runs it where its map is 14 or a multiple of 28 pixels wide).\n\n'
-          % (which, wino, tot, tot, tot - wino * 20.0 / 36.0, ceil))
+        w('Winograd F(2x2,3x3) runs the 3x3 s1 layers (forward / input gradient also on the 7x7 maps; the weight gradient where the map is 14 or a '
+          'multiple of 28 pixels wide); the launch-mix ceiling below is the bench\'s own: dense peak x algorithmic / executed flops of the launches it timed.\n\n')
         w('* %s\n* train steps alone: %.1f TFLOP/s algorithmic (`algorithmic_tflops_train_steps`)\n\n' % (roof(d), d['algorithmic_tflops_train_steps']))
         w(fam_table(d) + '\n\nphases: `%s`\n\n' % json.dumps(d['phases']))
         w('rocprofv3 --kernel-trace --stats of `bench.py --arch %s --steps 20 --warmup 5 --no-cpu-baseline` (bench line under the profiler: '

@@ -66,7 +66,7 @@ def main():
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / a.steps * 1e3
-    print('%s batch %d (%s): %.1f ms/step, %.0f img/s, %.1f TFLOP/s (conv MACs only)' % (
+    print('%s batch %d (%s): %.2f ms/step, %.0f img/s, %.1f TFLOP/s (conv MACs only)' % (
         a.arch, a.batch, a.math, ms, a.batch / ms * 1e3, a.batch * FLOP_PER_IMG.get(a.arch, 0) / ms / 1e9))
 
 
