@@ -314,12 +314,14 @@ bool ww_plan(const cpg_conv_desc *d, WwPlan &p) {
     g.nstages = (unsigned)nstages;
     g.nkb = d->K / 32, g.ncb = d->C / 32;
     const int64_t npairs = (int64_t)g.nkb * g.ncb;
-    // units per wave slot: 4.  Every unit costs a prologue / epilogue and a 9 x 32 x 32 partial sum that k_split_reduce has to read;
-    // 6 (the first choice) measured 35.25 ms per VGG16 pass against 34.0-34.3 ms for 1, 2 or 4 (the units of a launch are equally
-    // long: there is little to balance on an otherwise idle chip).  Not fewer than 4: a launch is only (units per slot) rounds of
-    // blocks, and when another stream's kernels (RCCL) hold some CUs a 2-round launch would grow by a whole round.  cpg_amd.dist
-    // asks for 8 when it wraps a model for more than one rank (cpg_set_shared_chip_hint).  CPG_WW_UNITS overrides.
-    int upw = shared_chip_hint() ? 8 : 4;
+    // units per wave slot.  Every unit costs a prologue / epilogue and a 9 x 32 x 32 partial sum (36.9 KB) that it writes and
+    // k_split_reduce reads: 4 units per slot are 4096 units = 151 MB of partials per launch whatever the layer's size -- the PMC
+    // passes over the bench (profiles/r03_traffic_bench.json) showed SphereNet-20's weight-gradient launches moving 4 x their
+    // algorithmic bytes, 22 % of them in the reduce.  One unit per slot (the units of a launch are equally long: nothing to
+    // balance on an idle chip): SphereNet-20 20.96 -> 19.92 ms per step, ResNet-50 73.83 -> 72.69, VGG16 121.10 -> 120.44.
+    // When another stream's kernels (RCCL) hold some CUs a one-round launch would grow by a whole round, so cpg_amd.dist asks
+    // for 4 rounds when it wraps a model for more than one rank (cpg_set_shared_chip_hint).  CPG_WW_UNITS overrides.
+    int upw = shared_chip_hint() ? 4 : 1;
     if (const char *f = getenv("CPG_WW_UNITS")) upw = std::max(1, atoi(f));
     int64_t want = std::max<int64_t>(1, ((int64_t)upw * 4 * kCUs) / npairs);
     want = std::min<int64_t>(want, nstages);
