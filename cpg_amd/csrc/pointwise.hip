@@ -22,6 +22,7 @@
 //   wgrad: gW[k][c] = sum_g gy[k][g] * x[c][g] for dense (stride 1), 4 | pixels-per-image layers: k_pw_wgrad below;
 //          strided / odd-sized ones stay on the generic split-K kernel of igemm_conv.hip.
 #include <algorithm>
+#include <type_traits>
 #include "igemm_core.h"
 
 using namespace cpg;
@@ -35,8 +36,35 @@ struct PwGeom {
     int in_plane, in_sy, in_sx;     // channel plane size of the tensor read, and its row / column pitch per grid step
     int out_plane, out_sy, out_sx;  // same for the tensor written
     int tiles_m;
-    long long G;               // N * HWo
-};
+    long long G;               // N * HWo (< 2^31 - 512: the kernels index the grid with 32-bit integers)
+    float inv_hwo, inv_ow;     // 1 / HWo, 1 / OW (divmod_small)
+    int flags;                 // kPwDenseIn: the tensor read is the grid itself (position = q); kPwDenseOut: same for the tensor written;
+};                             // kPwSingle: one "image" (the plain GEMMs): no image index at all
+enum { kPwDenseIn = 1, kPwDenseOut = 2, kPwSingle = 4 };
+inline void pw_finish_geom(PwGeom &g) {
+    g.inv_hwo = 1.0f / (float)g.HWo;
+    g.inv_ow = 1.0f / (float)g.OW;
+    g.flags = (g.N == 1 ? kPwSingle : 0) | ((g.in_sx == 1 && (g.in_sy == g.OW || g.N == 1 && g.in_sy == 0)) ? kPwDenseIn : 0) |
+              ((g.out_sx == 1 && (g.out_sy == g.OW || g.N == 1 && g.out_sy == 0)) ? kPwDenseOut : 0);
+}
+
+// rel / d and rel % d for rel < 2^24 (exact in fp32) and a quotient of a few hundred at most: one multiply by the reciprocal and one
+// correction step -- ~10 vector instructions where the compiler's 64-bit division is ~150.  On this chip every vector instruction of
+// a wave costs its SIMD 4 cycles of fp32 MFMA issue (the two share the fp32 datapath: MFMA-busy + 4 x VALU instructions = 0.95-0.98 of
+// the kernel's cycles in every counter pass, profiles/r03_pmc_pointwise.md), so the tile prologue / epilogue arithmetic is not free.
+__device__ __forceinline__ void divmod_small(unsigned rel, unsigned d, float inv, unsigned &qt, unsigned &rm) {
+    unsigned n = (unsigned)((float)rel * inv);
+    int r = (int)(rel - n * d);
+    if (r < 0) {
+        n -= 1;
+        r += (int)d;
+    } else if (r >= (int)d) {
+        n += 1;
+        r -= (int)d;
+    }
+    qt = n;
+    rm = (unsigned)r;
+}
 
 __device__ __forceinline__ f32x4 ld_sv4(const float *sbase, unsigned byte_off) {
     return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(sbase) + byte_off);
@@ -95,15 +123,32 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
     static_assert(!ADD || (DGRAD && !STATS), "the addend rides in plain input-gradient launches");
     static_assert(!STATS || !DGRAD, "statistics ride in forward launches");
     __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
     const int li = lane & 31, lh = lane >> 5;
 
     unsigned lb = xcd_remap(blockIdx.x, gridDim.x);      // m tile fastest: blocks sharing a pixel tile share an L2
-    const int tm = lb % g.tiles_m;
-    const long long g0 = (long long)(lb / g.tiles_m) * Cfg::BN;
+    // (the integer divisions of uniform values are expanded into vector code: pin the results to scalar registers, or everything
+    // derived from them -- descriptors, channel tests -- is computed per lane)
+    const int tm = __builtin_amdgcn_readfirstlane((int)(lb % (unsigned)g.tiles_m));
+    const unsigned g0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((lb / (unsigned)g.tiles_m) * Cfg::BN));   // first grid position of the tile (G < 2^31)
+    const unsigned Gu = (unsigned)g.G, HWo = (unsigned)g.HWo;
     const int m0 = tm * Cfg::BM;
-    const int n_first = (int)(g0 / g.HWo);
+    const bool single = g.flags & kPwSingle;
+    const int n_first = single ? 0 : __builtin_amdgcn_readfirstlane((int)(g0 / HWo));
+    const unsigned rel0 = g0 - (unsigned)n_first * HWo;  // the tile's first position within image n_first
+    // grid position rel0 + j -> (image - n_first, position in the tensor's plane given its row / column pitch)
+    auto locate = [&](unsigned j, bool dense, int sy, int sx, unsigned &n_rel, unsigned &pos) {
+        unsigned q = rel0 + j;
+        n_rel = 0;
+        if (!single) divmod_small(q, HWo, g.inv_hwo, n_rel, q);
+        pos = q;
+        if (!dense) {
+            unsigned row, col;
+            divmod_small(q, (unsigned)g.OW, g.inv_ow, row, col);
+            pos = row * (unsigned)sy + col * (unsigned)sx;
+        }
+    };
 
     // ---- staging descriptors (fixed for the life of the block) ----
     const int wcol = (tid % Cfg::W4) * 4, wrow0 = tid / Cfg::W4;
@@ -113,17 +158,16 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
     // positions past the last image -- the buffer unit's range check returns 0 for those
     constexpr int kOutOfRange = (int)0x80000000;
     int xbyte[Cfg::NX], xdst[Cfg::NX];
+    const bool dense_in = g.flags & kPwDenseIn;
 #pragma unroll
     for (int i = 0; i < Cfg::NX; ++i) {
         const int e = tid + 256 * i;
         constexpr int PER_ROW = Cfg::VEC ? Cfg::BN / 4 : Cfg::BN;
         const int cl = e / PER_ROW, j = (e - cl * PER_ROW) * (Cfg::VEC ? 4 : 1);
-        const long long gg = g0 + j;
-        const bool ok = e < Cfg::XE && gg < g.G;
-        const int n_rel = ok ? (int)(gg / g.HWo) - n_first : 0;
-        const int q = ok ? (int)(gg % g.HWo) : 0;
-        const int pos = (q / g.OW) * g.in_sy + (q % g.OW) * g.in_sx;
-        xbyte[i] = ok ? ((n_rel * g.C + cl) * g.in_plane + pos) * 4 : kOutOfRange;
+        const bool ok = e < Cfg::XE && g0 + (unsigned)j < Gu;
+        unsigned n_rel, pos;
+        locate((unsigned)j, dense_in, g.in_sy, g.in_sx, n_rel, pos);
+        xbyte[i] = ok ? (int)((((n_rel * (unsigned)g.C + (unsigned)cl) * (unsigned)g.in_plane) + pos) * 4u) : kOutOfRange;
         xdst[i] = e < Cfg::XE ? cl * Cfg::LDX + j : Cfg::CK * Cfg::LDX;            // spare row for the idle threads of the last pass
     }
     const long long remaining = (long long)(g.N - n_first) * g.C * g.in_plane * 4;
@@ -212,6 +256,11 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
     }
 
     // ---- epilogue: D col = grid position (lane & 31), D row = channel ----
+    // Addressing is 32-bit and mostly scalar: per fragment column a lane computes ONE byte offset (its grid position in the output
+    // tensor, + 4 lh channel planes); the channel of accumulator element e is uniform -- it goes into the buffer descriptor's base
+    // (one descriptor per group of 8 channels, built with scalar arithmetic) and the store's scalar offset.  Invalid grid positions
+    // carry the out-of-range offset, whole invalid channel groups are skipped by a scalar branch (the hosts only send channel
+    // counts that are multiples of 8 here: 16 for the convs, cpg_pw_gemm_nn_ok for the plain GEMMs).
     float s1[STATS ? Cfg::FM : 1][16], s2[STATS ? Cfg::FM : 1][16];
     if (STATS) {
 #pragma unroll
@@ -219,44 +268,67 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
 #pragma unroll
             for (int e = 0; e < 16; ++e) s1[fm][e] = s2[fm][e] = 0.0f;
     }
+    const bool dense_out = g.flags & kPwDenseOut;
+    const long long img_base = (long long)n_first * g.M * g.out_plane;             // (elements) image n_first, channel 0
+    const long long y_total = (long long)g.N * g.M * g.out_plane;
+    const unsigned plane4 = (unsigned)g.out_plane * 4u;
+    auto write_out = [&](auto has_bias) {        // two copies of the loop, picked by ONE uniform branch (the ResNet convs have no bias)
 #pragma unroll
     for (int fn = 0; fn < Cfg::FN; ++fn) {
-        const long long gg = g0 + (wn * Cfg::FN + fn) * 32 + li;
-        const bool pok = gg < g.G;
-        const int n = pok ? (int)(gg / g.HWo) : 0, q = pok ? (int)(gg % g.HWo) : 0;
-        const int64_t yoff = (int64_t)n * g.M * g.out_plane + (q / g.OW) * g.out_sy + (q % g.OW) * g.out_sx;
-        float *yout = y + yoff;
+        const unsigned pix = (unsigned)((wn * Cfg::FN + fn) * 32 + li);
+        const bool pok = g0 + pix < Gu;
+        unsigned n_rel, pos;
+        locate(pix, dense_out, g.out_sy, g.out_sx, n_rel, pos);
+        // byte offset of (image n_first + n_rel, channel 4 lh, position) from (image n_first, channel 0)
+        const int voff = pok ? (int)((((n_rel * (unsigned)g.M + 4u * (unsigned)lh) * (unsigned)g.out_plane) + pos) * 4u) : kOutOfRange;
 #pragma unroll
         for (int fm = 0; fm < Cfg::FM; ++fm) {
-            float bv[16];
+            const int rowf = m0 + (wm * Cfg::FM + fm) * 32;                         // channels rowf + 8 eg + (e & 3) + 4 lh
+            auto group_srd = [&](const float *base, int eg) {
+                const long long gbase = img_base + (long long)(rowf + 8 * eg) * g.out_plane;
+                const int records = (int)std::max<long long>(0, std::min<long long>((y_total - gbase) * 4, 0x7FFFFFFFll));
+                return __builtin_amdgcn_make_buffer_rsrc((void *)(base + gbase), 0, records, 0x00020000);
+            };
+            float av[16];
+            if (ADD) {                                                              // the fragment's 16 addend loads go out together
 #pragma unroll
-            for (int e = 0; e < 16; ++e) bv[e] = 0.0f;
-            if (ADD) {                       // 16 loads issued together, consumed by the stores below
+                for (int eg = 0; eg < 4; ++eg) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    bv[e] = (pok && co < g.M) ? addend[yoff + (int64_t)co * g.out_plane] : 0.0f;
+                    for (int r = 0; r < 4; ++r) av[4 * eg + r] = 0.0f;
+                    if (rowf + 8 * eg >= g.M) continue;                             // (uniform) a group past the last channel has no descriptor
+                    const __amdgpu_buffer_rsrc_t srd_a = group_srd(addend, eg);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        av[4 * eg + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_a, voff, r * plane4, 0));
                 }
             }
-            if (bias != nullptr) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    bv[e] = bias[co < g.M ? co : 0];
-                }
-            }
+            for (int eg = 0; eg < 4; ++eg) {
+                const int row0 = rowf + 8 * eg;
+                if (row0 >= g.M) continue;                                          // (uniform; M is a multiple of 8: whole groups)
+                const __amdgpu_buffer_rsrc_t srd_y = group_srd(y, eg);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int co = m0 + (wm * Cfg::FM + fm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const float v = acc[fm][fn][e] + bv[e];
-                if (pok && co < g.M) yout[(int64_t)co * g.out_plane] = v;
-                if (STATS && pok) {
-                    s1[fm][e] += v;
-                    s2[fm][e] += v * v;
+                for (int r = 0; r < 4; ++r) {
+                    const int e = 4 * eg + r;
+                    float v = acc[fm][fn][e];
+                    if (ADD) v += av[e];
+                    if (decltype(has_bias)::value) {
+                        const int co = row0 + r + 4 * lh;
+                        v += bias[co < g.M ? co : 0];
+                        if (STATS && !pok) v = 0.0f;                               // (without a bias a padded position is an exact 0)
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), srd_y, voff, r * plane4, 0);
+                    if (STATS) {
+                        s1[fm][e] += v;
+                        s2[fm][e] = fmaf(v, v, s2[fm][e]);
+                    }
                 }
             }
         }
     }
+    };
+    if (bias != nullptr) write_out(std::true_type{});
+    else write_out(std::false_type{});
     if (STATS) {
         // sum over the 32 pixel lanes of each half-wave (DPP adds; valid in lanes 16-31 / 48-63)
         const unsigned ntiles = gridDim.x / g.tiles_m, tile_n = xcd_remap(blockIdx.x, gridDim.x) / g.tiles_m;
@@ -524,7 +596,13 @@ int pw_wgrad_launch(const cpg_conv_desc *d, const float *x, const float *gy, con
 }
 
 //                BM  WM WN FN CK  VEC  MINW
-using PwV = PwCfg<128, 4, 1, 7, 16, true, 3>;       // dense reads, 4 | pixels per image: float4 staging
+#ifndef PW_MINW
+#define PW_MINW 3
+#endif
+#ifndef PW_CK
+#define PW_CK 16
+#endif
+using PwV = PwCfg<128, 4, 1, 7, PW_CK, true, PW_MINW>;       // dense reads, 4 | pixels per image: float4 staging
 using PwS = PwCfg<128, 4, 1, 7, 16, false, 2>;      // strided reads (1x1 s2 forward) or odd plane sizes (7x7 maps)
 // <= 64 channels produced (ResNet layer1: conv1 forward, conv3 input gradient): a 128-row tile would run half of its MFMAs on
 // rows that do not exist.  64 rows x 256 flattened pixels (2 x 2 waves, 4 fragments each); 56 x 56 maps x any batch divide by 256.
@@ -538,6 +616,9 @@ template <class Cfg, bool DGRAD>
 int launch(PwGeom g, const float *x, const float *wp, const float *bias, float *y, hipStream_t stream, const char *what,
            float *stats = nullptr, const float *addend = nullptr) {
     g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
+    pw_finish_geom(g);
+    if (g.G >= (1ll << 31) - 512 || (g.N > 1 && (int64_t)g.HWo + 1024 >= (1 << 24)))
+        return fail(CPG_E_UNSUPPORTED, "conv1x1: grid too large for 32-bit tile arithmetic");
     const int64_t blocks = (g.G + Cfg::BN - 1) / Cfg::BN * g.tiles_m;
     if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "conv1x1: grid too large");
     if constexpr (!DGRAD) {
@@ -570,6 +651,8 @@ extern "C" int cpg_conv1x1_supported(const cpg_conv_desc *d) {
     // whole 16-channel chunks on both sides (forward contracts over C, the input gradient over K); a tile's images are
     // addressed with 31-bit byte offsets
     const int64_t span = (int64_t)(256 / (OH * OW) + 2) * std::max(d->C, d->K) * d->H * d->W * 4;
+    // (32-bit tile arithmetic: grid positions below 2^31, a plane's positions exact in fp32 -- divmod_small)
+    if ((int64_t)d->N * OH * OW >= (1ll << 31) - 512 || (int64_t)OH * OW + 1024 >= (1 << 24)) return 0;
     return d->C % 16 == 0 && d->K % 16 == 0 && span < (1ll << 31) && (int64_t)std::max(d->C, d->K) * d->H * d->W < (1ll << 28);
 }
 
@@ -701,7 +784,7 @@ int cpg_pw_gemm_nt(const float *A, const float *B, int M, int C, int64_t K, cons
 bool cpg_pw_gemm_nn_ok(const float *X, int M, int Mp, int Kd, int64_t G) {
     // no split-K here: the output tiles alone must fill the chip (4096 -> 4096 dgrad at batch 256 has 38 of them: 4x slower)
     if (((G + 223) / 224) * ((M + 127) / 128) < 192) return false;
-    return !getenv("CPG_DISABLE_PW_GEMM") && Kd % 16 == 0 && Mp % 128 == 0 && Mp >= M && G < (1ll << 28) &&
+    return !getenv("CPG_DISABLE_PW_GEMM") && Kd % 16 == 0 && M % 8 == 0 && Mp % 128 == 0 && Mp >= M && G < (1ll << 28) &&
            (int64_t)Kd * G * 4 < (1ll << 31) && (int64_t)M * G < (1ll << 31) && (((uintptr_t)X) & 15) == 0;
 }
 // y[M][G] (+ bias[m]) from K-major Wp (row stride Mp >= M, a multiple of 128; rows beyond Kd are never read)

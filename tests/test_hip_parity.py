@@ -1754,7 +1754,8 @@ def test_conv_prelu_bias_gradient_from_the_prelu_backward():
         assert float((a - b).abs().max()) <= 1e-5 * sc + 1e-7
 
 
-@pytest.mark.parametrize('N,C,K,H', [(6, 64, 16, 28), (3, 256, 64, 14), (5, 32, 16, 7)])
+@pytest.mark.parametrize('N,C,K,H', [(6, 64, 16, 28), (3, 256, 64, 14), (5, 32, 16, 7),
+                                     (4, 16, 16, 14), (9, 48, 32, 7), (2, 144, 16, 30)])   # (fewer channels than a tile's rows: idle channel groups / waves)
 def test_skip_gradient_in_the_input_gradient_epilogue(N, C, K, H):
     """A residual block without a downsample path: its input feeds conv1 (1x1) and the identity branch.  Routed through
     SharableConv2d.forward_with_skip the two gradients of the input meet inside conv1's input-gradient kernel (cpg_conv2d_dgrad_add)

@@ -37,10 +37,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--only', default='', help='substring of the shape name')
     a = ap.parse_args()
     L, dev, st, P = _lib.lib(), 'cuda:0', _lib.stream_ptr(), _lib.dptr
     print('%-24s %8s %8s %8s   (TFLOP/s; ms)' % ('shape', 'fwd', 'dgrad', 'wgrad'))
     for name, C, K, H, k, s, p in SHAPES:
+        if a.only and a.only not in name:
+            continue
         OH = (H + 2 * p - k) // s + 1
         x = torch.randn(a.batch, C, H, H, device=dev)
         w = torch.randn(K, C, k, k, device=dev) * 0.05

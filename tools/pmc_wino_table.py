@@ -5,6 +5,7 @@ import csv
 import glob
 import sys
 
+KEEP = ('k_wg_', 'k_c3_fwd', 'k_pw')
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for root in sys.argv[1:]:
     for f in glob.glob(root + '/**/*counter_collection.csv', recursive=True):
@@ -15,7 +16,7 @@ for root in sys.argv[1:]:
             for n, v in c.items():
                 agg[k][n].append(v)
 for k, c in agg.items():
-    if 'k_wg_' not in k and 'k_c3_fwd' not in k:
+    if not any(t in k for t in KEEP):
         continue
     m = {n: sum(v) / len(v) for n, v in c.items()}
     print(k[:110])
