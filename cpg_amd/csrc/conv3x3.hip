@@ -1327,7 +1327,7 @@ W3Plan w3_plan(const cpg_conv_desc *d) {
     const int64_t tiles = (int64_t)p.tiles_co * p.tiles_ci;
     // split blocks per CU (each split writes a full set of partial sums): 2 instead of round 2's 4 -- SphereNet-20 20.96 -> 20.78,
     // ResNet-50 73.83 -> 73.49 ms per step (A/B through CPG_C3W_BPC; 8: 21.45 / 74.11)
-    int bpc = 2;
+    int bpc = shared_chip_hint() ? 4 : 2;      // (data parallel: RCCL's kernels hold CUs -- a one-round launch would grow by a whole round)
     if (const char *f = getenv("CPG_C3W_BPC")) bpc = std::max(1, atoi(f));
     int64_t want = ((int64_t)bpc * kCUs + tiles - 1) / tiles;
     if (want > units) want = units;

@@ -77,8 +77,8 @@ typedef struct cpg_prune_result {
 int cpg_version(void);
 /* Scheduling hint of the CALLING HOST THREAD (thread-local, default 0): 1 = other streams' kernels share the chip with this
  * thread's launches (a data-parallel run: RCCL's all-reduce kernels hold some CUs during the backward pass).  Only changes
- * scheduling and the summation order of split partial sums; the Winograd weight gradient then splits into 4 units per wave slot instead of 1 so that a launch that finds
- * CUs taken is still balanced by the dispatcher.  Set it before the workspace query of the calls it should affect.
+ * scheduling and the summation order of split partial sums; the weight gradients then split finer (Winograd: 4 units per wave slot instead of 1; pointwise / direct
+ * 3x3: 4 split blocks per CU instead of 2) so that a launch that finds CUs taken is still balanced by the dispatcher.  Set it before the workspace query of the calls it should affect.
  * Replaces nn.DataParallel's implicit "all GPUs are mine" (CPG_cifar100_main_normal.py:199-200). */
 int cpg_set_shared_chip_hint(int32_t shared);
 /* human-readable text for the last non-zero status returned on THIS thread */
