@@ -1328,7 +1328,7 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         if (ODD) oddcol = (g.W & 1) && tx == g.tw - 1;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int gh = 2 * ty - 1 + ph + i;
+            const int gh = 2 * ty - 1 + ph + (ph ? 2 - i : i);          // wave 1 holds its rows 3, 2, 1 (see T_col)
             roff[i] = (tv && (unsigned)gh < (unsigned)g.H) ? (cbase + gh * g.W + 2 * tx - (oddcol ? 1 : 0)) * 4 : kOutOfRange;
         }
         lo = tx == 0 ? 0 : (li + 1) * 2 - 1;
@@ -1338,7 +1338,7 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         const unsigned th = side ? t0 + W1_T - 1 : t0;
         const int nh = (int)(th / timg), rh = (int)(th % timg);
         const int tyh = (int)((unsigned)rh / twu), txh = (int)((unsigned)rh % twu);
-        const int ghh = 2 * tyh - 1 + ph + hi, gwh = side ? 2 * txh + 2 : 2 * txh - 1;
+        const int ghh = 2 * tyh - 1 + ph + (ph ? 2 - hi : hi), gwh = side ? 2 * txh + 2 : 2 * txh - 1;
         const bool okh = lane < 24 && th < ttot && (unsigned)ghh < (unsigned)g.H && (unsigned)gwh < (unsigned)g.W;
         hoff = okh ? (((nh - n0) * g.C + hc) * HW + ghh * g.W + gwh) * 4 : kOutOfRange;
     }
@@ -1347,8 +1347,11 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     const __amdgpu_buffer_rsrc_t srd_x =
         __builtin_amdgcn_make_buffer_rsrc((void *)(x + (int64_t)n0 * g.C * HW), 0, nimg_here * g.C * HW * 4, 0x00020000);
     // U records are per block of 32 channels: this wave reads float4 q = 4 ph .. + 3 of the records of blocks 2 kb, 2 kb + 1
-    const float *ubase = up + (int64_t)(2 * kb) * g.nch * W1_U + ph * 1024 + lane * 4;
-    const int64_t ukq = (int64_t)g.nch * W1_U;
+    // (through a buffer descriptor: four per-lane byte offsets computed once per unit, the chunk in the scalar offset, the float4 pair
+    //  in the instruction offset -- no vector instruction per load; 64-bit pointer arithmetic was four per chunk)
+    const __amdgpu_buffer_rsrc_t srd_u = __builtin_amdgcn_make_buffer_rsrc((void *)up, 0, (int)(((int64_t)g.nkb + 1) / 2 * 2 * g.nch * W1_U * 4), 0x00020000);
+    const int ubase = ((2 * kb) * g.nch * W1_U + ph * 1024 + lane * 4) * 4;
+    const int ukq = g.nch * W1_U * 4;
 
     // raw[c][row][slot][2] offsets of this lane (channels 2 lh + j)
     const int raw_own = (2 * lh) * 3 * W1_ROW + (li + 1) * 2;
@@ -1382,12 +1385,17 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         } else if (lane < 24)
             raw[halo_w] = q.halo;
     };
-    // Wave ph = 1 keeps its two transform rows in REVERSE order (local row 0 = row 3, local row 1 = row 2): then local row 0 of
-    // B^T d is e0 - e2 for both waves (rows held: 0 1 2 / 1 2 3) and only local row 1 differs -- 3 instead of 5 vector
-    // instructions per column pair in the loop -- and the row a wave GIVES the other in the epilogue is local row 1 for both.
-    const int urow = ph * 512;                                // float4 q ^ 2 of the wave's four: + 512 floats for q = 0, 1, - 512 for q = 2, 3
+    // Wave ph = 1 keeps its two transform rows in REVERSE order (local row 0 = row 3, local row 1 = row 2) AND its three patch rows
+    // in reverse order (e0, e1, e2 = patch rows 3, 2, 1; wave 0: 0, 1, 2): then local row 0 of B^T d is e0 - e2 for both waves
+    // (= row 0 = d0 - d2 for wave 0, = -(row 3) = d3 - d1 for wave 1) and local row 1 is e1 + sgn e2 (row 1 = d1 + d2, row 2 =
+    // d2 - d1) -- ONE fused multiply-add with the wave's sign where a select between two operands was two instructions: 2 instead
+    // of 3 vector instructions per column.  The negated row 3 is put right where the two waves' rows meet in the epilogue (own =
+    // r1 + sgn r0 instead of r0 + r1): every value is bit for bit what it was.  The row a wave GIVES the other is local row 1 for both.
+    const float sgn = ph ? -1.0f : 1.0f;
+    const int urow = ph * 512 * 4;                            // float4 q ^ 2 of the wave's four: + 512 floats for q = 0, 1, - 512 for q = 2, 3
+    const int uoff[4] = {ubase + urow, ubase - urow + 512 * 4, ubase + ukq + urow, ubase + ukq - urow + 512 * 4};   // [(q >> 2) * 2 + ((q >> 1) & 1)]
     auto G_u1 = [&](int ch, f32x4 (&u)[8], int q) {
-        u[q] = *reinterpret_cast<const f32x4 *>(ubase + ((q & 2) ? -urow : urow) + (q >> 2) * ukq + (int64_t)ch * W1_U + (q & 3) * 256);
+        u[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_u, uoff[(q >> 2) * 2 + ((q >> 1) & 1)] + (q & 1) * 256 * 4, ch * (W1_U * 4), 0));
     };
     // half patch of (tile li, channel 2 lh + j): rows ph .. ph + 2 -> the 8 values of transform rows 2 ph, 2 ph + 1 in d[0..7]
     auto T_read1 = [&](int stage, int j, float (&d)[12], int i) {
@@ -1395,14 +1403,13 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         const f32x2 own = *reinterpret_cast<const f32x2 *>(raw + (li + 1) * 2);
         d[i * 4 + 0] = raw[lo], d[i * 4 + 1] = own[0], d[i * 4 + 2] = own[1], d[i * 4 + 3] = raw[ro];
     };
-    // B^T d: ph = 0 holds patch rows 0, 1, 2 -> local rows (0, 1) = rows (0, 1) = d0 - d2, d1 + d2;
-    //        ph = 1 holds 1, 2, 3 -> local rows (0, 1) = rows (3, 2) = d1 - d3, d2 - d1
+    // B^T d: local rows (0, 1) = e0 - e2, e1 + sgn e2
     auto T_col = [&](float (&d)[12], int j0) {
 #pragma unroll
         for (int j = j0; j < j0 + 2; ++j) {
             const float e0 = d[0 * 4 + j], e1 = d[1 * 4 + j], e2 = d[2 * 4 + j];
             d[0 * 4 + j] = e0 - e2;
-            d[1 * 4 + j] = e1 + (ph ? -e0 : e2);
+            d[1 * 4 + j] = fmaf(sgn, e2, e1);
             asm volatile("" : "+v"(d[0 * 4 + j]), "+v"(d[1 * 4 + j]));
         }
     };
@@ -1524,12 +1531,12 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     float own0[32], own1[32];                  // the output row this wave finishes (a = ph), columns 0 / 1, per channel half and accumulator element
     __syncthreads();                           // both waves are done with their raw stages: the LDS becomes the exchange buffer
     float *xch = smem_all;
-    // local rows: wave 0 holds R0, R1, wave 1 holds R3, R2 (reversed).  Y0 = R0 + R1 + R2, Y1 = R1 - R2 - R3: a wave owns
+    // local rows: wave 0 holds R0, R1, wave 1 holds -R3, R2 (reversed; row 3 negated, see T_col).  Y0 = R0 + R1 + R2, Y1 = R1 - R2 - R3: a wave owns
     // +-(its two rows) and gives its local row 1 (R1 to Y1, R2 to Y0) to the other wave; the sign is applied when the two meet.
     auto part_e = [&](int kq, int e, const float (&m)[8]) {
         const float r00 = m[0] + m[1] + m[2], r01 = m[1] - m[2] - m[3];       // R[il][b] = sum_j A^T[b][j] M[i][j]
         const float r10 = m[4] + m[5] + m[6], r11 = m[5] - m[6] - m[7];
-        own0[kq * 16 + e] = r00 + r10, own1[kq * 16 + e] = r01 + r11;
+        own0[kq * 16 + e] = fmaf(sgn, r00, r10), own1[kq * 16 + e] = fmaf(sgn, r01, r11);   // wave 1's local row 0 is -R3 (T_col): R2 + R3
         f32x2 gv;                              // (one 8-byte LDS store / load per channel: xch[wave][kq][e][lane][2])
         gv[0] = r10, gv[1] = r11;
         *reinterpret_cast<f32x2 *>(xch + (((ph * 2 + kq) * 16 + e) * 64 + lane) * 2) = gv;
@@ -1578,7 +1585,6 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     const bool tv = tg < ttot && (!ODD || 2 * ty + ph < g.H);
     float *yout = y + ((int64_t)n * g.M) * HW + (2 * ty + ph) * g.W + 2 * tx;
     float s1[32], s2[32];
-    const float sgn = ph ? -1.0f : 1.0f;
     auto out_all = [&](auto hb) {                // (hb: with / without a conv bias -- two separate epilogues, see k_wg1)
 #pragma unroll
     for (int ke = 0; ke < 32; ++ke) {
