@@ -1285,6 +1285,9 @@ void k_wg2(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
 // odd-width map fetches the pair (W-2, W-1) instead of (W-1, W) -- nothing past the tensor is touched -- and stores (x[W-1], 0); its
 // outputs past the edge are not stored (one dword instead of the pair; the odd row of the last tile row not at all) and stay out of
 // the BatchNorm statistics.
+struct Bop {                                  // k_wg3's B operands of one channel: patch rows as register pairs (see T_read1)
+    f32x2 P[3], Q[3];
+};
 template <bool DGRAD, bool STATS, bool BNE = false, bool ODD = false>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
@@ -1392,31 +1395,38 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     // of 3 vector instructions per column.  The negated row 3 is put right where the two waves' rows meet in the epilogue (own =
     // r1 + sgn r0 instead of r0 + r1): every value is bit for bit what it was.  The row a wave GIVES the other is local row 1 for both.
     const float sgn = ph ? -1.0f : 1.0f;
+    f32x2 sgn2;
+    sgn2[0] = sgn, sgn2[1] = sgn;
     const int urow = ph * 512 * 4;                            // float4 q ^ 2 of the wave's four: + 512 floats for q = 0, 1, - 512 for q = 2, 3
     const int uoff[4] = {ubase + urow, ubase - urow + 512 * 4, ubase + ukq + urow, ubase + ukq - urow + 512 * 4};   // [(q >> 2) * 2 + ((q >> 1) & 1)]
     auto G_u1 = [&](int ch, f32x4 (&u)[8], int q) {
         u[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_u, uoff[(q >> 2) * 2 + ((q >> 1) & 1)] + (q & 1) * 256 * 4, ch * (W1_U * 4), 0));
     };
-    // half patch of (tile li, channel 2 lh + j): rows ph .. ph + 2 -> the 8 values of transform rows 2 ph, 2 ph + 1 in d[0..7]
-    auto T_read1 = [&](int stage, int j, float (&d)[12], int i) {
+    // half patch of (tile li, channel 2 lh + j): the wave's three patch rows as register PAIRS, P[i] = columns (1, 2) -- the lane's own
+    // pixel pair, one 8-byte LDS read -- and Q[i] = columns (0, 3).  The transforms below are packed fp32 instructions (two results per
+    // vector instruction: v_pk_add_f32 / v_pk_fma_f32 with op_sel / neg picking the halves and signs), 16 per chunk where the scalar
+    // form was 30 -- on this chip every vector instruction of the wave is MFMA time (profiles/r03_pmc_step_vgg16.md).
+    // After T_col and T_rowp rows 0, 1 hold the B operands: position il * 4 + j -> j = 0: Q[il][0], 1: P[il][0], 2: P[il][1], 3: Q[il][1].
+    auto T_read1 = [&](int stage, int j, Bop &d, int i) {
         const float *raw = smem + stage * W2_RAW + ((2 * lh + j) * 3 + i) * W1_ROW;
-        const f32x2 own = *reinterpret_cast<const f32x2 *>(raw + (li + 1) * 2);
-        d[i * 4 + 0] = raw[lo], d[i * 4 + 1] = own[0], d[i * 4 + 2] = own[1], d[i * 4 + 3] = raw[ro];
+        d.P[i] = *reinterpret_cast<const f32x2 *>(raw + (li + 1) * 2);
+        d.Q[i][0] = raw[lo], d.Q[i][1] = raw[ro];
     };
-    // B^T d: local rows (0, 1) = e0 - e2, e1 + sgn e2
-    auto T_col = [&](float (&d)[12], int j0) {
-#pragma unroll
-        for (int j = j0; j < j0 + 2; ++j) {
-            const float e0 = d[0 * 4 + j], e1 = d[1 * 4 + j], e2 = d[2 * 4 + j];
-            d[0 * 4 + j] = e0 - e2;
-            d[1 * 4 + j] = fmaf(sgn, e2, e1);
-            asm volatile("" : "+v"(d[0 * 4 + j]), "+v"(d[1 * 4 + j]));
-        }
+    // B^T d on a pair type (half = 0: the P pairs, 1: the Q pairs): local rows (0, 1) = e0 - e2, e1 + sgn e2
+    auto T_col = [&](Bop &d, int half) {
+        f32x2 &e0 = half ? d.Q[0] : d.P[0], &e1 = half ? d.Q[1] : d.P[1], &e2 = half ? d.Q[2] : d.P[2];
+        f32x2 r0, r1;
+        asm volatile("v_pk_add_f32 %0, %2, %3 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_fma_f32 %1, %4, %3, %5"
+                     : "=&v"(r0), "=&v"(r1) : "v"(e0), "v"(e2), "v"(sgn2), "v"(e1));
+        e0 = r0, e1 = r1;
     };
-    auto T_rowp = [&](float (&d)[12], int i) {
-        const float t0_ = d[i * 4 + 0], t1 = d[i * 4 + 1], t2 = d[i * 4 + 2], t3 = d[i * 4 + 3];
-        d[i * 4 + 0] = t0_ - t2, d[i * 4 + 1] = t1 + t2, d[i * 4 + 2] = t2 - t1, d[i * 4 + 3] = t1 - t3;
-        asm volatile("" : "+v"(d[i * 4 + 0]), "+v"(d[i * 4 + 1]), "+v"(d[i * 4 + 2]), "+v"(d[i * 4 + 3]));
+    // (B^T d) B on local row i: P = (t1, t2), Q = (t0, t3) -> Q = (t0 - t2, t1 - t3), P = (t1 + t2, t2 - t1)
+    auto T_rowp = [&](Bop &d, int i) {
+        f32x2 nq, np;
+        asm volatile("v_pk_add_f32 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,0]\n\t"
+                     "v_pk_add_f32 %1, %3, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]"
+                     : "=&v"(nq), "=&v"(np) : "v"(d.Q[i]), "v"(d.P[i]));
+        d.Q[i] = nq, d.P[i] = np;
     };
 
 
@@ -1436,7 +1446,7 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     const int last = nch - 1;
     auto clampc = [&](int c) { return min(c, last); };
     f32x4 ua[8], ub[8];                    // U of the current / next chunk: [kq * 4 + q]
-    float c0[12], c1[12], x0[12], x1[12];  // B operands ([0..7]) of the current chunk for channels 2 lh, 2 lh + 1 / the next chunk's, being transformed
+    Bop c0, c1, x0, x1;                    // B operands of the current chunk for channels 2 lh, 2 lh + 1 / the next chunk's, being transformed
     Rows rows;
     if (nch > 0) {
 #pragma unroll
@@ -1470,21 +1480,22 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         for (int k = 0; k < 7; ++k) G_row1(clampc(1), rows, k);
 #pragma unroll
         for (int i = 0; i < 3; ++i) { T_read1(0, 0, c0, i); T_read1(0, 1, c1, i); }
-        T_col(c0, 0); T_col(c0, 2); T_col(c1, 0); T_col(c1, 2);
+        T_col(c0, 0); T_col(c0, 1); T_col(c1, 0); T_col(c1, 1);
         T_rowp(c0, 0); T_rowp(c0, 1); T_rowp(c1, 0); T_rowp(c1, 1);
 #pragma unroll
         for (int k = 0; k < 7; ++k) W_row1(1, rows, k);
 #pragma unroll
         for (int k = 0; k < 7; ++k) G_row1(clampc(2), rows, k);
     }
-// accumulator a = kq * 8 + pp (channel half kq, local position pp)
+// accumulator a = kq * 8 + pp (channel half kq, local position pp = il * 4 + j: see T_read1 for where the operand sits)
+#define W3_B(B, pp) (((pp) & 3) == 0 ? (B).Q[(pp) >> 2][0] : ((pp) & 3) == 1 ? (B).P[(pp) >> 2][0] : ((pp) & 3) == 2 ? (B).P[(pp) >> 2][1] : (B).Q[(pp) >> 2][1])
 #define W3_SLOT(a, h, U, B, work)                                                                  \
-    W3_ONE_##a((U)[((a) >> 3) * 4 + (((a) & 7) >> 1)][((a) & 1) * 2 + (h)], (B)[(a) & 7]);         \
+    W3_ONE_##a((U)[((a) >> 3) * 4 + (((a) & 7) >> 1)][((a) & 1) * 2 + (h)], W3_B(B, (a) & 7));     \
     work;                                                                                          \
     __builtin_amdgcn_sched_barrier(0)
     // iteration it (par = it & 1): M(it); T(it + 1) from raw stage (it + 1) & 1; U(it + 1) requested; W(it + 2) stores the rows
     // requested one iteration ago, whose registers then take the loads of chunk it + 3
-    auto iter = [&](int it, int par, f32x4 (&ucur)[8], f32x4 (&unext)[8], float (&b0)[12], float (&b1)[12], float (&n0v)[12], float (&n1v)[12]) {
+    auto iter = [&](int it, int par, f32x4 (&ucur)[8], f32x4 (&unext)[8], Bop &b0, Bop &b1, Bop &n0v, Bop &n1v) {
         const int cu = clampc(it + 1), cr = clampc(it + 3);
         W3_SLOT(0, 0, ucur, b0, T_read1(par ^ 1, 0, n0v, 0));
         W3_SLOT(0, 1, ucur, b1, T_read1(par ^ 1, 0, n0v, 1));
@@ -1496,11 +1507,11 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         W3_SLOT(9, 1, ucur, b1, G_u1(cu, unext, 1));
         W3_SLOT(2, 0, ucur, b0, T_col(n0v, 0));
         W3_SLOT(2, 1, ucur, b1, G_u1(cu, unext, 2));
-        W3_SLOT(10, 0, ucur, b0, T_col(n0v, 2));
+        W3_SLOT(10, 0, ucur, b0, T_col(n0v, 1));
         W3_SLOT(10, 1, ucur, b1, G_u1(cu, unext, 3));
         W3_SLOT(3, 0, ucur, b0, T_col(n1v, 0));
         W3_SLOT(3, 1, ucur, b1, G_u1(cu, unext, 4));
-        W3_SLOT(11, 0, ucur, b0, T_col(n1v, 2));
+        W3_SLOT(11, 0, ucur, b0, T_col(n1v, 1));
         W3_SLOT(11, 1, ucur, b1, G_u1(cu, unext, 5));
         W3_SLOT(4, 0, ucur, b0, T_rowp(n0v, 0));
         W3_SLOT(4, 1, ucur, b1, G_u1(cu, unext, 6));
