@@ -599,7 +599,9 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     const int nimg_here = min(span, g.N - n0);
     const __amdgpu_buffer_rsrc_t srd_x =
         __builtin_amdgcn_make_buffer_rsrc((void *)(x + (int64_t)n0 * g.C * HW), 0, nimg_here * g.C * HW * 4, 0x00020000);
-    const float *ubase = up + (int64_t)kb * g.nch * W1_U + lane * 4;
+    // (U through a buffer descriptor: two per-lane byte offsets per unit, the chunk in the scalar offset, q in the instruction offset)
+    const __amdgpu_buffer_rsrc_t srd_u = __builtin_amdgcn_make_buffer_rsrc((void *)up, 0, (int)((int64_t)g.nkb * g.nch * W1_U * 4), 0x00020000);
+    const int ubase = (kb * g.nch * W1_U + lane * 4) * 4;
 
     // raw[c][row][slot][2] offsets of this lane (channels 2 lh + j)
     const int raw_own = (2 * lh) * 4 * W1_ROW + (li + 1) * 2;
@@ -636,7 +638,10 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
 #pragma unroll
         for (int k = 0; k < 9; ++k) W_row1(stage, q, k);
     };
-    auto G_u1 = [&](int ch, f32x4 (&u)[8], int q) { u[q] = *reinterpret_cast<const f32x4 *>(ubase + (int64_t)ch * W1_U + q * 256); };
+    const int ubase4 = ubase + 4 * 256 * 4;                   // (the instruction offset has 12 bits: q = 4 .. 7 from a second base)
+    auto G_u1 = [&](int ch, f32x4 (&u)[8], int q) {
+        u[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_u, (q < 4 ? ubase : ubase4) + (q & 3) * 256 * 4, ch * (W1_U * 4), 0));
+    };
     auto G_u = [&](int ch, f32x4 (&u)[8]) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) G_u1(ch, u, q);
