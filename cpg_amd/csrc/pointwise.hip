@@ -174,18 +174,19 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
     const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(x + (long long)n_first * g.C * g.in_plane), 0, (int)std::min<long long>(remaining, 0x7FFFFFFFll), 0x00020000);
 
+    // packed weights: (C rounded up to 16, + 16 slack rows) x Mp floats (pack_bytes)
+    const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, (int)std::min<long long>(((long long)g.C + 32) * g.Mp * 4, 0x7FFFFFFFll), 0x00020000);
     f32x4 rw[Cfg::NW4];
     f32x4 rxv[Cfg::VEC ? Cfg::NX : 1];
     float rxs[Cfg::VEC ? 1 : Cfg::NX];
     auto load_item = [&](int k, int c0) {
+        // (the chunk's share of every address is uniform: it rides in the loads' scalar offset, no vector add per load)
         if (k < Cfg::NW4) {
-            rw[k] = ld_sv4(wp + ((int64_t)c0 + Cfg::WROWS * k) * g.Mp, wbyte);
+            rw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_w, (int)wbyte, (c0 + Cfg::WROWS * k) * g.Mp * 4, 0));
         } else if (Cfg::VEC) {
-            rxv[k - Cfg::NW4] = __builtin_bit_cast(
-                f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, xbyte[k - Cfg::NW4] + c0 * g.in_plane * 4, 0, 0));
+            rxv[k - Cfg::NW4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, xbyte[k - Cfg::NW4], c0 * g.in_plane * 4, 0));
         } else {
-            rxs[k - Cfg::NW4] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, xbyte[k - Cfg::NW4] + c0 * g.in_plane * 4, 0, 0));
+            rxs[k - Cfg::NW4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, xbyte[k - Cfg::NW4], c0 * g.in_plane * 4, 0));
         }
     };
     auto store_item = [&](int k, float *stage) {
@@ -216,9 +217,12 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
 #pragma unroll
     for (int k = 0; k < Cfg::NITEMS; ++k) load_item(k, min(1, nch - 1) * Cfg::CK);
     __syncthreads();
-    for (int ch = 0; ch < nch; ++ch) {
-        const float *cur = smem + (ch & 1) * Cfg::STAGE;
-        float *other = smem + ((ch + 1) & 1) * Cfg::STAGE;
+    // (two copies of the chunk body, one per LDS stage: with the stage a compile-time constant every LDS address is a per-lane base
+    //  + an immediate -- selecting the stage at run time cost 19 vector address instructions per chunk)
+    auto chunk = [&](int ch, auto stage_c) {
+        constexpr int kPar = decltype(stage_c)::value;
+        const float *cur = smem + kPar * Cfg::STAGE;
+        float *other = smem + (kPar ^ 1) * Cfg::STAGE;
         const int c_next2 = min(ch + 2, nch - 1) * Cfg::CK;        // clamped: the tail re-stages data nobody reads
         float a[2][Cfg::FM], b[2][Cfg::FN];
         auto lds_operands = [&](int st, int set) {
@@ -253,6 +257,10 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
             }
         }
         __syncthreads();
+    };
+    for (int ch = 0; ch < nch; ch += 2) {
+        chunk(ch, std::integral_constant<int, 0>{});
+        if (ch + 1 < nch) chunk(ch + 1, std::integral_constant<int, 1>{});
     }
 
     // ---- epilogue: D col = grid position (lane & 31), D row = channel ----
@@ -438,10 +446,33 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(int M, int C, int HWo, long
     const int dst = chl * Cfg::LD + 4 * j4;
     int pos_g = kOutOfRange, pos_x = kOutOfRange;       // byte offset of (image, pixel) in gy / x for the unit being loaded
     int pgs[SCALAR ? 4 : 1], pxs[SCALAR ? 4 : 1];       // SCALAR: one position per pixel of the float4
+    // Units are described in order u0, u0 + 1, ... (clamped at the split's last unit), so the dense variant keeps (pixel within the
+    // image, byte offsets) per lane and ADVANCES them by one unit -- a dozen vector instructions where the division by the plane
+    // size and the two multiplications were ~30 (vector instructions are MFMA time on this chip, see k_pw).
+    int d_q = 0, d_g = 0;                               // dense: pixel within its image / flattened pixel of the lane's float4
+    int d_pg = 0, d_px = 0;                             // dense: byte offsets of that pixel in gy / x (valid or not)
+    long long d_u = -1;                                 // dense: the unit those describe
+    const int wrap_g = (M - 1) * HWo * 4, wrap_x = (C - 1) * HWo * 4;     // extra bytes when a lane's pixel moves on to the next image
     auto describe = [&](long long u) {      // G < 2^29 (host check): 32-bit arithmetic
+        if (!SCALAR) {
+            if (d_u < 0) {                                       // first unit of the split: one division
+                d_g = (int)u * Cfg::PIX + 4 * j4;
+                const int n = d_g / HWo;
+                d_q = d_g - n * HWo;
+                d_pg = (n * M * HWo + d_q) * 4, d_px = (n * C * HWo + d_q) * 4;
+            } else if (u != d_u) {                               // (uniform) the next unit; u == d_u: clamped at the last one
+                d_g += Cfg::PIX, d_q += Cfg::PIX, d_pg += Cfg::PIX * 4, d_px += Cfg::PIX * 4;
+                while (d_q >= HWo) d_q -= HWo, d_pg += wrap_g, d_px += wrap_x;    // (planes of >= 32 pixels: at most once)
+            }
+            d_u = u;
+            const bool ok = d_g < (int)G;
+            pos_g = ok ? d_pg : kOutOfRange;
+            pos_x = ok ? d_px : kOutOfRange;
+            return;
+        }
         const int g = (int)u * Cfg::PIX + 4 * j4;
         int n = g / HWo, q = g - n * HWo;
-        if (SCALAR) {
+        {
             int oy = q / xg.OW, ox = q - oy * xg.OW;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -452,11 +483,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(int M, int C, int HWo, long
                 if (ox == xg.OW) ox = 0, ++oy;
                 if (q == HWo) q = 0, oy = 0, ++n;
             }
-            return;
         }
-        const bool ok = g < (int)G;
-        pos_g = ok ? (n * M * HWo + q) * 4 : kOutOfRange;
-        pos_x = ok ? (n * C * HWo + q) * 4 : kOutOfRange;
     };
     f32x4 st[Cfg::NITEMS];
     auto load_item = [&](int k) {
@@ -491,8 +518,8 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(int M, int C, int HWo, long
 #pragma unroll
         for (int k = 0; k < Cfg::NITEMS; ++k) load_item(k);
         __syncthreads();
-        for (long long u = u0; u < u1; ++u) {
-            const int cur_i = (int)(u - u0) & 1;
+        auto unit = [&](long long u, auto stage_c) {             // (one copy per LDS stage: immediate LDS offsets, as in k_pw)
+            constexpr int cur_i = decltype(stage_c)::value;
             const float *cur = smem + cur_i * Cfg::STAGE;
             float *other = smem + (cur_i ^ 1) * Cfg::STAGE;
             describe(std::min(u + 2, u1 - 1));          // clamped: the tail re-stages data nobody reads
@@ -529,6 +556,10 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(int M, int C, int HWo, long
                 }
             }
             __syncthreads();
+        };
+        for (long long u = u0; u < u1; u += 2) {
+            unit(u, std::integral_constant<int, 0>{});
+            if (u + 1 < u1) unit(u + 1, std::integral_constant<int, 1>{});
         }
     }
     // partial result part[split][co][ci]: lanes 0-31 of a store cover 32 consecutive ci
