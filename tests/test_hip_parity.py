@@ -174,6 +174,53 @@ def test_conv_oracle(N, C, H, W, K, k, s, p, bias, pm):
         close(layer.bias.grad, r['gb'], rtol=1e-4, atol=1e-3, msg='gb')
 
 
+def test_pointwise_random_shapes_vs_torch():
+    """Seeded sweep over small 1x1 layers (any stride, planes from 1 pixel up, odd sizes, one image, channel counts around the 64- /
+    128-row tiles, bias / piggymask) against torch's own fp32 conv on the same device: the pointwise kernels index their tiles with
+    32-bit reciprocal-multiply divisions, per-group buffer descriptors and scalar offsets (pointwise.hip) -- every branch of that
+    arithmetic gets shapes here.  Forward, input gradient, weight / piggymask / bias gradients."""
+    rng = np.random.RandomState(20260928)
+    for it in range(60):
+        N = int(rng.choice([1, 2, 3, 5, 9, 17]))
+        C = 16 * int(rng.randint(1, 18))
+        K = 16 * int(rng.randint(1, 18))
+        H, W = int(rng.randint(1, 31)), int(rng.randint(1, 31))
+        s_ = int(rng.choice([1, 1, 1, 2, 3]))
+        bias, pm = bool(rng.randint(2)), bool(rng.randint(2))
+        g = torch.Generator().manual_seed(1000 + it)
+        x = torch.randn(N, C, H, W, generator=g)
+        w = torch.randn(K, C, 1, 1, generator=g) * (2.0 / C) ** 0.5
+        b = torch.randn(K, generator=g) * 0.1 if bias else None
+        pmv = torch.rand(K, C, 1, 1, generator=g) * 0.012 if pm else None
+        layer = nl.SharableConv2d(C, K, 1, stride=s_, padding=0, bias=bias).to(DEV)
+        layer.weight.data.copy_(w)
+        if bias:
+            layer.bias.data.copy_(b)
+        if pm:
+            layer.piggymask = nn.Parameter(pmv.to(DEV))
+        xd = x.to(DEV).requires_grad_(True)
+        y = layer(xd)
+        weff = w.to(DEV) * ((pmv.to(DEV) > 5e-3).float() if pm else 1.0)
+        xr = x.to(DEV).requires_grad_(True)
+        wr = weff.clone().requires_grad_(True)
+        br = b.to(DEV).clone().requires_grad_(True) if bias else None
+        yr = torch.nn.functional.conv2d(xr, wr, br, stride=s_)
+        tag = 'shape %d: N%d C%d K%d %dx%d s%d bias=%s pm=%s' % (it, N, C, K, H, W, s_, bias, pm)
+        sc = float(yr.detach().abs().max()) + 1e-6
+        assert float((y - yr).detach().abs().max()) <= 2e-5 * sc + 1e-6, tag
+        gy = torch.randn(y.shape, generator=g).to(DEV)
+        y.backward(gy)
+        yr.backward(gy)
+        assert float((xd.grad - xr.grad).abs().max()) <= 2e-5 * (float(xr.grad.abs().max()) + 1e-6) + 1e-6, tag + ' gx'
+        gws = float(wr.grad.abs().max()) + 1e-6
+        gw_ref = wr.grad * ((pmv.to(DEV) > 5e-3).float() if pm else 1.0)            # gW = g bin(pm) (models/layers.py:103)
+        assert float((layer.weight.grad - gw_ref).abs().max()) <= 3e-5 * gws + 1e-6, tag + ' gw'
+        if pm:
+            assert float((layer.piggymask.grad - wr.grad * w.to(DEV)).abs().max()) <= 3e-5 * gws + 1e-6, tag + ' gpm'
+        if bias:
+            assert float((layer.bias.grad - br.grad).abs().max()) <= 3e-5 * (float(br.grad.abs().max()) + 1e-6) + 1e-5, tag + ' gb'
+
+
 @pytest.mark.parametrize('N,C,H,W,K,bias,pm', [
     (16, 16, 2, 2, 32, False, False),      # 1 tile per image, 16 tiles in a 64-tile block; every patch row / column but two is padding
     (3, 32, 4, 4, 48, True, False),        # 4 tiles per image: a block spans all images
