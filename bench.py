@@ -142,6 +142,10 @@ class KernelClock:
         p.cpg_conv2d_fwd = timed('cpg_conv2d_fwd', conv_kind('conv_fwd'), conv_flops, wino_fwd)
         # same contraction as cpg_conv2d_fwd; its epilogue also emits the BatchNorm partial sums
         p.cpg_conv2d_fwd_bnstats = timed('cpg_conv2d_fwd_bnstats', conv_kind('conv_fwd'), conv_flops, wino_fwd)
+        # the fused stem (conv -> BatchNorm2d -> ReLU, conv output never written): the layer's algorithmic flops are counted on its
+        # BatchNorm/ReLU pass; the statistics pass before it recomputes the same conv (time counted, no extra algorithmic flops)
+        p.cpg_stem_bn_stats = timed('cpg_stem_bn_stats', conv_kind('conv_fwd'), lambda a: 0.0, None, lambda a: 0.0)
+        p.cpg_stem_bn_relu_fwd = timed('cpg_stem_bn_relu_fwd', conv_kind('conv_fwd'), conv_flops)
         # ... and the inference variant with the eval-mode BatchNorm + ReLU folded into the epilogue (validate)
         p.cpg_conv2d_fwd_bn_eval = timed('cpg_conv2d_fwd_bn_eval', conv_kind('conv_fwd'), conv_flops, wino_eval)
         # the opt-in bf16 MFMA kernels (--math bf16) get their own families: they are measured against the bf16 peak

@@ -100,6 +100,15 @@ _SIGNATURES = {
                                               ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
     'cpg_bn_bwd_from_partials': (ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32,
                                                 ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
+    'cpg_bn_bwd_finalize_partials': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp, _vp]),
+    'cpg_stem_bn_supported': (ctypes.c_int32, [ctypes.POINTER(ConvDesc)]),
+    'cpg_stem_bn_tiles': (ctypes.c_int32, [ctypes.POINTER(ConvDesc)]),
+    'cpg_stem_bn_stats': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_size_t, _vp]),
+    'cpg_stem_bn_relu_fwd': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'cpg_stem_bn_relu_bwd_reduce': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                   ctypes.c_size_t, _vp]),
+    'cpg_stem_bn_relu_bwd_apply': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                  _vp, _vp]),
     'cpg_bn_stats_finalize': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                              ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),
     'cpg_bn_add_relu_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32,

@@ -468,6 +468,18 @@ extern "C" int cpg_bn_bwd_from_partials(const float *partials, int32_t tiles, co
     return CPG_OK;
 }
 
+// the merge step of cpg_bn_bwd_from_partials on its own (the fused stem applies the result in its own kernel): partials[C][tiles][2]
+// = {sum gm, sum gm xhat} -> dbeta, dgamma and coef[2 c] = mean(gm), coef[2 c + 1] = mean(gm xhat) over N * HW elements
+extern "C" int cpg_bn_bwd_finalize_partials(const float *partials, int32_t tiles, int32_t N, int32_t C, int32_t HW, float *dgamma,
+                                            float *dbeta, float *coef, void *stream_v) {
+    CPG_REQUIRE(partials && dgamma && dbeta && coef, "cpg_bn_bwd_finalize_partials: null pointer");
+    CPG_REQUIRE(tiles > 0 && N > 0 && C > 0 && HW > 0 && (((uintptr_t)partials) & 7) == 0, "cpg_bn_bwd_finalize_partials: bad partial sums");
+    hipLaunchKernelGGL(k_bn_bwd_finalize_tiles, dim3(C), dim3(kThreads), 0, (hipStream_t)stream_v, partials, tiles, (double)N * HW, dgamma,
+                       dbeta, coef);
+    CPG_CHECK_LAUNCH("cpg_bn_bwd_finalize_partials");
+    return CPG_OK;
+}
+
 // y = relu(bn(x) + res): the tail of a residual block (models/resnet.py: `out = bn3(conv3(out)); out += identity;
 // relu(out)`) in the same two passes as plain BN -- 3 activation passes instead of 8 for the stock bn / add_ / relu_.
 extern "C" int cpg_bn_add_relu_fwd(const float *x, const float *res, const float *gamma, const float *beta, float eps, float momentum,

@@ -14,6 +14,17 @@
 //   * the next tile's patch is requested before the current tile's MFMAs (16 loads per tile, range-checked to zero outside the image);
 //   * per output row: 28 MFMAs, 32 stores of 2 x 128 contiguous bytes; the BatchNorm statistics (STATS) are summed per lane over the
 //     tile's 8 rows and reduced once per tile with DPP adds -> stats[k][tile][2], the layout of the other forward kernels.
+//
+// Round 3 -- the stem FUSED with the training-mode BatchNorm2d -> ReLU behind it (models/vgg.py:137-141: conv, BatchNorm2d, ReLU): the
+// conv output y (3.3 GB at batch 256) is never written.  Every pass that needs y recomputes it from the image -- 27 multiply-adds
+// per output against 4 bytes of HBM traffic saved per pass -- with this kernel's tile loop and a different epilogue (MODE):
+//   ST_STATS_ONLY   forward pass A: the statistics partial sums of y, no store                   (reads x: 0.15 GB)
+//   ST_BN_RELU      forward pass B: z = relu(bn(y)) stored                                       (writes z: 3.3 GB)
+//   ST_BWD_REDUCE   backward: partial sums {sum gm, sum gm xhat}, gm = gz [z > 0]                 (reads gz: 3.3 GB)
+//   ST_BWD_APPLY    backward: gy = (gm - mean(gm) - xhat mean(gm xhat)) invstd gamma stored       (reads gz, writes gy)
+// against conv (write y) + BN apply (read y, write z) + BN backward reduce (read y, gz) + apply (read y, gz, write gy): 13.2 GB of
+// y traffic per step gone.  The arithmetic per element is the unfused kernels' (bn_affine of bn_kernels.hip), so results agree to
+// the last bit wherever the summation order is the same.
 #include <algorithm>
 #include <type_traits>
 #include "igemm_core.h"
@@ -35,12 +46,36 @@ struct StemGeom {
     unsigned ntiles;
 };
 
-template <bool STATS>
+enum { ST_PLAIN = 0, ST_STATS = 1, ST_STATS_ONLY = 2, ST_BN_RELU = 3, ST_BWD_REDUCE = 4, ST_BWD_APPLY = 5 };
+struct StemBn {                                 // the BatchNorm behind the stem (fused modes): per-channel arrays of K floats
+    const float *gamma, *beta, *mean, *invstd;
+    const float *coef;                          // ST_BWD_APPLY: {mean(gm), mean(gm xhat)} per channel
+    const float *gz;                            // ST_BWD_*: gradient w.r.t. z = relu(bn(y)), laid out like y
+};
+
+template <int MODE>
 __global__ __launch_bounds__(256, 2)
 void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ pm, float thr,
-                const float *__restrict__ bias, float *__restrict__ y, float *__restrict__ stats) {
+                const float *__restrict__ bias, float *__restrict__ y, float *__restrict__ stats, StemBn bn) {
+    constexpr bool STATS = MODE == ST_STATS || MODE == ST_STATS_ONLY || MODE == ST_BWD_REDUCE;     // two sums per channel and tile
+    constexpr bool BN = MODE >= ST_BN_RELU;                                                        // needs the BatchNorm's constants
+    constexpr bool STORE = MODE == ST_PLAIN || MODE == ST_STATS || MODE == ST_BN_RELU || MODE == ST_BWD_APPLY;
+    constexpr bool TWO_PASS = STATS || BN;      // the two blocks of 32 output channels in two passes over the patch (register budget)
     __shared__ float smem_all[4 * ST_PATCH];
+    // backward modes: the BatchNorm's per-channel constants {mean, invstd, gamma, beta, mean(gm), mean(gm xhat)} live in LDS (64 x 8
+    // floats) and are read per accumulator element -- as registers (16 channels x 6 per lane) they pushed the kernel into scratch
+    __shared__ __attribute__((aligned(16))) float cst[(MODE >= ST_BWD_REDUCE) ? 64 * 8 : 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (MODE >= ST_BWD_REDUCE) {
+        if (tid < 64) {
+            const bool kv = tid < g.K;
+            cst[tid * 8 + 0] = kv ? bn.mean[tid] : 0.0f, cst[tid * 8 + 1] = kv ? bn.invstd[tid] : 0.0f;
+            cst[tid * 8 + 2] = kv ? bn.gamma[tid] : 0.0f, cst[tid * 8 + 3] = kv ? bn.beta[tid] : 0.0f;
+            cst[tid * 8 + 4] = (MODE == ST_BWD_APPLY && kv) ? bn.coef[2 * tid] : 0.0f;
+            cst[tid * 8 + 5] = (MODE == ST_BWD_APPLY && kv) ? bn.coef[2 * tid + 1] : 0.0f;
+        }
+        __syncthreads();                         // (the only barrier: before any wave leaves)
+    }
     const int li = lane & 31, lh = lane >> 5;
     float *smem = smem_all + wave * ST_PATCH;
     const int HW = g.H * g.W, CK = g.C * 9;
@@ -66,14 +101,17 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
         const int c = kk / 9, r = (kk % 9) / 3, s = kk % 3;
         boff[t] = (c * ST_ROWS + r) * ST_PW + s + li;
     }
-    float bv[2][16];
+    constexpr bool HASB = !BN;                  // (the fused BatchNorm modes take no conv bias -- the host refuses one: 32 registers)
+    float bv[HASB ? 2 : 1][HASB ? 16 : 1];
+    if constexpr (HASB) {
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int co = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            bv[mb][e] = (bias != nullptr && co < g.K) ? bias[co] : 0.0f;
-        }
+            for (int e = 0; e < 16; ++e) {
+                const int co = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                bv[mb][e] = (bias != nullptr && co < g.K) ? bias[co] : 0.0f;
+            }
+    }
 
     const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, g.N * g.C * HW * 4, 0x00020000);
     constexpr int kOOR = (int)0x80000000;
@@ -120,26 +158,49 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
         tile_coords(tile, n, y0, x0);
         write_patch();
         if (tile + nwaves < g.ntiles) issue_loads(tile + nwaves);
-        float s1[2][16], s2[2][16];
-        if (STATS) {
+        float s1[16], s2[16];                      // (one block of 32 channels at a time: STATS modes run two passes)
+        auto zero_sums = [&]() {
+            if (STATS) {
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) s1[mb][e] = s2[mb][e] = 0.0f;
-        }
+                for (int e = 0; e < 16; ++e) s1[e] = s2[e] = 0.0f;
+            }
+        };
         // y of this image through a buffer descriptor: the lane part of a store's address (pixel, + 4 channels for the upper
         // half-wave) is a 32-bit offset that is out of range for pixels outside the image (the store is dropped), the uniform
         // part of the channel is the instruction's scalar offset (K = 64: every channel of the two blocks exists)
-        const __amdgpu_buffer_rsrc_t srd_y = __builtin_amdgcn_make_buffer_rsrc((void *)(y + (int64_t)n * g.K * HW), 0, g.K * HW4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t srd_y = __builtin_amdgcn_make_buffer_rsrc((void *)((STORE ? y : (float *)x) + (STORE ? (int64_t)n * g.K * HW : 0)), 0, STORE ? g.K * HW4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t srd_gz = __builtin_amdgcn_make_buffer_rsrc((void *)(MODE >= ST_BWD_REDUCE ? bn.gz + (int64_t)n * g.K * HW : x), 0, MODE >= ST_BWD_REDUCE ? g.K * HW4 : 0, 0x00020000);
         const bool cok = x0 + li < g.W;
         const int pix0 = (y0 * g.W + x0 + li) * 4 + lh * 4 * HW4;
         // (a tile inside the image needs no per-pixel masks: `full` is wave-uniform)
         const bool full = x0 + ST_W <= g.W && y0 + ST_R <= g.H;
         // STATS: the two blocks of 32 output channels in two passes over the patch (the 64 sums of one pass would cost the second
         // resident block its registers: 0.81 instead of 0.68 ms); plain: both blocks share every B operand read
+        // fused modes: the BatchNorm's constants of this pass's 16 channels per lane (channel mb 32 + (e & 3) + 8 (e >> 2) + 4 lh)
+        constexpr bool REGC = MODE == ST_BN_RELU;
+        float cm[REGC ? 16 : 1], cis[REGC ? 16 : 1], cga[REGC ? 16 : 1], cbe[REGC ? 16 : 1];
+        auto load_bn = [&](int mb) {
+            if constexpr (REGC) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    cm[e] = bn.mean[co], cis[e] = bn.invstd[co], cga[e] = bn.gamma[co], cbe[e] = bn.beta[co];
+                }
+            }
+        };
         auto row = [&](int j, auto fullc, auto mbsel) {
             constexpr bool FULL = decltype(fullc)::value;
             constexpr int MB0 = decltype(mbsel)::value < 0 ? 0 : decltype(mbsel)::value, MB1 = decltype(mbsel)::value < 0 ? 2 : MB0 + 1;
+            const bool pok = FULL || (cok && y0 + j < g.H);
+            const int voff = pok ? pix0 + j * g.W * 4 : kOOR;
+            float gzv[MODE >= ST_BWD_REDUCE ? 16 : 1];
+            int copq = 0;
+            if constexpr (MODE >= ST_BWD_REDUCE) asm volatile("" : "+v"(copq));      // (hoisted out of the row loop the constants are 96 registers again)
+            if constexpr (MODE >= ST_BWD_REDUCE) {           // the row's 16 gradient values fly while its 14 MFMAs run (out of range: 0)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    gzv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_gz, voff, (MB0 * 32 + (e & 3) + 8 * (e >> 2)) * HW4, 0));
+            }
             f32x16 acc[2];
 #pragma unroll
             for (int mb = MB0; mb < MB1; ++mb)
@@ -152,19 +213,37 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
 #pragma unroll
                 for (int mb = MB0; mb < MB1; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[mb][t], b, acc[mb], 0, 0, 0);
             }
-            const bool pok = FULL || (cok && y0 + j < g.H);
-            const int voff = pok ? pix0 + j * g.W * 4 : kOOR;
 #pragma unroll
             for (int mb = MB0; mb < MB1; ++mb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int cu = mb * 32 + (e & 3) + 8 * (e >> 2);       // + 4 lh: in voff
-                    const float v = acc[mb][e] + bv[mb][e];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), srd_y, voff, cu * HW4, 0);
-                    if (STATS) {
+                    const float v = HASB ? acc[mb][e] + bv[HASB ? mb : 0][HASB ? e : 0] : acc[mb][e];
+                    if constexpr (MODE == ST_PLAIN || MODE == ST_STATS) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), srd_y, voff, cu * HW4, 0);
+                    }
+                    if constexpr (MODE == ST_STATS || MODE == ST_STATS_ONLY) {
                         const float vm = (FULL || pok) ? v : 0.0f;
-                        s1[mb][e] += vm;
-                        s2[mb][e] = fmaf(vm, vm, s2[mb][e]);
+                        s1[e] += vm;
+                        s2[e] = fmaf(vm, vm, s2[e]);
+                    }
+                    if constexpr (MODE == ST_BN_RELU) {                    // bn_affine of bn_kernels.hip, then the ReLU
+                        const float z = fmaxf((v - cm[e]) * cis[e] * cga[e] + cbe[e], 0.0f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, z), srd_y, voff, cu * HW4, 0);
+                    }
+                    if constexpr (MODE >= ST_BWD_REDUCE) {
+                        const float *cc = cst + (cu + 4 * lh) * 8 + copq;     // (copq = 0, opaque per row: keeps the reads in the row)
+                        const f32x4 c4 = *reinterpret_cast<const f32x4 *>(cc);                  // mean, invstd, gamma, beta
+                        const float xh = (v - c4[0]) * c4[1];
+                        const float gm = ((v - c4[0]) * c4[1] * c4[2] + c4[3] > 0.0f) ? gzv[e] : 0.0f;        // (gz of a pixel outside the image reads 0)
+                        if constexpr (MODE == ST_BWD_REDUCE) {
+                            s1[e] += gm;
+                            s2[e] = fmaf(gm, xh, s2[e]);
+                        } else {
+                            const f32x2 c2 = *reinterpret_cast<const f32x2 *>(cc + 4);           // mean(gm), mean(gm xhat)
+                            const float gyv = (gm - c2[0] - xh * c2[1]) * (c4[1] * c4[2]);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gyv), srd_y, voff, cu * HW4, 0);
+                        }
                     }
                 }
         };
@@ -179,22 +258,26 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
         };
         auto stats_out = [&](int mb) {
 #pragma unroll
-            for (int e = 0; e < 16; e += 8) half_wave_sum8(s1[mb] + e), half_wave_sum8(s2[mb] + e);
+            for (int e = 0; e < 16; e += 8) half_wave_sum8(s1 + e), half_wave_sum8(s2 + e);
             if (li == kHalfSumLane) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int co = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                     f32x2 o;
-                    o[0] = s1[mb][e], o[1] = s2[mb][e];
+                    o[0] = s1[e], o[1] = s2[e];
                     *reinterpret_cast<f32x2 *>(stats + ((int64_t)co * g.ntiles + tile) * 2) = o;
                 }
             }
         };
-        if (STATS) {
+        if (TWO_PASS) {
+            load_bn(0);
+            zero_sums();
             rows(std::integral_constant<int, 0>{});
-            stats_out(0);
+            if (STATS) stats_out(0);
+            load_bn(1);
+            zero_sums();
             rows(std::integral_constant<int, 1>{});
-            stats_out(1);
+            if (STATS) stats_out(1);
         } else {
             rows(std::integral_constant<int, -1>{});
         }
@@ -239,9 +322,86 @@ extern "C" int cpg_conv3x3_stem_run(int N, int C, int K, int H, int W, const flo
     unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)g.ntiles + 3) / 4, 4 * kCUs);
     if (const char *f = getenv("CPG_STEM_BLOCKS")) blocks = (unsigned)std::max(1, atoi(f));
     if (stats != nullptr)
-        hipLaunchKernelGGL(k_stem_fwd<true>, dim3(blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y, stats);
+        hipLaunchKernelGGL(k_stem_fwd<ST_STATS>, dim3(blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y, stats, StemBn{});
     else
-        hipLaunchKernelGGL(k_stem_fwd<false>, dim3(blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y, nullptr);
+        hipLaunchKernelGGL(k_stem_fwd<ST_PLAIN>, dim3(blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y, nullptr, StemBn{});
     CPG_CHECK_LAUNCH("cpg_conv2d_fwd(stem)");
+    return CPG_OK;
+}
+
+// ------------------------------------------------------------------------------ the stem fused with BatchNorm2d -> ReLU (see the header)
+namespace {
+bool stem_bn_geom(const cpg_conv_desc *d, StemGeom &g) {
+    if (getenv("CPG_NO_STEM_FUSE")) return false;
+    if (!(d->R == 3 && d->S == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1 && d->dil_h == 1 &&
+          d->dil_w == 1 && d->groups == 1))
+        return false;
+    return stem_geom(d->N, d->C, d->K, d->H, d->W, g);
+}
+unsigned stem_blocks(const StemGeom &g) {
+    unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)g.ntiles + 3) / 4, 4 * kCUs);
+    if (const char *f = getenv("CPG_STEM_BLOCKS")) blocks = (unsigned)std::max(1, atoi(f));
+    return blocks;
+}
+}  // namespace
+
+extern "C" int32_t cpg_stem_bn_supported(const cpg_conv_desc *d) {
+    StemGeom g;
+    return (d != nullptr && stem_bn_geom(d, g)) ? 1 : 0;
+}
+extern "C" int32_t cpg_stem_bn_tiles(const cpg_conv_desc *d) {
+    StemGeom g;
+    return (d != nullptr && stem_bn_geom(d, g)) ? (int32_t)g.ntiles : 0;
+}
+// pass A: stats[K][tiles][2] = {sum y, sum y^2} per tile of y = conv(x) (+ bias); y is not written
+extern "C" int cpg_stem_bn_stats(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
+                                 float *stats, size_t stats_bytes, void *stream_v) {
+    StemGeom g;
+    CPG_REQUIRE(d && x && w && stats, "cpg_stem_bn_stats: null pointer");
+    if (!stem_bn_geom(d, g)) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_stats: shape not supported");
+    if (bias != nullptr) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_stats: the fused stem takes no conv bias");
+    if (stats_bytes < (size_t)g.K * g.ntiles * 2 * sizeof(float)) return fail(CPG_E_WORKSPACE, "cpg_stem_bn_stats: statistics buffer too small");
+    hipLaunchKernelGGL(k_stem_fwd<ST_STATS_ONLY>, dim3(stem_blocks(g)), dim3(256), 0, (hipStream_t)stream_v, g, x, w, pm, thr, bias,
+                       (float *)nullptr, stats, StemBn{});
+    CPG_CHECK_LAUNCH("cpg_stem_bn_stats");
+    return CPG_OK;
+}
+// pass B: z = relu((y - mean) invstd gamma + beta), y recomputed
+extern "C" int cpg_stem_bn_relu_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,
+                                    const float *gamma, const float *beta, const float *mean, const float *invstd, float *z, void *stream_v) {
+    StemGeom g;
+    CPG_REQUIRE(d && x && w && gamma && beta && mean && invstd && z, "cpg_stem_bn_relu_fwd: null pointer");
+    if (!stem_bn_geom(d, g)) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_relu_fwd: shape not supported");
+    if (bias != nullptr) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_relu_fwd: the fused stem takes no conv bias");
+    hipLaunchKernelGGL(k_stem_fwd<ST_BN_RELU>, dim3(stem_blocks(g)), dim3(256), 0, (hipStream_t)stream_v, g, x, w, pm, thr, bias, z,
+                       (float *)nullptr, StemBn{gamma, beta, mean, invstd, nullptr, nullptr});
+    CPG_CHECK_LAUNCH("cpg_stem_bn_relu_fwd");
+    return CPG_OK;
+}
+// backward 1: partials[K][tiles][2] = {sum gm, sum gm xhat}, gm = gz [z > 0] (cpg_bn_bwd_finalize_partials merges them)
+extern "C" int cpg_stem_bn_relu_bwd_reduce(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr,
+                                           const float *bias, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                                           const float *gz, float *partials, size_t partials_bytes, void *stream_v) {
+    StemGeom g;
+    CPG_REQUIRE(d && x && w && gamma && beta && mean && invstd && gz && partials, "cpg_stem_bn_relu_bwd_reduce: null pointer");
+    if (!stem_bn_geom(d, g)) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_relu_bwd_reduce: shape not supported");
+    if (bias != nullptr) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_relu_bwd_reduce: the fused stem takes no conv bias");
+    if (partials_bytes < (size_t)g.K * g.ntiles * 2 * sizeof(float)) return fail(CPG_E_WORKSPACE, "cpg_stem_bn_relu_bwd_reduce: partial-sum buffer too small");
+    hipLaunchKernelGGL(k_stem_fwd<ST_BWD_REDUCE>, dim3(stem_blocks(g)), dim3(256), 0, (hipStream_t)stream_v, g, x, w, pm, thr, bias,
+                       (float *)nullptr, partials, StemBn{gamma, beta, mean, invstd, nullptr, gz});
+    CPG_CHECK_LAUNCH("cpg_stem_bn_relu_bwd_reduce");
+    return CPG_OK;
+}
+// backward 2: gy = (gm - coef[2c] - xhat coef[2c + 1]) invstd gamma -- the gradient w.r.t. the conv output, for cpg_conv2d_wgrad
+extern "C" int cpg_stem_bn_relu_bwd_apply(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr,
+                                          const float *bias, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                                          const float *coef, const float *gz, float *gy, void *stream_v) {
+    StemGeom g;
+    CPG_REQUIRE(d && x && w && gamma && beta && mean && invstd && coef && gz && gy, "cpg_stem_bn_relu_bwd_apply: null pointer");
+    if (!stem_bn_geom(d, g)) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_relu_bwd_apply: shape not supported");
+    if (bias != nullptr) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_relu_bwd_apply: the fused stem takes no conv bias");
+    hipLaunchKernelGGL(k_stem_fwd<ST_BWD_APPLY>, dim3(stem_blocks(g)), dim3(256), 0, (hipStream_t)stream_v, g, x, w, pm, thr, bias, gy,
+                       (float *)nullptr, StemBn{gamma, beta, mean, invstd, coef, gz});
+    CPG_CHECK_LAUNCH("cpg_stem_bn_relu_bwd_apply");
     return CPG_OK;
 }

@@ -8,6 +8,8 @@ backward (csrc/bn_kernels.hip).  Semantics are torch.nn.BatchNorm2d's: batch sta
 (biased variance for the normalisation, unbiased for running_var, momentum update, num_batches_tracked),
 running statistics in eval mode.  SURVEY.md section 8(f) item 2.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -419,6 +421,89 @@ def conv_bn_act(conv, bn, act, x):
     return bn_act(bn, act, y)
 
 
+FUSE_STEM = True           # conv(<= 3 -> 64 channels, 3x3 s1 p1) -> BatchNorm2d -> ReLU: the conv output is never written (cpg_stem_bn_*)
+
+
+class _StemConvBnReluFn(torch.autograd.Function):
+    """z = relu(bn(conv(x))) for the network stem (models/vgg.py:137-141) with the conv output recomputed in every pass that needs it
+    instead of stored: forward = statistics pass + BatchNorm/ReLU pass over the image, backward = reduction pass + apply pass over gz
+    (each recomputes conv(x)), then the stem's weight gradient from the resulting gy.  The image gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, pm, thr, gamma, beta, running_mean, running_var, eps, momentum):
+        from .layers import _conv_desc
+        x = x.contiguous()
+        w = weight.contiguous()
+        p = None if pm is None else pm.contiguous()
+        d = _conv_desc(x.shape, w.shape, (1, 1), (1, 1), (1, 1), 1)
+        L = _lib.lib()
+        s = _lib.stream_ptr()
+        N, K, H, W = x.shape[0], w.shape[0], x.shape[2], x.shape[3]
+        tiles = L.cpg_stem_bn_tiles(ctypes.byref(d))
+        stats = torch.empty((K, tiles, 2), dtype=torch.float32, device=x.device)
+        rc = L.cpg_stem_bn_stats(ctypes.byref(d), _lib.dptr(x, name='input'), _lib.dptr(w, name='weight'), _lib.dptr(p, name='piggymask'),
+                                 float(thr), None, _lib.dptr(stats), stats.numel() * 4, s)
+        _lib.check('cpg_stem_bn_stats', rc)
+        mean, invstd = _finalize_stats(stats, N, K, H * W, eps, momentum, running_mean, running_var, x.device)
+        z = torch.empty((N, K, H, W), dtype=torch.float32, device=x.device)
+        rc = L.cpg_stem_bn_relu_fwd(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w), _lib.dptr(p), float(thr), None, _lib.dptr(gamma, name='bn.weight'),
+                                    _lib.dptr(beta, name='bn.bias'), _lib.dptr(mean), _lib.dptr(invstd), _lib.dptr(z), s)
+        _lib.check('cpg_stem_bn_relu_fwd', rc)
+        ctx.save_for_backward(x, w, p, gamma, beta, mean, invstd)
+        ctx.desc, ctx.thr, ctx.tiles = d, float(thr), tiles
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, w, p, gamma, beta, mean, invstd = ctx.saved_tensors
+        d, thr, tiles = ctx.desc, ctx.thr, ctx.tiles
+        gz = gz.contiguous()
+        L = _lib.lib()
+        s = _lib.stream_ptr()
+        N, K, H, W = x.shape[0], w.shape[0], x.shape[2], x.shape[3]
+        partials = torch.empty((K, tiles, 2), dtype=torch.float32, device=x.device)
+        args = (ctypes.byref(d), _lib.dptr(x), _lib.dptr(w), _lib.dptr(p), thr, None, _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(mean),
+                _lib.dptr(invstd))
+        rc = L.cpg_stem_bn_relu_bwd_reduce(*args, _lib.dptr(gz, name='grad_output'), _lib.dptr(partials), partials.numel() * 4, s)
+        _lib.check('cpg_stem_bn_relu_bwd_reduce', rc)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        coef = torch.empty(2 * K, dtype=torch.float32, device=x.device)
+        rc = L.cpg_bn_bwd_finalize_partials(_lib.dptr(partials), tiles, N, K, H * W, _lib.dptr(dgamma), _lib.dptr(dbeta), _lib.dptr(coef), s)
+        _lib.check('cpg_bn_bwd_finalize_partials', rc)
+        gy = torch.empty((N, K, H, W), dtype=torch.float32, device=x.device)
+        rc = L.cpg_stem_bn_relu_bwd_apply(*args, _lib.dptr(coef), _lib.dptr(gz), _lib.dptr(gy), s)
+        _lib.check('cpg_stem_bn_relu_bwd_apply', rc)
+        gw = gpm = None
+        if ctx.needs_input_grad[1] or (p is not None and ctx.needs_input_grad[2]):
+            gw = torch.empty_like(w)
+            gpm = None if p is None else torch.empty_like(p)
+            ws, nbytes = _lib.workspace(L.cpg_conv2d_workspace_bytes(ctypes.byref(d)), x.device)
+            rc = L.cpg_conv2d_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), _lib.dptr(p), thr, _lib.dptr(gw), _lib.dptr(gpm),
+                                    None, _lib.dptr(ws), nbytes, s)
+            _lib.check('cpg_conv2d_wgrad', rc)
+        return None, gw, gpm, None, dgamma, dbeta, None, None, None, None
+
+
+def stem_conv_bn_relu(conv, bn, x):
+    """relu(bn(conv(x))) through _StemConvBnReluFn when the triple qualifies (a bias-free masked 3x3 s1 p1 stem in fp32 feeding a
+    training-mode, stat-tracking BatchNorm2d, an input that needs no gradient), else None."""
+    from .layers import _conv_desc
+    if not (ENABLED and FUSE_STEM and FusedSequential.fuse and FusedSequential.fuse_stats and hasattr(conv, 'forward_with_bn_stats')
+            and isinstance(bn, nn.BatchNorm2d) and bn.training and bn.track_running_stats and bn.affine and bn.momentum is not None
+            and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and torch.is_grad_enabled() and not x.requires_grad
+            and conv.bias is None and conv._math() == 'fp32' and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1)
+            and tuple(conv.padding) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and x.shape[0] > 0
+            and x.shape[1] == conv.weight.shape[1] and bn.weight.dtype == torch.float32):
+        return None
+    d = _conv_desc(x.shape, conv.weight.shape, (1, 1), (1, 1), (1, 1), 1)
+    if not _lib.lib().cpg_stem_bn_supported(ctypes.byref(d)):
+        return None
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _StemConvBnReluFn.apply(x, conv.weight, conv.piggymask, conv.info['threshold'], bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                   bn.eps, bn.momentum)
+
+
 FUSE_SKIP_ADD = True       # residual blocks: the identity branch's gradient is added in conv1's input-gradient epilogue
 
 
@@ -499,6 +584,14 @@ class FusedSequential(nn.Sequential):
                     if st is not None:
                         self.skip_log.append(st)
                     input, stats = y, None
+                    i += 3
+                    continue
+            if (self.fuse and FUSE_STEM and i + 2 < n and isinstance(nxt, nn.BatchNorm2d) and type(mods[i + 2]) is nn.ReLU
+                    and hasattr(m, 'forward_with_bn_stats') and getattr(m, 'in_channels', 99) <= 3
+                    and not (self.fuse_pool and i + 3 < n and _is_pool2(mods[i + 3]))):
+                z = stem_conv_bn_relu(m, nxt, input)         # the stem: conv -> BatchNorm2d -> ReLU without ever writing the conv output
+                if z is not None:
+                    input, stats, hint = z, None, None
                     i += 3
                     continue
             if (self.fuse and self.fuse_stats and ENABLED and hasattr(m, 'forward_with_bn_stats') and isinstance(nxt, nn.BatchNorm2d)

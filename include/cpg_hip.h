@@ -293,6 +293,32 @@ int cpg_bn_bwd_from_partials(const float *partials, int32_t tiles, const float *
                              const float *beta, const float *mean, const float *invstd, float *gx, float *dgamma, float *dbeta,
                              int32_t N, int32_t C, int32_t HW, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The merge step of cpg_bn_bwd_from_partials alone: partials[C][tiles][2] = {sum gm, sum gm * xhat} -> dbeta, dgamma and
+ * coef[2c] = mean(gm), coef[2c + 1] = mean(gm * xhat) over N * HW elements (fp64, fixed order). */
+int cpg_bn_bwd_finalize_partials(const float *partials, int32_t tiles, int32_t N, int32_t C, int32_t HW, float *dgamma, float *dbeta,
+                                 float *coef, void *stream);
+
+/* The network stem fused with the training-mode BatchNorm2d -> ReLU behind it (VGG16 features.0-2, models/vgg.py:137-141 `conv2d,
+ * nn.BatchNorm2d(v), nn.ReLU(inplace=True)`; SharableConv2d.forward, models/layers.py:98-109): a 3x3 s1 p1 conv from <= 3 channels to
+ * 64 whose output y is NEVER written -- every pass recomputes it from the image (27 multiply-adds per output against 4 bytes of
+ * HBM traffic per pass).  No conv bias.  Forward: cpg_stem_bn_stats (partial sums stats[64][tiles][2] of y) ->
+ * cpg_bn_stats_finalize -> cpg_stem_bn_relu_fwd (z = relu(bn(y))).  Backward: cpg_stem_bn_relu_bwd_reduce (partials[64][tiles][2]
+ * = {sum gm, sum gm * xhat}, gm = gz * [z > 0]) -> cpg_bn_bwd_finalize_partials -> cpg_stem_bn_relu_bwd_apply (gy, the gradient
+ * w.r.t. the conv output) -> cpg_conv2d_wgrad(x, gy).  The image itself gets no gradient through this path. */
+int32_t cpg_stem_bn_supported(const cpg_conv_desc *desc);
+int32_t cpg_stem_bn_tiles(const cpg_conv_desc *desc);
+int cpg_stem_bn_stats(const cpg_conv_desc *desc, const float *x, const float *w, const float *piggymask, float threshold,
+                      const float *bias, float *stats, size_t stats_bytes, void *stream);
+int cpg_stem_bn_relu_fwd(const cpg_conv_desc *desc, const float *x, const float *w, const float *piggymask, float threshold,
+                         const float *bias, const float *gamma, const float *beta, const float *mean, const float *invstd, float *z,
+                         void *stream);
+int cpg_stem_bn_relu_bwd_reduce(const cpg_conv_desc *desc, const float *x, const float *w, const float *piggymask, float threshold,
+                                const float *bias, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                                const float *gz, float *partials, size_t partials_bytes, void *stream);
+int cpg_stem_bn_relu_bwd_apply(const cpg_conv_desc *desc, const float *x, const float *w, const float *piggymask, float threshold,
+                               const float *bias, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                               const float *coef, const float *gz, float *gy, void *stream);
+
 /* y = relu(bn(x) + res): the tail of a residual block (models/resnet.py:69-74 `out = self.bn3(out); out += identity;
  * out = self.relu(out)`).  train != 0: batch statistics (mean / invstd out, running stats updated); train == 0: `mean`
  * / `invstd` are inputs.  Backward = relu mask from y, then cpg_bn_relu_bwd(relu = 0); the residual's gradient is the

@@ -174,6 +174,58 @@ def test_conv_oracle(N, C, H, W, K, k, s, p, bias, pm):
         close(layer.bias.grad, r['gb'], rtol=1e-4, atol=1e-3, msg='gb')
 
 
+@pytest.mark.parametrize('N,C,H,W,pm', [(3, 3, 40, 70, False), (2, 3, 224, 224, True), (5, 1, 17, 33, False), (4, 2, 64, 64, True)])
+def test_fused_stem_conv_bn_relu_matches_unfused(N, C, H, W, pm):
+    """The stem fused with its BatchNorm2d -> ReLU (cpg_stem_bn_*: the conv output is recomputed in every pass instead of stored)
+    against the unfused chain (stem conv with the statistics epilogue, fused BatchNorm kernels) and against torch in fp64: output,
+    running statistics, and the gradients of the weight, the piggymask and the BatchNorm's affine parameters."""
+    from cpg_amd.models import fused_bn as fb
+    g = torch.Generator().manual_seed(7 * N + H)
+    x = torch.randn(N, C, H, W, generator=g)
+    w0 = torch.randn(64, C, 3, 3, generator=g) * 0.3
+    pm0 = torch.rand(64, C, 3, 3, generator=g) * 0.012 if pm else None
+    gam, bet = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    gz = torch.randn(N, 64, H, W, generator=g)
+    res = {}
+    for fused in (True, False):
+        seq = fb.FusedSequential(nl.SharableConv2d(C, 64, 3, padding=1, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True)).to(DEV)
+        seq[0].weight.data.copy_(w0)
+        if pm:
+            seq[0].piggymask = nn.Parameter(pm0.clone().to(DEV))
+        seq[1].weight.data.copy_(gam)
+        seq[1].bias.data.copy_(bet)
+        seq.train()
+        old = fb.FUSE_STEM
+        fb.FUSE_STEM = fused
+        calls = []
+        L = __import__('cpg_amd._lib', fromlist=['lib']).lib()
+        try:
+            z = seq(x.to(DEV))
+            z.backward(gz.to(DEV))
+        finally:
+            fb.FUSE_STEM = old
+        res[fused] = [z.detach().clone(), seq[0].weight.grad.clone(), seq[1].weight.grad.clone(), seq[1].bias.grad.clone(),
+                      seq[1].running_mean.clone(), seq[1].running_var.clone(), seq[1].num_batches_tracked.clone()]
+        if pm:
+            res[fused].append(seq[0].piggymask.grad.clone())
+        if fused:
+            assert type(z.grad_fn).__name__ == '_StemConvBnReluFnBackward', type(z.grad_fn).__name__     # the fused path really ran
+    for a, b in zip(res[True], res[False]):
+        sc = float(b.double().abs().max()) + 1e-12
+        assert float((a.double() - b.double()).abs().max()) <= 2e-5 * sc, (float((a.double() - b.double()).abs().max()), sc)
+    assert torch.equal(res[True][0], res[False][0])                # same statistics tiles, same arithmetic: the output is bit-identical
+    # fp64 torch reference of the whole triple
+    xd = x.double().to(DEV)
+    weff = (w0 * ((pm0 > 5e-3).float() if pm else 1.0)).double().to(DEV).requires_grad_(True)
+    gd, bd = gam.double().to(DEV).requires_grad_(True), bet.double().to(DEV).requires_grad_(True)
+    zr = torch.relu(torch.nn.functional.batch_norm(torch.nn.functional.conv2d(xd, weff, padding=1), None, None, gd, bd, True, 0.1, 1e-5))
+    zr.backward(gz.double().to(DEV))
+    assert float((res[True][0].double() - zr.detach()).abs().max()) <= 2e-5 * float(zr.detach().abs().max())
+    gw_ref = weff.grad * ((pm0 > 5e-3).double().to(DEV) if pm else 1.0)
+    for got, want in ((res[True][1], gw_ref), (res[True][2], gd.grad), (res[True][3], bd.grad)):
+        assert float((got.double() - want).abs().max()) <= 1e-4 * (float(want.abs().max()) + 1e-9)
+
+
 def test_pointwise_random_shapes_vs_torch():
     """Seeded sweep over small 1x1 layers (any stride, planes from 1 pixel up, odd sizes, one image, channel counts around the 64- /
     128-row tiles, bias / piggymask) against torch's own fp32 conv on the same device: the pointwise kernels index their tiles with
