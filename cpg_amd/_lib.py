@@ -109,6 +109,9 @@ _SIGNATURES = {
                                                    ctypes.c_size_t, _vp]),
     'cpg_stem_bn_relu_bwd_apply': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                   _vp, _vp]),
+    'cpg_stem_bn_wgrad_workspace': (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
+    'cpg_stem_bn_relu_bwd_wgrad': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                  _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'cpg_bn_stats_finalize': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                              ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),
     'cpg_bn_add_relu_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32,

@@ -22,6 +22,9 @@
 //   ST_BN_RELU      forward pass B: z = relu(bn(y)) stored                                       (writes z: 3.3 GB)
 //   ST_BWD_REDUCE   backward: partial sums {sum gm, sum gm xhat}, gm = gz [z > 0]                 (reads gz: 3.3 GB)
 //   ST_BWD_APPLY    backward: gy = (gm - mean(gm) - xhat mean(gm xhat)) invstd gamma stored       (reads gz, writes gy)
+//   ST_BWD_WGRAD    backward: the same gy, not stored but contracted with the image patch right away -- the stem's weight gradient
+//                   gW[co][(c, r, s)] = sum over pixels of gy[co][pix] x[c][pix + (r, s) - 1] as a second MFMA (32 channels x 32 taps,
+//                   k = pixel pairs of a tile row), gy transposed through LDS; per-wave partial sums, k_split_reduce (reads gz only)
 // against conv (write y) + BN apply (read y, write z) + BN backward reduce (read y, gz) + apply (read y, gz, write gy): 13.2 GB of
 // y traffic per step gone.  The arithmetic per element is the unfused kernels' (bn_affine of bn_kernels.hip), so results agree to
 // the last bit wherever the summation order is the same.
@@ -46,7 +49,8 @@ struct StemGeom {
     unsigned ntiles;
 };
 
-enum { ST_PLAIN = 0, ST_STATS = 1, ST_STATS_ONLY = 2, ST_BN_RELU = 3, ST_BWD_REDUCE = 4, ST_BWD_APPLY = 5 };
+enum { ST_PLAIN = 0, ST_STATS = 1, ST_STATS_ONLY = 2, ST_BN_RELU = 3, ST_BWD_REDUCE = 4, ST_BWD_APPLY = 5, ST_BWD_WGRAD = 6 };
+constexpr int ST_TS = 36;                       // row stride of the gy transpose tile (ST_BWD_WGRAD): [channel 32][pixel parity 2][16], 16-byte rows
 struct StemBn {                                 // the BatchNorm behind the stem (fused modes): per-channel arrays of K floats
     const float *gamma, *beta, *mean, *invstd;
     const float *coef;                          // ST_BWD_APPLY: {mean(gm), mean(gm xhat)} per channel
@@ -60,6 +64,7 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
     constexpr bool STATS = MODE == ST_STATS || MODE == ST_STATS_ONLY || MODE == ST_BWD_REDUCE;     // two sums per channel and tile
     constexpr bool BN = MODE >= ST_BN_RELU;                                                        // needs the BatchNorm's constants
     constexpr bool STORE = MODE == ST_PLAIN || MODE == ST_STATS || MODE == ST_BN_RELU || MODE == ST_BWD_APPLY;
+    constexpr bool WG = MODE == ST_BWD_WGRAD;   // y = the per-wave partial weight gradients [wave][64][C 9]
     constexpr bool TWO_PASS = STATS || BN;      // the two blocks of 32 output channels in two passes over the patch (register budget)
     __shared__ float smem_all[4 * ST_PATCH];
     // backward modes: the BatchNorm's per-channel constants {mean, invstd, gamma, beta, mean(gm), mean(gm xhat)} live in LDS (64 x 8
@@ -71,14 +76,25 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
             const bool kv = tid < g.K;
             cst[tid * 8 + 0] = kv ? bn.mean[tid] : 0.0f, cst[tid * 8 + 1] = kv ? bn.invstd[tid] : 0.0f;
             cst[tid * 8 + 2] = kv ? bn.gamma[tid] : 0.0f, cst[tid * 8 + 3] = kv ? bn.beta[tid] : 0.0f;
-            cst[tid * 8 + 4] = (MODE == ST_BWD_APPLY && kv) ? bn.coef[2 * tid] : 0.0f;
-            cst[tid * 8 + 5] = (MODE == ST_BWD_APPLY && kv) ? bn.coef[2 * tid + 1] : 0.0f;
+            cst[tid * 8 + 4] = (MODE >= ST_BWD_APPLY && kv) ? bn.coef[2 * tid] : 0.0f;
+            cst[tid * 8 + 5] = (MODE >= ST_BWD_APPLY && kv) ? bn.coef[2 * tid + 1] : 0.0f;
         }
         __syncthreads();                         // (the only barrier: before any wave leaves)
     }
     const int li = lane & 31, lh = lane >> 5;
     float *smem = smem_all + wave * ST_PATCH;
     const int HW = g.H * g.W, CK = g.C * 9;
+    __shared__ __attribute__((aligned(16))) float tsm_all[WG ? 4 * 32 * ST_TS : 4];
+    float *tsm = tsm_all + (WG ? wave * 32 * ST_TS : 0);
+    // ST_BWD_WGRAD: tap k = li of the weight gradient's B operand: patch offset of (c, r, s) + the half-wave's pixel parity
+    const int wk = li < CK ? li : 0, wboff = ((wk / 9) * ST_ROWS + (wk % 9) / 3) * ST_PW + wk % 3 + lh;
+    f32x16 accw[WG ? 2 : 1];
+    if constexpr (WG) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accw[mb][e] = 0.0f;
+    }
 
     // A operands: W_eff[co = 32 mb + li][k = 2 t + lh], zero beyond the layer's channels / taps
     float A[2][ST_KS];
@@ -241,11 +257,27 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
                             s2[e] = fmaf(gm, xh, s2[e]);
                         } else {
                             const f32x2 c2 = *reinterpret_cast<const f32x2 *>(cc + 4);           // mean(gm), mean(gm xhat)
-                            const float gyv = (gm - c2[0] - xh * c2[1]) * (c4[1] * c4[2]);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gyv), srd_y, voff, cu * HW4, 0);
+                            float gyv = (gm - c2[0] - xh * c2[1]) * (c4[1] * c4[2]);
+                            if constexpr (MODE == ST_BWD_APPLY) {
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gyv), srd_y, voff, cu * HW4, 0);
+                            } else {                                   // a pixel outside the image has no gradient; [channel][parity][pixel / 2]
+                                if (!FULL && !pok) gyv = 0.0f;
+                                tsm[((e & 3) + 8 * (e >> 2) + 4 * lh) * ST_TS + (li & 1) * 16 + (li >> 1)] = gyv;
+                            }
                         }
                     }
                 }
+            if constexpr (WG) {
+                // gW[co = li of block MB0][tap li] += sum over the row's 32 pixels: A = gy[co][pixel 2 t + lh] (four 16-byte reads of the
+                // lane's channel row, its half-wave's parity), B = x[c][j + r][2 t + lh + s] (the patch at the tap's offset)
+                f32x4 ga[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ga[q] = *reinterpret_cast<const f32x4 *>(tsm + li * ST_TS + lh * 16 + 4 * q);
+                const float *brow = smem + j * ST_PW + wboff;
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    accw[MB0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[t >> 2][t & 3], brow[2 * t], accw[MB0], 0, 0, 0);
+            }
         };
         auto rows = [&](auto mbsel) {
             if (full) {
@@ -281,6 +313,16 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
         } else {
             rows(std::integral_constant<int, -1>{});
         }
+    }
+    if constexpr (WG) {                          // this wave's partial sums: y[wid][co][k], D row = channel, D column (lane) = tap
+        float *dstw = y + (int64_t)wid * g.K * CK;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (li < CK && co < g.K) dstw[co * CK + li] = accw[mb][e];
+            }
     }
 }
 
@@ -403,5 +445,33 @@ extern "C" int cpg_stem_bn_relu_bwd_apply(const cpg_conv_desc *d, const float *x
     hipLaunchKernelGGL(k_stem_fwd<ST_BWD_APPLY>, dim3(stem_blocks(g)), dim3(256), 0, (hipStream_t)stream_v, g, x, w, pm, thr, bias, gy,
                        (float *)nullptr, StemBn{gamma, beta, mean, invstd, coef, gz});
     CPG_CHECK_LAUNCH("cpg_stem_bn_relu_bwd_apply");
+    return CPG_OK;
+}
+
+// backward 2 + the stem's weight gradient in one pass: gy is formed per tile row and contracted with the image patch at once (never
+// written); per-wave partial sums in the workspace, merged by k_split_reduce with the autograd epilogue gW = g bin(pm), gPM = g W
+extern "C" size_t cpg_stem_bn_wgrad_workspace(const cpg_conv_desc *d) {
+    StemGeom g;
+    if (d == nullptr || !stem_bn_geom(d, g)) return 0;
+    return (size_t)stem_blocks(g) * 4 * g.K * g.C * 9 * sizeof(float);
+}
+extern "C" int cpg_stem_bn_relu_bwd_wgrad(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr,
+                                          const float *bias, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                                          const float *coef, const float *gz, float *gw, float *gpm, void *ws, size_t ws_bytes,
+                                          void *stream_v) {
+    StemGeom g;
+    CPG_REQUIRE(d && x && w && gamma && beta && mean && invstd && coef && gz && gw && ws, "cpg_stem_bn_relu_bwd_wgrad: null pointer");
+    CPG_REQUIRE((pm == nullptr) == (gpm == nullptr), "cpg_stem_bn_relu_bwd_wgrad: piggymask and its gradient come as a pair");
+    if (!stem_bn_geom(d, g)) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_relu_bwd_wgrad: shape not supported");
+    if (bias != nullptr) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_relu_bwd_wgrad: the fused stem takes no conv bias");
+    const unsigned blocks = stem_blocks(g);
+    if (ws_bytes < (size_t)blocks * 4 * g.K * g.C * 9 * sizeof(float)) return fail(CPG_E_WORKSPACE, "cpg_stem_bn_relu_bwd_wgrad: workspace too small");
+    hipStream_t stream = (hipStream_t)stream_v;
+    hipLaunchKernelGGL(k_stem_fwd<ST_BWD_WGRAD>, dim3(blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, (float *)ws, (float *)nullptr,
+                       StemBn{gamma, beta, mean, invstd, coef, gz});
+    const int nsplit = (int)std::min<int64_t>((int64_t)g.ntiles, (int64_t)blocks * 4);        // waves that had at least one tile
+    Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
+    launch_split_reduce((const float *)ws, nsplit, (int64_t)g.K * g.C * 9, 0, ep, stream);
+    CPG_CHECK_LAUNCH("cpg_stem_bn_relu_bwd_wgrad");
     return CPG_OK;
 }

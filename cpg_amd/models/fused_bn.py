@@ -421,6 +421,7 @@ def conv_bn_act(conv, bn, act, x):
     return bn_act(bn, act, y)
 
 
+FUSE_STEM_WGRAD = True     # ... and its weight gradient inside the BatchNorm backward's apply pass (cpg_stem_bn_relu_bwd_wgrad)
 FUSE_STEM = True           # conv(<= 3 -> 64 channels, 3x3 s1 p1) -> BatchNorm2d -> ReLU: the conv output is never written (cpg_stem_bn_*)
 
 
@@ -470,17 +471,23 @@ class _StemConvBnReluFn(torch.autograd.Function):
         coef = torch.empty(2 * K, dtype=torch.float32, device=x.device)
         rc = L.cpg_bn_bwd_finalize_partials(_lib.dptr(partials), tiles, N, K, H * W, _lib.dptr(dgamma), _lib.dptr(dbeta), _lib.dptr(coef), s)
         _lib.check('cpg_bn_bwd_finalize_partials', rc)
-        gy = torch.empty((N, K, H, W), dtype=torch.float32, device=x.device)
-        rc = L.cpg_stem_bn_relu_bwd_apply(*args, _lib.dptr(coef), _lib.dptr(gz), _lib.dptr(gy), s)
-        _lib.check('cpg_stem_bn_relu_bwd_apply', rc)
         gw = gpm = None
         if ctx.needs_input_grad[1] or (p is not None and ctx.needs_input_grad[2]):
             gw = torch.empty_like(w)
             gpm = None if p is None else torch.empty_like(p)
-            ws, nbytes = _lib.workspace(L.cpg_conv2d_workspace_bytes(ctypes.byref(d)), x.device)
-            rc = L.cpg_conv2d_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), _lib.dptr(p), thr, _lib.dptr(gw), _lib.dptr(gpm),
-                                    None, _lib.dptr(ws), nbytes, s)
-            _lib.check('cpg_conv2d_wgrad', rc)
+            if FUSE_STEM_WGRAD:
+                # gy is contracted with the image patch in the pass that forms it (never written)
+                ws, nbytes = _lib.workspace(L.cpg_stem_bn_wgrad_workspace(ctypes.byref(d)), x.device)
+                rc = L.cpg_stem_bn_relu_bwd_wgrad(*args, _lib.dptr(coef), _lib.dptr(gz), _lib.dptr(gw), _lib.dptr(gpm), _lib.dptr(ws), nbytes, s)
+                _lib.check('cpg_stem_bn_relu_bwd_wgrad', rc)
+            else:
+                gy = torch.empty((N, K, H, W), dtype=torch.float32, device=x.device)
+                rc = L.cpg_stem_bn_relu_bwd_apply(*args, _lib.dptr(coef), _lib.dptr(gz), _lib.dptr(gy), s)
+                _lib.check('cpg_stem_bn_relu_bwd_apply', rc)
+                ws, nbytes = _lib.workspace(L.cpg_conv2d_workspace_bytes(ctypes.byref(d)), x.device)
+                rc = L.cpg_conv2d_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(w), _lib.dptr(p), thr, _lib.dptr(gw), _lib.dptr(gpm),
+                                        None, _lib.dptr(ws), nbytes, s)
+                _lib.check('cpg_conv2d_wgrad', rc)
         return None, gw, gpm, None, dgamma, dbeta, None, None, None, None
 
 

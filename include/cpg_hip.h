@@ -303,8 +303,8 @@ int cpg_bn_bwd_finalize_partials(const float *partials, int32_t tiles, int32_t N
  * 64 whose output y is NEVER written -- every pass recomputes it from the image (27 multiply-adds per output against 4 bytes of
  * HBM traffic per pass).  No conv bias.  Forward: cpg_stem_bn_stats (partial sums stats[64][tiles][2] of y) ->
  * cpg_bn_stats_finalize -> cpg_stem_bn_relu_fwd (z = relu(bn(y))).  Backward: cpg_stem_bn_relu_bwd_reduce (partials[64][tiles][2]
- * = {sum gm, sum gm * xhat}, gm = gz * [z > 0]) -> cpg_bn_bwd_finalize_partials -> cpg_stem_bn_relu_bwd_apply (gy, the gradient
- * w.r.t. the conv output) -> cpg_conv2d_wgrad(x, gy).  The image itself gets no gradient through this path. */
+ * = {sum gm, sum gm * xhat}, gm = gz * [z > 0]) -> cpg_bn_bwd_finalize_partials -> cpg_stem_bn_relu_bwd_wgrad (the weight gradient; or
+ * cpg_stem_bn_relu_bwd_apply for gy, the gradient w.r.t. the conv output, and cpg_conv2d_wgrad(x, gy)).  The image itself gets no gradient through this path. */
 int32_t cpg_stem_bn_supported(const cpg_conv_desc *desc);
 int32_t cpg_stem_bn_tiles(const cpg_conv_desc *desc);
 int cpg_stem_bn_stats(const cpg_conv_desc *desc, const float *x, const float *w, const float *piggymask, float threshold,
@@ -318,6 +318,13 @@ int cpg_stem_bn_relu_bwd_reduce(const cpg_conv_desc *desc, const float *x, const
 int cpg_stem_bn_relu_bwd_apply(const cpg_conv_desc *desc, const float *x, const float *w, const float *piggymask, float threshold,
                                const float *bias, const float *gamma, const float *beta, const float *mean, const float *invstd,
                                const float *coef, const float *gz, float *gy, void *stream);
+/* ... or, instead of cpg_stem_bn_relu_bwd_apply + cpg_conv2d_wgrad: gy contracted with the image patch inside the same pass (gy is
+ * never written): gW = g * bin(pm), gPM = g * W as cpg_conv2d_wgrad.  workspace: cpg_stem_bn_wgrad_workspace(desc) bytes. */
+size_t cpg_stem_bn_wgrad_workspace(const cpg_conv_desc *desc);
+int cpg_stem_bn_relu_bwd_wgrad(const cpg_conv_desc *desc, const float *x, const float *w, const float *piggymask, float threshold,
+                               const float *bias, const float *gamma, const float *beta, const float *mean, const float *invstd,
+                               const float *coef, const float *gz, float *gw, float *gpm, void *workspace, size_t workspace_bytes,
+                               void *stream);
 
 /* y = relu(bn(x) + res): the tail of a residual block (models/resnet.py:69-74 `out = self.bn3(out); out += identity;
  * out = self.relu(out)`).  train != 0: batch statistics (mean / invstd out, running stats updated); train == 0: `mean`
