@@ -143,9 +143,12 @@ class KernelClock:
         # same contraction as cpg_conv2d_fwd; its epilogue also emits the BatchNorm partial sums
         p.cpg_conv2d_fwd_bnstats = timed('cpg_conv2d_fwd_bnstats', conv_kind('conv_fwd'), conv_flops, wino_fwd)
         # the fused stem (conv -> BatchNorm2d -> ReLU, conv output never written): the layer's algorithmic flops are counted on its
-        # BatchNorm/ReLU pass; the statistics pass before it recomputes the same conv (time counted, no extra algorithmic flops)
-        p.cpg_stem_bn_stats = timed('cpg_stem_bn_stats', conv_kind('conv_fwd'), lambda a: 0.0, None, lambda a: 0.0)
-        p.cpg_stem_bn_relu_fwd = timed('cpg_stem_bn_relu_fwd', conv_kind('conv_fwd'), conv_flops)
+        # BatchNorm/ReLU pass; the statistics pass before it recomputes the same conv (time counted, no extra algorithmic flops);
+        # its backward passes (cpg_stem_bn_relu_bwd_*) are BatchNorm-backward + weight-gradient work and are not clocked
+        # (a family of its own: these launches also do the BatchNorm's statistics / apply work and are HBM-bound -- in conv_fwd they
+        # would charge BatchNorm time to the Winograd kernels' roofline)
+        p.cpg_stem_bn_stats = timed('cpg_stem_bn_stats', conv_kind('stem_bn_fwd'), lambda a: 0.0, None, lambda a: 0.0)
+        p.cpg_stem_bn_relu_fwd = timed('cpg_stem_bn_relu_fwd', conv_kind('stem_bn_fwd'), conv_flops)
         # ... and the inference variant with the eval-mode BatchNorm + ReLU folded into the epilogue (validate)
         p.cpg_conv2d_fwd_bn_eval = timed('cpg_conv2d_fwd_bn_eval', conv_kind('conv_fwd'), conv_flops, wino_eval)
         # the opt-in bf16 MFMA kernels (--math bf16) get their own families: they are measured against the bf16 peak
@@ -466,7 +469,7 @@ def cpu_baseline(budget_s=45.0, steps=220, batch=256, validates=11, prune_events
 XGMI_LINK_GBS = 153.0                # MI355X_MICROARCH / task statement: 7 links x ~153 GB/s per GPU, point to point
 RCCL_ALLREDUCE_BUSBW_GBS = 310.0     # assumed large-message bus bandwidth of an 8-GPU RCCL all-reduce over xGMI (two links' worth)
 OVERLAP_SLOWDOWN = 1.17              # conv kernels beside 16 busy CUs' worth of other streams' kernels (tools/diag_interference.py)
-SINGLE_GPU_MS_PER_STEP = {'vgg16': 117.9, 'resnet50': 71.5, 'spherenet20': 21.4}   # batch 256, cycle ms per step (profiles/r03f_bench*.json)
+SINGLE_GPU_MS_PER_STEP = {'vgg16': 117.9, 'resnet50': 71.5, 'spherenet20': 21.4}   # batch 256, cycle ms per step (profiles/r03g_bench*.json)
 
 
 def predict_step_ms(arch, world, buckets, measured_single_gpu_ms=None):
