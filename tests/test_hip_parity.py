@@ -174,12 +174,14 @@ def test_conv_oracle(N, C, H, W, K, k, s, p, bias, pm):
         close(layer.bias.grad, r['gb'], rtol=1e-4, atol=1e-3, msg='gb')
 
 
+@pytest.mark.parametrize('wgrad_in_pass', [True, False])
 @pytest.mark.parametrize('N,C,H,W,pm', [(3, 3, 40, 70, False), (2, 3, 224, 224, True), (5, 1, 17, 33, False), (4, 2, 64, 64, True)])
-def test_fused_stem_conv_bn_relu_matches_unfused(N, C, H, W, pm):
+def test_fused_stem_conv_bn_relu_matches_unfused(N, C, H, W, pm, wgrad_in_pass, monkeypatch):
     """The stem fused with its BatchNorm2d -> ReLU (cpg_stem_bn_*: the conv output is recomputed in every pass instead of stored)
     against the unfused chain (stem conv with the statistics epilogue, fused BatchNorm kernels) and against torch in fp64: output,
     running statistics, and the gradients of the weight, the piggymask and the BatchNorm's affine parameters."""
     from cpg_amd.models import fused_bn as fb
+    monkeypatch.setattr(fb, 'FUSE_STEM_WGRAD', wgrad_in_pass)      # the weight gradient inside the apply pass, or gy written + cpg_conv2d_wgrad
     g = torch.Generator().manual_seed(7 * N + H)
     x = torch.randn(N, C, H, W, generator=g)
     w0 = torch.randn(64, C, 3, 3, generator=g) * 0.3
@@ -197,8 +199,6 @@ def test_fused_stem_conv_bn_relu_matches_unfused(N, C, H, W, pm):
         seq.train()
         old = fb.FUSE_STEM
         fb.FUSE_STEM = fused
-        calls = []
-        L = __import__('cpg_amd._lib', fromlist=['lib']).lib()
         try:
             z = seq(x.to(DEV))
             z.backward(gz.to(DEV))
