@@ -8,14 +8,17 @@ from cpg_amd.models import layers as nl
 from cpg_amd.utils import Optimizers
 from cpg_amd.utils.manager import Manager
 dev = torch.device('cuda', 0)
-net = bench.build_model(dev)
+ARCH = os.environ.get('ARCH', 'vgg16')
+bench.DATASET = bench.ARCHS[ARCH]['dataset']
+net = bench.build_model(dev, ARCH)
 from cpg_amd import dist as cdist
 model = cdist.DataParallel(net)
 masks = {n: torch.zeros(m.weight.shape, dtype=torch.uint8, device=dev) for n, m in model.named_modules()
          if isinstance(m, (nl.SharableConv2d, nl.SharableLinear))}
 g = torch.Generator(device=dev).manual_seed(1)
 B = int(os.environ.get('B', 256))
-pool = [(torch.randn(B, 3, 224, 224, generator=g, device=dev), torch.randint(0, 5, (B,), generator=g, device=dev)) for _ in range(2)]
+SZ, NCLS = bench.ARCHS[ARCH]['size'], bench.ARCHS[ARCH]['classes']
+pool = [(torch.randn(B, 3, SZ, SZ, generator=g, device=dev), torch.randint(0, NCLS, (B,), generator=g, device=dev)) for _ in range(2)]
 mgr = Manager(bench.make_args('finetune', 1), model, {}, masks, None, pool, 0, 0)
 mgr.pruner.make_finetuning_mask()
 opt = Optimizers(); opt.add(torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, nesterov=True), 1e-3)
