@@ -23,14 +23,15 @@ for f in glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True):
             seen.add((k, r['Dispatch_Id']))
             calls[k] += 1
 tot = sum(c['SQ_BUSY_CYCLES'] for c in agg.values()) / 32
-print('| kernel | calls | share of cycles | MFMA busy | VALU instr / MFMA | VALU time | sum | LDS instr / MFMA |')
+print('| kernel | calls | share of cycles | MFMA busy | other VALU instr / MFMA | VALU time | sum | LDS instr / MFMA |')
 print('|---|---:|---:|---:|---:|---:|---:|---:|')
 for k, c in sorted(agg.items(), key=lambda kv: -kv[1]['SQ_BUSY_CYCLES']):
     cyc = c['SQ_BUSY_CYCLES'] / 32
     if cyc / tot < 0.002:
         continue
     mf = c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc
-    va = c['SQ_INSTS_VALU'] / 1024 * 4 / cyc
     nm = c['SQ_INSTS_MFMA']
-    print('| `%s` | %d | %.3f | %.3f | %s | %.3f | %.3f | %s |' % (k, calls[k], cyc / tot, mf, '%.2f' % (c['SQ_INSTS_VALU'] / nm) if nm else '-', va, mf + va,
+    nv = c['SQ_INSTS_VALU'] - nm                      # SQ_INSTS_VALU counts the MFMA instructions too: the OTHER vector instructions
+    va = nv / 1024 * 4 / cyc
+    print('| `%s` | %d | %.3f | %.3f | %s | %.3f | %.3f | %s |' % (k, calls[k], cyc / tot, mf, '%.2f' % (nv / nm) if nm else '-', va, mf + va,
                                                               '%.2f' % (c['SQ_INSTS_LDS'] / nm) if nm else '-'))
