@@ -1450,7 +1450,11 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     }
     const int last = nch - 1;
     auto clampc = [&](int c) { return min(c, last); };
-    f32x4 ua[8], ub[8];                    // U of the current / next chunk: [kq * 4 + q]
+    // U of the current / next chunk: [kq * 4 + q].  U3 (every variant but the one with the statistics epilogue, which has no registers
+    // left): a third buffer -- the loads of chunk it + 2 go out during chunk it, two chunks (2 us) ahead of their first use instead of
+    // one; the wait counters showed the waves stalled on vector-memory data 13 % of the time with one chunk of distance
+    constexpr bool U3 = true;
+    f32x4 ua[8], ub[8], uc[U3 ? 8 : 1];
     Bop c0, c1, x0, x1;                    // B operands of the current chunk for channels 2 lh, 2 lh + 1 / the next chunk's, being transformed
     Rows rows;
     if (nch > 0) {
@@ -1458,6 +1462,10 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         for (int k = 0; k < 7; ++k) G_row1(0, rows, k);
 #pragma unroll
         for (int q = 0; q < 8; ++q) G_u1(0, ua, q);
+        if constexpr (U3) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) G_u1(min(1, nch - 1), ub, q);
+        }
     }
     // the accumulators are cleared while those loads fly (256 instructions, 0.4 us)
     __builtin_amdgcn_sched_barrier(0);
@@ -1501,27 +1509,27 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     // iteration it (par = it & 1): M(it); T(it + 1) from raw stage (it + 1) & 1; U(it + 1) requested; W(it + 2) stores the rows
     // requested one iteration ago, whose registers then take the loads of chunk it + 3
     auto iter = [&](int it, int par, f32x4 (&ucur)[8], f32x4 (&unext)[8], Bop &b0, Bop &b1, Bop &n0v, Bop &n1v) {
-        const int cu = clampc(it + 1), cr = clampc(it + 3);
-        W3_SLOT(0, 0, ucur, b0, T_read1(par ^ 1, 0, n0v, 0));
-        W3_SLOT(0, 1, ucur, b1, T_read1(par ^ 1, 0, n0v, 1));
-        W3_SLOT(8, 0, ucur, b0, T_read1(par ^ 1, 0, n0v, 2));
-        W3_SLOT(8, 1, ucur, b1, T_read1(par ^ 1, 1, n1v, 0));
-        W3_SLOT(1, 0, ucur, b0, T_read1(par ^ 1, 1, n1v, 1));
-        W3_SLOT(1, 1, ucur, b1, T_read1(par ^ 1, 1, n1v, 2));
-        W3_SLOT(9, 0, ucur, b0, G_u1(cu, unext, 0));
-        W3_SLOT(9, 1, ucur, b1, G_u1(cu, unext, 1));
-        W3_SLOT(2, 0, ucur, b0, T_col(n0v, 0));
-        W3_SLOT(2, 1, ucur, b1, G_u1(cu, unext, 2));
-        W3_SLOT(10, 0, ucur, b0, T_col(n0v, 1));
-        W3_SLOT(10, 1, ucur, b1, G_u1(cu, unext, 3));
-        W3_SLOT(3, 0, ucur, b0, T_col(n1v, 0));
-        W3_SLOT(3, 1, ucur, b1, G_u1(cu, unext, 4));
-        W3_SLOT(11, 0, ucur, b0, T_col(n1v, 1));
-        W3_SLOT(11, 1, ucur, b1, G_u1(cu, unext, 5));
-        W3_SLOT(4, 0, ucur, b0, T_rowp(n0v, 0));
-        W3_SLOT(4, 1, ucur, b1, G_u1(cu, unext, 6));
-        W3_SLOT(12, 0, ucur, b0, T_rowp(n0v, 1));
-        W3_SLOT(12, 1, ucur, b1, G_u1(cu, unext, 7));
+        const int cu = clampc(it + (U3 ? 2 : 1)), cr = clampc(it + 3);
+        W3_SLOT(0, 0, ucur, b0, G_u1(cu, unext, 0));
+        W3_SLOT(0, 1, ucur, b1, G_u1(cu, unext, 1));
+        W3_SLOT(8, 0, ucur, b0, G_u1(cu, unext, 2));
+        W3_SLOT(8, 1, ucur, b1, G_u1(cu, unext, 3));
+        W3_SLOT(1, 0, ucur, b0, G_u1(cu, unext, 4));
+        W3_SLOT(1, 1, ucur, b1, G_u1(cu, unext, 5));
+        W3_SLOT(9, 0, ucur, b0, G_u1(cu, unext, 6));
+        W3_SLOT(9, 1, ucur, b1, G_u1(cu, unext, 7));
+        W3_SLOT(2, 0, ucur, b0, T_read1(par ^ 1, 0, n0v, 0));
+        W3_SLOT(2, 1, ucur, b1, T_read1(par ^ 1, 0, n0v, 1));
+        W3_SLOT(10, 0, ucur, b0, T_read1(par ^ 1, 0, n0v, 2));
+        W3_SLOT(10, 1, ucur, b1, T_read1(par ^ 1, 1, n1v, 0));
+        W3_SLOT(3, 0, ucur, b0, T_read1(par ^ 1, 1, n1v, 1));
+        W3_SLOT(3, 1, ucur, b1, T_read1(par ^ 1, 1, n1v, 2));
+        W3_SLOT(11, 0, ucur, b0, T_col(n0v, 0));
+        W3_SLOT(11, 1, ucur, b1, T_col(n0v, 1));
+        W3_SLOT(4, 0, ucur, b0, T_col(n1v, 0));
+        W3_SLOT(4, 1, ucur, b1, T_col(n1v, 1));
+        W3_SLOT(12, 0, ucur, b0, T_rowp(n0v, 0));
+        W3_SLOT(12, 1, ucur, b1, T_rowp(n0v, 1));
         W3_SLOT(5, 0, ucur, b0, T_rowp(n1v, 0));
         W3_SLOT(5, 1, ucur, b1, T_rowp(n1v, 1));
         W3_SLOT(13, 0, ucur, b0, W_row1(par, rows, 0); G_row1(cr, rows, 0));
@@ -1536,9 +1544,20 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         W3_SLOT(15, 1, ucur, b1, );
     };
     WG_STAMP(2);
-    for (int it = 0; it < nch; it += 2) {
-        iter(it, 0, ua, ub, c0, c1, x0, x1);
-        if (it + 1 < nch) iter(it + 1, 1, ub, ua, x0, x1, c0, c1);
+    if constexpr (U3) {                       // (U buffers rotate with period 3, the operand sets with period 2: six iterations per trip)
+        for (int it = 0; it < nch; it += 6) {
+            iter(it, 0, ua, uc, c0, c1, x0, x1);
+            if (it + 1 < nch) iter(it + 1, 1, ub, ua, x0, x1, c0, c1);
+            if (it + 2 < nch) iter(it + 2, 0, uc, ub, c0, c1, x0, x1);
+            if (it + 3 < nch) iter(it + 3, 1, ua, uc, x0, x1, c0, c1);
+            if (it + 4 < nch) iter(it + 4, 0, ub, ua, c0, c1, x0, x1);
+            if (it + 5 < nch) iter(it + 5, 1, uc, ub, x0, x1, c0, c1);
+        }
+    } else {
+        for (int it = 0; it < nch; it += 2) {
+            iter(it, 0, ua, ub, c0, c1, x0, x1);
+            if (it + 1 < nch) iter(it + 1, 1, ub, ua, x0, x1, c0, c1);
+        }
     }
 
     WG_STAMP(3);
