@@ -1619,11 +1619,14 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     // (ODD: the odd row of the last tile row of an odd-height map does not exist -- the wave that owns it stores nothing for that tile)
     const bool tv = tg < ttot && (!ODD || 2 * ty + ph < g.H);
     float *yout = y + ((int64_t)n * g.M) * HW + (2 * ty + ph) * g.W + 2 * tx;
-    float s1[32], s2[32];
-    auto out_all = [&](auto hb) {                // (hb: with / without a conv bias -- two separate epilogues, see k_wg1)
+    // (the statistics go out per 32-channel half: with all 32 + 32 sums live next to own0 / own1 the kernel is past 256 vector registers and the
+    //  allocator parks values in scratch and in an accumulation register -- tests/test_abi_and_host.py checks the compiled code for both)
+    auto out_half = [&](auto hb, auto kqc) {     // (hb: with / without a conv bias -- two separate epilogues, see k_wg1)
+    constexpr int kq = decltype(kqc)::value;
+    float s1[16], s2[16];
 #pragma unroll
-    for (int ke = 0; ke < 32; ++ke) {
-        const int kq = ke >> 4, e = ke & 15;
+    for (int e = 0; e < 16; ++e) {
+        const int ke = kq * 16 + e;
         const int co = kb * 64 + kq * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         const f32x2 got = *reinterpret_cast<const f32x2 *>(xch + ((((ph ^ 1) * 2 + kq) * 16 + e) * 64 + lane) * 2);
         float v0 = fmaf(own0[ke], sgn, got[0]);             // (+- own + got, exactly)
@@ -1647,29 +1650,30 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
             *reinterpret_cast<f32x2 *>(yout + (int64_t)co * HW) = o;
         }
         if (STATS) {
-            s1[ke] = tv ? v0 + v1 : 0.0f;
-            s2[ke] = tv ? v0 * v0 + v1 * v1 : 0.0f;
+            s1[e] = tv ? v0 + v1 : 0.0f;
+            s2[e] = tv ? v0 * v0 + v1 * v1 : 0.0f;
         }
     }
-    };
-    if (bias != nullptr) out_all(std::true_type{}); else out_all(std::false_type{});
     if (STATS) {                               // every wave is its own statistics tile: stats[k][2 run + ph][2]
 #pragma unroll
-        for (int ke = 0; ke < 32; ke += 8) half_wave_sum8(s1 + ke), half_wave_sum8(s2 + ke);
+        for (int e = 0; e < 16; e += 8) half_wave_sum8(s1 + e), half_wave_sum8(s2 + e);
         if (li == kHalfSumLane) {
             const unsigned ntile = 2 * ((ttot + W1_T - 1) / W1_T);
 #pragma unroll
-            for (int ke = 0; ke < 32; ++ke) {
-                const int co = kb * 64 + (ke >> 4) * 32 + (ke & 3) + 8 * ((ke & 15) >> 2) + 4 * lh;
+            for (int e = 0; e < 16; ++e) {
+                const int co = kb * 64 + kq * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (co < g.M) {
                     float *dst = stats + ((int64_t)co * ntile + 2 * run + ph) * 2;
                     f32x2 o;
-                    o[0] = s1[ke], o[1] = s2[ke];
+                    o[0] = s1[e], o[1] = s2[e];
                     *reinterpret_cast<f32x2 *>(dst) = o;
                 }
             }
         }
     }
+    };
+    if (bias != nullptr) out_half(std::true_type{}, std::integral_constant<int, 0>{}), out_half(std::true_type{}, std::integral_constant<int, 1>{});
+    else out_half(std::false_type{}, std::integral_constant<int, 0>{}), out_half(std::false_type{}, std::integral_constant<int, 1>{});
     WG_STAMP(4);
     __syncthreads();                           // the exchange buffer becomes the next unit's raw stages
     }   // next logical block
