@@ -45,7 +45,7 @@ sys.path.insert(0, ROOT)
 import cpg_amd.models as models                     # noqa: E402
 from cpg_amd import dist as cdist                    # noqa: E402
 from cpg_amd.models import layers as nl              # noqa: E402
-from cpg_amd.utils import Optimizers                 # noqa: E402
+from cpg_amd.utils import Optimizers, settle_host_gc   # noqa: E402
 from cpg_amd.utils.fused_sgd import MaskedSGD        # noqa: E402
 from cpg_amd.utils.manager import Manager            # noqa: E402
 from cpg_amd.utils.prune import SparsePruner         # noqa: E402
@@ -585,6 +585,9 @@ def main():
                 bn.reset_running_stats()
         if model.sync_events is not None:
             model.sync_events = []
+    # what cpg_amd.driver.CPGSession does once a task's model stands: one full collection, then everything alive goes to the
+    # collector's permanent generation (a generation-2 pass over torch + the model is 80 ms of host time with no kernel enqueued)
+    settle_host_gc()
 
     def barrier():
         if world > 1:
@@ -630,7 +633,8 @@ def main():
                'config': {'workload': '%s, task-1 CPG cycle (finetune -> prune 0.0->0.1 -> recovery, validate after every 20th train '
                                       'step), batch %d per GPU' % (arch['workload'], a.batch),
                           'arch': a.arch, 'global_batch': global_batch, 'per_gpu_batch': a.batch, 'parallelism': 'dp%d' % world,
-                          'epoch_steps': EPOCH_STEPS, 'cycle': counts},
+                          'epoch_steps': EPOCH_STEPS, 'cycle': counts,
+                          'host_gc': 'collected + frozen after the warm-up (cpg_amd.utils.settle_host_gc, as CPGSession.start_task)'},
                # train steps only, in the ALGORITHMIC flops of SURVEY 8d (Winograd launches execute 16/36 of them, so this can
                # exceed the dense peak; whole_step below prices the step against what the MFMA pipe really had to do)
                'algorithmic_tflops_train_steps': round(value * arch['flop_train'] / world / 1e12, 2)}

@@ -27,7 +27,7 @@ from torch.nn.parameter import Parameter
 from . import dist as cdist
 from . import models
 from .models import layers as nl
-from .utils import Optimizers
+from .utils import Optimizers, settle_host_gc
 from .utils import checkpoint as ckpt
 from .utils.manager import Manager
 
@@ -144,6 +144,7 @@ class CPGSession(object):
         self.shared_layer_info[dataset]['network_width_multiplier'] = self.width
         if hasattr(self.model, 'refresh_hooks'):
             self.model.refresh_hooks()
+        settle_host_gc()                                    # the model, its masks and heads now live for the whole task
         return task_id
 
     def _fresh_piggymasks(self):
@@ -246,6 +247,7 @@ class CPGSession(object):
             ckpt.resize_masks(self.model, self.masks, 'finetune')
         else:
             self.masks.clear()
+        settle_host_gc()                                    # (the old width's modules are garbage now; the new ones are long-lived)
 
     # -- phases ------------------------------------------------------------------------------------------------
     def _manager(self, args, train_loader, val_loader, begin, end):
