@@ -56,7 +56,19 @@ struct WgGeom {
     int nkb, nch;             // blocks of BK output channels, chunks of 4 input channels
     int span;                 // images a block's 64 consecutive tiles can touch
     unsigned nblocks;         // k_wg1 / k_wg3: logical blocks of the launch (the grid may be smaller: blocks loop over them)
+    float inv_timg, inv_tw;   // 1 / tiles_img, 1 / tw (wg_divmod)
 };
+
+// rel / d and rel % d for rel < 2^24 (exact in fp32) and a small quotient: a multiply by the reciprocal and one correction step, ~10
+// vector instructions where the compiler's generic 32-bit division is ~30 -- a unit's set-up did eight of those, its epilogue four,
+// and on this chip every vector instruction of the single resident wave is MFMA time (the twin of pointwise.hip's divmod_small).
+__device__ __forceinline__ void wg_divmod(unsigned rel, unsigned d, float inv, unsigned &qt, unsigned &rm) {
+    const unsigned n = (unsigned)((float)rel * inv);
+    const int r = (int)(rel - n * d);
+    const int lt = r < 0 ? 1 : 0, ge = r >= (int)d ? 1 : 0;            // (selects, no branches)
+    qt = n + ge - lt;
+    rm = (unsigned)(r + (lt - ge) * (int)d);
+}
 
 // ------------------------------------------------------------------------------ weight transform
 __global__ __launch_bounds__(256) void k_wg_pack(const float *__restrict__ w, const float *__restrict__ pm, float thr,
@@ -1322,7 +1334,15 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     WG_STAMP(0);
     if (lane == 0 && dbg_u < 65536) wg_dbg[dbg_u * 8 + 6] = __builtin_amdgcn_s_getreg(63492), wg_dbg[dbg_u * 8 + 7] = __builtin_amdgcn_s_getreg(63508);
 #endif
-    const int n0 = (int)(t0 / timg);
+    const unsigned n0u = t0 / timg, r0 = t0 - n0u * timg;      // (uniform: the one generic division of a unit)
+    const int n0 = (int)n0u;
+    // tile t0 + add (add < 64) -> image relative to n0, tile row, tile column: r0 + add < tiles_img + 64 < 2^24 (cpg_conv3x3_wino_ok)
+    auto locate = [&](unsigned add, int &nrel, int &ty, int &tx) {
+        unsigned dn, r, tyu, txu;
+        wg_divmod(r0 + add, timg, g.inv_timg, dn, r);
+        wg_divmod(r, twu, g.inv_tw, tyu, txu);
+        nrel = (int)dn, ty = (int)tyu, tx = (int)txu;
+    };
 
     constexpr int kOutOfRange = (int)0x80000000;
     int roff[3], hoff, lo, ro;
@@ -1330,8 +1350,9 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     {
         const unsigned tg = t0 + li;
         const bool tv = tg < ttot;
-        const int n = (int)(tg / timg), r = (int)(tg % timg);
-        const int ty = (int)((unsigned)r / twu), tx = (int)((unsigned)r % twu);
+        int nrel, ty, tx;
+        locate((unsigned)li, nrel, ty, tx);
+        const int n = n0 + nrel;
         const int cbase = ((n - n0) * g.C + 2 * lh) * HW;
         if (ODD) oddcol = (g.W & 1) && tx == g.tw - 1;
 #pragma unroll
@@ -1344,8 +1365,9 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         // halo: lanes 0-23 = (side, row, channel): the column left of tile t0 / right of tile t0 + 31
         const int side = lane >= 12 ? 1 : 0, hl = lane - 12 * side, hi = hl >> 2, hc = hl & 3;
         const unsigned th = side ? t0 + W1_T - 1 : t0;
-        const int nh = (int)(th / timg), rh = (int)(th % timg);
-        const int tyh = (int)((unsigned)rh / twu), txh = (int)((unsigned)rh % twu);
+        int nhrel, tyh, txh;
+        locate(side ? W1_T - 1 : 0, nhrel, tyh, txh);
+        const int nh = n0 + nhrel;
         const int ghh = 2 * tyh - 1 + ph + (ph ? 2 - hi : hi), gwh = side ? 2 * txh + 2 : 2 * txh - 1;
         const bool okh = lane < 24 && th < ttot && (unsigned)ghh < (unsigned)g.H && (unsigned)gwh < (unsigned)g.W;
         hoff = okh ? (((nh - n0) * g.C + hc) * HW + ghh * g.W + gwh) * 4 : kOutOfRange;
@@ -1564,6 +1586,10 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     // ---- epilogue: this wave's 8 positions (transform rows i = 2 ph, 2 ph + 1) -> partial 2x2 outputs; the output transform is linear
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     float own0[32], own1[32];                  // the output row this wave finishes (a = ph), columns 0 / 1, per channel half and accumulator element
+    // (the epilogue's lane constants are derived from an opaque copy: computed from `lh` itself they are invariant in the persistent loop,
+    //  the compiler hoists all 32 channel offsets in front of it and spills them)
+    int lh_e = lh;
+    asm volatile("" : "+v"(lh_e));
     __syncthreads();                           // both waves are done with their raw stages: the LDS becomes the exchange buffer
     float *xch = smem_all;
     // local rows: wave 0 holds R0, R1, wave 1 holds -R3, R2 (reversed; row 3 negated, see T_col).  Y0 = R0 + R1 + R2, Y1 = R1 - R2 - R3: a wave owns
@@ -1614,21 +1640,42 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     }
     __syncthreads();
     const unsigned tg = t0 + li;
-    const int n = (int)(tg / timg), r = (int)(tg % timg);
-    const int ty = (int)((unsigned)r / twu), tx = (int)((unsigned)r % twu);
+    int nrel, ty, tx;
+    locate((unsigned)li, nrel, ty, tx);
+    const int n = n0 + nrel;
     // (ODD: the odd row of the last tile row of an odd-height map does not exist -- the wave that owns it stores nothing for that tile)
     const bool tv = tg < ttot && (!ODD || 2 * ty + ph < g.H);
     float *yout = y + ((int64_t)n * g.M) * HW + (2 * ty + ph) * g.W + 2 * tx;
+    // FAST (all 32 tiles of the unit exist, all 64 channels of the block exist, even map -- a wave-uniform test): plain stores at the unit's
+    // (scalar) base + a 32-bit lane offset + the running scalar channel offset, one vector add per store.  The general path computes a
+    // 64-bit address per store (a multiply-add and two shift-adds), compares and branches around it: 1 us of a unit for the few units
+    // on the ragged end of a launch that need it.
+    const bool fast_u = !ODD && t0 + W1_T <= ttot && g.M - kb * 64 >= 64;
+    char *ybase = reinterpret_cast<char *>(y + (int64_t)n0 * g.M * HW);
+    const unsigned yoff = (unsigned)(((nrel * g.M + kb * 64 + 4 * lh_e) * HW + (2 * ty + ph) * g.W + 2 * tx) * 4);
+    // (the scalar channel offsets are a running sum behind an opaque barrier: as multiples of HW they are invariant in the persistent
+    //  loop, the compiler would compute all 32 in front of it and spill scalar registers into vector lanes)
+    int HW4 = HW * 4;
+    asm volatile("" : "+s"(HW4));
     // (the statistics go out per 32-channel half: with all 32 + 32 sums live next to own0 / own1 the kernel is past 256 vector registers and the
     //  allocator parks values in scratch and in an accumulation register -- tests/test_abi_and_host.py checks the compiled code for both)
-    auto out_half = [&](auto hb, auto kqc) {     // (hb: with / without a conv bias -- two separate epilogues, see k_wg1)
+    auto out_half = [&](auto hb, auto kqc, auto fastc) {     // (hb: with / without a conv bias -- two separate epilogues, see k_wg1)
     constexpr int kq = decltype(kqc)::value;
+    constexpr bool FAST = decltype(fastc)::value;
     float s1[16], s2[16];
+    constexpr int GR = STATS ? 2 : 4;          // (the statistics variant has no registers for four)
+    f32x2 got4[GR];
+    int soff = kq * 32 * HW4;                  // (kq * 32 + (e & 3) + 8 * (e >> 2)) * HW4, stepped
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int ke = kq * 16 + e;
-        const int co = kb * 64 + kq * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const f32x2 got = *reinterpret_cast<const f32x2 *>(xch + ((((ph ^ 1) * 2 + kq) * 16 + e) * 64 + lane) * 2);
+        const int co = kb * 64 + kq * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh_e;
+        if ((e & (GR - 1)) == 0) {             // (the exchange reads of GR channels go out together: one LDS latency per GR stores)
+#pragma unroll
+            for (int j = 0; j < GR; ++j)
+                got4[j] = *reinterpret_cast<const f32x2 *>(xch + ((((ph ^ 1) * 2 + kq) * 16 + e + j) * 64 + lane) * 2);
+        }
+        const f32x2 got = got4[e & (GR - 1)];
         float v0 = fmaf(own0[ke], sgn, got[0]);             // (+- own + got, exactly)
         float v1 = fmaf(own1[ke], sgn, got[1]);
         if constexpr (decltype(hb)::value) {
@@ -1641,17 +1688,27 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
             v0 = (v0 - mu) * is * ga + be, v1 = (v1 - mu) * is * ga + be;
             if (bn.relu) v0 = fmaxf(v0, 0.0f), v1 = fmaxf(v1, 0.0f);
         }
-        if (ODD && oddcol) {                   // the second column is past the edge: one dword, and it stays out of the statistics
-            if (tv && co < g.M) yout[(int64_t)co * HW] = v0;
-            v1 = 0.0f;
-        } else if (tv && co < g.M) {
+        if constexpr (FAST) {
             f32x2 o;
             o[0] = v0, o[1] = v1;
-            *reinterpret_cast<f32x2 *>(yout + (int64_t)co * HW) = o;
-        }
-        if (STATS) {
-            s1[e] = tv ? v0 + v1 : 0.0f;
-            s2[e] = tv ? v0 * v0 + v1 * v1 : 0.0f;
+            *reinterpret_cast<f32x2 *>(ybase + (size_t)(yoff + (unsigned)soff)) = o;
+            soff += (e & 3) == 3 ? 5 * HW4 : HW4;
+            asm volatile("" : "+s"(soff));
+            if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (with no branch between them the scheduler hoists every exchange read: spills)
+            if (STATS) s1[e] = v0 + v1, s2[e] = v0 * v0 + v1 * v1;
+        } else {
+            if (ODD && oddcol) {               // the second column is past the edge: one dword, and it stays out of the statistics
+                if (tv && co < g.M) yout[(int64_t)co * HW] = v0;
+                v1 = 0.0f;
+            } else if (tv && co < g.M) {
+                f32x2 o;
+                o[0] = v0, o[1] = v1;
+                *reinterpret_cast<f32x2 *>(yout + (int64_t)co * HW) = o;
+            }
+            if (STATS) {
+                s1[e] = tv ? v0 + v1 : 0.0f;
+                s2[e] = tv ? v0 * v0 + v1 * v1 : 0.0f;
+            }
         }
     }
     if (STATS) {                               // every wave is its own statistics tile: stats[k][2 run + ph][2]
@@ -1661,7 +1718,7 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
             const unsigned ntile = 2 * ((ttot + W1_T - 1) / W1_T);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int co = kb * 64 + kq * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int co = kb * 64 + kq * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh_e;
                 if (co < g.M) {
                     float *dst = stats + ((int64_t)co * ntile + 2 * run + ph) * 2;
                     f32x2 o;
@@ -1672,8 +1729,16 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         }
     }
     };
-    if (bias != nullptr) out_half(std::true_type{}, std::integral_constant<int, 0>{}), out_half(std::true_type{}, std::integral_constant<int, 1>{});
-    else out_half(std::false_type{}, std::integral_constant<int, 0>{}), out_half(std::false_type{}, std::integral_constant<int, 1>{});
+    auto out_all = [&](auto hb) {
+        if constexpr (!ODD) {
+            if (fast_u) {
+                out_half(hb, std::integral_constant<int, 0>{}, std::true_type{}), out_half(hb, std::integral_constant<int, 1>{}, std::true_type{});
+                return;
+            }
+        }
+        out_half(hb, std::integral_constant<int, 0>{}, std::false_type{}), out_half(hb, std::integral_constant<int, 1>{}, std::false_type{});
+    };
+    if (bias != nullptr) out_all(std::true_type{}); else out_all(std::false_type{});
     WG_STAMP(4);
     __syncthreads();                           // the exchange buffer becomes the next unit's raw stages
     }   // next logical block
@@ -1720,7 +1785,7 @@ extern "C" int cpg_conv3x3_wino_ok(int N, int c_read, int m, int H, int W) {
     const int tiles_img = ((H + 1) / 2) * ((W + 1) / 2);
     const int span = (WG_T + tiles_img - 1) / tiles_img + 1;
     if ((int64_t)N * tiles_img + 64 >= (1ll << 31)) return 0;               // 32-bit tile indices in the kernels
-    return (int64_t)span * c_read * H * W * 4 < (1ll << 31);
+    return (int64_t)span * std::max(c_read, m) * H * W * 4 < (1ll << 31);   // (a unit's images behind one buffer descriptor: read and written)
 }
 
 extern "C" size_t cpg_conv3x3_wino_pack_bytes(int c_read, int m) {      // (the 64-channel blocking pads m further: covers both)
@@ -1814,6 +1879,7 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
         WgGeom g;
         g.N = N, g.C = c_read, g.H = H, g.W = W, g.M = m;
         g.th = (H + 1) / 2, g.tw = (W + 1) / 2, g.tiles_img = g.th * g.tw;
+        g.inv_timg = 1.0f / (float)g.tiles_img, g.inv_tw = 1.0f / (float)g.tw;
         g.tiles_total = (int64_t)N * g.tiles_img;
         g.nkb = pad_to(m, 32) / 32, g.nch = pad_to(c_read, WG_CK) / WG_CK;
         g.span = (W1_T + g.tiles_img - 1) / g.tiles_img + 1;
@@ -1885,6 +1951,7 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
     WgGeom g;
     g.N = N, g.C = c_read, g.H = H, g.W = W, g.M = m;
     g.th = H / 2, g.tw = W / 2, g.tiles_img = g.th * g.tw;
+    g.inv_timg = 1.0f / (float)g.tiles_img, g.inv_tw = 1.0f / (float)g.tw;
     g.tiles_total = (int64_t)N * g.tiles_img;
     g.nkb = pad_to(m, BK) / BK, g.nch = pad_to(c_read, WG_CK) / WG_CK;
     g.span = (WG_T + g.tiles_img - 1) / g.tiles_img + 1;
