@@ -99,8 +99,8 @@ with open(os.path.join(P, '%s_final.md' % out), 'w') as f:
     w('    rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --optin-steps 0\n')
     w('                                                      -> tables below; its bench line: profiles/%s_bench_under_rocprof_vgg16.json (%.1f img/s)\n\n'
       % (out, under['vgg16']['value']))
-    w('The VGG16 kernels are round 2\'s (profiles/r02n_final.md has their per-wave phase timing, r02m_pmc_wino.md their counters, r02_traffic.json '
-      'their HBM bytes); what changed in the bench line is its arithmetic:\n\n* %s\n' % roof(b20))
+    w('Counters of this state\'s kernels over whole train steps: profiles/r03_pmc_step_{vgg16,resnet50,spherenet20}.md (MFMA-busy, other vector '
+      'instructions per MFMA); per-unit phase times: DESIGN.md section 8 (tools/diag_wg_timing.py); HBM bytes: the traffic table below.\n\n* %s\n' % roof(b20))
     w('* `cpu_baseline`: %s\n\n' % json.dumps({k: v for k, v in b20['cpu_baseline'].items() if k != 'sample'}))
     w('## bench.py, K = 20 (HIP events around every C-ABI launch of the timed region)\n\n%s\n\n' % fam_table(b20))
     w('phases: `%s`\n\n' % json.dumps(b20['phases']))
