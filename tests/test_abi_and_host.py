@@ -308,6 +308,30 @@ def test_choose_ratio_table():
     assert choose_ratio({0.0: 0.9}, 0.5, 0.0, False) == 0.0     # the sweep recorded nothing
 
 
+def test_settle_host_gc_freezes_what_is_alive():
+    """cpg_amd.utils.settle_host_gc (called by CPGSession once a task's model stands, by bench.py after its warm-up): everything alive
+    moves to the collector's permanent generation, and a second call first gives cyclic garbage among the frozen objects back."""
+    import gc
+    from cpg_amd.utils import settle_host_gc
+    try:
+        settle_host_gc()
+        n1 = gc.get_freeze_count()
+        assert n1 > 1000
+
+        class Node(object):
+            pass
+        a, b = Node(), Node()
+        a.other, b.other = b, a                                  # a cycle that only the collector can free
+        settle_host_gc()                                         # frozen alive
+        assert gc.get_freeze_count() >= n1 + 2
+        n2 = gc.get_freeze_count()
+        del a, b
+        settle_host_gc()                                         # unfreeze + collect: the cycle is gone
+        assert gc.get_freeze_count() < n2 + 50                   # (a few objects of the test machinery come and go)
+    finally:
+        gc.unfreeze()
+
+
 def test_grouped_conv_is_refused_at_construction():
     """groups != 1 has no HIP kernel: the layer (and the resnext factories built on it) say so when they are constructed."""
     with pytest.raises(NotImplementedError):
