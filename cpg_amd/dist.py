@@ -226,8 +226,7 @@ class DataParallel(nn.Module):
             else:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
                 flat.mul_(inv)
-            for g, s in zip(grads, _unflatten_dense_tensors(flat, grads)):
-                g.copy_(s)
+            torch._foreach_copy_(grads, list(_unflatten_dense_tensors(flat, grads)))   # (one multi-tensor kernel, not one copy per tensor)
             self._small = []
         for work, g, packed in self._handles:
             work.wait()
@@ -273,8 +272,7 @@ class DataParallel(nn.Module):
         for bufs in by_dtype.values():          # one flat broadcast per dtype (running_mean / running_var; num_batches_tracked)
             flat = _flatten_dense_tensors(bufs)
             dist.broadcast(flat, src=src, group=self.process_group)
-            for b, f in zip(bufs, _unflatten_dense_tensors(flat, bufs)):
-                b.copy_(f)
+            torch._foreach_copy_(bufs, list(_unflatten_dense_tensors(flat, bufs)))
 
 
 def seed_per_rank(base=1, process_group=None):
