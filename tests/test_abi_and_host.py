@@ -310,24 +310,24 @@ def test_choose_ratio_table():
 
 def test_settle_host_gc_freezes_what_is_alive():
     """cpg_amd.utils.settle_host_gc (called by CPGSession once a task's model stands, by bench.py after its warm-up): everything alive
-    moves to the collector's permanent generation, and a second call first gives cyclic garbage among the frozen objects back."""
+    moves to the collector's permanent generation, and a later call first gives cyclic garbage among the frozen objects back."""
     import gc
+    import weakref
     from cpg_amd.utils import settle_host_gc
-    try:
-        settle_host_gc()
-        n1 = gc.get_freeze_count()
-        assert n1 > 1000
 
-        class Node(object):
-            pass
+    class Node(object):
+        pass
+    try:
         a, b = Node(), Node()
         a.other, b.other = b, a                                  # a cycle that only the collector can free
-        settle_host_gc()                                         # frozen alive
-        assert gc.get_freeze_count() >= n1 + 2
-        n2 = gc.get_freeze_count()
+        wa = weakref.ref(a)
+        settle_host_gc()
+        assert gc.get_freeze_count() > 1000                      # the interpreter, torch, the test modules ...
         del a, b
-        settle_host_gc()                                         # unfreeze + collect: the cycle is gone
-        assert gc.get_freeze_count() < n2 + 50                   # (a few objects of the test machinery come and go)
+        gc.collect()
+        assert wa() is not None                                  # frozen: a plain collection does not see the dead cycle
+        settle_host_gc()                                         # unfreeze + collect + freeze again
+        assert wa() is None
     finally:
         gc.unfreeze()
 
