@@ -51,6 +51,7 @@ struct WwGeom {
     int nkb, ncb, nsplit;
     unsigned su;              // stages per unit
     int span;                 // images a unit can touch
+    int xcd;                  // blocks in XCD-contiguous order (block b runs on XCD b % 8: each XCD walks one eighth of the units)
 };
 
 @@MMA@@
@@ -75,7 +76,7 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
     float *smem = smem_all + wave * WW_STAGE;
     const int HW = g.H * g.W;
     const unsigned npairs = (unsigned)(g.nkb * g.ncb);
-    const unsigned u = blockIdx.x * 4 + wave;
+    const unsigned u = (g.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x) * 4 + wave;
     if (u >= npairs * (unsigned)g.nsplit) return;                // (no barriers anywhere: a wave may leave)
     const unsigned pair = u % npairs, split = u / npairs;
     const int kb = (int)(pair % (unsigned)g.nkb), cb = (int)(pair / (unsigned)g.nkb);
@@ -333,6 +334,10 @@ bool ww_plan(const cpg_conv_desc *d, WwPlan &p) {
     if ((int64_t)g.span * std::max(d->C, d->K) * HW * 4 + (d->W + 4) * 4 >= (1ll << 31)) return false;
     p.ws_bytes = (size_t)g.nsplit * 9 * d->K * d->C * sizeof(float);
     p.blocks = (npairs * g.nsplit + 3) / 4;
+    {
+        const char *f = getenv("CPG_WW_XCD");
+        g.xcd = f == nullptr || f[0] != '0';
+    }
     return p.blocks <= 0x7FFFFFFFll;
 }
 
