@@ -469,7 +469,7 @@ def cpu_baseline(budget_s=45.0, steps=220, batch=256, validates=11, prune_events
 XGMI_LINK_GBS = 153.0                # MI355X_MICROARCH / task statement: 7 links x ~153 GB/s per GPU, point to point
 RCCL_ALLREDUCE_BUSBW_GBS = 310.0     # assumed large-message bus bandwidth of an 8-GPU RCCL all-reduce over xGMI (two links' worth)
 OVERLAP_SLOWDOWN = 1.17              # conv kernels beside 16 busy CUs' worth of other streams' kernels (tools/diag_interference.py)
-SINGLE_GPU_MS_PER_STEP = {'vgg16': 114.1, 'resnet50': 71.2, 'spherenet20': 21.2}   # batch 256, cycle ms per step (profiles/r03j_bench*.json)
+SINGLE_GPU_MS_PER_STEP = {'vgg16': 114.0, 'resnet50': 71.3, 'spherenet20': 21.2}   # batch 256, cycle ms per step (profiles/r03k_bench*.json)
 
 
 def predict_step_ms(arch, world, buckets, measured_single_gpu_ms=None):
