@@ -46,7 +46,7 @@ import cpg_amd.models as models                     # noqa: E402
 from cpg_amd import dist as cdist                    # noqa: E402
 from cpg_amd.models import layers as nl              # noqa: E402
 from cpg_amd.utils import Optimizers, settle_host_gc   # noqa: E402
-from cpg_amd.utils.fused_sgd import MaskedSGD        # noqa: E402
+from cpg_amd.utils.fused_sgd import MaskedAdam, MaskedSGD   # noqa: E402
 from cpg_amd.utils.manager import Manager            # noqa: E402
 from cpg_amd.utils.prune import SparsePruner         # noqa: E402
 
@@ -57,11 +57,11 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0       # same guide: dense bf16 (v_mfma_f32_32x32x
 # synthetic task, and the ALGORITHMIC flops of one train step per image = 2 x (3 x MACs of the masked layers - MACs of the first
 # layer, which has no input gradient) -- SURVEY.md section 8 / BASELINE.md section 3: 15.466 / 4.087 / 2.029 G MACs per image.
 ARCHS = {
-    'vgg16': dict(size=224, dataset='task1', classes=5, flop_train=92.62e9, flop_fwd=30.932e9,
+    'vgg16': dict(size=224, dataset='task1', classes=5, dataset2='task2', classes2=5, flop_train=92.62e9, flop_fwd=30.932e9,
                   workload='configs[1]: VGG16-BN custom_vgg 224x224'),
-    'resnet50': dict(size=224, dataset='cubs_cropped', classes=200, flop_train=2 * (3 * 4.087e9 - 0.118e9), flop_fwd=2 * 4.087e9,
+    'resnet50': dict(size=224, dataset='cubs_cropped', classes=200, dataset2='stanford_cars_cropped', classes2=196, flop_train=2 * (3 * 4.087e9 - 0.118e9), flop_fwd=2 * 4.087e9,
                      workload='configs[3] topology on one GPU: ResNet-50 (Bottleneck, masked 7x7 s2 / 1x1 / 3x3 s1 / 3x3 s2 convs) 224x224'),
-    'spherenet20': dict(size=112, dataset='face_verification', classes=4630, flop_train=2 * (3 * 2.029e9 - 0.0054e9), flop_fwd=2 * 2.029e9,
+    'spherenet20': dict(size=112, dataset='face_verification', classes=4630, dataset2='gender', classes2=2, flop_train=2 * (3 * 2.029e9 - 0.0054e9), flop_fwd=2 * 2.029e9,
                         workload='configs[4] topology on one GPU: SphereNet-20 112x112, AngleLinear head + AngleLoss'),
 }
 FLOP_PER_IMG_TRAIN = ARCHS['vgg16']['flop_train']
@@ -180,6 +180,23 @@ class KernelClock:
         return agg
 
 
+def csrc_digest():
+    """sha256 over the kernel sources (cpg_amd/csrc, sorted by name): committed counter files carry the digest of the sources they
+    were measured on, so that a kernel change makes `roofline.traffic` say it is stale instead of silently quoting old bytes."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'cpg_amd', 'csrc')
+    for name in sorted(os.listdir(d)):
+        if name.endswith(('.hip', '.h', '.cpp')):
+            h.update(name.encode())
+            with open(os.path.join(d, name), 'rb') as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+TRAFFIC_FILES = ('r04_traffic_bench.json', 'r03_traffic_bench.json')
+
+
 def pmc_traffic(arch, family, batch):
     """HBM bytes per launch of a kernel family from committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
     passes, gfx950 correction 2 x FETCH_SIZE + WRITE_SIZE).  First choice: profiles/r03_traffic_bench.json -- the passes ran over
@@ -187,15 +204,21 @@ def pmc_traffic(arch, family, batch):
     VGG16, the round-2 passes over one launch of each conv of a pass (profiles/r02_traffic.json).  None when neither applies."""
     if batch != 256:                 # every committed pass ran at the bench's default batch
         return None
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r03_traffic_bench.json')) as f:
-            fam = json.load(f)['archs'][arch]['families'][family]
-        return {'hbm_bytes_per_launch': round(fam['hbm_bytes_per_launch_corrected']),
-                'fetch_size_bytes_per_launch': round(fam['fetch_size_bytes_per_launch']),
-                'write_size_bytes_per_launch': round(fam['write_size_bytes_per_launch']),
-                'launches_counted': fam['launches'], 'source': 'profiles/r03_traffic_bench.json'}
-    except (OSError, KeyError, ValueError):
-        pass
+    for fname in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, 'profiles', fname)) as f:
+                doc = json.load(f)
+            fam = doc['archs'][arch]['families'][family]
+            stamp = doc.get('csrc_sha256')
+            return {'hbm_bytes_per_launch': round(fam['hbm_bytes_per_launch_corrected']),
+                    'fetch_size_bytes_per_launch': round(fam['fetch_size_bytes_per_launch']),
+                    'write_size_bytes_per_launch': round(fam['write_size_bytes_per_launch']),
+                    'launches_counted': fam['launches'], 'source': 'profiles/' + fname,
+                    'measured_at_commit': doc.get('commit'), 'measured_on_csrc_sha256': stamp,
+                    # the kernels changed since the counters were collected (or the file carries no digest): the bytes are history
+                    'stale': stamp != csrc_digest()}
+        except (OSError, KeyError, ValueError):
+            continue
     if arch != 'vgg16':
         return None
     for name in ('r02_traffic.json', 'r01_traffic.json'):
@@ -228,8 +251,8 @@ def build_model(device, arch='vgg16'):
     return net.to(device)
 
 
-def make_args(mode, freq, width=1.0):
-    return types.SimpleNamespace(mode=mode, dataset=DATASET, finetune_again=False, target_sparsity=0.1,
+def make_args(mode, freq, width=1.0, finetune_again=False):
+    return types.SimpleNamespace(mode=mode, dataset=DATASET, finetune_again=finetune_again, target_sparsity=0.1,
                                  initial_sparsity=0.0, pruning_frequency=freq, weight_decay=4e-5,
                                  network_width_multiplier=width, cuda=True, log_path=None, progress=False)
 
@@ -260,10 +283,34 @@ def cycle_plan(steps):
     return A, f
 
 
-def run_cycle(model, masks, pool, val_pool, steps, clock=None, marks=None, counts=None):
-    """The K-step task-1 cycle.  Returns number of train steps executed.  `marks` collects (label, steps, event) at the
+def make_optimizers(model, pruner, lr, lr_mask=None):
+    """SGD-nesterov over everything but the piggymasks and the other tasks' heads, the masked weights through the fused routing +
+    step pass (CPG_cifar100_main_normal.py:320-341); from task 2 on also Adam(lr_mask) over the piggymasks (:342-346), through
+    MaskedAdam's fused routing + step pass.  lr_mask None = task 1 (no piggymask exists)."""
+    root = model.module if hasattr(model, 'module') else model
+    idx = root.datasets.index(DATASET)
+    sgd_params, adam_params = [], []
+    for name, p in model.named_parameters():
+        if 'classifiers' in name:
+            if '.%d.' % idx in name:
+                sgd_params.append(p)
+        elif 'piggymask' in name:
+            adam_params.append(p)
+        else:
+            sgd_params.append(p)
+    o = Optimizers()
+    o.add(MaskedSGD(sgd_params, pruner=pruner, lr=lr, momentum=0.9, nesterov=True), lr)
+    if lr_mask is not None and adam_params:
+        o.add(MaskedAdam(adam_params, pruner=pruner, lr=lr_mask), lr_mask)
+    return o
+
+
+def run_cycle(model, masks, pool, val_pool, steps, clock=None, marks=None, counts=None, task=1):
+    """The K-step CPG cycle of one task.  Returns number of train steps executed.  `marks` collects (label, steps, event) at the
     phase boundaries (events only -- no synchronisation inside the timed region); `counts` receives the number of
-    validates and rank-prune events that actually ran."""
+    validates and rank-prune events that actually ran.  task >= 2: the same cycle with a piggymask on every masked layer --
+    finetune with Adam(lr_mask 5e-4) on the piggymasks, the prune run with lr_mask 0 (experiment1/CPG_cifar100_scratch_mul_1.5.sh:
+    39,57,116), `shared_ratio` in every validate batch (utils/manager.py:130-135, utils/prune.py:180-193)."""
     A, f = cycle_plan(steps)
     window = 4 * f
     done = 0
@@ -279,12 +326,8 @@ def run_cycle(model, masks, pool, val_pool, steps, clock=None, marks=None, count
     def loader(n, offset):
         return [pool[(offset + i) % len(pool)] for i in range(n)]
 
-    def sgd(lr, pruner):
-        # SGD-nesterov of CPG_cifar100_main_normal.py:339-340; the masked weights take the fused routing + step pass
-        opt = MaskedSGD([p for p in model.parameters()], pruner=pruner, lr=lr, momentum=0.9, nesterov=True)
-        o = Optimizers()
-        o.add(opt, lr)
-        return o
+    def sgd(lr, pruner, lr_mask):
+        return make_optimizers(model, pruner, lr, lr_mask if task > 1 else None)
 
     def chunks(n_phase):
         """split a phase's steps at the global every-20th-step validate points: yields (n_steps, validate_after)"""
@@ -299,7 +342,7 @@ def run_cycle(model, masks, pool, val_pool, steps, clock=None, marks=None, count
     # phase A: finetune (free slots claimed by task 1)
     mgr = Manager(make_args('finetune', f), model, {}, masks, None, val_pool, 0, 0)
     mgr.pruner.make_finetuning_mask()
-    opt = sgd(1e-2, mgr.pruner)
+    opt = sgd(1e-2, mgr.pruner, 5e-4)
     epoch = 0
     for n, val in list(chunks(A)):
         mgr.train_loader = loader(n, done)
@@ -315,7 +358,7 @@ def run_cycle(model, masks, pool, val_pool, steps, clock=None, marks=None, count
     events = 0
     if steps - done > 0:
         mgrB = Manager(make_args('prune', f), model, {}, masks, None, val_pool, 0, window)
-        opt = sgd(1e-3, mgrB.pruner)
+        opt = sgd(1e-3, mgrB.pruner, 0.0)
         step = 0
         for n, val in list(chunks(steps - done)):
             # keep window and recovery steps in separate marks
@@ -335,6 +378,56 @@ def run_cycle(model, masks, pool, val_pool, steps, clock=None, marks=None, count
     if counts is not None:
         counts.update(validates=n_val, prune_events=events, finetune_steps=A, prune_frequency=f, prune_window_steps=window)
     return done
+
+
+def begin_task2(model, masks, arch, device):
+    """Turn the resident network into the starting state of task 2 (what the reference reads back from task 1's final checkpoint,
+    CPG_cifar100_main_normal.py:196-290): every slot owned by task 1 except the 30 % smallest-magnitude weights of each layer, which
+    are free and zero (a finished gradual-prune sweep to 0.3: utils/prune.py:30-53 + make_pruned_zero), a new head, and a
+    piggymask `full(0.01)` on every masked layer (:263-270).  Phase A's make_finetuning_mask then hands the free slots to task 2."""
+    global DATASET
+    root = model.module if hasattr(model, 'module') else model
+    for m in masks.values():
+        m.fill_(1)
+    pr = SparsePruner(model, masks, make_args('prune', 1), 0, 1, 1)
+    pr._rank_prune_layers(0.3)
+    pr.make_pruned_zero()
+    free = sum(int((m == 0).sum()) for m in masks.values()) / float(sum(m.numel() for m in masks.values()))
+    root.add_dataset(arch['dataset2'], arch['classes2'])
+    root.set_dataset(arch['dataset2'])
+    root.classifiers.to(device)
+    DATASET = arch['dataset2']
+    fresh_piggymasks(model, masks)
+    return free
+
+
+def fresh_piggymasks(model, masks):
+    root = model.module if hasattr(model, 'module') else model
+    prefix = 'module.' if hasattr(model, 'module') else ''
+    for name, m in root.named_modules():
+        if isinstance(m, (nl.SharableConv2d, nl.SharableLinear)):
+            m.piggymask = nn.Parameter(torch.full_like(masks[prefix + name], 0.01, dtype=torch.float32))
+    if hasattr(model, 'refresh_hooks'):
+        model.refresh_hooks()
+
+
+def finetune_again_leg(model, masks, pool, val_pool, steps):
+    """The piggymask retrain that ends every task >= 2 (`--mode finetune --finetune_again`, lr 1e-3, lr_mask 1e-4, fresh
+    piggymasks: experiment1/CPG_cifar100_scratch_mul_1.5.sh:189-206, CPG_cifar100_main_normal.py:272-279,386-388): a validate
+    first (:391-393), then `steps` train steps -- no slot changes owner, weights of the task and the picker over older tasks' learn."""
+    fresh_piggymasks(model, masks)
+    mgr = Manager(make_args('finetune', 1, finetune_again=True), model, {}, masks, [pool[i % len(pool)] for i in range(2)], val_pool, 0, 0)
+    opt = make_optimizers(model, mgr.pruner, 1e-3, 1e-4)
+    validate(mgr, -1)
+    mgr.train(opt, 0, [1e-3, 1e-4], 0)                     # warm (Adam state allocation)
+    mgr.train_loader = [pool[i % len(pool)] for i in range(steps)]
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    mgr.train(opt, 0, [1e-3, 1e-4], 0)
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / steps
 
 
 def phase_report(marks, model, masks, batch):
@@ -394,75 +487,131 @@ def optin_modes(model, masks, pool, steps, batch):
     return res
 
 
-def cpu_baseline(budget_s=45.0, steps=220, batch=256, validates=11, prune_events=4, cpu_batch=64):
-    """Oracle ("port") of the same cycle on the host cores: a bounded sample of each ingredient -- >= 3 timed train
-    steps, one rank-prune event over all 15 layers, one validate batch -- extrapolated to the cycle the GPU ACTUALLY ran (K train
-    steps of `batch` images, the counted prune events and validates of 2 x 100 images), reported beside the GPU number (never
-    the target).  oracle/ is only ever used here as the measured CPU baseline.  The train steps are timed under BOTH thread
-    settings -- torch's default for the host (one per physical core) and SURVEY 8d's os.cpu_count() (every SMT thread) -- and
-    `value` uses the faster; the images come from the same seeded N(0,1) / randint generator as the GPU run's (on the CPU
-    generator).  cpu_batch < batch because a 256 x 224 x 224 step is ~1 minute: the deviation is a field, not prose."""
+def cpu_plumbing_cycle(steps=220, batch=32):
+    """BASELINE.json configs[0] / BASELINE.md section 4: the reference's own CPU-runnable case -- `custom_vgg_cifar100` (VGG16-BN at
+    32 x 32, full width), batch 32, the WHOLE section-8d mini-cycle on the host through the oracle: 20 finetune steps (lr 1e-2), a
+    200-step prune run 0 -> 0.1 (rank-prune events at steps 10 / 20 / 30 / 40, lr 1e-3), apply_mask + 2 eval batches of 100 + the
+    sparsity statistic after every 20 steps.  Returns (images/sec, seconds, prune events, validates)."""
+    from oracle import net as onet
+    from oracle import ops as oops
+    model, pruner, opt = onet.make_task1(1.0, 'cifar100', 'finetune', lr=1e-2, wd=4e-5)
+    g = torch.Generator().manual_seed(1)
+    pool = [(torch.randn(batch, 3, 32, 32, generator=g), torch.randint(0, 5, (batch,), generator=g)) for _ in range(3)]
+    val = [torch.randn(100, 3, 32, 32, generator=g) for _ in range(2)]
+    A, f = cycle_plan(steps)
+    events = validates = 0
+    t0 = time.time()
+    for step in range(steps):
+        if step == A:                                      # the prune run: same owner index, new schedule, lr 1e-3
+            pruner.mode, pruner.begin, pruner.end, pruner.frequency = 'prune', 0, 4 * f, f
+            pruner.initial, pruner.target, pruner.last_prune_step = 0.0, 0.1, 0
+            opt = torch.optim.SGD(list(model.parameters()), lr=1e-3, momentum=0.9, nesterov=True)
+        model.train()
+        x, t = pool[step % len(pool)]
+        before = pruner.last_prune_step
+        onet.train_step(model, pruner, opt, x, t, prune_step=step - A if step >= A else None, torch_routing=True)
+        events += int(step >= A and pruner.last_prune_step != before)
+        pruner.sparsity()
+        if (step + 1) % EPOCH_STEPS == 0:
+            pruner.apply_mask()
+            model.eval()
+            with torch.no_grad():
+                for v in val:
+                    model(v)
+                    pruner.sparsity()
+                    oops.zero_ratio([pruner.owners[n] for n, _ in model.masked_layers()], 1.0)
+            validates += 1
+    dt = time.time() - t0
+    return steps * batch / dt, dt, events, validates
+
+
+def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch=64, level='full'):
+    """Oracle ("port") of the same cycle on the host cores, reported beside the GPU number (never the target).
+    oracle/ is only ever used here as the measured CPU baseline.
+
+    1. Thread setting: >= 3 timed train steps at `probe_batch` under BOTH settings -- torch's default for the host (one thread per
+       physical core) and SURVEY 8d's os.cpu_count() (every SMT thread); the faster is used below, both rates are fields.
+    2. level 'full' (default): 3 timed train steps (after one warm-up step) at the GPU's own batch (256) under that setting -- section
+       8d's configuration, no batch extrapolation; `value` is built on this rate.  level 'quick': step 2 is skipped and the probe
+       rate is used (`extrapolated_from_probe_batch`: true).
+    3. One rank-prune event over all 15 layers, one validate batch of 100 (apply_mask + eval forward).
+    4. level 'full': BASELINE.md section 4's plumbing leg -- configs[0] (32 x 32, batch 32) through the whole mini-cycle on the host
+       (`plumbing`).
+    value = the cycle the GPU ACTUALLY ran (K train steps of `batch` images, its counted prune events and validates of 2 x 100
+    images) priced with those CPU times.  Images come from the same seeded N(0,1) / randint generator as the GPU run's."""
     from oracle import net as onet
     from oracle import ops as oops
     default_threads = torch.get_num_threads()
     all_threads = os.cpu_count() or default_threads
-    b = cpu_batch
     model, pruner, opt = onet.make_task1(1.0, 'imagenet', 'finetune', lr=1e-2, wd=4e-5)
     model.train()
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(b, 3, 224, 224, generator=g)
-    t = torch.randint(0, 5, (b,), generator=g)
+    xfull = torch.randn(batch, 3, 224, 224, generator=g)
+    tfull = torch.randint(0, 5, (batch,), generator=g)
+    x, t = xfull[:probe_batch].contiguous(), tfull[:probe_batch].contiguous()
 
-    def timed_steps(threads, min_steps=3, max_steps=6, budget=budget_s / 2):
-        torch.set_num_threads(threads)
-        onet.train_step(model, pruner, opt, x, t, torch_routing=True)      # warm-up (allocations, primitive cache)
+    def timed_steps(xb, tb, n, warm=True):
+        if warm:
+            onet.train_step(model, pruner, opt, xb, tb, torch_routing=True)      # allocations, primitive cache
         t0 = time.time()
-        n = 0
-        while n < min_steps or (time.time() - t0 < budget and n < max_steps):
-            onet.train_step(model, pruner, opt, x, t, torch_routing=True)
-            n += 1
-            if n >= 1 and time.time() - t0 > 4 * budget:                  # a pathological setting: report what was measured
-                break
-        return n, time.time() - t0
+        for _ in range(n):
+            onet.train_step(model, pruner, opt, xb, tb, torch_routing=True)
+        return time.time() - t0
 
     settings = {}
-    for name, threads in (('default', default_threads), ('cpu_count', all_threads)):
+    for i, (name, threads) in enumerate((('default', default_threads), ('cpu_count', all_threads))):
         if name == 'cpu_count' and threads == default_threads:
             settings[name] = dict(settings['default'])
             continue
-        n, dt = timed_steps(threads)
-        settings[name] = {'threads': threads, 'train_steps_timed': n, 'seconds': round(dt, 2), 'train_images_per_sec': round(b * n / dt, 3)}
+        torch.set_num_threads(threads)
+        dt = timed_steps(x, t, 3, warm=(i == 0))
+        settings[name] = {'threads': threads, 'train_steps_timed': 3, 'seconds': round(dt, 2), 'train_images_per_sec': round(probe_batch * 3 / dt, 3)}
     best = max(settings, key=lambda k: settings[k]['train_images_per_sec'])
     threads = settings[best]['threads']
     torch.set_num_threads(threads)
-    train_ips = settings[best]['train_images_per_sec']
+    probe_ips = settings[best]['train_images_per_sec']
+    full = None
+    if level == 'full':
+        dt = timed_steps(xfull, tfull, 3, warm=True)
+        full = {'batch': batch, 'threads': threads, 'train_steps_timed': 3, 'seconds': round(dt, 2), 'train_images_per_sec': round(batch * 3 / dt, 3)}
+    train_ips = full['train_images_per_sec'] if full else probe_ips
     # one rank-prune event (utils/prune.py:30-53 on every masked layer: boolean gather + k-th value + masked assign)
     t0 = time.time()
     for name, m in model.masked_layers():
         pruner.owners[name], _, _ = oops.rank_prune(m.weight.data.numpy(), pruner.owners[name], pruner.cur, 0.05)
     prune_s = time.time() - t0
-    # one validate batch (apply_mask + eval forward)
+    # one validate batch of 100 (apply_mask + eval forward)
     model.eval()
+    xv = xfull[:100].contiguous()
     t0 = time.time()
     pruner.apply_mask()
     with torch.no_grad():
-        model(x)
+        model(xv)
     val_s = time.time() - t0
+    del model, pruner, opt
+    plumbing = None
+    if level == 'full':
+        ips, secs, ev, nv = cpu_plumbing_cycle()
+        plumbing = {'workload': 'configs[0]: custom_vgg_cifar100 (VGG16-BN 32x32, full width), batch 32, the full 220-step mini-cycle '
+                                '(20 finetune + 200 prune-run steps, %d rank-prune events, %d validates of 2 x 100 images) on the host' % (ev, nv),
+                    'value': round(ips, 2), 'unit': 'images/sec', 'seconds': round(secs, 1), 'cores': threads, 'kind': 'port'}
     torch.set_num_threads(default_threads)
-    cycle_s = steps * batch / train_ips + prune_events * prune_s + validates * 200 * (val_s / b)
+    cycle_s = steps * batch / train_ips + prune_events * prune_s + validates * 2 * val_s
     return {'value': round(steps * batch / cycle_s, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
             'threads_default': default_threads, 'threads_cpu_count': all_threads, 'threads_used_for_value': threads,
             'train_images_per_sec_default_threads': settings['default']['train_images_per_sec'],
             'train_images_per_sec_cpu_count_threads': settings['cpu_count']['train_images_per_sec'],
             'train_steps_timed': {k: v['train_steps_timed'] for k, v in settings.items()},
-            'cpu_batch': b, 'gpu_batch': batch, 'extrapolated': True,
-            'train_images_per_sec': round(train_ips, 3), 'prune_event_s': round(prune_s, 2), 'validate_images_per_sec': round(b / val_s, 2),
-            'sample': '%d + %d train steps (fwd + bwd + gradient routing + SGD-nesterov) at %d / %d threads + 1 rank-prune event over the 15 '
-                      'layers (%.1f s) + 1 validate batch (apply_mask + eval forward, %.1f s) of the oracle VGG16-BN 224x224 at batch %d, '
-                      'torch-CPU fp32; value = the %d-step cycle the GPU ran (%d prune events, %d validates of 200 images) extrapolated '
-                      'from the faster thread setting'
-                      % (settings['default']['train_steps_timed'], settings['cpu_count']['train_steps_timed'], default_threads, all_threads,
-                         prune_s, val_s, b, steps, prune_events, validates)}
+            'probe_batch': probe_batch, 'gpu_batch': batch, 'full_batch_sample': full, 'extrapolated_from_probe_batch': full is None,
+            'train_images_per_sec': round(train_ips, 3), 'prune_event_s': round(prune_s, 2), 'validate_images_per_sec': round(100 / val_s, 2),
+            'plumbing': plumbing,
+            'sample': '3 + 3 train steps (fwd + bwd + gradient routing + SGD-nesterov) at batch %d under %d / %d threads%s + 1 rank-prune event '
+                      'over the 15 layers (%.1f s) + 1 validate batch of 100 (apply_mask + eval forward, %.1f s) of the oracle VGG16-BN 224x224, '
+                      'torch-CPU fp32; value = the %d-step cycle the GPU ran (%d prune events, %d validates of 2 x 100 images) priced with the '
+                      '%s train rate'
+                      % (probe_batch, default_threads, all_threads,
+                         (', then 1 warm-up + 3 timed train steps at batch %d under %d threads' % (batch, threads)) if full else '',
+                         prune_s, val_s, steps, prune_events, validates, 'batch-%d' % batch if full else 'probe-batch')}
 
 
 # ---- 8-GPU prediction (DESIGN.md section 6): what a SCALE run should show, so that a first hardware run can be judged in one read
@@ -506,6 +655,14 @@ def main():
     ap.add_argument('--steps', type=int, default=220, help='timed train steps (220 = the full section-8d cycle)')
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (config 2: 256)')
+    ap.add_argument('--global-batch', type=int, default=0,
+                    help="STRONG scaling, the reference's own data-parallel split (CPG_cifar100_main_normal.py:112-114,199: the batch "
+                         'is NOT scaled with the GPUs): this many images per step over all ranks, per-GPU batch = global / N; overrides '
+                         '--batch and reports "scaling": "strong"')
+    ap.add_argument('--task', type=int, default=1, choices=[1, 2],
+                    help='1 = the headline (task 1: no piggymask).  2 = the cycle 19 of the 20 tasks of configs[1] run: owner masks of a '
+                         'finished task 1 (30 %% of every layer free), a piggymask on every masked layer, SGD + Adam(lr_mask); its own line, '
+                         'never the headline; also times a task-1 cycle of the same length in the same process (task1_ms_per_step)')
     ap.add_argument('--arch', default='vgg16', choices=sorted(ARCHS),
                     help="topology of the cycle: 'vgg16' = the headline (BASELINE.json configs[1]); 'resnet50' / 'spherenet20' = the "
                          'topologies of configs[3] / configs[4] through the same cycle (their own lines, never the headline)')
@@ -516,6 +673,9 @@ def main():
                     help='after the timed cycle, also time this many train steps in each opt-in conv arithmetic (reported beside the '
                          'headline as opt_in_conv_math, never as value); 0 = skip')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline', default='full', choices=['full', 'quick'],
+                    help="'full' (default, ~6 min of host time): SURVEY 8d's CPU baseline -- 3 train steps at batch 256 on the faster thread "
+                         "setting + BASELINE.md section 4's configs[0] plumbing cycle; 'quick': the batch-64 probe only (~1.5 min)")
     ap.add_argument('--no-kernel-clock', action='store_true')
     a = ap.parse_args()
 
@@ -528,6 +688,10 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if a.global_batch:
+        if a.global_batch % a.gpus:
+            sys.exit('bench.py: --global-batch %d is not divisible by --gpus %d' % (a.global_batch, a.gpus))
+        a.batch = a.global_batch // a.gpus
     if world != a.gpus:
         sys.exit('bench.py: --gpus %d but WORLD_SIZE is %d; launch with torch.distributed.run --nproc-per-node %d '
                  '(or plain `python bench.py --gpus %d`, which re-launches itself)' % (a.gpus, world, a.gpus, a.gpus))
@@ -594,11 +758,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    task1_ms = free_share = None
+    if a.task == 2:
+        # the comparison leg: a task-1 cycle of the same length in this process (its own barrier-bracketed clock, kernels not clocked)
+        barrier()
+        t1 = time.perf_counter()
+        run_cycle(model, masks, pool, val_pool, a.steps)
+        barrier()
+        task1_ms = 1000.0 * (time.perf_counter() - t1) / a.steps
+        free_share = begin_task2(model, masks, arch, device)
+        # warm the task-2 kernels (pack passes with the binarizer, piggymask-gradient epilogues, fused Adam) on a copy of the masks
+        wm = Manager(make_args('finetune', 1), model, {}, {k: v.clone() for k, v in masks.items()},
+                     [pool[i % len(pool)] for i in range(max(1, min(2, a.warmup)))], val_pool, 0, 0)
+        wm.pruner.make_finetuning_mask()
+        wm.train(make_optimizers(model, wm.pruner, 0.0, 0.0), 0, [0.0, 0.0], 0)
+        validate(wm, 0)
+        del wm
+        if model.sync_events is not None:
+            model.sync_events = []
+        settle_host_gc()
+
     barrier()
     clock.enabled = True
     t0 = time.perf_counter()
     marks, counts = [], {}
-    done = run_cycle(model, masks, pool, val_pool, a.steps, clock, marks, counts)
+    done = run_cycle(model, masks, pool, val_pool, a.steps, clock, marks, counts, task=a.task)
     barrier()
     dt_local = dt = time.perf_counter() - t0
     clock.enabled = False
@@ -623,15 +807,20 @@ def main():
         A, f = cycle_plan(a.steps)
         metric = ('images/sec per CPG train-prune-retrain cycle, VGG16 task-1' if a.arch == 'vgg16' else
                   'images/sec per CPG train-prune-retrain cycle, %s (NOT the headline metric: the same cycle on another topology)' % a.arch)
+        if a.task != 1:
+            metric = ('images/sec per CPG train-prune-retrain cycle, %s task-%d (NOT the headline metric: the cycle of tasks >= 2 -- a piggymask '
+                      'on every masked layer, SGD + Adam)' % (a.arch, a.task))
+        if a.batch != 256 and a.task == 1 and a.arch == 'vgg16':
+            metric += ' (NOT the headline configuration: %d images per GPU instead of 256)' % a.batch
         out = {'metric': metric, 'value': round(value, 2),
                'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-               'ms_per_step': round(1000.0 * dt / a.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+               'ms_per_step': round(1000.0 * dt / a.steps, 3), 'higher_is_better': True, 'scaling': 'strong' if a.global_batch else 'weak',
                'vs_baseline': None, 'data': 'synthetic',
                'dtype': 'f32' if a.math == 'fp32' else
                ('bf16 operands' if a.math == 'bf16' else 'bf16x3 (two-term bf16 split of every operand, 3 MFMAs per product)')
                + ' / f32 accumulate in the 3x3 convolutions (OPT-IN, not the headline); stem, linear layers, BatchNorm, optimizer f32',
-               'config': {'workload': '%s, task-1 CPG cycle (finetune -> prune 0.0->0.1 -> recovery, validate after every 20th train '
-                                      'step), batch %d per GPU' % (arch['workload'], a.batch),
+               'config': {'workload': '%s, task-%d CPG cycle (finetune -> prune 0.0->0.1 -> recovery, validate after every 20th train '
+                                      'step), batch %d per GPU' % (arch['workload'], a.task, a.batch), 'task': a.task,
                           'arch': a.arch, 'global_batch': global_batch, 'per_gpu_batch': a.batch, 'parallelism': 'dp%d' % world,
                           'epoch_steps': EPOCH_STEPS, 'cycle': counts,
                           'host_gc': 'collected + frozen after the warm-up (cpg_amd.utils.settle_host_gc, as CPGSession.start_task)'},
@@ -683,6 +872,7 @@ def main():
                                'traffic': (traffic or {}).get('hbm_bytes_per_launch'),
                                'traffic_source': 'static: %s (rocprofv3 --pmc passes of this workload, committed; not collected in this run)'
                                                  % traffic['source'] if traffic else None,
+                               'traffic_stale': traffic['stale'] if traffic and 'stale' in traffic else None,
                                'traffic_detail': traffic,
                                # SURVEY 8d's bytes: each launch reads two of {x, y or gy, W} once and writes the third once
                                'algorithmic_bytes_per_launch': round(nb / cnt),
@@ -713,12 +903,20 @@ def main():
                 out['kernel_detail'] = {k: {'n': v[0], 'ms': round(v[1], 2), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2), 'winograd': v[3] < v[2]}
                                         for k, v in sorted(agg.items())}
         out['phases'] = phase_report(marks, model, masks, a.batch)
-        if a.math == 'fp32' and world == 1 and a.optin_steps > 0 and a.arch == 'vgg16':
+        if a.task == 2:
+            again_ms = finetune_again_leg(model, masks, pool, val_pool, max(2, min(a.steps, 10)))
+            out['task2'] = {'task1_ms_per_step': round(task1_ms, 3), 'task2_over_task1': round(1000.0 * dt / a.steps / task1_ms, 4),
+                            'free_share_handed_to_task2': round(free_share, 4), 'lr_mask_finetune': 5e-4, 'lr_mask_prune': 0.0,
+                            'finetune_again_ms_per_step': round(again_ms, 3),
+                            'note': 'task1_ms_per_step = the task-1 cycle of the same K in the same process, before the switch; the timed '
+                                    'region is the task-2 cycle alone; finetune_again = the piggymask retrain leg (lr 1e-3, lr_mask 1e-4, '
+                                    'fresh piggymasks), train steps only, timed after the cycle'}
+        if a.math == 'fp32' and world == 1 and a.optin_steps > 0 and a.arch == 'vgg16' and a.task == 1 and a.batch == 256:
             out['opt_in_conv_math'] = optin_modes(model, masks, pool, a.optin_steps, a.batch)
         if not a.no_cpu_baseline and world == 1:
-            if a.arch == 'vgg16':
+            if a.arch == 'vgg16' and a.task == 1:
                 out['cpu_baseline'] = cpu_baseline(steps=a.steps, batch=a.batch, validates=counts['validates'],
-                                                   prune_events=counts['prune_events'])
+                                                   prune_events=counts['prune_events'], level=a.cpu_baseline)
             else:
                 out['cpu_baseline'] = None      # oracle/net.py restates the VGG16 cycle only (the headline); see --arch vgg16
         print(json.dumps(out), flush=True)

@@ -14,6 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CPG_HIP_LIB') or os.path.join(_HERE, 'lib', 'libcpg_hip.so')   # override: A/B kernel experiments
 
+ABI_VERSION = 2         # include/cpg_hip.h: CPG_ABI_VERSION
 CPG_OK = 0
 CPG_E_KRANGE = 2
 MODE_FINETUNE = 0
@@ -40,6 +41,9 @@ assert PRUNE_RESULT_BYTES == 32
 _SIGNATURES = {
     'cpg_version': (ctypes.c_int, []),
     'cpg_set_shared_chip_hint': (ctypes.c_int, [ctypes.c_int32]),
+    'cpg_get_shared_chip_hint': (ctypes.c_int32, []),
+    'cpg_set_option': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32]),
+    'cpg_get_option': (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32)]),
     'cpg_last_error': (ctypes.c_char_p, []),
     'cpg_binarize_mask_weight': (ctypes.c_int, [_vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, _vp]),
     'cpg_conv2d_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
@@ -65,8 +69,8 @@ _SIGNATURES = {
     'cpg_unpack_owned': (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _vp, _vp, _vp]),
     'cpg_sgd_route_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _vp]),
-    'cpg_adam_route_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
-                                           ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_int64, _vp]),
+    'cpg_adam_route_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.c_int64, _vp]),
     'cpg_bn_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'cpg_bn_relu_fwd_train': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp,
                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
@@ -150,8 +154,8 @@ def lib():
             fn = getattr(handle, name)      # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if handle.cpg_version() != 1:
-            raise RuntimeError('cpg_amd: ABI version mismatch (library %d, binding 1)' % handle.cpg_version())
+        if handle.cpg_version() != ABI_VERSION:
+            raise RuntimeError('cpg_amd: ABI version mismatch (library %d, binding %d)' % (handle.cpg_version(), ABI_VERSION))
         _lib = handle
     return _lib
 
@@ -160,6 +164,41 @@ def check(fn_name, code):
     if code != CPG_OK:
         text = lib().cpg_last_error()
         raise CpgHipError(fn_name, code, text.decode(errors='replace') if text else '')
+
+
+OPT_UNSET = -(1 << 31)
+_WINO_KERNEL = {'block': 0, 'wave': 1, 'pair': 2, '64': 3}
+
+
+def get_option(name):
+    """Current value of a library switch (include/cpg_hip.h: cpg_get_option); None when it was never given."""
+    v = ctypes.c_int32(0)
+    check('cpg_get_option', lib().cpg_get_option(name.encode(), ctypes.byref(v)))
+    return None if v.value == OPT_UNSET else v.value
+
+
+def set_option(name, value):
+    """Set (value None: unset) a library switch through the C ABI.  The table is filled from the environment once, at load time; this is
+    the only way to change it afterwards.  CPG_WINO_KERNEL also takes its environment spelling ('block' | 'wave' | 'pair' | '64')."""
+    if isinstance(value, str):
+        value = _WINO_KERNEL[value] if name == 'CPG_WINO_KERNEL' else int(value)
+    check('cpg_set_option', lib().cpg_set_option(name.encode(), OPT_UNSET if value is None else int(value)))
+
+
+class option(object):
+    """`with option('CPG_NO_WINO', 1): ...` -- a library switch for the duration of a block (tests, A/B tools)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
 
 
 def stream_ptr():

@@ -532,7 +532,7 @@ extern "C" int cpg_bn_relu_bwd(const float *x, const float *gy, const float *gam
 // backward of out = relu(bn(x) + res) (cpg_bn_add_relu_fwd; models/resnet.py:62-71,96-104): gz = gy * [out > 0] is the gradient of
 // the residual branch AND of bn(x); one pass reads x, gy, out, writes gz and reduces {sum gz, sum gz * xhat}, the second applies
 // the BatchNorm gradient from x and gz -- 7 activation passes where threshold_backward + cpg_bn_relu_bwd made 8 (and one launch
-// of a stock elementwise kernel less).  gz may alias gy.
+// of a stock elementwise kernel less).  gz must NOT alias gy (the kernel declares both __restrict__).
 extern "C" int cpg_bn_add_relu_bwd(const float *x, const float *out, const float *gy, const float *gamma, const float *beta,
                                    const float *mean, const float *invstd, float *gx, float *gz, float *dgamma, float *dbeta, int32_t N,
                                    int32_t C, int32_t HW, int32_t train, void *ws, size_t ws_bytes, void *stream_v) {
@@ -804,7 +804,7 @@ __device__ __forceinline__ int pool3_argmax(const float *zs, const Pool3Dims &p,
             const int w = 2 * pw - 1 + q;
             if ((unsigned)w >= (unsigned)p.W) continue;
             const float v = zs[(h - h0) * p.W + w];
-            if (v > best) best = v, arg = h * p.W + w;
+            if (v > best || v != v) best = v, arg = h * p.W + w;      // (a NaN wins and stays: torch's max_pool2d propagates it)
         }
     }
     if (best_out) *best_out = best;

@@ -1182,8 +1182,8 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
         bn = &bn_local;
     }
     C3Geom g{N, c_read, H, W, m, Mp, 0, 0, 0, H, W, dgrad ? 1 : 0, 1};
-    if (const char *f = getenv("CPG_C3_FORCE")) {        // A/B experiments only (tools/conv_bench.py --ab)
-        switch (atoi(f)) {
+    if (const int force = opt(OPT_C3_FORCE); force != OPT_UNSET) {        // A/B experiments only (tools/conv_bench.py --ab)
+        switch (force) {
             case 0: return launch_fwd<CfgM128>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
             case 1: return launch_fwd<CfgM64>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
             case 2: return launch_fwd<CfgS16>(g, x, wp, bias, y, stream, what, stats, tiles_out, dry, bn, bb);
@@ -1199,7 +1199,7 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
     // tile alone measured the same, because its N*14/16 tiles put 3.5 block-equivalents on each CU, which rounds up to 4
     // (at batch 256 the layer is too small for 256 CUs).  Halving the blocks (two per tile, each half of the channel chunks,
     // atomically added into a zeroed y) makes it 7 half-blocks per CU.
-    if (W == 14 && H == 14 && m > 64 && c_read % 8 == 0 && bn == nullptr && !getenv("CPG_NO_V14")) {
+    if (W == 14 && H == 14 && m > 64 && c_read % 8 == 0 && bn == nullptr && !opt_on(OPT_NO_V14)) {
         // ... when that balances: per-CU MFMA time in block-equivalents of either tiling (the split pays a memset, atomics
         // and a second prologue; at 256 channels and batch 256 -- 3.5 half-blocks per CU -- it measured no gain)
         const int tm = (m + 127) / 128;
@@ -1226,7 +1226,7 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
 }  // namespace
 
 extern "C" int cpg_conv3x3_supported(const cpg_conv_desc *d) {
-    if (getenv("CPG_DISABLE_CONV3X3")) return 0;
+    if (cpg::opt_on(cpg::OPT_DISABLE_CONV3X3)) return 0;
     return d->R == 3 && d->S == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1 &&
            d->dil_h == 1 && d->dil_w == 1 && d->groups == 1 && d->N > 0 && d->C > 0 && d->K > 0 && d->H > 0 && d->W > 0 &&
            // staging uses 32-bit byte offsets inside a tile's (up to two) images
@@ -1265,7 +1265,7 @@ int cpg_conv3x3_fwd_bn_eval(const cpg_conv_desc *d, const float *x, const float 
                             int32_t *skip_stats, void *ws, size_t ws_bytes, hipStream_t stream) {
     CPG_REQUIRE(x && w && y && gamma && beta && mean && var, "cpg_conv2d_fwd_bn_eval: null pointer");
     static int dummy;
-    const bool skip = getenv("CPG_NO_DEAD_SKIP") == nullptr;
+    const bool skip = !opt_on(OPT_NO_DEAD_SKIP);
     const C3BnEval bn{gamma, beta, mean, var, eps, relu, skip ? &dummy : nullptr};
     int rc = run_fwd(false, d->N, d->C, d->K, d->H, d->W, d->K, d->C, x, w, pm, thr, bias, y, ws, ws_bytes, stream, nullptr, nullptr, false,
                      &bn);
@@ -1328,7 +1328,7 @@ W3Plan w3_plan(const cpg_conv_desc *d) {
     // split blocks per CU (each split writes a full set of partial sums): 2 instead of round 2's 4 -- SphereNet-20 20.96 -> 20.78,
     // ResNet-50 73.83 -> 73.49 ms per step (A/B through CPG_C3W_BPC; 8: 21.45 / 74.11)
     int bpc = shared_chip_hint() ? 4 : 2;      // (data parallel: RCCL's kernels hold CUs -- a one-round launch would grow by a whole round)
-    if (const char *f = getenv("CPG_C3W_BPC")) bpc = std::max(1, atoi(f));
+    bpc = std::max(1, opt_or(OPT_C3W_BPC, bpc));
     int64_t want = ((int64_t)bpc * kCUs + tiles - 1) / tiles;
     if (want > units) want = units;
     if (want < 1) want = 1;
@@ -1345,7 +1345,7 @@ using W3Nar = W3Cfg<4, 16>;       // everything else that is narrow
 using W3Sev = W3Cfg<7, 8, true>;   // 7 x 7 maps: one unit = one image
 using W3Tiny = W3Cfg<2, 14, true>; // 14-wide maps whose height is not a multiple of 4 (14 x 14: zero row waste)
 inline int w3_pick(const cpg_conv_desc *d) {
-    if (getenv("CPG_W3_PICK")) return atoi(getenv("CPG_W3_PICK"));
+    if (const int pick = opt(OPT_W3_PICK); pick != OPT_UNSET) return pick;
     if (d->W <= 8 && d->H <= 7) return 4;
     if (d->W % 28 == 0 && d->W >= 112) return 0;
     if (d->W % 14 == 0) return (d->H % 4 != 0 && d->H % 2 == 0) ? 3 : 1;
@@ -1515,7 +1515,7 @@ using W3S2b = W3Cfg<4, 8, false, 1>;         // everything else (7 x 7: 8-wide t
 }  // namespace
 
 extern "C" int cpg_conv3x3s2_supported(const cpg_conv_desc *d) {
-    if (getenv("CPG_DISABLE_CONV3X3") || getenv("CPG_NO_S2")) return 0;
+    if (cpg::opt_on(cpg::OPT_DISABLE_CONV3X3) || cpg::opt_on(cpg::OPT_NO_S2)) return 0;
     return d->R == 3 && d->S == 3 && d->stride_h == 2 && d->stride_w == 2 && d->pad_h == 1 && d->pad_w == 1 && d->dil_h == 1 &&
            d->dil_w == 1 && d->groups == 1 && d->N > 0 && d->C >= 16 && d->K >= 16 && d->H > 1 && d->W > 1 &&
            (int64_t)d->C * d->H * d->W < (1ll << 27) && (int64_t)d->K * d->H * d->W < (1ll << 27) && (int64_t)d->H * d->W <= (1ll << 22);

@@ -327,9 +327,7 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
 }
 
 bool stem_geom(int N, int C, int K, int H, int W, StemGeom &g) {
-    if (const char *f = getenv("CPG_NO_STEM")) {                 // (A/B experiments, tests: any value but "0" disables)
-        if (f[0] != '0') return false;
-    }
+    if (opt_on(OPT_NO_STEM)) return false;                       // (A/B experiments, tests)
     if (N < 1 || C < 1 || C > ST_CMAX || K != 64 || H < 1 || W < 1) return false;
     if ((int64_t)N * C * H * W * 4 >= (1ll << 31) || (int64_t)K * H * W * 4 >= (1ll << 31)) return false;   // (32-bit byte offsets into x and into one image of y)
     g.N = N, g.C = C, g.K = K, g.H = H, g.W = W;
@@ -362,7 +360,7 @@ extern "C" int cpg_conv3x3_stem_run(int N, int C, int K, int H, int W, const flo
     // 12 vs 24 tiles per wave), 3-10 % faster than 3, 6 or 12 grids (the weights are re-fetched by every wave) -- and when another
     // stream (RCCL) holds some CUs, an exactly-resident grid would have to wait for its last blocks.  CPG_STEM_BLOCKS overrides (A/B).
     unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)g.ntiles + 3) / 4, 4 * kCUs);
-    if (const char *f = getenv("CPG_STEM_BLOCKS")) blocks = (unsigned)std::max(1, atoi(f));
+    blocks = (unsigned)std::max(1, opt_or(OPT_STEM_BLOCKS, (int)blocks));
     if (stats != nullptr)
         hipLaunchKernelGGL(k_stem_fwd<ST_STATS>, dim3(blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y, stats, StemBn{});
     else
@@ -374,7 +372,7 @@ extern "C" int cpg_conv3x3_stem_run(int N, int C, int K, int H, int W, const flo
 // ------------------------------------------------------------------------------ the stem fused with BatchNorm2d -> ReLU (see the header)
 namespace {
 bool stem_bn_geom(const cpg_conv_desc *d, StemGeom &g) {
-    if (getenv("CPG_NO_STEM_FUSE")) return false;
+    if (opt_on(OPT_NO_STEM_FUSE)) return false;
     if (!(d->R == 3 && d->S == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1 && d->dil_h == 1 &&
           d->dil_w == 1 && d->groups == 1))
         return false;
@@ -382,7 +380,7 @@ bool stem_bn_geom(const cpg_conv_desc *d, StemGeom &g) {
 }
 unsigned stem_blocks(const StemGeom &g) {
     unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)g.ntiles + 3) / 4, 4 * kCUs);
-    if (const char *f = getenv("CPG_STEM_BLOCKS")) blocks = (unsigned)std::max(1, atoi(f));
+    blocks = (unsigned)std::max(1, opt_or(OPT_STEM_BLOCKS, (int)blocks));
     return blocks;
 }
 }  // namespace

@@ -1750,8 +1750,7 @@ inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 // lock step behind one barrier and it measured 3-4 % SLOWER than two independent 4-wave blocks per CU on every VGG16 layer
 // (DESIGN.md section 4.9), so it is only reachable through CPG_WINO_NW=8 (A/B experiments, tests).
 inline int wino_nw(int c_read, int m) {
-    if (const char *f = getenv("CPG_WINO_NW")) return atoi(f) == 8 ? 8 : 4;
-    return 4;
+    return opt_or(OPT_WINO_NW, 4) == 8 ? 8 : 4;
 }
 
 template <int NW>
@@ -1776,10 +1775,10 @@ int wino_launch(bool dgrad, const WgGeom &g, int64_t tblocks, const float *x, co
 // odd maps (7 x 7: ResNet-50 layer4, SphereNet conv4_x): only the two-wave kernel k_wg3 has the edge handling (its ODD instances), and it
 // only pays with a long channel loop -- >= 128 channels read, >= 64 produced, no forced kernel choice
 static inline bool wino_odd_ok(int c_read, int m, int H, int W) {
-    return ((H | W) & 1) && H >= 3 && W >= 3 && c_read >= 128 && m >= 64 && getenv("CPG_WINO_KERNEL") == nullptr && getenv("CPG_NO_WINO_ODD") == nullptr;
+    return ((H | W) & 1) && H >= 3 && W >= 3 && c_read >= 128 && m >= 64 && cpg::opt(cpg::OPT_WINO_KERNEL) == cpg::OPT_UNSET && !cpg::opt_on(cpg::OPT_NO_WINO_ODD);
 }
 extern "C" int cpg_conv3x3_wino_ok(int N, int c_read, int m, int H, int W) {
-    if (getenv("CPG_NO_WINO")) return 0;
+    if (cpg::opt_on(cpg::OPT_NO_WINO)) return 0;
     if (c_read % 4 || c_read < 16 || m < 16 || N < 1) return 0;
     if (((H | W) & 1) && !wino_odd_ok(c_read, m, H, W)) return 0;
     const int tiles_img = ((H + 1) / 2) * ((W + 1) / 2);
@@ -1798,12 +1797,8 @@ extern "C" size_t cpg_conv3x3_wino_pack_bytes(int c_read, int m) {      // (the 
 // CPG_WINO_KERNEL = wave | pair | 64 | block forces k_wg1 / k_wg2 / k_wg3 / the cooperative block kernel (A/B experiments, tests).
 enum { WV_BLOCK = 0, WV_WAVE = 1, WV_PAIR = 2, WV_PAIR64 = 3 };
 static inline int wino_variant(int c_read, int m, bool stats = true) {
-    if (const char *f = getenv("CPG_WINO_KERNEL")) {
-        if (f[0] == 'b') return WV_BLOCK;
-        if (f[0] == 'p') return WV_PAIR;
-        if (f[0] == '6') return WV_PAIR64;
-        return WV_WAVE;
-    }
+    if (const int forced = cpg::opt(cpg::OPT_WINO_KERNEL); forced != cpg::OPT_UNSET)      // (block | wave | pair | 64 -> WV_*)
+        return forced >= WV_BLOCK && forced <= WV_PAIR64 ? forced : WV_WAVE;
     // (without the statistics epilogue k_wg3 already pays off at 64 channels: 64 -> 64 @224 4.89 vs 5.13 ms)
     return (c_read >= (stats ? 128 : 64) && m >= 64) ? WV_PAIR64 : WV_WAVE;
 }
@@ -1815,8 +1810,7 @@ extern "C" int cpg_debug_wg_timing(unsigned long long *dst, int n) {
 #endif
 // CPG_WINO_PERSIST=0: one block per logical block instead of the persistent grid (A/B experiments)
 static inline bool wino_persist() {
-    const char *f = getenv("CPG_WINO_PERSIST");
-    return f == nullptr || f[0] != '0';
+    return cpg::opt_or(cpg::OPT_WINO_PERSIST, 1) != 0;
 }
 
 // How many resident grids' worth of persistent blocks a launch gets: 8.  One grid (every block resident from the start, ~200 units
@@ -1825,8 +1819,7 @@ static inline bool wino_persist() {
 // kernels on the communication stream) would run its last blocks alone afterwards; with 8 the dispatcher balances whatever
 // share of the chip is free to within 1/8 of a round.  CPG_WINO_GRIDS overrides (A/B experiments).
 static inline int wino_grids() {
-    if (const char *f = getenv("CPG_WINO_GRIDS")) return std::max(1, atoi(f));
-    return 8;
+    return std::max(1, cpg::opt_or(cpg::OPT_WINO_GRIDS, 8));
 }
 
 // number of BatchNorm-statistics tiles per channel of a forward launch (stats[m][tiles][2])

@@ -312,9 +312,7 @@ void k_stem2_wgrad(Stem2Geom g, int tiles_per_split, const float *__restrict__ x
 }
 
 bool stem2_geom(const cpg_conv_desc *d, Stem2Geom &g) {
-    if (const char *f = getenv("CPG_NO_STEM")) {                 // (A/B experiments, tests: any value but "0" disables)
-        if (f[0] != '0') return false;
-    }
+    if (opt_on(OPT_NO_STEM)) return false;                       // (A/B experiments, tests)
     if (!(d->R == d->S && (d->R == 7 || d->R == 3) && d->stride_h == 2 && d->stride_w == 2 && d->pad_h == d->R / 2 && d->pad_w == d->R / 2 &&
           d->dil_h == 1 && d->dil_w == 1 && d->groups == 1))
         return false;

@@ -10,8 +10,47 @@ namespace cpg {
 // thread-local last-error text (no global mutable state shared between host threads)
 char *err_buf();
 int fail(int code, const char *fmt, ...);
-// cpg_set_shared_chip_hint() of the calling host thread (thread-local; never changes results, only split counts / grids)
+// cpg_set_shared_chip_hint(): PROCESS-wide (a std::atomic -- the weight-gradient planners that read it run on autograd's
+// engine threads, not on the thread that set it); never changes results, only split counts / grids
 int shared_chip_hint();
+
+// ---- library options -----------------------------------------------------------------------------------------------
+// Every CPG_* switch of the dispatch code lives in ONE process-wide table of atomics that is filled from the environment
+// ONCE, when the library is loaded -- no getenv() on any launch path -- and changed afterwards only through the C ABI
+// (cpg_set_option / cpg_get_option, include/cpg_hip.h).  A switch that was never given reads OPT_UNSET.
+// Boolean switches: environment text "0" or "" = off, anything else = on.  Integer switches: atoi().
+enum Opt {
+    // policy: which arithmetic / kernel family a launch may use (results stay inside the documented tolerances)
+    OPT_NO_WINO,          // CPG_NO_WINO: direct kernels instead of Winograd F(2x2,3x3) everywhere
+    OPT_NO_WINO_WGRAD,    // CPG_NO_WINO_WGRAD: ... for the weight gradient only
+    OPT_NO_WINO_ODD,      // CPG_NO_WINO_ODD: no Winograd on odd-sized maps
+    OPT_NO_STEM,          // CPG_NO_STEM: the general kernels instead of the 3-channel stem kernels
+    OPT_NO_STEM_FUSE,     // CPG_NO_STEM_FUSE: report the fused stem (conv -> BatchNorm -> ReLU) as unsupported
+    OPT_NO_DEAD_SKIP,     // CPG_NO_DEAD_SKIP: inference kernels do not skip dead channels
+    OPT_NO_S2,            // CPG_NO_S2: generic kernel for 3x3 stride-2
+    OPT_NO_V14,           // CPG_NO_V14: no channel-split tiles on 14x14 maps (direct kernels)
+    OPT_DISABLE_CONV3X3,  // CPG_DISABLE_CONV3X3 / _CONV1X1 / _CONV1X1_WGRAD / _PW_GEMM: fall to the generic implicit-GEMM kernel
+    OPT_DISABLE_CONV1X1,
+    OPT_DISABLE_CONV1X1_WGRAD,
+    OPT_DISABLE_PW_GEMM,
+    // development / A-B tuning (tools/): tile, variant and split-count overrides
+    OPT_C3_FORCE,         // CPG_C3_FORCE=n: tile configuration of k_c3_fwd
+    OPT_C3W_BPC,          // CPG_C3W_BPC=n: split blocks per CU of k_c3_wgrad
+    OPT_W3_PICK,          // CPG_W3_PICK=n: unit shape of k_c3_wgrad
+    OPT_PWW_BPC,          // CPG_PWW_BPC=n: split blocks per CU of k_pw_wgrad
+    OPT_STEM_BLOCKS,      // CPG_STEM_BLOCKS=n: persistent blocks of the stem kernels
+    OPT_WINO_KERNEL,      // CPG_WINO_KERNEL=block|wave|pair|64 -> 0|1|2|3
+    OPT_WINO_NW,          // CPG_WINO_NW=4|8
+    OPT_WINO_PERSIST,     // CPG_WINO_PERSIST=0: one block per logical block
+    OPT_WINO_GRIDS,       // CPG_WINO_GRIDS=n
+    OPT_WW_UNITS,         // CPG_WW_UNITS=n: units per wave slot of k_wgw
+    OPT_WW_XCD,           // CPG_WW_XCD=0: dispatch-order units in k_wgw
+    OPT_COUNT
+};
+constexpr int OPT_UNSET = INT32_MIN;
+int opt(Opt o);                                   // the value, or OPT_UNSET
+inline bool opt_on(Opt o) { const int v = opt(o); return v != OPT_UNSET && v != 0; }     // boolean switches
+inline int opt_or(Opt o, int dflt) { const int v = opt(o); return v == OPT_UNSET ? dflt : v; }
 
 inline int hip_status(hipError_t e, const char *what) {
     if (e == hipSuccess) return CPG_OK;

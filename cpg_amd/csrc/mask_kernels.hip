@@ -275,15 +275,15 @@ __global__ __launch_bounds__(kThreads) void k_sgd_route(float *__restrict__ w, f
 // and the routed g is written back to .grad.  21 B read + 16 B written per element in one pass.
 __global__ __launch_bounds__(kThreads) void k_adam_route(float *__restrict__ pm, float *__restrict__ gpm, float *__restrict__ m1,
                                                          float *__restrict__ m2, const uint8_t *__restrict__ owner, int cur, int mode,
-                                                         float step_size, float beta1, float beta2, float eps, float bc2_sqrt,
+                                                         float step_size, float omb1, float beta2, float omb2, float eps, float bc2_sqrt,
                                                          int64_t n, int vec_ok) {
     const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const int64_t nthreads = (int64_t)gridDim.x * kThreads;
     auto one = [&](float &p, float &g, float &a, float &b, int o) {
         const bool keep = mode == CPG_MODE_FINETUNE && o != 0 && o < cur;
         const float gr = keep ? g : 0.0f;
-        a = fmaf(1.0f - beta1, gr - a, a);
-        b = fmaf(1.0f - beta2, gr * gr, beta2 * b);
+        a = fmaf(omb1, gr - a, a);                 // exp_avg.lerp_(grad, 1 - beta1)
+        b = fmaf(omb2, gr * gr, beta2 * b);        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
         const float denom = sqrtf(b) / bc2_sqrt + eps;
         p = fmaf(-step_size, a / denom, p);
         g = gr;
@@ -314,15 +314,17 @@ inline int is16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 }  // namespace
 
 extern "C" int cpg_adam_route_step(float *pm, float *gpm, float *exp_avg, float *exp_avg_sq, const uint8_t *owner, int32_t cur,
-                                   int32_t mode, float lr, float beta1, float beta2, float eps, int32_t step, int64_t n, void *stream) {
+                                   int32_t mode, double lr, double beta1, double beta2, double eps, int32_t step, int64_t n, void *stream) {
     CPG_REQUIRE(n >= 0 && (n == 0 || (pm && gpm && exp_avg && exp_avg_sq && owner)), "cpg_adam_route_step: null pointer or negative n");
     CPG_REQUIRE(mode == CPG_MODE_FINETUNE || mode == CPG_MODE_PRUNE, "cpg_adam_route_step: unknown mode %d", mode);
     CPG_REQUIRE(cur >= 0 && cur <= 255 && step >= 1, "cpg_adam_route_step: owner id %d / step %d out of range", cur, step);
     if (n == 0) return CPG_OK;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    // every derived constant is formed in double and rounded once, as torch does with its python-float hyper-parameters
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     const int vec = is16(pm) && is16(gpm) && is16(exp_avg) && is16(exp_avg_sq) && (((uintptr_t)owner) & 3) == 0;
     hipLaunchKernelGGL(k_adam_route, dim3(stream_grid(n, kThreads * 4)), dim3(kThreads), 0, (hipStream_t)stream, pm, gpm, exp_avg,
-                       exp_avg_sq, owner, cur, mode, (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2), n, vec);
+                       exp_avg_sq, owner, cur, mode, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                       (float)sqrt(bc2), n, vec);
     CPG_CHECK_LAUNCH("cpg_adam_route_step");
     return CPG_OK;
 }

@@ -591,7 +591,7 @@ PwWPlan pw_wgrad_plan(const cpg_conv_desc *d) {
     // split blocks per CU: every split writes a full set of partial sums that k_split_reduce reads back; 2 (one round of the two
     // resident blocks) instead of round 2's 4: ResNet-50 73.83 -> 72.98 ms per step (A/B through CPG_PWW_BPC)
     int bpc = shared_chip_hint() ? 4 : 2;      // (data parallel: RCCL's kernels hold CUs -- a one-round launch would grow by a whole round)
-    if (const char *f = getenv("CPG_PWW_BPC")) bpc = std::max(1, atoi(f));
+    bpc = std::max(1, opt_or(OPT_PWW_BPC, bpc));
     int64_t want = ((int64_t)bpc * kCUs + tiles - 1) / tiles;
     want = std::max<int64_t>(1, std::min<int64_t>(want, (units + 7) / 8));      // at least 8 units per split
     want = (want + kXCDs - 1) / kXCDs * kXCDs;
@@ -674,7 +674,7 @@ int launch(PwGeom g, const float *x, const float *wp, const float *bias, float *
 }  // namespace
 
 extern "C" int cpg_conv1x1_supported(const cpg_conv_desc *d) {
-    if (getenv("CPG_DISABLE_CONV1X1")) return 0;
+    if (cpg::opt_on(cpg::OPT_DISABLE_CONV1X1)) return 0;
     if (!(d->R == 1 && d->S == 1 && d->pad_h == 0 && d->pad_w == 0 && d->groups == 1 && d->stride_h >= 1 && d->stride_w >= 1 &&
           d->N > 0 && d->C > 0 && d->K > 0 && d->H > 0 && d->W > 0))
         return 0;
@@ -743,7 +743,7 @@ int cpg_conv1x1_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, c
 
 // dense pointwise layers whose activations can be staged as aligned float4 and addressed with 31-bit byte offsets
 extern "C" int cpg_conv1x1_wgrad_supported(const cpg_conv_desc *d) {
-    if (getenv("CPG_DISABLE_CONV1X1_WGRAD") || !cpg_conv1x1_supported(d)) return 0;
+    if (cpg::opt_on(cpg::OPT_DISABLE_CONV1X1_WGRAD) || !cpg_conv1x1_supported(d)) return 0;
     const int64_t hw = (int64_t)d->H * d->W;
     // (strided layers and planes that are not multiples of 4 pixels take the kernel's per-pixel staging)
     return (int64_t)d->N * std::max(d->C, d->K) * hw * 4 < (1ll << 31) && (int64_t)d->N * hw < (1ll << 29);
@@ -796,7 +796,7 @@ NtPlan nt_plan(int M, int C, int64_t K) {
 }  // namespace
 
 bool cpg_pw_gemm_nt_ok(const float *A, const float *B, int M, int C, int64_t K) {
-    return !getenv("CPG_DISABLE_PW_GEMM") && K % 4 == 0 && (((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0 &&
+    return !cpg::opt_on(cpg::OPT_DISABLE_PW_GEMM) && K % 4 == 0 && (((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0 &&
            (int64_t)std::max(M, C) * K * 4 < (1ll << 31) && K < (1ll << 29);
 }
 size_t cpg_pw_gemm_nt_workspace(int M, int C, int64_t K) { return nt_plan<PwW128>(M, C, K).ws_bytes; }
@@ -815,7 +815,7 @@ int cpg_pw_gemm_nt(const float *A, const float *B, int M, int C, int64_t K, cons
 bool cpg_pw_gemm_nn_ok(const float *X, int M, int Mp, int Kd, int64_t G) {
     // no split-K here: the output tiles alone must fill the chip (4096 -> 4096 dgrad at batch 256 has 38 of them: 4x slower)
     if (((G + 223) / 224) * ((M + 127) / 128) < 192) return false;
-    return !getenv("CPG_DISABLE_PW_GEMM") && Kd % 16 == 0 && M % 8 == 0 && Mp % 128 == 0 && Mp >= M && G < (1ll << 28) &&
+    return !cpg::opt_on(cpg::OPT_DISABLE_PW_GEMM) && Kd % 16 == 0 && M % 8 == 0 && Mp % 128 == 0 && Mp >= M && G < (1ll << 28) &&
            (int64_t)Kd * G * 4 < (1ll << 31) && (int64_t)M * G < (1ll << 31) && (((uintptr_t)X) & 15) == 0;
 }
 // y[M][G] (+ bias[m]) from K-major Wp (row stride Mp >= M, a multiple of 128; rows beyond Kd are never read)

@@ -32,30 +32,41 @@ from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
 class _ChunkedGradient(object):
     """Hand-off between a masked linear layer's weight-gradient kernels and the gradient exchange for ONE very large weight
     (VGG16 features.45: 4096 x 25088 = 411 MB): SharableLinear's backward computes the gradient in `nchunks` blocks of output rows
-    (independent GEMMs, each writes its rows of `buffer`) and calls ready() after launching each block, which starts that block's
-    all-reduce -- a single 411 MB message could only start after the whole weight-gradient kernel and could not overlap its own
-    producer; with 4 blocks, 3/4 of the exchange runs under the producer's remaining kernels.  Bits are unchanged: every output
-    row is computed by the same instruction sequence whichever block it is launched in."""
+    (independent GEMMs, each writes its rows of the gradient) and calls ready() after launching each block, which starts that
+    block's all-reduce -- a single 411 MB message could only start after the whole weight-gradient kernel and could not overlap its
+    own producer; with 4 blocks, 3/4 of the exchange runs under the producer's remaining kernels.  Bits are unchanged: every output
+    row is computed by the same instruction sequence whichever block it is launched in.
+
+    The gradient is a FRESH tensor per backward pass that autograd adopts as `p.grad` (no clone): nothing here keeps a reference to
+    the tensor itself -- the row blocks handed to RCCL alias its storage through Tensor.set_ (a plain slice would be a view whose
+    `_base` pins the tensor, and AccumulateGrad clones a gradient somebody else still holds: round 3 paid a 411 MB clone plus a
+    411 MB copy-back per step for that).  The collectives then reduce p.grad's own rows in place."""
 
     def __init__(self, owner, param, nchunks):
         self.owner, self.param, self.nchunks = owner, param, int(nchunks)
-        self._buf = None
-        self.pending = []           # [(work, rows tensor)] of the current backward pass
+        self.pending = []           # [(work, rows alias, first row)] of the current backward pass
+        self.base_ptr = None        # data_ptr of the gradient tensor the pending rows alias
 
     def active(self):
-        """Chunk this step?  Not when the surviving slots are exchanged as a packed buffer (task >= 2: the payload is small)."""
+        """Chunk this step?  Not when the surviving slots are exchanged as a packed buffer (task >= 2: the payload is small), and not
+        when a gradient is already there (accumulation over several backward passes: autograd ADDS into p.grad, so the rows on the
+        wire would not be p.grad's -- the whole-tensor path reduces the accumulated gradient correctly)."""
         o = self.owner
-        return o._active and (o._filter is None or o._plan(self.param) is None)
+        return o._active and self.param.grad is None and (o._filter is None or o._plan(self.param) is None)
 
     def buffer(self, like):
-        if self._buf is None or self._buf.shape != like.shape or self._buf.device != like.device:
-            self._buf = torch.empty_like(like)
-        return self._buf
+        self.pending = []
+        gw = torch.empty_like(like, memory_format=torch.contiguous_format)
+        self.base_ptr = gw.data_ptr()
+        return gw
 
-    def ready(self, rows):
+    def ready(self, gw, r0, r1):
         o = self.owner
         op = dist.ReduceOp.AVG if o._avg else dist.ReduceOp.SUM
-        self.pending.append((dist.all_reduce(rows, op=op, group=o.process_group, async_op=True), rows))
+        cols = gw.shape[1]
+        rows = torch.empty(0, dtype=gw.dtype, device=gw.device).set_(gw.untyped_storage(), gw.storage_offset() + r0 * cols,
+                                                                    (r1 - r0, cols), (cols, 1))      # alias, no `_base`
+        self.pending.append((dist.all_reduce(rows, op=op, group=o.process_group, async_op=True), rows, r0))
         o.bucket_log.append(('chunk', rows.numel() * 4))
 
 
@@ -74,8 +85,9 @@ class DataParallel(nn.Module):
         self._world = dist.get_world_size(process_group) if self._active else 1
         if self._active and self._world > 1 and any(p.is_cuda for p in module.parameters()):
             # the gradient all-reduce runs on RCCL's stream beside the backward kernels and holds some CUs: tell the library
-            # (a thread-local hint of its C ABI, not a process-wide environment variable) -- the Winograd weight gradient then
-            # uses more, shorter units per wave slot (a launch is `units` rounds of blocks; conv3x3_wino_wgrad.hip)
+            # (a process-wide hint of its C ABI -- the planners that read it run on autograd's engine thread, not on this one) --
+            # the Winograd weight gradient then uses more, shorter units per wave slot (a launch is `units` rounds of blocks;
+            # conv3x3_wino_wgrad.hip)
             from . import _lib
             _lib.lib().cpg_set_shared_chip_hint(1)
         self._handles = []
@@ -241,13 +253,14 @@ class DataParallel(nn.Module):
                 _lib.check('cpg_unpack_owned', rc)
         self._handles = []
         for p, ch in self._chunked:
-            for work, rows in ch.pending:
+            adopted = p.grad.data_ptr() == ch.base_ptr           # autograd took the gradient tensor itself: the rows ARE p.grad's
+            for work, rows, r0 in ch.pending:
                 work.wait()
                 if not self._avg:
                     rows.mul_(inv)
+                if not adopted:                                   # (it cloned: put the reduced rows where the optimizer reads)
+                    p.grad[r0:r0 + rows.shape[0]].copy_(rows)
             ch.pending = []
-            if p.grad.data_ptr() != ch._buf.data_ptr():          # (autograd copied instead of adopting the buffer)
-                p.grad.copy_(ch._buf)
         self._chunked = []
         self.last_bucket_log, self.bucket_log = self.bucket_log, []
         self.last_payload, self._step_payload = self._step_payload, {'dense_elems': 0, 'sent_elems': 0}

@@ -89,11 +89,15 @@ class CPGSession(object):
     """Holds everything the reference passes between processes through checkpoint files."""
 
     def __init__(self, arch='custom_vgg_cifar100', width=1.0, device='cuda', cfg=VGG16_CFG, data_parallel=True,
-                 fused_optimizers=True, seed=None):
+                 fused_optimizers=True, seed=None, freeze_gc=False):
         self.arch, self.width, self.device = arch, width, torch.device(device)
         self.cfg = cfg
         self.seed = seed
         self.fused_optimizers = fused_optimizers      # MaskedSGD / MaskedAdam: gradient routing fused into the optimizer passes
+        # OPT-IN (process-wide side effect): after (re)building a model, collect once and move every live object of the PROCESS to the
+        # collector's permanent generation (cpg_amd.utils.settle_host_gc) -- removes the ~80 ms generation-2 pauses from the step loop,
+        # but also freezes the embedding application's objects and undoes a freeze it did itself; off unless asked for
+        self.freeze_gc = bool(freeze_gc)
         self.shared_layer_info = {}
         self.masks = {}
         self.model = None
@@ -144,7 +148,8 @@ class CPGSession(object):
         self.shared_layer_info[dataset]['network_width_multiplier'] = self.width
         if hasattr(self.model, 'refresh_hooks'):
             self.model.refresh_hooks()
-        settle_host_gc()                                    # the model, its masks and heads now live for the whole task
+        if self.freeze_gc:
+            settle_host_gc()                                # the model, its masks and heads now live for the whole task
         return task_id
 
     def _fresh_piggymasks(self):
@@ -247,7 +252,8 @@ class CPGSession(object):
             ckpt.resize_masks(self.model, self.masks, 'finetune')
         else:
             self.masks.clear()
-        settle_host_gc()                                    # (the old width's modules are garbage now; the new ones are long-lived)
+        if self.freeze_gc:
+            settle_host_gc()                                # (the old width's modules are garbage now; the new ones are long-lived)
 
     # -- phases ------------------------------------------------------------------------------------------------
     def _manager(self, args, train_loader, val_loader, begin, end):

@@ -108,9 +108,9 @@ class _MaskedConv2dFn(torch.autograd.Function):
             raise RuntimeError('SharableConv2d: kernel larger than padded input')
         y = torch.empty((d.N, d.K, oh, ow), dtype=torch.float32, device=x.device)
         L = _lib.lib()
-        ctx.empty = d.N == 0
+        ctx.empty = d.N == 0 or d.K == 0
         ctx.bf16 = ctx.x3 = False
-        if ctx.empty:                   # an empty batch is legal for F.conv2d: empty output, zero parameter gradients
+        if ctx.empty:                   # an empty batch (or no output channels) is legal for F.conv2d: empty output, zero parameter gradients
             _lib.dptr(x, name='input'), _lib.dptr(w, name='weight')            # still no CPU / dtype fallback
             ctx.save_for_backward(x, w, p)
             ctx.desc, ctx.thr, ctx.has_bias = d, float(thr), bias is not None
@@ -168,7 +168,8 @@ class _MaskedConv2dFn(torch.autograd.Function):
         x, w, p = ctx.saved_tensors
         d, thr = ctx.desc, ctx.thr
         if ctx.empty:
-            return (torch.zeros_like(x), torch.zeros_like(w), None if p is None else torch.zeros_like(p),
+            # (an empty OUTPUT with a non-empty input -- out_channels == 0 -- still passes a residual branch's gradient through)
+            return (addend if addend is not None else torch.zeros_like(x), torch.zeros_like(w), None if p is None else torch.zeros_like(p),
                     torch.zeros(d.K, dtype=torch.float32, device=x.device) if ctx.has_bias else None, None, None, None, None, None, None,
                     None, None, None)
         gy = gy.contiguous()
@@ -315,7 +316,7 @@ class _MaskedLinearFn(torch.autograd.Function):
                                             _lib.dptr(gw[r0:r1]), _lib.dptr(None if gpm is None else gpm[r0:r1]),
                                             _lib.dptr(None if gb is None else gb[r0:r1]), batch, fin, rows, _lib.dptr(wsc), nbc, s)
                     _lib.check('cpg_linear_wgrad', rc)
-                    ch.ready(gw[r0:r1])
+                    ch.ready(gw, r0, r1)
             else:
                 gw = torch.empty_like(w)
                 rc = L.cpg_linear_wgrad(_lib.dptr(x2), _lib.dptr(gy2), _lib.dptr(w), _lib.dptr(p), thr, _lib.dptr(gw),

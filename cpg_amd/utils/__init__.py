@@ -13,8 +13,10 @@ def settle_host_gc():
     collector's permanent generation (`gc.freeze`).  The step loop allocates a few thousand container objects per step (autograd
     contexts, argument tuples), so CPython starts a full generation-2 pass every few dozen steps, and that pass walks every tracked
     object: 80 ms measured on the GPU box's host (tools/step_times.py), most of a VGG16 step, during which no kernel is enqueued.
-    After the freeze the same pass only visits what was allocated since.  Called by CPGSession whenever it has (re)built a model and
-    by bench.py after its warm-up; cyclic garbage among the frozen objects is reclaimed at the next call (unfreeze + collect)."""
+    After the freeze the same pass only visits what was allocated since.  PROCESS-WIDE side effects, hence opt-in: every object alive
+    in the embedding application is frozen too (cyclic garbage among them -- e.g. an old model's tensors in a reference cycle -- is only
+    reclaimed at the next call: unfreeze + collect), and a freeze the application did itself is undone.  Called by
+    CPGSession(freeze_gc=True) whenever it has (re)built a model, and by bench.py after its warm-up (disclosed in its JSON line)."""
     gc.unfreeze()
     gc.collect()
     gc.freeze()

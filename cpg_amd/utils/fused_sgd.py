@@ -83,6 +83,7 @@ class MaskedAdam(torch.optim.Adam):
         self.pruner = pruner
         pruner.fused_piggymask_step = True
         self._masked = {}
+        self._pristine = set()                   # id(p) of piggymasks whose Adam state is still exactly zero (see step())
 
     def _refresh(self):
         self._masked = {}
@@ -97,7 +98,7 @@ class MaskedAdam(torch.optim.Adam):
         s = _lib.stream_ptr()
         pr = self.pruner
         mode = {'finetune': _lib.MODE_FINETUNE, 'prune': _lib.MODE_PRUNE}.get(pr.args.mode)
-        held = []
+        held, idle = [], []
         for group in self.param_groups:
             beta1, beta2 = group['betas']
             for p in group['params']:
@@ -109,7 +110,18 @@ class MaskedAdam(torch.optim.Adam):
                     state['step'] = torch.tensor(0.0, dtype=torch.float32)
                     state['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    self._pristine.add(id(p))
                 state['step'] += 1
+                held.append((p, p.grad))
+                if mode == _lib.MODE_PRUNE and id(p) in self._pristine:
+                    # Prune mode routes EVERY piggymask gradient to zero (utils/prune.py:209-210), and this parameter's moments are
+                    # still exactly zero: Adam's update is then m = v = 0, pm -= step_size * 0 / eps -- nothing changes, bit for bit.
+                    # The whole prune phase of the reference (lr_mask 0, a fresh optimizer per phase) is this case: only the routed
+                    # gradient (all zeros) has to be left in .grad -- 4 B per element instead of the 37 B of the full pass.
+                    idle.append(p.grad)
+                    p.grad = None
+                    continue
+                self._pristine.discard(id(p))
                 owner = pr._owner(name, p.data)
                 rc = L.cpg_adam_route_step(_lib.dptr(p.data, name='piggymask'), _lib.dptr(p.grad, name='piggymask.grad'),
                                            _lib.dptr(state['exp_avg']), _lib.dptr(state['exp_avg_sq']),
@@ -117,9 +129,10 @@ class MaskedAdam(torch.optim.Adam):
                                            float(group['lr']), float(beta1), float(beta2), float(group['eps']),
                                            int(state['step']), p.numel(), s)
                 _lib.check('cpg_adam_route_step', rc)
-                held.append((p, p.grad))
                 p.grad = None
-        if held:
+        if idle:
+            torch._foreach_zero_(idle)           # (one multi-tensor kernel)
+        if len(held) > len(idle):
             pr._pm_mutations += 1                # the kernel wrote through data_ptr(): tensor._version did not move
         loss = super().step(closure)
         for p, g in held:

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CPG_ABI_VERSION 1
+#define CPG_ABI_VERSION 2
 
 #define CPG_OK 0
 #define CPG_E_INVALID (-1)
@@ -75,12 +75,26 @@ typedef struct cpg_prune_result {
 } cpg_prune_result;
 
 int cpg_version(void);
-/* Scheduling hint of the CALLING HOST THREAD (thread-local, default 0): 1 = other streams' kernels share the chip with this
- * thread's launches (a data-parallel run: RCCL's all-reduce kernels hold some CUs during the backward pass).  Only changes
- * scheduling and the summation order of split partial sums; the weight gradients then split finer (Winograd: 4 units per wave slot instead of 1; pointwise / direct
- * 3x3: 4 split blocks per CU instead of 2) so that a launch that finds CUs taken is still balanced by the dispatcher.  Set it before the workspace query of the calls it should affect.
- * Replaces nn.DataParallel's implicit "all GPUs are mine" (CPG_cifar100_main_normal.py:199-200). */
+/* PROCESS-wide scheduling hint (an atomic; default 0): 1 = other streams' kernels share the chip with this process's launches
+ * (a data-parallel run: RCCL's all-reduce kernels hold some CUs during the backward pass).  Only changes scheduling and the
+ * summation order of split partial sums; the weight gradients then split finer (Winograd: 4 units per wave slot instead of 1;
+ * pointwise / direct 3x3: 4 split blocks per CU instead of 2) so that a launch that finds CUs taken is still balanced by the
+ * dispatcher.  Set it before the workspace query of the calls it should affect.  Process-wide on purpose: the planners that read it
+ * run inside autograd's backward, on the engine's worker thread, not on the thread that set it (round 3's thread-local never reached
+ * them).  Replaces nn.DataParallel's implicit "all GPUs are mine" (CPG_cifar100_main_normal.py:199-200). */
 int cpg_set_shared_chip_hint(int32_t shared);
+int32_t cpg_get_shared_chip_hint(void);
+/* Library options.  Every CPG_* switch of the dispatch code (INTEGRATION.md lists them) lives in one process-wide table that is
+ * filled from the environment ONCE, when the library is loaded; no launch path calls getenv().  After loading, the table changes
+ * only through these two calls.  `name` is the switch's documented name ("CPG_NO_WINO", "CPG_WW_UNITS", ...); `value`: boolean
+ * switches 0 / 1, integer switches their number, CPG_WINO_KERNEL 0 = block, 1 = wave, 2 = pair, 3 = 64; CPG_OPT_UNSET = "never
+ * given" (the built-in default applies).  The policy switches -- the only ones an integrator should touch -- choose the arithmetic
+ * of the 3x3 convolutions: CPG_NO_WINO (direct fp32 MFMA instead of Winograd F(2x2,3x3) in all three passes), CPG_NO_WINO_WGRAD,
+ * CPG_NO_WINO_ODD, CPG_NO_STEM, CPG_NO_STEM_FUSE, CPG_NO_DEAD_SKIP; everything else is A/B tooling.  Unknown name: CPG_E_INVALID.
+ * There is no counterpart in the reference: F.conv2d takes whichever algorithm cuDNN / MIOpen selects (models/layers.py:106-109). */
+#define CPG_OPT_UNSET INT32_MIN
+int cpg_set_option(const char *name, int32_t value);
+int cpg_get_option(const char *name, int32_t *value);
 /* human-readable text for the last non-zero status returned on THIS thread */
 const char *cpg_last_error(void);
 
@@ -182,9 +196,12 @@ int cpg_sgd_route_step(float *w, float *gw, float *momentum_buf, const uint8_t *
 /* Fused piggymask step for task >= 2: the piggymask part of do_weight_decay_and_make_grads_zero (utils/prune.py:206-210:
  * finetune -> gradient zeroed where owner == 0 or owner >= cur, prune -> all zero) followed by torch.optim.Adam's update
  * (CPG_cifar100_main_normal.py:342-346; amsgrad = False, weight_decay = 0) in one pass; `step` is the 1-based Adam step
- * count, exp_avg / exp_avg_sq its state (zeros before step 1).  The routed gradient is written back to gpm. */
+ * count, exp_avg / exp_avg_sq its state (zeros before step 1).  The routed gradient is written back to gpm.
+ * The hyper-parameters are DOUBLES, as torch holds them (python floats): torch forms 1 - beta, lr / bias_correction1 and
+ * sqrt(bias_correction2) in double and only then rounds to fp32 -- 1 - 0.999 is 0.001 there, but 0.00099998713 when formed from
+ * the fp32 value 0.999f (ABI version 2; version 1 took floats and was 1.3e-5 off in exp_avg_sq). */
 int cpg_adam_route_step(float *pm, float *gpm, float *exp_avg, float *exp_avg_sq, const uint8_t *owner, int32_t cur,
-                        int32_t mode, float lr, float beta1, float beta2, float eps, int32_t step, int64_t n, void *stream);
+                        int32_t mode, double lr, double beta1, double beta2, double eps, int32_t step, int64_t n, void *stream);
 
 /* ---- nn.BatchNorm2d -> nn.ReLU(inplace) after each masked conv ----
  * (models/vgg.py:137-141: `layers += [conv2d, nn.BatchNorm2d(c), nn.ReLU(inplace=True)]`).

@@ -21,3 +21,29 @@ def load_golden(name):
 @pytest.fixture(scope='session')
 def golden():
     return load_golden
+
+
+class _LibOptions(object):
+    """Library switches (include/cpg_hip.h: cpg_set_option) for the duration of one test; the library reads the environment only
+    once, when it is loaded, so tests flip switches through the C ABI."""
+
+    def __init__(self):
+        self._old = {}
+
+    def set(self, name, value):
+        from cpg_amd import _lib
+        if name not in self._old:
+            self._old[name] = _lib.get_option(name)
+        _lib.set_option(name, value)
+
+    def restore(self):
+        from cpg_amd import _lib
+        for name, v in self._old.items():
+            _lib.set_option(name, v)
+
+
+@pytest.fixture
+def libopt():
+    o = _LibOptions()
+    yield o
+    o.restore()

@@ -286,20 +286,20 @@ def test_pointwise_random_shapes_vs_torch():
     (4, 128, 96, 96, 128, False, True),    # 576 logical k_wg3 blocks against a grid of 512
 ])
 @pytest.mark.parametrize('nw', [0, 1, 2, 3, 4, 8])
-def test_winograd_matches_direct(N, C, H, W, K, bias, pm, nw, monkeypatch):
+def test_winograd_matches_direct(N, C, H, W, K, bias, pm, nw, libopt):
     """The Winograd F(2x2, 3x3) forward / input-gradient kernels (conv3x3_wino.hip, the default for even maps with >= 16 channels)
     against the direct kernels (CPG_NO_WINO=1) and against fp64: same result to a few fp32 roundings of the output scale, bit-identical
     when repeated; shapes chosen for the tile enumeration's edge cases (the oracle comparisons of test_conv_oracle run through
     the same dispatch)."""
     if nw == 1:                                         # 0: the library's own choice per shape (k_wg1 or k_wg3)
-        monkeypatch.setenv('CPG_WINO_KERNEL', 'wave')    # one wave per unit (k_wg1)
+        libopt.set('CPG_WINO_KERNEL', 'wave')    # one wave per unit (k_wg1)
     elif nw == 2:
-        monkeypatch.setenv('CPG_WINO_KERNEL', 'pair')    # two waves per unit, the transform positions split between them (k_wg2)
+        libopt.set('CPG_WINO_KERNEL', 'pair')    # two waves per unit, the transform positions split between them (k_wg2)
     elif nw == 3:
-        monkeypatch.setenv('CPG_WINO_KERNEL', '64')      # ... with 64 output channels per wave (k_wg3)
+        libopt.set('CPG_WINO_KERNEL', '64')      # ... with 64 output channels per wave (k_wg3)
     elif nw != 0:
-        monkeypatch.setenv('CPG_WINO_KERNEL', 'block')   # the cooperative 4- / 8-wave block kernels (not the default: measured slower)
-        monkeypatch.setenv('CPG_WINO_NW', str(nw))
+        libopt.set('CPG_WINO_KERNEL', 'block')   # the cooperative 4- / 8-wave block kernels (not the default: measured slower)
+        libopt.set('CPG_WINO_NW', str(nw))
     g = torch.Generator().manual_seed(N + C + K + H)
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(K, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5
@@ -321,7 +321,7 @@ def test_winograd_matches_direct(N, C, H, W, K, bias, pm, nw, monkeypatch):
     y1, gx1 = run()
     y2, gx2 = run()
     assert torch.equal(y1, y2) and torch.equal(gx1, gx2)                    # deterministic
-    monkeypatch.setenv('CPG_NO_WINO', '1')
+    libopt.set('CPG_NO_WINO', '1')
     y0, gx0 = run()
     weff = w.double() * ((pmv > 5e-3).double() if pm else 1.0)
     y64 = nn.functional.conv2d(x.double(), weff, None if b is None else b.double(), padding=1)
@@ -342,7 +342,7 @@ def test_winograd_matches_direct(N, C, H, W, K, bias, pm, nw, monkeypatch):
     (2, 128, 13, 14, 72, True, False),     # only the height is odd
     (2, 128, 3, 3, 64, False, False),      # the smallest odd map
 ])
-def test_winograd_on_odd_maps(N, C, H, W, K, bias, pm, monkeypatch):
+def test_winograd_on_odd_maps(N, C, H, W, K, bias, pm, libopt):
     """Winograd F(2x2, 3x3) on maps with an odd height / width (k_wg3<..., ODD>: ceil(H/2) x ceil(W/2) tiles, the overhang never loaded
     past the tensor, never stored, never in the BatchNorm statistics): forward, input gradient and the fused statistics against the
     direct kernels and fp64; the launch really is a Winograd one (cpg_conv2d_winograd) and writes nothing outside its tensors."""
@@ -378,7 +378,7 @@ def test_winograd_on_odd_maps(N, C, H, W, K, bias, pm, monkeypatch):
     y1, gx1, _ = run(False)
     y1s, _, st = run(True)
     assert torch.equal(y1, y1s)
-    monkeypatch.setenv('CPG_NO_WINO', '1')
+    libopt.set('CPG_NO_WINO', '1')
     assert L.cpg_conv2d_winograd(ctypes.byref(d), 0) == 0
     y0, gx0, _ = run(False)
     weff = w.double() * ((pmv > 5e-3).double() if pm else 1.0)
@@ -429,7 +429,7 @@ def test_inference_epilogue_matches_unfused(N, C, K, H, W, bias):
     (70, 3, 16, 64, False, True),      # 280 tiles
     (12, 3, 224, 224, False, False),   # 2352 tiles for the 2048 persistent waves: a wave's second tile, the ragged last round
 ])
-def test_stem_kernel_matches_general_kernel(N, C, H, W, bias, pm, monkeypatch):
+def test_stem_kernel_matches_general_kernel(N, C, H, W, bias, pm, libopt):
     """conv3x3_stem.hip (<= 3 input channels, 64 output channels: one persistent wave per 8 x 32 tile, weights in registers)
     against the general direct kernel (CPG_NO_STEM=1) and fp64: output and the BatchNorm statistics tiles' totals."""
     g = torch.Generator().manual_seed(N + H + W)
@@ -447,7 +447,7 @@ def test_stem_kernel_matches_general_kernel(N, C, H, W, bias, pm, monkeypatch):
     y0, y1, st = run()
     y0b, y1b, stb = run()
     assert torch.equal(y0, y0b) and torch.equal(y1, y1b) and torch.equal(st, stb)
-    monkeypatch.setenv('CPG_NO_STEM', '1')
+    libopt.set('CPG_NO_STEM', '1')
     g0, g1, gst = run()
     weff = w.double() * ((pmv > 5e-3).double() if pm else 1.0)
     ref = torch.nn.functional.conv2d(x.double(), weff, b.double() if bias else None, padding=1)
@@ -474,7 +474,7 @@ def test_stem_kernel_matches_general_kernel(N, C, H, W, bias, pm, monkeypatch):
     (3, 32, 2, 14, 32, False),         # ... a single tile row
     (4, 32, 28, 14, 64, True),         # ... H != W
 ])
-def test_winograd_wgrad_matches_direct(N, C, H, W, K, pm, monkeypatch):
+def test_winograd_wgrad_matches_direct(N, C, H, W, K, pm, libopt):
     """The Winograd weight-gradient kernel (conv3x3_wino_wgrad.hip: the default for maps 14 or a multiple of 28 wide with channel
     counts that are multiples of 32) against the direct kernel (CPG_NO_WINO_WGRAD=1) and fp64, bit-identical when repeated."""
     import ctypes
@@ -498,7 +498,7 @@ def test_winograd_wgrad_matches_direct(N, C, H, W, K, pm, monkeypatch):
     g1, p1 = run()
     g2, p2 = run()
     assert torch.equal(g1, g2) and (not pm or torch.equal(p1, p2))
-    monkeypatch.setenv('CPG_NO_WINO_WGRAD', '1')
+    libopt.set('CPG_NO_WINO_WGRAD', '1')
     g0, p0 = run()
     raw = nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), padding=1)
     ref_w = raw * (pmv > 5e-3).double() if pm else raw
@@ -1290,7 +1290,10 @@ def test_route_and_hist_full_size_properties():
     assert torch.equal(hist[:256], want) and int(hist[:256].sum()) == n
 
 
-@pytest.mark.parametrize('C,K,H', [(64, 64, 224), (128, 128, 112), (256, 256, 56), (512, 512, 28), (512, 512, 14), (3, 64, 224)])
+@pytest.mark.parametrize('C,K,H', [(64, 64, 224), (128, 128, 112), (256, 256, 56), (512, 512, 28), (512, 512, 14), (3, 64, 224),
+                                   # the three WIDENING layers of VGG16 (features.7 / .14 / .24): k_wg1 -> k_wg3 hand-over in the forward /
+                                   # input gradient (C < 128 <= K and back), unequal channel-block counts (nkb != ncb) in k_wgw
+                                   (64, 128, 112), (128, 256, 56), (256, 512, 28)])
 def test_conv_full_size_properties(C, K, H):
     """The conv layers of config 2 at their full size (batch 256): properties that need no CPU reference.
     (1) adjoint identities  <conv(x, W), gy> = <x, dgrad(gy, W)> = <W, wgrad(x, gy)>  tie the three kernels to
@@ -1600,7 +1603,7 @@ def test_fused_bn_small_planes_fp64(N, C, H, W, relu, add):
 
 
 @pytest.mark.parametrize('algo', ['direct', 'winograd'])
-def test_fused_sequential_equals_unfused(algo, monkeypatch):
+def test_fused_sequential_equals_unfused(algo, libopt):
     """the same VGG with FusedSequential.fuse on / off: logits and every parameter gradient agree.  Both runs use the same conv
     kernels; what differs is the BatchNorm arithmetic (~1e-7), which this tiny train-mode net (batch 16, 2x2 maps at the end)
     amplifies through ReLU flips.  With the direct conv kernels the gradients agree to 2e-3; with the
@@ -1609,7 +1612,7 @@ def test_fused_sequential_equals_unfused(algo, monkeypatch):
     by direction."""
     from cpg_amd.models.fused_bn import FusedSequential
     if algo == 'direct':
-        monkeypatch.setenv('CPG_NO_WINO', '1')
+        libopt.set('CPG_NO_WINO', '1')
     net = build('vgg_cifar100', 0.25).to(DEV)
     g = torch.Generator().manual_seed(4)
     x = torch.randn(16, 3, 32, 32, generator=g).to(DEV)
@@ -2031,13 +2034,13 @@ def test_empty_batch_and_empty_layers():
 
 # --------------------------------------------------------------------------- fused masked SGD
 @pytest.mark.parametrize('nesterov', [True, False])
-def test_masked_sgd_equals_routing_then_torch_sgd(nesterov, monkeypatch):
+def test_masked_sgd_equals_routing_then_torch_sgd(nesterov, libopt):
     """4 steps of MaskedSGD vs routing + torch.optim.SGD on two copies of a narrow VGG: weights, routed grads and
     momentum buffers agree to fp32 round-off; owner masks mixed (current task, older task, free).  (Direct conv kernels: the
     test is about the optimizer arithmetic; the two copies drift apart at the rate of the conv kernels' rounding error, which is
     4x larger -- and crosses the 2e-6 band at step 3 -- with the Winograd kernels.)"""
     from cpg_amd.utils.fused_sgd import MaskedSGD
-    monkeypatch.setenv('CPG_NO_WINO', '1')
+    libopt.set('CPG_NO_WINO', '1')
     nets, pruners, opts = [], [], []
     for fused in (False, True):
         net = build('vgg_cifar100', 0.125).to(DEV)
@@ -2126,6 +2129,117 @@ def test_masked_adam_equals_routing_then_torch_adam(mode):
                 a, b = opts[0][1].state[p][key], opts[1][1].state[q][key]
                 np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-3, atol=1e-5 * (float(a.abs().max()) + 1e-30), err_msg=key + ' ' + n)
             assert float(opts[0][1].state[p]['step']) == float(opts[1][1].state[q]['step']) == 4.0
+
+
+@pytest.mark.parametrize('kind', ['sgd', 'adam_finetune', 'adam_prune'])
+def test_fused_optimizer_steps_full_size_vs_oracle(kind):
+    """cpg_sgd_route_step / cpg_adam_route_step on features.45 of config 2 (4096 x 25088 = 102.8 M elements) through the raw C ABI, two
+    steps each (the first allocates the state: `first` / step 1), against the CPU oracle's routing (oracle/ops.py::route_grads =
+    utils/prune.py:195-211) followed by torch-CPU SGD-nesterov / Adam (CPG_cifar100_main_normal.py:339-346): the zero pattern of the
+    routed gradient is exact, values agree to fused-multiply-add rounding."""
+    import ctypes
+    from oracle import ops as oops
+    L = __import__('cpg_amd._lib', fromlist=['x'])
+    n = 4096 * 25088
+    g = torch.Generator().manual_seed(31)
+    w = torch.randn(n, generator=g) * 0.01
+    owner = torch.randint(0, 4, (n,), generator=g, dtype=torch.uint8)            # 0 free, 1 / 2 older tasks, 3 the current task
+    cur, wd = 3, 4e-5
+    mode = 'prune' if kind == 'adam_prune' else 'finetune'
+    if kind == 'sgd':
+        p_cpu = torch.nn.Parameter(w.clone())
+        opt = torch.optim.SGD([p_cpu], lr=1e-2, momentum=0.9, nesterov=True)
+        wg = w.to(DEV)
+        state = [torch.empty(n, device=DEV)]
+    else:
+        pmv = torch.rand(n, generator=g) * 0.012
+        p_cpu = torch.nn.Parameter(pmv.clone())
+        opt = torch.optim.Adam([p_cpu], lr=5e-4)
+        wg = pmv.to(DEV)
+        state = [torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)]
+    og = owner.to(DEV)
+    for step in range(2):
+        grad = torch.randn(n, generator=g) * 1e-3
+        gg = grad.to(DEV)
+        if kind == 'sgd':
+            routed, _ = oops.route_grads(grad.numpy(), p_cpu.detach().numpy(), owner.numpy(), cur, wd)
+        else:
+            _, routed = oops.route_grads(grad.numpy(), grad.numpy(), owner.numpy(), cur, 0.0, gpm=grad.numpy(), mode=mode)
+        p_cpu.grad = torch.from_numpy(routed)
+        opt.step()
+        if kind == 'sgd':
+            rc = L.lib().cpg_sgd_route_step(L.dptr(wg), L.dptr(gg), L.dptr(state[0]), L.dptr(og, torch.uint8), cur, wd, 1e-2, 0.9, 1,
+                                            int(step == 0), n, L.stream_ptr())
+        else:
+            rc = L.lib().cpg_adam_route_step(L.dptr(wg), L.dptr(gg), L.dptr(state[0]), L.dptr(state[1]), L.dptr(og, torch.uint8), cur,
+                                             L.MODE_PRUNE if mode == 'prune' else L.MODE_FINETUNE, 5e-4, 0.9, 0.999, 1e-8, step + 1, n,
+                                             L.stream_ptr())
+        assert rc == 0
+        got_g = gg.cpu()
+        assert torch.equal(got_g == 0, p_cpu.grad == 0), 'routing zero pattern, step %d' % step       # bit-exact routing decision
+        assert float((got_g - p_cpu.grad).abs().max()) <= 1e-6 * float(p_cpu.grad.abs().max() + 1e-30)
+        got = wg.cpu()
+        sc = float(p_cpu.detach().abs().max())
+        assert float((got - p_cpu.detach()).abs().max()) <= 2e-6 * sc, '%s step %d' % (kind, step)
+    if kind == 'sgd':
+        mom = opt.state[p_cpu]['momentum_buffer']
+        assert float((state[0].cpu() - mom).abs().max()) <= 2e-6 * float(mom.abs().max())
+    else:
+        for got, key in zip(state, ('exp_avg', 'exp_avg_sq')):
+            ref = opt.state[p_cpu][key]
+            assert float((got.cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max() + 1e-30), key
+        if mode == 'prune':                                 # prune mode zeroes every piggymask gradient: Adam's state stays 0, nothing moves
+            assert int((state[0] != 0).sum()) == 0 and torch.equal(wg.cpu(), pmv)
+
+
+def test_shared_chip_hint_reaches_the_backward_thread():
+    """the weight-gradient planners run inside autograd's backward, i.e. on the engine's worker thread.  The hint
+    set on the main thread (what cpg_amd.dist.DataParallel does for world > 1) must be what a backward launch sees: read it -- and the
+    Winograd weight gradient's planned workspace, which grows with the 4-units-per-slot split -- from inside a backward hook."""
+    import threading
+    L = __import__('cpg_amd._lib', fromlist=['x'])
+    lib = L.lib()
+    d = nl._conv_desc((32, 64, 56, 56), (64, 64, 3, 3), (1, 1), (1, 1), (1, 1), 1)
+    seen = {}
+
+    def probe(tag):
+        def hook(grad):
+            seen[tag] = (threading.get_ident(), int(lib.cpg_get_shared_chip_hint()), int(lib.cpg_conv2d_workspace_bytes(ctypes.byref(d))))
+        return hook
+    import ctypes
+    layer = nl.SharableConv2d(64, 64, 3, padding=1, bias=False).to(DEV)
+    nn.init.normal_(layer.weight, 0, 0.05)
+    try:
+        for tag, hint in (('off', 0), ('on', 1)):
+            assert lib.cpg_set_shared_chip_hint(hint) == 0
+            x = torch.randn(32, 64, 56, 56, device=DEV, requires_grad=True)
+            y = layer(x)
+            y.register_hook(probe(tag))
+            y.sum().backward()
+            torch.cuda.synchronize()
+    finally:
+        lib.cpg_set_shared_chip_hint(0)
+    assert seen['off'][0] != threading.get_ident(), 'backward hooks of CUDA tensors run on the autograd engine thread'
+    assert seen['off'][1] == 0 and seen['on'][1] == 1
+    assert seen['on'][2] > seen['off'][2], 'the finer split of the shared-chip plan needs more partial sums: %r' % (seen,)
+
+
+def test_library_options_are_read_once_and_set_through_the_abi(monkeypatch):
+    """No launch path reads the environment: a variable set AFTER the library was loaded changes nothing, cpg_set_option does; unknown
+    names are refused."""
+    import ctypes
+    L = __import__('cpg_amd._lib', fromlist=['x'])
+    lib = L.lib()
+    d = nl._conv_desc((4, 64, 28, 28), (64, 64, 3, 3), (1, 1), (1, 1), (1, 1), 1)
+    assert L.get_option('CPG_NO_WINO') in (None, 0) and lib.cpg_conv2d_winograd(ctypes.byref(d), 0) == 1
+    monkeypatch.setenv('CPG_NO_WINO', '1')
+    assert lib.cpg_conv2d_winograd(ctypes.byref(d), 0) == 1
+    with L.option('CPG_NO_WINO', 1):
+        assert lib.cpg_conv2d_winograd(ctypes.byref(d), 0) == 0 and L.get_option('CPG_NO_WINO') == 1
+    assert lib.cpg_conv2d_winograd(ctypes.byref(d), 0) == 1
+    assert lib.cpg_set_option(b'CPG_NO_SUCH_SWITCH', 1) != 0
+    v = ctypes.c_int32(0)
+    assert lib.cpg_get_option(b'CPG_NO_SUCH_SWITCH', ctypes.byref(v)) != 0
 
 
 # --------------------------------------------------------------------------- two-task sequence through the driver (8f.4)
@@ -2311,6 +2425,22 @@ def test_data_parallel_wrapper_over_rccl_world1(monkeypatch):
                 torch.cuda.synchronize()
                 kinds = [k for k, _ in dp.last_bucket_log]
                 assert (kinds.count('chunk') == 4) == chunked, kinds
+                if chunked:
+                    # autograd ADOPTED the gradient tensor the row blocks alias (no clone, no copy-back): RCCL reduced p.grad's own rows
+                    ch = lin.weight._cpg_dp_chunk
+                    assert lin.weight.grad.data_ptr() == ch.base_ptr and not ch.pending
+                    # a second backward WITHOUT zero_grad accumulates: the chunked hand-over steps aside (the whole-tensor path reduces the sum)
+                    first = lin.weight.grad.clone()
+                    xi2 = xin.clone().requires_grad_(True)
+                    dp(xi2).backward(gout)
+                    dp.finish_gradient_sync()
+                    assert [k for k, _ in dp.last_bucket_log].count('chunk') == 0
+                    torch.testing.assert_close(lin.weight.grad, 2 * first, rtol=1e-6, atol=1e-7)
+                    lin.zero_grad(set_to_none=True)
+                    xi = xin.clone().requires_grad_(True)
+                    dp(xi).backward(gout)
+                    dp.finish_gradient_sync()
+                    torch.cuda.synchronize()
                 res[chunked] = [xi.grad.clone()] + [prm.grad.clone() for prm in lin.parameters()]
             for a, b in zip(res[False], res[True]):
                 assert torch.equal(a, b), 'chunked and one-piece gradients differ (piggymask %s)' % pm_on

@@ -103,12 +103,9 @@ def main():
                 res = {v: [] for v in vals}
                 for _ in range(a.reps):
                     for v in vals:
-                        if v == '-':
-                            os.environ.pop(var, None)
-                        else:
-                            os.environ[var] = v
+                        _lib.set_option(var, None if v == '-' else v)      # (the library reads the environment only when it is loaded)
                         res[v].append(timeit(runs[k], a.iters))
-                os.environ.pop(var, None)
+                _lib.set_option(var, None)
                 print('%-6s %-6s ' % (name, k) + '  '.join('%s=%s: %.3f ms %.1f TF' % (var, v, sorted(t)[len(t) // 2], flops / sorted(t)[len(t) // 2] / 1e9)
                                                           for v, t in res.items()), flush=True)
                 continue

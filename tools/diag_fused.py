@@ -12,8 +12,8 @@ t = torch.randint(0, 5, (16,), generator=g).to(DEV)
 sd = {k: v.clone() for k, v in net.state_dict().items()}
 res = {}
 for algo in ('direct', 'winograd'):
-    if algo == 'direct': os.environ['CPG_NO_WINO'] = '1'
-    else: os.environ.pop('CPG_NO_WINO', None)
+    from cpg_amd import _lib as _l
+    _l.set_option('CPG_NO_WINO', 1 if algo == 'direct' else None)
     for fuse in (False, True):
         net.load_state_dict(sd); net.zero_grad(); net.train()
         FusedSequential.fuse = fuse

@@ -22,8 +22,8 @@ def fhook(name, store):
             out.register_hook(lambda gr: store.__setitem__(name, (gr.detach().clone(), None)))
     return hook
 for algo in ('direct', 'winograd'):
-    if algo == 'direct': os.environ['CPG_NO_WINO'] = '1'
-    else: os.environ.pop('CPG_NO_WINO', None)
+    from cpg_amd import _lib as _l
+    _l.set_option('CPG_NO_WINO', 1 if algo == 'direct' else None)
     store = cap.setdefault(algo, {})
     hs = []
     for n, m in net.features.named_children():

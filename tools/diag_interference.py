@@ -45,10 +45,10 @@ def main():
              ('stem forward 3->64 @224', layer(256, 3, 64, 224)[0], 'CPG_STEM_BLOCKS', ['512', '1024'])]
     for name, fn, var, vals in cases:
         for v in vals:
-            os.environ[var] = v
+            _lib.set_option(var, v)
             free = min(timed(fn, False) for _ in range(3))
             busy = min(timed(fn, True) for _ in range(3))
             print('%-40s %s=%-5s idle chip %.3f ms   with %d parked waves %.3f ms  (x %.2f)' % (name, var, v, free, a.hogs, busy, busy / free), flush=True)
-        os.environ.pop(var)
+        _lib.set_option(var, None)
 
 main()

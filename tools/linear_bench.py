@@ -49,12 +49,9 @@ def main():
                 for v in vals.split(','):
                     ts = []
                     for _ in range(a.reps):
-                        if v == '-':
-                            os.environ.pop(var, None)
-                        else:
-                            os.environ[var] = v
+                        _lib.set_option(var, None if v == '-' else v)
                         ts.append(timeit(fn, a.iters))
-                    os.environ.pop(var, None)
+                    _lib.set_option(var, None)
                     t = sorted(ts)[len(ts) // 2]
                     out.append('%s=%s: %.3f ms %.1f TF' % (var, v, t, flops / t / 1e9))
                 print('%5d->%-5d %-6s %s' % (fin, fout, k, '  '.join(out)), flush=True)

@@ -29,10 +29,8 @@ def main():
     if a.switch.startswith('env:'):             # env:NAME -- True = variable set to "1", False = unset (read by the library per call)
         class _Env(object):
             def __setattr__(self, name, value):
-                if value:
-                    os.environ[name] = '1'
-                else:
-                    os.environ.pop(name, None)
+                from cpg_amd import _lib
+                _lib.set_option(name, 1 if value else None)      # (the library reads the environment only when it is loaded)
         owner, attr = _Env(), a.switch[4:]
     else:
         path, attr = a.switch.rsplit('.', 1)

@@ -72,9 +72,9 @@ def main():
         }
         for k, (f0, f1, r0, r1) in runs.items():
             r1.fill_(float('nan'))
-            os.environ['CPG_NO_WINO'] = '1'          # the public entry points dispatch to the Winograd kernels themselves
+            _lib.set_option('CPG_NO_WINO', 1)          # the public entry points dispatch to the Winograd kernels themselves
             t0 = timeit(f0, a.iters)
-            os.environ.pop('CPG_NO_WINO')
+            _lib.set_option('CPG_NO_WINO', None)
             t1 = timeit(f1, a.iters)
             err = ((r1 - r0).abs().max() / r0.abs().max()).item()
             extra = ''

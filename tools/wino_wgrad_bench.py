@@ -55,18 +55,18 @@ def main():
             print('%-5s not eligible' % name)
             continue
         need = L.cpg_conv2d_workspace_bytes(ctypes.byref(d))
-        os.environ['CPG_NO_WINO_WGRAD'] = '1'                 # (the direct kernel's partial sums may need more)
+        _lib.set_option('CPG_NO_WINO_WGRAD', 1)                 # (the direct kernel's partial sums may need more)
         need = max(need, L.cpg_conv2d_workspace_bytes(ctypes.byref(d)))
-        os.environ.pop('CPG_NO_WINO_WGRAD')
+        _lib.set_option('CPG_NO_WINO_WGRAD', None)
         ws, nb = _lib.workspace(need, dev)
         nbw = raw.cpg_conv3x3_wino_wgrad_workspace(ctypes.byref(d))
         wsw = torch.empty(nbw // 4 + 64, device=dev)
         flops = 2.0 * N * K * H * H * C * 9
 
         def f0():
-            os.environ['CPG_NO_WINO_WGRAD'] = '1'
+            _lib.set_option('CPG_NO_WINO_WGRAD', 1)
             rc = L.cpg_conv2d_wgrad(ctypes.byref(d), P(x), P(gy), P(w), None, 5e-3, P(gw0), None, None, P(ws), nb, st)
-            os.environ.pop('CPG_NO_WINO_WGRAD')
+            _lib.set_option('CPG_NO_WINO_WGRAD', None)
             assert rc == 0, (rc, L.cpg_last_error())
 
         def f1():
