@@ -1792,15 +1792,17 @@ extern "C" size_t cpg_conv3x3_wino_pack_bytes(int c_read, int m) {      // (the 
 }
 
 // Which Winograd forward / input-gradient kernel a launch uses.  Default: k_wg3 (two waves per unit, 64 output channels each) when the
-// channel loop is long (>= 128 channels read) and there are at least 64 channels to produce -- 4 % faster there --, else k_wg1 (one
-// wave per unit): for 64-channel layers the shorter loop makes k_wg3's heavier epilogue (and its statistics) cost more than it saves.
+// layer reads and produces at least 64 channels, else k_wg1 (one wave per unit).  (Until round 4 the launches WITH the BatchNorm-statistics
+// epilogue switched at 128 channels read: k_wg3's statistics epilogue was the heavier one.  After round 3's work on it -- sums per
+// 32-channel half, scalar-base stores, the third filter buffer -- the interleaved A/B (tools/conv_bench.py --only fwdstats --ab
+// CPG_WINO_KERNEL=-,64) reads 64 -> 64 @224 4.716 -> 4.546 ms and 64 -> 128 @112 2.277 -> 2.217 ms for k_wg3.)
 // CPG_WINO_KERNEL = wave | pair | 64 | block forces k_wg1 / k_wg2 / k_wg3 / the cooperative block kernel (A/B experiments, tests).
 enum { WV_BLOCK = 0, WV_WAVE = 1, WV_PAIR = 2, WV_PAIR64 = 3 };
 static inline int wino_variant(int c_read, int m, bool stats = true) {
     if (const int forced = cpg::opt(cpg::OPT_WINO_KERNEL); forced != cpg::OPT_UNSET)      // (block | wave | pair | 64 -> WV_*)
         return forced >= WV_BLOCK && forced <= WV_PAIR64 ? forced : WV_WAVE;
-    // (without the statistics epilogue k_wg3 already pays off at 64 channels: 64 -> 64 @224 4.89 vs 5.13 ms)
-    return (c_read >= (stats ? 128 : 64) && m >= 64) ? WV_PAIR64 : WV_WAVE;
+    (void)stats;
+    return (c_read >= 64 && m >= 64) ? WV_PAIR64 : WV_WAVE;
 }
 
 #ifdef WG_TIMING

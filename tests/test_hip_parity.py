@@ -473,6 +473,11 @@ def test_stem_kernel_matches_general_kernel(N, C, H, W, bias, pm, libopt):
     (64, 32, 14, 14, 32, False),       # ... several stages per unit, units starting in the middle of an image pair's rows
     (3, 32, 2, 14, 32, False),         # ... a single tile row
     (4, 32, 28, 14, 64, True),         # ... H != W
+    # shared staging of the x rows (round 4): the four waves of a block share one input-channel block (K a multiple of 128) ...
+    (3, 64, 28, 28, 128, True),        # ... 4 x 2 channel blocks, one segment, odd image count, piggymask
+    (2, 128, 56, 56, 256, False),      # ... two segments per row (halo items split over the waves), 8 x 4 channel blocks
+    (24, 32, 28, 28, 128, False),      # ... several stages per unit (the double buffer, an odd number of stages in the last unit)
+    (40, 64, 28, 28, 64, True),        # ... or pairs of waves do (64 output channels: 2 x 2 channel blocks), several stages per unit
 ])
 def test_winograd_wgrad_matches_direct(N, C, H, W, K, pm, libopt):
     """The Winograd weight-gradient kernel (conv3x3_wino_wgrad.hip: the default for maps 14 or a multiple of 28 wide with channel
@@ -498,6 +503,11 @@ def test_winograd_wgrad_matches_direct(N, C, H, W, K, pm, libopt):
     g1, p1 = run()
     g2, p2 = run()
     assert torch.equal(g1, g2) and (not pm or torch.equal(p1, p2))
+    # the shared-staging variants change who loads the x rows, not one operand or the order of one sum: bit-identical to private staging
+    libopt.set('CPG_WW_SHARE', 0)
+    gl, pl = run()
+    assert torch.equal(g1, gl) and (not pm or torch.equal(p1, pl))
+    libopt.set('CPG_WW_SHARE', None)
     libopt.set('CPG_NO_WINO_WGRAD', '1')
     g0, p0 = run()
     raw = nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), padding=1)

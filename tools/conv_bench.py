@@ -74,7 +74,7 @@ def main():
         flops = 2.0 * a.batch * K * H * H * C * 9
         P = _lib.dptr
         tiles = L.cpg_conv2d_bnstats_tiles(ctypes.byref(d))
-        stats = torch.empty(max(1, K * tiles * 2), device=dev)
+        stats = torch.empty(max(1, K * tiles * 2) * 4, device=dev)       # (x 4: an --ab over kernel variants may change the tile count)
         runs = {'fwdstats': lambda: L.cpg_conv2d_fwd_bnstats(ctypes.byref(d), P(x), P(w), P(pm), 5e-3, None, P(y), P(stats), stats.numel() * 4, P(ws), nb, st),
                 'fwd': lambda: L.cpg_conv2d_fwd(ctypes.byref(d), P(x), P(w), P(pm), 5e-3, None, P(y), P(ws), nb, st),
                 'dgrad': lambda: L.cpg_conv2d_dgrad(ctypes.byref(d), P(gy), P(w), P(pm), 5e-3, P(gx), P(ws), nb, st),

@@ -67,13 +67,27 @@ __device__ unsigned long long ww_dbg[65536 * 8];
 #endif
 // (blocks of one or two waves and an XCD-contiguous unit order were measured: within 0.5 % on every layer, a single wave without the
 //  reorder 6 % slower on the 64-channel layers)
-template <bool NARROW>
+// GS > 0 (round 4; wide maps only): the waves of a block that work on the SAME input-channel block cb -- GS = 4: all four (output-channel
+// blocks 4 j .. 4 j + 3), GS = 2: two pairs -- stage that block's x rows ONCE, each wave loading and storing 1 / GS of them, into a shared,
+// double-buffered LDS region (one workgroup barrier per stage: the next stage's rows are stored into the OTHER buffer in the last k-step of
+// a stage, the barrier sits between those stores and the first operand reads of the next stage; every wave has finished reading a buffer
+// before it arrives at the barrier after which that buffer is written again).  gy rows stay wave-private.  Per stage and wave: 13 (GS = 4)
+// or 18 (GS = 2) vector-memory instructions and as many LDS store groups instead of 28 -- and the x rows are requested from L2 once per
+// GS units instead of once per unit.
+template <bool NARROW, int GS = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ part) {
-    __shared__ __attribute__((aligned(16))) float smem_all[4 * WW_STAGE];
+    static_assert(GS == 0 || (!NARROW && (GS == 2 || GS == 4)), "shared staging: wide maps, groups of 2 or 4 waves");
+    constexpr int NG = GS ? 4 / GS : 0;                          // x-sharing groups per block
+    __shared__ __attribute__((aligned(16))) float smem_all[GS ? NG * 2 * WW_XS + 4 * 32 * WW_GC : 4 * WW_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    float *smem = smem_all + wave * WW_STAGE;
+    const int gw = GS ? wave % GS : 0;                           // this wave's index within its x-sharing group
+    float *smem = GS ? smem_all : smem_all + wave * WW_STAGE;
+    // x rows of a stage: buffer 0 / 1 (the same private buffer without sharing); gy rows: wave-private in both designs
+    float *xb0 = GS ? smem_all + (wave / (GS ? GS : 1)) * 2 * WW_XS : smem;
+    float *xb1 = GS ? xb0 + WW_XS : smem;
+    float *gyp = GS ? smem_all + NG * 2 * WW_XS + wave * 32 * WW_GC : smem + WW_XS;
     const int HW = g.H * g.W;
     const unsigned npairs = (unsigned)(g.nkb * g.ncb);
     const unsigned u = (g.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x) * 4 + wave;
@@ -112,16 +126,18 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
     // 8-byte loads, lanes = (8 pairs x 8 items), item = (row, half) for x -> one channel per load (32 loads), (channel, row, half)
     // for gy (16 loads).  The half is the low bit of the item so that the 16 lanes of a ds_write_b64 group fill 28 different banks.
     const int xrow = NARROW ? rem >> 1 : rem & 3, half = rem & 1;
+    // (shared staging: wave gw of a group takes the x items j GS + gw and the halo items j GS + gw -- its share of the channel offset is
+    //  part of the per-lane constants, so that the item index of a load / store stays a compile-time constant)
     const int vx_const = NARROW ? (half * g.C * HW + xrow * g.W) * 4 + qd * 8 + 16
-                                : ((rem >> 2) * HW + xrow * g.W) * 4 + qd * 16 + 16;   // x item (c = 2 j + rem / 4, row = rem % 4)
+                                : ((rem >> 2) * HW + xrow * g.W + gw * 2 * HW) * 4 + qd * 16 + 16;   // x item (c = 2 j + rem / 4, row = rem % 4)
     const int vg_const = NARROW ? ((rem >> 2) * HW + half * g.K * HW + ((rem >> 1) & 1) * g.W) * 4 + qd * 8
                                 : ((rem >> 1) * HW + (rem & 1) * g.W) * 4 + qd * 16;   // gy item (k = 4 j + rem / 2, row = rem % 2)
     const int hside = lane & 1, hrow = (lane >> 1) & 3;                             // halo item (c = 8 j + lane / 8, row, side)
-    const int vh_const = ((lane >> 3) * HW + hrow * g.W) * 4 + (hside ? 28 * 4 + 16 : 12);
-    const int xw_addr = NARROW ? xrow * WW_XR + 16 * half + 2 + 2 * qd : (rem >> 2) * WW_XC + xrow * WW_XR + 2 + 4 * qd;
-    const int gw_addr = NARROW ? WW_XS + (rem >> 2) * WW_GC + ((rem >> 1) & 1) * WW_GR + 14 * half + 2 * qd
-                               : WW_XS + (rem >> 1) * WW_GC + (rem & 1) * WW_GR + 4 * qd;
-    const int hw_addr = (lane >> 3) * WW_XC + hrow * WW_XR + (hside ? 30 : 1);
+    const int vh_const = ((lane >> 3) * HW + hrow * g.W + gw * 8 * HW) * 4 + (hside ? 28 * 4 + 16 : 12);
+    const int xw_addr = NARROW ? xrow * WW_XR + 16 * half + 2 + 2 * qd : (rem >> 2) * WW_XC + xrow * WW_XR + 2 + 4 * qd + gw * 2 * WW_XC;
+    const int gw_addr = NARROW ? (rem >> 2) * WW_GC + ((rem >> 1) & 1) * WW_GR + 14 * half + 2 * qd          // (relative to gyp)
+                               : (rem >> 1) * WW_GC + (rem & 1) * WW_GR + 4 * qd;
+    const int hw_addr = (lane >> 3) * WW_XC + hrow * WW_XR + (hside ? 30 : 1) + gw * 8 * WW_XC;
     if constexpr (NARROW) {                                      // the padding columns 0, 1, 16, 17, 32, 33 of every x row
         for (int i = lane; i < 32 * 4 * 6; i += 64) {
             const int rowi = i / 6, col = i % 6;
@@ -185,7 +201,7 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
             } else if (idx < 48) {
                 i32x2 v;
                 v[0] = rg[(idx - 32) >> 1][2 * (idx & 1)], v[1] = rg[(idx - 32) >> 1][2 * (idx & 1) + 1];
-                *reinterpret_cast<i32x2 *>(smem + gw_addr + (idx - 32) * 2 * WW_GC) = v;
+                *reinterpret_cast<i32x2 *>(gyp + gw_addr + (idx - 32) * 2 * WW_GC) = v;
             }
         } else if (idx < 16) {
             i32x2 *d = reinterpret_cast<i32x2 *>(smem + xw_addr + idx * 2 * WW_XC);
@@ -193,7 +209,7 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
             lo[0] = rx[idx][0], lo[1] = rx[idx][1], hi[0] = rx[idx][2], hi[1] = rx[idx][3];
             d[0] = lo, d[1] = hi;
         } else if (idx < 24) {
-            i32x2 *d = reinterpret_cast<i32x2 *>(smem + gw_addr + (idx - 16) * 4 * WW_GC);
+            i32x2 *d = reinterpret_cast<i32x2 *>(gyp + gw_addr + (idx - 16) * 4 * WW_GC);
             i32x2 lo, hi;
             lo[0] = rg[idx - 16][0], lo[1] = rg[idx - 16][1], hi[0] = rg[idx - 16][2], hi[1] = rg[idx - 16][3];
             d[0] = lo, d[1] = hi;
@@ -201,20 +217,45 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
             smem[hw_addr + (idx - 24) * 8 * WW_XC] = rh[idx - 24];
         }
     };
+    // shared staging (GS > 0): item i of this wave = x item j GS + gw (i < XL), gy item i - XL (own 8), halo item j GS + gw
+    constexpr int XL = GS ? 16 / GS : 0, HL = GS ? 4 / GS : 0, NSI = XL + 8 + HL;
+    auto g_load_s = [&](int i) {
+        if (i < XL)
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_x, vx, sx + i * GS * 2 * HW * 4, 0);
+        else if (i < XL + 8)
+            rg[i - XL] = __builtin_amdgcn_raw_buffer_load_b128(srd_g, vg, sgo + (i - XL) * 4 * HW * 4, 0);
+        else if (i < NSI)
+            rh[i - XL - 8] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, vh, sx + (i - XL - 8) * GS * 8 * HW * 4, 0));
+    };
+    auto w_store_s = [&](int i, float *xb) {
+        if (i < XL) {
+            i32x2 *d = reinterpret_cast<i32x2 *>(xb + xw_addr + i * GS * 2 * WW_XC);
+            i32x2 lo, hi;
+            lo[0] = rx[i][0], lo[1] = rx[i][1], hi[0] = rx[i][2], hi[1] = rx[i][3];
+            d[0] = lo, d[1] = hi;
+        } else if (i < XL + 8) {
+            i32x2 *d = reinterpret_cast<i32x2 *>(gyp + gw_addr + (i - XL) * 4 * WW_GC);
+            i32x2 lo, hi;
+            lo[0] = rg[i - XL][0], lo[1] = rg[i - XL][1], hi[0] = rg[i - XL][2], hi[1] = rg[i - XL][3];
+            d[0] = lo, d[1] = hi;
+        } else if (i < NSI) {
+            xb[hw_addr + (i - XL - 8) * GS * 8 * WW_XC] = rh[i - XL - 8];
+        }
+    };
     // ---- T: operands of k-step ks (tile 2 ks + lh of the stage in LDS), in 14 micro steps ----
     // tile of (k-step ks, half-wave lh): wide 2 ks + lh of the 14-tile segment, NARROW tile ks of image n + lh
     constexpr int kLhX = NARROW ? 16 : 2, kLhG = NARROW ? 14 : 2, kKs = NARROW ? 2 : 4;
-    const int xr_base = li * WW_XC + 2 + lh * kLhX, gr_base = WW_XS + li * WW_GC + lh * kLhG;
-    auto t_micro = [&](int m, int ks, float (&A)[16], float (&B)[16]) {
+    const int xr_base = li * WW_XC + 2 + lh * kLhX, gr_base = li * WW_GC + lh * kLhG;
+    auto t_micro = [&](int m, int ks, float (&A)[16], float (&B)[16], const float *xb) {
         if (m < 4) {                                             // patch row m: own pair + the neighbours' halves
-            const float *r = smem + xr_base + kKs * ks + m * WW_XR;
+            const float *r = xb + xr_base + kKs * ks + m * WW_XR;
             const f32x2 own = *reinterpret_cast<const f32x2 *>(r);
             // the neighbours' halves as 8-byte reads too: a 4-byte read of 32 lanes at an even channel stride is 2-way conflicted
             const f32x2 lo = *reinterpret_cast<const f32x2 *>(r - 2), hi = *reinterpret_cast<const f32x2 *>(r + 2);
             B[m * 4 + 0] = lo[1], B[m * 4 + 1] = own[0], B[m * 4 + 2] = own[1], B[m * 4 + 3] = hi[0];
         } else if (m == 4) {                                     // the gy tile: A[0] = y00, A[3] = y01, A[12] = y10, A[15] = y11
-            const f32x2 y0 = *reinterpret_cast<const f32x2 *>(smem + gr_base + kKs * ks);
-            const f32x2 y1 = *reinterpret_cast<const f32x2 *>(smem + gr_base + kKs * ks + WW_GR);
+            const f32x2 y0 = *reinterpret_cast<const f32x2 *>(gyp + gr_base + kKs * ks);
+            const f32x2 y1 = *reinterpret_cast<const f32x2 *>(gyp + gr_base + kKs * ks + WW_GR);
             A[0] = y0[0], A[3] = y0[1], A[12] = y1[0], A[15] = y1[1];
         } else if (m < 7) {                                      // V = B^T d B: column pass of columns 2 (m - 5), + 1
 #pragma unroll
@@ -245,18 +286,30 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
     float A0[16], B0[16], A1[16], B1[16];
     // prologue: stage 0 into LDS, its first operands, stage 1's coordinates ready
     stage_offsets();
+    if constexpr (GS > 0) {
 #pragma unroll
-    for (int i = 0; i < (NARROW ? 48 : 28); ++i) g_load(i, 0);
+        for (int i = 0; i < NSI; ++i) g_load_s(i);
 #pragma unroll
-    for (int i = 0; i < (NARROW ? 48 : 28); ++i) w_store(i);
+        for (int i = 0; i < NSI; ++i) w_store_s(i, xb0);
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int i = 0; i < (NARROW ? 48 : 28); ++i) g_load(i, 0);
+#pragma unroll
+        for (int i = 0; i < (NARROW ? 48 : 28); ++i) w_store(i);
+    }
     advance_stage();
 #pragma unroll
-    for (int m = 0; m < 14; ++m) t_micro(m, 0, A0, B0);
+    for (int m = 0; m < 14; ++m) t_micro(m, 0, A0, B0, xb0);
 
     WW_STAMP(2);
     for (int st = 0; st < nst; st += 2) {
         if constexpr (NARROW) {
 @@BODY_N@@
+        } else if constexpr (GS == 4) {
+@@BODY_S4@@
+        } else if constexpr (GS == 2) {
+@@BODY_S2@@
         } else {
 @@BODY@@
         }
@@ -298,10 +351,11 @@ struct WwPlan {
     size_t ws_bytes;
     int64_t blocks;
     bool narrow;              // maps 14 pixels wide: a stage is one tile row of two images
+    int gs;                   // waves of a block that share the staging of their x rows (0: none; k_wgw<false, gs>)
 };
 
 bool ww_plan(const cpg_conv_desc *d, WwPlan &p) {
-    if (getenv("CPG_NO_WINO") || getenv("CPG_NO_WINO_WGRAD")) return false;
+    if (opt_on(OPT_NO_WINO) || opt_on(OPT_NO_WINO_WGRAD)) return false;
     if (d->R != 3 || d->S != 3 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 1 || d->pad_w != 1 || d->dil_h != 1 ||
         d->dil_w != 1 || d->groups != 1)
         return false;
@@ -323,7 +377,7 @@ bool ww_plan(const cpg_conv_desc *d, WwPlan &p) {
     // When another stream's kernels (RCCL) hold some CUs a one-round launch would grow by a whole round, so cpg_amd.dist asks
     // for 4 rounds when it wraps a model for more than one rank (cpg_set_shared_chip_hint).  CPG_WW_UNITS overrides.
     int upw = shared_chip_hint() ? 4 : 1;
-    if (const char *f = getenv("CPG_WW_UNITS")) upw = std::max(1, atoi(f));
+    upw = std::max(1, opt_or(OPT_WW_UNITS, upw));
     int64_t want = std::max<int64_t>(1, ((int64_t)upw * 4 * kCUs) / npairs);
     want = std::min<int64_t>(want, nstages);
     g.su = (unsigned)((nstages + want - 1) / want);
@@ -334,10 +388,13 @@ bool ww_plan(const cpg_conv_desc *d, WwPlan &p) {
     if ((int64_t)g.span * std::max(d->C, d->K) * HW * 4 + (d->W + 4) * 4 >= (1ll << 31)) return false;
     p.ws_bytes = (size_t)g.nsplit * 9 * d->K * d->C * sizeof(float);
     p.blocks = (npairs * g.nsplit + 3) / 4;
-    {
-        const char *f = getenv("CPG_WW_XCD");
-        g.xcd = f == nullptr || f[0] != '0';
-    }
+    g.xcd = opt_or(OPT_WW_XCD, 1) != 0;
+    // shared staging of the x rows (wide maps): the four units of a block are consecutive (split, cb, kb) with kb fastest -- all four
+    // share cb when there are >= 4 output-channel blocks (a multiple of 4), pairs of them when there are 2 (mod 4); every block must be
+    // whole (no wave may leave early: the variant has a barrier per stage).  CPG_WW_SHARE = 0 / 2 / 4 overrides.
+    p.gs = 0;
+    if (!p.narrow && npairs % 4 == 0) p.gs = g.nkb % 4 == 0 ? 4 : (g.nkb % 2 == 0 ? 2 : 0);
+    if (const int f = opt(OPT_WW_SHARE); f != OPT_UNSET && (f == 0 || (p.gs != 0 && (f == 2 || (f == 4 && p.gs == 4))))) p.gs = f;
     return p.blocks <= 0x7FFFFFFFll;
 }
 
@@ -366,6 +423,10 @@ extern "C" int cpg_conv3x3_wino_wgrad(const cpg_conv_desc *d, const float *x, co
         return fail(CPG_E_WORKSPACE, "cpg_conv2d_wgrad(winograd): workspace %zu < %zu bytes", ws_bytes, p.ws_bytes);
     if (p.narrow)
         hipLaunchKernelGGL(k_wgw<true>, dim3((unsigned)p.blocks), dim3(256), 0, stream, p.g, x, gy, (float *)ws);
+    else if (p.gs == 4)
+        hipLaunchKernelGGL((k_wgw<false, 4>), dim3((unsigned)p.blocks), dim3(256), 0, stream, p.g, x, gy, (float *)ws);
+    else if (p.gs == 2)
+        hipLaunchKernelGGL((k_wgw<false, 2>), dim3((unsigned)p.blocks), dim3(256), 0, stream, p.g, x, gy, (float *)ws);
     else
         hipLaunchKernelGGL(k_wgw<false>, dim3((unsigned)p.blocks), dim3(256), 0, stream, p.g, x, gy, (float *)ws);
     Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};
