@@ -118,12 +118,13 @@ _SIGNATURES = {
                                                   _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'cpg_bn_stats_finalize': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                              ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),
+    'cpg_bn_add_relu_mask_bytes': (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'cpg_bn_add_relu_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32,
-                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
+                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp, _vp]),
     'cpg_bn_relu_pool3_supported': (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32]),
     'cpg_bn_relu_pool3_fwd': (ctypes.c_int, [_vp] * 6 + [ctypes.c_int32] * 4 + [_vp]),
     'cpg_bn_relu_pool3_bwd': (ctypes.c_int, [_vp] * 9 + [ctypes.c_int32] * 5 + [_vp, ctypes.c_size_t, _vp]),
-    'cpg_bn_add_relu_bwd': (ctypes.c_int, [_vp] * 11 + [ctypes.c_int32] * 4 + [_vp, ctypes.c_size_t, _vp]),
+    'cpg_bn_add_relu_bwd': (ctypes.c_int, [_vp] * 11 + [ctypes.c_int32] * 4 + [_vp, ctypes.c_size_t, _vp, _vp]),
     'cpg_prelu_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp]),
     'cpg_prelu_bwd_bias': (ctypes.c_int, [_vp] * 6 + [ctypes.c_int32] * 4 + [_vp, ctypes.c_size_t, _vp]),
     'cpg_prelu_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),

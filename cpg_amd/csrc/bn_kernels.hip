@@ -138,11 +138,14 @@ __global__ void k_bn_finalize(const double *__restrict__ partial, BnDims d, floa
 // GROUP threads (a whole block, or one wave for small feature maps) own one (n, c) plane at a time, so the
 // four per-channel scalars sit in registers and every access is a contiguous 16 B per lane.
 // `res` (may be null): a residual added before the ReLU -- the tail of a ResNet block, relu(bn3(conv3) + identity).
+// `mask` (may be null; needs 4 | HW and 16-byte aligned tensors): one byte per float4 of y whose bits 0-3 say which of its four
+// elements are > 0 -- the ReLU mask the backward of relu(bn(x) + res) needs (it cannot be recomputed from x alone), at 1/16 of the
+// bytes of the output it would otherwise re-read.
 template <bool RELU, int GROUP>
 __global__ __launch_bounds__(kThreads) void k_bn_apply(const float *__restrict__ x, const float *__restrict__ res,
                                                        float *__restrict__ y, BnDims d, const float *__restrict__ mean,
                                                        const float *__restrict__ invstd, const float *__restrict__ gamma,
-                                                       const float *__restrict__ beta) {
+                                                       const float *__restrict__ beta, uint8_t *__restrict__ mask = nullptr) {
     const int64_t planes = (int64_t)d.N * d.C;
     const bool vec = (d.HW & 3) == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 15) == 0 && (((uintptr_t)res) & 15) == 0;
     const int gl = threadIdx.x % GROUP;
@@ -168,6 +171,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const float *__restrict__
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 }
                 reinterpret_cast<float4 *>(q)[i] = v;
+                if (mask != nullptr)
+                    mask[pl * (d.HW >> 2) + i] = (uint8_t)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0));
             }
         } else {
             for (int i = gl; i < d.HW; i += GROUP) {
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_reduce(const float *__restr
                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
                                                             double *__restrict__ partial, const float *__restrict__ out = nullptr,
-                                                            float *__restrict__ gz = nullptr) {
+                                                            float *__restrict__ gz = nullptr, const uint8_t *__restrict__ mask = nullptr) {
     __shared__ double red[4];
     const int c = blockIdx.x, s = blockIdx.y;
     const int n0 = s * d.imgs_per_slice, n1 = min(d.N, n0 + d.imgs_per_slice);
@@ -206,7 +211,19 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_reduce(const float *__restr
     };
     if (MASKY) {
         const bool vec3 = vec && (((uintptr_t)out) & 15) == 0 && (((uintptr_t)gz) & 15) == 0;
-        if (vec3)
+        if (vec && mask != nullptr && (((uintptr_t)gz) & 15) == 0)
+            // the forward left one byte per float4 of `out` (bits 0-3: element > 0): 1/16 of the bytes of re-reading `out`
+            walk_planes(d.HW >> 2, n0, n1, [&](int n, int j) {
+                const int64_t q4 = ((int64_t)n * d.C + c) * (d.HW >> 2) + j, off = 4 * q4;
+                const float4 xv = *reinterpret_cast<const float4 *>(x + off);
+                float4 gv = *reinterpret_cast<const float4 *>(gy + off);
+                const unsigned mb = mask[q4];
+                gv.x = (mb & 1u) ? gv.x : 0.f; gv.y = (mb & 2u) ? gv.y : 0.f;
+                gv.z = (mb & 4u) ? gv.z : 0.f; gv.w = (mb & 8u) ? gv.w : 0.f;
+                *reinterpret_cast<float4 *>(gz + off) = gv;
+                visit(xv.x, gv.x); visit(xv.y, gv.y); visit(xv.z, gv.z); visit(xv.w, gv.w);
+            }, flush);
+        else if (vec3)
             walk_planes(d.HW >> 2, n0, n1, [&](int n, int j) {
                 const int64_t off = ((int64_t)n * d.C + c) * d.HW + 4 * j;
                 const float4 xv = *reinterpret_cast<const float4 *>(x + off);
@@ -318,11 +335,11 @@ unsigned plane_grid(const BnDims &d) {
 }
 template <bool RELU>
 void launch_apply(const BnDims &d, const float *x, float *y, const float *mean, const float *invstd, const float *gamma,
-                  const float *beta, hipStream_t stream, const float *res = nullptr) {
+                  const float *beta, hipStream_t stream, const float *res = nullptr, uint8_t *mask = nullptr) {
     if (wave_planes(d))
-        hipLaunchKernelGGL((k_bn_apply<RELU, 64>), dim3(plane_grid(d)), dim3(kThreads), 0, stream, x, res, y, d, mean, invstd, gamma, beta);
+        hipLaunchKernelGGL((k_bn_apply<RELU, 64>), dim3(plane_grid(d)), dim3(kThreads), 0, stream, x, res, y, d, mean, invstd, gamma, beta, mask);
     else
-        hipLaunchKernelGGL((k_bn_apply<RELU, 256>), dim3(plane_grid(d)), dim3(kThreads), 0, stream, x, res, y, d, mean, invstd, gamma, beta);
+        hipLaunchKernelGGL((k_bn_apply<RELU, 256>), dim3(plane_grid(d)), dim3(kThreads), 0, stream, x, res, y, d, mean, invstd, gamma, beta, mask);
 }
 template <bool RELU, bool TRAIN>
 void launch_bwd_apply(const BnDims &d, const float *x, const float *gy, float *gx, const float *mean, const float *invstd,
@@ -482,9 +499,14 @@ extern "C" int cpg_bn_bwd_finalize_partials(const float *partials, int32_t tiles
 
 // y = relu(bn(x) + res): the tail of a residual block (models/resnet.py: `out = bn3(conv3(out)); out += identity;
 // relu(out)`) in the same two passes as plain BN -- 3 activation passes instead of 8 for the stock bn / add_ / relu_.
+// relu_mask (may be NULL; cpg_bn_add_relu_mask_bytes(N, C, HW) bytes, 0 = this shape has no mask): receives the ReLU mask of y, one byte
+// per four elements, for cpg_bn_add_relu_bwd.
+extern "C" size_t cpg_bn_add_relu_mask_bytes(int32_t N, int32_t C, int32_t HW) {
+    return (N > 0 && C > 0 && HW > 0 && HW % 4 == 0) ? (size_t)N * C * (HW / 4) : 0;
+}
 extern "C" int cpg_bn_add_relu_fwd(const float *x, const float *res, const float *gamma, const float *beta, float eps, float momentum,
                                    float *running_mean, float *running_var, float *mean, float *invstd, float *y, int32_t N,
-                                   int32_t C, int32_t HW, int32_t train, void *ws, size_t ws_bytes, void *stream_v) {
+                                   int32_t C, int32_t HW, int32_t train, void *ws, size_t ws_bytes, void *stream_v, uint8_t *relu_mask) {
     BnDims d;
     int rc = make_dims(N, C, HW, d);
     if (rc) return rc;
@@ -499,7 +521,10 @@ extern "C" int cpg_bn_add_relu_fwd(const float *x, const float *res, const float
         hipLaunchKernelGGL(k_bn_finalize, dim3((C + 63) / 64), dim3(64), 0, stream, partial, d, eps, momentum, mean, invstd,
                            running_mean, running_var);
     }
-    launch_apply<true>(d, x, y, mean, invstd, gamma, beta, stream, res);
+    if (relu_mask != nullptr)
+        CPG_REQUIRE(HW % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res)) & 15) == 0,
+                    "cpg_bn_add_relu_fwd: the ReLU mask needs 4 | HW and 16-byte aligned tensors");
+    launch_apply<true>(d, x, y, mean, invstd, gamma, beta, stream, res, relu_mask);
     CPG_CHECK_LAUNCH("cpg_bn_add_relu_fwd");
     return CPG_OK;
 }
@@ -533,19 +558,23 @@ extern "C" int cpg_bn_relu_bwd(const float *x, const float *gy, const float *gam
 // the residual branch AND of bn(x); one pass reads x, gy, out, writes gz and reduces {sum gz, sum gz * xhat}, the second applies
 // the BatchNorm gradient from x and gz -- 7 activation passes where threshold_backward + cpg_bn_relu_bwd made 8 (and one launch
 // of a stock elementwise kernel less).  gz must NOT alias gy (the kernel declares both __restrict__).
+// relu_mask (round 4, may be NULL): the byte mask cpg_bn_add_relu_fwd wrote; with it `out` is not read (and may be NULL) -- 6 1/16 passes.
 extern "C" int cpg_bn_add_relu_bwd(const float *x, const float *out, const float *gy, const float *gamma, const float *beta,
                                    const float *mean, const float *invstd, float *gx, float *gz, float *dgamma, float *dbeta, int32_t N,
-                                   int32_t C, int32_t HW, int32_t train, void *ws, size_t ws_bytes, void *stream_v) {
+                                   int32_t C, int32_t HW, int32_t train, void *ws, size_t ws_bytes, void *stream_v, const uint8_t *relu_mask) {
     BnDims d;
     int rc = make_dims(N, C, HW, d);
     if (rc) return rc;
-    CPG_REQUIRE(x && out && gy && gamma && beta && mean && invstd && gx && gz && dgamma && dbeta && ws, "cpg_bn_add_relu_bwd: null pointer");
+    CPG_REQUIRE(x && (out || relu_mask) && gy && gamma && beta && mean && invstd && gx && gz && dgamma && dbeta && ws, "cpg_bn_add_relu_bwd: null pointer");
+    if (relu_mask != nullptr)
+        CPG_REQUIRE(HW % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)gy) | ((uintptr_t)gz)) & 15) == 0,
+                    "cpg_bn_add_relu_bwd: the ReLU mask needs 4 | HW and 16-byte aligned tensors");
     if (ws_bytes < cpg_bn_workspace_bytes(N, C, HW)) return fail(CPG_E_WORKSPACE, "cpg_bn_add_relu_bwd: workspace too small");
     hipStream_t stream = (hipStream_t)stream_v;
     double *partial = (double *)ws;
     float *coef = (float *)(partial + (size_t)C * d.slices * 2);
     hipLaunchKernelGGL((k_bn_bwd_reduce<false, true>), dim3(C, d.slices), dim3(kThreads), 0, stream, x, gy, d, mean, invstd, gamma, beta,
-                       partial, out, gz);
+                       partial, out, gz, relu_mask);
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 63) / 64), dim3(64), 0, stream, partial, d, dgamma, dbeta, coef);
     if (train) launch_bwd_apply<false, true>(d, x, gz, gx, mean, invstd, gamma, beta, coef, stream);
     else launch_bwd_apply<false, false>(d, x, gz, gx, mean, invstd, gamma, beta, coef, stream);

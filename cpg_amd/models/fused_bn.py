@@ -138,20 +138,32 @@ class _BnAddReluFn(torch.autograd.Function):
         else:
             mean, invstd = running_mean, torch.rsqrt(running_var + eps)
             ws, nb = None, 0
+        # the backward's ReLU mask as one byte per four outputs, written by the forward pass (the backward then does not re-read y)
+        mask = None
+        nmask = L.cpg_bn_add_relu_mask_bytes(N, C, HW) if (RELU_BYTE_MASK and any(ctx.needs_input_grad)) else 0
+        if nmask and x.data_ptr() % 16 == 0 and res.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0:
+            mask = torch.empty(nmask, dtype=torch.uint8, device=x.device)
         rc = L.cpg_bn_add_relu_fwd(_lib.dptr(x, name='input'), _lib.dptr(res, name='residual'), _lib.dptr(gamma), _lib.dptr(beta),
                                    float(eps), float(momentum), _lib.dptr(None if apply_only else running_mean),
                                    _lib.dptr(None if apply_only else running_var), _lib.dptr(mean), _lib.dptr(invstd), _lib.dptr(y),
-                                   N, C, HW, int(not apply_only), _lib.dptr(ws), nb, _lib.stream_ptr())
+                                   N, C, HW, int(not apply_only), _lib.dptr(ws), nb, _lib.stream_ptr(), _lib.dptr(mask, torch.uint8))
         _lib.check('cpg_bn_add_relu_fwd', rc)
-        ctx.save_for_backward(x, y, gamma, beta, mean, invstd)
+        if mask is not None:
+            ctx.save_for_backward(x, mask, gamma, beta, mean, invstd)
+        else:
+            ctx.save_for_backward(x, y, gamma, beta, mean, invstd)
+        ctx.has_mask = mask is not None
         ctx.cfg = (N, C, HW, bool(training))
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        mask, y = (y, None) if ctx.has_mask else (None, y)
         N, C, HW, training = ctx.cfg
         gy = gy.contiguous()
+        if mask is not None and gy.data_ptr() % 16:
+            gy = gy.clone()
         L = _lib.lib()
         gx = torch.empty_like(x)
         gz = torch.empty_like(x)                       # gy * [y > 0]: the residual branch's gradient, written by the reduction pass
@@ -159,7 +171,7 @@ class _BnAddReluFn(torch.autograd.Function):
         ws, nb = _lib.workspace(L.cpg_bn_workspace_bytes(N, C, HW), x.device)
         rc = L.cpg_bn_add_relu_bwd(_lib.dptr(x), _lib.dptr(y), _lib.dptr(gy, name='grad_output'), _lib.dptr(gamma), _lib.dptr(beta),
                                    _lib.dptr(mean), _lib.dptr(invstd), _lib.dptr(gx), _lib.dptr(gz), _lib.dptr(dgamma), _lib.dptr(dbeta),
-                                   N, C, HW, int(training), _lib.dptr(ws), nb, _lib.stream_ptr())
+                                   N, C, HW, int(training), _lib.dptr(ws), nb, _lib.stream_ptr(), _lib.dptr(mask, torch.uint8))
         _lib.check('cpg_bn_add_relu_bwd', rc)
         return gx, gz, dgamma, dbeta, None, None, None, None, None, None
 
@@ -378,6 +390,7 @@ def prelu(mod, x, res=None):
     return y if res is None else res + y
 
 
+RELU_BYTE_MASK = True   # relu(bn(x) + res): the forward leaves the ReLU mask as one byte per four outputs for the backward
 ENABLED = True      # module-wide switch (tests compare the fused against the stock evaluation)
 
 

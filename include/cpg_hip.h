@@ -345,18 +345,19 @@ int cpg_stem_bn_relu_bwd_wgrad(const cpg_conv_desc *desc, const float *x, const 
 
 /* y = relu(bn(x) + res): the tail of a residual block (models/resnet.py:69-74 `out = self.bn3(out); out += identity;
  * out = self.relu(out)`).  train != 0: batch statistics (mean / invstd out, running stats updated); train == 0: `mean`
- * / `invstd` are inputs.  Backward = relu mask from y, then cpg_bn_relu_bwd(relu = 0); the residual's gradient is the
- * masked gradient itself. */
+ * / `invstd` are inputs.  relu_mask (may be NULL; cpg_bn_add_relu_mask_bytes() bytes, 0 = no mask for this shape: 4 must divide HW)
+ * receives the ReLU mask of y, one byte per four consecutive elements (bit j: element 4 i + j > 0), for cpg_bn_add_relu_bwd. */
+size_t cpg_bn_add_relu_mask_bytes(int32_t N, int32_t C, int32_t HW);
 int cpg_bn_add_relu_fwd(const float *x, const float *res, const float *gamma, const float *beta, float eps,
                         float momentum, float *running_mean, float *running_var, float *mean, float *invstd, float *y,
-                        int32_t N, int32_t C, int32_t HW, int32_t train, void *ws, size_t ws_bytes, void *stream);
+                        int32_t N, int32_t C, int32_t HW, int32_t train, void *ws, size_t ws_bytes, void *stream, uint8_t *relu_mask);
 /* Backward of cpg_bn_add_relu_fwd (out = relu(bn(x) + residual), the tail of a residual block, models/resnet.py:62-71,96-104 --
- * stock torch: threshold_backward, then the BatchNorm backward, 8 passes): gz = gy * [out > 0] (the residual branch's gradient, may
- * alias gy) is written by the reduction pass that also needs it, gx is the BatchNorm input gradient.  7 passes. */
+ * stock torch: threshold_backward, then the BatchNorm backward, 8 passes): gz = gy * [out > 0] (the residual branch's gradient; must
+ * not alias gy) is written by the reduction pass that also needs it, gx is the BatchNorm input gradient.  7 passes -- 6 1/16 with
+ * relu_mask (the forward's byte mask; `out` is then not read and may be NULL), 6 % of a ResNet-50 step's BatchNorm traffic. */
 int cpg_bn_add_relu_bwd(const float *x, const float *out, const float *gy, const float *gamma, const float *beta,
-                        const float *mean, const float *invstd, float *gx, float *gz, float *dgamma, float *dbeta,
-                        int32_t N, int32_t C, int32_t HW, int32_t train, void *workspace, size_t workspace_bytes,
-                        void *stream);
+                        const float *mean, const float *invstd, float *gx, float *gz, float *dgamma, float *dbeta, int32_t N,
+                        int32_t C, int32_t HW, int32_t train, void *ws, size_t ws_bytes, void *stream, const uint8_t *relu_mask);
 
 /* BatchNorm2d -> ReLU -> MaxPool2d(2, 2) fused (the 5 VGG blocks that end in 'M', models/vgg.py:131-141).
  * y_pooled / g_pooled: [N][C][H/2][W/2]; H and W even.  train != 0: batch statistics are computed (and

@@ -1837,6 +1837,42 @@ def test_resnet_block_fused_bn_equals_stock_bn(block, stride):
         assert float(np.abs(g1[n] - g0[n]).max()) <= 1e-3 * sc, n
 
 
+@pytest.mark.parametrize('N,C,H,W', [(6, 24, 28, 28), (3, 16, 56, 56), (5, 8, 14, 14), (2, 8, 7, 7), (130, 4, 12, 20)])
+def test_bn_add_relu_byte_mask_equals_reading_the_output(N, C, H, W, monkeypatch):
+    """relu(bn(x) + res), the tail of a residual block: with the forward's byte mask (one byte per four outputs, round 4) the backward
+    must produce what it produces from the saved output -- the same masked gradient bit for bit, the same BatchNorm sums; shapes whose
+    plane is not a multiple of 4 (7 x 7) have no mask and take the old path."""
+    from cpg_amd.models import fused_bn
+    g = torch.Generator().manual_seed(N * C + H)
+    x = torch.randn(N, C, H, W, generator=g).to(DEV)
+    res = torch.randn(N, C, H, W, generator=g).to(DEV)
+    gy = torch.randn(N, C, H, W, generator=g).to(DEV)
+    outs = {}
+    for use_mask in (True, False):
+        monkeypatch.setattr(fused_bn, 'RELU_BYTE_MASK', use_mask)
+        bn = nn.BatchNorm2d(C).to(DEV).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+        xd, rd = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        y = fused_bn.bn_add_act(bn, nn.ReLU(), xd, rd)
+        y.backward(gy)
+        outs[use_mask] = (y.detach().clone(), xd.grad.clone(), rd.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+    # output and masked gradient: exactly equal; the BatchNorm sums run through differently compiled copies of the same expression
+    # (a select feeding a fused multiply-add): equal to the last bits
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][2], outs[False][2])
+    for a, b in zip(outs[True], outs[False]):
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+    bn = nn.BatchNorm2d(C).to(DEV).train().double()
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, C))
+        bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+    yr = torch.relu(bn(x.double()) + res.double())
+    assert float((outs[True][0].double() - yr).abs().max()) <= 2e-5 * float(yr.abs().max())
+    # the residual's gradient is the masked gradient itself: exactly gy where the output is positive, exactly 0 elsewhere
+    assert torch.equal(outs[True][2], torch.where(outs[True][0] > 0, gy, torch.zeros_like(gy)))
+
+
 def test_conv_prelu_bias_gradient_from_the_prelu_backward():
     """SphereNet's biased conv -> PReLU pair (models/spherenet.py:203-247): the conv's bias gradient comes out of the PReLU's backward
     pass (cpg_prelu_bwd_bias) instead of a reduction pass over the conv's output gradient -- same gradients as the plain composition."""
