@@ -79,7 +79,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ part) {
     static_assert(GS == 0 || (!NARROW && (GS == 2 || GS == 4)), "shared staging: wide maps, groups of 2 or 4 waves");
     constexpr int NG = GS ? 4 / GS : 0;                          // x-sharing groups per block
-    __shared__ __attribute__((aligned(16))) float smem_all[GS ? NG * 2 * WW_XS + 4 * 32 * WW_GC : 4 * WW_STAGE];
+    // TS (GS == 4): the four waves of a group also SHARE THE INPUT TRANSFORM.  Their B operands are the same 16 values per lane (the
+    // transformed patch of input channel li for the lane's tile): wave w computes transform row w only -- two patch rows, 4 + 4 adds
+    // instead of four rows and 32 --, leaves its four values in a shared, double-buffered LDS array (one 16-byte store) and reads
+    // all sixteen back after a barrier (four 16-byte reads): 20 instead of 44 vector-ALU instructions per k-step (on this chip
+    // each one is fp32-MFMA issue time), the same sums bit for bit.
+    constexpr bool TS = GS == 4;
+    constexpr int WW_BS = 2 * 16 * 64;                           // floats of the shared-B array of one group: [buffer][position quad][lane][4]
+    __shared__ __attribute__((aligned(16))) float smem_all[GS ? NG * 2 * WW_XS + 4 * 32 * WW_GC + (TS ? WW_BS : 0) : 4 * WW_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int gw = GS ? wave % GS : 0;                           // this wave's index within its x-sharing group
@@ -88,6 +95,7 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
     float *xb0 = GS ? smem_all + (wave / (GS ? GS : 1)) * 2 * WW_XS : smem;
     float *xb1 = GS ? xb0 + WW_XS : smem;
     float *gyp = GS ? smem_all + NG * 2 * WW_XS + wave * 32 * WW_GC : smem + WW_XS;
+    float *bsh = smem_all + NG * 2 * WW_XS + 4 * 32 * WW_GC;      // (TS only)
     const int HW = g.H * g.W;
     const unsigned npairs = (unsigned)(g.nkb * g.ncb);
     const unsigned u = (g.xcd ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x) * 4 + wave;
@@ -281,6 +289,34 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
         }
     };
 
+    // ---- TS: this wave's share of the input transform, in 7 micro steps (0, 1: read the two patch rows the wave's transform row needs;
+    // 2: column + row pass of that row, store; [barrier]; 3-6: read back the sixteen values) ----
+    // transform row w of B^T d: w = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3  ->  d[ra] + sg * d[rb]
+    const int b_ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1), b_rb = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
+    const float b_sg = wave == 1 ? 1.0f : -1.0f;
+    float ta[4], tb[4];
+    auto b_micro = [&](int m, int ks, int buf, float (&B)[16], const float *xb) {
+        if (m < 2) {
+            const float *r = xb + xr_base + kKs * ks + (m == 0 ? b_ra : b_rb) * WW_XR;
+            const f32x2 own = *reinterpret_cast<const f32x2 *>(r);
+            const f32x2 lo = *reinterpret_cast<const f32x2 *>(r - 2), hi = *reinterpret_cast<const f32x2 *>(r + 2);
+            float (&t)[4] = m == 0 ? ta : tb;
+            t[0] = lo[1], t[1] = own[0], t[2] = own[1], t[3] = hi[0];
+        } else if (m == 2) {
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = __builtin_fmaf(b_sg, tb[j], ta[j]);       // (sg = +-1: exactly the add / subtract)
+            f32x4 v;
+            v[0] = e[0] - e[2], v[1] = e[1] + e[2], v[2] = e[2] - e[1], v[3] = e[1] - e[3];
+            *reinterpret_cast<f32x4 *>(bsh + ((buf * 4 + wave) * 64 + lane) * 4) = v;
+        } else {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(bsh + ((buf * 4 + (m - 3)) * 64 + lane) * 4);
+            B[(m - 3) * 4 + 0] = v[0], B[(m - 3) * 4 + 1] = v[1], B[(m - 3) * 4 + 2] = v[2], B[(m - 3) * 4 + 3] = v[3];
+        }
+    };
+    // workgroup barrier that waits for this wave's LDS traffic only (__syncthreads would also wait for the stage loads in flight)
+#define WW_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
     WW_STAMP(1);
 @@ZERO@@
     float A0[16], B0[16], A1[16], B1[16];
@@ -299,8 +335,17 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
         for (int i = 0; i < (NARROW ? 48 : 28); ++i) w_store(i);
     }
     advance_stage();
+    if constexpr (TS) {
 #pragma unroll
-    for (int m = 0; m < 14; ++m) t_micro(m, 0, A0, B0, xb0);
+        for (int m = 0; m < 3; ++m) b_micro(m, 0, 0, B0, xb0);
+        WW_LDS_BARRIER();
+#pragma unroll
+        for (int m = 3; m < 7; ++m) b_micro(m, 0, 0, B0, xb0);
+        t_micro(4, 0, A0, B0, xb0), t_micro(11, 0, A0, B0, xb0), t_micro(12, 0, A0, B0, xb0), t_micro(13, 0, A0, B0, xb0);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 14; ++m) t_micro(m, 0, A0, B0, xb0);
+    }
 
     WW_STAMP(2);
     for (int st = 0; st < nst; st += 2) {

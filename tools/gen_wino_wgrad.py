@@ -17,18 +17,29 @@ out_calls = ''.join('        WW_RD_%d(m); out_e(%d, m);\n' % (e, e) for e in ran
 
 # slot tables: for k-steps 0..5: slot p -> T micro p (0..13), G loads on k-steps 1, 2
 # (narrow = the 14-pixel-wide maps: 48 eight-byte loads / stores per stage instead of 28 sixteen-byte ones)
-def kstep(ks, cur, nxt, narrow=False, gs=0, half=0):
+def kstep(ks, cur, nxt, narrow=False, gs=0, half=0, kk=0):
     """gs > 0: the shared-staging variants (GS = gs): NSI = 16 / gs + 8 + 4 / gs items per wave and stage instead of 28; the x rows of the
     stage in flight live in buffer `half` (xb0 / xb1), the next stage's go into the other one, a workgroup barrier between the stores and
-    the next stage's first operand reads."""
+    the next stage's first operand reads.  gs == 4 also shares the input transform (b_micro: 7 micro steps + a barrier per k-step; the
+    shared-B buffer of the operands made during body k-step kk, for k-step kk + 1, is (kk + 1) & 1)."""
     lines = []
     xcur, xnxt = ('xb%d' % half, 'xb%d' % (half ^ 1))
     nsi = (16 // gs + 8 + 4 // gs) if gs else 0
     per = -(-nsi // 7) if gs else 0
+    ts = gs == 4
+    bb = (kk + 1) & 1
     for p in range(16):
         work = []
         if ks < 6:
-            if p < 14: work.append('t_micro(%d, %d, A%s, B%s, %s)' % (p, ks + 1, nxt, nxt, xcur))
+            if ts:
+                tm = {0: 'b_micro(0, %d, %d, B%s, %s)', 1: 'b_micro(1, %d, %d, B%s, %s)', 3: 'b_micro(2, %d, %d, B%s, %s)',
+                      8: 'b_micro(3, %d, %d, B%s, %s)', 9: 'b_micro(4, %d, %d, B%s, %s)', 10: 'b_micro(5, %d, %d, B%s, %s)',
+                      11: 'b_micro(6, %d, %d, B%s, %s)'}
+                am = {2: 4, 4: 11, 5: 12, 6: 13}
+                if p in tm: work.append(tm[p] % (ks + 1, bb, nxt, xcur))
+                if p in am: work.append('t_micro(%d, %d, A%s, B%s, %s)' % (am[p], ks + 1, nxt, nxt, xcur))
+                if p == 7: work.append('WW_LDS_BARRIER()')
+            elif p < 14: work.append('t_micro(%d, %d, A%s, B%s, %s)' % (p, ks + 1, nxt, nxt, xcur))
             if gs:
                 if ks == 1 and p < min(14, nsi): work.append('g_load_s(%d)' % p)
                 if ks == 2 and p < nsi - 14: work.append('g_load_s(%d)' % (14 + p))
@@ -37,11 +48,25 @@ def kstep(ks, cur, nxt, narrow=False, gs=0, half=0):
             else:
                 if ks == 1 and p < 14: work.append('g_load(%d, nst_idx)' % p)
                 if ks == 2 and p < 14: work.append('g_load(%d, nst_idx)' % (14 + p))
+        elif ts:
+            # last k-step of a stage: the next stage's rows into the other x buffer (13 items over slots 0-5), stage barrier, then the
+            # first operands of the next stage from that buffer
+            sl = {0: [0, 1, 2], 1: [3, 4], 2: [5, 6], 3: [7, 8], 4: [9, 10], 5: [11, 12]}
+            if p in sl: work.append('; '.join('w_store_s(%d, %s)' % (i, xnxt) for i in sl[p]))
+            if p == 6: work.append('WW_LDS_BARRIER()')
+            if p == 7: work.append('b_micro(0, 0, %d, B%s, %s)' % (bb, nxt, xnxt))
+            if p == 8: work.append('b_micro(1, 0, %d, B%s, %s)' % (bb, nxt, xnxt))
+            if p == 9: work.append('t_micro(4, 0, A%s, B%s, %s)' % (nxt, nxt, xnxt))
+            if p == 10: work.append('b_micro(2, 0, %d, B%s, %s)' % (bb, nxt, xnxt))
+            if p == 11: work.append('; '.join('t_micro(%d, 0, A%s, B%s, %s)' % (m, nxt, nxt, xnxt) for m in (11, 12, 13)))
+            if p == 12: work.append('WW_LDS_BARRIER()')
+            if p == 13: work.append('; '.join('b_micro(%d, 0, %d, B%s, %s)' % (m, bb, nxt, xnxt) for m in (3, 4)))
+            if p == 14: work.append('; '.join('b_micro(%d, 0, %d, B%s, %s)' % (m, bb, nxt, xnxt) for m in (5, 6)))
         else:
             if p < 7 and gs:
                 items = [per * p + q for q in range(per) if per * p + q < nsi]
                 work.append('; '.join('w_store_s(%d, %s)' % (i, xnxt) for i in items))
-                if p == 6: work.append('__syncthreads()')
+                if p == 6: work.append('WW_LDS_BARRIER()')
             elif p < 7 and narrow: work.append('; '.join('w_store(%d)' % (7 * p + q) for q in range(7) if 7 * p + q < 48))
             elif p < 7: work.append('; '.join('w_store(%d)' % (4 * p + q) for q in range(4)))
             else:
@@ -61,7 +86,7 @@ def make_body(narrow, gs=0):
     if half == 1:
         body += '            if (st + 1 >= nst) break;\n'
     for ks in range(7):
-        body += '            // k-step %d\n' % ks + kstep(ks, sets[cur], sets[cur ^ 1], narrow, gs, half).replace('        WW_', '            WW_')
+        body += '            // k-step %d\n' % ks + kstep(ks, sets[cur], sets[cur ^ 1], narrow, gs, half, 7 * half + ks).replace('        WW_', '            WW_')
         cur ^= 1
     body += '            advance_stage();\n        }\n'
   return body
