@@ -478,6 +478,9 @@ def test_stem_kernel_matches_general_kernel(N, C, H, W, bias, pm, libopt):
     (2, 128, 56, 56, 256, False),      # ... two segments per row (halo items split over the waves), 8 x 4 channel blocks
     (24, 32, 28, 28, 128, False),      # ... several stages per unit (the double buffer, an odd number of stages in the last unit)
     (40, 64, 28, 28, 64, True),        # ... or pairs of waves do (64 output channels: 2 x 2 channel blocks), several stages per unit
+    (5, 64, 14, 14, 128, True),        # ... the narrow variant with shared staging + shared transform: odd image count, piggymask
+    (64, 32, 14, 14, 128, False),      # ... several stages per unit
+    (3, 64, 2, 14, 256, False),        # ... a single tile row, 8 x 2 channel blocks
 ])
 def test_winograd_wgrad_matches_direct(N, C, H, W, K, pm, libopt):
     """The Winograd weight-gradient kernel (conv3x3_wino_wgrad.hip: the default for maps 14 or a multiple of 28 wide with channel

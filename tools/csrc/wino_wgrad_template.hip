@@ -77,7 +77,7 @@ __device__ unsigned long long ww_dbg[65536 * 8];
 template <bool NARROW, int GS = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ part) {
-    static_assert(GS == 0 || (!NARROW && (GS == 2 || GS == 4)), "shared staging: wide maps, groups of 2 or 4 waves");
+    static_assert(GS == 0 || GS == 4 || (!NARROW && GS == 2), "shared staging: groups of 4 waves, or 2 on wide maps");
     constexpr int NG = GS ? 4 / GS : 0;                          // x-sharing groups per block
     // TS (GS == 4): the four waves of a group also SHARE THE INPUT TRANSFORM.  Their B operands are the same 16 values per lane (the
     // transformed patch of input channel li for the lane's tile): wave w computes transform row w only -- two patch rows, 4 + 4 adds
@@ -136,20 +136,21 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
     const int xrow = NARROW ? rem >> 1 : rem & 3, half = rem & 1;
     // (shared staging: wave gw of a group takes the x items j GS + gw and the halo items j GS + gw -- its share of the channel offset is
     //  part of the per-lane constants, so that the item index of a load / store stays a compile-time constant)
-    const int vx_const = NARROW ? (half * g.C * HW + xrow * g.W) * 4 + qd * 8 + 16
+    const int vx_const = NARROW ? (half * g.C * HW + xrow * g.W + gw * HW) * 4 + qd * 8 + 16
                                 : ((rem >> 2) * HW + xrow * g.W + gw * 2 * HW) * 4 + qd * 16 + 16;   // x item (c = 2 j + rem / 4, row = rem % 4)
     const int vg_const = NARROW ? ((rem >> 2) * HW + half * g.K * HW + ((rem >> 1) & 1) * g.W) * 4 + qd * 8
                                 : ((rem >> 1) * HW + (rem & 1) * g.W) * 4 + qd * 16;   // gy item (k = 4 j + rem / 2, row = rem % 2)
     const int hside = lane & 1, hrow = (lane >> 1) & 3;                             // halo item (c = 8 j + lane / 8, row, side)
     const int vh_const = ((lane >> 3) * HW + hrow * g.W + gw * 8 * HW) * 4 + (hside ? 28 * 4 + 16 : 12);
-    const int xw_addr = NARROW ? xrow * WW_XR + 16 * half + 2 + 2 * qd : (rem >> 2) * WW_XC + xrow * WW_XR + 2 + 4 * qd + gw * 2 * WW_XC;
+    const int xw_addr = NARROW ? xrow * WW_XR + 16 * half + 2 + 2 * qd + gw * WW_XC : (rem >> 2) * WW_XC + xrow * WW_XR + 2 + 4 * qd + gw * 2 * WW_XC;
     const int gw_addr = NARROW ? (rem >> 2) * WW_GC + ((rem >> 1) & 1) * WW_GR + 14 * half + 2 * qd          // (relative to gyp)
                                : (rem >> 1) * WW_GC + (rem & 1) * WW_GR + 4 * qd;
     const int hw_addr = (lane >> 3) * WW_XC + hrow * WW_XR + (hside ? 30 : 1) + gw * 8 * WW_XC;
     if constexpr (NARROW) {                                      // the padding columns 0, 1, 16, 17, 32, 33 of every x row
-        for (int i = lane; i < 32 * 4 * 6; i += 64) {
+        for (int i = lane; i < 32 * 4 * 6; i += 64) {                // (shared staging: of both buffers; every wave of the group writes the same zeros)
             const int rowi = i / 6, col = i % 6;
-            smem[(rowi >> 2) * WW_XC + (rowi & 3) * WW_XR + (col >> 1) * 16 + (col & 1)] = 0.0f;
+            xb0[(rowi >> 2) * WW_XC + (rowi & 3) * WW_XR + (col >> 1) * 16 + (col & 1)] = 0.0f;
+            if (GS) xb1[(rowi >> 2) * WW_XC + (rowi & 3) * WW_XR + (col >> 1) * 16 + (col & 1)] = 0.0f;
         }
     }
     int sx, sgo, vx, vg, vh;                                     // stage part of the offsets (scalar) / per-lane part with validity
@@ -226,17 +227,39 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
         }
     };
     // shared staging (GS > 0): item i of this wave = x item j GS + gw (i < XL), gy item i - XL (own 8), halo item j GS + gw
-    constexpr int XL = GS ? 16 / GS : 0, HL = GS ? 4 / GS : 0, NSI = XL + 8 + HL;
+    // (NARROW: 32 / GS eight-byte x items -- one channel each -- and the wave's own 16 gy items, no halo)
+    constexpr int XL = GS ? (NARROW ? 32 : 16) / GS : 0, GL = NARROW ? 16 : 8, HL = (GS && !NARROW) ? 4 / GS : 0, NSI = XL + GL + HL;
     auto g_load_s = [&](int i) {
-        if (i < XL)
-            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_x, vx, sx + i * GS * 2 * HW * 4, 0);
-        else if (i < XL + 8)
-            rg[i - XL] = __builtin_amdgcn_raw_buffer_load_b128(srd_g, vg, sgo + (i - XL) * 4 * HW * 4, 0);
-        else if (i < NSI)
-            rh[i - XL - 8] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, vh, sx + (i - XL - 8) * GS * 8 * HW * 4, 0));
+        if constexpr (NARROW) {
+            i32x2 v;
+            if (i < XL)
+                v = __builtin_amdgcn_raw_buffer_load_b64(srd_x, vx, sx + i * GS * HW * 4, 0);
+            else
+                v = __builtin_amdgcn_raw_buffer_load_b64(srd_g, vg, sgo + (i - XL) * 2 * HW * 4, 0);
+            if (i < XL)
+                rx[i >> 1][2 * (i & 1)] = v[0], rx[i >> 1][2 * (i & 1) + 1] = v[1];
+            else
+                rg[(i - XL) >> 1][2 * ((i - XL) & 1)] = v[0], rg[(i - XL) >> 1][2 * ((i - XL) & 1) + 1] = v[1];
+        } else {
+            if (i < XL)
+                rx[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_x, vx, sx + i * GS * 2 * HW * 4, 0);
+            else if (i < XL + 8)
+                rg[i - XL] = __builtin_amdgcn_raw_buffer_load_b128(srd_g, vg, sgo + (i - XL) * 4 * HW * 4, 0);
+            else if (i < NSI)
+                rh[i - XL - 8] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, vh, sx + (i - XL - 8) * GS * 8 * HW * 4, 0));
+        }
     };
     auto w_store_s = [&](int i, float *xb) {
-        if (i < XL) {
+        if constexpr (NARROW) {
+            i32x2 v;
+            if (i < XL) {
+                v[0] = rx[i >> 1][2 * (i & 1)], v[1] = rx[i >> 1][2 * (i & 1) + 1];
+                *reinterpret_cast<i32x2 *>(xb + xw_addr + i * GS * WW_XC) = v;
+            } else if (i < NSI) {
+                v[0] = rg[(i - XL) >> 1][2 * ((i - XL) & 1)], v[1] = rg[(i - XL) >> 1][2 * ((i - XL) & 1) + 1];
+                *reinterpret_cast<i32x2 *>(gyp + gw_addr + (i - XL) * 2 * WW_GC) = v;
+            }
+        } else if (i < XL) {
             i32x2 *d = reinterpret_cast<i32x2 *>(xb + xw_addr + i * GS * 2 * WW_XC);
             i32x2 lo, hi;
             lo[0] = rx[i][0], lo[1] = rx[i][1], hi[0] = rx[i][2], hi[1] = rx[i][3];
@@ -349,7 +372,9 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
 
     WW_STAMP(2);
     for (int st = 0; st < nst; st += 2) {
-        if constexpr (NARROW) {
+        if constexpr (NARROW && GS == 4) {
+@@BODY_NS4@@
+        } else if constexpr (NARROW) {
 @@BODY_N@@
         } else if constexpr (GS == 4) {
 @@BODY_S4@@
@@ -438,7 +463,7 @@ bool ww_plan(const cpg_conv_desc *d, WwPlan &p) {
     // share cb when there are >= 4 output-channel blocks (a multiple of 4), pairs of them when there are 2 (mod 4); every block must be
     // whole (no wave may leave early: the variant has a barrier per stage).  CPG_WW_SHARE = 0 / 2 / 4 overrides.
     p.gs = 0;
-    if (!p.narrow && npairs % 4 == 0) p.gs = g.nkb % 4 == 0 ? 4 : (g.nkb % 2 == 0 ? 2 : 0);
+    if (npairs % 4 == 0) p.gs = g.nkb % 4 == 0 ? 4 : ((g.nkb % 2 == 0 && !p.narrow) ? 2 : 0);
     if (const int f = opt(OPT_WW_SHARE); f != OPT_UNSET && (f == 0 || (p.gs != 0 && (f == 2 || (f == 4 && p.gs == 4))))) p.gs = f;
     return p.blocks <= 0x7FFFFFFFll;
 }
@@ -466,7 +491,9 @@ extern "C" int cpg_conv3x3_wino_wgrad(const cpg_conv_desc *d, const float *x, co
     if (!ww_plan(d, p)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_wgrad(winograd): shape not supported");
     if (ws == nullptr || ws_bytes < p.ws_bytes)
         return fail(CPG_E_WORKSPACE, "cpg_conv2d_wgrad(winograd): workspace %zu < %zu bytes", ws_bytes, p.ws_bytes);
-    if (p.narrow)
+    if (p.narrow && p.gs == 4)
+        hipLaunchKernelGGL((k_wgw<true, 4>), dim3((unsigned)p.blocks), dim3(256), 0, stream, p.g, x, gy, (float *)ws);
+    else if (p.narrow)
         hipLaunchKernelGGL(k_wgw<true>, dim3((unsigned)p.blocks), dim3(256), 0, stream, p.g, x, gy, (float *)ws);
     else if (p.gs == 4)
         hipLaunchKernelGGL((k_wgw<false, 4>), dim3((unsigned)p.blocks), dim3(256), 0, stream, p.g, x, gy, (float *)ws);

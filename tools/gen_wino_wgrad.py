@@ -24,7 +24,8 @@ def kstep(ks, cur, nxt, narrow=False, gs=0, half=0, kk=0):
     shared-B buffer of the operands made during body k-step kk, for k-step kk + 1, is (kk + 1) & 1)."""
     lines = []
     xcur, xnxt = ('xb%d' % half, 'xb%d' % (half ^ 1))
-    nsi = (16 // gs + 8 + 4 // gs) if gs else 0
+    nsi = ((32 // gs + 16) if narrow else (16 // gs + 8 + 4 // gs)) if gs else 0
+    first = 16 if narrow else 14                 # staging loads that ride in k-step 1 (the rest in k-step 2)
     per = -(-nsi // 7) if gs else 0
     ts = gs == 4
     bb = (kk + 1) & 1
@@ -41,8 +42,8 @@ def kstep(ks, cur, nxt, narrow=False, gs=0, half=0, kk=0):
                 if p == 7: work.append('WW_LDS_BARRIER()')
             elif p < 14: work.append('t_micro(%d, %d, A%s, B%s, %s)' % (p, ks + 1, nxt, nxt, xcur))
             if gs:
-                if ks == 1 and p < min(14, nsi): work.append('g_load_s(%d)' % p)
-                if ks == 2 and p < nsi - 14: work.append('g_load_s(%d)' % (14 + p))
+                if ks == 1 and p < min(first, nsi): work.append('g_load_s(%d)' % p)
+                if ks == 2 and p < nsi - first: work.append('g_load_s(%d)' % (first + p))
             elif narrow:
                 if 1 <= ks <= 3: work.append('g_load(%d, nst_idx)' % (16 * (ks - 1) + p))
             else:
@@ -51,7 +52,12 @@ def kstep(ks, cur, nxt, narrow=False, gs=0, half=0, kk=0):
         elif ts:
             # last k-step of a stage: the next stage's rows into the other x buffer (13 items over slots 0-5), stage barrier, then the
             # first operands of the next stage from that buffer
-            sl = {0: [0, 1, 2], 1: [3, 4], 2: [5, 6], 3: [7, 8], 4: [9, 10], 5: [11, 12]}
+            q6, r6 = divmod(nsi, 6)                # nsi items over slots 0-5
+            sl, nxt_i = {}, 0
+            for k6 in range(6):
+                cnt = q6 + (1 if k6 < r6 else 0)
+                sl[k6] = list(range(nxt_i, nxt_i + cnt))
+                nxt_i += cnt
             if p in sl: work.append('; '.join('w_store_s(%d, %s)' % (i, xnxt) for i in sl[p]))
             if p == 6: work.append('WW_LDS_BARRIER()')
             if p == 7: work.append('b_micro(0, 0, %d, B%s, %s)' % (bb, nxt, xnxt))
@@ -91,10 +97,10 @@ def make_body(narrow, gs=0):
     body += '            advance_stage();\n        }\n'
   return body
 
-body, body_n, body_s4, body_s2 = make_body(False), make_body(True), make_body(False, 4), make_body(False, 2)
+body, body_n, body_s4, body_s2, body_ns4 = make_body(False), make_body(True), make_body(False, 4), make_body(False, 2), make_body(True, 4)
 
 src = open(os.path.join(ROOT, 'tools', 'csrc', 'wino_wgrad_template.hip')).read()
-src = src.replace('@@MMA@@', mma).replace('@@ZERO@@', zero).replace('@@RD@@', rd).replace('@@OUT@@', out_calls).replace('@@BODY@@', body).replace('@@BODY_N@@', body_n).replace('@@BODY_S4@@', body_s4).replace('@@BODY_S2@@', body_s2)
+src = src.replace('@@MMA@@', mma).replace('@@ZERO@@', zero).replace('@@RD@@', rd).replace('@@OUT@@', out_calls).replace('@@BODY@@', body).replace('@@BODY_N@@', body_n).replace('@@BODY_S4@@', body_s4).replace('@@BODY_S2@@', body_s2).replace('@@BODY_NS4@@', body_ns4)
 src = '// GENERATED by tools/gen_wino_wgrad.py from tools/csrc/wino_wgrad_template.hip -- edit those, not this file.\n' + src
 open(os.path.join(ROOT, 'cpg_amd', 'csrc', 'conv3x3_wino_wgrad.hip'), 'w').write(src)
 print('ok', len(src))
