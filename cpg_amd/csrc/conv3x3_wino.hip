@@ -1305,24 +1305,39 @@ void k_wg2(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
 struct Bop {                                  // k_wg3's B operands of one channel: patch rows as register pairs (see T_read1)
     f32x2 P[3], Q[3];
 };
-template <bool DGRAD, bool STATS, bool BNE = false, bool ODD = false>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
+// SH (round 4; even maps, training launches, a multiple of 128 output channels): a block is FOUR waves = TWO units on the SAME tile run
+// (output-channel blocks 2 j, 2 j + 1).  The B operands of a chunk -- the transformed patch of the lane's tile for channels 2 lh, 2 lh + 1 --
+// are the same for both units, so the waves (unit 0, ph) and (unit 1, ph) split them: unit u fetches, stages and transforms channel
+// 2 lh + u only (3 + 1 instead of 6 + 1 row loads and LDS stores, 9 instead of 18 raw reads, 8 instead of 16 packed transform
+// instructions per chunk), leaves its eight operand values in a shared double-buffered LDS array (two 16-byte stores) and both read
+// all sixteen back after a barrier that waits for LDS traffic only (four 16-byte reads).  Everything else -- filter operands,
+// accumulators, the epilogue and its exchange between the two waves of a unit -- is per unit, as before; every sum is bit for bit
+// what the two-wave block computes.
+template <bool DGRAD, bool STATS, bool BNE = false, bool ODD = false, bool SH = false>
+__global__ __launch_bounds__(SH ? 256 : 128) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
            float *__restrict__ y, float *__restrict__ stats, WgBnEval bn) {
-    __shared__ __attribute__((aligned(16))) float smem_all[2 * 64 * 64];       // 2 x 2 raw stages (3264 floats) / the exchange buffer (32 KB)
-    const int tid = threadIdx.x, lane = tid & 63, ph = __builtin_amdgcn_readfirstlane(tid >> 6);
+    static_assert(!SH || (!BNE && !ODD), "shared B operands: training launches on even maps");
+    constexpr int UNITF = 2 * 64 * 64;                       // per unit: 2 x 2 raw stages (3264 floats) / the epilogue's exchange buffer (32 KB)
+    constexpr int BXF = 2 * 2 * 2 * 2 * 64 * 4;              // SH: [buffer][ph][channel j][half][lane][4] transformed operands (16 KB)
+    __shared__ __attribute__((aligned(16))) float smem_all[SH ? 2 * UNITF + BXF : UNITF];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int un = SH ? wv >> 1 : 0, ph = SH ? wv & 1 : wv;   // unit of the block, wave of the unit
     const int li = lane & 31, lh = lane >> 5;
     const int HW = g.H * g.W;
-    float *smem = smem_all + ph * 2 * W2_RAW;                 // this wave's private raw stages
+    float *unit_smem = smem_all + un * UNITF;
+    float *smem = unit_smem + ph * 2 * W2_RAW;                // this wave's private raw stages
+    float *bx = smem_all + 2 * UNITF;                         // (SH only)
 
     // persistent blocks, as in k_wg1 (two blocks of two waves per CU are resident)
-    for (unsigned base = 0; base < g.nblocks; base += gridDim.x) {
+    const unsigned nlb = SH ? g.nblocks >> 1 : g.nblocks;     // SH: pairs of logical blocks (the host only sends an even number of channel blocks)
+    for (unsigned base = 0; base < nlb; base += gridDim.x) {
     // (virtual block v runs on XCD v % 8 = blockIdx % 8 -- the grid is a multiple of 8 blocks whenever there is more than one
     //  round -- and XCD x owns the x-th eighth of ALL logical blocks, walking through it round after round: consecutive tile runs,
     //  which share half of their input rows, stay in one XCD's L2 as with one block per logical block)
     const unsigned v = base + blockIdx.x;
-    if (v >= g.nblocks) break;
-    const unsigned lb = xcd_remap(v, g.nblocks);
+    if (v >= nlb) break;
+    const unsigned lb = SH ? 2 * xcd_remap(v, nlb) + (unsigned)un : xcd_remap(v, nlb);
     const int nkb64 = (g.nkb + 1) / 2;                        // (g.nkb counts blocks of 32 channels)
     const int kb = lb % nkb64;                                // block of 64 output channels
     const unsigned ttot = (unsigned)g.tiles_total, timg = (unsigned)g.tiles_img, twu = (unsigned)g.tw;
@@ -1415,6 +1430,23 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         } else if (lane < 24)
             raw[halo_w] = q.halo;
     };
+    // SH: this wave stages channel 2 lh + un only (k = 0..2: its three patch rows; k = 3: the halo values, all four channels as before)
+    const int un_goff = un * HW * 4;
+    const int raw_own_s = raw_own + un * 3 * W1_ROW, tr_base = ((2 * lh + un) * 3) * W1_ROW;
+    auto G_rows = [&](int ch, Rows &q, int k) {
+        const int soff = ch * WG_CK * HW * 4;
+        if (k < 3)
+            q.r[0][k] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[k], soff + un_goff, 0);
+        else
+            q.halo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, hoff, soff, 0));
+    };
+    auto W_rows = [&](int stage, const Rows &q, int k) {
+        float *raw = smem + stage * W2_RAW;
+        if (k < 3)
+            *reinterpret_cast<i32x2 *>(raw + raw_own_s + k * W1_ROW) = q.r[0][k];
+        else if (lane < 24)
+            raw[halo_w] = q.halo;
+    };
     // Wave ph = 1 keeps its two transform rows in REVERSE order (local row 0 = row 3, local row 1 = row 2) AND its three patch rows
     // in reverse order (e0, e1, e2 = patch rows 3, 2, 1; wave 0: 0, 1, 2): then local row 0 of B^T d is e0 - e2 for both waves
     // (= row 0 = d0 - d2 for wave 0, = -(row 3) = d3 - d1 for wave 1) and local row 1 is e1 + sgn e2 (row 1 = d1 + d2, row 2 =
@@ -1439,6 +1471,26 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         d.P[i] = *reinterpret_cast<const f32x2 *>(raw + (li + 1) * 2);
         d.Q[i][0] = raw[lo], d.Q[i][1] = raw[ro];
     };
+    auto T_reads = [&](int stage, Bop &d, int i) {            // SH: patch row i of this wave's channel 2 lh + un
+        const float *raw = smem + stage * W2_RAW + tr_base + i * W1_ROW;
+        d.P[i] = *reinterpret_cast<const f32x2 *>(raw + (li + 1) * 2);
+        d.Q[i][0] = raw[lo], d.Q[i][1] = raw[ro];
+    };
+    // SH: the transformed operands of channel 2 lh + un (local rows 0, 1: P and Q pairs) go to bx[buffer][ph][un]; both waves with this ph
+    // then read channel j's from bx[buffer][ph][j]
+    auto X_put = [&](int buf, const Bop &d) {
+        float *dst = bx + ((((buf * 2 + ph) * 2 + un) * 2) * 64 + lane) * 4;
+        f32x4 a, b;
+        a[0] = d.P[0][0], a[1] = d.P[0][1], a[2] = d.Q[0][0], a[3] = d.Q[0][1];
+        b[0] = d.P[1][0], b[1] = d.P[1][1], b[2] = d.Q[1][0], b[3] = d.Q[1][1];
+        *reinterpret_cast<f32x4 *>(dst) = a;
+        *reinterpret_cast<f32x4 *>(dst + 256) = b;
+    };
+    auto X_get = [&](int buf, int j, Bop &d, int half) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(bx + ((((buf * 2 + ph) * 2 + j) * 2 + half) * 64 + lane) * 4);
+        d.P[half][0] = v[0], d.P[half][1] = v[1], d.Q[half][0] = v[2], d.Q[half][1] = v[3];
+    };
+#define W3_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
     // B^T d on a pair type (half = 0: the P pairs, 1: the Q pairs): local rows (0, 1) = e0 - e2, e1 + sgn e2
     auto T_col = [&](Bop &d, int half) {
         f32x2 &e0 = half ? d.Q[0] : d.P[0], &e1 = half ? d.Q[1] : d.P[1], &e2 = half ? d.Q[2] : d.P[2];
@@ -1478,10 +1530,16 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     constexpr bool U3 = true;
     f32x4 ua[8], ub[8], uc[U3 ? 8 : 1];
     Bop c0, c1, x0, x1;                    // B operands of the current chunk for channels 2 lh, 2 lh + 1 / the next chunk's, being transformed
+    Bop mine;                              // SH: the half this wave transforms
     Rows rows;
     if (nch > 0) {
+        if constexpr (SH) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) G_row1(0, rows, k);
+            for (int k = 0; k < 4; ++k) G_rows(0, rows, k);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) G_row1(0, rows, k);
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) G_u1(0, ua, q);
         if constexpr (U3) {
@@ -1508,7 +1566,25 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     asm volatile("v_accvgpr_write_b32 a224, 0\n\tv_accvgpr_write_b32 a225, 0\n\tv_accvgpr_write_b32 a226, 0\n\tv_accvgpr_write_b32 a227, 0\n\tv_accvgpr_write_b32 a228, 0\n\tv_accvgpr_write_b32 a229, 0\n\tv_accvgpr_write_b32 a230, 0\n\tv_accvgpr_write_b32 a231, 0\n\tv_accvgpr_write_b32 a232, 0\n\tv_accvgpr_write_b32 a233, 0\n\tv_accvgpr_write_b32 a234, 0\n\tv_accvgpr_write_b32 a235, 0\n\tv_accvgpr_write_b32 a236, 0\n\tv_accvgpr_write_b32 a237, 0\n\tv_accvgpr_write_b32 a238, 0\n\tv_accvgpr_write_b32 a239, 0" : : : "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239");
     asm volatile("v_accvgpr_write_b32 a240, 0\n\tv_accvgpr_write_b32 a241, 0\n\tv_accvgpr_write_b32 a242, 0\n\tv_accvgpr_write_b32 a243, 0\n\tv_accvgpr_write_b32 a244, 0\n\tv_accvgpr_write_b32 a245, 0\n\tv_accvgpr_write_b32 a246, 0\n\tv_accvgpr_write_b32 a247, 0\n\tv_accvgpr_write_b32 a248, 0\n\tv_accvgpr_write_b32 a249, 0\n\tv_accvgpr_write_b32 a250, 0\n\tv_accvgpr_write_b32 a251, 0\n\tv_accvgpr_write_b32 a252, 0\n\tv_accvgpr_write_b32 a253, 0\n\tv_accvgpr_write_b32 a254, 0\n\tv_accvgpr_write_b32 a255, 0" : : : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
     __builtin_amdgcn_sched_barrier(0);
-    if (nch > 0) {
+    if constexpr (SH) {
+        if (nch > 0) {                        // (nch is the same for the two units of a block: the barriers pair up)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) W_rows(0, rows, k);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) G_rows(clampc(1), rows, k);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) T_reads(0, mine, i);
+            T_col(mine, 0); T_col(mine, 1);
+            T_rowp(mine, 0); T_rowp(mine, 1);
+            X_put(0, mine);
+            W3_LDS_BARRIER();
+            X_get(0, 0, c0, 0); X_get(0, 0, c0, 1); X_get(0, 1, c1, 0); X_get(0, 1, c1, 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) W_rows(1, rows, k);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) G_rows(clampc(2), rows, k);
+        }
+    } else if (nch > 0) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) W_row1(0, rows, k);
 #pragma unroll
@@ -1532,6 +1608,44 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     // requested one iteration ago, whose registers then take the loads of chunk it + 3
     auto iter = [&](int it, int par, f32x4 (&ucur)[8], f32x4 (&unext)[8], Bop &b0, Bop &b1, Bop &n0v, Bop &n1v) {
         const int cu = clampc(it + (U3 ? 2 : 1)), cr = clampc(it + 3);
+        if constexpr (SH) {
+            // the next chunk's operands: this wave's channel, the barrier, both channels read back; then the rows of chunk it + 2 / it + 3
+            W3_SLOT(0, 0, ucur, b0, G_u1(cu, unext, 0));
+            W3_SLOT(0, 1, ucur, b1, G_u1(cu, unext, 1));
+            W3_SLOT(8, 0, ucur, b0, G_u1(cu, unext, 2));
+            W3_SLOT(8, 1, ucur, b1, G_u1(cu, unext, 3));
+            W3_SLOT(1, 0, ucur, b0, G_u1(cu, unext, 4));
+            W3_SLOT(1, 1, ucur, b1, G_u1(cu, unext, 5));
+            W3_SLOT(9, 0, ucur, b0, G_u1(cu, unext, 6));
+            W3_SLOT(9, 1, ucur, b1, G_u1(cu, unext, 7));
+            W3_SLOT(2, 0, ucur, b0, T_reads(par ^ 1, mine, 0));
+            W3_SLOT(2, 1, ucur, b1, T_reads(par ^ 1, mine, 1));
+            W3_SLOT(10, 0, ucur, b0, T_reads(par ^ 1, mine, 2));
+            W3_SLOT(10, 1, ucur, b1, T_col(mine, 0));
+            W3_SLOT(3, 0, ucur, b0, T_col(mine, 1));
+            W3_SLOT(3, 1, ucur, b1, T_rowp(mine, 0));
+            W3_SLOT(11, 0, ucur, b0, T_rowp(mine, 1));
+            W3_SLOT(11, 1, ucur, b1, X_put(par ^ 1, mine));
+            // (the barrier sits ten slots behind the stores it waits for: its s_waitcnt then finds them done -- right behind them the wave
+            //  stood at the wait for an LDS latency per chunk while the MFMA pipe drained -- and the two units may drift by that much)
+            W3_SLOT(4, 0, ucur, b0, W_rows(par, rows, 0); G_rows(cr, rows, 0));
+            W3_SLOT(4, 1, ucur, b1, W_rows(par, rows, 1); G_rows(cr, rows, 1));
+            W3_SLOT(12, 0, ucur, b0, W_rows(par, rows, 2); G_rows(cr, rows, 2));
+            W3_SLOT(12, 1, ucur, b1, W_rows(par, rows, 3); G_rows(cr, rows, 3));
+            W3_SLOT(5, 0, ucur, b0, );
+            W3_SLOT(5, 1, ucur, b1, );
+            W3_SLOT(13, 0, ucur, b0, );
+            W3_SLOT(13, 1, ucur, b1, );
+            W3_SLOT(6, 0, ucur, b0, );
+            W3_SLOT(6, 1, ucur, b1, W3_LDS_BARRIER());
+            W3_SLOT(14, 0, ucur, b0, X_get(par ^ 1, 0, n0v, 0));
+            W3_SLOT(14, 1, ucur, b1, X_get(par ^ 1, 0, n0v, 1));
+            W3_SLOT(7, 0, ucur, b0, X_get(par ^ 1, 1, n1v, 0));
+            W3_SLOT(7, 1, ucur, b1, X_get(par ^ 1, 1, n1v, 1));
+            W3_SLOT(15, 0, ucur, b0, );
+            W3_SLOT(15, 1, ucur, b1, );
+            return;
+        }
         W3_SLOT(0, 0, ucur, b0, G_u1(cu, unext, 0));
         W3_SLOT(0, 1, ucur, b1, G_u1(cu, unext, 1));
         W3_SLOT(8, 0, ucur, b0, G_u1(cu, unext, 2));
@@ -1591,7 +1705,7 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     int lh_e = lh;
     asm volatile("" : "+v"(lh_e));
     __syncthreads();                           // both waves are done with their raw stages: the LDS becomes the exchange buffer
-    float *xch = smem_all;
+    float *xch = unit_smem;
     // local rows: wave 0 holds R0, R1, wave 1 holds -R3, R2 (reversed; row 3 negated, see T_col).  Y0 = R0 + R1 + R2, Y1 = R1 - R2 - R3: a wave owns
     // +-(its two rows) and gives its local row 1 (R1 to Y1, R2 to Y0) to the other wave; the sign is applied when the two meet.
     auto part_e = [&](int kq, int e, const float (&m)[8]) {
@@ -1898,6 +2012,19 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
                     hipLaunchKernelGGL((k_wg3<false, true, false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, stats, none);
                 else
                     hipLaunchKernelGGL((k_wg3<false, false, false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, none);
+                CPG_CHECK_LAUNCH(what);
+                return CPG_OK;
+            }
+            // two units per block sharing the input transform (k_wg3<..., SH>): training launches whose 64-channel blocks pair up
+            if (bne == nullptr && ((g.nkb + 1) / 2) % 2 == 0 && cpg::opt_or(cpg::OPT_WG3_SHARE, 1) != 0) {
+                int64_t pairs = (int64_t)g.nblocks / 2;
+                if (persist) pairs = std::min<int64_t>(pairs, (int64_t)wino_grids() * kCUs);       // (one four-wave block per CU is resident)
+                if (dgrad)
+                    hipLaunchKernelGGL((k_wg3<true, false, false, false, true>), dim3((unsigned)pairs), dim3(256), 0, stream, g, x, up, bias, y, nullptr, none);
+                else if (stats != nullptr)
+                    hipLaunchKernelGGL((k_wg3<false, true, false, false, true>), dim3((unsigned)pairs), dim3(256), 0, stream, g, x, up, bias, y, stats, none);
+                else
+                    hipLaunchKernelGGL((k_wg3<false, false, false, false, true>), dim3((unsigned)pairs), dim3(256), 0, stream, g, x, up, bias, y, nullptr, none);
                 CPG_CHECK_LAUNCH(what);
                 return CPG_OK;
             }

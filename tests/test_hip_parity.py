@@ -284,6 +284,8 @@ def test_pointwise_random_shapes_vs_torch():
     (2, 64, 112, 112, 64, False, False),   # 56-tile rows, block halos inside a row
     (8, 32, 96, 96, 64, True, False),      # 288 logical k_wg1 blocks: more than the persistent grid holds (256), a ragged second round
     (4, 128, 96, 96, 128, False, True),    # 576 logical k_wg3 blocks against a grid of 512
+    (3, 64, 28, 28, 256, True, True),      # k_wg3 with two units per block sharing the input transform (round 4): 4 channel blocks, bias, piggymask
+    (9, 192, 14, 14, 160, False, False),   # ... a ragged last channel block (160 = 2.5 x 64), tile runs that straddle images
 ])
 @pytest.mark.parametrize('nw', [0, 1, 2, 3, 4, 8])
 def test_winograd_matches_direct(N, C, H, W, K, bias, pm, nw, libopt):
@@ -321,6 +323,19 @@ def test_winograd_matches_direct(N, C, H, W, K, bias, pm, nw, libopt):
     y1, gx1 = run()
     y2, gx2 = run()
     assert torch.equal(y1, y2) and torch.equal(gx1, gx2)                    # deterministic
+    if nw in (0, 3):
+        # k_wg3's shared-transform blocks (two units per block, each transforming half of the B operands) change who computes an operand,
+        # not its value or the order of a sum: bit-identical to one unit per block -- output, input gradient and the BatchNorm statistics
+        def stats_run():
+            yy, st = layer.forward_with_bn_stats(x.to(DEV))
+            return yy.detach().cpu(), (None if st is None else st.detach().cpu())
+        ys, sts = stats_run()
+        libopt.set('CPG_WG3_SHARE', 0)
+        y3, gx3 = run()
+        ys0, sts0 = stats_run()
+        libopt.set('CPG_WG3_SHARE', None)
+        assert torch.equal(y1, y3) and torch.equal(gx1, gx3) and torch.equal(ys, ys0)
+        assert (sts is None) == (sts0 is None) and (sts is None or torch.equal(sts, sts0))
     libopt.set('CPG_NO_WINO', '1')
     y0, gx0 = run()
     weff = w.double() * ((pmv > 5e-3).double() if pm else 1.0)
