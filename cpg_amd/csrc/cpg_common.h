@@ -45,6 +45,7 @@ enum Opt {
     OPT_WINO_GRIDS,       // CPG_WINO_GRIDS=n
     OPT_WW_UNITS,         // CPG_WW_UNITS=n: units per wave slot of k_wgw
     OPT_WW_XCD,           // CPG_WW_XCD=0: dispatch-order units in k_wgw
+    OPT_PW_TILE,          // CPG_PW_TILE=0: the pointwise kernels' 128-row tile as 4 x 1 waves of 7 pixel fragments (224 pixels, round 3); 1: 2 x 2 waves of 2 x 4 fragments (256 pixels)
     OPT_WG3_SHARE,        // CPG_WG3_SHARE=0: k_wg3 as blocks of one unit (two waves), every unit transforming all of its B operands (round 3)
     OPT_WW_SHARE,         // CPG_WW_SHARE=0: every wave of k_wgw stages its own x rows (round 3); 2 / 4: force that sharing group
     OPT_COUNT

@@ -633,8 +633,15 @@ int pw_wgrad_launch(const cpg_conv_desc *d, const float *x, const float *gy, con
 #ifndef PW_CK
 #define PW_CK 16
 #endif
+#ifndef PW_TILE_DEFAULT
+#define PW_TILE_DEFAULT 0
+#endif
 using PwV = PwCfg<128, 4, 1, 7, PW_CK, true, PW_MINW>;       // dense reads, 4 | pixels per image: float4 staging
 using PwS = PwCfg<128, 4, 1, 7, 16, false, 2>;      // strided reads (1x1 s2 forward) or odd plane sizes (7x7 maps)
+// round 4: 128 rows x 256 flattened pixels as 2 x 2 waves of 2 x 4 fragments -- 6 LDS operand reads per 8 MFMAs where the 4 x 1 / 7-fragment
+// tile has 8 per 7 (the four waves of that tile all read the same seven B operands)
+using PwV2 = PwCfg<128, 2, 2, 4, PW_CK, true, 2>;
+inline bool pw_wide() { return cpg::opt_or(cpg::OPT_PW_TILE, PW_TILE_DEFAULT) != 0; }
 // <= 64 channels produced (ResNet layer1: conv1 forward, conv3 input gradient): a 128-row tile would run half of its MFMAs on
 // rows that do not exist.  64 rows x 256 flattened pixels (2 x 2 waves, 4 fragments each); 56 x 56 maps x any batch divide by 256.
 using PwV64 = PwCfg<64, 2, 2, 4, 16, true, 3>;
@@ -692,7 +699,8 @@ size_t cpg_conv1x1_pack_workspace(const cpg_conv_desc *d) { return std::max(pack
 // pixel tiles of the forward launch = rows of the [K][tiles][2] statistics buffer of cpg_conv2d_fwd_bnstats
 int cpg_conv1x1_bnstats_tiles(const cpg_conv_desc *d) {
     const int OH = (d->H - 1) / d->stride_h + 1, OW = (d->W - 1) / d->stride_w + 1;
-    const int bn = d->K <= 64 ? PwV64::BN : PwV::BN;
+    const bool wide = pw_wide() && d->stride_h == 1 && d->stride_w == 1 && (OH * OW) % 4 == 0;
+    const int bn = d->K <= 64 ? PwV64::BN : (wide ? PwV2::BN : PwV::BN);
     return (int)(((int64_t)d->N * OH * OW + bn - 1) / bn);
 }
 
@@ -712,6 +720,10 @@ int cpg_conv1x1_fwd(const cpg_conv_desc *d, const float *x, const float *w, cons
     static_assert(PwV::BN == PwS::BN && PwV64::BN == PwS64::BN, "cpg_conv1x1_bnstats_tiles counts tiles of either staging flavour");
     const bool vec = dense && (OH * OW) % 4 == 0 && (((uintptr_t)x) & 15) == 0;
     if (d->K <= 64) return vec ? launch<PwV64, false>(g, x, wp, bias, y, stream, what, stats) : launch<PwS64, false>(g, x, wp, bias, y, stream, what, stats);
+    if (pw_wide() && dense && (OH * OW) % 4 == 0) {
+        CPG_REQUIRE(vec || stats == nullptr, "%s: the fused-statistics launch needs a 16-byte aligned input", what);
+        if (vec) return launch<PwV2, false>(g, x, wp, bias, y, stream, what, stats);
+    }
     if (vec) return launch<PwV, false>(g, x, wp, bias, y, stream, what, stats);
     return launch<PwS, false>(g, x, wp, bias, y, stream, what, stats);
 }
@@ -737,6 +749,7 @@ int cpg_conv1x1_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, c
     if (addend != nullptr && !dense) return fail(CPG_E_UNSUPPORTED, "%s: the fused addend needs a dense (stride 1) layer", what);
     const bool vec = (OH * OW) % 4 == 0 && (((uintptr_t)gy) & 15) == 0;
     if (d->C <= 64) return vec ? launch<PwV64, true>(g, gy, wp, nullptr, gx, stream, what, nullptr, addend) : launch<PwS64, true>(g, gy, wp, nullptr, gx, stream, what, nullptr, addend);
+    if (vec && pw_wide()) return launch<PwV2, true>(g, gy, wp, nullptr, gx, stream, what, nullptr, addend);
     if (vec) return launch<PwV, true>(g, gy, wp, nullptr, gx, stream, what, nullptr, addend);
     return launch<PwS, true>(g, gy, wp, nullptr, gx, stream, what, nullptr, addend);
 }
@@ -822,6 +835,7 @@ bool cpg_pw_gemm_nn_ok(const float *X, int M, int Mp, int Kd, int64_t G) {
 int cpg_pw_gemm_nn(const float *wp, int Mp, const float *X, int M, int Kd, int64_t G, const float *bias, float *y, hipStream_t stream,
                    const char *what) {
     PwGeom g{1, Kd, M, Mp, (int)G, (int)G, (int)G, 0, 1, (int)G, 0, 1, 0, (long long)G};
+    if (G % 4 == 0 && pw_wide()) return launch<PwV2, false>(g, X, wp, bias, y, stream, what);
     if (G % 4 == 0) return launch<PwV, false>(g, X, wp, bias, y, stream, what);
     return launch<PwS, false>(g, X, wp, bias, y, stream, what);
 }
