@@ -618,14 +618,25 @@ def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch
 XGMI_LINK_GBS = 153.0                # MI355X_MICROARCH / task statement: 7 links x ~153 GB/s per GPU, point to point
 RCCL_ALLREDUCE_BUSBW_GBS = 310.0     # assumed large-message bus bandwidth of an 8-GPU RCCL all-reduce over xGMI (two links' worth)
 OVERLAP_SLOWDOWN = 1.17              # conv kernels beside 16 busy CUs' worth of other streams' kernels (tools/diag_interference.py)
-SINGLE_GPU_MS_PER_STEP = {'vgg16': 114.0, 'resnet50': 71.3, 'spherenet20': 21.2}   # batch 256, cycle ms per step (profiles/r03k_bench*.json)
+# cycle ms per step on ONE GPU by per-GPU batch (profiles/r04*_bench*.json; the 128 / 64 / 32 rows are the reference's own split: 256 images over 2 / 4 / 8 GPUs)
+SINGLE_GPU_MS_PER_STEP = {'vgg16': {256: 110.5, 128: 59.4, 64: 32.5, 32: 19.2}, 'resnet50': {256: 70.9}, 'spherenet20': {256: 21.1}}
 
 
-def predict_step_ms(arch, world, buckets, measured_single_gpu_ms=None):
+def single_gpu_ms(arch, batch):
+    """Measured single-GPU cycle time per step at this per-GPU batch; batches without a measurement are scaled from the nearest larger one
+    (an optimistic guess: small batches lose efficiency)."""
+    tab = SINGLE_GPU_MS_PER_STEP[arch]
+    if batch in tab:
+        return tab[batch]
+    near = min((b for b in tab if b >= batch), default=max(tab))
+    return tab[near] * batch / near
+
+
+def predict_step_ms(arch, world, buckets, measured_single_gpu_ms=None, batch=256):
     """Weak scaling (256 images per GPU): step = single-GPU step + what the gradient exchange adds.  All but the LAST messages
     run under the remaining backward kernels (which slow down by OVERLAP_SLOWDOWN while RCCL holds CUs); the last message -- the
     coalesced small tensors, issued after backward -- is exposed."""
-    t1 = measured_single_gpu_ms or SINGLE_GPU_MS_PER_STEP[arch]
+    t1 = measured_single_gpu_ms or single_gpu_ms(arch, batch)
     if world <= 1:
         return {'predicted_ms_per_step': t1, 'allreduce_ms_total': 0.0, 'exposed_ms': 0.0}
     algbw = RCCL_ALLREDUCE_BUSBW_GBS * world / (2.0 * (world - 1))                  # GB/s of payload
@@ -840,7 +851,7 @@ def main():
             # layer, 'coalesced' = all small tensors (BatchNorm, biases, head) in one message after backward
             buckets = list(model.last_bucket_log)
             out['multi_gpu']['buckets'] = [{'kind': k, 'bytes': b} for k, b in buckets]
-            out['multi_gpu'].update(predict_step_ms(a.arch, world, buckets))
+            out['multi_gpu'].update(predict_step_ms(a.arch, world, buckets, batch=a.batch))
         agg = clock.summary()
         if agg:
             tot_ms = sum(v[1] for v in agg.values())
