@@ -367,3 +367,58 @@ def test_winograd_kernels_keep_their_accumulators_to_themselves(src, names, agpr
         assert 'scratch_' not in body, name
         assert len(re.findall(r'v_accvgpr_read', body)) % zero == 0, name
     assert found >= 2
+
+
+def test_library_options_table_on_the_host(monkeypatch):
+    """The option table of the C ABI (cpg_set_option / cpg_get_option) needs no GPU: values, unset, the Winograd-kernel spellings, unknown
+    names, and that a switch changes the library's own dispatch answer (cpg_conv2d_winograd) while an environment variable set AFTER
+    loading does not."""
+    import ctypes
+    lib = L.lib()
+    d = L.ConvDesc()
+    d.N, d.C, d.H, d.W, d.K, d.R, d.S = 4, 64, 28, 28, 64, 3, 3
+    d.stride_h = d.stride_w = d.pad_h = d.pad_w = d.dil_h = d.dil_w = d.groups = 1
+    assert L.get_option('CPG_NO_WINO') in (None, 0)
+    assert lib.cpg_conv2d_winograd(ctypes.byref(d), 0) == 1 and lib.cpg_conv2d_winograd(ctypes.byref(d), 2) == 1
+    monkeypatch.setenv('CPG_NO_WINO', '1')
+    assert lib.cpg_conv2d_winograd(ctypes.byref(d), 0) == 1               # the environment was read once, at load time
+    with L.option('CPG_NO_WINO', 1):
+        assert L.get_option('CPG_NO_WINO') == 1 and lib.cpg_conv2d_winograd(ctypes.byref(d), 0) == 0
+        with L.option('CPG_NO_WINO', None):
+            assert L.get_option('CPG_NO_WINO') is None and lib.cpg_conv2d_winograd(ctypes.byref(d), 0) == 1
+        assert L.get_option('CPG_NO_WINO') == 1
+    assert lib.cpg_conv2d_winograd(ctypes.byref(d), 0) == 1
+    with L.option('CPG_NO_WINO_WGRAD', 1):
+        assert lib.cpg_conv2d_winograd(ctypes.byref(d), 0) == 1 and lib.cpg_conv2d_winograd(ctypes.byref(d), 2) == 0
+    for spelling, value in (('block', 0), ('wave', 1), ('pair', 2), ('64', 3)):
+        with L.option('CPG_WINO_KERNEL', spelling):
+            assert L.get_option('CPG_WINO_KERNEL') == value
+    assert L.get_option('CPG_WINO_KERNEL') is None
+    assert lib.cpg_set_option(b'CPG_NO_SUCH_SWITCH', 1) != 0 and b'unknown option' in lib.cpg_last_error()
+    v = ctypes.c_int32(0)
+    assert lib.cpg_get_option(b'CPG_NO_SUCH_SWITCH', ctypes.byref(v)) != 0
+    # the shared-chip hint is process-wide
+    import threading
+    assert lib.cpg_get_shared_chip_hint() == 0
+    lib.cpg_set_shared_chip_hint(1)
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(lib.cpg_get_shared_chip_hint()))
+    t.start(); t.join()
+    lib.cpg_set_shared_chip_hint(0)
+    assert seen == [1]
+
+
+def test_bench_cycle_plan_and_scaling_table():
+    """bench.py's host logic: the K-step cycle keeps its shape (A finetune steps, 4 prune events in a window of 4 f steps), the
+    single-GPU time table behind the scaling prediction, --global-batch arithmetic."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.cycle_plan(220) == (20, 10) and b.cycle_plan(20) == (2, 1) and b.cycle_plan(1) == (1, 1)
+    assert b.single_gpu_ms('vgg16', 32) < b.single_gpu_ms('vgg16', 64) < b.single_gpu_ms('vgg16', 256)
+    assert abs(b.single_gpu_ms('resnet50', 128) - b.single_gpu_ms('resnet50', 256) / 2) < 1e-9      # (no measurement: scaled)
+    pr = b.predict_step_ms('vgg16', 8, [('chunk', 1 << 26), ('tensor', 1 << 24), ('coalesced', 1 << 16)], batch=32)
+    assert pr['single_gpu_ms_per_step'] == b.single_gpu_ms('vgg16', 32) and pr['predicted_ms_per_step'] > pr['single_gpu_ms_per_step']
+    assert len(b.csrc_digest()) == 64
+
