@@ -162,7 +162,7 @@ with open(os.path.join(P, '%s_batch_split.md' % out), 'w') as f:
         if k in kd128:
             a, b = kd128[k], kd32[k]
             w('| %s (128 -> 32) | %.3f | %.1f | %.3f | %.1f | %.2f |\n' % (k, a['ms'] / a['n'], a['tflops'], b['ms'] / b['n'], b['tflops'], b['tflops'] / max(a['tflops'], 1e-9)))
-    w('\n(the batch-256 line carries no per-layer detail in this bundle; the 128 column is within 2-5 % of it, see %s_final.md)\n\n' % out)
+    w('\n(the batch-256 line carries no per-layer detail in this bundle; the 128 column is within 2-5 %% of it, see %s_final.md)\n\n' % out)
     w('## rocprofv3 --kernel-trace --stats of `bench.py --batch 32 --steps 20 --warmup 5 --no-cpu-baseline --optin-steps 0`\n\n')
     w(read(g('summary_%s_b32.md')))
     w('\n')
