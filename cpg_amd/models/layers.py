@@ -355,11 +355,9 @@ class SharableConv2d(_Sharable):
         super().__init__()
         if in_channels % groups or out_channels % groups:
             raise ValueError('in_channels and out_channels must be divisible by groups')
-        if groups != 1:
-            # the reference forwards `groups` to F.conv2d (models/layers.py:108-109) but no CPG configuration uses it; there is
-            # no grouped HIP kernel, so fail where the layer is built, not at the first forward (resnext*, VGG(groups=...))
-            raise NotImplementedError('SharableConv2d(groups=%d): grouped convolutions are not implemented in cpg_amd '
-                                      '(every CPG configuration uses groups=1)' % groups)
+        # groups > 1 (the reference forwards `groups` to F.conv2d, models/layers.py:108-109; no CPG configuration uses it -- the resnext*
+        # factories and VGG(groups=...) exist in its model files): one launch of the groups == 1 kernels per group on a contiguous
+        # channel slice, see _grouped() -- correct and on the HIP path, not tuned
         self.in_channels, self.out_channels, self.groups = in_channels, out_channels, groups
         self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
         self.padding, self.dilation = _pair(padding), _pair(dilation)
@@ -372,7 +370,25 @@ class SharableConv2d(_Sharable):
             self.register_parameter('bias', None)
         self._init_mask_state(mask_init, mask_scale, threshold_fn, threshold)
 
+    def _grouped(self, input):
+        """groups > 1: y = cat_g conv2d(x[:, g-th channel slice], W[g-th row block] * bin(pm[...]), b[...]) -- every group through the
+        groups == 1 kernels (autograd slices / concatenates; the row blocks of weight, piggymask and bias are contiguous views)."""
+        G = self.groups
+        if input.dim() != 4 or input.shape[1] != self.weight.shape[1] * G:
+            raise RuntimeError('SharableConv2d: input %s does not match weight %s (groups=%d)'
+                               % (tuple(input.shape), tuple(self.weight.shape), G))
+        ko = self.out_channels // G
+        outs = []
+        for gi, xg in enumerate(input.chunk(G, dim=1)):
+            rows = slice(gi * ko, (gi + 1) * ko)
+            outs.append(_MaskedConv2dFn.apply(xg.contiguous(), self.weight[rows], None if self.piggymask is None else self.piggymask[rows],
+                                              None if self.bias is None else self.bias[rows], self.info['threshold'], self.stride,
+                                              self.padding, self.dilation, 1, False, self._math(), None, None))
+        return torch.cat(outs, dim=1)
+
     def forward(self, input, layer_info=None, name=None, bn_hint=None, bias_sink=None):
+        if self.groups != 1:
+            return self._grouped(input)
         return _MaskedConv2dFn.apply(input, self.weight, self.piggymask, self.bias, self.info['threshold'],
                                      self.stride, self.padding, self.dilation, self.groups, False, self._math(), bn_hint, bias_sink)
 
@@ -382,6 +398,8 @@ class SharableConv2d(_Sharable):
     def forward_with_bn_stats(self, input, bn_hint=None):
         """(y, stats): forward plus the BatchNorm partial sums of y from the same kernel; stats is None when this shape
         has no fused-statistics kernel.  Used by cpg_amd.models.fused_bn.FusedSequential for conv -> BatchNorm2d runs."""
+        if self.groups != 1:
+            return self._grouped(input), None
         y, stats = _MaskedConv2dFn.apply(input, self.weight, self.piggymask, self.bias, self.info['threshold'],
                                          self.stride, self.padding, self.dilation, self.groups, True, self._math(), bn_hint)
         return y, (stats if stats.numel() else None)
@@ -389,6 +407,8 @@ class SharableConv2d(_Sharable):
     def forward_with_skip(self, input):
         """(y, stats or None, skip): forward (+ BatchNorm partial sums where the shape has them) and the input handed back for the
         residual branch; the two gradients of the input are summed inside the input-gradient kernel (_MaskedConv2dSkipFn)."""
+        if self.groups != 1:
+            return self._grouped(input), None, input
         y, stats, skip = _MaskedConv2dSkipFn.apply(input, self.weight, self.piggymask, self.bias, self.info['threshold'],
                                                    self.stride, self.padding, self.dilation, self.groups, self._math())
         return y, (stats if stats.numel() else None), skip
@@ -399,7 +419,7 @@ class SharableConv2d(_Sharable):
         kernel (the caller then runs the layers one by one).  skip_stats: optional int32[2] device tensor that receives
         {1 + last live input channel, output tiles skipped} (dead-channel skip, see include/cpg_hip.h)."""
         if (torch.is_grad_enabled() or input.dim() != 4 or input.shape[0] == 0 or input.shape[1] != self.weight.shape[1] * self.groups
-                or self._math() != 'fp32'):
+                or self._math() != 'fp32' or self.groups != 1):
             return None
         x = input.contiguous()
         w = self.weight.contiguous()

@@ -332,12 +332,19 @@ def test_settle_host_gc_freezes_what_is_alive():
         gc.unfreeze()
 
 
-def test_grouped_conv_is_refused_at_construction():
-    """groups != 1 has no HIP kernel: the layer (and the resnext factories built on it) say so when they are constructed."""
-    with pytest.raises(NotImplementedError):
-        nl.SharableConv2d(8, 8, 3, groups=2)
-    with pytest.raises(NotImplementedError):
-        M.resnext50_32x4d(dataset_history=[], dataset2num_classes={}, network_width_multiplier=1.0, shared_layer_info={})
+def test_grouped_conv_constructs_and_has_no_cpu_fallback():
+    """groups > 1 (models/layers.py:108-109 forwards it to F.conv2d): the layer and the resnext factories construct with the reference's
+    parameter shapes; the forward runs one groups == 1 launch per group on the HIP path -- and, like everything else, refuses CPU tensors."""
+    conv = nl.SharableConv2d(8, 12, 3, padding=1, groups=2)
+    assert tuple(conv.weight.shape) == (12, 4, 3, 3) and conv.groups == 2
+    nn.init.normal_(conv.weight)
+    nn.init.zeros_(conv.bias)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        conv(torch.zeros(1, 8, 6, 6))
+    with pytest.raises(RuntimeError, match='does not match weight'):
+        conv(torch.zeros(1, 6, 6, 6))
+    net = M.resnext50_32x4d(dataset_history=[], dataset2num_classes={}, network_width_multiplier=1.0, shared_layer_info={})
+    assert net.layer1[0].conv2.groups == 4 and tuple(net.layer1[0].conv2.weight.shape) == (128, 32, 3, 3)
 
 
 @pytest.mark.parametrize('src,names,agprs', [('conv3x3_wino.hip', r'k_wg[123]I', (128, 256)), ('conv3x3_wino_wgrad.hip', r'k_wgwI', (256,))])

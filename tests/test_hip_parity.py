@@ -174,6 +174,45 @@ def test_conv_oracle(N, C, H, W, K, k, s, p, bias, pm):
         close(layer.bias.grad, r['gb'], rtol=1e-4, atol=1e-3, msg='gb')
 
 
+@pytest.mark.parametrize('N,C,K,H,W,k,s,p,G,bias,pm', [
+    (3, 32, 64, 14, 14, 3, 1, 1, 4, False, True),      # ResNeXt-style 3x3: 4 groups of 8 -> 16 channels (generic kernels: < 16 channels a group)
+    (2, 64, 64, 12, 12, 3, 1, 1, 2, True, False),      # two groups of 32 -> 32 (Winograd kernels per group), bias
+    (2, 32, 32, 9, 9, 1, 1, 0, 4, True, True),         # grouped pointwise
+    (2, 48, 96, 10, 10, 3, 2, 1, 3, False, False),     # strided, 3 groups
+])
+def test_grouped_conv_vs_oracle(N, C, K, H, W, k, s, p, G, bias, pm):
+    """groups > 1 (models/layers.py:108-109; no CPG configuration uses it): one launch of the groups == 1 kernels per group.  Output and
+    all gradients against the oracle's F.conv2d(groups=G) restatement."""
+    g = torch.Generator().manual_seed(N + C + K + G)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C // G, k, k, generator=g) * 0.2
+    b = torch.randn(K, generator=g) * 0.1 if bias else None
+    pmv = torch.rand(K, C // G, k, k, generator=g) * 0.012 if pm else None
+    layer = nl.SharableConv2d(C, K, k, stride=s, padding=p, groups=G, bias=bias).to(DEV)
+    layer.weight.data.copy_(w)
+    if bias:
+        layer.bias.data.copy_(b)
+    if pm:
+        layer.piggymask = nn.Parameter(pmv.to(DEV))
+    xd = x.to(DEV).requires_grad_(True)
+    y = layer(xd)
+    want = ops.conv2d_forward(x.numpy(), w.numpy(), None if pmv is None else pmv.numpy(), None if b is None else b.numpy(), s, p, 1, G)
+    close(y, want, rtol=1e-4, atol=2e-5, msg='y')
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.to(DEV))
+    r = ops.conv2d_backward(x.numpy(), w.numpy(), gy.numpy(), None if pmv is None else pmv.numpy(), bias, s, p, 1, G)
+    scale = float(np.abs(r['gw']).max())
+    close(xd.grad, r['gx'], rtol=1e-4, atol=2e-5, msg='gx')
+    close(layer.weight.grad, r['gw'], rtol=1e-4, atol=1e-5 * max(scale, 1.0), msg='gw')
+    if pm:
+        close(layer.piggymask.grad, r['gpm'], rtol=1e-4, atol=1e-5 * max(scale, 1.0), msg='gpm')
+    if bias:
+        close(layer.bias.grad, r['gb'], rtol=1e-4, atol=1e-3, msg='gb')
+    with torch.no_grad():
+        y2, st = layer.forward_with_bn_stats(x.to(DEV))
+    assert st is None and torch.equal(y2, y.detach())
+
+
 @pytest.mark.parametrize('wgrad_in_pass', [True, False])
 @pytest.mark.parametrize('N,C,H,W,pm', [(3, 3, 40, 70, False), (2, 3, 224, 224, True), (5, 1, 17, 33, False), (4, 2, 64, 64, True)])
 def test_fused_stem_conv_bn_relu_matches_unfused(N, C, H, W, pm, wgrad_in_pass, monkeypatch):
