@@ -246,3 +246,12 @@ def test_bench_self_launches_two_ranks(tmp_path):
     bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'],
                          env=dict(env, WORLD_SIZE='1', RANK='0'), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and 'WORLD_SIZE' in (bad.stderr + bad.stdout)
+    # the reference's own split (the batch is NOT scaled with the GPUs, CPG_cifar100_main_normal.py:112-114,199): --global-batch
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--global-batch', '8',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
+    assert out['scaling'] == 'strong' and out['config']['global_batch'] == 8 and out['config']['per_gpu_batch'] == 4
+    odd = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--global-batch', '7'], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert odd.returncode != 0 and 'divisible' in (odd.stderr + odd.stdout)
