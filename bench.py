@@ -690,6 +690,10 @@ def main():
     ap.add_argument('--no-kernel-clock', action='store_true')
     a = ap.parse_args()
 
+    if a.global_batch:
+        if a.global_batch % a.gpus:
+            sys.exit('bench.py: --global-batch %d is not divisible by --gpus %d' % (a.global_batch, a.gpus))
+        a.batch = a.global_batch // a.gpus
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
         # started as a plain `python bench.py --gpus N`: become N ranks, one per GPU
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
@@ -699,10 +703,6 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    if a.global_batch:
-        if a.global_batch % a.gpus:
-            sys.exit('bench.py: --global-batch %d is not divisible by --gpus %d' % (a.global_batch, a.gpus))
-        a.batch = a.global_batch // a.gpus
     if world != a.gpus:
         sys.exit('bench.py: --gpus %d but WORLD_SIZE is %d; launch with torch.distributed.run --nproc-per-node %d '
                  '(or plain `python bench.py --gpus %d`, which re-launches itself)' % (a.gpus, world, a.gpus, a.gpus))
