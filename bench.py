@@ -778,6 +778,9 @@ def main():
         barrier()
         task1_ms = 1000.0 * (time.perf_counter() - t1) / a.steps
         free_share = begin_task2(model, masks, arch, device)
+        # task 2 has its own label space (a new head with classes2 outputs): same images, labels of that range
+        pool = [(x, torch.randint(0, arch['classes2'], (x.shape[0],), generator=g, device=device)) for x, _ in pool]
+        val_pool = [(x, torch.randint(0, arch['classes2'], (x.shape[0],), generator=g, device=device)) for x, _ in val_pool]
         # warm the task-2 kernels (pack passes with the binarizer, piggymask-gradient epilogues, fused Adam) on a copy of the masks
         wm = Manager(make_args('finetune', 1), model, {}, {k: v.clone() for k, v in masks.items()},
                      [pool[i % len(pool)] for i in range(max(1, min(2, a.warmup)))], val_pool, 0, 0)
