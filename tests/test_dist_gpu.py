@@ -255,3 +255,24 @@ def test_bench_self_launches_two_ranks(tmp_path):
     odd = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--global-batch', '7'], env=env, capture_output=True,
                          text=True, timeout=300)
     assert odd.returncode != 0 and 'divisible' in (odd.stderr + odd.stdout)
+
+
+@pytest.mark.parametrize('arch', ['resnet50', 'vgg16'])
+def test_bench_task2_line(arch):
+    """`bench.py --task 2` end to end at a tiny batch: the task-1 leg, the switch to task 2 (30 % of every layer free, a new head with ITS OWN
+    label range -- ResNet-50's second task has 196 classes where the first has 200 --, piggymasks on every masked layer), the cycle
+    with SGD + Adam, the finetune_again leg; the JSON line carries the ratio block."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--arch', arch, '--task', '2', '--steps', '4', '--warmup', '1', '--batch', '8',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
+    assert out['config']['task'] == 2 and 'NOT the headline' in out['metric'] and out['n_gpus'] == 1
+    t2 = out['task2']
+    assert t2['task1_ms_per_step'] > 0 and t2['finetune_again_ms_per_step'] > 0 and abs(t2['free_share_handed_to_task2'] - 0.3) < 0.01
+    assert out['config']['cycle']['prune_events'] >= 1 and 'roofline' in out and out.get('cpu_baseline') is None
+
