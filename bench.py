@@ -746,15 +746,23 @@ def main():
     val_pool = [(torch.randn(100, 3, sz, sz, generator=g, device=device),
                  torch.randint(0, ncls, (100,), generator=g, device=device)) for _ in range(2)]
 
-    # warm-up: W untimed plain train steps (allocator, first-launch code loading) + one validate (eval-mode kernels)
-    if a.warmup > 0:
-        wm = Manager(make_args('finetune', 1), model, {}, {k: v.clone() for k, v in masks.items()},
-                     [pool[i % len(pool)] for i in range(a.warmup)], val_pool, 0, 0)
+    def warm_up(n, lr_mask=None):
+        """n untimed train steps on a COPY of the owner masks with every learning rate 0 (weights, masks and -- restored below -- BatchNorm
+        statistics unchanged): allocator, first-launch code loading.  The last one (n >= 2) is a prune-mode step with a rank-prune
+        event, so that the kernels of an event and of the optimizers' prune-mode paths are not loaded inside the timed prune window;
+        before it one validate (eval-mode kernels)."""
+        wmasks = {k: v.clone() for k, v in masks.items()}
+        wm = Manager(make_args('finetune', 1), model, {}, wmasks, [pool[i % len(pool)] for i in range(n - 1 if n >= 2 else n)], val_pool, 0, 0)
         wm.pruner.make_finetuning_mask()
-        opt = Optimizers()
-        opt.add(torch.optim.SGD(model.parameters(), lr=0.0, momentum=0.9, nesterov=True), 0.0)
-        wm.train(opt, 0, [0.0], 0)
-        validate(wm, 0)                                   # (all slots owned by task 1: apply_mask changes nothing)
+        wm.train(make_optimizers(model, wm.pruner, 0.0, lr_mask), 0, [0.0], 0)
+        validate(wm, 0)                                   # (every slot is owned by a task <= the current one: apply_mask changes nothing)
+        if n >= 2:                                        # AFTER the validate: the event releases slots of the mask copy, which an
+            wp = Manager(make_args('prune', 1), model, {}, wmasks, [pool[(n - 1) % len(pool)]], val_pool, 0, 4)     # apply_mask would zero
+            wp.train(make_optimizers(model, wp.pruner, 0.0, lr_mask), 0, [0.0], 1)       # (prune step 1 of a window of 4: an event)
+
+    # warm-up: W untimed train steps + one validate
+    if a.warmup > 0:
+        warm_up(a.warmup)
         for bn in model.modules():                        # lr = 0 keeps weights; also restore BN statistics
             if isinstance(bn, nn.BatchNorm2d):
                 bn.reset_running_stats()
@@ -781,13 +789,8 @@ def main():
         # task 2 has its own label space (a new head with classes2 outputs): same images, labels of that range
         pool = [(x, torch.randint(0, arch['classes2'], (x.shape[0],), generator=g, device=device)) for x, _ in pool]
         val_pool = [(x, torch.randint(0, arch['classes2'], (x.shape[0],), generator=g, device=device)) for x, _ in val_pool]
-        # warm the task-2 kernels (pack passes with the binarizer, piggymask-gradient epilogues, fused Adam) on a copy of the masks
-        wm = Manager(make_args('finetune', 1), model, {}, {k: v.clone() for k, v in masks.items()},
-                     [pool[i % len(pool)] for i in range(max(1, min(2, a.warmup)))], val_pool, 0, 0)
-        wm.pruner.make_finetuning_mask()
-        wm.train(make_optimizers(model, wm.pruner, 0.0, 0.0), 0, [0.0, 0.0], 0)
-        validate(wm, 0)
-        del wm
+        # warm the task-2 kernels (pack passes with the binarizer, piggymask-gradient epilogues, fused Adam in both modes, shared_ratio)
+        warm_up(max(2, min(3, a.warmup)), lr_mask=0.0)
         if model.sync_events is not None:
             model.sync_events = []
         settle_host_gc()

@@ -21,7 +21,18 @@ SZ, NCLS = bench.ARCHS[ARCH]['size'], bench.ARCHS[ARCH]['classes']
 pool = [(torch.randn(B, 3, SZ, SZ, generator=g, device=dev), torch.randint(0, NCLS, (B,), generator=g, device=dev)) for _ in range(2)]
 mgr = Manager(bench.make_args('finetune', 1), model, {}, masks, None, pool, 0, 0)
 mgr.pruner.make_finetuning_mask()
-opt = Optimizers(); opt.add(torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, nesterov=True), 1e-3)
+if os.environ.get('TASK2'):            # the cycle of tasks >= 2: piggymasks on every masked layer, MaskedSGD + MaskedAdam (bench.py --task 2)
+    bench.begin_task2(model, masks, bench.ARCHS[ARCH], dev)
+    pool = [(x, torch.randint(0, bench.ARCHS[ARCH]['classes2'], (B,), generator=g, device=dev)) for x, _ in pool]
+    mgr = Manager(bench.make_args('finetune', 1), model, {}, masks, None, pool, 0, 0)
+    mgr.pruner.make_finetuning_mask()                      # the free slots go to task 2
+    if os.environ.get('MODE') == 'prune':                  # a prune run with an event EVERY step (the prune window of the K = 20 cycle)
+        mgr = Manager(bench.make_args('prune', 1), model, {}, masks, None, pool, -20, 40)
+    opt = bench.make_optimizers(model, mgr.pruner, 1e-3, 5e-4)
+elif os.environ.get('FUSED'):
+    opt = bench.make_optimizers(model, mgr.pruner, 1e-3, None)
+else:
+    opt = Optimizers(); opt.add(torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, nesterov=True), 1e-3)
 def steps(n):
     mgr.train_loader = [pool[i % 2] for i in range(n)]
     mgr.train(opt, 0, [1e-3], 0)
