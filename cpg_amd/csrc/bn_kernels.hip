@@ -405,12 +405,27 @@ __global__ __launch_bounds__(kThreads) void k_bn_finalize_tiles(const float *__r
     __shared__ double red[4];
     const int c = blockIdx.x;
     const float2 *p = reinterpret_cast<const float2 *>(partials) + (int64_t)c * tiles;
-    double s = 0.0, ss = 0.0;
-    for (int t = threadIdx.x; t < tiles; t += kThreads) {
-        const float2 v = p[t];
-        s += (double)v.x;
-        ss += (double)v.y;
+    // four loads in flight per thread (a 224 x 224 x 256-image layer has 28 672 tiles per channel and only 64 channels = 64 blocks:
+    // the loop is latency-bound); four partial sums merged in a fixed order
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    int t = threadIdx.x;
+    for (; t + 3 * kThreads < tiles; t += 4 * kThreads) {
+        const float2 a = p[t], b = p[t + kThreads], c2 = p[t + 2 * kThreads], d = p[t + 3 * kThreads];
+        s0 += (double)a.x;
+        q0 += (double)a.y;
+        s1 += (double)b.x;
+        q1 += (double)b.y;
+        s2 += (double)c2.x;
+        q2 += (double)c2.y;
+        s3 += (double)d.x;
+        q3 += (double)d.y;
     }
+    for (; t < tiles; t += kThreads) {
+        const float2 v = p[t];
+        s0 += (double)v.x;
+        q0 += (double)v.y;
+    }
+    const double s = (s0 + s1) + (s2 + s3), ss = (q0 + q1) + (q2 + q3);
     const double ts = block_sum(s, red);
     const double tss = block_sum(ss, red);
     if (threadIdx.x == 0) {
