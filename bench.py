@@ -74,6 +74,13 @@ class KernelClock:
     def __init__(self):
         self.records = []           # (kind, algorithmic flops, start_event, end_event, executed flops, algorithmic bytes)
         self.enabled = False
+        # `--clock-every N`: only every N-th train step of the cycle (and every validate) carries events -- an event pair costs the
+        # queue ~ 7 us per launch (same-box A/B: all launches clocked 2345 vs none 2360 images/s on VGG16, 71.2 vs 70.4 ms on
+        # ResNet-50's 160 launches per step).  Launches of the other steps are only counted (`unclocked`), so the whole-region
+        # figures still cover every launch.
+        self.timing = True
+        self.step = None                    # index of the train step the launches belong to (None: a validate)
+        self.unclocked = [0, 0.0, 0.0]      # launches, algorithmic flops, executed flops of the enabled-but-untimed launches
 
     def wrap(self, lib):
         clock = self
@@ -85,13 +92,20 @@ class KernelClock:
             def call(*args):
                 if not clock.enabled:
                     return raw(*args)
+                if not clock.timing:
+                    fl = flops_fn(args)
+                    u = clock.unclocked
+                    u[0] += 1
+                    u[1] += fl
+                    u[2] += fl / 2.25 if wino is not None and wino(args) else fl
+                    return raw(*args)
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 rc = raw(*args)
                 e.record()
                 fl = flops_fn(args)
                 clock.records.append((kind(args), fl, s, e, fl / 2.25 if wino is not None and wino(args) else fl,
-                                      bytes_fn(args) if bytes_fn else 0.0))
+                                      bytes_fn(args) if bytes_fn else 0.0, clock.step))
                 return rc
             return call
 
@@ -167,16 +181,29 @@ class KernelClock:
         p.cpg_linear_wgrad = timed('cpg_linear_wgrad', lambda a: 'linear_wgrad', lin_flops(8), None, lin_bytes(8))
         return p
 
-    def summary(self):
+    def summary(self, train_steps=None):
+        """{kind: [launches, ms, algorithmic flops, executed flops, algorithmic bytes]} over the timed region.  With `--clock-every N`
+        only some train steps carry events while every validate does: each train-step record stands for train_steps / clocked steps
+        launches (a stratified sample -- without the weights the validate launches, batch 100 with the BatchNorm epilogue, would
+        count N times too often in a family's average)."""
         agg = {}
-        for kind, flops, s, e, executed, nbytes in self.records:
+        steps = set(r[6] for r in self.records if r[6] is not None)
+        self.train_steps_clocked, self.train_ms, self.launches_clocked = len(steps), 0.0, len(self.records)
+        w_train = float(train_steps) / len(steps) if train_steps and steps else 1.0
+        for kind, flops, s, e, executed, nbytes, step in self.records:
             ms = s.elapsed_time(e)
+            w = 1.0
+            if step is not None:
+                self.train_ms += ms
+                w = w_train
             a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += ms
-            a[2] += flops
-            a[3] += executed
-            a[4] += nbytes
+            a[0] += w
+            a[1] += w * ms
+            a[2] += w * flops
+            a[3] += w * executed
+            a[4] += w * nbytes
+        for a in agg.values():
+            a[0] = int(round(a[0]))
         return agg
 
 
@@ -323,7 +350,27 @@ def run_cycle(model, masks, pool, val_pool, steps, clock=None, marks=None, count
             marks.append((label, n, ev))
     mark('start')
 
+    every = max(1, int(getattr(clock, 'every', 1))) if clock is not None else 1
+
+    class SampledSteps(object):
+        """A phase's batches (Manager.train iterates over it once); switches the kernel clock's events on for every `every`-th step
+        of the cycle and back on behind the last one (validates are always clocked)."""
+
+        def __init__(self, n, offset):
+            self.batches, self.first = [pool[(offset + i) % len(pool)] for i in range(n)], offset
+
+        def __len__(self):
+            return len(self.batches)
+
+        def __iter__(self):
+            for i, b in enumerate(self.batches):
+                clock.timing, clock.step = (self.first + i) % every == every // 2, self.first + i
+                yield b
+            clock.timing, clock.step = True, None
+
     def loader(n, offset):
+        if clock is not None:
+            return SampledSteps(n, offset)
         return [pool[(offset + i) % len(pool)] for i in range(n)]
 
     def sgd(lr, pruner, lr_mask):
@@ -688,6 +735,9 @@ def main():
                     help="'full' (default, ~6 min of host time): SURVEY 8d's CPU baseline -- 3 train steps at batch 256 on the faster thread "
                          "setting + BASELINE.md section 4's configs[0] plumbing cycle; 'quick': the batch-64 probe only (~1.5 min)")
     ap.add_argument('--no-kernel-clock', action='store_true')
+    ap.add_argument('--clock-every', type=int, default=4,
+                    help='HIP events around the masked-layer launches of every N-th train step of the timed cycle and of every validate '
+                         '(1 = every launch; the launches of the other steps are counted, not timed)')
     a = ap.parse_args()
 
     if a.global_batch:
@@ -728,6 +778,7 @@ def main():
     nl.set_conv_math(a.math)
     from cpg_amd import _lib
     clock = KernelClock()
+    clock.every = max(1, a.clock_every)
     if not a.no_kernel_clock and rank == 0:
         proxy = clock.wrap(_lib.lib())
         _lib._lib = proxy                                  # route the Python mirror's calls through the timers
@@ -858,7 +909,7 @@ def main():
             buckets = list(model.last_bucket_log)
             out['multi_gpu']['buckets'] = [{'kind': k, 'bytes': b} for k, b in buckets]
             out['multi_gpu'].update(predict_step_ms(a.arch, world, buckets, batch=a.batch))
-        agg = clock.summary()
+        agg = clock.summary(a.steps)
         if agg:
             tot_ms = sum(v[1] for v in agg.values())
             fam = {}
@@ -897,14 +948,22 @@ def main():
                                'launches': cnt, 'avg_launch_ms': round(ms / cnt, 4),
                                'share_of_masked_kernel_time': round(ms / tot_ms, 3)}
             # the whole timed region against the dense peak, in executed multiply-adds (every masked launch, train + validate)
-            ex_all = sum(v[3] for v in fam.values())
-            fl_all = sum(v[2] for v in fam.values())
+            # (every launch of the region: the clocked ones un-weighted + the ones that were only counted)
+            ex_all = sum(r[4] for r in clock.records) + clock.unclocked[2]
+            fl_all = sum(r[1] for r in clock.records) + clock.unclocked[1]
             out['whole_step'] = {'mfma_tflops_executed': round(ex_all / dt / 1e12, 2),
                                  'frac_of_dense_fp32_mfma_peak': round(ex_all / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                  'algorithmic_tflops': round(fl_all / dt / 1e12, 2),
                                  'frac_of_launch_mix_ceiling': round(ex_all / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                  'launch_mix_ceiling_tflops': round(PEAK_FP32_MFMA_TFLOPS * fl_all / ex_all, 2),
-                                 'note': 'all masked conv / linear launches of the timed region (train steps and validates) over the wall time'}
+                                 'note': 'all masked conv / linear launches of the timed region (train steps and validates; clocked or only '
+                                         'counted) over the wall time'}
+            out['kernel_clock'] = {'every': clock.every, 'train_steps_clocked': clock.train_steps_clocked,
+                                   'launches_clocked': clock.launches_clocked, 'launches_counted_only': clock.unclocked[0],
+                                   'note': 'HIP events around the masked-layer launches of every N-th train step of the cycle and of every '
+                                           'validate (an event pair costs the queue ~ 7 us); roofline / kernel_families are averages over the '
+                                           'clocked launches, a train-step launch weighted by train steps / clocked train steps (a stratified '
+                                           'sample of the region: launch counts and ms are the estimates for all of it)'}
             out['kernel_families'] = {k: dict({'launches': v[0], 'ms': round(v[1], 2), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2),
                                                'mfma_tflops_executed': round(v[3] / (v[1] * 1e-3) / 1e12, 2),
                                                'algorithmic_bytes_per_launch': round(v[4] / v[0]),
@@ -915,7 +974,7 @@ def main():
                 out['winograd_note'] = ('launches for which cpg_conv2d_winograd() answers 1 (3x3 s1 p1 convs on even maps with >= 16 channels: forward, '
                                         'input gradient, weight gradient, inference epilogue) run Winograd F(2x2,3x3): "tflops" counts the ALGORITHMIC '
                                         'flops of SURVEY section 8d, "mfma_tflops_executed" the multiply-adds the MFMA pipe really performed (16/36 of them)')
-            out['masked_kernel_ms_per_step'] = round(tot_ms / a.steps, 2)
+            out['masked_kernel_ms_per_step'] = round(clock.train_ms / max(1, clock.train_steps_clocked), 2)     # (train steps; validates apart)
             if os.environ.get('CPG_BENCH_DETAIL'):
                 out['kernel_detail'] = {k: {'n': v[0], 'ms': round(v[1], 2), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2), 'winograd': v[3] < v[2]}
                                         for k, v in sorted(agg.items())}

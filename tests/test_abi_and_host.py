@@ -429,3 +429,30 @@ def test_bench_cycle_plan_and_scaling_table():
     assert pr['single_gpu_ms_per_step'] == b.single_gpu_ms('vgg16', 32) and pr['predicted_ms_per_step'] > pr['single_gpu_ms_per_step']
     assert len(b.csrc_digest()) == 64
 
+
+
+def test_bench_kernel_clock_weights_the_sampled_train_steps():
+    """bench.py --clock-every N: events on some train steps only, on every validate; the summary weights a train-step record by
+    train steps / clocked train steps, so family averages estimate the all-launch figures (launch counts included)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod2', os.path.join(ROOT, 'bench.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+
+    class Ev(object):
+        def __init__(self, ms):
+            self.ms = ms
+
+        def elapsed_time(self, other):
+            return other.ms
+
+    c = b.KernelClock()
+    for step in (2, 6):                                     # two of eight train steps clocked, 3 launches each, 2 ms each
+        for _ in range(3):
+            c.records.append(('conv_fwd 3x3', 10.0, Ev(0), Ev(2.0), 10.0 / 2.25, 100.0, step))
+    c.records.append(('conv_fwd 3x3', 4.0, Ev(0), Ev(1.0), 4.0, 40.0, None))       # a validate launch: always clocked, weight 1
+    agg = c.summary(train_steps=8)
+    n, ms, fl, ex, nb = agg['conv_fwd 3x3']
+    assert n == 25 and abs(ms - (24 * 2.0 + 1.0)) < 1e-9 and abs(fl - (24 * 10.0 + 4.0)) < 1e-9 and abs(nb - 2440.0) < 1e-9
+    assert c.train_steps_clocked == 2 and abs(c.train_ms - 12.0) < 1e-9 and c.launches_clocked == 7
+    assert b.KernelClock().summary(train_steps=8) == {}
