@@ -572,12 +572,12 @@ def cpu_plumbing_cycle(steps=220, batch=32):
     return steps * batch / dt, dt, events, validates
 
 
-def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch=64, level='full'):
+def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch=None, level='full'):
     """Oracle ("port") of the same cycle on the host cores, reported beside the GPU number (never the target).
     oracle/ is only ever used here as the measured CPU baseline.
 
-    1. Thread setting: >= 3 timed train steps at `probe_batch` under BOTH settings -- torch's default for the host (one thread per
-       physical core) and SURVEY 8d's os.cpu_count() (every SMT thread); the faster is used below, both rates are fields.
+    1. Thread setting: >= 3 timed train steps at `probe_batch` (32 under 'full', 64 under 'quick') under BOTH settings -- torch's
+       default for the host (one thread per physical core) and SURVEY 8d's os.cpu_count() (every SMT thread); the faster is used below, both rates are fields.
     2. level 'full' (default): 3 timed train steps (after one warm-up step) at the GPU's own batch (256) under that setting -- section
        8d's configuration, no batch extrapolation; `value` is built on this rate.  level 'quick': step 2 is skipped and the probe
        rate is used (`extrapolated_from_probe_batch`: true).
@@ -588,6 +588,10 @@ def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch
     images) priced with those CPU times.  Images come from the same seeded N(0,1) / randint generator as the GPU run's."""
     from oracle import net as onet
     from oracle import ops as oops
+    if probe_batch is None:
+        # 'full': the probe only picks the thread setting (value is built on the batch-256 sample), and every SMT thread is ~4 x slower --
+        # 32 images keep that leg at ~1.5 min; 'quick' builds value on the probe itself: 64
+        probe_batch = 32 if level == 'full' else 64
     default_threads = torch.get_num_threads()
     all_threads = os.cpu_count() or default_threads
     model, pruner, opt = onet.make_task1(1.0, 'imagenet', 'finetune', lr=1e-2, wd=4e-5)
@@ -732,7 +736,7 @@ def main():
                          'headline as opt_in_conv_math, never as value); 0 = skip')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline', default='full', choices=['full', 'quick'],
-                    help="'full' (default, ~6 min of host time): SURVEY 8d's CPU baseline -- 3 train steps at batch 256 on the faster thread "
+                    help="'full' (default, ~8 min of host time): SURVEY 8d's CPU baseline -- 3 train steps at batch 256 on the faster thread "
                          "setting + BASELINE.md section 4's configs[0] plumbing cycle; 'quick': the batch-64 probe only (~1.5 min)")
     ap.add_argument('--no-kernel-clock', action='store_true')
     ap.add_argument('--clock-every', type=int, default=4,
