@@ -112,7 +112,7 @@ with open(os.path.join(P, '%s_final.md' % out), 'w') as f:
     w('* %s\n' % roof(b20))
     cb = b220.get('cpu_baseline') or {}
     w('* `cpu_baseline` (K = 220 run, section-8d configuration): %s\n\n' % json.dumps({k: v for k, v in cb.items() if k != 'sample'}))
-    w('## bench.py, K = 20 (HIP events around every C-ABI launch of the timed region)\n\n%s\n\n' % fam_table(b20))
+    w('## bench.py, K = 20 (HIP events around the C-ABI launches of every 4th train step and of every validate; launch counts and ms are the estimates for the whole timed region)\n\n%s\n\n' % fam_table(b20))
     w('phases: `%s`\n\n' % json.dumps(b20['phases']))
     w(traffic_table())
     w('## rocprofv3 --kernel-trace --stats of the same command (25 train + 4 eval passes incl. warm-up)\n\n')
