@@ -782,7 +782,7 @@ def main():
     nl.set_conv_math(a.math)
     from cpg_amd import _lib
     clock = KernelClock()
-    clock.every = max(1, a.clock_every)
+    clock.every = max(1, a.clock_every) if a.steps >= 4 * max(1, a.clock_every) else 1     # (short runs: every launch)
     if not a.no_kernel_clock and rank == 0:
         proxy = clock.wrap(_lib.lib())
         _lib._lib = proxy                                  # route the Python mirror's calls through the timers
