@@ -783,6 +783,10 @@ def main():
     from cpg_amd import _lib
     clock = KernelClock()
     clock.every = max(1, a.clock_every) if a.steps >= 4 * max(1, a.clock_every) else 1     # (short runs: every launch)
+    if os.environ.get('ROCPROF_COUNTER_COLLECTION', '').lower() not in ('', '0', 'false', 'off'):
+        # under `rocprofv3 --pmc` a queue that carries events on some steps only was aborted with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT
+        # (ResNet-50, ROCm 7.2; every launch clocked, or none, runs): counter passes clock every launch
+        clock.every = 1
     if not a.no_kernel_clock and rank == 0:
         proxy = clock.wrap(_lib.lib())
         _lib._lib = proxy                                  # route the Python mirror's calls through the timers
