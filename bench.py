@@ -669,8 +669,8 @@ def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch
 XGMI_LINK_GBS = 153.0                # MI355X_MICROARCH / task statement: 7 links x ~153 GB/s per GPU, point to point
 RCCL_ALLREDUCE_BUSBW_GBS = 310.0     # assumed large-message bus bandwidth of an 8-GPU RCCL all-reduce over xGMI (two links' worth)
 OVERLAP_SLOWDOWN = 1.17              # conv kernels beside 16 busy CUs' worth of other streams' kernels (tools/diag_interference.py)
-# cycle ms per step on ONE GPU by per-GPU batch (profiles/r04*_bench*.json; the 128 / 64 / 32 rows are the reference's own split: 256 images over 2 / 4 / 8 GPUs)
-SINGLE_GPU_MS_PER_STEP = {'vgg16': {256: 110.0, 128: 57.6, 64: 31.8, 32: 18.9}, 'resnet50': {256: 70.5}, 'spherenet20': {256: 20.9}}
+# cycle ms per step on ONE GPU by per-GPU batch (profiles/r04c_bench*.json; the 128 / 64 / 32 rows are the reference's own split: 256 images over 2 / 4 / 8 GPUs)
+SINGLE_GPU_MS_PER_STEP = {'vgg16': {256: 109.3, 128: 57.5, 64: 31.7, 32: 18.7}, 'resnet50': {256: 69.8}, 'spherenet20': {256: 20.6}}
 
 
 def single_gpu_ms(arch, batch):
