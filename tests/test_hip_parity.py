@@ -1562,7 +1562,9 @@ def test_fused_bn_relu_matches_torch(N, C, H, W, training):
     assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked)
 
 
-@pytest.mark.parametrize('N,C,H,W', [(4, 64, 56, 56), (2, 16, 224, 224), (8, 512, 14, 14), (3, 5, 6, 10), (2, 3, 2, 2)])
+# (block-per-plane, wave-per-plane and the flattened small-plane walk of the backward passes)
+@pytest.mark.parametrize('N,C,H,W', [(4, 64, 56, 56), (2, 16, 224, 224), (8, 512, 14, 14), (3, 5, 6, 10), (2, 3, 2, 2), (2, 8, 112, 112),
+                                     (3, 7, 28, 28), (2, 5, 4, 8), (1, 2, 2, 4)])
 @pytest.mark.parametrize('training', [True, False])
 def test_fused_bn_relu_pool_matches_torch(N, C, H, W, training):
     from cpg_amd.models.fused_bn import bn_relu_pool
