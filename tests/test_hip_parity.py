@@ -565,16 +565,59 @@ def test_winograd_wgrad_matches_direct(N, C, H, W, K, pm, libopt):
     gl, pl = run()
     assert torch.equal(g1, gl) and (not pm or torch.equal(p1, pl))
     libopt.set('CPG_WW_SHARE', None)
-    libopt.set('CPG_NO_WINO_WGRAD', '1')
-    g0, p0 = run()
     raw = nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), padding=1)
     ref_w = raw * (pmv > 5e-3).double() if pm else raw
     sc = float(raw.abs().max())
+    # more, shorter units per wave slot (what cpg_amd.dist asks for beside RCCL's kernels: 4): other split points, the same sums
+    for units in (2, 4):
+        libopt.set('CPG_WW_UNITS', units)
+        gu, pu = run()
+        assert float((gu - ref_w).abs().max()) < 1e-5 * sc, units
+        if pm:
+            assert float((pu - raw * w.double()).abs().max()) < 1e-5 * float((raw * w.double()).abs().max()), units
+    libopt.set('CPG_WW_UNITS', None)
+    libopt.set('CPG_NO_WINO_WGRAD', '1')
+    g0, p0 = run()
     assert float((g1 - ref_w).abs().max()) < 1e-5 * sc and float((g0 - ref_w).abs().max()) < 1e-5 * sc
     assert not torch.equal(g1, g0)
     if pm:
         ref_p = raw * w.double()
         assert float((p1 - ref_p).abs().max()) < 1e-5 * float(ref_p.abs().max())
+
+
+@pytest.mark.parametrize('C,K,H', [(128, 256, 56), (64, 64, 112), (512, 512, 14)])
+def test_winograd_wgrad_shared_chip_hint_full_batch(C, K, H):
+    """The weight gradient a rank computes beside RCCL's kernels (cpg_set_shared_chip_hint(1): 4 units per wave slot instead of 1 --
+    other split points and a 4 x larger partial-sum workspace) at batch 256, on the three staging variants (four waves sharing the rows
+    and the transform, pairs sharing the rows, the 14-pixel maps): equal to the idle-chip launch up to the order of the partial sums,
+    bit-identical when repeated, and the hint changes the plan (workspace bytes)."""
+    import ctypes
+    from cpg_amd import _lib
+    lib = _lib.lib()
+    N = 256
+    g = torch.Generator().manual_seed(C + K + H)
+    x = torch.randn(N, C, H, H, generator=g).relu_().to(DEV)
+    gy = torch.randn(N, K, H, H, generator=g).to(DEV)
+    layer = nl.SharableConv2d(C, K, 3, padding=1, bias=False).to(DEV)
+    layer.weight.data.copy_(torch.randn(K, C, 3, 3, generator=g) * 0.1)
+    d = nl._conv_desc((N, C, H, H), (K, C, 3, 3), (1, 1), (1, 1), (1, 1), 1)
+
+    def run():
+        layer.zero_grad()
+        layer(x).backward(gy)
+        return layer.weight.grad.clone()
+    try:
+        ws0 = int(lib.cpg_conv2d_workspace_bytes(ctypes.byref(d)))
+        g0 = run()
+        assert lib.cpg_set_shared_chip_hint(1) == 0
+        ws1 = int(lib.cpg_conv2d_workspace_bytes(ctypes.byref(d)))
+        g1, g1b = run(), run()
+    finally:
+        lib.cpg_set_shared_chip_hint(0)
+    assert ws1 > ws0
+    assert torch.equal(g1, g1b)
+    sc = float(g0.abs().max())
+    assert float((g1 - g0).abs().max()) < 1e-5 * sc and not torch.equal(g1, g0)
 
 
 @pytest.mark.parametrize('B,I,O,pm', [(32, 25088, 512, False), (256, 4096, 4096, True), (7, 513, 129, True), (1, 64, 5, False),
