@@ -620,6 +620,40 @@ def test_winograd_wgrad_shared_chip_hint_full_batch(C, K, H):
     assert float((g1 - g0).abs().max()) < 1e-5 * sc and not torch.equal(g1, g0)
 
 
+@pytest.mark.parametrize('N,C,K,H,ks,stride', [(32, 64, 256, 56, 1, 1), (32, 256, 64, 56, 1, 1), (16, 512, 2048, 7, 1, 1), (32, 256, 512, 56, 1, 2),
+                                               (32, 128, 128, 28, 3, 2), (8, 48, 80, 20, 3, 1), (64, 3, 64, 112, 3, 2)])
+def test_direct_weight_gradients_under_the_shared_chip_hint(N, C, K, H, ks, stride):
+    """The split-K weight-gradient kernels that are not Winograd (pointwise, strided / odd-channel 3 x 3, the stride-2 stems: ResNet-50's
+    and SphereNet-20's layers) plan 4 instead of 2 blocks per CU under cpg_set_shared_chip_hint(1) -- the launch plan of a rank of a
+    multi-GPU job.  Same gradient (fp64 reference), bit-identical when repeated."""
+    from cpg_amd import _lib
+    lib = _lib.lib()
+    pad = ks // 2
+    g = torch.Generator().manual_seed(N + C + K + H)
+    x = torch.randn(N, C, H, H, generator=g).relu_()
+    w = torch.randn(K, C, ks, ks, generator=g) * 0.1
+    OH = (H + 2 * pad - ks) // stride + 1
+    gy = torch.randn(N, K, OH, OH, generator=g)
+    layer = nl.SharableConv2d(C, K, ks, stride=stride, padding=pad, bias=False).to(DEV)
+    layer.weight.data.copy_(w)
+    xd, gyd = x.to(DEV), gy.to(DEV)
+
+    def run():
+        layer.zero_grad()
+        layer(xd).backward(gyd)
+        return layer.weight.grad.cpu().double()
+    try:
+        g0 = run()
+        assert lib.cpg_set_shared_chip_hint(1) == 0
+        g1, g1b = run(), run()
+    finally:
+        lib.cpg_set_shared_chip_hint(0)
+    ref = nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), stride=stride, padding=pad)
+    sc = float(ref.abs().max())
+    assert torch.equal(g1, g1b)
+    assert float((g0 - ref).abs().max()) < 1e-5 * sc and float((g1 - ref).abs().max()) < 1e-5 * sc
+
+
 @pytest.mark.parametrize('B,I,O,pm', [(32, 25088, 512, False), (256, 4096, 4096, True), (7, 513, 129, True), (1, 64, 5, False),
                                       (256, 4096, 4096, False), (100, 1024, 256, False), (48, 260, 384, False),
                                       # features.45 of config 2 at its own shape (89 % of all masked weights), both mask modes,
