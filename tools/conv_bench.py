@@ -22,7 +22,10 @@ VGG = [('f0', 3, 64, 224, 1), ('f3', 64, 64, 224, 1), ('f7', 64, 128, 112, 1), (
 
 
 def timeit(fn, iters):
-    fn()
+    rc = fn()
+    if rc:      # (an --ab value that changes the launch plan may outgrow the workspace sized for the default plan: say so, do not time the refusal)
+        from cpg_amd import _lib
+        raise RuntimeError('launch refused (rc %d): %s' % (rc, _lib.lib().cpg_last_error().decode() if hasattr(_lib.lib(), 'cpg_last_error') else ''))
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
@@ -101,6 +104,11 @@ def main():
                 var, vals = a.ab.split('=')
                 vals = vals.split(',')
                 res = {v: [] for v in vals}
+                for v in vals:          # a value may change the launch plan (units per wave slot, ...): size the workspace for the largest
+                    _lib.set_option(var, None if v == '-' else v)
+                    need = L.cpg_conv2d_workspace_bytes(ctypes.byref(d))
+                    if need > nb:
+                        ws, nb = _lib.workspace(need, dev)
                 for _ in range(a.reps):
                     for v in vals:
                         _lib.set_option(var, None if v == '-' else v)      # (the library reads the environment only when it is loaded)
