@@ -207,6 +207,15 @@ class KernelClock:
         return agg
 
 
+def _flush_c_stdio():
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:       # (no libc handle: nothing buffered that we could reach)
+        pass
+
+
 def csrc_digest():
     """sha256 over the kernel sources (cpg_amd/csrc, sorted by name): committed counter files carry the digest of the sources they
     were measured on, so that a kernel change makes `roofline.traffic` say it is stale instead of silently quoting old bytes."""
@@ -877,6 +886,12 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         replicas_identical = bool(torch.equal(lo, hi))
+    again_ms = phases = None
+    if a.task == 2:
+        # (every rank: the leg's train steps exchange gradients; after the timed region, the replica checksum and the phase report,
+        # which prices a rank-prune event on the cycle's final masks)
+        phases = phase_report(marks, model, masks, a.batch) if rank == 0 else None
+        again_ms = finetune_again_leg(model, masks, pool, val_pool, max(2, min(a.steps, 10)))
     if rank == 0:
         global_batch = a.batch * world
         value = global_batch * a.steps / dt
@@ -986,9 +1001,8 @@ def main():
             if os.environ.get('CPG_BENCH_DETAIL'):
                 out['kernel_detail'] = {k: {'n': v[0], 'ms': round(v[1], 2), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2), 'winograd': v[3] < v[2]}
                                         for k, v in sorted(agg.items())}
-        out['phases'] = phase_report(marks, model, masks, a.batch)
+        out['phases'] = phases if phases is not None else phase_report(marks, model, masks, a.batch)
         if a.task == 2:
-            again_ms = finetune_again_leg(model, masks, pool, val_pool, max(2, min(a.steps, 10)))
             out['task2'] = {'task1_ms_per_step': round(task1_ms, 3), 'task2_over_task1': round(1000.0 * dt / a.steps / task1_ms, 4),
                             'free_share_handed_to_task2': round(free_share, 4), 'lr_mask_finetune': 5e-4, 'lr_mask_prune': 0.0,
                             'finetune_again_ms_per_step': round(again_ms, 3),
@@ -1003,10 +1017,17 @@ def main():
                                                    prune_events=counts['prune_events'], level=a.cpu_baseline)
             else:
                 out['cpu_baseline'] = None      # oracle/net.py restates the VGG16 cycle only (the headline); see --arch vgg16
-        print(json.dumps(out), flush=True)
+    # The ONE JSON line must be the last thing on stdout.  RCCL writes its version banner through C stdio, which is block-buffered on
+    # a pipe and would otherwise come out at process exit, behind the line: every rank empties its C buffers, then a barrier, then
+    # rank 0 prints.
+    _flush_c_stdio()
     if dist.is_initialized():
         dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
         dist.destroy_process_group()
+        _flush_c_stdio()
 
 
 if __name__ == '__main__':

@@ -257,6 +257,21 @@ def test_bench_self_launches_two_ranks(tmp_path):
     assert odd.returncode != 0 and 'divisible' in (odd.stderr + odd.stdout)
 
 
+def test_bench_json_line_is_the_last_stdout_line_with_rccl(tmp_path):
+    """With a process group on RCCL (here: world 1, CPG_DP_FORCE=1 -- every hook and collective of the N > 1 path) RCCL's version banner
+    sits in the C stdio buffer of a piped stdout until the process ends; bench.py must still END its stdout with the one JSON line."""
+    import json
+    import subprocess
+    env = dict(os.environ, CPG_DP_FORCE='1', RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--batch', '4',
+                        '--no-cpu-baseline', '--optin-steps', '0'], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert lines[-1].startswith('{'), lines[-5:]
+    out = json.loads(lines[-1])
+    assert out['n_gpus'] == 1 and out['steps'] == 3 and 'roofline' in out
+
+
 @pytest.mark.parametrize('arch', ['resnet50', 'vgg16'])
 def test_bench_task2_line(arch):
     """`bench.py --task 2` end to end at a tiny batch: the task-1 leg, the switch to task 2 (30 % of every layer free, a new head with ITS OWN
