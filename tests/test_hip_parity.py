@@ -620,6 +620,40 @@ def test_winograd_wgrad_shared_chip_hint_full_batch(C, K, H):
     assert float((g1 - g0).abs().max()) < 1e-5 * sc and not torch.equal(g1, g0)
 
 
+@pytest.mark.parametrize('hint', [0, 1])
+def test_winograd_kernels_repeat_bit_for_bit_at_full_occupancy(hint):
+    """The shared-staging / shared-transform Winograd kernels hand operands between waves through double-buffered LDS behind LDS-only
+    barriers: a hazard there shows as run-to-run differences at batch 256 (every wave slot of the chip busy) before it shows in a
+    tolerance test.  Forward with BatchNorm statistics, input gradient and weight gradient of three layers (four waves sharing, pairs
+    sharing, the 14-pixel maps), six repetitions each, with the idle-chip and the multi-GPU launch plans (tools/soak_determinism.py
+    runs all eight VGG16 shapes x 20)."""
+    from cpg_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    try:
+        assert lib.cpg_set_shared_chip_hint(hint) == 0
+        for C, K, H in [(128, 256, 56), (64, 64, 112), (512, 512, 14)]:
+            x = torch.randn(256, C, H, H, generator=g, device=DEV).relu_().requires_grad_(True)
+            gy = torch.randn(256, K, H, H, generator=g, device=DEV)
+            layer = nl.SharableConv2d(C, K, 3, padding=1, bias=False).to(DEV)
+            layer.weight.data.normal_(0, 0.05, generator=g)
+            first = None
+            for r in range(6):
+                layer.zero_grad()
+                x.grad = None
+                y, stats = layer.forward_with_bn_stats(x)
+                y.backward(gy)
+                cur = (y.detach().clone(), stats.detach().clone(), x.grad.clone(), layer.weight.grad.clone())
+                if first is None:
+                    first = cur
+                else:
+                    for name, p, q in zip(('y', 'stats', 'gx', 'gw'), first, cur):
+                        assert torch.equal(p, q), (C, K, H, r, name)
+            del x, gy, layer, first, cur
+    finally:
+        lib.cpg_set_shared_chip_hint(0)
+
+
 @pytest.mark.parametrize('N,C,K,H,ks,stride', [(32, 64, 256, 56, 1, 1), (32, 256, 64, 56, 1, 1), (16, 512, 2048, 7, 1, 1), (32, 256, 512, 56, 1, 2),
                                                (32, 128, 128, 28, 3, 2), (8, 48, 80, 20, 3, 1), (64, 3, 64, 112, 3, 2)])
 def test_direct_weight_gradients_under_the_shared_chip_hint(N, C, K, H, ks, stride):
