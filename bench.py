@@ -925,7 +925,8 @@ def main():
                                 'per_rank_ms_per_step': per_rank_ms,
                                 'exposed_allreduce_ms_per_step': round(sync_ms / max(1, len(ev)), 3),
                                 'allreduced_gradient_bytes_per_step': int(sum(p.numel() for p in net.parameters() if p.requires_grad) * 4),
-                                'dropout_seed_rank0': dropout_seed, 'replicas_identical_after_cycle': replicas_identical}
+                                'dropout_seed_rank0': dropout_seed, 'replicas_identical_after_cycle': replicas_identical,
+                                'shared_chip_hint': getattr(model, 'shared_chip_hint', 0)}
             # the messages of one train step in launch order (kind, bytes): 'chunk' = a row block of a very large linear weight
             # handed over while its producer still runs, 'tensor' = one large gradient, 'packed' = the surviving slots of a
             # layer, 'coalesced' = all small tensors (BatchNorm, biases, head) in one message after backward

@@ -1327,8 +1327,10 @@ W3Plan w3_plan(const cpg_conv_desc *d) {
     const int64_t tiles = (int64_t)p.tiles_co * p.tiles_ci;
     // split blocks per CU (each split writes a full set of partial sums): 2 instead of round 2's 4 -- SphereNet-20 20.96 -> 20.78,
     // ResNet-50 73.83 -> 73.49 ms per step (A/B through CPG_C3W_BPC; 8: 21.45 / 74.11)
-    int bpc = shared_chip_hint() ? 4 : 2;      // (data parallel: RCCL's kernels hold CUs -- a one-round launch would grow by a whole round)
-    bpc = std::max(1, opt_or(OPT_C3W_BPC, bpc));
+    // (until round 4 the shared-chip hint of a multi-GPU rank doubled this; measured beside RCCL's kernels -- a world-1 group, every hook
+    // and message of the N > 1 path -- 4 blocks per CU cost ResNet-50 1.4 ms and SphereNet-20 0.9 ms per step, more than the whole
+    // all-reduce of their gradients lasts: profiles/r04_ab_shared_chip_plans.txt)
+    const int bpc = std::max(1, opt_or(OPT_C3W_BPC, 2));
     int64_t want = ((int64_t)bpc * kCUs + tiles - 1) / tiles;
     if (want > units) want = units;
     if (want < 1) want = 1;

@@ -590,8 +590,8 @@ PwWPlan pw_wgrad_plan(const cpg_conv_desc *d) {
     const int64_t tiles = (int64_t)p.tiles_co * p.tiles_ci;
     // split blocks per CU: every split writes a full set of partial sums that k_split_reduce reads back; 2 (one round of the two
     // resident blocks) instead of round 2's 4: ResNet-50 73.83 -> 72.98 ms per step (A/B through CPG_PWW_BPC)
-    int bpc = shared_chip_hint() ? 4 : 2;      // (data parallel: RCCL's kernels hold CUs -- a one-round launch would grow by a whole round)
-    bpc = std::max(1, opt_or(OPT_PWW_BPC, bpc));
+    // (the shared-chip hint no longer changes this: see conv3x3.hip's weight-gradient planner)
+    const int bpc = std::max(1, opt_or(OPT_PWW_BPC, 2));
     int64_t want = ((int64_t)bpc * kCUs + tiles - 1) / tiles;
     want = std::max<int64_t>(1, std::min<int64_t>(want, (units + 7) / 8));      // at least 8 units per split
     want = (want + kXCDs - 1) / kXCDs * kXCDs;

@@ -78,18 +78,27 @@ class DataParallel(nn.Module):
         self.large_numel = int(large_numel)
         self.chunk_numel, self.nchunks = int(chunk_numel), int(nchunks)       # weights at least this large go out in `nchunks` row blocks
         self.bucket_log = []             # (kind, bytes) of every message of the current step, in launch order (bench.py reports it)
+        self.shared_chip_bytes = 256 << 20     # gradient volume from which RCCL's kernels are a noticeable share of the backward
+        self.shared_chip_hint = 0
         self.last_bucket_log = []
         # CPG_DP_FORCE=1: run the hooks / collectives even at world size 1 (functional test of the RCCL path on one GPU)
         self._active = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size(process_group) > 1 or os.environ.get('CPG_DP_FORCE') == '1')
         self._world = dist.get_world_size(process_group) if self._active else 1
         if self._active and self._world > 1 and any(p.is_cuda for p in module.parameters()):
-            # the gradient all-reduce runs on RCCL's stream beside the backward kernels and holds some CUs: tell the library
-            # (a process-wide hint of its C ABI -- the planners that read it run on autograd's engine thread, not on this one) --
-            # the Winograd weight gradient then uses more, shorter units per wave slot (a launch is `units` rounds of blocks;
-            # conv3x3_wino_wgrad.hip)
+            # the gradient all-reduce runs on RCCL's stream beside the backward kernels and holds some CUs while a message is on the
+            # wire.  When that is a noticeable share of the backward (VGG16: 537 MB of gradients, ~3 ms of an 8-GPU step) tell the
+            # library (a process-wide hint of its C ABI -- the planners that read it run on autograd's engine thread, not on this
+            # one): the Winograd weight gradient then runs two rounds of half-length units per wave slot, so that a launch that finds
+            # CUs taken grows by half instead of doubling (conv3x3_wino_wgrad.hip).  Networks whose whole exchange lasts a few
+            # hundred microseconds (ResNet-50 94 MB, SphereNet-20 56 MB) keep the idle-chip plans: beside RCCL's real kernels the
+            # extra rounds cost more than the exchange lasts (profiles/r04_ab_shared_chip_plans.txt).  CPG_DP_SHARED_CHIP=0 / 1
+            # overrides.
             from . import _lib
-            _lib.lib().cpg_set_shared_chip_hint(1)
+            grad_bytes = sum(p.numel() * p.element_size() for p in module.parameters() if p.requires_grad)
+            want = os.environ.get('CPG_DP_SHARED_CHIP')
+            self.shared_chip_hint = int(want) if want in ('0', '1') else int(grad_bytes >= self.shared_chip_bytes)
+            _lib.lib().cpg_set_shared_chip_hint(self.shared_chip_hint)
         self._handles = []
         self._small = []
         self._chunked = []               # [(param, _ChunkedGradient)] whose row blocks are in flight

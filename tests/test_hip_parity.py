@@ -587,8 +587,8 @@ def test_winograd_wgrad_matches_direct(N, C, H, W, K, pm, libopt):
 
 @pytest.mark.parametrize('C,K,H', [(128, 256, 56), (64, 64, 112), (512, 512, 14)])
 def test_winograd_wgrad_shared_chip_hint_full_batch(C, K, H):
-    """The weight gradient a rank computes beside RCCL's kernels (cpg_set_shared_chip_hint(1): 4 units per wave slot instead of 1 --
-    other split points and a 4 x larger partial-sum workspace) at batch 256, on the three staging variants (four waves sharing the rows
+    """The weight gradient a rank computes beside RCCL's kernels (cpg_set_shared_chip_hint(1): 2 units per wave slot instead of 1 --
+    other split points and a larger partial-sum workspace) at batch 256, on the three staging variants (four waves sharing the rows
     and the transform, pairs sharing the rows, the 14-pixel maps): equal to the idle-chip launch up to the order of the partial sums,
     bit-identical when repeated, and the hint changes the plan (workspace bytes)."""
     import ctypes
@@ -658,8 +658,8 @@ def test_winograd_kernels_repeat_bit_for_bit_at_full_occupancy(hint):
                                                (32, 128, 128, 28, 3, 2), (8, 48, 80, 20, 3, 1), (64, 3, 64, 112, 3, 2)])
 def test_direct_weight_gradients_under_the_shared_chip_hint(N, C, K, H, ks, stride):
     """The split-K weight-gradient kernels that are not Winograd (pointwise, strided / odd-channel 3 x 3, the stride-2 stems: ResNet-50's
-    and SphereNet-20's layers) plan 4 instead of 2 blocks per CU under cpg_set_shared_chip_hint(1) -- the launch plan of a rank of a
-    multi-GPU job.  Same gradient (fp64 reference), bit-identical when repeated."""
+    and SphereNet-20's layers) ignore cpg_set_shared_chip_hint(1) since round 4 (they planned 4 instead of 2 blocks per CU under it)
+    -- the hint of a rank of a multi-GPU job must leave them correct either way.  Same gradient (fp64 reference), bit-identical when repeated."""
     from cpg_amd import _lib
     lib = _lib.lib()
     pad = ks // 2
@@ -2411,7 +2411,7 @@ def test_fused_optimizer_steps_full_size_vs_oracle(kind):
 def test_shared_chip_hint_reaches_the_backward_thread():
     """the weight-gradient planners run inside autograd's backward, i.e. on the engine's worker thread.  The hint
     set on the main thread (what cpg_amd.dist.DataParallel does for world > 1) must be what a backward launch sees: read it -- and the
-    Winograd weight gradient's planned workspace, which grows with the 4-units-per-slot split -- from inside a backward hook."""
+    Winograd weight gradient's planned workspace, which grows with the more-units-per-slot split -- from inside a backward hook."""
     import threading
     L = __import__('cpg_amd._lib', fromlist=['x'])
     lib = L.lib()

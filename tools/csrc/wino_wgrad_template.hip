@@ -444,9 +444,12 @@ bool ww_plan(const cpg_conv_desc *d, WwPlan &p) {
     // passes over the bench (profiles/r03_traffic_bench.json) showed SphereNet-20's weight-gradient launches moving 4 x their
     // algorithmic bytes, 22 % of them in the reduce.  One unit per slot (the units of a launch are equally long: nothing to
     // balance on an idle chip): SphereNet-20 20.96 -> 19.92 ms per step, ResNet-50 73.83 -> 72.69, VGG16 121.10 -> 120.44.
-    // When another stream's kernels (RCCL) hold some CUs a one-round launch would grow by a whole round, so cpg_amd.dist asks
-    // for 4 rounds when it wraps a model for more than one rank (cpg_set_shared_chip_hint).  CPG_WW_UNITS overrides.
-    int upw = shared_chip_hint() ? 4 : 1;
+    // When another stream's kernels (RCCL) hold some CUs a one-round launch grows by a whole round (x 2); with two rounds of
+    // half-length units it grows by one of them (x 1.5) at 0.6 % of the idle-chip time (4 rounds: x 1.25 at 1.5-3 %, 9 % on the
+    // 14-pixel maps).  cpg_amd.dist raises the hint (cpg_set_shared_chip_hint) when a rank's gradients keep RCCL busy for a
+    // noticeable share of the backward (VGG16's 537 MB); until round 4 the hint meant 4 rounds for every multi-GPU rank, which
+    // beside RCCL's real kernels cost more than it can save (profiles/r04_ab_shared_chip_plans.txt).  CPG_WW_UNITS overrides.
+    int upw = shared_chip_hint() ? 2 : 1;
     upw = std::max(1, opt_or(OPT_WW_UNITS, upw));
     int64_t want = std::max<int64_t>(1, ((int64_t)upw * 4 * kCUs) / npairs);
     want = std::min<int64_t>(want, nstages);
