@@ -271,11 +271,12 @@ def pmc_traffic(arch, family, batch):
 
 
 DATASET = 'task1'                    # set by main() from --arch
+WIDTH = 1.0                          # the ROOTED width multiplier the models and SparsePruner's statistics see; set by main() from --width-multiplier
 
 
 def build_model(device, arch='vgg16'):
     torch.manual_seed(1)                       # reference default seed (CPG_cifar100_main_normal.py:79,135)
-    kw = dict(dataset_history=[], dataset2num_classes={}, network_width_multiplier=1.0, shared_layer_info={})
+    kw = dict(dataset_history=[], dataset2num_classes={}, network_width_multiplier=WIDTH, shared_layer_info={})
     if arch == 'vgg16':
         net = models.custom_vgg(VGG_CFG, **kw)             # CPG_imagenet_main.py:193-196
     elif arch == 'resnet50':
@@ -287,7 +288,8 @@ def build_model(device, arch='vgg16'):
     return net.to(device)
 
 
-def make_args(mode, freq, width=1.0, finetune_again=False):
+def make_args(mode, freq, width=None, finetune_again=False):
+    width = WIDTH if width is None else width
     return types.SimpleNamespace(mode=mode, dataset=DATASET, finetune_again=finetune_again, target_sparsity=0.1,
                                  initial_sparsity=0.0, pruning_frequency=freq, weight_decay=4e-5,
                                  network_width_multiplier=width, cuda=True, log_path=None, progress=False)
@@ -734,6 +736,10 @@ def main():
                     help='1 = the headline (task 1: no piggymask).  2 = the cycle 19 of the 20 tasks of configs[1] run: owner masks of a '
                          'finished task 1 (30 %% of every layer free), a piggymask on every masked layer, SGD + Adam(lr_mask); its own line, '
                          'never the headline; also times a task-1 cycle of the same length in the same process (task1_ms_per_step)')
+    ap.add_argument('--width-multiplier', type=float, default=1.0,
+                    help="the reference's RAW --network_width_multiplier (main() takes its square root, CPG_cifar100_main_normal.py:115): 1.5 = "
+                         'the GROWN network most of the 20 tasks of configs[1] run in (experiment1/CPG_cifar100_scratch_mul_1.5.sh:90-94: '
+                         'int(v * 1.2247) = 78 / 156 / 313 / 627 channels, 30723 -> 5016 -> 5016 FC); its own line, never the headline')
     ap.add_argument('--arch', default='vgg16', choices=sorted(ARCHS),
                     help="topology of the cycle: 'vgg16' = the headline (BASELINE.json configs[1]); 'resnet50' / 'spherenet20' = the "
                          'topologies of configs[3] / configs[4] through the same cycle (their own lines, never the headline)')
@@ -785,9 +791,10 @@ def main():
         torch.cuda.set_device(0)
     device = torch.device('cuda', torch.cuda.current_device())
 
-    global DATASET
+    global DATASET, WIDTH
     arch = ARCHS[a.arch]
     DATASET = arch['dataset']
+    WIDTH = 1.0 if a.width_multiplier == 1.0 else a.width_multiplier ** 0.5
     nl.set_conv_math(a.math)
     from cpg_amd import _lib
     clock = KernelClock()
@@ -903,6 +910,9 @@ def main():
                       'on every masked layer, SGD + Adam)' % (a.arch, a.task))
         if a.batch != 256 and a.task == 1 and a.arch == 'vgg16':
             metric += ' (NOT the headline configuration: %d images per GPU instead of 256)' % a.batch
+        if a.width_multiplier != 1.0:
+            metric += (' (NOT the headline configuration: the network grown to raw width multiplier %g = x %.4f channels per layer)'
+                       % (a.width_multiplier, WIDTH))
         out = {'metric': metric, 'value': round(value, 2),
                'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
                'ms_per_step': round(1000.0 * dt / a.steps, 3), 'higher_is_better': True, 'scaling': 'strong' if a.global_batch else 'weak',
@@ -912,12 +922,16 @@ def main():
                + ' / f32 accumulate in the 3x3 convolutions (OPT-IN, not the headline); stem, linear layers, BatchNorm, optimizer f32',
                'config': {'workload': '%s, task-%d CPG cycle (finetune -> prune 0.0->0.1 -> recovery, validate after every 20th train '
                                       'step), batch %d per GPU' % (arch['workload'], a.task, a.batch), 'task': a.task,
-                          'arch': a.arch, 'global_batch': global_batch, 'per_gpu_batch': a.batch, 'parallelism': 'dp%d' % world,
+                          'arch': a.arch, 'width_multiplier_raw': a.width_multiplier, 'width_multiplier_rooted': WIDTH,
+                          'masked_layer_channels': [int(m.weight.shape[0]) for m in net.modules()
+                                                    if isinstance(m, (nl.SharableConv2d, nl.SharableLinear))] if a.width_multiplier != 1.0 else None,
+                          'global_batch': global_batch, 'per_gpu_batch': a.batch, 'parallelism': 'dp%d' % world,
                           'epoch_steps': EPOCH_STEPS, 'cycle': counts,
                           'host_gc': 'collected + frozen after the warm-up (cpg_amd.utils.settle_host_gc, as CPGSession.start_task)'},
                # train steps only, in the ALGORITHMIC flops of SURVEY 8d (Winograd launches execute 16/36 of them, so this can
                # exceed the dense peak; whole_step below prices the step against what the MFMA pipe really had to do)
-               'algorithmic_tflops_train_steps': round(value * arch['flop_train'] / world / 1e12, 2)}
+               # (the per-image constant is the width-1.0 network's; other widths: see whole_step.algorithmic_tflops, from the launches)
+               'algorithmic_tflops_train_steps': round(value * arch['flop_train'] / world / 1e12, 2) if a.width_multiplier == 1.0 else None}
         if world > 1:
             ev = model.sync_events or []
             sync_ms = sum(s.elapsed_time(e) for s, e in ev)
@@ -948,7 +962,7 @@ def main():
             cnt, ms, fl, ex, nb = fam[dom]
             ach = fl / (ms * 1e-3) / 1e12                      # algorithmic flops (SURVEY 8d units) per second
             exe = ex / (ms * 1e-3) / 1e12                      # multiply-adds the MFMA pipe really executed, as flops per second
-            traffic = pmc_traffic(a.arch, dom, a.batch)
+            traffic = pmc_traffic(a.arch, dom, a.batch) if a.width_multiplier == 1.0 else None     # (the committed passes ran at width 1.0)
             dense = PEAK_BF16_MFMA_TFLOPS if dom.endswith('_bf16') else PEAK_FP32_MFMA_TFLOPS
             # The ceiling of THIS launch mix: a launch that runs Winograd F(2x2,3x3) needs 16/36 of its algorithmic multiply-adds,
             # so its algorithmic ceiling is 2.25 x the dense MFMA peak; a direct launch's is the dense peak.  Weighted by MFMA
@@ -1010,10 +1024,10 @@ def main():
                             'note': 'task1_ms_per_step = the task-1 cycle of the same K in the same process, before the switch; the timed '
                                     'region is the task-2 cycle alone; finetune_again = the piggymask retrain leg (lr 1e-3, lr_mask 1e-4, '
                                     'fresh piggymasks), train steps only, timed after the cycle'}
-        if a.math == 'fp32' and world == 1 and a.optin_steps > 0 and a.arch == 'vgg16' and a.task == 1 and a.batch == 256:
+        if a.math == 'fp32' and world == 1 and a.optin_steps > 0 and a.arch == 'vgg16' and a.task == 1 and a.batch == 256 and a.width_multiplier == 1.0:
             out['opt_in_conv_math'] = optin_modes(model, masks, pool, a.optin_steps, a.batch)
         if not a.no_cpu_baseline and world == 1:
-            if a.arch == 'vgg16' and a.task == 1:
+            if a.arch == 'vgg16' and a.task == 1 and a.width_multiplier == 1.0:
                 out['cpu_baseline'] = cpu_baseline(steps=a.steps, batch=a.batch, validates=counts['validates'],
                                                    prune_events=counts['prune_events'], level=a.cpu_baseline)
             else:

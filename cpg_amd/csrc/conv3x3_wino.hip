@@ -70,6 +70,15 @@ __device__ __forceinline__ void wg_divmod(unsigned rel, unsigned d, float inv, u
     rm = (unsigned)(r + (lt - ge) * (int)d);
 }
 
+// First input channel of chunk `ch`.  A channel count that is not a multiple of the chunk (the reference's grown networks: 78 / 313 /
+// 627 channels, models/vgg.py:124-154 with sqrt(1.5)) makes the LAST chunk start at C - 4 instead of past the end: it overlaps the chunk
+// before it, and the pack kernels give the overlapped channels (already contracted there) zero filters.  The conv kernels then never read
+// a channel that does not exist -- no range check, no predicate in the main loop, one scalar min per chunk.
+__host__ __device__ __forceinline__ int wg_chunk_base(int ch, int C) {
+    const int b = ch * WG_CK;
+    return b < C - WG_CK ? b : C - WG_CK;
+}
+
 // ------------------------------------------------------------------------------ weight transform
 __global__ __launch_bounds__(256) void k_wg_pack(const float *__restrict__ w, const float *__restrict__ pm, float thr,
                                                  float *__restrict__ up, int K, int C, int M, int Cin, int nch, int dgrad, int BK) {
@@ -80,13 +89,13 @@ __global__ __launch_bounds__(256) void k_wg_pack(const float *__restrict__ w, co
         const int kl = (int)((o / WG_CK) % BK);
         const int64_t rec = o / (WG_CK * BK);                // kb * nch + ch
         const int ch = (int)(rec % nch), kb = (int)(rec / nch);
-        const int m = kb * BK + kl, c = ch * WG_CK + cl;     // produced / read channel
+        const int m = kb * BK + kl, c = wg_chunk_base(ch, Cin) + cl;     // produced / read channel (the last chunk may overlap the one before)
         float g[3][3];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int s = 0; s < 3; ++s) g[r][s] = 0.0f;
-        if (m < M && c < Cin) {
+        if (m < M && c >= ch * WG_CK) {
             const int co = dgrad ? c : m, ci = dgrad ? m : c;
             const int64_t off = ((int64_t)co * C + ci) * 9;
 #pragma unroll
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_wg_fwd(WgGeom g, c
     auto G = [&](int ch, Regs &r) {
         r.u[0] = *reinterpret_cast<const f32x4 *>(ubase + (int64_t)ch * Cfg::U);
         r.u[1] = *reinterpret_cast<const f32x4 *>(ubase + (int64_t)ch * Cfg::U + Cfg::NT * 4);
-        const int soff = ch * WG_CK * HW * 4;
+        const int soff = wg_chunk_base(ch, g.C) * HW * 4;
 #pragma unroll
         for (int i = 0; i < Cfg::NROW; ++i) r.row[i] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[i], soff, 0);
         if (halo_wave) r.halo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, hoff, soff, 0));
@@ -477,13 +486,13 @@ __global__ __launch_bounds__(256) void k_wg1_pack(const float *__restrict__ w, c
         const int kl = (int)((o / WG_CK) % 32);
         const int64_t rec = o / (WG_CK * 32);
         const int ch = (int)(rec % nch), kb = (int)(rec / nch);
-        const int m = kb * 32 + kl, c = ch * WG_CK + cl;
+        const int m = kb * 32 + kl, c = wg_chunk_base(ch, Cin) + cl;     // (the last chunk may overlap the one before: wg_chunk_base)
         float g[3][3];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int s = 0; s < 3; ++s) g[r][s] = 0.0f;
-        if (m < M && c < Cin) {
+        if (m < M && c >= ch * WG_CK) {
             const int co = dgrad ? c : m, ci = dgrad ? m : c;
             const int64_t off = ((int64_t)co * C + ci) * 9;
 #pragma unroll
@@ -504,7 +513,7 @@ __global__ __launch_bounds__(256) void k_wg1_pack(const float *__restrict__ w, c
                 for (int s = 0; s < 3; ++s) nz |= g[r][s] != 0.0f;
             if (nz) {
                 live[m] = 1;
-                live[Mp + 4 + c / 4] = 1;
+                live[Mp + 4 + ch] = 1;
             }
         }
         float t[4][3], u[16];
@@ -629,7 +638,7 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         float halo;
     };
     auto G_row1 = [&](int ch, Rows &q, int k) {             // k = 0..7: row k & 3 of channel 2 lh + k / 4;  k = 8: the halo values
-        const int soff = ch * WG_CK * HW * 4;
+        const int soff = wg_chunk_base(ch, g.C) * HW * 4;
         if (k < 8)
             q.r[k >> 2][k & 3] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[k & 3], soff + (k >> 2) * HW * 4, 0);
         else
@@ -1041,7 +1050,7 @@ void k_wg2(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         float halo;
     };
     auto G_row1 = [&](int ch, Rows &q, int k) {             // k = 0..5: row k % 3 of channel 2 lh + k / 3;  k = 6: the halo values
-        const int soff = ch * WG_CK * HW * 4;
+        const int soff = wg_chunk_base(ch, g.C) * HW * 4;
         if (k < 6)
             q.r[k / 3][k % 3] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[k % 3], soff + (k / 3) * HW * 4, 0);
         else
@@ -1412,7 +1421,7 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         float halo;
     };
     auto G_row1 = [&](int ch, Rows &q, int k) {             // k = 0..5: row k % 3 of channel 2 lh + k / 3;  k = 6: the halo values
-        const int soff = ch * WG_CK * HW * 4;
+        const int soff = wg_chunk_base(ch, g.C) * HW * 4;
         if (k < 6)
             q.r[k / 3][k % 3] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[k % 3], soff + (k / 3) * HW * 4, 0);
         else
@@ -1434,7 +1443,7 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     const int un_goff = un * HW * 4;
     const int raw_own_s = raw_own + un * 3 * W1_ROW, tr_base = ((2 * lh + un) * 3) * W1_ROW;
     auto G_rows = [&](int ch, Rows &q, int k) {
-        const int soff = ch * WG_CK * HW * 4;
+        const int soff = wg_chunk_base(ch, g.C) * HW * 4;
         if (k < 3)
             q.r[0][k] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[k], soff + un_goff, 0);
         else
@@ -1884,7 +1893,7 @@ int wino_launch(bool dgrad, const WgGeom &g, int64_t tblocks, const float *x, co
 }  // namespace
 
 // ---- host side ---------------------------------------------------------------------------------------------------
-// eligibility of one launch (c_read channels contracted, m produced): even maps, channel chunks of 4, the staging offsets of
+// eligibility of one launch (c_read channels contracted, m produced): even maps, the staging offsets of
 // the images a block can touch fit 31 bits
 // odd maps (7 x 7: ResNet-50 layer4, SphereNet conv4_x): only the two-wave kernel k_wg3 has the edge handling (its ODD instances), and it
 // only pays with a long channel loop -- >= 128 channels read, >= 64 produced, no forced kernel choice
@@ -1893,7 +1902,7 @@ static inline bool wino_odd_ok(int c_read, int m, int H, int W) {
 }
 extern "C" int cpg_conv3x3_wino_ok(int N, int c_read, int m, int H, int W) {
     if (cpg::opt_on(cpg::OPT_NO_WINO)) return 0;
-    if (c_read % 4 || c_read < 16 || m < 16 || N < 1) return 0;
+    if (c_read < 16 || m < 16 || N < 1) return 0;           // (any channel count: wg_chunk_base)
     if (((H | W) & 1) && !wino_odd_ok(c_read, m, H, W)) return 0;
     const int tiles_img = ((H + 1) / 2) * ((W + 1) / 2);
     const int span = (WG_T + tiles_img - 1) / tiles_img + 1;

@@ -16,8 +16,17 @@ session keeps SNAPSHOTS (cloned state_dict + owner masks): "copy the chosen rati
 snapshot restore, "grow" (exit 2 -> bash adds 0.5 to the width multiplier and re-runs finetune from the previous task's
 checkpoint) is `grow()`: a wider net, the previous state copied into its top-left corner, owner masks zero-padded
 (:208-249).  Data loading is whatever iterable of (images, labels) the caller provides.
+
+TWO WIDTH NUMBERS, as in the reference.  The bash loop and the command line carry the RAW multiplier (1.0, 1.5, 2.0 ...:
+experiment1/CPG_cifar100_scratch_mul_1.5.sh:36,90-94 adds 0.5 to it); main() takes its SQUARE ROOT before anything else sees
+it (CPG_cifar100_main_normal.py:115-116), and that rooted number is what the model constructors multiply the channel
+counts with (models/vgg.py:124-154: int(v * m)), what SparsePruner's statistics square again, what is compared with the
+(rooted) cap and what `shared_layer_info[dataset]['network_width_multiplier']` records.  So raw 1.0 -> 1.5 grows VGG16 from
+64 / 128 / 256 / 512 channels to int(v * 1.2247) = 78 / 156 / 313 / 627 -- the parameter count grows by ~1.5, not the channel
+count.  The session keeps both: `width_multiplier` (raw; growth adds `width_step` to it) and `width` = sqrt(raw).
 """
 import copy
+import math
 import types
 
 import torch
@@ -66,7 +75,7 @@ class TaskResult(object):
         self.chosen_ratio = 0.0
         self.needs_growth = False       # the accuracy goal was missed even at the width cap (the reference's exit code 2 with nowhere to go)
         self.no_free_capacity = False   # reference exit code 5
-        self.grown_to = []              # width multipliers tried after the first one
+        self.grown_to = []              # RAW width multipliers tried after the first one (the model widths are their square roots)
         self.retrain_kept = None        # task >= 2: did the piggymask retrain beat the pruned model (choose_retrain_or_not.py)
         self.retrain_acc = None
         self.steps = 0
@@ -79,7 +88,7 @@ class Snapshot(object):
     def __init__(self, sess):
         self.state = {k: v.detach().clone() for k, v in sess.net.state_dict().items()}
         self.masks = {k: v.clone() for k, v in sess.masks.items()}
-        self.width = sess.width
+        self.width, self.width_multiplier = sess.width, sess.width_multiplier
         self.datasets = list(sess.net.datasets)
         self.dataset2num_classes = dict(sess.net.dataset2num_classes)
         self.shared_layer_info = copy.deepcopy(sess.shared_layer_info)
@@ -88,9 +97,17 @@ class Snapshot(object):
 class CPGSession(object):
     """Holds everything the reference passes between processes through checkpoint files."""
 
-    def __init__(self, arch='custom_vgg_cifar100', width=1.0, device='cuda', cfg=VGG16_CFG, data_parallel=True,
-                 fused_optimizers=True, seed=None, freeze_gc=False):
-        self.arch, self.width, self.device = arch, width, torch.device(device)
+    def __init__(self, arch='custom_vgg_cifar100', width=None, device='cuda', cfg=VGG16_CFG, data_parallel=True,
+                 fused_optimizers=True, seed=None, freeze_gc=False, width_multiplier=None):
+        """width_multiplier: the RAW multiplier of the reference's command line (--network_width_multiplier, before main() takes its
+        square root); `width`: the rooted, model-space value the constructors see.  Give one of them (neither: 1.0)."""
+        assert width is None or width_multiplier is None, 'give the rooted width OR the raw width_multiplier'
+        if width_multiplier is not None:
+            self.width_multiplier, self.width = float(width_multiplier), math.sqrt(width_multiplier)      # (:115)
+        else:
+            self.width = 1.0 if width is None else width
+            self.width_multiplier = self.width * self.width
+        self.arch, self.device = arch, torch.device(device)
         self.cfg = cfg
         self.seed = seed
         self.fused_optimizers = fused_optimizers      # MaskedSGD / MaskedAdam: gradient routing fused into the optimizer passes
@@ -102,7 +119,7 @@ class CPGSession(object):
         self.masks = {}
         self.model = None
         self.data_parallel = data_parallel
-        self.net = self._build(width, [], {}, reseed=True)
+        self.net = self._build(self.width, [], {}, reseed=True)
 
     def _build(self, width, datasets, dataset2num_classes, reseed=False):
         """A fresh network of the session's topology.  reseed=True (construction, growth): the global generator is seeded, as
@@ -230,11 +247,13 @@ class CPGSession(object):
         ckpt.collect_task_layers(self.model, self.shared_layer_info, dataset)
         self.shared_layer_info[dataset]['network_width_multiplier'] = self.width
 
-    def grow(self, new_width, snap=None):
-        """The reference's exit code 2: bash adds 0.5 to network_width_multiplier and re-runs `--mode finetune` from the
-        PREVIOUS task's checkpoint (experiment1/CPG_cifar100_scratch_mul_1.5.sh:89-94) into a wider model; weights and
-        BatchNorm vectors land in the top-left corner (utils/manager.py:233-264), the new rows / columns keep their fresh
-        initialisation, owner masks are zero-padded = the new slots are free (CPG_cifar100_main_normal.py:208-232)."""
+    def grow(self, new_width_multiplier, snap=None):
+        """The reference's exit code 2: bash adds 0.5 to the RAW network_width_multiplier and re-runs `--mode finetune` from the
+        PREVIOUS task's checkpoint (experiment1/CPG_cifar100_scratch_mul_1.5.sh:89-94); main() roots it (:115) and builds a wider
+        model with sqrt(raw); weights and BatchNorm vectors land in the top-left corner (utils/manager.py:233-264), the new rows /
+        columns keep their fresh initialisation, owner masks are zero-padded = the new slots are free
+        (CPG_cifar100_main_normal.py:208-232)."""
+        new_width = math.sqrt(new_width_multiplier)
         datasets = list(snap.datasets) if snap is not None else []
         d2n = dict(snap.dataset2num_classes) if snap is not None else {}
         if snap is not None:
@@ -242,7 +261,7 @@ class CPGSession(object):
             self.shared_layer_info.update(copy.deepcopy(snap.shared_layer_info))
         else:
             self.shared_layer_info.clear()
-        self.width = new_width
+        self.width, self.width_multiplier = new_width, float(new_width_multiplier)
         self.net = self._build(new_width, datasets, d2n, reseed=True).to(self.device)
         self.model = cdist.DataParallel(self.net) if self.data_parallel else self.net
         if snap is not None:
@@ -348,33 +367,34 @@ class CPGSession(object):
 
     def run_task(self, dataset, num_classes, train_loader, val_loader, accuracy_goal=0.0, finetune_epochs=1,
                  prune_epochs=1, sparsities=(0.1, 0.2, 0.3), args=None, min_train_acc=0.95, allow_acc_loss=0.0,
-                 max_width=None, width_step=0.5, retrain_epochs=1, total_num_tasks=None):
+                 max_width_multiplier=None, width_step=0.5, retrain_epochs=1, total_num_tasks=None):
         """finetune [-> grow and retry] -> prune sweep -> choose ratio -> (task >= 2) piggymask retrain -> keep the better.
 
         accuracy_goal plays baseline_cifar100_acc.txt's role, min_train_acc the reference's hard-coded 0.95
-        (CPG_cifar100_main_normal.py:452,469,487), max_width its --max_allowed_network_width_multiplier (None: never grow),
+        (CPG_cifar100_main_normal.py:452,469,487), max_width_multiplier its --max_allowed_network_width_multiplier (None: never
+        grow) and width_step the 0.5 bash adds per exit 2 -- both in RAW multiplier units, as on the reference's command line --,
         total_num_tasks its --total_num_tasks (forced pruning at the width cap, :494-506)."""
         res = TaskResult()
         args = args or default_args()
         args = copy.copy(args)
         args.dataset = dataset
         before = self.snapshot() if self.model is not None else None      # the previous task's final checkpoint
-        max_width = self.width if max_width is None else max_width
+        max_raw = self.width_multiplier if max_width_multiplier is None else max_width_multiplier
         while True:
             args.network_width_multiplier = self.width
             task_id = self.start_task(dataset, num_classes)
             mgr, tr, va = self.finetune(args, train_loader, val_loader, finetune_epochs)
             res.finetune_acc, res.finetune_train_acc = va, tr
             res.ratio_to_acc = {0.0: round(va, 4)}
-            at_cap = self.width >= max_width
+            at_cap = self.width_multiplier >= max_raw
             if (tr > min_train_acc and va >= accuracy_goal) or at_cap:
                 # capacity is enough -- or the width cap is reached, where the reference carries on with what it has
                 # (exit 0 / 5, :474-478; a train accuracy below the bar at the cap would make its bash loop exit 2 forever)
                 break
             # exit 2: widen and re-run the finetune from the previous task's checkpoint
-            new_width = min(max_width, self.width + width_step)
-            res.grown_to.append(new_width)
-            self.grow(new_width, before)
+            new_raw = min(max_raw, self.width_multiplier + width_step)         # (bash: bc <<< $network_width_multiplier+0.5)
+            res.grown_to.append(new_raw)
+            self.grow(new_raw, before)
         res.needs_growth = va < accuracy_goal                      # the goal was missed at the width cap: more capacity would be needed
         self.commit_task(dataset)
         if mgr.pruner.calculate_curr_task_ratio() == 0.0:
@@ -385,7 +405,7 @@ class CPGSession(object):
         stages = {}
         prev = 0.0
         must = 0.0
-        if self.width >= max_width and va < accuracy_goal and total_num_tasks:
+        if self.width_multiplier >= max_raw and va < accuracy_goal and total_num_tasks:
             remain = total_num_tasks - len(self.net.datasets)
             must = 1.0 - round(1.0 / (remain + 1), 1)               # :494-506
         for s in sparsities:
@@ -400,7 +420,7 @@ class CPGSession(object):
             if must and s >= must:
                 break
         # ---- tools/choose_appropriate_pruning_ratio_for_next_task.py: sparsest recorded ratio that holds the goal
-        forced = self.width >= max_width and res.ratio_to_acc[0.0] < accuracy_goal
+        forced = self.width_multiplier >= max_raw and res.ratio_to_acc[0.0] < accuracy_goal
         res.chosen_ratio = choose_ratio(res.ratio_to_acc, accuracy_goal, allow_acc_loss, forced)
         self.restore(stages[res.chosen_ratio] if res.chosen_ratio else scratch)
         self.commit_task(dataset)

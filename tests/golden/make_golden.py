@@ -17,6 +17,8 @@ The fixtures pin:
   * apply_mask / make_pruned_zero / make_finetuning_mask (utils/prune.py:213-243)
   * module names/shapes + first forward of VGG / ResNet-50 / SphereNet-20
   * a 12-step prune-mode trajectory of a narrow VGG16-BN (utils/manager.py:39-100)
+  * network growth: raw multiplier + step -> sqrt -> wider model, top-left copy, mask padding
+    (CPG_cifar100_main_normal.py:115,155-232 + utils/manager.py:233-264)
 
 torch version is recorded in every fixture: the reference has no tests of its
 own, so "reference source + this torch CPU build" is the operative oracle.
@@ -765,12 +767,99 @@ def gen_checkpoint():
     print('wrote reference_checkpoint-7.pth.tar', os.path.getsize(os.path.join(OUT, 'reference_checkpoint-7.pth.tar')))
 
 
+def tensor_crc(t):
+    """crc32 of a tensor's bytes (contiguous, CPU): the bit-exact comparison key of the large tensors in growth.npz"""
+    return zlib.crc32(t.detach().cpu().contiguous().numpy().tobytes()) & 0xFFFFFFFF
+
+
+def gen_growth():
+    """The reference's NETWORK GROWTH path (exit code 2) at small scale, run through the reference's own code wherever it is callable:
+
+      bash      adds a step to the RAW multiplier                      (experiment1/CPG_cifar100_scratch_mul_1.5.sh:90-94)
+      main()    takes its square root                                  (CPG_cifar100_main_normal.py:115)
+                reads history / masks / shared_layer_info from the previous task's checkpoint (:155-164)
+                builds the wider model under the run's seed (:135, :184-197: models/vgg.py int(v * sqrt(raw)))
+                zero-pads the owner masks (:208-232)                   [inline code of main(): restated below, line by line]
+      Manager.load_checkpoint  copies the old tensors into the top-left corner (utils/manager.py:233-264)   [called]
+
+    Task 1 lives at raw 1/64 (width 0.125: 8 / 16 / 32 / 64 channels), the grown network at raw 2/64 (width 0.17678: 11 / 22 / 45 / 90
+    channels -- ragged, as 78 / 156 / 313 / 627 are at raw 1.5).  The fixture holds the seeds the state is built from, the grown
+    model's small tensors in full and a crc32 + (sum, abs-sum) of every tensor, and the padded owner masks."""
+    import math
+    import shutil
+    import tempfile
+    from utils.manager import Manager
+    raw0, step = 1.0 / 64, 1.0 / 64
+    raw1 = raw0 + step
+    w0, w1 = math.sqrt(raw0), math.sqrt(raw1)
+    fmt = '{save_folder}/checkpoint-{epoch}.pth.tar'
+    tmp = tempfile.mkdtemp()
+    try:
+        # ---- task 1 at raw0: the seeded initial weights, owner ids as its prune phase leaves them (1 = kept, 0 = released), BatchNorm
+        # statistics off their initial values; written by the reference's Manager.save_checkpoint
+        net = build_ref('vgg_cifar100', w0, dataset='t1')                         # (torch.manual_seed(1) inside)
+        model = nn.DataParallel(net)
+        g = torch.Generator().manual_seed(77)
+        masks, shared = {}, {'t1': {k: {} for k in ('bias', 'bn_layer_running_mean', 'bn_layer_running_var', 'bn_layer_weight',
+                                                     'bn_layer_bias', 'piggymask')}}
+        shared['t1']['network_width_multiplier'] = w0
+        for name, mod in model.named_modules():
+            if isinstance(mod, (nl.SharableConv2d, nl.SharableLinear)):
+                masks[name] = torch.randint(0, 2, mod.weight.shape, generator=g, dtype=torch.uint8)
+            elif isinstance(mod, nn.BatchNorm2d):
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+        fake = types.SimpleNamespace(args=types.SimpleNamespace(checkpoint_format=fmt, dataset='t1'), model=model,
+                                     shared_layer_info=shared, pruner=types.SimpleNamespace(masks=masks))
+        Manager.save_checkpoint(fake, None, 0, tmp)
+        # ---- the next task's `--mode finetune` run after exit code 2, with the raw multiplier raised by `step`
+        checkpoint = torch.load(fmt.format(save_folder=tmp, epoch=1), weights_only=False)
+        dataset_history = checkpoint['dataset_history']                            # (:155-164)
+        dataset2num_classes = checkpoint['dataset2num_classes']
+        masks = checkpoint['masks']
+        shared_layer_info = checkpoint['shared_layer_info']
+        torch.manual_seed(1)                                                       # (:135)
+        model = models.custom_vgg_cifar100(VGG_CFG, dataset_history=dataset_history, dataset2num_classes=dataset2num_classes,
+                                           network_width_multiplier=w1, shared_layer_info=shared_layer_info)      # (:184-191)
+        model.add_dataset('t2', 5)                                                 # (:196-197)
+        model.set_dataset('t2')
+        model = nn.DataParallel(model)
+        for name, module in model.named_modules():                                 # (:208-232, mode finetune: zero-pad = the new slots are free)
+            if isinstance(module, nl.SharableConv2d):
+                assert masks[name].size(1) <= module.weight.data.size(1)
+                mask = torch.ByteTensor(module.weight.data.size()).fill_(0)
+                mask[:masks[name].size(0), :masks[name].size(1), :, :].copy_(masks[name])
+                masks[name] = mask
+            elif isinstance(module, nl.SharableLinear):
+                mask = torch.ByteTensor(module.weight.data.size()).fill_(0)
+                mask[:masks[name].size(0), :masks[name].size(1)].copy_(masks[name])
+                masks[name] = mask
+        fake = types.SimpleNamespace(args=types.SimpleNamespace(checkpoint_format=fmt, dataset='t2'), model=model)
+        Manager.load_checkpoint(fake, None, 1, tmp)                                 # (:348 -> utils/manager.py:233-264)
+    finally:
+        shutil.rmtree(tmp)
+    sd = model.module.state_dict()
+    names = list(sd.keys())
+    arrs = dict(raw0=raw0, raw1=raw1, step=step, width0=w0, width1=w1, seed=1, mask_seed=77,
+                names=np.array(names), shapes=np.array([list(sd[k].shape) + [0] * (4 - sd[k].dim()) for k in names]),
+                crc=np.array([tensor_crc(sd[k]) for k in names], dtype=np.uint32),
+                digest=np.array([[float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in names]),
+                mask_names=np.array(sorted(masks)), mask_crc=np.array([tensor_crc(masks[k]) for k in sorted(masks)], dtype=np.uint32))
+    for k in names:
+        if sd[k].numel() <= 4096:
+            arrs['t/' + k] = sd[k]
+    for k in masks:
+        arrs['m/' + k] = masks[k]
+    save('growth', **arrs)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     if only:                                  # regenerate selected fixtures: python make_golden.py gen_one_shot ...
         for fn in only:
             globals()[fn]()
         sys.exit(0)
+    gen_growth()
     gen_one_shot()
     gen_manager_trajectory()
     gen_net_train_steps()

@@ -297,6 +297,80 @@ def test_resize_masks_pad_on_growth_and_crop_for_inference():
         assert torch.equal(masks[n], old[n])
 
 
+def _growth_session_vs_reference(device):
+    """CPGSession.grow against the REFERENCE's growth path (tests/golden/make_golden.py::gen_growth ran bash's `raw + step`,
+    main()'s square root, the seeded wider model, the inline mask padding and Manager.load_checkpoint's top-left copy:
+    experiment1/CPG_cifar100_scratch_mul_1.5.sh:90-94, CPG_cifar100_main_normal.py:115,135,155-232, utils/manager.py:233-264).
+    The session rebuilds the same task-1 state from the recorded seeds (its seeded initialisation is bit-identical to the
+    reference's: test_seeded_init_matches_reference), grows by the same RAW step and must land on the same channel counts,
+    the same bits in every tensor of the grown model and the same padded owner masks."""
+    import math
+    import zlib
+    from cpg_amd.driver import CPGSession
+
+    def crc(t):
+        return zlib.crc32(t.detach().cpu().contiguous().numpy().tobytes()) & 0xFFFFFFFF
+    g = load_golden('growth')
+    raw0, step = float(g['raw0']), float(g['step'])
+    sess = CPGSession('custom_vgg_cifar100', width_multiplier=raw0, device=device, seed=int(g['seed']))
+    assert sess.width == float(g['width0']) == math.sqrt(raw0)
+    sess.start_task('t1', 5)
+    gen = torch.Generator().manual_seed(int(g['mask_seed']))
+    for name, mod in sess.model.named_modules():
+        if isinstance(mod, (nl.SharableConv2d, nl.SharableLinear)):
+            sess.masks[name].copy_(torch.randint(0, 2, mod.weight.shape, generator=gen, dtype=torch.uint8))
+        elif isinstance(mod, nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=gen) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=gen) + 0.5)
+    sess.commit_task('t1')
+    snap = sess.snapshot()
+    sess.grow(sess.width_multiplier + step, snap)              # bash: network_width_multiplier + step; main(): sqrt
+    sess.start_task('t2', 5)
+    assert sess.width_multiplier == float(g['raw1']) and sess.width == float(g['width1']) == math.sqrt(raw0 + step)
+    assert sess.shared_layer_info['t1']['network_width_multiplier'] == float(g['width0'])
+    assert sess.shared_layer_info['t2']['network_width_multiplier'] == float(g['width1'])        # the ROOTED value (:291)
+    sd = sess.net.state_dict()
+    names = [str(n) for n in g['names']]
+    ours = [k for k in sd if not k.endswith('piggymask')]       # (task 2's piggymasks are created by start_task, :251-270)
+    assert ours == names
+    # the ragged channel counts of the rooted multiplier: int(v * sqrt(2 / 64)) = 11 / 22 / 45 / 90
+    assert [sd['features.%d.weight' % i].shape[0] for i in (0, 7, 14, 24)] == [11, 22, 45, 90]
+    for n, shape, c in zip(names, g['shapes'], g['crc']):
+        assert list(sd[n].shape) == [int(v) for v in shape[:sd[n].dim()]], n
+        if 't/' + n in g.files:
+            assert np.array_equal(sd[n].detach().cpu().numpy(), g['t/' + n]), n
+        assert crc(sd[n]) == int(c), 'grown tensor %s differs from the reference' % n
+    assert sorted(sess.masks) == [str(n) for n in g['mask_names']]
+    for k in sess.masks:
+        assert sess.masks[k].dtype == torch.uint8 and np.array_equal(sess.masks[k].cpu().numpy(), g['m/' + k]), k
+    for _, m in sess.net.named_modules():
+        if isinstance(m, (nl.SharableConv2d, nl.SharableLinear)):
+            assert m.piggymask is not None and m.piggymask.shape == m.weight.shape and bool((m.piggymask == 0.01).all())
+
+
+def test_growth_matches_reference_host():
+    _growth_session_vs_reference('cpu')                         # (construction, copies and mask padding need no kernel)
+
+
+@pytest.mark.gpu
+def test_growth_matches_reference_gpu():
+    _growth_session_vs_reference('cuda:0')
+
+
+def test_growth_from_raw_1_to_1p5_gives_the_reference_channel_counts():
+    """experiment1's one growth step: raw 1.0 + 0.5 -> sqrt(1.5) = 1.2247 -> int(v * 1.2247) = 78 / 156 / 313 / 627 channels and
+    5016-wide FC layers (models/vgg.py:104-121) -- not 1.5 x the channels (96 / 192 / 384 / 768), which is what an additive step in
+    model space would build."""
+    from cpg_amd.driver import CPGSession
+    sess = CPGSession('custom_vgg_cifar100', width_multiplier=1.0, device='cpu', seed=1)
+    assert sess.width == 1.0
+    sess.grow(sess.width_multiplier + 0.5)
+    assert sess.width_multiplier == 1.5 and sess.width == 1.5 ** 0.5
+    sd = sess.net.state_dict()
+    assert [sd['features.%d.weight' % i].shape[0] for i in (0, 3, 7, 14, 24, 40)] == [78, 78, 156, 313, 627, 627]
+    assert tuple(sd['features.45.weight'].shape) == (5016, 627) and tuple(sd['features.47.weight'].shape) == (5016, 5016)
+
+
 def test_choose_ratio_table():
     """The selection rule itself (host logic): walk the record from the sparsest ratio down."""
     from cpg_amd.driver import choose_ratio

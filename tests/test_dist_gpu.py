@@ -193,7 +193,7 @@ def _driver_worker(rank, world, port, out_dir):
         args = default_args(lr=5e-2, lr_mask=5e-4, pruning_frequency=1, pruning_interval=1, prune_lr=1e-2)
         # an unreachable goal at the first width forces the grow branch; min_train_acc sits where shard accuracies can straddle it
         res = sess.run_task('t1', 5, train, val, accuracy_goal=2.0, finetune_epochs=1, prune_epochs=1, sparsities=(0.2, 0.4), args=args,
-                            min_train_acc=0.3, max_width=0.25, width_step=0.125)
+                            min_train_acc=0.3, max_width_multiplier=0.0625, width_step=0.046875)      # raw 1/64 -> 1/16: widths 0.125 -> 0.25
         torch.cuda.synchronize()
         torch.save({'res': {'grown_to': res.grown_to, 'ratio_to_acc': res.ratio_to_acc, 'chosen_ratio': res.chosen_ratio,
                             'finetune_train_acc': res.finetune_train_acc, 'finetune_acc': res.finetune_acc},
@@ -213,7 +213,7 @@ def test_two_ranks_driver_decisions_are_rank_identical(tmp_path):
     r0 = torch.load(os.path.join(tmp_path, 'drv_rank0.pt'))
     r1 = torch.load(os.path.join(tmp_path, 'drv_rank1.pt'))
     assert r0['res'] == r1['res'], (r0['res'], r1['res'])
-    assert r0['res']['grown_to'] == [0.25]                      # the goal was missed at width 0.125: both ranks widened once
+    assert r0['res']['grown_to'] == [0.0625]                      # the goal was missed at width 0.125: both ranks widened once
     for k in r0['sd']:
         assert torch.equal(r0['sd'][k], r1['sd'][k]), 'ranks diverged in %s' % k
     for k in r0['masks']:

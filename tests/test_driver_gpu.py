@@ -103,8 +103,8 @@ def test_growth_pads_masks_keeps_old_weights_and_old_task_logits(tmp_path):
     # task 2 with an unreachable accuracy goal: exit code 2 -> widen by 0.125 (cap 0.25) and finetune again from task 1's state
     tr2, va2 = _loaders(1)
     res2 = sess.run_task('t2', 5, tr2, va2, accuracy_goal=2.0, finetune_epochs=1, prune_epochs=1, sparsities=(0.3,), args=args,
-                         min_train_acc=-1.0, max_width=0.25, width_step=0.125, retrain_epochs=1, total_num_tasks=2)
-    assert res2.grown_to == [0.25] and sess.width == 0.25 and res2.needs_growth      # (goal 2.0 stays missed at the cap)
+                         min_train_acc=-1.0, max_width_multiplier=0.0625, width_step=0.046875, retrain_epochs=1, total_num_tasks=2)   # raw 1/64 -> 1/16: widths 0.125 -> 0.25
+    assert res2.grown_to == [0.0625] and sess.width == 0.25 and sess.width_multiplier == 0.0625 and res2.needs_growth      # (goal 2.0 stays missed at the cap)
     assert sess.shared_layer_info['t1']['network_width_multiplier'] == 0.125
     assert sess.shared_layer_info['t2']['network_width_multiplier'] == 0.25
     for name, m in sess.model.named_modules():
@@ -155,7 +155,7 @@ def test_serving_old_task_from_grown_network_skips_dead_channels():
                   min_train_acc=-1.0)
     tr2, va2 = _loaders(1)
     sess.run_task('t2', 5, tr2, va2, accuracy_goal=2.0, finetune_epochs=1, prune_epochs=1, sparsities=(0.3,), args=args,
-                  min_train_acc=-1.0, max_width=1.0, width_step=0.5, retrain_epochs=1, total_num_tasks=2)
+                  min_train_acc=-1.0, max_width_multiplier=1.0, width_step=0.75, retrain_epochs=1, total_num_tasks=2)   # raw 0.25 -> 1.0: widths 0.5 -> 1.0
     assert sess.width == 1.0
     acc_c, logits_c = sess.evaluate('t1', va1)                       # the reference's way: a cropped width-0.5 model
     FusedSequential.skip_log = []

@@ -145,6 +145,18 @@ def test_linear_golden(name):
     (5, 3, 30, 64, 64, 3, 2, 1, True, False),        # SphereNet stem (3x3 s2 from 3 channels, bias)
     (2, 2, 16, 18, 64, 3, 2, 1, False, True),        # ... two input channels
     (1, 3, 224, 224, 64, 7, 2, 3, False, False),     # the ResNet stem's own map: 4 x 32 tiles, several tiles per wave
+    # the GROWN VGG16 of configs[1] (raw multiplier 1.5 -> sqrt -> int(v * 1.2247): 78 / 156 / 313 / 627 channels,
+    # CPG_cifar100_main_normal.py:115-116 + models/vgg.py:124-154): channel counts that are no multiple of the Winograd kernels' chunk (4) /
+    # block (32): the last chunk / block overlaps its neighbour (wg_chunk_base, k0 / c0 in k_wgw)
+    (1, 3, 224, 224, 78, 3, 1, 1, False, False),     # features.0 of the grown net (the 64-output stem kernel does not apply)
+    (1, 78, 224, 224, 78, 3, 1, 1, False, True),     # features.3
+    (2, 78, 112, 112, 156, 3, 1, 1, False, False),   # features.7
+    (2, 156, 56, 56, 313, 3, 1, 1, False, True),     # features.14
+    (3, 313, 28, 28, 627, 3, 1, 1, False, False),    # features.24
+    (5, 627, 14, 14, 627, 3, 1, 1, False, True),     # features.34 (the narrow weight-gradient stages: image pairs, odd image count)
+    (2, 33, 28, 28, 35, 3, 1, 1, True, True),        # one channel past the block on both sides, bias
+    (2, 67, 14, 14, 61, 3, 1, 1, False, False),      # C % 4 = 3, K < 64 (k_wg1), narrow weight-gradient stages
+    (3, 18, 12, 20, 19, 3, 1, 1, True, False),       # C % 4 = 2 just above the Winograd minimum (16)
 ])
 def test_conv_oracle(N, C, H, W, K, k, s, p, bias, pm):
     g = torch.Generator().manual_seed(N * 1000 + C + K)
@@ -692,7 +704,9 @@ def test_direct_weight_gradients_under_the_shared_chip_hint(N, C, K, H, ks, stri
                                       (256, 4096, 4096, False), (100, 1024, 256, False), (48, 260, 384, False),
                                       # features.45 of config 2 at its own shape (89 % of all masked weights), both mask modes,
                                       # and at the per-GPU batch of the 8-GPU reference configuration / the validate batch
-                                      (256, 25088, 4096, False), (256, 25088, 4096, True), (32, 25088, 4096, True), (100, 25088, 4096, False)])
+                                      (256, 25088, 4096, False), (256, 25088, 4096, True), (32, 25088, 4096, True), (100, 25088, 4096, False),
+                                      # the grown network's FC layers (raw multiplier 1.5: 627 * 49 -> int(4096 * sqrt(1.5)) = 5016; odd row length)
+                                      (32, 30723, 5016, True), (16, 5016, 5016, False)])
 def test_linear_oracle(B, I, O, pm):
     g = torch.Generator().manual_seed(B + I + O)
     x = torch.randn(B, I, generator=g)
@@ -1471,7 +1485,9 @@ def test_route_and_hist_full_size_properties():
 @pytest.mark.parametrize('C,K,H', [(64, 64, 224), (128, 128, 112), (256, 256, 56), (512, 512, 28), (512, 512, 14), (3, 64, 224),
                                    # the three WIDENING layers of VGG16 (features.7 / .14 / .24): k_wg1 -> k_wg3 hand-over in the forward /
                                    # input gradient (C < 128 <= K and back), unequal channel-block counts (nkb != ncb) in k_wgw
-                                   (64, 128, 112), (128, 256, 56), (256, 512, 28)])
+                                   (64, 128, 112), (128, 256, 56), (256, 512, 28),
+                                   # the grown network of configs[1] (raw width multiplier 1.5: int(v * sqrt(1.5)) channels)
+                                   (78, 78, 224), (78, 156, 112), (156, 313, 56), (313, 627, 28), (627, 627, 14), (3, 78, 224)])
 def test_conv_full_size_properties(C, K, H):
     """The conv layers of config 2 at their full size (batch 256): properties that need no CPU reference.
     (1) adjoint identities  <conv(x, W), gy> = <x, dgrad(gy, W)> = <W, wgrad(x, gy)>  tie the three kernels to
@@ -1593,7 +1609,7 @@ def test_conv_full_size_properties_other_nets(C, K, H, k, s, p, bias):
         assert abs(float(layer.piggymask.grad[ko, c, r, q]) - want * float(w[ko, c, r, q])) <= tol + 1e-4 * abs(want * float(w[ko, c, r, q]))
 
 
-@pytest.mark.parametrize('B,I,O', [(256, 25088, 4096), (256, 4096, 4096)])
+@pytest.mark.parametrize('B,I,O', [(256, 25088, 4096), (256, 4096, 4096), (256, 30723, 5016), (256, 5016, 5016)])   # (+ the grown network's: raw multiplier 1.5)
 @pytest.mark.parametrize('pm_on', [False, True])
 def test_linear_full_size_properties(B, I, O, pm_on):
     """The two masked FC layers of config 2 at full size, with and without a piggymask: adjoint identities tie

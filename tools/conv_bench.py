@@ -46,6 +46,8 @@ def main():
     ap.add_argument('--shape', default='', help='extra 3x3 layer "C,K,H" (name x0) instead of the VGG list')
     ap.add_argument('--ab', default='', help='A/B inside one process: NAME=v1,v2,... toggles that env var between timed runs (median of --reps rounds)')
     ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--width-multiplier', type=float, default=1.0,
+                    help="RAW width multiplier of the reference's command line: the VGG list with int(v * sqrt(m)) channels (1.5: 78 / 156 / 313 / 627)")
     ap.add_argument('--pmc-pass', action='store_true', help='no timing: launch every conv of one VGG16 pass exactly once (for rocprofv3 --pmc)')
     a = ap.parse_args()
     L = _lib.lib()
@@ -55,6 +57,9 @@ def main():
     print('%-6s %-6s %9s %9s' % ('layer', 'pass', 'ms', 'TFLOP/s'))
     tot = {}
     layers = VGG
+    if a.width_multiplier != 1.0:
+        r = a.width_multiplier ** 0.5
+        layers = [(n, c if c == 3 else int(c * r), int(k * r), h, m) for n, c, k, h, m in VGG]
     if a.shape:
         c, k, h = (int(v) for v in a.shape.split(','))
         layers = [('x0', c, k, h, 1)]

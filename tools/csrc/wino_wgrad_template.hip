@@ -102,6 +102,11 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
     if (u >= npairs * (unsigned)g.nsplit) return;                // (no barriers anywhere: a wave may leave)
     const unsigned pair = u % npairs, split = u / npairs;
     const int kb = (int)(pair % (unsigned)g.nkb), cb = (int)(pair / (unsigned)g.nkb);
+    // first channel of the unit's blocks.  Channel counts that are not multiples of 32 (the reference's grown networks: 78 / 156 / 313 / 627,
+    // models/vgg.py:124-154 with sqrt(1.5)): the LAST block starts at K - 32 / C - 32 and overlaps its neighbour -- every lane works on a
+    // channel that exists, nothing in the main loop is predicated, and the overlapped (k, c) entries are computed twice from the same
+    // operands in the same order: both units store the same bits.
+    const int k0 = min(kb * 32, g.K - 32), c0 = min(cb * 32, g.C - 32);
     const unsigned s_begin = split * g.su;
     const int nst = (int)min(g.su, g.nstages - s_begin);
     WW_STAMP(0);
@@ -157,15 +162,15 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
     auto stage_offsets = [&]() {
         const bool top = ty == 0, bot = ty == g.th - 1;
         if constexpr (NARROW) {
-            sx = (((n - n0) * g.C + cb * 32) * HW + 2 * ty * g.W) * 4;
-            sgo = (((n - n0) * g.K + kb * 32) * HW + 2 * ty * g.W) * 4;
+            sx = (((n - n0) * g.C + c0) * HW + 2 * ty * g.W) * 4;
+            sgo = (((n - n0) * g.K + k0) * HW + 2 * ty * g.W) * 4;
             const bool gone = half && n + 1 >= g.N;              // an odd batch: the last stage has one image only
             vx = ((xrow == 0 && top) || (xrow == 3 && bot) || gone) ? kOOR : vx_const;
             vg = gone ? kOOR : vg_const;
             vh = kOOR;
         } else {
-            sx = (((n - n0) * g.C + cb * 32) * HW + 2 * ty * g.W + 28 * tseg) * 4;
-            sgo = (((n - n0) * g.K + kb * 32) * HW + 2 * ty * g.W + 28 * tseg) * 4;
+            sx = (((n - n0) * g.C + c0) * HW + 2 * ty * g.W + 28 * tseg) * 4;
+            sgo = (((n - n0) * g.K + k0) * HW + 2 * ty * g.W + 28 * tseg) * 4;
             vx = ((xrow == 0 && top) || (xrow == 3 && bot)) ? kOOR : vx_const;
             vg = vg_const;
             vh = ((hrow == 0 && top) || (hrow == 3 && bot) || (hside == 0 && tseg == 0) || (hside == 1 && tseg == g.nseg - 1)) ? kOOR : vh_const;
@@ -388,7 +393,7 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
     WW_STAMP(3);
     // ---- epilogue: dg = G^T M G per (k, c); M[i][j] = sigma_i sigma_j acc[4 i + j], sigma = (1, 1, 1, -1) ----
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    float *pout = part + ((int64_t)split * 9 * g.K + kb * 32) * g.C + cb * 32 + li;
+    float *pout = part + ((int64_t)split * 9 * g.K + k0) * g.C + c0 + li;
     const int64_t tap_plane = (int64_t)g.K * g.C;
     auto out_e = [&](int e, float (&m)[16]) {
         m[3] = -m[3], m[7] = -m[7], m[11] = -m[11], m[12] = -m[12], m[13] = -m[13], m[14] = -m[14];
@@ -430,14 +435,14 @@ bool ww_plan(const cpg_conv_desc *d, WwPlan &p) {
         d->dil_w != 1 || d->groups != 1)
         return false;
     p.narrow = d->W == 14;
-    if (d->H % 2 || (d->W % 28 && !p.narrow) || d->C % 32 || d->K % 32 || d->N < 1) return false;
+    if (d->H % 2 || (d->W % 28 && !p.narrow) || d->C < 32 || d->K < 32 || d->N < 1) return false;
     WwGeom &g = p.g;
     g.N = d->N, g.C = d->C, g.K = d->K, g.H = d->H, g.W = d->W;
     g.th = d->H / 2, g.tw = d->W / 2, g.nseg = p.narrow ? 1 : g.tw / 14;
     const int64_t nstages = (int64_t)(p.narrow ? (d->N + 1) / 2 : d->N) * g.th * g.nseg;
     if (nstages >= (1ll << 28)) return false;
     g.nstages = (unsigned)nstages;
-    g.nkb = d->K / 32, g.ncb = d->C / 32;
+    g.nkb = (d->K + 31) / 32, g.ncb = (d->C + 31) / 32;      // (any channel count >= 32: the last block overlaps, see k0 / c0 in k_wgw)
     const int64_t npairs = (int64_t)g.nkb * g.ncb;
     // units per wave slot.  Every unit costs a prologue / epilogue and a 9 x 32 x 32 partial sum (36.9 KB) that it writes and
     // k_split_reduce reads: 4 units per slot are 4096 units = 151 MB of partials per launch whatever the layer's size -- the PMC
