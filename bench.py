@@ -519,7 +519,7 @@ def optin_modes(model, masks, pool, steps, batch):
     """Train-step time of the same model in the two OPT-IN conv arithmetics (cpg_amd.models.layers.set_conv_math), measured
     after the timed cycle and reported beside it -- information for the reader, not the metric: 'bf16x3' (two-term bf16 split,
     3 MFMAs per product) holds north_star's 1e-4 logit bar (tests/test_hip_parity.py::test_first_forward_logits_golden_bf16x3),
-    'bf16' does not (2e-2 of the output scale)."""
+    'bf16' does not (2e-2 of the output scale) -- both COMPUTED here by parity_check under the mode, not asserted."""
     res = {}
     for mode in ('bf16x3', 'bf16'):
         nl.set_conv_math(mode)
@@ -538,11 +538,84 @@ def optin_modes(model, masks, pool, steps, batch):
             e.record()
             torch.cuda.synchronize()
             ms = s.elapsed_time(e) / steps
+            pc = parity_check(model.module if hasattr(model, 'module') else model, pool[0][0], WIDTH)      # (under THIS conv arithmetic)
             res[mode] = {'train_ms_per_step': round(ms, 3), 'train_images_per_sec': round(batch / ms * 1e3, 1),
-                         'meets_1e-4_logit_bar': mode == 'bf16x3'}
+                         'meets_1e-4_logit_bar': None if pc is None else pc['ok'], 'parity_check': pc}
         finally:
             nl.set_conv_math('fp32')
     return res
+
+
+def parity_check(net, x, width, images=4):
+    """IN-RUN correctness evidence, AFTER the timed region and outside it: the model the cycle just trained (its weights, BatchNorm
+    statistics, piggymasks, head -- whatever state the cycle left) is copied into the CPU oracle (oracle.net.OracleVGG: checker only, never
+    timed, never on the product path) and both run `images` images of the bench's own input pool forward, (a) in TRAIN mode -- the kernels
+    the timed train steps ran: Winograd forward with the BatchNorm-statistics epilogue, fused BN -> ReLU (-> pool), the FC GEMMs; Dropout's p
+    is 0 for the check, its masks come from different generators -- and (b) in EVAL mode (the inference epilogues the validates ran).
+    north_star's bar: logits within 1e-4 (of the logit scale).  The conv arithmetic is whatever nl.set_conv_math says at the call.
+    VGG only (oracle/net.py restates the VGG cycle); other topologies return None."""
+    import numpy as np
+    from oracle import net as onet                     # checker only
+    root = net
+    if not hasattr(root, 'features') or not hasattr(root, 'classifiers') or 'VGG' not in type(root).__name__:
+        return None
+    t0 = time.perf_counter()
+    ref = onet.OracleVGG(width, 'imagenet')
+    for ds in root.datasets:
+        ref.add_dataset(ds, root.dataset2num_classes[ds])
+    cur = [i for i, c in enumerate(root.classifiers) if c is root.classifier][0]
+    ref.set_dataset(root.datasets[cur])
+    sd = {k: v.detach().cpu() for k, v in root.state_dict().items()}
+    hip_layers = dict(root.named_modules())
+    with torch.no_grad():
+        for name, mod in ref.named_modules():
+            if name in ('', 'head'):
+                continue
+            for pn, p in list(mod.named_parameters(recurse=False)) + list(mod.named_buffers(recurse=False)):
+                key = name + '.' + pn
+                if pn == 'piggymask':
+                    continue
+                p.copy_(sd[key])
+            if isinstance(mod, onet._Masked):
+                pm = getattr(hip_layers[name], 'piggymask', None)
+                mod.piggymask = None if pm is None else nn.Parameter(pm.detach().cpu().clone())
+                mod.threshold = float(hip_layers[name].info['threshold']) if hasattr(hip_layers[name], 'info') else mod.threshold
+    xs = x[:images]
+    xc = xs.detach().cpu()
+    drops = [m for m in root.modules() if isinstance(m, nn.Dropout)]
+    old_p = [m.p for m in drops]
+    bns = [m for m in root.modules() if isinstance(m, nn.BatchNorm2d)]
+    saved = [(m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone()) for m in bns]
+    was_training = root.training
+    res = {}
+    try:
+        for m in drops:
+            m.p = 0.0
+        for m in ref.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+        for mode in ('train', 'eval'):
+            root.train(mode == 'train')
+            ref.train(mode == 'train')
+            with torch.no_grad():
+                got = root(xs).detach().float().cpu()
+                want = ref(xc).detach()
+            scale = max(float(want.abs().max()), 1e-30)
+            res[mode] = float((got - want).abs().max()) / scale
+            finite = bool(torch.isfinite(got).all())
+            res[mode + '_finite'] = finite
+    finally:
+        for m, p_ in zip(drops, old_p):
+            m.p = p_
+        for m, (a_, b_, c_) in zip(bns, saved):          # (the train-mode pass moved the running statistics: put them back)
+            m.running_mean.copy_(a_), m.running_var.copy_(b_), m.num_batches_tracked.copy_(c_)
+        root.train(was_training)
+    worst = max(res['train'], res['eval'])
+    return {'max_rel_logit_err': float('%.3g' % worst), 'train_mode_forward': float('%.3g' % res['train']),
+            'eval_mode_forward': float('%.3g' % res['eval']), 'bar': 1e-4, 'ok': bool(worst < 1e-4 and res['train_finite'] and res['eval_finite']),
+            'images': int(xs.shape[0]), 'conv_math': nl.CONV_MATH,
+            'oracle': 'oracle.net.OracleVGG on the host, state copied from the timed model after the cycle; outside the timed region',
+            'host_seconds': round(time.perf_counter() - t0, 1)}
 
 
 def cpu_plumbing_cycle(steps=220, batch=32):
@@ -1017,6 +1090,13 @@ def main():
                 out['kernel_detail'] = {k: {'n': v[0], 'ms': round(v[1], 2), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2), 'winograd': v[3] < v[2]}
                                         for k, v in sorted(agg.items())}
         out['phases'] = phases if phases is not None else phase_report(marks, model, masks, a.batch)
+        # in-run correctness evidence (outside the timed region): finite loss, the sparsity the cycle's rank-prune events must have reached,
+        # and the timed model's logits against the CPU oracle
+        spars = SparsePruner(model, masks, make_args('prune', 1), 0, 1, 1).calculate_sparsity() if a.task == 1 else None
+        out['cycle_check'] = {'prune_events': counts.get('prune_events'), 'sparsity_after_cycle': spars,
+                              'expected_sparsity': 0.1 if (a.task == 1 and counts.get('prune_events', 0) >= 4) else None,
+                              'weights_finite': bool(all(torch.isfinite(p).all() for p in net.parameters()))}
+        out['parity_check'] = parity_check(net, pool[0][0], WIDTH) if world == 1 else None
         if a.task == 2:
             out['task2'] = {'task1_ms_per_step': round(task1_ms, 3), 'task2_over_task1': round(1000.0 * dt / a.steps / task1_ms, 4),
                             'free_share_handed_to_task2': round(free_share, 4), 'lr_mask_finetune': 5e-4, 'lr_mask_prune': 0.0,

@@ -618,6 +618,11 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     }
     const int span = (W1_T + g.tiles_img - 1) / g.tiles_img + 1;
     const int nimg_here = min(span, g.N - n0);
+    // byte offset of the LAST chunk's first channel, set once the chunk count is known: min(last chunk * 4, C - 4) channels.  Every row load
+    // takes min(chunk * stride, x_last_off): chunks past the end re-read the last one (what clampc did for them), and with a channel count
+    // that is no multiple of 4 the last chunk starts at C - 4, overlapping its neighbour (wg_chunk_base; the pack kernel zeroes its filters
+    // for the channels the neighbour already contracted) -- one scalar multiply and one min per chunk, as before.
+    int x_last_off = 0;
     const __amdgpu_buffer_rsrc_t srd_x =
         __builtin_amdgcn_make_buffer_rsrc((void *)(x + (int64_t)n0 * g.C * HW), 0, nimg_here * g.C * HW * 4, 0x00020000);
     // (U through a buffer descriptor: two per-lane byte offsets per unit, the chunk in the scalar offset, q in the instruction offset)
@@ -638,7 +643,7 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         float halo;
     };
     auto G_row1 = [&](int ch, Rows &q, int k) {             // k = 0..7: row k & 3 of channel 2 lh + k / 4;  k = 8: the halo values
-        const int soff = wg_chunk_base(ch, g.C) * HW * 4;
+        const int soff = min(ch * (WG_CK * HW * 4), x_last_off);      // (see x_last_off)
         if (k < 8)
             q.r[k >> 2][k & 3] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[k & 3], soff + (k >> 2) * HW * 4, 0);
         else
@@ -726,6 +731,7 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         }
     }
     const int last = nch - 1;
+    x_last_off = __builtin_amdgcn_readfirstlane(min(last * WG_CK, g.C - WG_CK) * HW * 4);
     auto clampc = [&](int c) { return min(c, last); };
     f32x4 u0[8], u1[8], u2[8];             // U of chunks it, it + 1, it + 2 (three rotating sets: requested two iterations ahead)
     float b0[16], b1[16];                  // B operands of the current chunk: V of channels 2 lh, 2 lh + 1
@@ -803,7 +809,7 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     // the row set of this parity, which is then re-used for the loads of chunk it + 4; U(it + 2) is requested at the top
     auto iter = [&](int it, int par, f32x4 (&ucur)[8], f32x4 (&ufar)[8], Rows &rows, float (&c0)[16], float (&c1)[16],
                     float (&x0)[16], float (&x1)[16]) {
-        const int cu = clampc(it + 2), cr = clampc(it + 4);
+        const int cu = clampc(it + 2), cr = it + 4;
         W1_SLOT(0, 0, ucur, c0, T_read2(par ^ 1, 0, x0, 0));
         W1_SLOT(0, 1, ucur, c1, T_read2(par ^ 1, 0, x0, 2));
         W1_SLOT(1, 0, ucur, c0, T_read2(par ^ 1, 1, x1, 0));
@@ -1032,6 +1038,11 @@ void k_wg2(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     }
     const int span = (W1_T + g.tiles_img - 1) / g.tiles_img + 1;
     const int nimg_here = min(span, g.N - n0);
+    // byte offset of the LAST chunk's first channel, set once the chunk count is known: min(last chunk * 4, C - 4) channels.  Every row load
+    // takes min(chunk * stride, x_last_off): chunks past the end re-read the last one (what clampc did for them), and with a channel count
+    // that is no multiple of 4 the last chunk starts at C - 4, overlapping its neighbour (wg_chunk_base; the pack kernel zeroes its filters
+    // for the channels the neighbour already contracted) -- one scalar multiply and one min per chunk, as before.
+    int x_last_off = 0;
     const __amdgpu_buffer_rsrc_t srd_x =
         __builtin_amdgcn_make_buffer_rsrc((void *)(x + (int64_t)n0 * g.C * HW), 0, nimg_here * g.C * HW * 4, 0x00020000);
     const float *ubase = up + (int64_t)kb * g.nch * W1_U + ph * 1024 + lane * 4;     // this wave's four float4 of a chunk: q = 4 ph .. + 3
@@ -1050,7 +1061,7 @@ void k_wg2(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         float halo;
     };
     auto G_row1 = [&](int ch, Rows &q, int k) {             // k = 0..5: row k % 3 of channel 2 lh + k / 3;  k = 6: the halo values
-        const int soff = wg_chunk_base(ch, g.C) * HW * 4;
+        const int soff = min(ch * (WG_CK * HW * 4), x_last_off);      // (see x_last_off)
         if (k < 6)
             q.r[k / 3][k % 3] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[k % 3], soff + (k / 3) * HW * 4, 0);
         else
@@ -1108,6 +1119,7 @@ void k_wg2(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         }
     }
     const int last = nch - 1;
+    x_last_off = __builtin_amdgcn_readfirstlane(min(last * WG_CK, g.C - WG_CK) * HW * 4);
     auto clampc = [&](int c) { return min(c, last); };
     f32x4 ua[4], ub[4];                    // U of the current / next chunk
     float c0[12], c1[12], x0[12], x1[12];  // B operands ([0..7]) of the current chunk for channels 2 lh, 2 lh + 1 / the next chunk's, being transformed
@@ -1137,7 +1149,7 @@ void k_wg2(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     // iteration it (par = it & 1): M(it); T(it + 1) from raw stage (it + 1) & 1; U(it + 1) requested; W(it + 2) stores the rows
     // requested one iteration ago, whose registers then take the loads of chunk it + 3
     auto iter = [&](int it, int par, f32x4 (&ucur)[4], f32x4 (&unext)[4], float (&b0)[12], float (&b1)[12], float (&n0v)[12], float (&n1v)[12]) {
-        const int cu = clampc(it + 1), cr = clampc(it + 3);
+        const int cu = clampc(it + 1), cr = it + 3;
         W2_SLOT(0, 0, ucur, b0, T_read1(par ^ 1, 0, n0v, 0); T_read1(par ^ 1, 0, n0v, 1));
         W2_SLOT(0, 1, ucur, b1, T_read1(par ^ 1, 0, n0v, 2); T_read1(par ^ 1, 1, n1v, 0));
         W2_SLOT(1, 0, ucur, b0, T_read1(par ^ 1, 1, n1v, 1); T_read1(par ^ 1, 1, n1v, 2));
@@ -1398,6 +1410,11 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     }
     const int span = (W1_T + g.tiles_img - 1) / g.tiles_img + 1;
     const int nimg_here = min(span, g.N - n0);
+    // byte offset of the LAST chunk's first channel, set once the chunk count is known: min(last chunk * 4, C - 4) channels.  Every row load
+    // takes min(chunk * stride, x_last_off): chunks past the end re-read the last one (what clampc did for them), and with a channel count
+    // that is no multiple of 4 the last chunk starts at C - 4, overlapping its neighbour (wg_chunk_base; the pack kernel zeroes its filters
+    // for the channels the neighbour already contracted) -- one scalar multiply and one min per chunk, as before.
+    int x_last_off = 0;
     const __amdgpu_buffer_rsrc_t srd_x =
         __builtin_amdgcn_make_buffer_rsrc((void *)(x + (int64_t)n0 * g.C * HW), 0, nimg_here * g.C * HW * 4, 0x00020000);
     // U records are per block of 32 channels: this wave reads float4 q = 4 ph .. + 3 of the records of blocks 2 kb, 2 kb + 1
@@ -1421,7 +1438,7 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         float halo;
     };
     auto G_row1 = [&](int ch, Rows &q, int k) {             // k = 0..5: row k % 3 of channel 2 lh + k / 3;  k = 6: the halo values
-        const int soff = wg_chunk_base(ch, g.C) * HW * 4;
+        const int soff = min(ch * (WG_CK * HW * 4), x_last_off);      // (see x_last_off)
         if (k < 6)
             q.r[k / 3][k % 3] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[k % 3], soff + (k / 3) * HW * 4, 0);
         else
@@ -1443,7 +1460,7 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     const int un_goff = un * HW * 4;
     const int raw_own_s = raw_own + un * 3 * W1_ROW, tr_base = ((2 * lh + un) * 3) * W1_ROW;
     auto G_rows = [&](int ch, Rows &q, int k) {
-        const int soff = wg_chunk_base(ch, g.C) * HW * 4;
+        const int soff = min(ch * (WG_CK * HW * 4), x_last_off);      // (see x_last_off)
         if (k < 3)
             q.r[0][k] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[k], soff + un_goff, 0);
         else
@@ -1532,6 +1549,7 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         }
     }
     const int last = nch - 1;
+    x_last_off = __builtin_amdgcn_readfirstlane(min(last * WG_CK, g.C - WG_CK) * HW * 4);
     auto clampc = [&](int c) { return min(c, last); };
     // U of the current / next chunk: [kq * 4 + q].  U3 (every variant but the one with the statistics epilogue, which has no registers
     // left): a third buffer -- the loads of chunk it + 2 go out during chunk it, two chunks (2 us) ahead of their first use instead of
@@ -1616,7 +1634,7 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     // iteration it (par = it & 1): M(it); T(it + 1) from raw stage (it + 1) & 1; U(it + 1) requested; W(it + 2) stores the rows
     // requested one iteration ago, whose registers then take the loads of chunk it + 3
     auto iter = [&](int it, int par, f32x4 (&ucur)[8], f32x4 (&unext)[8], Bop &b0, Bop &b1, Bop &n0v, Bop &n1v) {
-        const int cu = clampc(it + (U3 ? 2 : 1)), cr = clampc(it + 3);
+        const int cu = clampc(it + (U3 ? 2 : 1)), cr = it + 3;
         if constexpr (SH) {
             // the next chunk's operands: this wave's channel, the barrier, both channels read back; then the rows of chunk it + 2 / it + 3
             W3_SLOT(0, 0, ucur, b0, G_u1(cu, unext, 0));
@@ -1925,7 +1943,13 @@ static inline int wino_variant(int c_read, int m, bool stats = true) {
     if (const int forced = cpg::opt(cpg::OPT_WINO_KERNEL); forced != cpg::OPT_UNSET)      // (block | wave | pair | 64 -> WV_*)
         return forced >= WV_BLOCK && forced <= WV_PAIR64 ? forced : WV_WAVE;
     (void)stats;
-    return (c_read >= 64 && m >= 64) ? WV_PAIR64 : WV_WAVE;
+    if (c_read < 64 || m < 64) return WV_WAVE;
+    // Channel counts that are no multiple of 64 (the grown networks: 78 / 156 / 313 / 627 outputs): a unit of k_wg3 produces 64 channels, one
+    // of k_wg1 32, and the padding of the last block is MFMA time.  At equal padding k_wg3 is the faster kernel by 5-8 % (shared transform),
+    // so the one-wave kernel takes the layer when its blocks waste at least 10 % less: m = 78 (96 vs 128 computed) 9.88 -> 7.73 ms,
+    // m = 156 (160 vs 192) 6.37 -> 5.81 ms; m = 313 / 627 (both 320 / 640) stay on k_wg3: 5.21 vs 5.49 ms  (conv_bench --width-multiplier 1.5).
+    const int p64 = (m + 63) / 64 * 64, p32 = (m + 31) / 32 * 32;
+    return p64 * 10 > p32 * 11 ? WV_WAVE : WV_PAIR64;
 }
 
 #ifdef WG_TIMING

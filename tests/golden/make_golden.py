@@ -853,6 +853,32 @@ def gen_growth():
     save('growth', **arrs)
 
 
+def gen_full_width_logits():
+    """Eval-mode logits of the three topologies at WIDTH 1.0 and the input sizes BASELINE.json's configs name (models/vgg.py:124-154,280-282;
+    models/resnet.py:103-222; models/spherenet.py:201-251): the whole-network check of north_star's 1e-4 logit bar at full size (the
+    first_forward_* fixtures above are 0.125 / 0.25 wide).  Weights: the reference's seed-1 initialisation (ResNet-50: the He re-draw of
+    reinit_resnet -- its own N(0, 0.001) makes every activation underflow); BatchNorm running statistics drawn off their initial
+    values and stored; inputs on a 1/16 grid.  The fixture holds x, the statistics, the logits and a (sum, abs-sum) digest per parameter."""
+    for arch, shape, ncls in [('vgg', (1, 3, 224, 224), 5), ('resnet50', (2, 3, 224, 224), 5), ('spherenet20', (2, 3, 112, 112), 7)]:
+        net = build_ref(arch, 1.0, num_classes=ncls)
+        if arch == 'resnet50':
+            reinit_resnet(net, 2)
+        g = torch.Generator().manual_seed(23)
+        arrs = {}
+        for name, mod in net.named_modules():
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+                arrs['bn_mean/' + name] = mod.running_mean.clone()
+                arrs['bn_var/' + name] = mod.running_var.clone()
+        x = quant(torch.randn(*shape, generator=g))
+        net.eval()
+        with torch.no_grad():
+            y = net(x)
+        digest = np.array([[float(p.double().sum()), float(p.double().abs().sum())] for p in net.parameters()])
+        save('full_width_logits_' + arch, x=x, y=y, param_digest=digest, num_classes=ncls, width=1.0, **arrs)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     if only:                                  # regenerate selected fixtures: python make_golden.py gen_one_shot ...
@@ -860,6 +886,7 @@ if __name__ == '__main__':
             globals()[fn]()
         sys.exit(0)
     gen_growth()
+    gen_full_width_logits()
     gen_one_shot()
     gen_manager_trajectory()
     gen_net_train_steps()

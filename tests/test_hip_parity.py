@@ -1144,6 +1144,36 @@ def test_first_forward_logits_golden(arch, width, fx):
     close(y, g['y'], rtol=1e-4, atol=1e-4 * scale, msg=arch)
 
 
+
+@pytest.mark.parametrize('arch', ['vgg', 'resnet50', 'spherenet20'])
+def test_full_width_logits_golden(arch):
+    """The three topologies at WIDTH 1.0 and the input sizes BASELINE.json's configs name, against logits the REFERENCE produced
+    (tests/golden/make_golden.py::gen_full_width_logits; models/vgg.py:124-154,280-282, models/resnet.py:103-222,
+    models/spherenet.py:201-251): the seed-1 initial weights (ResNet-50: He re-draw, seed 2 -- the reference's N(0, 0.001) underflows),
+    the fixture's BatchNorm running statistics, eval mode, logits within 1e-4 of the reference's scale."""
+    g = load_golden('full_width_logits_' + arch)
+    m = build(arch, 1.0, int(g['num_classes']))
+    if arch == 'resnet50':
+        torch.manual_seed(2)
+        for mod in m.modules():
+            if isinstance(mod, nl.SharableConv2d):
+                nn.init.kaiming_normal_(mod.weight, mode='fan_out', nonlinearity='relu')
+    digest = np.array([[float(p.double().sum()), float(p.double().abs().sum())] for p in m.parameters()])
+    np.testing.assert_allclose(digest, g['param_digest'], rtol=1e-12, atol=0, err_msg='initial weights differ from the reference')
+    nbn = 0
+    for name, mod in m.named_modules():
+        if isinstance(mod, nn.BatchNorm2d):
+            mod.running_mean.copy_(T(g['bn_mean/' + name], torch.float32).cpu())
+            mod.running_var.copy_(T(g['bn_var/' + name], torch.float32).cpu())
+            nbn += 1
+    assert nbn == sum(1 for k in g.files if k.startswith('bn_mean/'))
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        y = m(T(g['x']))
+    scale = float(np.abs(g['y']).max())
+    close(y, g['y'], rtol=1e-4, atol=1e-4 * scale, msg=arch)
+
+
 @pytest.mark.parametrize('math', ['fp32', 'bf16x3'])
 @pytest.mark.parametrize('mode', ['prune', 'finetune'])
 def test_trajectory_golden(mode, math):
@@ -2595,6 +2625,170 @@ def test_two_task_sequence_matches_oracle():
         older = (rp3.owners[n] > 0) & (rp3.owners[n] < 2)
         assert not np.any(hip_pm.grad.cpu().numpy()[~older]), n
     assert abs(mgr.pruner.calculate_shared_part_ratio() - 1.0) < 1e-12    # every piggymask value still > 0.005
+
+
+
+# --------------------------------------------------------------------------- the WHOLE network at full width vs the oracle
+@pytest.mark.parametrize('task', [1, 2])
+def test_full_width_vgg16_train_step_vs_oracle(task):
+    """north_star's "forward logits match the reference within 1e-4" at the size BASELINE.json's configs[1] names: custom_vgg
+    (models/vgg.py:124-154,280-282) at width 1.0 -- 13 Winograd layers in sequence, contractions up to 4608 deep, the two-wave
+    kernels with the shared transform, the fused stem, the 25088-wide FC --, seed 1, 224 x 224, batch 4, TRAIN mode (batch
+    statistics; Dropout's p set to 0 on both sides: its masks come from different generators), one Manager.train step with
+    the fused optimizers against oracle.net.OracleVGG doing the same step on the host.
+    task 1: prune mode, every slot owned by task 1, a rank-prune event after the step.
+    task 2: finetune mode, 30 % of every layer free -> claimed by task 2, a random piggymask on every masked layer
+            (~58 % pass the threshold), SGD on the weights + Adam on the piggymasks.
+
+    LOGITS are held to 1e-4 of the logit scale against the fp32 oracle (measured: ~5e-6).
+    GRADIENTS of a 16-layer network cannot be: a ReLU input or a max-pool pair that lies inside the forward round-off takes different
+    sides in two correct fp32 implementations, and one flipped element moves the weight-gradient entries it touches by ~ 1 / sqrt(N H W)
+    of their value.  The reference's OWN arithmetic shows it: the oracle run in fp32 and in fp64 on this very input differs by 0.1-4 % of
+    each conv layer's gradient scale (eval-mode BatchNorm: still 0.3 % for every layer in front of the last pooling stage; the per-layer
+    kernels are pinned at 1e-4 at exactly these shapes by test_conv_full_size_properties).  So the yardstick is the oracle in FP64, and
+    the bar per layer is the reference arithmetic's own distance from it: err(HIP, fp64) <= 4 x err(oracle fp32, fp64) + 1e-4, in the
+    maximum norm and in the Euclidean norm.  A composition error (wrong layer wiring, wrong statistics, a dropped channel block) is an
+    O(0.1 .. 1) error and fails this by orders of magnitude."""
+    import copy
+    from cpg_amd.driver import CPGSession, default_args
+    from cpg_amd.utils.manager import Manager
+    from oracle import net as onet
+    B = 4
+    sess = CPGSession('custom_vgg', 1.0, device=DEV, seed=1)
+    sess.start_task('t1', 5)
+    torch.manual_seed(1)
+    ref = onet.OracleVGG(1.0, 'imagenet')
+    ref.add_dataset('t1', 5)
+    ref.set_dataset('t1')
+    for (n, p), (_, q) in zip(sess.net.features.named_parameters(), ref.features.named_parameters()):
+        assert torch.equal(p.detach().cpu(), q.detach()), n               # the same seeded initial weights
+    gen = torch.Generator().manual_seed(97 + task)
+    owners = {}
+    for n, m in ref.masked_layers():
+        if task == 1:
+            owners[n] = np.ones(tuple(m.weight.shape), np.uint8)
+        else:
+            owners[n] = (torch.rand(m.weight.shape, generator=gen) < 0.7).to(torch.uint8).numpy()       # 1 = task 1's, 0 = free
+        sess.masks['module.' + n].copy_(torch.from_numpy(owners[n]))
+    if task == 2:
+        sess.start_task('t2', 5)
+        ref.add_dataset('t2', 5)
+        ref.set_dataset('t2')
+        for n, m in ref.masked_layers():
+            pm = torch.rand(m.weight.shape, generator=gen) * 0.012
+            m.piggymask = nn.Parameter(pm.clone())
+            dict(sess.net.named_modules())[n].piggymask.data.copy_(pm)
+    for i, head in enumerate(sess.net.classifiers):
+        ref.classifiers[i].load_state_dict({k: v.cpu() for k, v in head.state_dict().items()})
+    for m in list(sess.net.modules()) + list(ref.modules()):
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+    x = torch.randn(B, 3, 224, 224, generator=gen)
+    t = torch.randint(0, 5, (B,), generator=gen)
+    # ---- the yardstick: the same forward / backward in fp64 (a copy of the oracle taken before anything steps)
+    ref64 = copy.deepcopy(ref).double().train()
+    out64 = ref64(x.double())
+    nn.functional.cross_entropy(out64, t).backward()
+    g64 = {n: m.weight.grad.detach() for n, m in ref64.masked_layers()}
+    gpm64 = {n: m.piggymask.grad.detach() for n, m in ref64.masked_layers()} if task == 2 else {}
+    ds = 't%d' % task
+    if task == 1:
+        args = default_args(dataset=ds, mode='prune', lr=1e-3, initial_sparsity=0.0, target_sparsity=0.3, pruning_frequency=1)
+        mgr = Manager(args, sess.model, sess.shared_layer_info, sess.masks, None, None, 0, 2)
+        rp = onet.OraclePruner(ref, owners, 'prune', 1, 1, 0, 2, 1, 0.0, 0.3, 4e-5, 1.0)
+        ropt = [torch.optim.SGD(ref.parameters(), lr=1e-3, momentum=0.9, nesterov=True)]
+        start = 1                                                           # (prune step 1 of a window of 2: an event, ratio > 0)
+    else:
+        args = default_args(dataset=ds, mode='finetune', lr=1e-2, lr_mask=5e-4)
+        mgr = Manager(args, sess.model, sess.shared_layer_info, sess.masks, None, None, 0, 0)
+        mgr.pruner.make_finetuning_mask()
+        rp = onet.OraclePruner(ref, owners, 'finetune', 1, 2, 0, 0, 1, 0.0, 0.3, 4e-5, 1.0)
+        rp.claim_free()
+        wparams = [p for n, p in ref.named_parameters() if 'piggymask' not in n and 'classifiers.0.' not in n]
+        pparams = [p for n, p in ref.named_parameters() if 'piggymask' in n]
+        ropt = [torch.optim.SGD(wparams, lr=1e-2, momentum=0.9, nesterov=True), torch.optim.Adam(pparams, lr=5e-4)]
+        start = 0
+    opts = sess.make_optimizers(args, mgr.pruner)                           # MaskedSGD (+ MaskedAdam): routing fused into the update
+    hip_layers = dict(sess.net.named_modules())
+    w0 = {n: hip_layers[n].weight.detach().clone() for n, _ in ref.masked_layers()}
+    # raw gradients as autograd leaves them (before routing), captured on both sides
+    raw, raw_pm = {}, {}
+    hooks = []
+    for n, _ in ref.masked_layers():
+        hooks.append(hip_layers[n].weight.register_hook(lambda g_, n=n: raw.__setitem__(n, g_.detach().clone())))
+        if task == 2:
+            hooks.append(hip_layers[n].piggymask.register_hook(lambda g_, n=n: raw_pm.__setitem__(n, g_.detach().clone())))
+    outs = []
+    h = sess.model.register_forward_hook(lambda m, i, o: outs.append(o.detach().cpu()))
+    mgr.train_loader = [(x.to(DEV), t.to(DEV))]
+    mgr.train(opts, 0, list(opts.lrs), start)
+    h.remove()
+    for hk in hooks:
+        hk.remove()
+    # ---- the same step on the host, in the reference's precision
+    ref.train()
+    for o in ropt:
+        o.zero_grad()
+    rout = ref(x)
+    nn.functional.cross_entropy(rout, t).backward()
+    rgw = {n: m.weight.grad.detach().clone() for n, m in ref.masked_layers()}
+    rgpm = {n: m.piggymask.grad.detach().clone() for n, m in ref.masked_layers()} if task == 2 else {}
+    rp.route()
+    for o in ropt:
+        o.step()
+    if task == 1:
+        rp.gradually_prune(start)
+    # ---- logits: north_star's bar, against the fp32 oracle (and the fp64 one)
+    got, want = outs[0], rout.detach()
+    err = float((got - want).abs().max()) / max(1.0, float(want.abs().max()))
+    err64 = float((got.double() - out64.detach()).abs().max()) / max(1.0, float(out64.abs().max()))
+    assert err < 1e-4 and err64 < 1e-4, 'full-width logits differ from the oracle by %g (fp64 oracle: %g) of the logit scale' % (err, err64)
+
+    def dist(a, b64):                                                       # (max norm, Euclidean norm), relative to the fp64 tensor
+        d = a.double().cpu() - b64
+        return float(d.abs().max()) / float(b64.abs().max()), float(d.norm()) / float(b64.norm())
+    report, bad = [], []
+    for n, m in ref.masked_layers():
+        pairs = [('gW', raw[n], rgw[n], g64[n])] + ([('gPM', raw_pm[n], rgpm[n], gpm64[n])] if task == 2 else [])
+        for what, hip_g, cpu_g, yard in pairs:
+            hm, h2 = dist(hip_g, yard)
+            cm, c2 = dist(cpu_g, yard)
+            report.append('%s %s hip %.1e / %.1e cpu32 %.1e / %.1e' % (n, what, hm, h2, cm, c2))
+            if hm > 4 * cm + 1e-4 or h2 > 4 * c2 + 1e-4:
+                bad.append(report[-1])
+        if task == 2:
+            assert torch.equal(raw[n].cpu() == 0, (m.piggymask.detach() <= 5e-3) | (raw[n].cpu() == 0)), n   # zero where the binariser says 0
+        # the update: what the step did to the weights, against the fp32 oracle's step (routing: only the current task's slots move)
+        dw_h = (hip_layers[n].weight.detach() - w0[n]).cpu()
+        dw_r = m.weight.detach() - w0[n].cpu()
+        scd = float(dw_r.abs().max())
+        moved_h, moved_r = dw_h != 0, dw_r != 0
+        if task == 2:
+            mine = torch.from_numpy(rp.owners[n] == rp.cur)
+            assert not bool(moved_h[~mine].any()) and not bool(moved_r[~mine].any()), 'frozen weights moved in ' + n
+        cmx = dist(rgw[n], g64[n])[0]
+        assert float((dw_h - dw_r).abs().max()) <= (8 * cmx + 2e-4) * scd + 1e-9, 'weight update ' + n
+    print('full-width (max / L2 distance from the fp64 oracle; logits %.1e / %.1e):\n  ' % (err, err64) + '\n  '.join(report))
+    assert not bad, 'further from the fp64 oracle than 4 x the fp32 oracle is:\n  ' + '\n  '.join(bad)
+    if task == 1:                                                           # the event released the same slots (up to ties at the cutoff)
+        mism = sum(int((sess.masks['module.' + n].cpu().numpy() != rp.owners[n]).sum()) for n, _ in ref.masked_layers())
+        assert mism <= 1e-5 * sum(v.numel() for v in sess.masks.values()), mism
+    else:
+        # Adam's first step is lr * g / (|g| + eps) = +- lr whatever |g| is: an entry whose gradient is smaller than the round-off above moves
+        # the other way.  So: (a) the piggymask moved only on older-task slots, by at most lr; (b) where it moved differently from the fp32
+        # oracle's, the fp64 gradient is small; the share of such entries is bounded by the fp32 oracle's own sign disagreement with fp64.
+        for n, m in ref.masked_layers():
+            older = torch.from_numpy((rp.owners[n] > 0) & (rp.owners[n] < rp.cur))
+            pm_h = hip_layers[n].piggymask.detach().cpu()
+            pm_r = m.piggymask.detach()
+            pm0 = dict(ref64.named_modules())[n].piggymask.detach().float()
+            assert torch.equal(pm_h[~older], pm0[~older]), 'piggymask moved outside the older tasks\' slots in ' + n
+            assert float((pm_h - pm0).abs().max()) <= 5e-4 * 1.001 + 1e-9, n
+            differ = (pm_h - pm_r).abs() > 2e-5
+            g6 = gpm64[n]
+            f_hip = float(differ[older].float().mean())
+            f_cpu = float(((torch.sign(rgpm[n].double()) != torch.sign(g6)) & older).float().sum() / max(1, int(older.sum())))
+            assert f_hip <= 4 * f_cpu + 1e-3, 'piggymask update %s: %.2e of the entries moved differently (fp32 oracle vs fp64 signs: %.2e)' % (n, f_hip, f_cpu)
 
 
 # --------------------------------------------------------------------------- RCCL (kept last: it owns a process group)

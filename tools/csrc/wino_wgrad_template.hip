@@ -106,7 +106,9 @@ void k_wgw(WwGeom g, const float *__restrict__ x, const float *__restrict__ gy, 
     // models/vgg.py:124-154 with sqrt(1.5)): the LAST block starts at K - 32 / C - 32 and overlaps its neighbour -- every lane works on a
     // channel that exists, nothing in the main loop is predicated, and the overlapped (k, c) entries are computed twice from the same
     // operands in the same order: both units store the same bits.
-    const int k0 = min(kb * 32, g.K - 32), c0 = min(cb * 32, g.C - 32);
+    // (readfirstlane: without it the compiler carried the two minima in vector registers and every staging load of the wide instances got
+    //  a waterfall loop around its scalar offset -- 3-5 % of the kernel)
+    const int k0 = __builtin_amdgcn_readfirstlane(min(kb * 32, g.K - 32)), c0 = __builtin_amdgcn_readfirstlane(min(cb * 32, g.C - 32));
     const unsigned s_begin = split * g.su;
     const int nst = (int)min(g.su, g.nstages - s_begin);
     WW_STAMP(0);
@@ -454,9 +456,25 @@ bool ww_plan(const cpg_conv_desc *d, WwPlan &p) {
     // 14-pixel maps).  cpg_amd.dist raises the hint (cpg_set_shared_chip_hint) when a rank's gradients keep RCCL busy for a
     // noticeable share of the backward (VGG16's 537 MB); until round 4 the hint meant 4 rounds for every multi-GPU rank, which
     // beside RCCL's real kernels cost more than it can save (profiles/r04_ab_shared_chip_plans.txt).  CPG_WW_UNITS overrides.
+    // Channel-block pairs that do not divide the wave slots (the grown networks: 627 -> 627 has 400 pairs, 2 splits = 800 units on 1024 slots,
+    // 78 % of one round): up to two more rounds are tried and the plan with the best slot use wins, an extra round priced at 1.5 % (the
+    // figures above) -- 400 pairs: 5 splits = 2000 units = 97.7 % of two rounds.  The width-1.0 layers keep their one-round plans.
     int upw = shared_chip_hint() ? 2 : 1;
-    upw = std::max(1, opt_or(OPT_WW_UNITS, upw));
-    int64_t want = std::max<int64_t>(1, ((int64_t)upw * 4 * kCUs) / npairs);
+    const int64_t slots = 4 * kCUs;
+    if (const int forced = opt(OPT_WW_UNITS); forced != OPT_UNSET) {
+        upw = std::max(1, forced);
+    } else {
+        double best = -1.0;
+        int best_r = upw;
+        for (int r = upw; r <= upw + 2; ++r) {
+            const int64_t w = std::min<int64_t>(std::max<int64_t>(1, r * slots / npairs), nstages);
+            const int64_t units = npairs * w, rounds = (units + slots - 1) / slots;
+            const double eff = (double)units / (double)(rounds * slots) - 0.015 * (double)(rounds - upw);
+            if (eff > best + 1e-9) best = eff, best_r = r;
+        }
+        upw = best_r;
+    }
+    int64_t want = std::max<int64_t>(1, ((int64_t)upw * slots) / npairs);
     want = std::min<int64_t>(want, nstages);
     g.su = (unsigned)((nstages + want - 1) / want);
     g.nsplit = (int)((nstages + g.su - 1) / g.su);
