@@ -755,6 +755,10 @@ RCCL_ALLREDUCE_BUSBW_GBS = 310.0     # assumed large-message bus bandwidth of an
 OVERLAP_SLOWDOWN = 1.17              # conv kernels beside 16 busy CUs' worth of other streams' kernels (tools/diag_interference.py)
 # cycle ms per step on ONE GPU by per-GPU batch (profiles/r04c_bench*.json; the 128 / 64 / 32 rows are the reference's own split: 256 images over 2 / 4 / 8 GPUs)
 SINGLE_GPU_MS_PER_STEP = {'vgg16': {256: 109.3, 128: 57.5, 64: 31.7, 32: 18.7}, 'resnet50': {256: 69.8}, 'spherenet20': {256: 20.6}}
+# What the exchange machinery costs a step BEFORE any link time, measured on one GPU with a world-1 RCCL group (CPG_DP_FORCE=1: every hook,
+# row-block hand-over, packed / coalesced message, finish_gradient_sync, RCCL's copy kernels on their own stream):
+# VGG16 111.6 vs 108.7 ms, ResNet-50 71.7 vs 69.8.  SphereNet-20 was not measured: scaled from ResNet-50 by gradient bytes (89 MB / 94 MB).
+WORLD1_EXCHANGE_FLOOR_MS = {'vgg16': 2.9, 'resnet50': 1.9, 'spherenet20': 1.8}
 
 
 def single_gpu_ms(arch, batch):
@@ -779,11 +783,14 @@ def predict_step_ms(arch, world, buckets, measured_single_gpu_ms=None, batch=256
     total_ms = sum(b / 1e9 / algbw * 1e3 + per_msg_latency_ms for _, b in buckets)
     last_ms = (buckets[-1][1] / 1e9 / algbw * 1e3 + per_msg_latency_ms) if buckets else 0.0
     hidden = total_ms - last_ms
-    return {'predicted_ms_per_step': round(t1 + hidden * (OVERLAP_SLOWDOWN - 1.0) + last_ms, 3), 'allreduce_ms_total': round(total_ms, 3),
-            'exposed_ms': round(last_ms + hidden * (OVERLAP_SLOWDOWN - 1.0), 3), 'assumed_algbw_GBs': round(algbw, 1),
-            'assumed_busbw_GBs': RCCL_ALLREDUCE_BUSBW_GBS, 'single_gpu_ms_per_step': t1,
-            'model': 'step(N) = step(1) + (overlapped all-reduce time) x (%.2f - 1) + last message; messages priced at payload / algbw + 30 us'
-                     % OVERLAP_SLOWDOWN}
+    # the interference term can never be below the measured world-1 floor (the same kernels beside the backward with zero wire time)
+    floor = WORLD1_EXCHANGE_FLOOR_MS.get(arch, 0.0)
+    interference = max(hidden * (OVERLAP_SLOWDOWN - 1.0), floor)
+    return {'predicted_ms_per_step': round(t1 + interference + last_ms, 3), 'allreduce_ms_total': round(total_ms, 3),
+            'exposed_ms': round(last_ms + interference, 3), 'assumed_algbw_GBs': round(algbw, 1),
+            'assumed_busbw_GBs': RCCL_ALLREDUCE_BUSBW_GBS, 'single_gpu_ms_per_step': t1, 'world1_exchange_floor_ms': floor,
+            'model': 'step(N) = step(1) + max((overlapped all-reduce time) x (%.2f - 1), measured world-1 exchange floor) + last message; '
+                     'messages priced at payload / algbw + 30 us' % OVERLAP_SLOWDOWN}
 
 
 def _free_port():

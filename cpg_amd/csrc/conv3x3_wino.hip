@@ -622,7 +622,7 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     // takes min(chunk * stride, x_last_off): chunks past the end re-read the last one (what clampc did for them), and with a channel count
     // that is no multiple of 4 the last chunk starts at C - 4, overlapping its neighbour (wg_chunk_base; the pack kernel zeroes its filters
     // for the channels the neighbour already contracted) -- one scalar multiply and one min per chunk, as before.
-    int x_last_off = 0;
+    int x_last_off = 0, x_last = 0;
     const __amdgpu_buffer_rsrc_t srd_x =
         __builtin_amdgcn_make_buffer_rsrc((void *)(x + (int64_t)n0 * g.C * HW), 0, nimg_here * g.C * HW * 4, 0x00020000);
     // (U through a buffer descriptor: two per-lane byte offsets per unit, the chunk in the scalar offset, q in the instruction offset)
@@ -643,7 +643,9 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         float halo;
     };
     auto G_row1 = [&](int ch, Rows &q, int k) {             // k = 0..7: row k & 3 of channel 2 lh + k / 4;  k = 8: the halo values
-        const int soff = min(ch * (WG_CK * HW * 4), x_last_off);      // (see x_last_off)
+        // (the inference instance has no scalar register left for x_last_off -- it spilled a vector register pair to scratch --: it clamps the
+        //  chunk index with `last`, which its filter loads keep live anyway)
+        const int soff = BNE ? wg_chunk_base(min(ch, x_last), g.C) * HW * 4 : min(ch * (WG_CK * HW * 4), x_last_off);      // (see x_last_off)
         if (k < 8)
             q.r[k >> 2][k & 3] = __builtin_amdgcn_raw_buffer_load_b64(srd_x, roff[k & 3], soff + (k >> 2) * HW * 4, 0);
         else
@@ -731,7 +733,8 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         }
     }
     const int last = nch - 1;
-    x_last_off = __builtin_amdgcn_readfirstlane(min(last * WG_CK, g.C - WG_CK) * HW * 4);
+    x_last = last;
+    if (!BNE) x_last_off = __builtin_amdgcn_readfirstlane(min(last * WG_CK, g.C - WG_CK) * HW * 4);
     auto clampc = [&](int c) { return min(c, last); };
     f32x4 u0[8], u1[8], u2[8];             // U of chunks it, it + 1, it + 2 (three rotating sets: requested two iterations ahead)
     float b0[16], b1[16];                  // B operands of the current chunk: V of channels 2 lh, 2 lh + 1

@@ -36,7 +36,7 @@ def _batches():
     return [(torch.randn(B, 3, 32, 32, generator=g), torch.randint(0, 5, (B,), generator=g)) for _ in range(STEPS)]
 
 
-def _run(rank, world, data_parallel, scenario='task1_prune'):
+def _run(rank, world, data_parallel, scenario='task1_prune', dev='cuda:0'):
     """scenario 'task1_prune': 3 prune-mode steps (rank-prune events after steps 1 and 2) through Manager.train.
     scenario 'task2_finetune': task 2 of two -- 70 % of the slots belong to task 1 (frozen, picked through piggymasks), the free
     ones are claimed and trained; MaskedSGD + MaskedAdam; the data-parallel exchange sends only the slots that survive routing.
@@ -48,7 +48,6 @@ def _run(rank, world, data_parallel, scenario='task1_prune'):
     from cpg_amd.utils import Optimizers
     from cpg_amd.utils.fused_sgd import MaskedSGD
     from cpg_amd.utils.manager import Manager
-    dev = 'cuda:0'
     torch.manual_seed(1)
     net = M.custom_vgg_cifar100(VGG_CFG, dataset_history=[], dataset2num_classes={}, network_width_multiplier=WIDTH, shared_layer_info={})
     net.add_dataset('t1', 5)
@@ -113,13 +112,19 @@ class _Wrap(torch.nn.Module):
         return self.module(x)
 
 
-def _worker(rank, world, port, out_dir, scenario):
+def _worker(rank, world, port, out_dir, scenario, backend='gloo'):
+    """backend 'gloo': every rank on cuda:0 (a one-GPU box); 'nccl' (= RCCL): rank r on cuda:r (tests/test_dist_rccl.py)."""
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = 'cuda:0'
+    if backend == 'nccl':
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dev = 'cuda:%d' % rank
+        torch.cuda.set_device(rank)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
-        sd, masks, active, payload = _run(rank, world, True, scenario)
+        sd, masks, active, payload = _run(rank, world, True, scenario, dev)
         assert active
         torch.save({'sd': sd, 'masks': masks, 'payload': payload}, os.path.join(out_dir, 'rank%d.pt' % rank))
         dist.barrier()
@@ -127,23 +132,20 @@ def _worker(rank, world, port, out_dir, scenario):
         dist.destroy_process_group()
 
 
-def _two_ranks(tmp_path, scenario):
+def _two_ranks(tmp_path, scenario, world=2, backend='gloo'):
     import torch.multiprocessing as mp
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), scenario), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), scenario, backend), nprocs=world, join=True)
     r0 = torch.load(os.path.join(tmp_path, 'rank0.pt'))
-    r1 = torch.load(os.path.join(tmp_path, 'rank1.pt'))
-    for k in r0['sd']:
-        assert torch.equal(r0['sd'][k], r1['sd'][k]), 'ranks diverged in %s' % k
-    for k in r0['masks']:
-        assert torch.equal(r0['masks'][k], r1['masks'][k]), 'ranks diverged in mask %s' % k
+    for r in range(1, world):
+        r1 = torch.load(os.path.join(tmp_path, 'rank%d.pt' % r))
+        for k in r0['sd']:
+            assert torch.equal(r0['sd'][k], r1['sd'][k]), 'ranks 0 and %d diverged in %s' % (r, k)
+        for k in r0['masks']:
+            assert torch.equal(r0['masks'][k], r1['masks'][k]), 'ranks 0 and %d diverged in mask %s' % (r, k)
     return r0
 
 
-def test_two_ranks_task2_piggymasks_compacted_gradient_exchange(tmp_path):
-    """Task 2 under data parallelism: only the gradient slots that survive routing are exchanged (cpg_pack_owned), and the
-    result still equals one process on the full batch -- weights of task 1 untouched, task-2 slots and piggymasks trained."""
-    r0 = _two_ranks(tmp_path, 'task2_finetune')
+def check_task2_against_single_process(r0):
     pay = r0['payload']
     assert 0 < pay['sent_elems'] < 0.75 * pay['dense_elems'], pay          # ~30 % of the weight slots + ~70 % of the piggymask slots
     sd, masks, _, _ = _run(0, 1, False, 'task2_finetune')
@@ -155,8 +157,13 @@ def test_two_ranks_task2_piggymasks_compacted_gradient_exchange(tmp_path):
         assert torch.equal(r0['masks'][k], masks[k]), k
 
 
-def test_two_ranks_hip_model_masked_sgd_prune_match_single_process(tmp_path):
-    r0 = _two_ranks(tmp_path, 'task1_prune')
+def test_two_ranks_task2_piggymasks_compacted_gradient_exchange(tmp_path):
+    """Task 2 under data parallelism: only the gradient slots that survive routing are exchanged (cpg_pack_owned), and the
+    result still equals one process on the full batch -- weights of task 1 untouched, task-2 slots and piggymasks trained."""
+    check_task2_against_single_process(_two_ranks(tmp_path, 'task2_finetune'))
+
+
+def check_task1_against_single_process(r0):
     sd, masks, _, _ = _run(0, 1, False)                    # one process, the full batch
     for k, v in sd.items():
         if v.dtype.is_floating_point:
@@ -167,6 +174,10 @@ def test_two_ranks_hip_model_masked_sgd_prune_match_single_process(tmp_path):
     assert mism <= max(2, 1e-4 * total), 'owner masks differ from the single-process run in %d of %d slots' % (mism, total)
     released = sum(int((v == 0).sum()) for v in masks.values())
     assert released > 0.05 * total                         # the prune events really released weights
+
+
+def test_two_ranks_hip_model_masked_sgd_prune_match_single_process(tmp_path):
+    check_task1_against_single_process(_two_ranks(tmp_path, 'task1_prune'))
 
 
 def _driver_worker(rank, world, port, out_dir):
