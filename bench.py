@@ -618,6 +618,89 @@ def parity_check(net, x, width, images=4):
             'host_seconds': round(time.perf_counter() - t0, 1)}
 
 
+def run_task_sequence(a, device):
+    """--task-sequence T: T tasks back to back through cpg_amd.driver.CPGSession at the bench's full size (configs[1]: custom_vgg 224 x 224,
+    batch 256), each with the section-8d cycle the headline times for task 1 -- finetune (1 epoch) -> gradual prune 0 -> 0.1 (10 epochs, rank-
+    prune events in the first two) with a validate after every epoch -> choose the ratio -> (task >= 2) the piggymask retrain (1 epoch)
+    -- and the reference's GROWTH forced on the last task (an accuracy goal no model reaches: exit code 2 -> raw multiplier + 0.5 ->
+    sqrt -> 78 / 156 / 313 / 627 channels, the previous tasks' weights in the top-left corner, experiment1/CPG_cifar100_scratch_mul_1.5.sh:
+    46-211).  Owner ids >= 3, piggymasks picking from several older tasks, growth mid-sequence and CPGSession itself at full size.
+    Its own JSON line (never the headline): per task the wall time per train step, the owner-id histogram, shared_ratio, and the
+    gradient payload a data-parallel exchange sends per step (owned slots, + the older tasks' slots for the piggymask gradients in finetune
+    mode) against the dense one."""
+    from cpg_amd.driver import CPGSession, default_args
+    T = a.task_sequence
+    E = max(2, a.steps // 11)                      # steps per epoch: 220 -> 20 (section 8d)
+    sess = CPGSession('custom_vgg', width_multiplier=a.width_multiplier, device=device, seed=1, freeze_gc=True)
+    g = torch.Generator(device=device).manual_seed(1)
+    xs = [torch.randn(a.batch, 3, 224, 224, generator=g, device=device) for _ in range(3)]
+    xv = [torch.randn(100, 3, 224, 224, generator=g, device=device) for _ in range(2)]
+
+    class Counting(object):
+        def __init__(self, batches):
+            self.batches, self.served = batches, 0
+
+        def __len__(self):
+            return len(self.batches)
+
+        def __iter__(self):
+            for b in self.batches:
+                self.served += 1
+                yield b
+    tasks = []
+    t_all = time.perf_counter()
+    for t in range(1, T + 1):
+        name = 'task%d' % t
+        labels = [torch.randint(0, 5, (a.batch,), generator=g, device=device) for _ in range(3)]
+        vlabels = [torch.randint(0, 5, (100,), generator=g, device=device) for _ in range(2)]
+        train = Counting([(xs[i % 3], labels[i % 3]) for i in range(E)])
+        val = [(xv[i], vlabels[i]) for i in range(2)]
+        args = default_args(dataset=name, lr=1e-2, lr_mask=5e-4, prune_lr=1e-3, pruning_frequency=max(1, E // 2), pruning_interval=2,
+                            network_width_multiplier=sess.width)
+        grow = t == T and T >= 2
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = sess.run_task(name, 5, train, val, accuracy_goal=2.0 if grow else 0.0, finetune_epochs=1, prune_epochs=10, sparsities=(0.1,),
+                            args=args, min_train_acc=-1.0, max_width_multiplier=(sess.width_multiplier + 0.5) if grow else None,
+                            width_step=0.5, retrain_epochs=1, total_num_tasks=T)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        hist = torch.zeros(256, dtype=torch.int64, device=device)
+        for m in sess.masks.values():
+            hist += torch.bincount(m.reshape(-1).long(), minlength=256)
+        hist = hist.cpu().tolist()
+        n_all = sum(hist)
+        pr = SparsePruner(sess.model, sess.masks, default_args(mode='inference', dataset=name, network_width_multiplier=sess.width), 0, 0, t)
+        owned, older = hist[t], sum(hist[1:t])
+        tasks.append({'task': t, 'train_steps': train.served, 'wall_s': round(wall, 2),
+                      'wall_ms_per_train_step': round(1000.0 * wall / max(1, train.served), 2),
+                      'width_multiplier_raw': sess.width_multiplier, 'width_multiplier_rooted': round(sess.width, 6), 'grown_to': res.grown_to,
+                      'masked_weights': n_all, 'owner_histogram': {str(i): c for i, c in enumerate(hist) if c},
+                      'ratio_to_acc': {str(k): v for k, v in res.ratio_to_acc.items()}, 'chosen_ratio': res.chosen_ratio,
+                      'retrain_kept': res.retrain_kept, 'shared_ratio': round(pr.calculate_shared_part_ratio(), 6) if t > 1 else None,
+                      'sparsity': pr.calculate_sparsity(),
+                      'dp_payload_bytes_per_step': {'dense_weights': 4 * n_all, 'prune_mode': 4 * owned,
+                                                    'finetune_mode': 4 * (owned + (older if t > 1 else 0)),
+                                                    'dense_with_piggymasks': (8 if t > 1 else 4) * n_all},
+                      'channels': [int(m.weight.shape[0]) for m in sess.net.modules() if isinstance(m, (nl.SharableConv2d, nl.SharableLinear))][:14:3]})
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t_all
+    steps = sum(t['train_steps'] for t in tasks)
+    # every earlier task still answers exactly as it did: evaluate task 1 on its own (cropped) network before / after is the driver test's
+    # job (tests/test_driver_gpu.py); here: the logits of task 1 are finite and its head reads the narrow share of the features
+    acc1, logits1 = sess.evaluate('task1', [(xv[0], torch.zeros(100, dtype=torch.long, device=device))])
+    return {'metric': 'images/sec over a %d-task CPG sequence through CPGSession, VGG16 224x224 batch %d (NOT the headline metric: finetune -> prune '
+                      '-> piggymask retrain per task, growth forced on the last task)' % (T, a.batch),
+            'value': round(a.batch * steps / total, 2), 'unit': 'images/sec', 'n_gpus': 1, 'steps': steps, 'warmup': 0,
+            'ms_per_step': round(1000.0 * total / steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'data': 'synthetic',
+            'dtype': 'f32', 'config': {'workload': 'configs[1]: VGG16-BN custom_vgg 224x224, %d-task sequence (epochs of %d steps: 1 finetune + 10 prune '
+                                                   '+ 1 retrain from task 2, validate after every epoch), batch %d' % (T, E, a.batch),
+                                       'tasks': T, 'epoch_steps': E, 'per_gpu_batch': a.batch, 'start_width_multiplier_raw': a.width_multiplier},
+            'tasks': tasks, 'task1_after_sequence': {'logits_finite': bool(all(torch.isfinite(o).all() for o in logits1)), 'accuracy': acc1},
+            'note': 'wall time includes validates, snapshots, the ratio choice, the growth rebuild (last task: a finetune at the old width, then '
+                    'the wider model) -- everything CPGSession.run_task does; the cycle-only step time of a task is the headline bench / --task 2'}
+
+
 def cpu_plumbing_cycle(steps=220, batch=32):
     """BASELINE.json configs[0] / BASELINE.md section 4: the reference's own CPU-runnable case -- `custom_vgg_cifar100` (VGG16-BN at
     32 x 32, full width), batch 32, the WHOLE section-8d mini-cycle on the host through the oracle: 20 finetune steps (lr 1e-2), a
@@ -820,6 +903,9 @@ def main():
                     help="the reference's RAW --network_width_multiplier (main() takes its square root, CPG_cifar100_main_normal.py:115): 1.5 = "
                          'the GROWN network most of the 20 tasks of configs[1] run in (experiment1/CPG_cifar100_scratch_mul_1.5.sh:90-94: '
                          'int(v * 1.2247) = 78 / 156 / 313 / 627 channels, 30723 -> 5016 -> 5016 FC); its own line, never the headline')
+    ap.add_argument('--task-sequence', type=int, default=0,
+                    help='T > 0: T tasks back to back through cpg_amd.driver.CPGSession at full size, growth forced on the last one; prints its '
+                         'own JSON line (per-task step time, owner-id histogram, shared_ratio, data-parallel payload) instead of the cycle bench')
     ap.add_argument('--arch', default='vgg16', choices=sorted(ARCHS),
                     help="topology of the cycle: 'vgg16' = the headline (BASELINE.json configs[1]); 'resnet50' / 'spherenet20' = the "
                          'topologies of configs[3] / configs[4] through the same cycle (their own lines, never the headline)')
@@ -871,6 +957,11 @@ def main():
         torch.cuda.set_device(0)
     device = torch.device('cuda', torch.cuda.current_device())
 
+    if a.task_sequence > 0:
+        if world != 1 or a.arch != 'vgg16':
+            sys.exit('bench.py: --task-sequence runs on one GPU with --arch vgg16')
+        print(json.dumps(run_task_sequence(a, device)), flush=True)
+        return
     global DATASET, WIDTH
     arch = ARCHS[a.arch]
     DATASET = arch['dataset']

@@ -696,7 +696,10 @@ extern "C" int cpg_conv1x1_supported(const cpg_conv_desc *d) {
 
 size_t cpg_conv1x1_pack_workspace(const cpg_conv_desc *d) { return std::max(pack_bytes(d->C, d->K), pack_bytes(d->K, d->C)); }
 
-// pixel tiles of the forward launch = rows of the [K][tiles][2] statistics buffer of cpg_conv2d_fwd_bnstats
+// pixel tiles of the forward launch = rows of the [K][tiles][2] statistics buffer of cpg_conv2d_fwd_bnstats.  The launch below derives
+// the same tile from the same inputs (K, stride, plane size, CPG_PW_TILE); where the wide tile additionally needs a 16-byte aligned input
+// it REFUSES a fused-statistics launch on an unaligned one instead of falling back to another tile size.  CPG_PW_TILE is A/B tooling:
+// like every planner switch it must not change between a query and the launch it sized (include/cpg_hip.h).
 int cpg_conv1x1_bnstats_tiles(const cpg_conv_desc *d) {
     const int OH = (d->H - 1) / d->stride_h + 1, OW = (d->W - 1) / d->stride_w + 1;
     const bool wide = pw_wide() && d->stride_h == 1 && d->stride_w == 1 && (OH * OW) % 4 == 0;
@@ -827,7 +830,8 @@ int cpg_pw_gemm_nt(const float *A, const float *B, int M, int C, int64_t K, cons
 
 bool cpg_pw_gemm_nn_ok(const float *X, int M, int Mp, int Kd, int64_t G) {
     // no split-K here: the output tiles alone must fill the chip (4096 -> 4096 dgrad at batch 256 has 38 of them: 4x slower)
-    if (((G + 223) / 224) * ((M + 127) / 128) < 192) return false;
+    const int64_t bn = (G % 4 == 0 && pw_wide()) ? PwV2::BN : PwV::BN;      // (the pixel tile of the launch cpg_pw_gemm_nn makes)
+    if (((G + bn - 1) / bn) * ((M + 127) / 128) < 192) return false;
     return !cpg::opt_on(cpg::OPT_DISABLE_PW_GEMM) && Kd % 16 == 0 && M % 8 == 0 && Mp % 128 == 0 && Mp >= M && G < (1ll << 28) &&
            (int64_t)Kd * G * 4 < (1ll << 31) && (int64_t)M * G < (1ll << 31) && (((uintptr_t)X) & 15) == 0;
 }

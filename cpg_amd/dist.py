@@ -52,10 +52,26 @@ class _ChunkedGradient(object):
         when a gradient is already there (accumulation over several backward passes: autograd ADDS into p.grad, so the rows on the
         wire would not be p.grad's -- the whole-tensor path reduces the accumulated gradient correctly)."""
         o = self.owner
+        if self.pending:
+            # A weight used TWICE in one graph: its second backward call arrives while the first call's row blocks are on the wire and before
+            # AccumulateGrad has set p.grad.  Autograd will SUM the two gradients, so the first call's rows are joined NOW (they then hold the
+            # global mean, identical on every rank) and this call takes the whole-tensor path: the parameter's gradient hook all-reduces
+            # mean(g1) + g2_local, whose mean over ranks is mean(g1) + mean(g2).
+            self.join()
+            return False
         return o._active and self.param.grad is None and (o._filter is None or o._plan(self.param) is None)
 
-    def buffer(self, like):
+    def join(self):
+        o = self.owner
+        for work, rows, _ in self.pending:
+            work.wait()
+            if not o._avg:
+                rows.mul_(1.0 / o._world)
         self.pending = []
+
+    def buffer(self, like):
+        if self.pending:
+            raise RuntimeError('cpg_amd.dist: a chunked gradient exchange is still in flight for this weight (buffer() without active())')
         gw = torch.empty_like(like, memory_format=torch.contiguous_format)
         self.base_ptr = gw.data_ptr()
         return gw
@@ -262,6 +278,11 @@ class DataParallel(nn.Module):
                 _lib.check('cpg_unpack_owned', rc)
         self._handles = []
         for p, ch in self._chunked:
+            if p.grad is None:                                    # (the backward pass produced row blocks but no gradient was kept)
+                for work, _, _ in ch.pending:
+                    work.wait()
+                ch.pending = []
+                continue
             adopted = p.grad.data_ptr() == ch.base_ptr           # autograd took the gradient tensor itself: the rows ARE p.grad's
             for work, rows, r0 in ch.pending:
                 work.wait()

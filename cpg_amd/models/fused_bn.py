@@ -371,7 +371,8 @@ def conv_prelu(conv, mod, x, res=None):
     delivers the conv's bias gradient (the per-channel sum of the gradient it writes), so the conv's backward runs no bias reduction."""
     from .layers import BiasGradSink
     if (ENABLED and type(mod) is nn.PReLU and x.is_cuda and getattr(conv, 'bias', None) is not None and torch.is_grad_enabled()
-            and mod.weight.numel() in (1, conv.out_channels) and conv._math() == 'fp32'):
+            and mod.weight.numel() in (1, conv.out_channels) and conv._math() == 'fp32'
+            and getattr(conv, 'groups', 1) == 1):           # (a grouped conv runs one call per group: each computes its own bias gradient)
         sink = BiasGradSink()
         y = conv(x, bias_sink=sink)
         if y.dtype == torch.float32 and y.dim() == 4 and y.is_contiguous() and (res is None or (res.shape == y.shape and res.is_contiguous())):

@@ -397,7 +397,9 @@ class SharableConv2d(_Sharable):
 
     def forward_with_bn_stats(self, input, bn_hint=None):
         """(y, stats): forward plus the BatchNorm partial sums of y from the same kernel; stats is None when this shape
-        has no fused-statistics kernel.  Used by cpg_amd.models.fused_bn.FusedSequential for conv -> BatchNorm2d runs."""
+        has no fused-statistics kernel (groups > 1 among them: the per-group calls take no statistics epilogue, no BatchNorm-backward hint
+        and no bias sink -- callers get stats None and run the separate statistics pass).  Used by cpg_amd.models.fused_bn.FusedSequential
+        for conv -> BatchNorm2d runs."""
         if self.groups != 1:
             return self._grouped(input), None
         y, stats = _MaskedConv2dFn.apply(input, self.weight, self.piggymask, self.bias, self.info['threshold'],

@@ -83,7 +83,6 @@ class MaskedAdam(torch.optim.Adam):
         self.pruner = pruner
         pruner.fused_piggymask_step = True
         self._masked = {}
-        self._pristine = set()                   # id(p) of piggymasks whose Adam state is still exactly zero (see step())
 
     def _refresh(self):
         self._masked = {}
@@ -110,10 +109,12 @@ class MaskedAdam(torch.optim.Adam):
                     state['step'] = torch.tensor(0.0, dtype=torch.float32)
                     state['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    self._pristine.add(id(p))
+                    # the moments are exactly zero until the kernel below has run once.  The flag lives IN the state (not in a set of
+                    # id(p) beside it), so that load_state_dict() / any replacement of the state drops it with the state it described
+                    state['_pristine'] = True
                 state['step'] += 1
                 held.append((p, p.grad))
-                if mode == _lib.MODE_PRUNE and id(p) in self._pristine:
+                if mode == _lib.MODE_PRUNE and state.get('_pristine', False):
                     # Prune mode routes EVERY piggymask gradient to zero (utils/prune.py:209-210), and this parameter's moments are
                     # still exactly zero: Adam's update is then m = v = 0, pm -= step_size * 0 / eps -- nothing changes, bit for bit.
                     # The whole prune phase of the reference (lr_mask 0, a fresh optimizer per phase) is this case: only the routed
@@ -121,7 +122,7 @@ class MaskedAdam(torch.optim.Adam):
                     idle.append(p.grad)
                     p.grad = None
                     continue
-                self._pristine.discard(id(p))
+                state.pop('_pristine', None)
                 owner = pr._owner(name, p.data)
                 rc = L.cpg_adam_route_step(_lib.dptr(p.data, name='piggymask'), _lib.dptr(p.grad, name='piggymask.grad'),
                                            _lib.dptr(state['exp_avg']), _lib.dptr(state['exp_avg_sq']),

@@ -77,11 +77,14 @@ typedef struct cpg_prune_result {
 int cpg_version(void);
 /* PROCESS-wide scheduling hint (an atomic; default 0): 1 = other streams' kernels share the chip with this process's launches
  * (a data-parallel run: RCCL's all-reduce kernels hold some CUs during the backward pass).  Only changes scheduling and the
- * summation order of split partial sums; the weight gradients then split finer (Winograd: 4 units per wave slot instead of 1;
- * pointwise / direct 3x3: 4 split blocks per CU instead of 2) so that a launch that finds CUs taken is still balanced by the
- * dispatcher.  Set it before the workspace query of the calls it should affect.  Process-wide on purpose: the planners that read it
- * run inside autograd's backward, on the engine's worker thread, not on the thread that set it (round 3's thread-local never reached
- * them).  Replaces nn.DataParallel's implicit "all GPUs are mine" (CPG_cifar100_main_normal.py:199-200). */
+ * summation order of split partial sums.  Since round 4 ONE planner reads it: the Winograd weight gradient runs 2 rounds of half-length
+ * units per wave slot instead of 1 (a launch that finds CUs taken then grows by half a round instead of a whole one); the pointwise and
+ * direct 3x3 weight-gradient planners ignore it (beside RCCL's real kernels their finer splits cost more than they saved).  It changes
+ * the workspace a weight-gradient call needs, and it is PROCESS-wide (the planners run inside autograd's backward, on the engine's
+ * worker thread, not on the thread that set it): set it once, before the first workspace query, and do not change it while ANY thread
+ * is between a workspace query and the launch it sized -- a launch whose plan outgrew its workspace fails with CPG_E_WORKSPACE, it
+ * never overruns.  cpg_amd.dist.DataParallel raises it only for >= 256 MB of gradients per step (VGG16).  Replaces nn.DataParallel's
+ * implicit "all GPUs are mine" (CPG_cifar100_main_normal.py:199-200). */
 int cpg_set_shared_chip_hint(int32_t shared);
 int32_t cpg_get_shared_chip_hint(void);
 /* Library options.  Every CPG_* switch of the dispatch code (INTEGRATION.md lists them) lives in one process-wide table that is
@@ -91,7 +94,25 @@ int32_t cpg_get_shared_chip_hint(void);
  * given" (the built-in default applies).  The policy switches -- the only ones an integrator should touch -- choose the arithmetic
  * of the 3x3 convolutions: CPG_NO_WINO (direct fp32 MFMA instead of Winograd F(2x2,3x3) in all three passes), CPG_NO_WINO_WGRAD,
  * CPG_NO_WINO_ODD, CPG_NO_STEM, CPG_NO_STEM_FUSE, CPG_NO_DEAD_SKIP; everything else is A/B tooling.  Unknown name: CPG_E_INVALID.
- * There is no counterpart in the reference: F.conv2d takes whichever algorithm cuDNN / MIOpen selects (models/layers.py:106-109). */
+ * There is no counterpart in the reference: F.conv2d takes whichever algorithm cuDNN / MIOpen selects (models/layers.py:106-109).
+ *
+ * WHICH SWITCHES CHANGE RESULTS.  Every path computes the same fp32 convolution / GEMM; what a switch can change is the rounding
+ * (always inside the 1e-4 parity bar, every combination is covered by tests/test_hip_parity.py):
+ *   arithmetic (Winograd transforms vs direct taps: differences of 1e-6 of the output scale):
+ *       CPG_NO_WINO, CPG_NO_WINO_WGRAD, CPG_NO_WINO_ODD, CPG_DISABLE_CONV3X3, CPG_C3_FORCE (tile shape of the direct kernel = its
+ *       channel-split accumulation), CPG_NO_S2, CPG_NO_V14, CPG_W3_PICK, CPG_DISABLE_CONV1X1, CPG_DISABLE_CONV1X1_WGRAD,
+ *       CPG_DISABLE_PW_GEMM, CPG_NO_STEM (stem kernel vs general kernel: other k order of the 27 taps);
+ *   summation order only (how a reduction over pixels / tiles / channel blocks is split and added: last-bit differences, mostly in
+ *   weight gradients and BatchNorm statistics):
+ *       CPG_WW_UNITS, CPG_WW_SHARE, CPG_C3W_BPC, CPG_PWW_BPC, CPG_PW_TILE, CPG_WINO_KERNEL, CPG_WINO_NW, CPG_STEM_BLOCKS,
+ *       CPG_NO_STEM_FUSE (fused stem recomputes y instead of reading it back: same bits where the summation order is the same),
+ *       and cpg_set_shared_chip_hint (above);
+ *   no effect on any result bit (scheduling / mapping of the same work):
+ *       CPG_WINO_PERSIST, CPG_WINO_GRIDS, CPG_WW_XCD, CPG_WG3_SHARE, CPG_NO_DEAD_SKIP (skips work whose inputs are exactly zero).
+ * A run is bit-reproducible for a fixed set of switch values and a fixed hint; the defaults are what every committed number used.
+ * The table is global state, but not per-call mutable state: no entry point writes it, and a concurrent cpg_set_option only ever
+ * changes which of the above equivalent plans a LATER call picks (the workspace caveat of the hint applies to CPG_WW_UNITS,
+ * CPG_C3W_BPC, CPG_PWW_BPC and CPG_PW_TILE as well). */
 #define CPG_OPT_UNSET INT32_MIN
 int cpg_set_option(const char *name, int32_t value);
 int cpg_get_option(const char *name, int32_t *value);
