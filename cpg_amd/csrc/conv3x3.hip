@@ -1083,6 +1083,7 @@ extern "C" int cpg_conv3x3_stem_tiles(int N, int C, int K, int H, int W);
 extern "C" int cpg_conv3x3_stem_run(int N, int C, int K, int H, int W, const float *x, const float *w, const float *pm, float thr,
                                     const float *bias, float *y, float *stats, hipStream_t stream);
 extern "C" size_t cpg_conv3x3_wino_pack_bytes(int c_read, int m);
+extern "C" size_t cpg_conv3x3_wino_tail_bytes(int N, int c_read, int m, int H, int W);
 extern "C" int cpg_conv3x3_wino_tiles(int N, int c_read, int m, int H, int W);
 extern "C" int cpg_conv3x3_wino_eval_ok(int N, int c_read, int m, int H, int W);
 extern "C" int cpg_conv3x3_wino_run_bn_eval(int N, int C, int K, int H, int W, const float *x, const float *w, const float *pm, float thr,
@@ -1236,7 +1237,9 @@ extern "C" int cpg_conv3x3_supported(const cpg_conv_desc *d) {
 
 size_t cpg_conv3x3_pack_workspace(const cpg_conv_desc *d) {
     return std::max(pack_bytes(d->C, d->K), pack_bytes(d->K, d->C)) + 16 +
-           std::max(cpg_conv3x3_wino_pack_bytes(d->C, d->K), cpg_conv3x3_wino_pack_bytes(d->K, d->C));
+           std::max(cpg_conv3x3_wino_pack_bytes(d->C, d->K), cpg_conv3x3_wino_pack_bytes(d->K, d->C)) + 256 +
+           // (the partial outputs of a Winograd launch's tail pieces, behind its packed filter: conv3x3_wino.hip, k_wg3<.., SPLIT>)
+           std::max(cpg_conv3x3_wino_tail_bytes(d->N, d->C, d->K, d->H, d->W), cpg_conv3x3_wino_tail_bytes(d->N, d->K, d->C, d->H, d->W));
 }
 
 int cpg_conv3x3_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr, const float *bias,

@@ -57,6 +57,11 @@ struct WgGeom {
     int span;                 // images a block's 64 consecutive tiles can touch
     unsigned nblocks;         // k_wg1 / k_wg3: logical blocks of the launch (the grid may be smaller: blocks loop over them)
     float inv_timg, inv_tw;   // 1 / tiles_img, 1 / tw (wg_divmod)
+    // k_wg3<.., SPLIT> (the tail launch of wino_run): logical blocks split_first .. of the layer, each cut into split_s pieces of split_nch
+    // channel chunks; piece s writes its partial outputs to y + s * split_stride
+    unsigned split_first;
+    int split_s, split_nch;
+    int64_t split_stride;
 };
 
 // rel / d and rel % d for rel < 2^24 (exact in fp32) and a small quotient: a multiply by the reciprocal and one correction step, ~10
@@ -1337,11 +1342,17 @@ struct Bop {                                  // k_wg3's B operands of one chann
 // all sixteen back after a barrier that waits for LDS traffic only (four 16-byte reads).  Everything else -- filter operands,
 // accumulators, the epilogue and its exchange between the two waves of a unit -- is per unit, as before; every sum is bit for bit
 // what the two-wave block computes.
-template <bool DGRAD, bool STATS, bool BNE = false, bool ODD = false, bool SH = false>
+// SPLIT (round 5): the TAIL launch of a layer whose units do not fill their last round (SphereNet-20's 256 -> 256 @14 at batch 256: 784
+// four-wave blocks on 256 CUs = 3.06 rounds -- the last 16 blocks ran alone for a whole round).  wino_run() launches the full rounds as
+// before and the leftover logical blocks here, each cut into split_s pieces along the channel loop (piece s contracts chunks
+// s * split_nch .. and stores its partial outputs -- the output transform is linear -- to its own slice of a workspace); k_wg_tail_reduce
+// adds the slices in a fixed order (+ bias) into y.  No statistics / inference epilogue, even maps.
+template <bool DGRAD, bool STATS, bool BNE = false, bool ODD = false, bool SH = false, bool SPLIT = false>
 __global__ __launch_bounds__(SH ? 256 : 128) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
            float *__restrict__ y, float *__restrict__ stats, WgBnEval bn) {
     static_assert(!SH || (!BNE && !ODD), "shared B operands: training launches on even maps");
+    static_assert(!SPLIT || (!STATS && !BNE && !ODD), "the tail launch has the plain epilogue only");
     constexpr int UNITF = 2 * 64 * 64;                       // per unit: 2 x 2 raw stages (3264 floats) / the epilogue's exchange buffer (32 KB)
     constexpr int BXF = 2 * 2 * 2 * 2 * 64 * 4;              // SH: [buffer][ph][channel j][half][lane][4] transformed operands (16 KB)
     __shared__ __attribute__((aligned(16))) float smem_all[SH ? 2 * UNITF + BXF : UNITF];
@@ -1361,7 +1372,12 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     //  which share half of their input rows, stay in one XCD's L2 as with one block per logical block)
     const unsigned v = base + blockIdx.x;
     if (v >= nlb) break;
-    const unsigned lb = SH ? 2 * xcd_remap(v, nlb) + (unsigned)un : xcd_remap(v, nlb);
+    // SPLIT: virtual block v = (leftover block or pair v / split_s, piece v % split_s); g.nblocks counts the pieces
+    const int piece = SPLIT ? (int)(v % (unsigned)g.split_s) : 0;
+    const unsigned lb = SPLIT ? g.split_first + (SH ? 2 * (v / (unsigned)g.split_s) + (unsigned)un : v / (unsigned)g.split_s)
+                              : (SH ? 2 * xcd_remap(v, nlb) + (unsigned)un : xcd_remap(v, nlb));
+    const int ch0 = SPLIT ? piece * g.split_nch : 0;          // first channel chunk of this unit's contraction
+    float *const yy = SPLIT ? y + (int64_t)piece * g.split_stride : y;
     const int nkb64 = (g.nkb + 1) / 2;                        // (g.nkb counts blocks of 32 channels)
     const int kb = lb % nkb64;                                // block of 64 output channels
     const unsigned ttot = (unsigned)g.tiles_total, timg = (unsigned)g.tiles_img, twu = (unsigned)g.tw;
@@ -1419,12 +1435,12 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     // for the channels the neighbour already contracted) -- one scalar multiply and one min per chunk, as before.
     int x_last_off = 0;
     const __amdgpu_buffer_rsrc_t srd_x =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(x + (int64_t)n0 * g.C * HW), 0, nimg_here * g.C * HW * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void *)(x + ((int64_t)n0 * g.C + ch0 * WG_CK) * HW), 0, (nimg_here * g.C - ch0 * WG_CK) * HW * 4, 0x00020000);
     // U records are per block of 32 channels: this wave reads float4 q = 4 ph .. + 3 of the records of blocks 2 kb, 2 kb + 1
     // (through a buffer descriptor: four per-lane byte offsets computed once per unit, the chunk in the scalar offset, the float4 pair
     //  in the instruction offset -- no vector instruction per load; 64-bit pointer arithmetic was four per chunk)
     const __amdgpu_buffer_rsrc_t srd_u = __builtin_amdgcn_make_buffer_rsrc((void *)up, 0, (int)(((int64_t)g.nkb + 1) / 2 * 2 * g.nch * W1_U * 4), 0x00020000);
-    const int ubase = ((2 * kb) * g.nch * W1_U + ph * 1024 + lane * 4) * 4;
+    const int ubase = (((2 * kb) * g.nch + ch0) * W1_U + ph * 1024 + lane * 4) * 4;
     const int ukq = g.nch * W1_U * 4;
 
     // raw[c][row][slot][2] offsets of this lane (channels 2 lh + j)
@@ -1539,7 +1555,7 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
 
 
     WG_STAMP(1);
-    int nch = g.nch;
+    int nch = SPLIT ? min(g.split_nch, g.nch - ch0) : g.nch;
     if (BNE && bn.live != nullptr) {                          // inference: skip what apply_mask killed (wave-uniform decisions)
         const int alive = (kb * 64 + lane < g.M) ? bn.live[kb * 64 + lane] : 0;
         const bool dead = __ballot(alive != 0) == 0ull;
@@ -1552,7 +1568,7 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
         }
     }
     const int last = nch - 1;
-    x_last_off = __builtin_amdgcn_readfirstlane(min(last * WG_CK, g.C - WG_CK) * HW * 4);
+    x_last_off = __builtin_amdgcn_readfirstlane(min(last * WG_CK, g.C - WG_CK - ch0 * WG_CK) * HW * 4);
     auto clampc = [&](int c) { return min(c, last); };
     // U of the current / next chunk: [kq * 4 + q].  U3 (every variant but the one with the statistics epilogue, which has no registers
     // left): a third buffer -- the loads of chunk it + 2 go out during chunk it, two chunks (2 us) ahead of their first use instead of
@@ -1789,13 +1805,13 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     const int n = n0 + nrel;
     // (ODD: the odd row of the last tile row of an odd-height map does not exist -- the wave that owns it stores nothing for that tile)
     const bool tv = tg < ttot && (!ODD || 2 * ty + ph < g.H);
-    float *yout = y + ((int64_t)n * g.M) * HW + (2 * ty + ph) * g.W + 2 * tx;
+    float *yout = yy + ((int64_t)n * g.M) * HW + (2 * ty + ph) * g.W + 2 * tx;
     // FAST (all 32 tiles of the unit exist, all 64 channels of the block exist, even map -- a wave-uniform test): plain stores at the unit's
     // (scalar) base + a 32-bit lane offset + the running scalar channel offset, one vector add per store.  The general path computes a
     // 64-bit address per store (a multiply-add and two shift-adds), compares and branches around it: 1 us of a unit for the few units
     // on the ragged end of a launch that need it.
     const bool fast_u = !ODD && t0 + W1_T <= ttot && g.M - kb * 64 >= 64;
-    char *ybase = reinterpret_cast<char *>(y + (int64_t)n0 * g.M * HW);
+    char *ybase = reinterpret_cast<char *>(yy + (int64_t)n0 * g.M * HW);
     const unsigned yoff = (unsigned)(((nrel * g.M + kb * 64 + 4 * lh_e) * HW + (2 * ty + ph) * g.W + 2 * tx) * 4);
     // (the scalar channel offsets are a running sum behind an opaque barrier: as multiples of HW they are invariant in the persistent
     //  loop, the compiler would compute all 32 in front of it and spill scalar registers into vector lanes)
@@ -1888,7 +1904,69 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     }   // next logical block
 }
 
+// y = bias + sum over the pieces of k_wg3<.., SPLIT>'s partial outputs, for the logical blocks lb_first .. lb_end - 1 of the layer (each: 64 output
+// channels x 32 tiles x 2 x 2 pixels).  The pieces are added in index order: the result does not depend on which piece finished first.
+// `part` is piece 0's slice, addressed like y (image n at (n * M + m) * H W); piece s lies s * stride floats further.
+__global__ __launch_bounds__(256) void k_wg_tail_reduce(WgGeom g, const float *__restrict__ part, const float *__restrict__ bias,
+                                                        float *__restrict__ y, unsigned lb_first, unsigned lb_end) {
+    const int64_t total = (int64_t)(lb_end - lb_first) * 64 * W1_T;
+    const int nkb64 = (g.nkb + 1) / 2, HW = g.H * g.W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i & (W1_T - 1)), kl = (int)((i >> 5) & 63);
+        const unsigned lb = lb_first + (unsigned)(i >> 11);
+        const int m = (int)(lb % (unsigned)nkb64) * 64 + kl;
+        const int64_t tile = (int64_t)(lb / (unsigned)nkb64) * W1_T + t;
+        if (m >= g.M || tile >= g.tiles_total) continue;
+        const int n = (int)(tile / g.tiles_img), r = (int)(tile % g.tiles_img);
+        const int ty = r / g.tw, tx = r % g.tw;
+        const int64_t off = ((int64_t)n * g.M + m) * HW + (int64_t)(2 * ty) * g.W + 2 * tx;
+        const float b = bias != nullptr ? bias[m] : 0.0f;
+        f32x2 a0, a1;
+        a0[0] = a0[1] = a1[0] = a1[1] = b;
+        for (int sidx = 0; sidx < g.split_s; ++sidx) {
+            const float *p = part + (int64_t)sidx * g.split_stride + off;
+            const f32x2 v0 = *reinterpret_cast<const f32x2 *>(p), v1 = *reinterpret_cast<const f32x2 *>(p + g.W);
+            a0[0] += v0[0], a0[1] += v0[1], a1[0] += v1[0], a1[1] += v1[1];
+        }
+        *reinterpret_cast<f32x2 *>(y + off) = a0;
+        *reinterpret_cast<f32x2 *>(y + off + g.W) = a1;
+    }
+}
+
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+// The tail of a k_wg3 launch (see k_wg3<.., SPLIT>): `units` blocks (SH: four-wave blocks of two units, one resident per CU; otherwise
+// two-wave blocks, two per CU) = some full rounds + `left` blocks that would run a whole round alone.  When they are at most half a round,
+// each is cut into S <= 16 pieces along the channel loop (>= 2 chunks per piece) so that the pieces fill (at most) one round of 1 / S length.
+struct WgTail {
+    bool on;
+    unsigned first_lb, end_lb;    // logical blocks of the tail
+    int64_t main_units, left;
+    int S, nch_per, n_first;
+    int64_t stride;               // floats per piece: images n_first .. N - 1 of the output
+    size_t bytes;
+};
+static WgTail wino_tail_plan(const WgGeom &g0, int64_t nblocks, bool sh) {
+    WgTail t{};
+    if (opt_or(OPT_WINO_TAIL, 1) == 0) return t;
+    const int64_t units = sh ? nblocks / 2 : nblocks, slots = sh ? kCUs : 2 * kCUs;
+    const int64_t full = units / slots * slots, left = units - full;
+    if (full == 0 || left == 0 || left * 2 > slots) return t;
+    int S = (int)std::min<int64_t>(slots / left, 16);
+    S = std::min(S, g0.nch / 2);
+    if (S < 2) return t;
+    const int per = (g0.nch + S - 1) / S;
+    S = (g0.nch + per - 1) / per;
+    if (S < 2) return t;
+    t.first_lb = (unsigned)(sh ? 2 * full : full), t.end_lb = (unsigned)nblocks;
+    t.main_units = full, t.left = left, t.S = S, t.nch_per = per;
+    const int nkb64 = (g0.nkb + 1) / 2;
+    t.n_first = (int)(((int64_t)(t.first_lb / (unsigned)nkb64) * W1_T) / g0.tiles_img);
+    t.stride = (int64_t)(g0.N - t.n_first) * g0.M * g0.H * g0.W;
+    t.bytes = (size_t)S * t.stride * sizeof(float);
+    t.on = t.bytes <= ((size_t)64 << 20) && t.stride > 0;
+    return t;
+}
 
 // waves per block for a launch.  The 8-wave / 64-channel block does half the staging work per MFMA, but its eight waves run in
 // lock step behind one barrier and it measured 3-4 % SLOWER than two independent 4-wave blocks per CU on every VGG16 layer
@@ -1935,6 +2013,28 @@ extern "C" size_t cpg_conv3x3_wino_pack_bytes(int c_read, int m) {      // (the 
     return (size_t)pad_to(m, 64) * pad_to(c_read, WG_CK) * 16 * sizeof(float);
 }
 
+static inline int wino_variant(int c_read, int m, bool stats = true);
+static void wino_geom(WgGeom &g, int N, int c_read, int m, int H, int W) {
+    g = WgGeom{};
+    g.N = N, g.C = c_read, g.H = H, g.W = W, g.M = m;
+    g.th = (H + 1) / 2, g.tw = (W + 1) / 2, g.tiles_img = g.th * g.tw;
+    g.inv_timg = 1.0f / (float)g.tiles_img, g.inv_tw = 1.0f / (float)g.tw;
+    g.tiles_total = (int64_t)N * g.tiles_img;
+    g.nkb = pad_to(m, 32) / 32, g.nch = pad_to(c_read, WG_CK) / WG_CK;
+    g.span = (W1_T + g.tiles_img - 1) / g.tiles_img + 1;
+}
+static inline bool wino_sh(const WgGeom &g) { return ((g.nkb + 1) / 2) % 2 == 0 && cpg::opt_or(cpg::OPT_WG3_SHARE, 1) != 0; }
+// workspace behind the packed filter for the partial outputs of a tail launch (0: this launch has none) -- part of cpg_conv2d_workspace_bytes
+extern "C" size_t cpg_conv3x3_wino_tail_bytes(int N, int c_read, int m, int H, int W) {
+    if (((H | W) & 1) || !cpg_conv3x3_wino_ok(N, c_read, m, H, W) || wino_variant(c_read, m, false) != 3 /* WV_PAIR64 */) return 0;
+    WgGeom g;
+    wino_geom(g, N, c_read, m, H, W);
+    const int64_t blocks = ((g.tiles_total + W1_T - 1) / W1_T) * ((g.nkb + 1) / 2);
+    if (blocks > 0x7FFFFFFFll) return 0;
+    const WgTail t = wino_tail_plan(g, blocks, wino_sh(g));
+    return t.on ? t.bytes + 256 : 0;
+}
+
 // Which Winograd forward / input-gradient kernel a launch uses.  Default: k_wg3 (two waves per unit, 64 output channels each) when the
 // layer reads and produces at least 64 channels, else k_wg1 (one wave per unit).  (Until round 4 the launches WITH the BatchNorm-statistics
 // epilogue switched at 128 channels read: k_wg3's statistics epilogue was the heavier one.  After round 3's work on it -- sums per
@@ -1942,7 +2042,7 @@ extern "C" size_t cpg_conv3x3_wino_pack_bytes(int c_read, int m) {      // (the 
 // CPG_WINO_KERNEL=-,64) reads 64 -> 64 @224 4.716 -> 4.546 ms and 64 -> 128 @112 2.277 -> 2.217 ms for k_wg3.)
 // CPG_WINO_KERNEL = wave | pair | 64 | block forces k_wg1 / k_wg2 / k_wg3 / the cooperative block kernel (A/B experiments, tests).
 enum { WV_BLOCK = 0, WV_WAVE = 1, WV_PAIR = 2, WV_PAIR64 = 3 };
-static inline int wino_variant(int c_read, int m, bool stats = true) {
+static inline int wino_variant(int c_read, int m, bool stats) {
     if (const int forced = cpg::opt(cpg::OPT_WINO_KERNEL); forced != cpg::OPT_UNSET)      // (block | wave | pair | 64 -> WV_*)
         return forced >= WV_BLOCK && forced <= WV_PAIR64 ? forced : WV_WAVE;
     (void)stats;
@@ -2022,12 +2122,7 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
     const int variant = odd ? WV_PAIR64 : wino_variant(c_read, m, stats != nullptr);
     if (variant != WV_BLOCK) {
         WgGeom g;
-        g.N = N, g.C = c_read, g.H = H, g.W = W, g.M = m;
-        g.th = (H + 1) / 2, g.tw = (W + 1) / 2, g.tiles_img = g.th * g.tw;
-        g.inv_timg = 1.0f / (float)g.tiles_img, g.inv_tw = 1.0f / (float)g.tw;
-        g.tiles_total = (int64_t)N * g.tiles_img;
-        g.nkb = pad_to(m, 32) / 32, g.nch = pad_to(c_read, WG_CK) / WG_CK;
-        g.span = (W1_T + g.tiles_img - 1) / g.tiles_img + 1;
+        wino_geom(g, N, c_read, m, H, W);
         float *up = (float *)ws;
         const WgBnEval none{nullptr, nullptr, nullptr, nullptr, 0.0f, 0, nullptr, 0};
         hipLaunchKernelGGL(k_wg1_pack, dim3(stream_grid((int64_t)g.nkb * g.nch * 32 * WG_CK, 256)), dim3(256), 0, stream, w, pm, thr, up,
@@ -2051,8 +2146,28 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
                 CPG_CHECK_LAUNCH(what);
                 return CPG_OK;
             }
+            // The leftover units of the last round (k_wg3<.., SPLIT>): the full rounds run as before on logical blocks 0 .. first_lb - 1, the rest
+            // as pieces of the channel loop into the workspace behind the packed filter, k_wg_tail_reduce adds the pieces (+ bias) into y.
+            const bool sh = bne == nullptr && wino_sh(g);
+            WgTail tail{};
+            const size_t tail_off = (need + 255) / 256 * 256;
+            if (bne == nullptr && stats == nullptr) tail = wino_tail_plan(g, g.nblocks, sh);
+            if (tail.on && ws_bytes < tail_off + tail.bytes) tail.on = false;       // (a caller with the round-4 workspace: one launch, as before)
+            WgGeom gt = g;
+            float *part0 = nullptr;
+            if (tail.on) {
+                g.nblocks = tail.first_lb;
+                gt.split_first = tail.first_lb, gt.split_s = tail.S, gt.split_nch = tail.nch_per, gt.split_stride = tail.stride;
+                gt.nblocks = (unsigned)((sh ? 2 : 1) * tail.left * tail.S);
+                // piece 0's slice, addressed like y: its first image is n_first
+                part0 = reinterpret_cast<float *>(reinterpret_cast<uintptr_t>(ws) + tail_off) - (int64_t)tail.n_first * g.M * H * W;
+            }
+            auto finish_tail = [&]() {
+                hipLaunchKernelGGL(k_wg_tail_reduce, dim3(stream_grid((int64_t)(tail.end_lb - tail.first_lb) * 64 * W1_T, 256)), dim3(256), 0, stream,
+                                   gt, part0, bias, y, tail.first_lb, tail.end_lb);
+            };
             // two units per block sharing the input transform (k_wg3<..., SH>): training launches whose 64-channel blocks pair up
-            if (bne == nullptr && ((g.nkb + 1) / 2) % 2 == 0 && cpg::opt_or(cpg::OPT_WG3_SHARE, 1) != 0) {
+            if (sh) {
                 int64_t pairs = (int64_t)g.nblocks / 2;
                 if (persist) pairs = std::min<int64_t>(pairs, (int64_t)wino_grids() * kCUs);       // (one four-wave block per CU is resident)
                 if (dgrad)
@@ -2061,9 +2176,18 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
                     hipLaunchKernelGGL((k_wg3<false, true, false, false, true>), dim3((unsigned)pairs), dim3(256), 0, stream, g, x, up, bias, y, stats, none);
                 else
                     hipLaunchKernelGGL((k_wg3<false, false, false, false, true>), dim3((unsigned)pairs), dim3(256), 0, stream, g, x, up, bias, y, nullptr, none);
+                if (tail.on) {
+                    const unsigned tb = (unsigned)(tail.left * tail.S);
+                    if (dgrad)
+                        hipLaunchKernelGGL((k_wg3<true, false, false, false, true, true>), dim3(tb), dim3(256), 0, stream, gt, x, up, nullptr, part0, nullptr, none);
+                    else
+                        hipLaunchKernelGGL((k_wg3<false, false, false, false, true, true>), dim3(tb), dim3(256), 0, stream, gt, x, up, nullptr, part0, nullptr, none);
+                    finish_tail();
+                }
                 CPG_CHECK_LAUNCH(what);
                 return CPG_OK;
             }
+            if (tail.on) blocks = std::min<int64_t>(blocks, (int64_t)g.nblocks);
             if (bne != nullptr)
                 hipLaunchKernelGGL((k_wg3<false, false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, *bne);
             else if (dgrad)
@@ -2072,6 +2196,14 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
                 hipLaunchKernelGGL((k_wg3<false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, stats, none);
             else
                 hipLaunchKernelGGL((k_wg3<false, false>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, none);
+            if (tail.on) {
+                const unsigned tb = (unsigned)(tail.left * tail.S);
+                if (dgrad)
+                    hipLaunchKernelGGL((k_wg3<true, false, false, false, false, true>), dim3(tb), dim3(128), 0, stream, gt, x, up, nullptr, part0, nullptr, none);
+                else
+                    hipLaunchKernelGGL((k_wg3<false, false, false, false, false, true>), dim3(tb), dim3(128), 0, stream, gt, x, up, nullptr, part0, nullptr, none);
+                finish_tail();
+            }
             CPG_CHECK_LAUNCH(what);
             return CPG_OK;
         }

@@ -632,6 +632,65 @@ def test_winograd_wgrad_shared_chip_hint_full_batch(C, K, H):
     assert float((g1 - g0).abs().max()) < 1e-5 * sc and not torch.equal(g1, g0)
 
 
+@pytest.mark.parametrize('N,C,K,H,bias', [(256, 256, 256, 14, True),      # SphereNet-20 conv3_x: 784 four-wave blocks = 3.06 rounds (16 left: 16 pieces each)
+                                          (256, 512, 512, 14, False),     # VGG16 features.34: 6.125 rounds (32 blocks left: 8 pieces)
+                                          (200, 192, 192, 14, True),      # two-wave blocks (three 64-channel blocks): 921 blocks = 1.8 rounds -> no tail
+                                          (29, 250, 192, 28, True),       # two-wave blocks, 534 = 1.04 rounds; ragged channels (250 read: the last chunk overlaps)
+                                          (11, 96, 128, 56, False)])      # 270 four-wave blocks; the tail starts in the middle of image 10
+def test_winograd_tail_pieces_equal_the_single_launch(N, C, K, H, bias, libopt):
+    """k_wg3<.., SPLIT> + k_wg_tail_reduce (the leftover units of a Winograd launch's last round, cut along the channel loop) against the
+    same launch without the tail (CPG_WINO_TAIL=0, round 4's plan): forward and input gradient agree to fp32 round-off of a different
+    association of the channel sum, the tail path repeats bit for bit, and the images of the full rounds keep their bits.  Sampled entries are recomputed from the definition in fp64 (they fall in the tail: the LAST images of the batch)."""
+    import ctypes
+    from cpg_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(N + C + K + H)
+    x = torch.randn(N, C, H, H, generator=g, device=DEV)
+    w = torch.randn(K, C, 3, 3, generator=g, device=DEV) * (2.0 / (C * 9)) ** 0.5
+    b = torch.randn(K, generator=g, device=DEV) * 0.1 if bias else None
+    gy = torch.randn(N, K, H, H, generator=g, device=DEV)
+    layer = nl.SharableConv2d(C, K, 3, padding=1, bias=bias).to(DEV)
+    layer.weight.data.copy_(w)
+    if bias:
+        layer.bias.data.copy_(b)
+    d = nl._conv_desc(x.shape, w.shape, (1, 1), (1, 1), (1, 1), 1)
+
+    def run():
+        xd = x.clone().requires_grad_(True)
+        y = layer(xd)
+        y.backward(gy)
+        return y.detach().clone(), xd.grad.clone()
+    y1, gx1 = run()
+    y1b, gx1b = run()
+    assert torch.equal(y1, y1b) and torch.equal(gx1, gx1b)                 # fixed-order sum of the pieces
+    libopt.set('CPG_WINO_TAIL', 0)
+    y0, gx0 = run()
+    libopt.set('CPG_WINO_TAIL', None)
+    has_tail = (N, C, K, H) != (200, 192, 192, 14)                         # (1.8 rounds: the leftover is more than half a round -- one launch)
+    for a, ref in ((y1, y0), (gx1, gx0)):
+        sc = float(ref.abs().max())
+        assert float((a - ref).abs().max()) <= 2e-6 * sc
+    if not has_tail:
+        assert torch.equal(y1, y0) and torch.equal(gx1, gx0)
+    else:
+        # another association of the channel sum: the tail really ran (in the forward, the input gradient or both: they are planned apart)
+        assert not (torch.equal(y1, y0) and torch.equal(gx1, gx0))
+        head = max(1, N // 2)
+        assert torch.equal(y1[:head], y0[:head]) and torch.equal(gx1[:head], gx0[:head])       # the full rounds are untouched
+    rs = np.random.RandomState(N + H)
+    xp = torch.nn.functional.pad(x, (1, 1, 1, 1)).double()
+    gyp = torch.nn.functional.pad(gy, (1, 1, 1, 1)).double()
+    wd = w.double()
+    for _ in range(24):
+        n, k, c = N - 1 - rs.randint(min(N, 3)), rs.randint(K), rs.randint(C)
+        h, ww = rs.randint(H), rs.randint(H)
+        want = float((xp[n, :, h:h + 3, ww:ww + 3] * wd[k]).sum()) + (float(b[k]) if bias else 0.0)
+        assert abs(float(y1[n, k, h, ww]) - want) <= 1e-4 * abs(want) + 2e-5
+        want = float((gyp[n, :, h:h + 3, ww:ww + 3].flip(-1, -2) * wd[:, c]).sum())
+        assert abs(float(gx1[n, c, h, ww]) - want) <= 1e-4 * abs(want) + 2e-5
+
+
+
 @pytest.mark.parametrize('hint', [0, 1])
 def test_winograd_kernels_repeat_bit_for_bit_at_full_occupancy(hint):
     """The shared-staging / shared-transform Winograd kernels hand operands between waves through double-buffered LDS behind LDS-only
