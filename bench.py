@@ -1176,6 +1176,10 @@ def main():
             out['kernel_families'] = {k: dict({'launches': v[0], 'ms': round(v[1], 2), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2),
                                                'mfma_tflops_executed': round(v[3] / (v[1] * 1e-3) / 1e12, 2),
                                                'algorithmic_bytes_per_launch': round(v[4] / v[0]),
+                                               # what those bytes alone take at the 6.3 TB/s a float4 copy reaches on this part, beside the
+                                               # launch's measured average: the families that stream a weight (linear_* at task >= 2 / small
+                                               # batches) are to be read against THIS floor, not against the MFMA peak
+                                               'avg_launch_ms': round(v[1] / v[0], 4), 'hbm_floor_ms_per_launch': round(v[4] / v[0] / 6.3e12 * 1e3, 4),
                                                'frac_of_dense_peak_executed': round(v[3] / (v[1] * 1e-3) / 1e12 /
                                                                                     (PEAK_BF16_MFMA_TFLOPS if k.endswith('_bf16') else PEAK_FP32_MFMA_TFLOPS), 4)})
                                       for k, v in sorted(fam.items())}

@@ -833,6 +833,8 @@ int cpg_pw_gemm_nt(const float *A, const float *B, int M, int C, int64_t K, cons
 bool cpg_pw_gemm_nn_ok(const float *X, int M, int Mp, int Kd, int64_t G);
 int cpg_pw_gemm_nn(const float *wp, int Mp, const float *X, int M, int Kd, int64_t G, const float *bias, float *y, hipStream_t stream,
                    const char *what);
+int cpg_pw_gemm_nn_masked(const float *wp, int Mp, const float *X, int M, int Kd, int64_t G, const float *pm, const float *w, float thr,
+                          float *gw, float *gpm, hipStream_t stream, const char *what);
 void cpg_pw_pack_transpose(const float *a, int R, int Cc, float *wp, hipStream_t stream);
 size_t cpg_pw_pack_transpose_bytes(int R, int Cc);
 namespace {
@@ -917,6 +919,9 @@ extern "C" int cpg_linear_wgrad(const float *x, const float *gy, const float *w,
     if (pm == nullptr && (((uintptr_t)gy) & 15) == 0 && cpg_pw_gemm_nn_ok(x, out_f, out_f, batch, in_f))
         // gW[o][i] = sum_b gy[b][o] x[b][i]: gy is already K-major ([b][o], o a multiple of 128), x[b][:] the other operand
         rc = cpg_pw_gemm_nn(gy, out_f, x, out_f, batch, in_f, nullptr, gw, (hipStream_t)stream, "cpg_linear_wgrad");
+    else if (pm != nullptr && (((uintptr_t)gy) & 15) == 0 && cpg_pw_gemm_nn_ok(x, out_f, out_f, batch, in_f))
+        // ... and with a piggymask the same GEMM with the autograd epilogue of bin(pm) * W (gW = g bin(pm), gPM = g W from ONE accumulator tile)
+        rc = cpg_pw_gemm_nn_masked(gy, out_f, x, out_f, batch, in_f, pm, w, thr, gw, gpm, (hipStream_t)stream, "cpg_linear_wgrad");
     else
         rc = launch_gemm<false, false, 0>(gy, out_f, x, in_f, nullptr, thr, out_f, in_f, batch, ep, ws, ws_bytes,
                                           (hipStream_t)stream, "cpg_linear_wgrad");

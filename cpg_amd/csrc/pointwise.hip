@@ -116,12 +116,23 @@ __global__ __launch_bounds__(256) void k_pw_pack(const float *__restrict__ w, co
 // ADD (input-gradient launches): y = result + addend, elementwise at the stored positions -- the gradient of the OTHER consumer of the
 // conv's input (a residual block's identity branch, models/resnet.py:84,104: `out += identity`), which autograd would otherwise add
 // in a separate 3-pass kernel.
-template <class Cfg, bool DGRAD, bool STATS = false, bool ADD = false>
+// MASK (round 5; the plain-GEMM form: the weight gradient of a masked linear layer WITH a piggymask, models/layers.py:190 -- the autograd of
+// bin(pm) * W): the accumulator tile is g = gW_eff; the epilogue reads pm and W at the output's own positions and stores
+// y = gW = g * bin(pm) and mk.gpm = g * W -- both gradients from one tile, W and pm read once.  Until round 5 these launches ran on the
+// generic k_gemm (0.30 of the MFMA peak on features.45, a 16-step contraction in front of a 1.6 GB epilogue).
+struct PwMask {
+    const float *pm, *w;
+    float *gpm;
+    float thr;
+};
+template <class Cfg, bool DGRAD, bool STATS = false, bool ADD = false, bool MASK = false>
 __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__restrict__ x, const float *__restrict__ wp,
                                                        const float *__restrict__ bias, float *__restrict__ y,
-                                                       float *__restrict__ stats = nullptr, const float *__restrict__ addend = nullptr) {
+                                                       float *__restrict__ stats = nullptr, const float *__restrict__ addend = nullptr,
+                                                       PwMask mk = PwMask{nullptr, nullptr, nullptr, 0.0f}) {
     static_assert(!ADD || (DGRAD && !STATS), "the addend rides in plain input-gradient launches");
     static_assert(!STATS || !DGRAD, "statistics ride in forward launches");
+    static_assert(!MASK || (!DGRAD && !STATS && !ADD), "the piggymask epilogue rides in plain forward-form launches");
     __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -297,6 +308,10 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
                 const int records = (int)std::max<long long>(0, std::min<long long>((y_total - gbase) * 4, 0x7FFFFFFFll));
                 return __builtin_amdgcn_make_buffer_rsrc((void *)(base + gbase), 0, records, 0x00020000);
             };
+            // (Round 5 tried requesting the NEXT fragment's addend before this fragment's stores -- two register sets, loads one fragment ahead:
+            //  no change, 217.6 vs 218.1 ms over ResNet-50's input-gradient family.  The launch is bound by bytes, not by a late load:
+            //  256 <- 64 channels @56 x 56 moves gy + addend + gx = 1.85 GB (14 flops per byte) in 0.447 ms -- the 0.29 ms those bytes take at
+            //  6.3 TB/s plus the 0.17 ms of its MFMA work; profiles/r05_pmc_wait_resnet50.md.)
             float av[16];
             if (ADD) {                                                              // the fragment's 16 addend loads go out together
 #pragma unroll
@@ -309,6 +324,35 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
                     for (int r = 0; r < 4; ++r)
                         av[4 * eg + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_a, voff, r * plane4, 0));
                 }
+            }
+            if constexpr (MASK) {
+                // the piggymask and the weight of the fragment's 16 outputs: 32 loads out together, then two stores per output
+                float pv[16], wv[16];
+#pragma unroll
+                for (int eg = 0; eg < 4; ++eg) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pv[4 * eg + r] = wv[4 * eg + r] = 0.0f;
+                    if (rowf + 8 * eg >= g.M) continue;
+                    const __amdgpu_buffer_rsrc_t srd_p = group_srd(mk.pm, eg), srd_w = group_srd(mk.w, eg);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pv[4 * eg + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_p, voff, r * plane4, 0));
+                        wv[4 * eg + r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_w, voff, r * plane4, 0));
+                    }
+                }
+#pragma unroll
+                for (int eg = 0; eg < 4; ++eg) {
+                    if (rowf + 8 * eg >= g.M) continue;
+                    const __amdgpu_buffer_rsrc_t srd_y = group_srd(y, eg), srd_g = group_srd(mk.gpm, eg);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = 4 * eg + r;
+                        const float v = acc[fm][fn][e];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v * binarize(pv[e], mk.thr)), srd_y, voff, r * plane4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v * wv[e]), srd_g, voff, r * plane4, 0);
+                    }
+                }
+                continue;
             }
 #pragma unroll
             for (int eg = 0; eg < 4; ++eg) {
@@ -652,7 +696,7 @@ inline size_t pack_bytes(int c_read, int m) { return ((size_t)pad_to(c_read, 16)
 
 template <class Cfg, bool DGRAD>
 int launch(PwGeom g, const float *x, const float *wp, const float *bias, float *y, hipStream_t stream, const char *what,
-           float *stats = nullptr, const float *addend = nullptr) {
+           float *stats = nullptr, const float *addend = nullptr, const PwMask *mask = nullptr) {
     g.tiles_m = (g.M + Cfg::BM - 1) / Cfg::BM;
     pw_finish_geom(g);
     if (g.G >= (1ll << 31) - 512 || (g.N > 1 && (int64_t)g.HWo + 1024 >= (1 << 24)))
@@ -660,6 +704,12 @@ int launch(PwGeom g, const float *x, const float *wp, const float *bias, float *
     const int64_t blocks = (g.G + Cfg::BN - 1) / Cfg::BN * g.tiles_m;
     if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "conv1x1: grid too large");
     if constexpr (!DGRAD) {
+        if (mask != nullptr) {
+            hipLaunchKernelGGL((k_pw<Cfg, false, false, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, (float *)nullptr,
+                               (const float *)nullptr, *mask);
+            CPG_CHECK_LAUNCH(what);
+            return CPG_OK;
+        }
         if (stats != nullptr) {
             hipLaunchKernelGGL((k_pw<Cfg, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, x, wp, bias, y, stats, (const float *)nullptr);
             CPG_CHECK_LAUNCH(what);
@@ -842,6 +892,14 @@ int cpg_pw_gemm_nn(const float *wp, int Mp, const float *X, int M, int Kd, int64
     if (G % 4 == 0 && pw_wide()) return launch<PwV2, false>(g, X, wp, bias, y, stream, what);
     if (G % 4 == 0) return launch<PwV, false>(g, X, wp, bias, y, stream, what);
     return launch<PwS, false>(g, X, wp, bias, y, stream, what);
+}
+// the same GEMM with the autograd epilogue of bin(pm) * W: gw[M][G] = D * bin(pm), gpm[M][G] = D * w (pm, w, gpm laid out like gw)
+int cpg_pw_gemm_nn_masked(const float *wp, int Mp, const float *X, int M, int Kd, int64_t G, const float *pm, const float *w, float thr,
+                          float *gw, float *gpm, hipStream_t stream, const char *what) {
+    PwGeom g{1, Kd, M, Mp, (int)G, (int)G, (int)G, 0, 1, (int)G, 0, 1, 0, (long long)G};
+    const PwMask mk{pm, w, gpm, thr};
+    if (G % 4 == 0) return launch<PwV, false>(g, X, wp, nullptr, gw, stream, what, nullptr, nullptr, &mk);
+    return launch<PwS, false>(g, X, wp, nullptr, gw, stream, what, nullptr, nullptr, &mk);
 }
 // K-major transpose of a row-major [R][Cc] matrix into wp[Cc (padded to 16)][R (padded to 128)]
 void cpg_pw_pack_transpose(const float *a, int R, int Cc, float *wp, hipStream_t stream) {
