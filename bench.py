@@ -230,7 +230,7 @@ def csrc_digest():
     return h.hexdigest()
 
 
-TRAFFIC_FILES = ('r04_traffic_bench.json', 'r03_traffic_bench.json')
+TRAFFIC_FILES = ('r05_traffic_bench.json', 'r04_traffic_bench.json', 'r03_traffic_bench.json')
 
 
 def pmc_traffic(arch, family, batch):

@@ -1,0 +1,46 @@
+# one GPU-box call (round 5): tests, smoke, the bench lines (headline = vgg16 task 1; task 2; the reference's unscaled-batch split 128 / 64 / 32;
+# the other two topologies; the grown network; the 3-task sequence), rocprofv3 kernel summaries (headline, task 2, batch 32, the other topologies), FETCH_SIZE / WRITE_SIZE
+# passes over the bench itself.  TAG names the outputs under gpurun_out/; COMMIT is stamped into the traffic file.
+TAG=${TAG:-r5a}
+R=$PWD
+timeout 1800 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/pytest_${TAG}.log 2>&1; grep -E "passed|failed|error" gpurun_out/pytest_${TAG}.log | tail -3
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/smoke_${TAG}.txt
+python bench.py > gpurun_out/bench_${TAG}.log 2>&1; tail -1 gpurun_out/bench_${TAG}.log | cut -c1-200
+python bench.py --steps 20 --warmup 5 --cpu-baseline quick > gpurun_out/bench_${TAG}_k20.log 2>&1; tail -1 gpurun_out/bench_${TAG}_k20.log | cut -c1-200
+python bench.py --task 2 --steps 20 --warmup 5 > gpurun_out/bench_${TAG}_task2.log 2>&1; tail -1 gpurun_out/bench_${TAG}_task2.log | cut -c1-200
+python bench.py --task 2 > gpurun_out/bench_${TAG}_task2_k220.log 2>&1; tail -1 gpurun_out/bench_${TAG}_task2_k220.log | cut -c1-200
+export CPG_BENCH_DETAIL=1
+for b in 128 64 32; do
+  python bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline --optin-steps 0 > gpurun_out/bench_${TAG}_b$b.log 2>&1; tail -1 gpurun_out/bench_${TAG}_b$b.log | cut -c1-200
+done
+unset CPG_BENCH_DETAIL
+for a in resnet50 spherenet20; do
+  python bench.py --arch $a --steps 20 --warmup 5 > gpurun_out/bench_${TAG}_$a.log 2>&1; tail -1 gpurun_out/bench_${TAG}_$a.log | cut -c1-200
+  python tools/net_bench.py --arch $a --steps 10 2>&1 | tail -1 | tee -a gpurun_out/net_${TAG}.txt
+done
+python tools/generic_bench.py --iters 5 > gpurun_out/generic_${TAG}.txt 2>&1
+# round 5: the GROWN network (raw width multiplier 1.5: 78 / 156 / 313 / 627 channels) and the 3-task sequence through CPGSession
+python bench.py --width-multiplier 1.5 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_${TAG}_grown.log 2>&1; tail -1 gpurun_out/bench_${TAG}_grown.log | cut -c1-200
+python tools/conv_bench.py --width-multiplier 1.5 --iters 5 > gpurun_out/conv_bench_${TAG}_grown.txt 2>&1; tail -3 gpurun_out/conv_bench_${TAG}_grown.txt
+python bench.py --task-sequence 3 > gpurun_out/bench_${TAG}_seq3.log 2>&1; tail -1 gpurun_out/bench_${TAG}_seq3.log | cut -c1-200
+python tools/conv_bench.py --iters 5 > gpurun_out/conv_bench_${TAG}.txt 2>&1; tail -3 gpurun_out/conv_bench_${TAG}.txt
+cd /tmp && export TMPDIR=/tmp
+for cfg in "vgg16:--arch vgg16" "resnet50:--arch resnet50" "spherenet20:--arch spherenet20" "task2:--task 2" "b32:--batch 32" "grown:--width-multiplier 1.5"; do
+  a=${cfg%%:*}; flags=${cfg#*:}
+  rm -rf $R/gpurun_out/prof_${TAG}_$a
+  rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_$a -o run -- python $R/bench.py $flags --steps 20 --warmup 5 --no-cpu-baseline --optin-steps 0 > $R/gpurun_out/prof_${TAG}_$a.log 2>&1
+  db=$(find $R/gpurun_out/prof_${TAG}_$a -name '*.db' | head -1)
+  python $R/tools/rocprof_summary.py $db 60 > $R/gpurun_out/summary_${TAG}_$a.md 2>&1
+  rm -rf $R/gpurun_out/prof_${TAG}_$a
+done
+# HBM traffic of the bench's own launch mix: FETCH_SIZE and WRITE_SIZE in separate counter passes (kernel trace only)
+for a in vgg16 resnet50 spherenet20; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    # --clock-every 1: with the sampled kernel clock (events on some steps only) rocprofv3's counter collection aborted ResNet-50's queue with
+    # HSA_STATUS_ERROR_INVALID_PACKET_FORMAT and then hung in its signal handler (a whole bundle was lost to that); every launch clocked, or
+    # none, runs.  Bounded anyway.
+    timeout -s KILL 900 rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/btraffic/${a}_$c -o run --output-format csv -- python $R/bench.py --arch $a --steps 20 --warmup 1 --no-cpu-baseline --optin-steps 0 --clock-every 1 > $R/gpurun_out/btraffic_${a}_$c.log 2>&1
+  done
+done
+python $R/tools/bench_traffic.py $R/gpurun_out/btraffic ${COMMIT:-unknown} > $R/gpurun_out/traffic_${TAG}.json 2> $R/gpurun_out/traffic_${TAG}.err
+rm -rf $R/gpurun_out/btraffic
