@@ -553,14 +553,17 @@ def parity_check(net, x, width, images=4):
     the timed train steps ran: Winograd forward with the BatchNorm-statistics epilogue, fused BN -> ReLU (-> pool), the FC GEMMs; Dropout's p
     is 0 for the check, its masks come from different generators -- and (b) in EVAL mode (the inference epilogues the validates ran).
     north_star's bar: logits within 1e-4 (of the logit scale).  The conv arithmetic is whatever nl.set_conv_math says at the call.
-    VGG only (oracle/net.py restates the VGG cycle); other topologies return None."""
+    All three topologies (oracle/net.py: OracleVGG, OracleResNet, OracleSphereNet -- the A-Softmax head's (cos, phi) pair is compared
+    element by element)."""
     import numpy as np
     from oracle import net as onet                     # checker only
     root = net
-    if not hasattr(root, 'features') or not hasattr(root, 'classifiers') or 'VGG' not in type(root).__name__:
+    kind = type(root).__name__
+    if not hasattr(root, 'classifiers') or kind not in ('VGG', 'ResNet', 'SphereNet'):
         return None
     t0 = time.perf_counter()
-    ref = onet.OracleVGG(width, 'imagenet')
+    ref = {'VGG': lambda: onet.OracleVGG(width, 'imagenet'), 'ResNet': lambda: onet.OracleResNet(width),
+           'SphereNet': lambda: onet.OracleSphereNet(width)}[kind]()
     for ds in root.datasets:
         ref.add_dataset(ds, root.dataset2num_classes[ds])
     cur = [i for i, c in enumerate(root.classifiers) if c is root.classifier][0]
@@ -598,12 +601,14 @@ def parity_check(net, x, width, images=4):
             root.train(mode == 'train')
             ref.train(mode == 'train')
             with torch.no_grad():
-                got = root(xs).detach().float().cpu()
-                want = ref(xc).detach()
-            scale = max(float(want.abs().max()), 1e-30)
-            res[mode] = float((got - want).abs().max()) / scale
-            finite = bool(torch.isfinite(got).all())
-            res[mode + '_finite'] = finite
+                got, want = root(xs), ref(xc)
+            got = got if isinstance(got, tuple) else (got,)                     # (the A-Softmax head returns (cos, phi): both are compared)
+            want = want if isinstance(want, tuple) else (want,)
+            res[mode], res[mode + '_finite'] = 0.0, True
+            for a_, b_ in zip(got, want):
+                a_, b_ = a_.detach().float().cpu(), b_.detach()
+                res[mode] = max(res[mode], float((a_ - b_).abs().max()) / max(float(b_.abs().max()), 1e-30))
+                res[mode + '_finite'] = res[mode + '_finite'] and bool(torch.isfinite(a_).all())
     finally:
         for m, p_ in zip(drops, old_p):
             m.p = p_
@@ -614,7 +619,7 @@ def parity_check(net, x, width, images=4):
     return {'max_rel_logit_err': float('%.3g' % worst), 'train_mode_forward': float('%.3g' % res['train']),
             'eval_mode_forward': float('%.3g' % res['eval']), 'bar': 1e-4, 'ok': bool(worst < 1e-4 and res['train_finite'] and res['eval_finite']),
             'images': int(xs.shape[0]), 'conv_math': nl.CONV_MATH,
-            'oracle': 'oracle.net.OracleVGG on the host, state copied from the timed model after the cycle; outside the timed region',
+            'oracle': 'oracle.net.Oracle%s on the host, state copied from the timed model after the cycle; outside the timed region' % kind,
             'host_seconds': round(time.perf_counter() - t0, 1)}
 
 
@@ -739,7 +744,7 @@ def cpu_plumbing_cycle(steps=220, batch=32):
     return steps * batch / dt, dt, events, validates
 
 
-def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch=None, level='full'):
+def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch=None, level='full', arch='vgg16'):
     """Oracle ("port") of the same cycle on the host cores, reported beside the GPU number (never the target).
     oracle/ is only ever used here as the measured CPU baseline.
 
@@ -761,19 +766,20 @@ def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch
         probe_batch = 32 if level == 'full' else 64
     default_threads = torch.get_num_threads()
     all_threads = os.cpu_count() or default_threads
-    model, pruner, opt = onet.make_task1(1.0, 'imagenet', 'finetune', lr=1e-2, wd=4e-5)
+    A = ARCHS[arch]
+    model, pruner, opt, crit = onet.make_task1_net(arch, A['dataset'], A['classes'], 'finetune', lr=1e-2, wd=4e-5)
     model.train()
     g = torch.Generator().manual_seed(1)
-    xfull = torch.randn(batch, 3, 224, 224, generator=g)
-    tfull = torch.randint(0, 5, (batch,), generator=g)
+    xfull = torch.randn(batch, 3, A['size'], A['size'], generator=g)
+    tfull = torch.randint(0, A['classes'], (batch,), generator=g)
     x, t = xfull[:probe_batch].contiguous(), tfull[:probe_batch].contiguous()
 
     def timed_steps(xb, tb, n, warm=True):
         if warm:
-            onet.train_step(model, pruner, opt, xb, tb, torch_routing=True)      # allocations, primitive cache
+            onet.train_step(model, pruner, opt, xb, tb, torch_routing=True, criterion=crit)      # allocations, primitive cache
         t0 = time.time()
         for _ in range(n):
-            onet.train_step(model, pruner, opt, xb, tb, torch_routing=True)
+            onet.train_step(model, pruner, opt, xb, tb, torch_routing=True, criterion=crit)
         return time.time() - t0
 
     settings = {}
@@ -804,11 +810,13 @@ def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch
     t0 = time.time()
     pruner.apply_mask()
     with torch.no_grad():
-        model(xv)
+        # (config 5's validate is evalLFW: apply_mask + eval-mode embeddings, utils/manager.py:156-195)
+        model.forward_to_embeddings(xv) if 'face_verification' in A['dataset'] else model(xv)
     val_s = time.time() - t0
+    n_layers = len(model.masked_layers())
     del model, pruner, opt
     plumbing = None
-    if level == 'full':
+    if level == 'full' and arch == 'vgg16':
         ips, secs, ev, nv = cpu_plumbing_cycle()
         plumbing = {'workload': 'configs[0]: custom_vgg_cifar100 (VGG16-BN 32x32, full width), batch 32, the full 220-step mini-cycle '
                                 '(20 finetune + 200 prune-run steps, %d rank-prune events, %d validates of 2 x 100 images) on the host' % (ev, nv),
@@ -824,12 +832,13 @@ def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch
             'train_images_per_sec': round(train_ips, 3), 'prune_event_s': round(prune_s, 2), 'validate_images_per_sec': round(100 / val_s, 2),
             'plumbing': plumbing,
             'sample': '3 + 3 train steps (fwd + bwd + gradient routing + SGD-nesterov) at batch %d under %d / %d threads%s + 1 rank-prune event '
-                      'over the 15 layers (%.1f s) + 1 validate batch of 100 (apply_mask + eval forward, %.1f s) of the oracle VGG16-BN 224x224, '
+                      'over the %d masked layers (%.1f s) + 1 validate batch of 100 (apply_mask + eval forward, %.1f s) of the oracle %s %dx%d, '
                       'torch-CPU fp32; value = the %d-step cycle the GPU ran (%d prune events, %d validates of 2 x 100 images) priced with the '
                       '%s train rate'
                       % (probe_batch, default_threads, all_threads,
                          (', then 1 warm-up + 3 timed train steps at batch %d under %d threads' % (batch, threads)) if full else '',
-                         prune_s, val_s, steps, prune_events, validates, 'batch-%d' % batch if full else 'probe-batch')}
+                         n_layers, prune_s, val_s, {'vgg16': 'VGG16-BN', 'resnet50': 'ResNet-50', 'spherenet20': 'SphereNet-20 (AngleLinear head + AngleLoss)'}[arch],
+                         A['size'], A['size'], steps, prune_events, validates, 'batch-%d' % batch if full else 'probe-batch')}
 
 
 # ---- 8-GPU prediction: what a SCALE run should show, so that a first hardware run can be judged in one read
@@ -1209,11 +1218,11 @@ def main():
         if a.math == 'fp32' and world == 1 and a.optin_steps > 0 and a.arch == 'vgg16' and a.task == 1 and a.batch == 256 and a.width_multiplier == 1.0:
             out['opt_in_conv_math'] = optin_modes(model, masks, pool, a.optin_steps, a.batch)
         if not a.no_cpu_baseline and world == 1:
-            if a.arch == 'vgg16' and a.task == 1 and a.width_multiplier == 1.0:
+            if a.task == 1 and a.width_multiplier == 1.0:
                 out['cpu_baseline'] = cpu_baseline(steps=a.steps, batch=a.batch, validates=counts['validates'],
-                                                   prune_events=counts['prune_events'], level=a.cpu_baseline)
+                                                   prune_events=counts['prune_events'], level=a.cpu_baseline, arch=a.arch)
             else:
-                out['cpu_baseline'] = None      # oracle/net.py restates the VGG16 cycle only (the headline); see --arch vgg16
+                out['cpu_baseline'] = None      # (the task-2 / grown lines: the task-1 width-1.0 line of the same topology carries it)
     # The ONE JSON line must be the last thing on stdout.  RCCL writes its version banner through C stdio, which is block-buffered on
     # a pipe and would otherwise come out at process exit, behind the line: every rank empties its C buffers, then a barrier, then
     # rank 0 prints.

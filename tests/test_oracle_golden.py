@@ -215,3 +215,82 @@ def test_oracle_matches_reference_manager_train_and_validate(mode):
     np.testing.assert_allclose(ev.numpy(), g['eval_logits'], rtol=1e-5, atol=1e-6)
     assert abs(float((ev.argmax(2) == tv).float().mean()) - float(g['val_acc'])) < 1e-6
     assert abs(pruner.sparsity() - float(g['sparsity'])) < 1e-12
+
+
+# --------------------------------------------------------------------------- round 5: the ResNet-50 / SphereNet-20 restatements
+def _oracle_net(arch, width, ncls, dataset='t1', he_seed=None):
+    torch.manual_seed(1)
+    m = onet.OracleResNet(width) if arch == 'resnet50' else onet.OracleSphereNet(width)
+    m.add_dataset(dataset, ncls)
+    m.set_dataset(dataset)
+    if he_seed is not None:                       # make_golden.reinit_resnet: He-normal drawn in module order
+        torch.manual_seed(he_seed)
+        for mod in m.modules():
+            if isinstance(mod, onet.MaskedConv):
+                torch.nn.init.kaiming_normal_(mod.weight, mode='fan_out', nonlinearity='relu')
+    return m
+
+
+@pytest.mark.parametrize('arch,fixture,width,he', [('resnet50', 'first_forward_resnet50', 0.25, None), ('spherenet20', 'first_forward_spherenet20', 0.25, None),
+                                                   ('resnet50', 'full_width_logits_resnet50', 1.0, 2), ('spherenet20', 'full_width_logits_spherenet20', 1.0, None)])
+def test_oracle_resnet_spherenet_init_and_forward(arch, fixture, width, he):
+    """OracleResNet / OracleSphereNet (models/resnet.py:60-222, models/spherenet.py:101-251) against the reference's own
+    seed-1 initialisation (sum / abs-sum per parameter) and eval-mode logits, narrow and at width 1.0."""
+    g = load_golden(fixture)
+    m = _oracle_net(arch, width, int(g['num_classes']), he_seed=he)
+    digest = np.array([[float(p.detach().double().sum()), float(p.detach().double().abs().sum())] for p in m.parameters()])
+    np.testing.assert_allclose(digest, g['param_digest'], rtol=1e-12, atol=0)
+    for name, mod in m.named_modules():
+        if isinstance(mod, torch.nn.BatchNorm2d) and 'bn_mean/' + name in g.files:
+            mod.running_mean.copy_(torch.from_numpy(g['bn_mean/' + name]))
+            mod.running_var.copy_(torch.from_numpy(g['bn_var/' + name]))
+    m.eval()
+    with torch.no_grad():
+        y = m(torch.from_numpy(g['x'])).numpy()
+    np.testing.assert_allclose(y, g['y'], rtol=1e-5, atol=1e-6 * max(1.0, float(np.abs(g['y']).max())))
+
+
+@pytest.mark.parametrize('arch', ['resnet50', 'spherenet20'])
+def test_oracle_train_steps_match_reference(arch):
+    """Three TRAIN-mode steps of the narrow ResNet-50 / SphereNet-20 (+ AngleLinear head, AngleLoss) through the oracle's own pieces --
+    forward, loss, backward, OraclePruner.route, SGD-nesterov, rank-prune events -- against what the reference's modules produced
+    (train_steps_*.npz): logits and losses of every step, the raw gradients of the four watched convs, the prune ratios, the owner
+    masks and the final weights.  Same torch-CPU ops in the same order: held to 1e-5."""
+    g = load_golden('train_steps_' + arch)
+    width, ncls = float(g['width']), int(g['num_classes'])
+    dataset = 'face_verification' if arch == 'spherenet20' else 't1'
+    m = _oracle_net(arch, width, ncls, dataset, he_seed=2 if arch == 'resnet50' else None)
+    digest = np.array([[float(p.detach().double().sum()), float(p.detach().double().abs().sum())] for p in m.parameters()])
+    np.testing.assert_allclose(digest, g['param_digest'], rtol=1e-12, atol=1e-12)
+    owners = {n: np.ones(tuple(l.weight.shape), np.uint8) for n, l in m.masked_layers()}
+    pruner = onet.OraclePruner(m, owners, 'prune', 1, 1, 0, 2, 1, 0.0, 0.3, float(g['wd']), width)
+    opt = torch.optim.SGD(list(m.parameters()), lr=float(g['lr']), momentum=0.9, nesterov=True, weight_decay=0.0)
+    crit = onet.OracleAngleLoss() if dataset == 'face_verification' else torch.nn.CrossEntropyLoss()
+    xs, ts = torch.from_numpy(g['x']), torch.from_numpy(g['t'])
+    watch = [str(w) for w in g['watch']]
+    mods = dict(m.named_modules())
+    m.train()
+    for s in range(xs.shape[0]):
+        opt.zero_grad()
+        out = m(xs[s])
+        loss = crit(out, ts[s])
+        loss.backward()
+        o1 = out[0] if isinstance(out, tuple) else out
+        sc = float(np.abs(g['logits'][s]).max())
+        np.testing.assert_allclose(o1.detach().numpy(), g['logits'][s], rtol=1e-5, atol=1e-5 * sc, err_msg='logits step %d' % s)
+        if isinstance(out, tuple):
+            np.testing.assert_allclose(out[1].detach().numpy(), g['logits2'][s], rtol=1e-5, atol=1e-5 * float(np.abs(g['logits2'][s]).max()))
+        assert abs(float(loss.detach()) - g['losses'][s]) <= 1e-5 * max(1.0, abs(g['losses'][s]))
+        for n in watch:
+            ref = g['grad/' + n][s]
+            np.testing.assert_allclose(mods[n].weight.grad.numpy(), ref, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()), err_msg='grad %s step %d' % (n, s))
+        pruner.route()
+        opt.step()
+        ratio = pruner.gradually_prune(s)
+        assert ratio == float(g['ratios'][s])
+    names = [n for n, _ in m.masked_layers()]
+    assert [int((pruner.owners[n] == 0).sum()) for n in names] == [int(v) for v in g['mask_zero_counts']]
+    for n in watch:
+        np.testing.assert_array_equal(pruner.owners[n], g['mask/module.' + n])
+        np.testing.assert_allclose(mods[n].weight.detach().numpy(), g['final/' + n], rtol=1e-5, atol=1e-7)
+    assert abs(pruner.sparsity() - float(g['sparsity'])) < 1e-12
