@@ -1,4 +1,4 @@
-// Masked 3x3 / stride 1 / pad 1 convolution of an image-like input (<= 3 channels) to 64 channels: the network stem
+// Masked 3x3 / stride 1 / pad 1 convolution of an image-like input (<= 3 channels) to 64 (.. 96, round 5) channels: the network stem
 // (VGG16 features.0, models/vgg.py:131-141 of the reference; SharableConv2d.forward, models/layers.py:98-109).
 //
 // The layer is HBM-bound: 27 multiplies per output against 4 bytes written -- batch 256 @ 224 x 224 writes 3.29 GB and reads 0.15 GB,
@@ -57,7 +57,12 @@ struct StemBn {                                 // the BatchNorm behind the stem
     const float *gz;                            // ST_BWD_*: gradient w.r.t. z = relu(bn(y)), laid out like y
 };
 
-template <int MODE>
+// NB / RAG (round 5): blocks of 32 output channels and whether the last one is partial.  <.., 2, false> is the 64-channel stem of the
+// reference's width-1.0 networks, unchanged; <.., 3, true> takes 65 .. 96 channels -- the GROWN VGG16's features.0 has int(64 sqrt(1.5)) = 78
+// (models/vgg.py:131-136 with CPG_cifar100_main_normal.py:115) and ran the general direct kernel + the unfused BatchNorm passes until
+// round 5.  A channel past K has zero weights (its accumulator is an exact 0) and a per-lane offset that is out of range: its stores are
+// dropped, its loads read 0 (only the per-lane part of a buffer offset is range-checked, the scalar channel offset is not).
+template <int MODE, int NB = 2, bool RAG = false>
 __global__ __launch_bounds__(256, 2)
 void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ pm, float thr,
                 const float *__restrict__ bias, float *__restrict__ y, float *__restrict__ stats, StemBn bn) {
@@ -69,10 +74,10 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
     __shared__ float smem_all[4 * ST_PATCH];
     // backward modes: the BatchNorm's per-channel constants {mean, invstd, gamma, beta, mean(gm), mean(gm xhat)} live in LDS (64 x 8
     // floats) and are read per accumulator element -- as registers (16 channels x 6 per lane) they pushed the kernel into scratch
-    __shared__ __attribute__((aligned(16))) float cst[(MODE >= ST_BWD_REDUCE) ? 64 * 8 : 4];
+    __shared__ __attribute__((aligned(16))) float cst[(MODE >= ST_BWD_REDUCE) ? NB * 32 * 8 : 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if constexpr (MODE >= ST_BWD_REDUCE) {
-        if (tid < 64) {
+        if (tid < NB * 32) {
             const bool kv = tid < g.K;
             cst[tid * 8 + 0] = kv ? bn.mean[tid] : 0.0f, cst[tid * 8 + 1] = kv ? bn.invstd[tid] : 0.0f;
             cst[tid * 8 + 2] = kv ? bn.gamma[tid] : 0.0f, cst[tid * 8 + 3] = kv ? bn.beta[tid] : 0.0f;
@@ -88,40 +93,50 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
     float *tsm = tsm_all + (WG ? wave * 32 * ST_TS : 0);
     // ST_BWD_WGRAD: tap k = li of the weight gradient's B operand: patch offset of (c, r, s) + the half-wave's pixel parity
     const int wk = li < CK ? li : 0, wboff = ((wk / 9) * ST_ROWS + (wk % 9) / 3) * ST_PW + wk % 3 + lh;
-    f32x16 accw[WG ? 2 : 1];
+    f32x16 accw[WG ? NB : 1];
     if constexpr (WG) {
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) accw[mb][e] = 0.0f;
     }
 
     // A operands: W_eff[co = 32 mb + li][k = 2 t + lh], zero beyond the layer's channels / taps
-    float A[2][ST_KS];
+    // ALDS (three blocks in the two-pass modes): 42 weight registers beside the BatchNorm constants of a pass spilled (up to 301 dwords of
+    // scratch in the fused forward); the block keeps the operands in LDS instead ([block][step][lane], 10.5 KB, written once) and a pass
+    // reads its 14 back.
+    constexpr bool ALDS = NB == 3 && TWO_PASS;
+    __shared__ float a_lds[ALDS ? NB * ST_KS * 64 : 1];
+    float A[ALDS ? 1 : NB][ST_KS];
     int boff[ST_KS];                             // B operand: float index of (channel, tap) of k = 2 t + lh in the patch, + li
 #pragma unroll
     for (int t = 0; t < ST_KS; ++t) {
         const int k = 2 * t + lh;
         const bool kv = k < CK;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        for (int mb = 0; mb < NB; ++mb) {
             const int co = mb * 32 + li;
             float v = 0.0f;
             if (kv && co < g.K) {
                 v = w[co * CK + k];
                 if (pm != nullptr) v *= binarize(pm[co * CK + k], thr);
             }
-            A[mb][t] = v;
+            if constexpr (ALDS) {
+                if (wave == 0) a_lds[(mb * ST_KS + t) * 64 + lane] = v;
+            } else {
+                A[mb][t] = v;
+            }
         }
         const int kk = kv ? k : 0;               // (padding taps: a zero weight against any finite patch element)
         const int c = kk / 9, r = (kk % 9) / 3, s = kk % 3;
         boff[t] = (c * ST_ROWS + r) * ST_PW + s + li;
     }
     constexpr bool HASB = !BN;                  // (the fused BatchNorm modes take no conv bias -- the host refuses one: 32 registers)
-    float bv[HASB ? 2 : 1][HASB ? 16 : 1];
-    if constexpr (HASB) {
+    constexpr bool BPASS = HASB && TWO_PASS && NB == 3;     // three blocks, two-pass modes: the bias of ONE block at a time (48 registers spilled)
+    float bv[HASB ? (BPASS ? 1 : NB) : 1][HASB ? 16 : 1];
+    if constexpr (HASB && !BPASS) {
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -165,6 +180,7 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
         if (lane < 2 * ST_CMAX * ST_ROWS) smem[(lane >> 1) * ST_PW + ((lane & 1) ? ST_W + 1 : 0)] = ph;
     };
 
+    if constexpr (ALDS) __syncthreads();          // (before any wave leaves)
     const unsigned nwaves = gridDim.x * 4, wid = blockIdx.x * 4 + wave;
     if (wid >= g.ntiles) return;                 // (no barriers anywhere: a wave may leave)
     const int HW4 = HW * 4;
@@ -195,29 +211,69 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
         // fused modes: the BatchNorm's constants of this pass's 16 channels per lane (channel mb 32 + (e & 3) + 8 (e >> 2) + 4 lh)
         constexpr bool REGC = MODE == ST_BN_RELU;
         float cm[REGC ? 16 : 1], cis[REGC ? 16 : 1], cga[REGC ? 16 : 1], cbe[REGC ? 16 : 1];
+        // (RAG + REGC: the BatchNorm's four per-channel arrays behind buffer descriptors of K floats: beta, mean, invstd, gamma)
+        __amdgpu_buffer_rsrc_t srd_bn[4];
+        if constexpr (RAG && REGC) {
+            srd_bn[0] = __builtin_amdgcn_make_buffer_rsrc((void *)bn.beta, 0, g.K * 4, 0x00020000);
+            srd_bn[1] = __builtin_amdgcn_make_buffer_rsrc((void *)bn.mean, 0, g.K * 4, 0x00020000);
+            srd_bn[2] = __builtin_amdgcn_make_buffer_rsrc((void *)bn.invstd, 0, g.K * 4, 0x00020000);
+            srd_bn[3] = __builtin_amdgcn_make_buffer_rsrc((void *)bn.gamma, 0, g.K * 4, 0x00020000);
+        }
         auto load_bn = [&](int mb) {
-            if constexpr (REGC) {
+            if constexpr (BPASS) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int co = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    cm[e] = bn.mean[co], cis[e] = bn.invstd[co], cga[e] = bn.gamma[co], cbe[e] = bn.beta[co];
+                    bv[0][e] = (bias != nullptr && co < g.K) ? bias[co] : 0.0f;
+                }
+            }
+            if constexpr (ALDS) {
+#pragma unroll
+                for (int t = 0; t < ST_KS; ++t) A[0][t] = a_lds[(mb * ST_KS + t) * 64 + lane];
+            }
+            if constexpr (REGC) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if constexpr (RAG) {
+                        // range-checked loads (a channel past K reads 0): one per-lane offset + a scalar offset -- a clamped index per element
+                        // made 64 address pairs and 273 dwords of scratch
+                        const int vo = (4 * lh + (e & 3) + 8 * (e >> 2)) * 4 + mb * 128;
+                        cm[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_bn[1], vo, 0, 0));
+                        cis[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_bn[2], vo, 0, 0));
+                        cga[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_bn[3], vo, 0, 0));
+                        cbe[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_bn[0], vo, 0, 0));
+                    } else {
+                        const int co = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        cm[e] = bn.mean[co], cis[e] = bn.invstd[co], cga[e] = bn.gamma[co], cbe[e] = bn.beta[co];
+                    }
                 }
             }
         };
         auto row = [&](int j, auto fullc, auto mbsel) {
             constexpr bool FULL = decltype(fullc)::value;
-            constexpr int MB0 = decltype(mbsel)::value < 0 ? 0 : decltype(mbsel)::value, MB1 = decltype(mbsel)::value < 0 ? 2 : MB0 + 1;
+            constexpr int MB0 = decltype(mbsel)::value < 0 ? 0 : decltype(mbsel)::value, MB1 = decltype(mbsel)::value < 0 ? NB : MB0 + 1;
             const bool pok = FULL || (cok && y0 + j < g.H);
             const int voff = pok ? pix0 + j * g.W * 4 : kOOR;
+            // RAG: the per-lane offset of output e of block mb -- out of range for a channel past K (see the kernel's header)
+            // (only the LAST block can be partial: K >= 64.  The channel count goes through an opaque scalar per row: as a loop invariant the
+            //  sixteen masked offsets were hoisted out of the row loop and spilled -- 273 dwords of scratch in the fused forward)
+            int klim = g.K;
+            if constexpr (RAG) asm volatile("" : "+s"(klim));
+            auto voff_of = [&](int mb, int e) -> int {
+                if constexpr (RAG) {
+                    if (mb == NB - 1) return ((NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh < klim) ? voff : kOOR;
+                }
+                return voff;
+            };
             float gzv[MODE >= ST_BWD_REDUCE ? 16 : 1];
             int copq = 0;
             if constexpr (MODE >= ST_BWD_REDUCE) asm volatile("" : "+v"(copq));      // (hoisted out of the row loop the constants are 96 registers again)
             if constexpr (MODE >= ST_BWD_REDUCE) {           // the row's 16 gradient values fly while its 14 MFMAs run (out of range: 0)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    gzv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_gz, voff, (MB0 * 32 + (e & 3) + 8 * (e >> 2)) * HW4, 0));
+                    gzv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_gz, voff_of(MB0, e), (MB0 * 32 + (e & 3) + 8 * (e >> 2)) * HW4, 0));
             }
-            f32x16 acc[2];
+            f32x16 acc[NB];
 #pragma unroll
             for (int mb = MB0; mb < MB1; ++mb)
 #pragma unroll
@@ -227,16 +283,16 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
             for (int t = 0; t < ST_KS; ++t) {
                 const float b = prow[boff[t]];
 #pragma unroll
-                for (int mb = MB0; mb < MB1; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[mb][t], b, acc[mb], 0, 0, 0);
+                for (int mb = MB0; mb < MB1; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[ALDS ? 0 : mb][t], b, acc[mb], 0, 0, 0);
             }
 #pragma unroll
             for (int mb = MB0; mb < MB1; ++mb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int cu = mb * 32 + (e & 3) + 8 * (e >> 2);       // + 4 lh: in voff
-                    const float v = HASB ? acc[mb][e] + bv[HASB ? mb : 0][HASB ? e : 0] : acc[mb][e];
+                    const float v = HASB ? acc[mb][e] + bv[(HASB && !BPASS) ? mb : 0][HASB ? e : 0] : acc[mb][e];
                     if constexpr (MODE == ST_PLAIN || MODE == ST_STATS) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), srd_y, voff, cu * HW4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), srd_y, voff_of(mb, e), cu * HW4, 0);
                     }
                     if constexpr (MODE == ST_STATS || MODE == ST_STATS_ONLY) {
                         const float vm = (FULL || pok) ? v : 0.0f;
@@ -245,7 +301,7 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
                     }
                     if constexpr (MODE == ST_BN_RELU) {                    // bn_affine of bn_kernels.hip, then the ReLU
                         const float z = fmaxf((v - cm[e]) * cis[e] * cga[e] + cbe[e], 0.0f);
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, z), srd_y, voff, cu * HW4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, z), srd_y, voff_of(mb, e), cu * HW4, 0);
                     }
                     if constexpr (MODE >= ST_BWD_REDUCE) {
                         const float *cc = cst + (cu + 4 * lh) * 8 + copq;     // (copq = 0, opaque per row: keeps the reads in the row)
@@ -259,7 +315,7 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
                             const f32x2 c2 = *reinterpret_cast<const f32x2 *>(cc + 4);           // mean(gm), mean(gm xhat)
                             float gyv = (gm - c2[0] - xh * c2[1]) * (c4[1] * c4[2]);
                             if constexpr (MODE == ST_BWD_APPLY) {
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gyv), srd_y, voff, cu * HW4, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gyv), srd_y, voff_of(mb, e), cu * HW4, 0);
                             } else {                                   // a pixel outside the image has no gradient; [channel][parity][pixel / 2]
                                 if (!FULL && !pok) gyv = 0.0f;
                                 tsm[((e & 3) + 8 * (e >> 2) + 4 * lh) * ST_TS + (li & 1) * 16 + (li >> 1)] = gyv;
@@ -295,6 +351,7 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int co = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (RAG && co >= g.K) continue;
                     f32x2 o;
                     o[0] = s1[e], o[1] = s2[e];
                     *reinterpret_cast<f32x2 *>(stats + ((int64_t)co * g.ntiles + tile) * 2) = o;
@@ -310,6 +367,12 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
             zero_sums();
             rows(std::integral_constant<int, 1>{});
             if (STATS) stats_out(1);
+            if constexpr (NB == 3) {
+                load_bn(2);
+                zero_sums();
+                rows(std::integral_constant<int, 2>{});
+                if (STATS) stats_out(2);
+            }
         } else {
             rows(std::integral_constant<int, -1>{});
         }
@@ -317,7 +380,7 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
     if constexpr (WG) {                          // this wave's partial sums: y[wid][co][k], D row = channel, D column (lane) = tap
         float *dstw = y + (int64_t)wid * g.K * CK;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -326,9 +389,16 @@ void k_stem_fwd(StemGeom g, const float *__restrict__ x, const float *__restrict
     }
 }
 
+// (the 64-channel instance, or the three-block instance with the partial-block masks)
+#define STEM_LAUNCH(MODE, grid, block, shm, stream, ...)                                                          \
+    do {                                                                                                          \
+        if (g.K == 64) hipLaunchKernelGGL((k_stem_fwd<MODE, 2, false>), grid, block, shm, stream, __VA_ARGS__);   \
+        else hipLaunchKernelGGL((k_stem_fwd<MODE, 3, true>), grid, block, shm, stream, __VA_ARGS__);              \
+    } while (0)
+
 bool stem_geom(int N, int C, int K, int H, int W, StemGeom &g) {
     if (opt_on(OPT_NO_STEM)) return false;                       // (A/B experiments, tests)
-    if (N < 1 || C < 1 || C > ST_CMAX || K != 64 || H < 1 || W < 1) return false;
+    if (N < 1 || C < 1 || C > ST_CMAX || K < 64 || K > 96 || H < 1 || W < 1) return false;      // (64: <.., 2, false>; 65 .. 96: <.., 3, true>)
     if ((int64_t)N * C * H * W * 4 >= (1ll << 31) || (int64_t)K * H * W * 4 >= (1ll << 31)) return false;   // (32-bit byte offsets into x and into one image of y)
     g.N = N, g.C = C, g.K = K, g.H = H, g.W = W;
     g.tiles_x = (W + ST_W - 1) / ST_W, g.tiles_y = (H + ST_R - 1) / ST_R;
@@ -362,9 +432,9 @@ extern "C" int cpg_conv3x3_stem_run(int N, int C, int K, int H, int W, const flo
     unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)g.ntiles + 3) / 4, 4 * kCUs);
     blocks = (unsigned)std::max(1, opt_or(OPT_STEM_BLOCKS, (int)blocks));
     if (stats != nullptr)
-        hipLaunchKernelGGL(k_stem_fwd<ST_STATS>, dim3(blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y, stats, StemBn{});
+        STEM_LAUNCH(ST_STATS, dim3(blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y, stats, StemBn{});
     else
-        hipLaunchKernelGGL(k_stem_fwd<ST_PLAIN>, dim3(blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y, nullptr, StemBn{});
+        STEM_LAUNCH(ST_PLAIN, dim3(blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, y, nullptr, StemBn{});
     CPG_CHECK_LAUNCH("cpg_conv2d_fwd(stem)");
     return CPG_OK;
 }
@@ -401,7 +471,7 @@ extern "C" int cpg_stem_bn_stats(const cpg_conv_desc *d, const float *x, const f
     if (!stem_bn_geom(d, g)) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_stats: shape not supported");
     if (bias != nullptr) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_stats: the fused stem takes no conv bias");
     if (stats_bytes < (size_t)g.K * g.ntiles * 2 * sizeof(float)) return fail(CPG_E_WORKSPACE, "cpg_stem_bn_stats: statistics buffer too small");
-    hipLaunchKernelGGL(k_stem_fwd<ST_STATS_ONLY>, dim3(stem_blocks(g)), dim3(256), 0, (hipStream_t)stream_v, g, x, w, pm, thr, bias,
+    STEM_LAUNCH(ST_STATS_ONLY, dim3(stem_blocks(g)), dim3(256), 0, (hipStream_t)stream_v, g, x, w, pm, thr, bias,
                        (float *)nullptr, stats, StemBn{});
     CPG_CHECK_LAUNCH("cpg_stem_bn_stats");
     return CPG_OK;
@@ -413,7 +483,7 @@ extern "C" int cpg_stem_bn_relu_fwd(const cpg_conv_desc *d, const float *x, cons
     CPG_REQUIRE(d && x && w && gamma && beta && mean && invstd && z, "cpg_stem_bn_relu_fwd: null pointer");
     if (!stem_bn_geom(d, g)) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_relu_fwd: shape not supported");
     if (bias != nullptr) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_relu_fwd: the fused stem takes no conv bias");
-    hipLaunchKernelGGL(k_stem_fwd<ST_BN_RELU>, dim3(stem_blocks(g)), dim3(256), 0, (hipStream_t)stream_v, g, x, w, pm, thr, bias, z,
+    STEM_LAUNCH(ST_BN_RELU, dim3(stem_blocks(g)), dim3(256), 0, (hipStream_t)stream_v, g, x, w, pm, thr, bias, z,
                        (float *)nullptr, StemBn{gamma, beta, mean, invstd, nullptr, nullptr});
     CPG_CHECK_LAUNCH("cpg_stem_bn_relu_fwd");
     return CPG_OK;
@@ -427,7 +497,7 @@ extern "C" int cpg_stem_bn_relu_bwd_reduce(const cpg_conv_desc *d, const float *
     if (!stem_bn_geom(d, g)) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_relu_bwd_reduce: shape not supported");
     if (bias != nullptr) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_relu_bwd_reduce: the fused stem takes no conv bias");
     if (partials_bytes < (size_t)g.K * g.ntiles * 2 * sizeof(float)) return fail(CPG_E_WORKSPACE, "cpg_stem_bn_relu_bwd_reduce: partial-sum buffer too small");
-    hipLaunchKernelGGL(k_stem_fwd<ST_BWD_REDUCE>, dim3(stem_blocks(g)), dim3(256), 0, (hipStream_t)stream_v, g, x, w, pm, thr, bias,
+    STEM_LAUNCH(ST_BWD_REDUCE, dim3(stem_blocks(g)), dim3(256), 0, (hipStream_t)stream_v, g, x, w, pm, thr, bias,
                        (float *)nullptr, partials, StemBn{gamma, beta, mean, invstd, nullptr, gz});
     CPG_CHECK_LAUNCH("cpg_stem_bn_relu_bwd_reduce");
     return CPG_OK;
@@ -440,7 +510,7 @@ extern "C" int cpg_stem_bn_relu_bwd_apply(const cpg_conv_desc *d, const float *x
     CPG_REQUIRE(d && x && w && gamma && beta && mean && invstd && coef && gz && gy, "cpg_stem_bn_relu_bwd_apply: null pointer");
     if (!stem_bn_geom(d, g)) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_relu_bwd_apply: shape not supported");
     if (bias != nullptr) return fail(CPG_E_UNSUPPORTED, "cpg_stem_bn_relu_bwd_apply: the fused stem takes no conv bias");
-    hipLaunchKernelGGL(k_stem_fwd<ST_BWD_APPLY>, dim3(stem_blocks(g)), dim3(256), 0, (hipStream_t)stream_v, g, x, w, pm, thr, bias, gy,
+    STEM_LAUNCH(ST_BWD_APPLY, dim3(stem_blocks(g)), dim3(256), 0, (hipStream_t)stream_v, g, x, w, pm, thr, bias, gy,
                        (float *)nullptr, StemBn{gamma, beta, mean, invstd, coef, gz});
     CPG_CHECK_LAUNCH("cpg_stem_bn_relu_bwd_apply");
     return CPG_OK;
@@ -465,7 +535,7 @@ extern "C" int cpg_stem_bn_relu_bwd_wgrad(const cpg_conv_desc *d, const float *x
     const unsigned blocks = stem_blocks(g);
     if (ws_bytes < (size_t)blocks * 4 * g.K * g.C * 9 * sizeof(float)) return fail(CPG_E_WORKSPACE, "cpg_stem_bn_relu_bwd_wgrad: workspace too small");
     hipStream_t stream = (hipStream_t)stream_v;
-    hipLaunchKernelGGL(k_stem_fwd<ST_BWD_WGRAD>, dim3(blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, (float *)ws, (float *)nullptr,
+    STEM_LAUNCH(ST_BWD_WGRAD, dim3(blocks), dim3(256), 0, stream, g, x, w, pm, thr, bias, (float *)ws, (float *)nullptr,
                        StemBn{gamma, beta, mean, invstd, coef, gz});
     const int nsplit = (int)std::min<int64_t>((int64_t)g.ntiles, (int64_t)blocks * 4);        // waves that had at least one tile
     Epilogue ep{gw, nullptr, BIAS_NONE, 1, 1, pm, w, gpm, thr};

@@ -1907,29 +1907,51 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
 // y = bias + sum over the pieces of k_wg3<.., SPLIT>'s partial outputs, for the logical blocks lb_first .. lb_end - 1 of the layer (each: 64 output
 // channels x 32 tiles x 2 x 2 pixels).  The pieces are added in index order: the result does not depend on which piece finished first.
 // `part` is piece 0's slice, addressed like y (image n at (n * M + m) * H W); piece s lies s * stride floats further.
+template <bool STATS>
 __global__ __launch_bounds__(256) void k_wg_tail_reduce(WgGeom g, const float *__restrict__ part, const float *__restrict__ bias,
-                                                        float *__restrict__ y, unsigned lb_first, unsigned lb_end) {
+                                                        float *__restrict__ y, unsigned lb_first, unsigned lb_end, float *__restrict__ stats) {
+    // one half-wave = the 32 tiles of one (unit, channel): total is a multiple of 32, so a half-wave is never split by the loop bound
     const int64_t total = (int64_t)(lb_end - lb_first) * 64 * W1_T;
     const int nkb64 = (g.nkb + 1) / 2, HW = g.H * g.W;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int t = (int)(i & (W1_T - 1)), kl = (int)((i >> 5) & 63);
         const unsigned lb = lb_first + (unsigned)(i >> 11);
         const int m = (int)(lb % (unsigned)nkb64) * 64 + kl;
-        const int64_t tile = (int64_t)(lb / (unsigned)nkb64) * W1_T + t;
-        if (m >= g.M || tile >= g.tiles_total) continue;
-        const int n = (int)(tile / g.tiles_img), r = (int)(tile % g.tiles_img);
-        const int ty = r / g.tw, tx = r % g.tw;
-        const int64_t off = ((int64_t)n * g.M + m) * HW + (int64_t)(2 * ty) * g.W + 2 * tx;
-        const float b = bias != nullptr ? bias[m] : 0.0f;
+        const unsigned run = lb / (unsigned)nkb64;
+        const int64_t tile = (int64_t)run * W1_T + t;
+        const bool ok = m < g.M && tile < g.tiles_total;
         f32x2 a0, a1;
-        a0[0] = a0[1] = a1[0] = a1[1] = b;
-        for (int sidx = 0; sidx < g.split_s; ++sidx) {
-            const float *p = part + (int64_t)sidx * g.split_stride + off;
-            const f32x2 v0 = *reinterpret_cast<const f32x2 *>(p), v1 = *reinterpret_cast<const f32x2 *>(p + g.W);
-            a0[0] += v0[0], a0[1] += v0[1], a1[0] += v1[0], a1[1] += v1[1];
+        a0[0] = a0[1] = a1[0] = a1[1] = 0.0f;
+        int64_t off = 0;
+        if (ok) {
+            const int n = (int)(tile / g.tiles_img), r = (int)(tile % g.tiles_img);
+            const int ty = r / g.tw, tx = r % g.tw;
+            off = ((int64_t)n * g.M + m) * HW + (int64_t)(2 * ty) * g.W + 2 * tx;
+            const float b = bias != nullptr ? bias[m] : 0.0f;
+            a0[0] = a0[1] = a1[0] = a1[1] = b;
+            for (int sidx = 0; sidx < g.split_s; ++sidx) {
+                const float *p = part + (int64_t)sidx * g.split_stride + off;
+                const f32x2 v0 = *reinterpret_cast<const f32x2 *>(p), v1 = *reinterpret_cast<const f32x2 *>(p + g.W);
+                a0[0] += v0[0], a0[1] += v0[1], a1[0] += v1[0], a1[1] += v1[1];
+            }
+            *reinterpret_cast<f32x2 *>(y + off) = a0;
+            *reinterpret_cast<f32x2 *>(y + off + g.W) = a1;
         }
-        *reinterpret_cast<f32x2 *>(y + off) = a0;
-        *reinterpret_cast<f32x2 *>(y + off + g.W) = a1;
+        if constexpr (STATS) {
+            // the BatchNorm partial sums of the unit, in k_wg3's layout: statistics tile 2 run + ph holds output row ph of the unit's 32 tiles
+            // (a wave of the main kernel is its own tile).  Sum over the half-wave's 32 lanes (xor shuffles below 32 stay inside it); a
+            // lane without a tile / channel contributes zeros.
+            float s[4] = {a0[0] + a0[1], a0[0] * a0[0] + a0[1] * a0[1], a1[0] + a1[1], a1[0] * a1[0] + a1[1] * a1[1]};
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s[q] += __shfl_xor(s[q], d, 64);
+            if (t == 0 && m < g.M) {
+                const unsigned ntile = 2 * (unsigned)((g.tiles_total + W1_T - 1) / W1_T);
+                float *dst = stats + ((int64_t)m * ntile + 2 * run) * 2;
+                dst[0] = s[0], dst[1] = s[1], dst[2] = s[2], dst[3] = s[3];
+            }
+        }
     }
 }
 
@@ -2151,7 +2173,7 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
             const bool sh = bne == nullptr && wino_sh(g);
             WgTail tail{};
             const size_t tail_off = (need + 255) / 256 * 256;
-            if (bne == nullptr && stats == nullptr) tail = wino_tail_plan(g, g.nblocks, sh);
+            if (bne == nullptr) tail = wino_tail_plan(g, g.nblocks, sh);      // (with the BatchNorm statistics too: k_wg_tail_reduce<true> sums them)
             if (tail.on && ws_bytes < tail_off + tail.bytes) tail.on = false;       // (a caller with the round-4 workspace: one launch, as before)
             WgGeom gt = g;
             float *part0 = nullptr;
@@ -2163,8 +2185,11 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
                 part0 = reinterpret_cast<float *>(reinterpret_cast<uintptr_t>(ws) + tail_off) - (int64_t)tail.n_first * g.M * H * W;
             }
             auto finish_tail = [&]() {
-                hipLaunchKernelGGL(k_wg_tail_reduce, dim3(stream_grid((int64_t)(tail.end_lb - tail.first_lb) * 64 * W1_T, 256)), dim3(256), 0, stream,
-                                   gt, part0, bias, y, tail.first_lb, tail.end_lb);
+                const dim3 rg(stream_grid((int64_t)(tail.end_lb - tail.first_lb) * 64 * W1_T, 256));
+                if (stats != nullptr)
+                    hipLaunchKernelGGL(k_wg_tail_reduce<true>, rg, dim3(256), 0, stream, gt, part0, bias, y, tail.first_lb, tail.end_lb, stats);
+                else
+                    hipLaunchKernelGGL(k_wg_tail_reduce<false>, rg, dim3(256), 0, stream, gt, part0, bias, y, tail.first_lb, tail.end_lb, (float *)nullptr);
             };
             // two units per block sharing the input transform (k_wg3<..., SH>): training launches whose 64-channel blocks pair up
             if (sh) {

@@ -63,6 +63,11 @@ class Manager(object):
             model.set_gradient_filter(self.pruner)
         self.train_loader = train_loader
         self.val_loader = val_loader
+        if getattr(args, 'freeze_gc', False):
+            # OPT-IN (args.freeze_gc; no counterpart in the reference): the model, its masks and the pruner exist now -- one full collection,
+            # then gc.freeze(): removes the 80 ms generation-2 collector pauses from the step loop (cpg_amd.utils.settle_host_gc: process-wide)
+            from . import settle_host_gc
+            settle_host_gc()
         self.progress = bool(getattr(args, 'progress', True)) and tqdm is not None
         self.last_stats = {}
         self.postfix_interval = float(getattr(args, 'postfix_interval', 0.5))
