@@ -830,11 +830,15 @@ bool cpg_pw_gemm_nt_ok(const float *A, const float *B, int M, int C, int64_t K);
 size_t cpg_pw_gemm_nt_workspace(int M, int C, int64_t K);
 int cpg_pw_gemm_nt(const float *A, const float *B, int M, int C, int64_t K, const Epilogue &ep, void *ws, size_t ws_bytes,
                    hipStream_t stream, const char *what);
+int cpg_pw_gemm_nt_maskb(const float *A, const float *B, const float *pmB, float thr, int M, int C, int64_t K, const Epilogue &ep, void *ws,
+                         size_t ws_bytes, hipStream_t stream, const char *what);
 bool cpg_pw_gemm_nn_ok(const float *X, int M, int Mp, int Kd, int64_t G);
 int cpg_pw_gemm_nn(const float *wp, int Mp, const float *X, int M, int Kd, int64_t G, const float *bias, float *y, hipStream_t stream,
                    const char *what);
 int cpg_pw_gemm_nn_masked(const float *wp, int Mp, const float *X, int M, int Kd, int64_t G, const float *pm, const float *w, float thr,
                           float *gw, float *gpm, hipStream_t stream, const char *what);
+int cpg_pw_gemm_nn_maskx(const float *wp, int Mp, const float *X, const float *pmX, float thr, int M, int Kd, int64_t G, float *y,
+                         hipStream_t stream, const char *what);
 void cpg_pw_pack_transpose(const float *a, int R, int Cc, float *wp, hipStream_t stream);
 size_t cpg_pw_pack_transpose_bytes(int R, int Cc);
 namespace {
@@ -889,6 +893,8 @@ extern "C" int cpg_linear_fwd(const float *x, const float *w, const float *pm, f
     Epilogue ep{y, bias, bias ? BIAS_INNER : BIAS_NONE, out_f, 1, nullptr, nullptr, nullptr, thr};
     if (pm == nullptr && cpg_pw_gemm_nt_ok(x, w, batch, out_f, in_f))          // y[b][o] = x[b][:] . W[o][:]
         return cpg_pw_gemm_nt(x, w, batch, out_f, in_f, ep, ws, ws_bytes, (hipStream_t)stream, "cpg_linear_fwd");
+    if (pm != nullptr && (((uintptr_t)pm) & 15) == 0 && cpg_pw_gemm_nt_ok(x, w, batch, out_f, in_f))      // (round 5) ... x[b][:] . (W * bin(pm))[o][:]
+        return cpg_pw_gemm_nt_maskb(x, w, pm, thr, batch, out_f, in_f, ep, ws, ws_bytes, (hipStream_t)stream, "cpg_linear_fwd");
     return launch_gemm<true, true, 2>(x, in_f, w, in_f, pm, thr, batch, out_f, in_f, ep, ws, ws_bytes, (hipStream_t)stream,
                                       "cpg_linear_fwd");
 }
@@ -898,10 +904,13 @@ extern "C" int cpg_linear_dgrad(const float *gy, const float *w, const float *pm
     CPG_REQUIRE(gy && w && gx && batch > 0 && in_f > 0 && out_f > 0, "cpg_linear_dgrad: bad argument");
     Epilogue ep{gx, nullptr, BIAS_NONE, 1, 1, nullptr, nullptr, nullptr, thr};
     const int Mp_b = (batch + 127) / 128 * 128;
-    if (pm == nullptr && ws != nullptr && ws_bytes >= cpg_pw_pack_transpose_bytes(batch, out_f) && (((uintptr_t)ws) & 15) == 0 &&
-        cpg_pw_gemm_nn_ok(w, batch, Mp_b, out_f, in_f)) {
-        // gx[b][i] = sum_o gy[b][o] W[o][i]: gy^T packed K-major (4 MB) is the "weight", W[o][:] the K-major operand
+    if (ws != nullptr && ws_bytes >= cpg_pw_pack_transpose_bytes(batch, out_f) && (((uintptr_t)ws) & 15) == 0 &&
+        cpg_pw_gemm_nn_ok(w, batch, Mp_b, out_f, in_f) && (pm == nullptr || (in_f % 4 == 0 && (((uintptr_t)pm) & 15) == 0))) {
+        // gx[b][i] = sum_o gy[b][o] W[o][i]: gy^T packed K-major (4 MB) is the "weight", W[o][:] the K-major operand -- with a piggymask
+        // (round 5) the operand is W * bin(pm), formed in the kernel's staging (k_pw<.., MASKX>): W and pm are read once
         cpg_pw_pack_transpose(gy, batch, out_f, (float *)ws, (hipStream_t)stream);
+        if (pm != nullptr)
+            return cpg_pw_gemm_nn_maskx((const float *)ws, Mp_b, w, pm, thr, batch, out_f, in_f, gx, (hipStream_t)stream, "cpg_linear_dgrad");
         return cpg_pw_gemm_nn((const float *)ws, Mp_b, w, batch, out_f, in_f, nullptr, gx, (hipStream_t)stream, "cpg_linear_dgrad");
     }
     return launch_gemm<true, false, 2>(gy, out_f, w, in_f, pm, thr, batch, in_f, out_f, ep, ws, ws_bytes, (hipStream_t)stream,

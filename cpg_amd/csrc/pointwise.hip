@@ -125,7 +125,10 @@ struct PwMask {
     float *gpm;
     float thr;
 };
-template <class Cfg, bool DGRAD, bool STATS = false, bool ADD = false, bool MASK = false>
+// MASKX (round 5; plain-GEMM form: the INPUT gradient of a masked linear layer with a piggymask, gx = gy . (W * bin(pm))): the K-major operand
+// X is the weight itself; its piggymask (mk.pm, laid out like X) is fetched beside it and the binarised product goes to LDS -- W and pm are
+// read once, nothing is materialised.
+template <class Cfg, bool DGRAD, bool STATS = false, bool ADD = false, bool MASK = false, bool MASKX = false>
 __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__restrict__ x, const float *__restrict__ wp,
                                                        const float *__restrict__ bias, float *__restrict__ y,
                                                        float *__restrict__ stats = nullptr, const float *__restrict__ addend = nullptr,
@@ -133,6 +136,7 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
     static_assert(!ADD || (DGRAD && !STATS), "the addend rides in plain input-gradient launches");
     static_assert(!STATS || !DGRAD, "statistics ride in forward launches");
     static_assert(!MASK || (!DGRAD && !STATS && !ADD), "the piggymask epilogue rides in plain forward-form launches");
+    static_assert(!MASKX || (Cfg::VEC && !DGRAD && !STATS && !ADD && !MASK), "the masked operand: float4 staging, plain forward-form launches");
     __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -187,8 +191,11 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
 
     // packed weights: (C rounded up to 16, + 16 slack rows) x Mp floats (pack_bytes)
     const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, (int)std::min<long long>(((long long)g.C + 32) * g.Mp * 4, 0x7FFFFFFFll), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_pm = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(MASKX ? mk.pm + (long long)n_first * g.C * g.in_plane : x), 0, MASKX ? (int)std::min<long long>(remaining, 0x7FFFFFFFll) : 0, 0x00020000);
     f32x4 rw[Cfg::NW4];
     f32x4 rxv[Cfg::VEC ? Cfg::NX : 1];
+    f32x4 rpm[MASKX ? Cfg::NX : 1];
     float rxs[Cfg::VEC ? 1 : Cfg::NX];
     auto load_item = [&](int k, int c0) {
         // (the chunk's share of every address is uniform: it rides in the loads' scalar offset, no vector add per load)
@@ -196,6 +203,8 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
             rw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_w, (int)wbyte, (c0 + Cfg::WROWS * k) * g.Mp * 4, 0));
         } else if (Cfg::VEC) {
             rxv[k - Cfg::NW4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, xbyte[k - Cfg::NW4], c0 * g.in_plane * 4, 0));
+            if constexpr (MASKX)
+                rpm[k - Cfg::NW4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_pm, xbyte[k - Cfg::NW4], c0 * g.in_plane * 4, 0));
         } else {
             rxs[k - Cfg::NW4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_x, xbyte[k - Cfg::NW4], c0 * g.in_plane * 4, 0));
         }
@@ -203,8 +212,14 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
     auto store_item = [&](int k, float *stage) {
         if (k < Cfg::NW4)
             *reinterpret_cast<f32x4 *>(stage + wdst + Cfg::WROWS * k * Cfg::LDW) = rw[k];
-        else if (Cfg::VEC)
-            *reinterpret_cast<f32x4 *>(stage + Cfg::W_ELEMS + xdst[k - Cfg::NW4]) = rxv[k - Cfg::NW4];
+        else if (Cfg::VEC) {
+            f32x4 v = rxv[k - Cfg::NW4];
+            if constexpr (MASKX) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] *= binarize(rpm[k - Cfg::NW4][q], mk.thr);
+            }
+            *reinterpret_cast<f32x4 *>(stage + Cfg::W_ELEMS + xdst[k - Cfg::NW4]) = v;
+        }
         else
             stage[Cfg::W_ELEMS + xdst[k - Cfg::NW4]] = rxs[k - Cfg::NW4];
     };
@@ -450,10 +465,14 @@ struct PwWCfg {
 struct PwWX {
     int plane, OW, sy, sx;
 };
-template <class Cfg, bool SCALAR = false>
+// MASKB (round 5; the plain-GEMM form = the FORWARD of a masked linear layer with a piggymask, y = x . (W * bin(pm))^T): the operand read as
+// "x" is the weight; its piggymask (pmb, laid out like it) is fetched beside it and the binarised product goes to LDS.
+template <class Cfg, bool SCALAR = false, bool MASKB = false>
 __global__ __launch_bounds__(256, 2) void k_pw_wgrad(int M, int C, int HWo, long long G, int tiles_co, int tiles_ci,
                                                      int units_per_split, const float *__restrict__ x,
-                                                     const float *__restrict__ gy, float *__restrict__ part, PwWX xg = PwWX{0, 0, 0, 0}) {
+                                                     const float *__restrict__ gy, float *__restrict__ part, PwWX xg = PwWX{0, 0, 0, 0},
+                                                     const float *__restrict__ pmb = nullptr, float thr = 0.0f) {
+    static_assert(!MASKB || !SCALAR, "the masked operand: float4 staging");
     __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -482,6 +501,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(int M, int C, int HWo, long
     constexpr int kOutOfRange = (int)0x80000000;
     const __amdgpu_buffer_rsrc_t srd_g = __builtin_amdgcn_make_buffer_rsrc((void *)gy, 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_pb = __builtin_amdgcn_make_buffer_rsrc((void *)(MASKB ? pmb : x), 0, MASKB ? 0x7FFFFFFF : 0, 0x00020000);
     int a_chan[Cfg::NA], b_chan[Cfg::NB];               // byte offset of the channel plane
 #pragma unroll
     for (int i = 0; i < Cfg::NA; ++i) a_chan[i] = min(co0 + chl + 32 * i, M - 1) * HWo * 4;
@@ -530,6 +550,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(int M, int C, int HWo, long
         }
     };
     f32x4 st[Cfg::NITEMS];
+    f32x4 stm[MASKB ? Cfg::NB : 1];            // (MASKB) the piggymask of the staged weight rows
     auto load_item = [&](int k) {
         if (SCALAR) {
 #pragma unroll
@@ -540,14 +561,24 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(int M, int C, int HWo, long
         }
         if (k < Cfg::NA)
             st[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_g, pos_g + a_chan[k], 0, 0));
-        else
+        else {
             st[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, pos_x + b_chan[k - Cfg::NA], 0, 0));
+            if constexpr (MASKB)
+                stm[k - Cfg::NA] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_pb, pos_x + b_chan[k - Cfg::NA], 0, 0));
+        }
     };
     auto store_item = [&](int k, float *stage) {
         float *p = stage + (k < Cfg::NA ? 32 * k * Cfg::LD : Cfg::A_ELEMS + 32 * (k - Cfg::NA) * Cfg::LD) + dst;
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        *reinterpret_cast<f32x2 *>(p) = f32x2{st[k][0], st[k][1]};
-        *reinterpret_cast<f32x2 *>(p + 2) = f32x2{st[k][2], st[k][3]};
+        f32x4 v = st[k];
+        if constexpr (MASKB) {
+            if (k >= Cfg::NA) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] *= binarize(stm[k - Cfg::NA][q], thr);
+            }
+        }
+        *reinterpret_cast<f32x2 *>(p) = f32x2{v[0], v[1]};
+        *reinterpret_cast<f32x2 *>(p + 2) = f32x2{v[2], v[3]};
     };
     const int a_base = (wco * (Cfg::BCO / 2) + li) * Cfg::LD + lh;
     const int b_base = Cfg::A_ELEMS + (wci * (Cfg::BCI / 2) + li) * Cfg::LD + lh;
@@ -877,6 +908,17 @@ int cpg_pw_gemm_nt(const float *A, const float *B, int M, int C, int64_t K, cons
     CPG_CHECK_LAUNCH(what);
     return CPG_OK;
 }
+// the same product with B masked in staging: D[M][C] = A[M][K] . (B * bin(pmB))[C][K]^T
+int cpg_pw_gemm_nt_maskb(const float *A, const float *B, const float *pmB, float thr, int M, int C, int64_t K, const Epilogue &ep, void *ws,
+                         size_t ws_bytes, hipStream_t stream, const char *what) {
+    const NtPlan p = nt_plan<PwW128>(M, C, K);
+    if (ws == nullptr || ws_bytes < p.ws_bytes) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, p.ws_bytes);
+    hipLaunchKernelGGL((k_pw_wgrad<PwW128, false, true>), dim3((unsigned)(p.tiles_co * p.tiles_ci * p.nsplit)), dim3(256), 0, stream, M, C, (int)K,
+                       (long long)K, p.tiles_co, p.tiles_ci, p.units_per_split, B, A, (float *)ws, PwWX{0, 0, 0, 0}, pmB, thr);
+    launch_split_reduce((const float *)ws, p.nsplit, (int64_t)M * C, 0, ep, stream);
+    CPG_CHECK_LAUNCH(what);
+    return CPG_OK;
+}
 
 bool cpg_pw_gemm_nn_ok(const float *X, int M, int Mp, int Kd, int64_t G) {
     // no split-K here: the output tiles alone must fill the chip (4096 -> 4096 dgrad at batch 256 has 38 of them: 4x slower)
@@ -892,6 +934,23 @@ int cpg_pw_gemm_nn(const float *wp, int Mp, const float *X, int M, int Kd, int64
     if (G % 4 == 0 && pw_wide()) return launch<PwV2, false>(g, X, wp, bias, y, stream, what);
     if (G % 4 == 0) return launch<PwV, false>(g, X, wp, bias, y, stream, what);
     return launch<PwS, false>(g, X, wp, bias, y, stream, what);
+}
+// the same GEMM with the K-major operand masked in staging: y[M][G] = Wp^T . (X * bin(pmX)), pmX laid out like X (two resident blocks
+// per CU: the piggymask's staging registers)
+using PwVM = PwCfg<128, 4, 1, 7, PW_CK, true, 2>;
+int cpg_pw_gemm_nn_maskx(const float *wp, int Mp, const float *X, const float *pmX, float thr, int M, int Kd, int64_t G, float *y,
+                         hipStream_t stream, const char *what) {
+    PwGeom g{1, Kd, M, Mp, (int)G, (int)G, (int)G, 0, 1, (int)G, 0, 1, 0, (long long)G};
+    const PwMask mk{pmX, nullptr, nullptr, thr};
+    g.tiles_m = (g.M + PwVM::BM - 1) / PwVM::BM;
+    pw_finish_geom(g);
+    if (g.G >= (1ll << 31) - 512) return fail(CPG_E_UNSUPPORTED, "%s: grid too large for 32-bit tile arithmetic", what);
+    const int64_t blocks = (g.G + PwVM::BN - 1) / PwVM::BN * g.tiles_m;
+    if (blocks > 0x7FFFFFFFll) return fail(CPG_E_UNSUPPORTED, "%s: grid too large", what);
+    hipLaunchKernelGGL((k_pw<PwVM, false, false, false, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g, X, wp, (const float *)nullptr, y,
+                       (float *)nullptr, (const float *)nullptr, mk);
+    CPG_CHECK_LAUNCH(what);
+    return CPG_OK;
 }
 // the same GEMM with the autograd epilogue of bin(pm) * W: gw[M][G] = D * bin(pm), gpm[M][G] = D * w (pm, w, gpm laid out like gw)
 int cpg_pw_gemm_nn_masked(const float *wp, int Mp, const float *X, int M, int Kd, int64_t G, const float *pm, const float *w, float thr,

@@ -16,9 +16,11 @@ def short(name):
 
 
 # the families bench.py reports (its HIP-event clock brackets the whole library call: + k_c3_pack for fwd / dgrad,
-# + k_c3_wgrad_reduce for wgrad); k_pw / k_pw_wgrad serve the 1x1 convs AND the un-masked linear layers
-FAMS = [('conv_fwd', r'k_c3_fwd<.*>, false(, (true|false))*>|k_conv_fwd|k_wg_fwd<\d, false|k_wg[13]<false|k_stem_fwd|k_stem2_fwd|k_pw<.*>, false'),
-        ('conv_dgrad', r'k_c3_fwd<.*>, true(, (true|false))*>|k_conv_dgrad|k_wg_fwd<\d, true|k_wg[13]<true|k_c3s2_dgrad|k_pw<.*>, true'),
+# + k_c3_wgrad_reduce for wgrad); k_pw / k_pw_wgrad serve the 1x1 convs AND the un-masked linear layers.
+# (round 5) k_wg3<.., SPLIT = true> -- the tail pieces of a launch -- and k_wg_tail_reduce are helpers of the launch whose main kernel is
+# k_wg3<.., false>: they are not counted as launches
+FAMS = [('conv_fwd', r'k_c3_fwd<.*>, false(, (true|false))*>|k_conv_fwd|k_wg_fwd<\d, false|k_wg1<false|k_wg3<false(?:, \w+){4}, false>|k_stem_fwd|k_stem2_fwd|k_pw<.*>, false'),
+        ('conv_dgrad', r'k_c3_fwd<.*>, true(, (true|false))*>|k_conv_dgrad|k_wg_fwd<\d, true|k_wg1<true|k_wg3<true(?:, \w+){4}, false>|k_c3s2_dgrad|k_pw<.*>, true'),
         ('conv_wgrad', r'k_c3_wgrad<|k_c3_wgrad_smallc|k_conv_wgrad|k_wgw|k_stem2_wgrad|k_pw_wgrad'),
         ('fused BatchNorm / ReLU / pool / PReLU', r'k_bn|k_prelu'),
         ('stock torch elementwise / pooling', r'at::native')]
