@@ -175,6 +175,11 @@ class KernelClock:
         # (same contraction; its epilogue also does the BatchNorm-backward reduction of the layer below)
         p.cpg_conv2d_dgrad_bnbwd = timed('cpg_conv2d_dgrad_bnbwd', conv_kind('conv_dgrad'), conv_flops)
         p.cpg_conv2d_dgrad = timed('cpg_conv2d_dgrad', conv_kind('conv_dgrad'), conv_flops, wino_dgrad)
+        # ... and with the other consumer's gradient added in the epilogue (ResNet's bottlenecks, SphereNet's residual units): the same
+        # contraction + one more tensor of the input's size read.  (Until round 5 these launches were neither clocked nor counted: ResNet-50's
+        # input-gradient family and whole_step left out 13 launches per step.)
+        p.cpg_conv2d_dgrad_add = timed('cpg_conv2d_dgrad_add', conv_kind('conv_dgrad'), conv_flops, wino_dgrad,
+                                       lambda a: conv_bytes(a) + 4.0 * a[0]._obj.N * a[0]._obj.C * a[0]._obj.H * a[0]._obj.W)
         p.cpg_conv2d_wgrad = timed('cpg_conv2d_wgrad', conv_kind('conv_wgrad'), conv_flops, wino_wgrad)
         p.cpg_linear_fwd = timed('cpg_linear_fwd', lambda a: 'linear_fwd', lin_flops(6), None, lin_bytes(6))
         p.cpg_linear_dgrad = timed('cpg_linear_dgrad', lambda a: 'linear_dgrad', lin_flops(5), None, lin_bytes(5))

@@ -1347,12 +1347,17 @@ struct Bop {                                  // k_wg3's B operands of one chann
 // before and the leftover logical blocks here, each cut into split_s pieces along the channel loop (piece s contracts chunks
 // s * split_nch .. and stores its partial outputs -- the output transform is linear -- to its own slice of a workspace); k_wg_tail_reduce
 // adds the slices in a fixed order (+ bias) into y.  No statistics / inference epilogue, even maps.
-template <bool DGRAD, bool STATS, bool BNE = false, bool ODD = false, bool SH = false, bool SPLIT = false>
+// ADD (round 5; input-gradient launches): y = result + addend, elementwise -- the gradient of the OTHER consumer of the conv's input (SphereNet's
+// residual units, models/spherenet.py:121-131: `x = x + relu(conv(relu(conv(x))))`: x feeds the first conv and the sum), which autograd would
+// otherwise add in a separate 3-pass kernel.  The addend comes in through the `bias` parameter (an input-gradient launch has no bias) and is
+// shaped like y.
+template <bool DGRAD, bool STATS, bool BNE = false, bool ODD = false, bool SH = false, bool SPLIT = false, bool ADD = false>
 __global__ __launch_bounds__(SH ? 256 : 128) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
            float *__restrict__ y, float *__restrict__ stats, WgBnEval bn) {
     static_assert(!SH || (!BNE && !ODD), "shared B operands: training launches on even maps");
     static_assert(!SPLIT || (!STATS && !BNE && !ODD), "the tail launch has the plain epilogue only");
+    static_assert(!ADD || (DGRAD && !STATS && !BNE && !SPLIT), "the addend rides in plain input-gradient launches");
     constexpr int UNITF = 2 * 64 * 64;                       // per unit: 2 x 2 raw stages (3264 floats) / the epilogue's exchange buffer (32 KB)
     constexpr int BXF = 2 * 2 * 2 * 2 * 64 * 4;              // SH: [buffer][ph][channel j][half][lane][4] transformed operands (16 KB)
     __shared__ __attribute__((aligned(16))) float smem_all[SH ? 2 * UNITF + BXF : UNITF];
@@ -1812,6 +1817,9 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     // on the ragged end of a launch that need it.
     const bool fast_u = !ODD && t0 + W1_T <= ttot && g.M - kb * 64 >= 64;
     char *ybase = reinterpret_cast<char *>(yy + (int64_t)n0 * g.M * HW);
+    // (ADD) the addend at the same offsets as y: `bias` IS the addend tensor
+    const char *abase = reinterpret_cast<const char *>(bias + (ADD ? (int64_t)n0 * g.M * HW : 0));
+    const float *aout = bias + (ADD ? ((int64_t)n * g.M) * HW + (2 * ty + ph) * g.W + 2 * tx : 0);
     const unsigned yoff = (unsigned)(((nrel * g.M + kb * 64 + 4 * lh_e) * HW + (2 * ty + ph) * g.W + 2 * tx) * 4);
     // (the scalar channel offsets are a running sum behind an opaque barrier: as multiples of HW they are invariant in the persistent
     //  loop, the compiler would compute all 32 in front of it and spill scalar registers into vector lanes)
@@ -1825,6 +1833,7 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     float s1[16], s2[16];
     constexpr int GR = STATS ? 2 : 4;          // (the statistics variant has no registers for four)
     f32x2 got4[GR];
+    f32x2 ad4[(ADD && FAST) ? GR : 1];         // (ADD, fast path) the addend of the group's GR channels, requested with the exchange reads
     int soff = kq * 32 * HW4;                  // (kq * 32 + (e & 3) + 8 * (e >> 2)) * HW4, stepped
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -1834,13 +1843,32 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
 #pragma unroll
             for (int j = 0; j < GR; ++j)
                 got4[j] = *reinterpret_cast<const f32x2 *>(xch + ((((ph ^ 1) * 2 + kq) * 16 + e + j) * 64 + lane) * 2);
+            if constexpr (ADD && FAST && decltype(hb)::value) {
+                static_assert(!ADD || GR == 4, "a group is the four channels between two 5 HW jumps of the running offset");
+#pragma unroll
+                for (int j = 0; j < GR; ++j)
+                    ad4[j] = *reinterpret_cast<const f32x2 *>(abase + (size_t)(yoff + (unsigned)(soff + j * HW4)));
+            }
         }
         const f32x2 got = got4[e & (GR - 1)];
         float v0 = fmaf(own0[ke], sgn, got[0]);             // (+- own + got, exactly)
         float v1 = fmaf(own1[ke], sgn, got[1]);
         if constexpr (decltype(hb)::value) {
-            const float bv = bias[co < g.M ? co : 0];
-            v0 += bv, v1 += bv;
+            if constexpr (ADD) {
+                if constexpr (FAST) {
+                    v0 += ad4[e & (GR - 1)][0], v1 += ad4[e & (GR - 1)][1];
+                } else if (tv && co < g.M) {
+                    if (ODD && oddcol) {
+                        v0 += aout[(int64_t)co * HW];
+                    } else {
+                        const f32x2 ad = *reinterpret_cast<const f32x2 *>(aout + (int64_t)co * HW);
+                        v0 += ad[0], v1 += ad[1];
+                    }
+                }
+            } else {
+                const float bv = bias[co < g.M ? co : 0];
+                v0 += bv, v1 += bv;
+            }
         }
         if (BNE) {                             // y = [max(0,] (conv + bias - mean) * invstd * gamma + beta [)]
             const int cc = co < g.M ? co : 0;
@@ -1909,7 +1937,8 @@ void k_wg3(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
 // `part` is piece 0's slice, addressed like y (image n at (n * M + m) * H W); piece s lies s * stride floats further.
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_wg_tail_reduce(WgGeom g, const float *__restrict__ part, const float *__restrict__ bias,
-                                                        float *__restrict__ y, unsigned lb_first, unsigned lb_end, float *__restrict__ stats) {
+                                                        float *__restrict__ y, unsigned lb_first, unsigned lb_end, float *__restrict__ stats,
+                                                        const float *__restrict__ addend) {
     // one half-wave = the 32 tiles of one (unit, channel): total is a multiple of 32, so a half-wave is never split by the loop bound
     const int64_t total = (int64_t)(lb_end - lb_first) * 64 * W1_T;
     const int nkb64 = (g.nkb + 1) / 2, HW = g.H * g.W;
@@ -1933,6 +1962,10 @@ __global__ __launch_bounds__(256) void k_wg_tail_reduce(WgGeom g, const float *_
                 const float *p = part + (int64_t)sidx * g.split_stride + off;
                 const f32x2 v0 = *reinterpret_cast<const f32x2 *>(p), v1 = *reinterpret_cast<const f32x2 *>(p + g.W);
                 a0[0] += v0[0], a0[1] += v0[1], a1[0] += v1[0], a1[1] += v1[1];
+            }
+            if (addend != nullptr) {                                 // (the fused skip gradient of an input-gradient launch: k_wg3<.., ADD>)
+                const f32x2 d0 = *reinterpret_cast<const f32x2 *>(addend + off), d1 = *reinterpret_cast<const f32x2 *>(addend + off + g.W);
+                a0[0] += d0[0], a0[1] += d0[1], a1[0] += d1[0], a1[1] += d1[1];
             }
             *reinterpret_cast<f32x2 *>(y + off) = a0;
             *reinterpret_cast<f32x2 *>(y + off + g.W) = a1;
@@ -2108,12 +2141,25 @@ extern "C" int cpg_conv3x3_wino_tiles(int N, int c_read, int m, int H, int W) {
 // y[N][m][H][W] = conv3x3(x[N][c_read][H][W], W .* bin(pm)) (+ bias); dgrad: x = gy, the filter transposed and flipped.
 // w is the layer's [K][C][3][3] weight.  stats (forward only, may be null): [m][tiles][2] partial sums for the BatchNorm.
 static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, int C, const float *x, const float *w, const float *pm,
-                    float thr, const float *bias, float *y, float *stats, void *ws, size_t ws_bytes, hipStream_t stream, const WgBnEval *bne);
+                    float thr, const float *bias, float *y, float *stats, void *ws, size_t ws_bytes, hipStream_t stream, const WgBnEval *bne,
+                    const float *addend = nullptr);
 
 extern "C" int cpg_conv3x3_wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, int C, const float *x,
                                     const float *w, const float *pm, float thr, const float *bias, float *y, float *stats,
                                     void *ws, size_t ws_bytes, hipStream_t stream) {
     return wino_run(dgrad, N, c_read, m, H, W, K, C, x, w, pm, thr, bias, y, stats, ws, ws_bytes, stream, nullptr);
+}
+
+// input gradient + addend (gx = dgrad(gy) + addend): the two-wave kernel's launches (>= 64 channels on both sides, or an odd map)
+extern "C" int cpg_conv3x3_wino_dgrad_add_ok(int N, int c_read, int m, int H, int W) {
+    if (!cpg_conv3x3_wino_ok(N, c_read, m, H, W)) return 0;
+    return (((H | W) & 1) || wino_variant(c_read, m, false) == WV_PAIR64) ? 1 : 0;
+}
+extern "C" int cpg_conv3x3_wino_dgrad_add(int N, int c_read, int m, int H, int W, int K, int C, const float *gy, const float *w, const float *pm,
+                                          float thr, const float *addend, float *gx, void *ws, size_t ws_bytes, hipStream_t stream) {
+    if (!cpg_conv3x3_wino_dgrad_add_ok(N, c_read, m, H, W) || addend == nullptr)
+        return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_dgrad_add(winograd): shape not supported");
+    return wino_run(1, N, c_read, m, H, W, K, C, gy, w, pm, thr, nullptr, gx, nullptr, ws, ws_bytes, stream, nullptr, addend);
 }
 
 // 1: the inference epilogue is available on the Winograd kernel (the one-wave kernel only)
@@ -2135,8 +2181,13 @@ extern "C" int cpg_conv3x3_wino_run_bn_eval(int N, int C, int K, int H, int W, c
 }
 
 static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, int C, const float *x, const float *w, const float *pm,
-                    float thr, const float *bias, float *y, float *stats, void *ws, size_t ws_bytes, hipStream_t stream, const WgBnEval *bne) {
+                    float thr, const float *bias, float *y, float *stats, void *ws, size_t ws_bytes, hipStream_t stream, const WgBnEval *bne,
+                    const float *addend) {
     const char *what = dgrad ? "cpg_conv2d_dgrad(winograd)" : "cpg_conv2d_fwd(winograd)";
+    // addend (input-gradient launches of the two-wave kernel only: cpg_conv3x3_wino_dgrad_add_ok): added to the result in the epilogue
+    // (k_wg3<.., ADD>; the tail pieces' share in k_wg_tail_reduce)
+    if (addend != nullptr && (!dgrad || bias != nullptr || bne != nullptr || stats != nullptr))
+        return fail(CPG_E_INVALID, "%s: an addend rides in plain input-gradient launches only", what);
     const size_t need = cpg_conv3x3_wino_pack_bytes(c_read, m);
     if (ws == nullptr || ws_bytes < need) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
     CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
@@ -2159,6 +2210,8 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
             if (odd) {
                 if (bne != nullptr)
                     hipLaunchKernelGGL((k_wg3<false, false, true, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, *bne);
+                else if (dgrad && addend != nullptr)
+                    hipLaunchKernelGGL((k_wg3<true, false, false, true, false, false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, addend, y, nullptr, none);
                 else if (dgrad)
                     hipLaunchKernelGGL((k_wg3<true, false, false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, none);
                 else if (stats != nullptr)
@@ -2187,15 +2240,17 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
             auto finish_tail = [&]() {
                 const dim3 rg(stream_grid((int64_t)(tail.end_lb - tail.first_lb) * 64 * W1_T, 256));
                 if (stats != nullptr)
-                    hipLaunchKernelGGL(k_wg_tail_reduce<true>, rg, dim3(256), 0, stream, gt, part0, bias, y, tail.first_lb, tail.end_lb, stats);
+                    hipLaunchKernelGGL(k_wg_tail_reduce<true>, rg, dim3(256), 0, stream, gt, part0, bias, y, tail.first_lb, tail.end_lb, stats, (const float *)nullptr);
                 else
-                    hipLaunchKernelGGL(k_wg_tail_reduce<false>, rg, dim3(256), 0, stream, gt, part0, bias, y, tail.first_lb, tail.end_lb, (float *)nullptr);
+                    hipLaunchKernelGGL(k_wg_tail_reduce<false>, rg, dim3(256), 0, stream, gt, part0, bias, y, tail.first_lb, tail.end_lb, (float *)nullptr, addend);
             };
             // two units per block sharing the input transform (k_wg3<..., SH>): training launches whose 64-channel blocks pair up
             if (sh) {
                 int64_t pairs = (int64_t)g.nblocks / 2;
                 if (persist) pairs = std::min<int64_t>(pairs, (int64_t)wino_grids() * kCUs);       // (one four-wave block per CU is resident)
-                if (dgrad)
+                if (dgrad && addend != nullptr)
+                    hipLaunchKernelGGL((k_wg3<true, false, false, false, true, false, true>), dim3((unsigned)pairs), dim3(256), 0, stream, g, x, up, addend, y, nullptr, none);
+                else if (dgrad)
                     hipLaunchKernelGGL((k_wg3<true, false, false, false, true>), dim3((unsigned)pairs), dim3(256), 0, stream, g, x, up, bias, y, nullptr, none);
                 else if (stats != nullptr)
                     hipLaunchKernelGGL((k_wg3<false, true, false, false, true>), dim3((unsigned)pairs), dim3(256), 0, stream, g, x, up, bias, y, stats, none);
@@ -2215,6 +2270,8 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
             if (tail.on) blocks = std::min<int64_t>(blocks, (int64_t)g.nblocks);
             if (bne != nullptr)
                 hipLaunchKernelGGL((k_wg3<false, false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, *bne);
+            else if (dgrad && addend != nullptr)
+                hipLaunchKernelGGL((k_wg3<true, false, false, false, false, false, true>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, addend, y, nullptr, none);
             else if (dgrad)
                 hipLaunchKernelGGL((k_wg3<true, false>), dim3((unsigned)blocks), dim3(128), 0, stream, g, x, up, bias, y, nullptr, none);
             else if (stats != nullptr)

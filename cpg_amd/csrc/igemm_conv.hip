@@ -743,13 +743,22 @@ extern "C" int cpg_conv2d_dgrad(const cpg_conv_desc *d, const float *gy, const f
 }
 
 // input gradient + addend (the gradient of the input's other consumer): dense pointwise layers only
+extern "C" int cpg_conv3x3_wino_dgrad_add_ok(int N, int c_read, int m, int H, int W);
+extern "C" int cpg_conv3x3_wino_dgrad_add(int N, int c_read, int m, int H, int W, int K, int C, const float *gy, const float *w, const float *pm,
+                                          float thr, const float *addend, float *gx, void *ws, size_t ws_bytes, hipStream_t stream);
 extern "C" int32_t cpg_conv2d_dgrad_add_supported(const cpg_conv_desc *d) {
-    return d && !cpg_conv3x3_supported(d) && cpg_conv1x1_supported(d) && d->stride_h == 1 && d->stride_w == 1 ? 1 : 0;
+    if (d == nullptr) return 0;
+    // (round 5) the 3x3 s1 p1 layers whose input gradient runs the two-wave Winograd kernel: SphereNet's residual units
+    if (cpg_conv3x3_supported(d)) return cpg_conv3x3_wino_dgrad_add_ok(d->N, d->K, d->C, d->H, d->W) ? 1 : 0;
+    return cpg_conv1x1_supported(d) && d->stride_h == 1 && d->stride_w == 1 ? 1 : 0;
 }
 extern "C" int cpg_conv2d_dgrad_add(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, const float *addend,
                                     float *gx, void *ws, size_t ws_bytes, void *stream) {
-    if (!cpg_conv2d_dgrad_add_supported(d)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_dgrad_add: only dense 1x1 layers fuse the addend");
-    CPG_REQUIRE(addend != nullptr, "cpg_conv2d_dgrad_add: null addend");
+    if (!cpg_conv2d_dgrad_add_supported(d))
+        return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_dgrad_add: dense 1x1 layers and the 3x3 layers of the two-wave Winograd kernel fuse the addend");
+    CPG_REQUIRE(addend != nullptr && gy && w && gx, "cpg_conv2d_dgrad_add: null pointer");
+    if (cpg_conv3x3_supported(d))
+        return cpg_conv3x3_wino_dgrad_add(d->N, d->K, d->C, d->H, d->W, d->K, d->C, gy, w, pm, thr, addend, gx, ws, ws_bytes, (hipStream_t)stream);
     return cpg_conv1x1_dgrad(d, gy, w, pm, thr, gx, ws, ws_bytes, (hipStream_t)stream, addend);
 }
 

@@ -381,6 +381,22 @@ def conv_prelu(conv, mod, x, res=None):
     return prelu(mod, conv(x), res)
 
 
+def conv_prelu_skip(conv, mod, x):
+    """(mod(conv(x)), x) for the FIRST conv of a SphereNet residual unit (models/spherenet.py:121-131: `x = x + relu(conv(relu(conv(x))))`):
+    x feeds this conv and the unit's sum.  The returned x is routed through the conv's autograd node, which then receives BOTH gradients
+    of x and adds the sum's in its input-gradient epilogue (cpg_conv2d_dgrad_add: the two-wave Winograd kernel's ADD instances) instead of
+    leaving a separate add kernel to autograd.  Falls back to (conv_prelu(conv, mod, x), x) when the pair does not qualify."""
+    from .layers import BiasGradSink
+    if (ENABLED and type(mod) is nn.PReLU and x.is_cuda and torch.is_grad_enabled() and x.requires_grad and mod.weight.numel() in (1, conv.out_channels)
+            and conv._math() == 'fp32' and getattr(conv, 'groups', 1) == 1 and x.dim() == 4 and x.is_contiguous()):
+        sink = BiasGradSink() if getattr(conv, 'bias', None) is not None else None
+        y, _, skip = conv.forward_with_skip(x, bias_sink=sink, want_stats=False)
+        if y.dtype == torch.float32 and y.is_contiguous():
+            return _PReluFn.apply(y, mod.weight, None, sink), skip
+        return prelu(mod, y), skip
+    return conv_prelu(conv, mod, x), x
+
+
 def prelu(mod, x, res=None):
     """mod(x) [+ res] for an nn.PReLU module (models/spherenet.py); HIP kernels when the tensor qualifies."""
     if (ENABLED and type(mod) is nn.PReLU and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()

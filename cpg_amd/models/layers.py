@@ -238,14 +238,21 @@ class _MaskedConv2dSkipFn(torch.autograd.Function):
     gradients and folds their sum into the input-gradient kernel's epilogue instead of leaving it to a separate add kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, pm, bias, thr, stride, padding, dilation, groups, math):
-        y, stats = _MaskedConv2dFn.forward(ctx, x, weight, pm, bias, thr, stride, padding, dilation, groups, True, math, None)
+    def forward(ctx, x, weight, pm, bias, thr, stride, padding, dilation, groups, math, bias_sink=None, want_stats=True):
+        # (bias_sink / want_stats = False: SphereNet's biased conv -> PReLU pairs, fused_bn.conv_prelu_skip -- the PReLU's backward delivers the
+        #  bias gradient, and no BatchNorm follows: the plain forward epilogue)
+        if want_stats:
+            y, stats = _MaskedConv2dFn.forward(ctx, x, weight, pm, bias, thr, stride, padding, dilation, groups, True, math, None, bias_sink)
+        else:
+            y = _MaskedConv2dFn.forward(ctx, x, weight, pm, bias, thr, stride, padding, dilation, groups, False, math, None, bias_sink)
+            stats = torch.empty(0, dtype=torch.float32, device=x.device)
+            ctx.mark_non_differentiable(stats)
         return y, stats, x.view_as(x)
 
     @staticmethod
     def backward(ctx, gy, _gstats, gskip):
         r = _MaskedConv2dFn.backward(ctx, gy, None, addend=gskip)
-        return r[:4] + (None,) * 6
+        return r[:4] + (None,) * 8
 
 
 class _MaskedLinearFn(torch.autograd.Function):
@@ -406,13 +413,13 @@ class SharableConv2d(_Sharable):
                                          self.stride, self.padding, self.dilation, self.groups, True, self._math(), bn_hint)
         return y, (stats if stats.numel() else None)
 
-    def forward_with_skip(self, input):
+    def forward_with_skip(self, input, bias_sink=None, want_stats=True):
         """(y, stats or None, skip): forward (+ BatchNorm partial sums where the shape has them) and the input handed back for the
         residual branch; the two gradients of the input are summed inside the input-gradient kernel (_MaskedConv2dSkipFn)."""
         if self.groups != 1:
             return self._grouped(input), None, input
         y, stats, skip = _MaskedConv2dSkipFn.apply(input, self.weight, self.piggymask, self.bias, self.info['threshold'],
-                                                   self.stride, self.padding, self.dilation, self.groups, self._math())
+                                                   self.stride, self.padding, self.dilation, self.groups, self._math(), bias_sink, want_stats)
         return y, (stats if stats.numel() else None), skip
 
     def forward_bn_eval(self, input, bn, relu=True, skip_stats=None):

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
 from . import layers as nl
-from .fused_bn import conv_prelu
+from .fused_bn import conv_prelu, conv_prelu_skip
 from .vgg import View
 
 __all__ = ['SphereNet', 'spherenet20', 'AngleLoss', 'AngleLinear']
@@ -104,8 +104,9 @@ class SphereNet(nn.Module):
             x = conv_prelu(getattr(self, 'conv%d_1' % stage), getattr(self, 'relu%d_1' % stage), x)
             for u in range(units):
                 a, b = 2 * u + 2, 2 * u + 3
-                y = conv_prelu(getattr(self, 'conv%d_%d' % (stage, a)), getattr(self, 'relu%d_%d' % (stage, a)), x)
-                x = conv_prelu(getattr(self, 'conv%d_%d' % (stage, b)), getattr(self, 'relu%d_%d' % (stage, b)), y, res=x)
+                # x feeds conv a and the unit's sum: both gradients of x meet in conv a's input-gradient epilogue (conv_prelu_skip)
+                y, skip = conv_prelu_skip(getattr(self, 'conv%d_%d' % (stage, a)), getattr(self, 'relu%d_%d' % (stage, a)), x)
+                x = conv_prelu(getattr(self, 'conv%d_%d' % (stage, b)), getattr(self, 'relu%d_%d' % (stage, b)), y, res=skip)
         return self.flatten(x)
 
     def forward(self, x):

@@ -139,8 +139,10 @@ int cpg_conv2d_fwd(const cpg_conv_desc *d, const float *x, const float *w, const
 int cpg_conv2d_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm,
                      float thr, float *gx, void *ws, size_t ws_bytes, void *stream);
 /* Input gradient with the gradient of the input's OTHER consumer added in the epilogue: gx = dgrad(gy) + addend.  A residual block's
- * input feeds conv1 and the identity branch (models/resnet.py:84-104); autograd would sum the two gradients in a separate 3-pass
- * kernel.  Dense 1x1 layers only (cpg_conv2d_dgrad_add_supported); addend is shaped like gx and may not alias it. */
+ * input feeds conv1 and the identity branch (models/resnet.py:84-104; models/spherenet.py:121-131: x + relu(conv(relu(conv(x))))); autograd
+ * would sum the two gradients in a separate 3-pass kernel.  Dense 1x1 layers, and (round 5) the 3x3 s1 p1 layers whose input gradient
+ * runs the two-wave Winograd kernel (>= 64 channels on both sides, or a 7 x 7 map): cpg_conv2d_dgrad_add_supported; addend is shaped
+ * like gx and may not alias it. */
 int32_t cpg_conv2d_dgrad_add_supported(const cpg_conv_desc *desc);
 int cpg_conv2d_dgrad_add(const cpg_conv_desc *desc, const float *gy, const float *w, const float *piggymask, float threshold,
                          const float *addend, float *gx, void *workspace, size_t workspace_bytes, void *stream);

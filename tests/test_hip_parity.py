@@ -2066,8 +2066,8 @@ def test_resnet_spherenet_backward_matches_torch_ops(arch, width, shape, ncls, m
                                                                                  self.padding, self.dilation, self.groups))
     # (the residual blocks' first conv goes through forward_with_skip: the reference run must not take the HIP path there either)
     monkeypatch.setattr(nl.SharableConv2d, 'forward_with_skip',
-                        lambda self, input: (F.conv2d(input, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups),
-                                             None, input))
+                        lambda self, input, **kw: (F.conv2d(input, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups),
+                                                   None, input))
     out_ref, g_ref = run()
     np.testing.assert_allclose(out_hip, out_ref, rtol=1e-3, atol=1e-4 * float(np.abs(out_ref).max()))
     assert set(g_hip) == set(g_ref)
@@ -2242,6 +2242,77 @@ def test_skip_gradient_in_the_input_gradient_epilogue(N, C, K, H):
     for a, b in zip(res[True], res[False]):
         sc = float(b.abs().max())
         assert float((a - b).abs().max()) <= 1e-6 * sc
+
+
+@pytest.mark.parametrize('N,C,K,H', [(6, 64, 64, 28),        # SphereNet conv1_x at a small batch: four-wave blocks, general epilogue on the ragged end
+                                     (256, 256, 256, 14),    # conv3_x at batch 256: 3.06 rounds -> the addend of the tail tiles is added by k_wg_tail_reduce
+                                     (40, 128, 192, 28),     # two-wave blocks (three 64-channel blocks of INPUT channels = the produced side of the gradient)
+                                     (9, 512, 512, 7),       # conv4_x: the odd-map instance (edge tiles: one column, one row)
+                                     (3, 32, 48, 14)])       # < 64 channels: the one-wave kernel has no addend -> the separate add (still the right values)
+def test_skip_gradient_in_the_winograd_input_gradient_epilogue(N, C, K, H):
+    """The 3 x 3 twin of test_skip_gradient_in_the_input_gradient_epilogue: SphereNet's residual units (models/spherenet.py:121-131,
+    `x = x + relu(conv(relu(conv(x))))`) route x through conv_prelu_skip, and the two gradients of x meet in the Winograd input-gradient
+    kernel (k_wg3<.., ADD>, cpg_conv2d_dgrad_add) instead of a separate add: same values as the plain composition (the sum is formed in
+    another order: 2e-6 of the scale), bit-identical on repeat, the fused entry point really runs where the shape has it."""
+    import ctypes
+    from cpg_amd import _lib
+    from cpg_amd.models import fused_bn as fb
+    torch.manual_seed(C + K + H)
+    conv = nl.SharableConv2d(C, K, 3, padding=1, bias=True).to(DEV)
+    nn.init.kaiming_normal_(conv.weight, mode='fan_out')
+    conv.bias.data.normal_(0, 0.1)
+    act = nn.PReLU(K).to(DEV)
+    x0 = torch.randn(N, C, H, H, device=DEV)
+    gz, gs = torch.randn(N, K, H, H, device=DEV), torch.randn(N, C, H, H, device=DEV)
+    calls = []
+    L = _lib.lib()
+    raw = L.cpg_conv2d_dgrad_add
+
+    class Spy(object):
+        def __getattr__(self, name):
+            if name == 'cpg_conv2d_dgrad_add':
+                def f(*a):
+                    calls.append(1)
+                    return raw(*a)
+                return f
+            return getattr(L, name)
+
+    def run(fused):
+        conv.zero_grad()
+        act.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        if fused:
+            z, skip = fb.conv_prelu_skip(conv, act, x)
+        else:
+            z, skip = fb.conv_prelu(conv, act, x), x
+        ((z * gz).sum() + (skip * gs).sum()).backward()
+        return z.detach().clone(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone(), act.weight.grad.clone()
+    old, _lib._lib = _lib._lib, Spy()
+    try:
+        a1 = run(True)
+        a2 = run(True)
+    finally:
+        _lib._lib = old
+    b = run(False)
+    d = nl._conv_desc(x0.shape, conv.weight.shape, (1, 1), (1, 1), (1, 1), 1)
+    assert bool(calls) == bool(L.cpg_conv2d_dgrad_add_supported(ctypes.byref(d))) == (min(C, K) >= 64)
+    for u, v in zip(a1, a2):
+        assert torch.equal(u, v)
+    for u, v in zip(a1, b):
+        sc = float(v.abs().max())
+        assert float((u - v).abs().max()) <= 2e-6 * sc
+    # the fused sum against the definition at sampled entries (the last images: the tail's tiles at batch 256)
+    rs = np.random.RandomState(N + H)
+    with torch.no_grad():
+        y = torch.nn.functional.conv2d(x0.double(), conv.weight.double(), conv.bias.double(), padding=1)
+        gy = gz.double() * torch.where(y > 0, torch.ones_like(y), act.weight.double().view(1, -1, 1, 1))
+        gyp = torch.nn.functional.pad(gy, (1, 1, 1, 1))
+        wd = conv.weight.double()
+        for _ in range(16):
+            n, c = N - 1 - rs.randint(min(N, 3)), rs.randint(C)
+            h, w_ = rs.randint(H), rs.randint(H)
+            want = float((gyp[n, :, h:h + 3, w_:w_ + 3].flip(-1, -2) * wd[:, c]).sum()) + float(gs[n, c, h, w_])
+            assert abs(float(a1[1][n, c, h, w_]) - want) <= 1e-4 * abs(want) + 2e-5
 
 
 @pytest.mark.parametrize('N,C,H,W,shared', [(8, 64, 56, 56, False), (5, 12, 7, 9, False), (3, 16, 28, 28, True), (2, 3, 1, 1, False)])
