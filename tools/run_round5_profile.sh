@@ -33,14 +33,12 @@ for cfg in "vgg16:--arch vgg16" "resnet50:--arch resnet50" "spherenet20:--arch s
   python $R/tools/rocprof_summary.py $db 60 > $R/gpurun_out/summary_${TAG}_$a.md 2>&1
   rm -rf $R/gpurun_out/prof_${TAG}_$a
 done
-# HBM traffic of the bench's own launch mix: FETCH_SIZE and WRITE_SIZE in separate counter passes (kernel trace only)
-for a in vgg16 resnet50 spherenet20; do
-  for c in FETCH_SIZE WRITE_SIZE; do
-    # --clock-every 1: with the sampled kernel clock (events on some steps only) rocprofv3's counter collection aborted ResNet-50's queue with
-    # HSA_STATUS_ERROR_INVALID_PACKET_FORMAT and then hung in its signal handler (a whole bundle was lost to that); every launch clocked, or
-    # none, runs.  Bounded anyway.
-    timeout -s KILL 900 rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/btraffic/${a}_$c -o run --output-format csv -- python $R/bench.py --arch $a --steps 20 --warmup 1 --no-cpu-baseline --optin-steps 0 --clock-every 1 > $R/gpurun_out/btraffic_${a}_$c.log 2>&1
-  done
-done
-python $R/tools/bench_traffic.py $R/gpurun_out/btraffic ${COMMIT:-unknown} > $R/gpurun_out/traffic_${TAG}.json 2> $R/gpurun_out/traffic_${TAG}.err
-rm -rf $R/gpurun_out/btraffic
+# HBM traffic of the bench's own launch mix: FETCH_SIZE and WRITE_SIZE in separate counter passes (kernel trace only, every launch clocked; a pass
+# takes ~10 s -- bounded at 300 s and retried once: rocprofv3 has hung in its signal handler on this pool)
+cd $R
+COMMIT=${COMMIT:-unknown} LIMIT=300 bash tools/run_traffic.sh
+for a in vgg16 resnet50 spherenet20; do for c in FETCH_SIZE WRITE_SIZE; do
+  if [ ! -e gpurun_out/btraffic/${a}_$c/.collected ]; then ARCHS=$a COMMIT=${COMMIT:-unknown} LIMIT=300 bash tools/run_traffic.sh; break; fi
+done; done
+cp gpurun_out/traffic.json gpurun_out/traffic_${TAG}.json
+rm -rf gpurun_out/btraffic
