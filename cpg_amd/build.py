@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libcpg_hip.so')
-SOURCES = ['cpg_common.cpp', 'mask_kernels.hip', 'rank_prune.hip', 'igemm_conv.hip', 'conv3x3.hip', 'pointwise.hip', 'bn_kernels.hip', 'grad_pack.hip', 'conv3x3_bf16.hip', 'conv3x3_wino.hip', 'conv3x3_wino_wgrad.hip', 'conv3x3_stem.hip', 'conv_stem_s2.hip']
+SOURCES = ['cpg_common.cpp', 'mask_kernels.hip', 'rank_prune.hip', 'igemm_conv.hip', 'conv3x3.hip', 'pointwise.hip', 'bn_kernels.hip', 'grad_pack.hip', 'conv3x3_bf16.hip', 'conv3x3_wino.hip', 'conv3x3_wino_wgrad.hip', 'conv3x3_stem.hip', 'conv_stem_s2.hip', 'fc_small.hip']
 HEADERS = ['cpg_common.h', 'igemm_core.h', os.path.join('..', '..', 'include', 'cpg_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 

@@ -37,7 +37,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"CPG_C3_FORCE", INT},          {"CPG_C3W_BPC", INT},          {"CPG_W3_PICK", INT},           {"CPG_PWW_BPC", INT},
     {"CPG_STEM_BLOCKS", INT},       {"CPG_WINO_KERNEL", WINO_KERNEL}, {"CPG_WINO_NW", INT},        {"CPG_WINO_PERSIST", INT},
     {"CPG_WINO_GRIDS", INT},        {"CPG_WW_UNITS", INT},         {"CPG_WW_XCD", INT},            {"CPG_PW_TILE", INT},           {"CPG_WG3_SHARE", INT},
-    {"CPG_WW_SHARE", INT},          {"CPG_WINO_TAIL", INT},
+    {"CPG_WW_SHARE", INT},          {"CPG_WINO_TAIL", INT},         {"CPG_FC_SMALL", INT},
 };
 
 struct Table {

@@ -49,6 +49,7 @@ enum Opt {
     OPT_WG3_SHARE,        // CPG_WG3_SHARE=0: k_wg3 as blocks of one unit (two waves), every unit transforming all of its B operands (round 3)
     OPT_WW_SHARE,         // CPG_WW_SHARE=0: every wave of k_wgw stages its own x rows (round 3); 2 / 4: force that sharing group
     OPT_WINO_TAIL,        // CPG_WINO_TAIL=0: no channel-split tail launch for the leftover units of k_wg3's last round (round 4 behaviour)
+    OPT_FC_SMALL,         // CPG_FC_SMALL=0: linear layers at <= 64 rows on the batch-256 tiles / the generic split-K kernel (round 4 behaviour)
     OPT_COUNT
 };
 constexpr int OPT_UNSET = INT32_MIN;

@@ -850,9 +850,15 @@ int cpg_pw_gemm_nn_maskx(const float *wp, int Mp, const float *X, const float *p
                          hipStream_t stream, const char *what);
 void cpg_pw_pack_transpose(const float *a, int R, int Cc, float *wp, hipStream_t stream);
 size_t cpg_pw_pack_transpose_bytes(int R, int Cc);
+// fc_small.hip: the weight-streaming input gradient at <= 64 rows
+bool cpg_fc_small_dgrad_ok(const float *w, const float *pm, const float *gx, int batch, int in_f, int out_f);
+size_t cpg_fc_small_dgrad_workspace(int batch, int in_f, int out_f);
+int cpg_fc_small_dgrad(const float *gy, const float *w, const float *pm, float thr, float *gx, int batch, int in_f, int out_f, void *ws,
+                       size_t ws_bytes, hipStream_t stream, const char *what);
 namespace {
 size_t linear_ws(int batch, int in_f, int out_f) {
     size_t best = std::max(cpg_pw_gemm_nt_workspace(batch, out_f, in_f), cpg_pw_pack_transpose_bytes(batch, out_f));
+    best = std::max(best, cpg_fc_small_dgrad_workspace(batch, in_f, out_f));
     int ns, per;
     {   // fwd: M=batch N=out K=in
         int64_t tiles = (int64_t)((batch + 127) / 128) * ((out_f + 127) / 128);
@@ -912,6 +918,10 @@ extern "C" int cpg_linear_dgrad(const float *gy, const float *w, const float *pm
                                 int32_t in_f, int32_t out_f, void *ws, size_t ws_bytes, void *stream) {
     CPG_REQUIRE(gy && w && gx && batch > 0 && in_f > 0 && out_f > 0, "cpg_linear_dgrad: bad argument");
     Epilogue ep{gx, nullptr, BIAS_NONE, 1, 1, nullptr, nullptr, nullptr, thr};
+    // (round 5) <= 64 rows: the weight is STREAMED once, operands straight from global memory (fc_small.hip)
+    if (batch <= 64 && ws != nullptr && ws_bytes >= cpg_fc_small_dgrad_workspace(batch, in_f, out_f) && (((uintptr_t)ws) & 15) == 0 &&
+        (((uintptr_t)gy) & 3) == 0 && cpg_fc_small_dgrad_ok(w, pm, gx, batch, in_f, out_f))
+        return cpg_fc_small_dgrad(gy, w, pm, thr, gx, batch, in_f, out_f, ws, ws_bytes, (hipStream_t)stream, "cpg_linear_dgrad");
     const int Mp_b = (batch + 127) / 128 * 128;
     if (ws != nullptr && ws_bytes >= cpg_pw_pack_transpose_bytes(batch, out_f) && (((uintptr_t)ws) & 15) == 0 &&
         cpg_pw_gemm_nn_ok(w, batch, Mp_b, out_f, in_f) && (pm == nullptr || (in_f % 4 == 0 && (((uintptr_t)pm) & 15) == 0))) {

@@ -448,11 +448,14 @@ __global__ __launch_bounds__(256, Cfg::MINW) void k_pw(PwGeom g, const float *__
 // buffer_load_dwordx4 and two ds_write_b64.  Two LDS stages, one barrier per unit; the 8 loads + 16 LDS stores of
 // unit u+2 / u+1 ride between the 64 MFMAs of unit u (conv3x3.hip's k_c3_wgrad scheme).  Block = BCO x BCI
 // channels, 2 x 2 waves, each wave (BCO/2) x (BCI/2).
-template <int BCO_, int BCI_>
+// WCO_ x (4 / WCO_) waves: 2 x 2 for the conv layers; 1 x 4 with BCO = 32 for the plain-GEMM form with <= 32 rows (the forward of a linear
+// layer at <= 32 images per GPU, the reference's own 256 / 8 split: a 128-row tile spent 3/4 of its MFMAs on rows that do not exist).
+template <int BCO_, int BCI_, int WCO_ = 2>
 struct PwWCfg {
     static constexpr int BCO = BCO_, BCI = BCI_, PIX = 32, LD = PIX + 2;
-    static constexpr int FM = BCO / 64, FN = BCI / 64;
-    static_assert(BCO % 64 == 0 && BCI % 64 == 0, "wave tiles are multiples of 32 x 32");
+    static constexpr int WCO = WCO_, WCI = 4 / WCO_;
+    static constexpr int FM = BCO / (32 * WCO), FN = BCI / (32 * WCI);
+    static_assert(BCO % (32 * WCO) == 0 && BCI % (32 * WCI) == 0 && WCO * WCI == 4, "wave tiles are multiples of 32 x 32");
     static constexpr int NA = BCO * (PIX / 4) / 256, NB = BCI * (PIX / 4) / 256;     // float4 per thread per unit
     static constexpr int A_ELEMS = BCO * LD, STAGE = (BCO + BCI) * LD;
     static constexpr int NITEMS = NA + NB, NS = PIX / 2;
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(int M, int C, int HWo, long
     __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int sub = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wco = sub >> 1, wci = sub & 1;
+    const int wco = sub / Cfg::WCI, wci = sub % Cfg::WCI;
     const int li = lane & 31, lh = lane >> 5;
     // all (co, ci) tiles of one split on one XCD (block b runs on XCD b % 8): the split's units are read once per L2
     const int tiles = tiles_co * tiles_ci;
@@ -580,8 +583,8 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(int M, int C, int HWo, long
         *reinterpret_cast<f32x2 *>(p) = f32x2{v[0], v[1]};
         *reinterpret_cast<f32x2 *>(p + 2) = f32x2{v[2], v[3]};
     };
-    const int a_base = (wco * (Cfg::BCO / 2) + li) * Cfg::LD + lh;
-    const int b_base = Cfg::A_ELEMS + (wci * (Cfg::BCI / 2) + li) * Cfg::LD + lh;
+    const int a_base = (wco * (Cfg::BCO / Cfg::WCO) + li) * Cfg::LD + lh;
+    const int b_base = Cfg::A_ELEMS + (wci * (Cfg::BCI / Cfg::WCI) + li) * Cfg::LD + lh;
 
     if (u0 < u1) {
         describe(u0);
@@ -645,8 +648,8 @@ __global__ __launch_bounds__(256, 2) void k_pw_wgrad(int M, int C, int HWo, long
         for (int fn = 0; fn < Cfg::FN; ++fn)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int co = co0 + wco * (Cfg::BCO / 2) + fm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const int ci = ci0 + wci * (Cfg::BCI / 2) + fn * 32 + li;
+                const int co = co0 + wco * (Cfg::BCO / Cfg::WCO) + fm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int ci = ci0 + wci * (Cfg::BCI / Cfg::WCI) + fn * 32 + li;
                 if (co < M && ci < C) dstp[(int64_t)co * C + ci] = acc[fm][fn][e];
             }
 }
@@ -882,7 +885,10 @@ NtPlan nt_plan(int M, int C, int64_t K) {
     p.tiles_co = (M + Cfg::BCO - 1) / Cfg::BCO;
     p.tiles_ci = (C + Cfg::BCI - 1) / Cfg::BCI;
     const int64_t units = (K + Cfg::PIX - 1) / Cfg::PIX, tiles = (int64_t)p.tiles_co * p.tiles_ci;
-    int64_t want = (4 * kCUs + tiles - 1) / tiles;
+    // split blocks per CU: 4; the 32-row tiles (an HBM-bound stream of the other operand) 2 = one round of the two resident blocks,
+    // half the partial sums
+    const int bpc = std::max(1, opt_or(OPT_PWW_BPC, Cfg::BCO == 32 ? 2 : 4));
+    int64_t want = ((int64_t)bpc * kCUs + tiles - 1) / tiles;
     want = std::max<int64_t>(1, std::min<int64_t>(want, (units + 7) / 8));
     want = (want + kXCDs - 1) / kXCDs * kXCDs;
     p.units_per_split = (int)((units + want - 1) / want);
@@ -896,28 +902,48 @@ bool cpg_pw_gemm_nt_ok(const float *A, const float *B, int M, int C, int64_t K) 
     return !cpg::opt_on(cpg::OPT_DISABLE_PW_GEMM) && K % 4 == 0 && (((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0 &&
            (int64_t)std::max(M, C) * K * 4 < (1ll << 31) && K < (1ll << 29);
 }
-size_t cpg_pw_gemm_nt_workspace(int M, int C, int64_t K) { return nt_plan<PwW128>(M, C, K).ws_bytes; }
-int cpg_pw_gemm_nt(const float *A, const float *B, int M, int C, int64_t K, const Epilogue &ep, void *ws, size_t ws_bytes,
-                   hipStream_t stream, const char *what) {
-    const NtPlan p = nt_plan<PwW128>(M, C, K);
+// the tile by the row count: 128 rows; 64 (<= 64 rows); 32 x 128 on 1 x 4 waves (<= 32 rows: the linear forward at <= 32 images per GPU;
+// features.45 at batch 32: 0.245 -> 0.081 ms, 5.1 TB/s of weight bytes; the 32 x 256 tile: 0.087)
+using PwW32 = PwWCfg<32, 128, 1>;
+using PwW32n = PwWCfg<32, 256, 1>;       // (development: CPG_FC_SMALL bit 8)
+namespace {
+template <class Cfg, bool MASKB>
+int nt_launch(const float *A, const float *B, const float *pmB, float thr, int M, int C, int64_t K, const Epilogue &ep, void *ws, size_t ws_bytes,
+              hipStream_t stream, const char *what) {
+    const NtPlan p = nt_plan<Cfg>(M, C, K);
     if (ws == nullptr || ws_bytes < p.ws_bytes) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, p.ws_bytes);
-    // k_pw_wgrad(M, C, HWo, G, ...): "gy" = A with M rows, "x" = B with C rows, one image of HWo = G = K pixels
-    hipLaunchKernelGGL(k_pw_wgrad<PwW128>, dim3((unsigned)(p.tiles_co * p.tiles_ci * p.nsplit)), dim3(256), 0, stream, M, C, (int)K,
-                       (long long)K, p.tiles_co, p.tiles_ci, p.units_per_split, B, A, (float *)ws);
-    launch_split_reduce((const float *)ws, p.nsplit, (int64_t)M * C, 0, ep, stream);
-    CPG_CHECK_LAUNCH(what);
-    return CPG_OK;
-}
-// the same product with B masked in staging: D[M][C] = A[M][K] . (B * bin(pmB))[C][K]^T
-int cpg_pw_gemm_nt_maskb(const float *A, const float *B, const float *pmB, float thr, int M, int C, int64_t K, const Epilogue &ep, void *ws,
-                         size_t ws_bytes, hipStream_t stream, const char *what) {
-    const NtPlan p = nt_plan<PwW128>(M, C, K);
-    if (ws == nullptr || ws_bytes < p.ws_bytes) return fail(CPG_E_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, p.ws_bytes);
-    hipLaunchKernelGGL((k_pw_wgrad<PwW128, false, true>), dim3((unsigned)(p.tiles_co * p.tiles_ci * p.nsplit)), dim3(256), 0, stream, M, C, (int)K,
+    // k_pw_wgrad(M, C, HWo, G, ...): "gy" = A with M rows, "x" = B with C rows, one image of HWo = G = K pixels; MASKB: B * bin(pmB) in staging
+    hipLaunchKernelGGL((k_pw_wgrad<Cfg, false, MASKB>), dim3((unsigned)(p.tiles_co * p.tiles_ci * p.nsplit)), dim3(256), 0, stream, M, C, (int)K,
                        (long long)K, p.tiles_co, p.tiles_ci, p.units_per_split, B, A, (float *)ws, PwWX{0, 0, 0, 0}, pmB, thr);
     launch_split_reduce((const float *)ws, p.nsplit, (int64_t)M * C, 0, ep, stream);
     CPG_CHECK_LAUNCH(what);
     return CPG_OK;
+}
+inline int nt_rows(int M) {
+    const int o = cpg::opt_or(cpg::OPT_FC_SMALL, 1);
+    return o == 0 ? 128 : M <= 32 ? ((o & 256) ? 33 : 32) : M <= 64 ? 64 : 128;
+}
+}  // namespace
+size_t cpg_pw_gemm_nt_workspace(int M, int C, int64_t K) {      // (of every tile a switch could select: options may change between query and call)
+    return std::max(std::max(nt_plan<PwW128>(M, C, K).ws_bytes, nt_plan<PwW32n>(M, C, K).ws_bytes),
+                    std::max(nt_plan<PwW32>(M, C, K).ws_bytes, nt_plan<PwW64o>(M, C, K).ws_bytes));
+}
+int cpg_pw_gemm_nt(const float *A, const float *B, int M, int C, int64_t K, const Epilogue &ep, void *ws, size_t ws_bytes,
+                   hipStream_t stream, const char *what) {
+    const int r = nt_rows(M);
+    if (r == 32) return nt_launch<PwW32, false>(A, B, nullptr, 0.0f, M, C, K, ep, ws, ws_bytes, stream, what);
+    if (r == 33) return nt_launch<PwW32n, false>(A, B, nullptr, 0.0f, M, C, K, ep, ws, ws_bytes, stream, what);
+    if (r == 64) return nt_launch<PwW64o, false>(A, B, nullptr, 0.0f, M, C, K, ep, ws, ws_bytes, stream, what);
+    return nt_launch<PwW128, false>(A, B, nullptr, 0.0f, M, C, K, ep, ws, ws_bytes, stream, what);
+}
+// the same product with B masked in staging: D[M][C] = A[M][K] . (B * bin(pmB))[C][K]^T
+int cpg_pw_gemm_nt_maskb(const float *A, const float *B, const float *pmB, float thr, int M, int C, int64_t K, const Epilogue &ep, void *ws,
+                         size_t ws_bytes, hipStream_t stream, const char *what) {
+    const int r = nt_rows(M);
+    if (r == 32) return nt_launch<PwW32, true>(A, B, pmB, thr, M, C, K, ep, ws, ws_bytes, stream, what);
+    if (r == 33) return nt_launch<PwW32n, true>(A, B, pmB, thr, M, C, K, ep, ws, ws_bytes, stream, what);
+    if (r == 64) return nt_launch<PwW64o, true>(A, B, pmB, thr, M, C, K, ep, ws, ws_bytes, stream, what);
+    return nt_launch<PwW128, true>(A, B, pmB, thr, M, C, K, ep, ws, ws_bytes, stream, what);
 }
 
 bool cpg_pw_gemm_nn_ok(const float *X, int M, int Mp, int Kd, int64_t G) {

@@ -105,6 +105,7 @@ int32_t cpg_get_shared_chip_hint(void);
  *   summation order only (how a reduction over pixels / tiles / channel blocks is split and added: last-bit differences, mostly in
  *   weight gradients and BatchNorm statistics):
  *       CPG_WW_UNITS, CPG_WW_SHARE, CPG_C3W_BPC, CPG_PWW_BPC, CPG_PW_TILE, CPG_WINO_KERNEL, CPG_WINO_NW, CPG_STEM_BLOCKS, CPG_WINO_TAIL,
+ *       CPG_FC_SMALL (linear layers at <= 64 rows: which kernel streams the weight = how the contraction is split),
  *       CPG_NO_STEM_FUSE (fused stem recomputes y instead of reading it back: same bits where the summation order is the same),
  *       and cpg_set_shared_chip_hint (above);
  *   no effect on any result bit (scheduling / mapping of the same work):

@@ -784,7 +784,10 @@ def test_direct_weight_gradients_under_the_shared_chip_hint(N, C, K, H, ks, stri
                                       # and at the per-GPU batch of the 8-GPU reference configuration / the validate batch
                                       (256, 25088, 4096, False), (256, 25088, 4096, True), (32, 25088, 4096, True), (100, 25088, 4096, False),
                                       # the grown network's FC layers (raw multiplier 1.5: 627 * 49 -> int(4096 * sqrt(1.5)) = 5016; odd row length)
-                                      (32, 30723, 5016, True), (16, 5016, 5016, False)])
+                                      (32, 30723, 5016, True), (16, 5016, 5016, False),
+                                      # <= 64 rows (the reference's own 256 / 8 split): the weight-streaming input gradient and the 32- / 64-row forward
+                                      # tiles -- ragged column tiles, row counts that leave waves without work, one and two row fragments
+                                      (32, 25088, 4096, False), (64, 4096, 4096, True), (33, 4100, 1000, False), (8, 132, 18, True), (64, 1028, 50, False)])
 def test_linear_oracle(B, I, O, pm):
     g = torch.Generator().manual_seed(B + I + O)
     x = torch.randn(B, I, generator=g)
@@ -1717,7 +1720,8 @@ def test_conv_full_size_properties_other_nets(C, K, H, k, s, p, bias):
         assert abs(float(layer.piggymask.grad[ko, c, r, q]) - want * float(w[ko, c, r, q])) <= tol + 1e-4 * abs(want * float(w[ko, c, r, q]))
 
 
-@pytest.mark.parametrize('B,I,O', [(256, 25088, 4096), (256, 4096, 4096), (256, 30723, 5016), (256, 5016, 5016)])   # (+ the grown network's: raw multiplier 1.5)
+@pytest.mark.parametrize('B,I,O', [(256, 25088, 4096), (256, 4096, 4096), (256, 30723, 5016), (256, 5016, 5016),    # (+ the grown network's: raw multiplier 1.5)
+                                   (32, 25088, 4096), (64, 25088, 4096), (32, 5016, 5016)])                           # (+ the per-GPU batch of the reference's 8-GPU split)
 @pytest.mark.parametrize('pm_on', [False, True])
 def test_linear_full_size_properties(B, I, O, pm_on):
     """The two masked FC layers of config 2 at full size, with and without a piggymask: adjoint identities tie
@@ -1762,6 +1766,43 @@ def test_linear_full_size_properties(B, I, O, pm_on):
         # the whole mask pattern of gW (bit-exact): zero exactly where the binarised piggymask is zero
         assert torch.equal(layer.weight.grad == 0, (keep == 0) | (layer.weight.grad == 0))
         assert int(((layer.weight.grad != 0) & (keep == 0)).sum()) == 0
+
+
+@pytest.mark.parametrize('B,I,O,pm_on', [(32, 25088, 4096, False), (32, 25088, 4096, True), (64, 4096, 4096, True), (20, 516, 200, False)])
+def test_linear_small_batch_paths_equal_the_batch_256_paths(B, I, O, pm_on):
+    """<= 64 rows: the forward on the 32- / 64-row tiles of the pointwise weight-gradient kernel and the weight-streaming input
+    gradient (fc_small.hip) against the kernels the same call runs with CPG_FC_SMALL=0 -- same products, another summation order --
+    and the small-batch launches repeat bit for bit (fixed-order reductions)."""
+    from cpg_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(B + I + O)
+    x = torch.randn(B, I, generator=g, device=DEV)
+    w = torch.randn(O, I, generator=g, device=DEV) * I ** -0.5
+    gy = torch.randn(B, O, generator=g, device=DEV)
+    pm = torch.rand(O, I, generator=g, device=DEV) * 0.012 if pm_on else None
+
+    def run():
+        layer = nl.SharableLinear(I, O).to(DEV)
+        layer.weight.data.copy_(w)
+        layer.bias.data.zero_()
+        if pm_on:
+            layer.piggymask = nn.Parameter(pm.clone())
+        xd = x.clone().requires_grad_(True)
+        y = layer(xd)
+        y.backward(gy)
+        return y.detach(), xd.grad
+    y1, gx1 = run()
+    y1b, gx1b = run()
+    assert torch.equal(y1, y1b), 'forward does not repeat'
+    assert torch.equal(gx1, gx1b), 'input gradient does not repeat'
+    with _lib.option('CPG_FC_SMALL', 0):
+        y0, gx0 = run()
+    keep = (pm > 5e-3).double() if pm_on else 1.0
+    yr = x.double() @ (w.double() * keep).t()
+    gr = gy.double() @ (w.double() * keep)
+    for got, old, ref in ((y1, y0, yr), (gx1, gx0, gr)):
+        sc = float(ref.abs().max())
+        assert float((got.double() - ref).abs().max()) <= 1e-5 * sc and float((old.double() - ref).abs().max()) <= 1e-5 * sc
+
 
 
 # --------------------------------------------------------------------------- fused BatchNorm -> ReLU (SURVEY 8f.2)
