@@ -332,6 +332,16 @@ class _MaskedLinearFn(torch.autograd.Function):
         return gx, gw, gpm, gb, None
 
 
+class HeadLinear(nn.Linear):
+    """A task head that is a plain nn.Linear in the reference (never masked, never pruned: models/spherenet.py:240-245, the 25 088 -> 512
+    embedding in front of AngleLinear) on the same C-ABI GEMMs as the masked linear layers, without a mask: parameters, state_dict keys
+    and initialisation are nn.Linear's.  In SphereNet-20's train step stock torch spent 0.38 ms (of 19.9) in three library GEMMs for this
+    layer -- 27 TFLOP/s in its weight gradient, a 256-deep contraction."""
+
+    def forward(self, input):
+        return _MaskedLinearFn.apply(input, self.weight, None, self.bias, 0.0)
+
+
 class _Sharable(nn.Module):
     """State shared by both masked layers: threshold bookkeeping and the late-bound piggymask.
 

@@ -127,8 +127,8 @@ class SphereNet(nn.Module):
     def _head(self, width, dataset, num_classes):
         flat = int(width * 512) * 7 * 7
         if 'face_verification' in dataset:
-            return nn.Sequential(nn.Linear(flat, 512), AngleLinear(512, num_classes))
-        return nn.Linear(flat, num_classes)
+            return nn.Sequential(nl.HeadLinear(flat, 512), AngleLinear(512, num_classes))
+        return nl.HeadLinear(flat, num_classes)
 
     def _reconstruct_classifiers(self):
         for dataset, num_classes in self.dataset2num_classes.items():
