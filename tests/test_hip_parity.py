@@ -1768,6 +1768,29 @@ def test_linear_full_size_properties(B, I, O, pm_on):
         assert int(((layer.weight.grad != 0) & (keep == 0)).sum()) == 0
 
 
+@pytest.mark.parametrize('B,I,O', [(256, 25088, 512), (5, 33, 7), (32, 516, 10)])
+def test_head_linear_is_nn_linear_on_the_c_abi(B, I, O):
+    """layers.HeadLinear (SphereNet-20's embedding head, a plain nn.Linear in the reference: models/spherenet.py:240-245): nn.Linear's
+    parameters, state_dict keys and seeded initialisation; forward and all three gradients against fp64 torch."""
+    torch.manual_seed(3)
+    ref = nn.Linear(I, O)
+    torch.manual_seed(3)
+    head = nl.HeadLinear(I, O)
+    assert isinstance(head, nn.Linear) and list(head.state_dict()) == list(ref.state_dict())
+    assert torch.equal(head.weight, ref.weight) and torch.equal(head.bias, ref.bias)
+    head = head.to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(B + I + O)
+    x = torch.randn(B, I, generator=g, device=DEV, requires_grad=True)
+    gy = torch.randn(B, O, generator=g, device=DEV)
+    y = head(x)
+    y.backward(gy)
+    xd, wd, bd = x.detach().double(), head.weight.detach().double(), head.bias.detach().double()
+    for got, want in ((y.detach(), xd @ wd.t() + bd), (x.grad, gy.double() @ wd), (head.weight.grad, gy.double().t() @ xd),
+                      (head.bias.grad, gy.double().sum(0))):
+        sc = float(want.abs().max())
+        assert float((got.double() - want).abs().max()) <= 1e-5 * sc
+
+
 @pytest.mark.parametrize('B,I,O,pm_on', [(32, 25088, 4096, False), (32, 25088, 4096, True), (64, 4096, 4096, True), (20, 516, 200, False)])
 def test_linear_small_batch_paths_equal_the_batch_256_paths(B, I, O, pm_on):
     """<= 64 rows: the forward on the 32- / 64-row tiles of the pointwise weight-gradient kernel and the weight-streaming input
