@@ -1768,6 +1768,36 @@ def test_linear_full_size_properties(B, I, O, pm_on):
         assert int(((layer.weight.grad != 0) & (keep == 0)).sum()) == 0
 
 
+@pytest.mark.parametrize('seed', range(12))
+def test_linear_small_batch_random_shapes(seed):
+    """Seeded random shapes at <= 64 rows (row lengths a multiple of 4: the weight-streaming input gradient; every output count: units
+    that leave waves or whole splits without rows), with and without a piggymask: y, gx, gW, gPM against fp64."""
+    rs = np.random.RandomState(1000 + seed)
+    B, I, O, pm_on = int(rs.randint(1, 65)), 4 * int(rs.randint(1, 700)), int(rs.randint(1, 900)), bool(seed % 2)
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn(B, I, generator=g, device=DEV, requires_grad=True)
+    w = torch.randn(O, I, generator=g, device=DEV) * I ** -0.5
+    gy = torch.randn(B, O, generator=g, device=DEV)
+    layer = nl.SharableLinear(I, O).to(DEV)
+    layer.weight.data.copy_(w)
+    layer.bias.data.zero_()
+    keep = 1.0
+    if pm_on:
+        pm = torch.rand(O, I, generator=g, device=DEV) * 0.012
+        layer.piggymask = nn.Parameter(pm.clone())
+        keep = (pm > 5e-3).double()
+    y = layer(x)
+    y.backward(gy)
+    weff = w.double() * keep
+    gweff = gy.double().t() @ x.detach().double()
+    checks = [(y.detach(), x.detach().double() @ weff.t(), 'y'), (x.grad, gy.double() @ weff, 'gx'), (layer.weight.grad, gweff * keep, 'gw')]
+    if pm_on:
+        checks.append((layer.piggymask.grad, gweff * w.double(), 'gpm'))
+    for got, want, name in checks:
+        sc = max(float(want.abs().max()), 1e-30)
+        assert float((got.double() - want).abs().max()) <= 1e-5 * sc, (name, B, I, O, pm_on)
+
+
 @pytest.mark.parametrize('B,I,O', [(256, 25088, 512), (5, 33, 7), (32, 516, 10)])
 def test_head_linear_is_nn_linear_on_the_c_abi(B, I, O):
     """layers.HeadLinear (SphereNet-20's embedding head, a plain nn.Linear in the reference: models/spherenet.py:240-245): nn.Linear's
