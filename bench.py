@@ -13,8 +13,8 @@ already resident in HBM, weights from the reference's init at seed 1 (Dropout st
 The K timed steps are the section-8d cycle with a shape that does NOT depend on K:
 
     validate (apply_mask + 2 eval batches of 100)   after every 20th train step (20-step epochs: 1 validate per 20 steps)
-    phase A "finetune"                              the first A = max(1, round(K / 11)) steps, SGD-nesterov lr 1e-2
-    phase B "prune 0.0 -> 0.1" + recovery           the other K - A steps, lr 1e-3; pruning window = first 4 f steps of the
+    phase A "finetune"                              the first A = max(1, round(K / 11)) steps, SGD-nesterov lr 1e-2 (SphereNet-20: 1e-3)
+    phase B "prune 0.0 -> 0.1" + recovery           the other K - A steps, lr 1e-3 (SphereNet-20: 5e-4); pruning window = first 4 f steps of the
                                                     phase, rank-prune event every f = max(1, A // 2) steps -> 4 events,
                                                     then fixed-mask recovery
     mask statistics                                 every train step and every validate batch (utils/manager.py:77-88,126-136)
@@ -61,9 +61,13 @@ ARCHS = {
                   workload='configs[1]: VGG16-BN custom_vgg 224x224'),
     'resnet50': dict(size=224, dataset='cubs_cropped', classes=200, dataset2='stanford_cars_cropped', classes2=196, flop_train=2 * (3 * 4.087e9 - 0.118e9), flop_fwd=2 * 4.087e9,
                      workload='configs[3] topology on one GPU: ResNet-50 (Bottleneck, masked 7x7 s2 / 1x1 / 3x3 s1 / 3x3 s2 convs) 224x224'),
+    # lrs: the reference's own learning rates for this configuration (experiment3/FvGeEm_CPG_face.sh:21-25,130: finetune 1e-3, prune run
+    # 5e-4).  The VGG16 cycle's 1e-2 / 1e-3 makes this BatchNorm-free network diverge on random labels within 5 steps -- on torch's own ops
+    # exactly as on the HIP kernels (tools/diag_sph_nan.py) -- and every K >= 60 cycle then ran on NaN weights (`cycle_check` said so).
     'spherenet20': dict(size=112, dataset='face_verification', classes=4630, dataset2='gender', classes2=2, flop_train=2 * (3 * 2.029e9 - 0.0054e9), flop_fwd=2 * 2.029e9,
-                        workload='configs[4] topology on one GPU: SphereNet-20 112x112, AngleLinear head + AngleLoss'),
+                        workload='configs[4] topology on one GPU: SphereNet-20 112x112, AngleLinear head + AngleLoss', lrs=(1e-3, 5e-4)),
 }
+LRS = (1e-2, 1e-3)      # (finetune, prune run) of the timed cycle: experiment1's; main() takes ARCHS[arch]['lrs'] when the topology has its own
 FLOP_PER_IMG_TRAIN = ARCHS['vgg16']['flop_train']
 
 
@@ -405,11 +409,11 @@ def run_cycle(model, masks, pool, val_pool, steps, clock=None, marks=None, count
     # phase A: finetune (free slots claimed by task 1)
     mgr = Manager(make_args('finetune', f), model, {}, masks, None, val_pool, 0, 0)
     mgr.pruner.make_finetuning_mask()
-    opt = sgd(1e-2, mgr.pruner, 5e-4)
+    opt = sgd(LRS[0], mgr.pruner, 5e-4)
     epoch = 0
     for n, val in list(chunks(A)):
         mgr.train_loader = loader(n, done)
-        mgr.train(opt, epoch, [1e-2], 0)
+        mgr.train(opt, epoch, [LRS[0]], 0)
         mark('finetune_train', n)
         done += n
         if val:
@@ -421,7 +425,7 @@ def run_cycle(model, masks, pool, val_pool, steps, clock=None, marks=None, count
     events = 0
     if steps - done > 0:
         mgrB = Manager(make_args('prune', f), model, {}, masks, None, val_pool, 0, window)
-        opt = sgd(1e-3, mgrB.pruner, 0.0)
+        opt = sgd(LRS[1], mgrB.pruner, 0.0)
         step = 0
         for n, val in list(chunks(steps - done)):
             # keep window and recovery steps in separate marks
@@ -429,7 +433,7 @@ def run_cycle(model, masks, pool, val_pool, steps, clock=None, marks=None, count
             for m in parts:
                 mgrB.train_loader = loader(m, done)
                 in_window = step < window
-                _, step = mgrB.train(opt, epoch, [1e-3], step)
+                _, step = mgrB.train(opt, epoch, [LRS[1]], step)
                 mark('prune_window_train' if in_window else 'recovery_train', m)
                 done += m
             if val:
@@ -772,7 +776,7 @@ def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch
     default_threads = torch.get_num_threads()
     all_threads = os.cpu_count() or default_threads
     A = ARCHS[arch]
-    model, pruner, opt, crit = onet.make_task1_net(arch, A['dataset'], A['classes'], 'finetune', lr=1e-2, wd=4e-5)
+    model, pruner, opt, crit = onet.make_task1_net(arch, A['dataset'], A['classes'], 'finetune', lr=A.get('lrs', LRS)[0], wd=4e-5)
     model.train()
     g = torch.Generator().manual_seed(1)
     xfull = torch.randn(batch, 3, A['size'], A['size'], generator=g)
@@ -976,9 +980,10 @@ def main():
             sys.exit('bench.py: --task-sequence runs on one GPU with --arch vgg16')
         print(json.dumps(run_task_sequence(a, device)), flush=True)
         return
-    global DATASET, WIDTH
+    global DATASET, WIDTH, LRS
     arch = ARCHS[a.arch]
     DATASET = arch['dataset']
+    LRS = arch.get('lrs', LRS)
     WIDTH = 1.0 if a.width_multiplier == 1.0 else a.width_multiplier ** 0.5
     nl.set_conv_math(a.math)
     from cpg_amd import _lib
@@ -1111,7 +1116,7 @@ def main():
                           'masked_layer_channels': [int(m.weight.shape[0]) for m in net.modules()
                                                     if isinstance(m, (nl.SharableConv2d, nl.SharableLinear))] if a.width_multiplier != 1.0 else None,
                           'global_batch': global_batch, 'per_gpu_batch': a.batch, 'parallelism': 'dp%d' % world,
-                          'epoch_steps': EPOCH_STEPS, 'cycle': counts,
+                          'epoch_steps': EPOCH_STEPS, 'cycle': counts, 'lr_finetune': LRS[0], 'lr_prune_run': LRS[1],
                           'host_gc': 'collected + frozen after the warm-up (cpg_amd.utils.settle_host_gc, as CPGSession.start_task)'},
                # train steps only, in the ALGORITHMIC flops of SURVEY 8d (Winograd launches execute 16/36 of them, so this can
                # exceed the dense peak; whole_step below prices the step against what the MFMA pipe really had to do)
