@@ -1217,6 +1217,9 @@ def main():
         out['cycle_check'] = {'prune_events': counts.get('prune_events'), 'sparsity_after_cycle': spars,
                               'expected_sparsity': 0.1 if (a.task == 1 and counts.get('prune_events', 0) >= 4) else None,
                               'weights_finite': bool(all(torch.isfinite(p).all() for p in net.parameters()))}
+        if not out['cycle_check']['weights_finite']:
+            # a cycle that left NaN / inf weights times kernels on garbage: say so in the metric itself, not only in cycle_check
+            out['metric'] += ' (INVALID RUN: non-finite weights after the cycle)'
         out['parity_check'] = parity_check(net, pool[0][0], WIDTH) if world == 1 else None
         if a.task == 2:
             out['task2'] = {'task1_ms_per_step': round(task1_ms, 3), 'task2_over_task1': round(1000.0 * dt / a.steps / task1_ms, 4),
