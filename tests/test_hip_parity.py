@@ -2172,6 +2172,51 @@ def test_resnet_spherenet_backward_matches_torch_ops(arch, width, shape, ncls, m
         assert err <= 2e-3 * sc, '%s: max err %g vs scale %g' % (n, err, sc)
 
 
+def test_spherenet_training_trajectory_matches_torch_ops(monkeypatch):
+    """SphereNet-20 at full width (112 x 112, AngleLinear + AngleLoss) through 15 SGD-nesterov steps at the reference's learning rate for
+    this configuration (experiment3/FvGeEm_CPG_face.sh:21-25: 1e-3): the loss trajectory on the HIP kernels (Winograd convs, fused PReLU,
+    skip-gradient epilogue, HeadLinear) against the SAME run on torch's own ops from the same state -- a BatchNorm-free network, so the
+    comparison is not chaotic over this many steps (tools/diag_sph_nan.py: within 1e-3 for 36 steps at batch 256)."""
+    import torch.nn.functional as F
+    from cpg_amd.models import fused_bn
+    from cpg_amd.models.spherenet import AngleLoss
+    g = torch.Generator().manual_seed(4)
+    pool = [(torch.randn(32, 3, 112, 112, generator=g).to(DEV), torch.randint(0, 100, (32,), generator=g).to(DEV)) for _ in range(3)]
+
+    def run():
+        torch.manual_seed(1)
+        net = M.spherenet20(dataset_history=[], dataset2num_classes={}, network_width_multiplier=1.0, shared_layer_info={})
+        net.add_dataset('face_verification', 100)
+        net.set_dataset('face_verification')
+        net = net.to(DEV).train()
+        opt = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9, nesterov=True, weight_decay=4e-5)
+        crit, losses = AngleLoss(), []
+        for i in range(15):
+            x, t = pool[i % 3]
+            opt.zero_grad()
+            loss = crit(net(x), t)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        return losses
+    hip = run()
+    monkeypatch.setattr(fused_bn, 'ENABLED', False)
+    monkeypatch.setattr(nl.SharableConv2d, 'forward',
+                        lambda self, input, layer_info=None, name=None, **kw: F.conv2d(input, self.weight, self.bias, self.stride,
+                                                                                 self.padding, self.dilation, self.groups))
+    monkeypatch.setattr(nl.SharableConv2d, 'forward_with_skip',
+                        lambda self, input, **kw: (F.conv2d(input, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups),
+                                                   None, input))
+    monkeypatch.setattr(nl.HeadLinear, 'forward', nn.Linear.forward)
+    ref = run()
+    assert all(np.isfinite(hip)) and all(np.isfinite(ref))
+    # round-off differences are amplified step by step (PReLU knife edges, a loss that falls from 10 to 4 in 12 steps): measured 3e-7 at
+    # step 0, 1e-3 at step 3, 8e-3 at step 12 on batch 32
+    for i, (a, b) in enumerate(zip(hip, ref)):
+        assert abs(a - b) <= (5e-3 if i < 6 else 5e-2) * abs(b), (i, hip, ref)
+    assert abs(hip[0] - ref[0]) <= 1e-5 * abs(ref[0])
+
+
 @pytest.mark.parametrize('block,stride', [('Bottleneck', 1), ('Bottleneck', 2), ('BasicBlock', 1), ('BasicBlock', 2)])
 def test_resnet_block_fused_bn_equals_stock_bn(block, stride):
     """One residual block in TRAIN mode: the fused BatchNorm(+ReLU) evaluation (main path and conv1x1 -> BN shortcut)
