@@ -632,6 +632,25 @@ def parity_check(net, x, width, images=4):
             'host_seconds': round(time.perf_counter() - t0, 1)}
 
 
+# --task-sequence: per topology the session builder, the task list (dataset, classes, finetune lr, prune-run lr, lr_mask) of the reference's
+# script for that configuration, whether task 1 is the pretrained pass-through and whether tasks >= 2 end with the piggymask
+# retrain (`--finetune_again`: experiment1 only)
+SEQUENCES = {
+    'vgg16': dict(builder='custom_vgg', pass_through_first=False, piggymask_retrain=True,
+                  tasks=[('task%d' % i, 5, 1e-2, 1e-3, 5e-4) for i in range(1, 21)],                   # experiment1/CPG_cifar100_scratch_mul_1.5.sh:46-211
+                  flow='finetune -> prune -> piggymask retrain per task, growth forced once', epochs='1 finetune + 10 prune + 1 retrain from task 2'),
+    'resnet50': dict(builder='resnet50', pass_through_first=True, piggymask_retrain=False,                # experiment2/CPG_imagenet.sh:6-44
+                     tasks=[('imagenet', 1000, 1e-3, 3e-4, 1e-4), ('cubs_cropped', 200, 1e-3, 1e-3, 1e-4), ('stanford_cars_cropped', 196, 1e-2, 1e-3, 1e-4),
+                            ('flowers', 102, 1e-3, 1e-3, 1e-4), ('wikiart', 195, 1e-3, 1e-3, 1e-4), ('sketches', 250, 1e-3, 1e-3, 1e-4)],
+                     flow="configs[3]'s flow: task 1 = pretrained pass-through (claim, validate, no training) + prune run; tasks >= 2 = finetune with "
+                          'piggymasks + prune run', epochs='task 1: 10 prune; tasks >= 2: 1 finetune + 10 prune'),
+    'spherenet20': dict(builder='spherenet20', pass_through_first=True, piggymask_retrain=False,          # experiment3/FvGeEm_CPG_face.sh:7-26,130
+                        tasks=[('face_verification', 4630, 1e-3, 5e-4, 5e-4), ('gender', 3, 5e-4, 5e-4, 5e-4), ('emotion', 7, 5e-4, 5e-4, 5e-4)],
+                        flow="configs[4]'s flow: face_verification (AngleLinear + AngleLoss, pass-through + prune run, evaluated as embeddings) -> gender "
+                             '(nn.Linear + CE) -> emotion (class-weighted CE), per-task bias / PReLU stash', epochs='task 1: 10 prune; tasks >= 2: 1 finetune + 10 prune'),
+}
+
+
 def run_task_sequence(a, device):
     """--task-sequence T: T tasks back to back through cpg_amd.driver.CPGSession at the bench's full size (configs[1]: custom_vgg 224 x 224,
     batch 256), each with the section-8d cycle the headline times for task 1 -- finetune (1 epoch) -> gradual prune 0 -> 0.1 (10 epochs, rank-
@@ -645,10 +664,15 @@ def run_task_sequence(a, device):
     from cpg_amd.driver import CPGSession, default_args
     T = a.task_sequence
     E = max(2, a.steps // 11)                      # steps per epoch: 220 -> 20 (section 8d)
-    sess = CPGSession('custom_vgg', width_multiplier=a.width_multiplier, device=device, seed=1, freeze_gc=True)
+    plan = SEQUENCES[a.arch]
+    if T > len(plan['tasks']):
+        sys.exit('bench.py: --task-sequence %d: the %s sequence has %d tasks' % (T, a.arch, len(plan['tasks'])))
+    sz = ARCHS[a.arch]['size']
+    sess = CPGSession(plan['builder'], width_multiplier=a.width_multiplier, device=device, seed=1, freeze_gc=True)
     g = torch.Generator(device=device).manual_seed(1)
-    xs = [torch.randn(a.batch, 3, 224, 224, generator=g, device=device) for _ in range(3)]
-    xv = [torch.randn(100, 3, 224, 224, generator=g, device=device) for _ in range(2)]
+    xs = [torch.randn(a.batch, 3, sz, sz, generator=g, device=device) for _ in range(3)]
+    xv = [torch.randn(100, 3, sz, sz, generator=g, device=device) for _ in range(2)]
+    grow_at = a.grow_at_task if a.grow_at_task else (T if (a.arch == 'vgg16' and T >= 2) else 0)
 
     class Counting(object):
         def __init__(self, batches):
@@ -663,22 +687,52 @@ def run_task_sequence(a, device):
                 yield b
     tasks = []
     t_all = time.perf_counter()
+    first_logits = {}
+    invariant = {'checked': 0, 'bit_identical': True}
+    # what each task's FIRST rank-prune event saw and did (device-side counts only): when more candidates are exact zeros than the rank k
+    # asks for, the k-th smallest |w| is 0 and `abs(w) <= cutoff` (utils/prune.py:45) releases ALL of them -- the sparsity of that task then
+    # reads above the schedule's target (round 5: 0.396 after a run to 0.1); tests/test_sequence_gpu.py holds the event bit-equal to the oracle
+    first_events = {}
+    orig_rank_prune = SparsePruner._rank_prune_layers
+
+    def spy(self, ratio):
+        first = self.prune_events == 0 and self.current_dataset_idx not in first_events
+        zeros = sum(int(((m.weight.data == 0) & (self.masks[n] == self.current_dataset_idx)).sum()) for n, m in self._layers()) if first else 0
+        recs = orig_rank_prune(self, ratio)
+        if first:
+            first_events[self.current_dataset_idx] = {
+                'ratio': ratio, 'k_total': sum(r['k'] for r in recs), 'released_total': sum(r['n_released'] for r in recs),
+                'owned_slots_exactly_zero_before': zeros, 'layers_with_cutoff_zero': sum(1 for r in recs if r['cutoff'] == 0.0),
+                'released_beyond_k': sum(max(0, r['n_released'] - r['k']) for r in recs)}
+        return recs
+    SparsePruner._rank_prune_layers = spy
     for t in range(1, T + 1):
-        name = 'task%d' % t
-        labels = [torch.randint(0, 5, (a.batch,), generator=g, device=device) for _ in range(3)]
-        vlabels = [torch.randint(0, 5, (100,), generator=g, device=device) for _ in range(2)]
+        name, ncls, lr_ft, lr_pr, lr_mask = plan['tasks'][t - 1]
+        labels = [torch.randint(0, ncls, (a.batch,), generator=g, device=device) for _ in range(3)]
+        vlabels = [torch.randint(0, ncls, (100,), generator=g, device=device) for _ in range(2)]
         train = Counting([(xs[i % 3], labels[i % 3]) for i in range(E)])
         val = [(xv[i], vlabels[i]) for i in range(2)]
-        args = default_args(dataset=name, lr=1e-2, lr_mask=5e-4, prune_lr=1e-3, pruning_frequency=max(1, E // 2), pruning_interval=2,
+        args = default_args(dataset=name, lr=lr_ft, lr_mask=lr_mask, prune_lr=lr_pr, pruning_frequency=max(1, E // 2), pruning_interval=2,
                             network_width_multiplier=sess.width)
-        grow = t == T and T >= 2
+        grow = t == grow_at
+        passthrough = plan['pass_through_first'] and t == 1
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = sess.run_task(name, 5, train, val, accuracy_goal=2.0 if grow else 0.0, finetune_epochs=1, prune_epochs=10, sparsities=(0.1,),
+        res = sess.run_task(name, ncls, train, val, accuracy_goal=2.0 if grow else 0.0, finetune_epochs=1, prune_epochs=10, sparsities=(0.1,),
                             args=args, min_train_acc=-1.0, max_width_multiplier=(sess.width_multiplier + 0.5) if grow else None,
-                            width_step=0.5, retrain_epochs=1, total_num_tasks=T)
+                            width_step=0.5, retrain_epochs=1, total_num_tasks=T, pretrained_pass_through=passthrough,
+                            piggymask_retrain=plan['piggymask_retrain'])
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
+        # CPG's invariant, asserted in the run: every task learnt so far answers BIT-identically to when it was finished
+        first_logits[name] = (val, sess.evaluate(name, val)[1])
+        for older, (oval, outs0) in first_logits.items():
+            outs = sess.evaluate(older, oval)[1]
+            same = all(torch.equal(x_, y_) for x_, y_ in zip(outs0, outs))
+            invariant['checked'] += 1
+            invariant['bit_identical'] = invariant['bit_identical'] and same
+            if not same:
+                invariant.setdefault('broken', []).append('%s after %s' % (older, name))
         hist = torch.zeros(256, dtype=torch.int64, device=device)
         for m in sess.masks.values():
             hist += torch.bincount(m.reshape(-1).long(), minlength=256)
@@ -686,7 +740,7 @@ def run_task_sequence(a, device):
         n_all = sum(hist)
         pr = SparsePruner(sess.model, sess.masks, default_args(mode='inference', dataset=name, network_width_multiplier=sess.width), 0, 0, t)
         owned, older = hist[t], sum(hist[1:t])
-        tasks.append({'task': t, 'train_steps': train.served, 'wall_s': round(wall, 2),
+        tasks.append({'task': t, 'dataset': name, 'num_classes': ncls, 'pass_through': passthrough, 'train_steps': train.served, 'wall_s': round(wall, 2),
                       'wall_ms_per_train_step': round(1000.0 * wall / max(1, train.served), 2),
                       'width_multiplier_raw': sess.width_multiplier, 'width_multiplier_rooted': round(sess.width, 6), 'grown_to': res.grown_to,
                       'masked_weights': n_all, 'owner_histogram': {str(i): c for i, c in enumerate(hist) if c},
@@ -698,18 +752,24 @@ def run_task_sequence(a, device):
                                                     'dense_with_piggymasks': (8 if t > 1 else 4) * n_all},
                       'channels': [int(m.weight.shape[0]) for m in sess.net.modules() if isinstance(m, (nl.SharableConv2d, nl.SharableLinear))][:14:3]})
     torch.cuda.synchronize()
+    SparsePruner._rank_prune_layers = orig_rank_prune
+    for t_ in tasks:
+        t_['first_rank_prune_event'] = first_events.get(t_['task'])
     total = time.perf_counter() - t_all
     steps = sum(t['train_steps'] for t in tasks)
     # every earlier task still answers exactly as it did: evaluate task 1 on its own (cropped) network before / after is the driver test's
     # job (tests/test_driver_gpu.py); here: the logits of task 1 are finite and its head reads the narrow share of the features
-    acc1, logits1 = sess.evaluate('task1', [(xv[0], torch.zeros(100, dtype=torch.long, device=device))])
-    return {'metric': 'images/sec over a %d-task CPG sequence through CPGSession, VGG16 224x224 batch %d (NOT the headline metric: finetune -> prune '
-                      '-> piggymask retrain per task, growth forced on the last task)' % (T, a.batch),
+    acc1, logits1 = sess.evaluate(plan['tasks'][0][0], [(xv[0], torch.zeros(100, dtype=torch.long, device=device))])
+    finite = bool(all(torch.isfinite(p).all() for p in sess.net.parameters()))
+    return {'metric': 'images/sec over a %d-task CPG sequence through CPGSession, %s %dx%d batch %d (NOT the headline metric: %s)'
+                      % (T, a.arch, sz, sz, a.batch, plan['flow']),
+            'valid': finite and invariant['bit_identical'], 'weights_finite': finite, 'earlier_tasks_bit_identical': invariant,
             'value': round(a.batch * steps / total, 2), 'unit': 'images/sec', 'n_gpus': 1, 'steps': steps, 'warmup': 0,
             'ms_per_step': round(1000.0 * total / steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'data': 'synthetic',
-            'dtype': 'f32', 'config': {'workload': 'configs[1]: VGG16-BN custom_vgg 224x224, %d-task sequence (epochs of %d steps: 1 finetune + 10 prune '
-                                                   '+ 1 retrain from task 2, validate after every epoch), batch %d' % (T, E, a.batch),
-                                       'tasks': T, 'epoch_steps': E, 'per_gpu_batch': a.batch, 'start_width_multiplier_raw': a.width_multiplier},
+            'dtype': 'f32', 'config': {'workload': '%s, %d-task sequence %s (epochs of %d steps: %s, validate after every epoch), batch %d'
+                                                   % (ARCHS[a.arch]['workload'], T, [p_[0] for p_ in plan['tasks'][:T]], E, plan['epochs'], a.batch),
+                                       'arch': a.arch, 'tasks': T, 'epoch_steps': E, 'per_gpu_batch': a.batch, 'grow_at_task': grow_at,
+                                       'start_width_multiplier_raw': a.width_multiplier},
             'tasks': tasks, 'task1_after_sequence': {'logits_finite': bool(all(torch.isfinite(o).all() for o in logits1)), 'accuracy': acc1},
             'note': 'wall time includes validates, snapshots, the ratio choice, the growth rebuild (last task: a finetune at the old width, then '
                     'the wider model) -- everything CPGSession.run_task does; the cycle-only step time of a task is the headline bench / --task 2'}
@@ -757,9 +817,10 @@ def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch
     """Oracle ("port") of the same cycle on the host cores, reported beside the GPU number (never the target).
     oracle/ is only ever used here as the measured CPU baseline.
 
-    1. Thread setting: >= 3 timed train steps at `probe_batch` (32 under 'full', 64 under 'quick') under BOTH settings -- torch's
-       default for the host (one thread per physical core) and SURVEY 8d's os.cpu_count() (every SMT thread); the faster is used below, both rates are fields.
-    2. level 'full' (default): 3 timed train steps (after one warm-up step) at the GPU's own batch (256) under that setting -- section
+    1. Thread setting: 3 timed train steps at `probe_batch` (32 under 'full', 64 under 'quick') under torch's default for the host (one
+       thread per physical core); SURVEY 8d's os.cpu_count() (every SMT thread) gets one 8-image step first and the full 3-step probe only
+       when that is within 2 x of the default's rate (it has been 4 - 6 x slower on every box); the faster is used below, both rates are fields.
+    2. level 'full' (default): 2 timed train steps (after one warm-up step) at the GPU's own batch (256) under that setting -- section
        8d's configuration, no batch extrapolation; `value` is built on this rate.  level 'quick': step 2 is skipped and the probe
        rate is used (`extrapolated_from_probe_batch`: true).
     3. One rank-prune event over all 15 layers, one validate batch of 100 (apply_mask + eval forward).
@@ -797,6 +858,15 @@ def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch
             settings[name] = dict(settings['default'])
             continue
         torch.set_num_threads(threads)
+        if name == 'cpu_count':
+            # every SMT thread has been 4 - 6 x SLOWER than one thread per core on every box so far (r05: 0.57 vs 3.38 images/s, 168 s of
+            # host time for the 3-step probe): one step at 8 images first; only a setting within 2 x of the default gets the full probe
+            x8, t8 = x[:8].contiguous(), t[:8].contiguous()
+            dt = timed_steps(x8, t8, 1, warm=False)
+            if 8 / dt < 0.5 * settings['default']['train_images_per_sec']:
+                settings[name] = {'threads': threads, 'train_steps_timed': 1, 'probe_batch': 8, 'seconds': round(dt, 2),
+                                  'train_images_per_sec': round(8 / dt, 3)}
+                continue
         dt = timed_steps(x, t, 3, warm=(i == 0))
         settings[name] = {'threads': threads, 'train_steps_timed': 3, 'seconds': round(dt, 2), 'train_images_per_sec': round(probe_batch * 3 / dt, 3)}
     best = max(settings, key=lambda k: settings[k]['train_images_per_sec'])
@@ -805,8 +875,8 @@ def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch
     probe_ips = settings[best]['train_images_per_sec']
     full = None
     if level == 'full':
-        dt = timed_steps(xfull, tfull, 3, warm=True)
-        full = {'batch': batch, 'threads': threads, 'train_steps_timed': 3, 'seconds': round(dt, 2), 'train_images_per_sec': round(batch * 3 / dt, 3)}
+        dt = timed_steps(xfull, tfull, 2, warm=True)          # (1 warm-up + 2 timed steps of ~70 s each: the step time repeats within 1 %)
+        full = {'batch': batch, 'threads': threads, 'train_steps_timed': 2, 'seconds': round(dt, 2), 'train_images_per_sec': round(batch * 2 / dt, 3)}
     train_ips = full['train_images_per_sec'] if full else probe_ips
     # one rank-prune event (utils/prune.py:30-53 on every masked layer: boolean gather + k-th value + masked assign)
     t0 = time.time()
@@ -840,12 +910,13 @@ def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch
             'probe_batch': probe_batch, 'gpu_batch': batch, 'full_batch_sample': full, 'extrapolated_from_probe_batch': full is None,
             'train_images_per_sec': round(train_ips, 3), 'prune_event_s': round(prune_s, 2), 'validate_images_per_sec': round(100 / val_s, 2),
             'plumbing': plumbing,
-            'sample': '3 + 3 train steps (fwd + bwd + gradient routing + SGD-nesterov) at batch %d under %d / %d threads%s + 1 rank-prune event '
+            'sample': '3 train steps (fwd + bwd + gradient routing + SGD-nesterov) at batch %d under %d threads, a 1-step look at %d threads (3 steps when it '
+                      'is within 2 x)%s + 1 rank-prune event '
                       'over the %d masked layers (%.1f s) + 1 validate batch of 100 (apply_mask + eval forward, %.1f s) of the oracle %s %dx%d, '
                       'torch-CPU fp32; value = the %d-step cycle the GPU ran (%d prune events, %d validates of 2 x 100 images) priced with the '
                       '%s train rate'
                       % (probe_batch, default_threads, all_threads,
-                         (', then 1 warm-up + 3 timed train steps at batch %d under %d threads' % (batch, threads)) if full else '',
+                         (', then 1 warm-up + 2 timed train steps at batch %d under %d threads' % (batch, threads)) if full else '',
                          n_layers, prune_s, val_s, {'vgg16': 'VGG16-BN', 'resnet50': 'ResNet-50', 'spherenet20': 'SphereNet-20 (AngleLinear head + AngleLoss)'}[arch],
                          A['size'], A['size'], steps, prune_events, validates, 'batch-%d' % batch if full else 'probe-batch')}
 
@@ -894,6 +965,46 @@ def predict_step_ms(arch, world, buckets, measured_single_gpu_ms=None, batch=256
                      'messages priced at payload / algbw + 30 us' % OVERLAP_SLOWDOWN}
 
 
+OTHER_WORKLOADS = [('resnet50', ['--arch', 'resnet50']), ('spherenet20', ['--arch', 'spherenet20']),
+                   ('vgg16_grown_1.5', ['--width-multiplier', '1.5']), ('vgg16_task2', ['--task', '2'])]
+
+
+def other_workloads(steps, warmup, timeout_s=240):
+    """The other single-GPU workloads of BASELINE.json's configs through the SAME cycle, each in its own `python bench.py` process started
+    after the headline's timed region (this process idles meanwhile; nothing of it is inside any timed region): configs[3]'s topology
+    (ResNet-50), configs[4]'s (SphereNet-20, at the reference's lrs), the GROWN VGG16 (raw multiplier 1.5: where most of configs[1]'s 20
+    tasks run) and the task-2 cycle (piggymasks + Adam).  A summary of each child's own JSON line; the full line is what
+    `python bench.py <flags>` prints."""
+    import subprocess
+    res = {}
+    for name, flags in OTHER_WORKLOADS:
+        cmd = [sys.executable, os.path.abspath(__file__)] + flags + ['--steps', str(steps), '--warmup', str(warmup), '--no-cpu-baseline',
+                                                                     '--optin-steps', '0', '--no-other-workloads']
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            line = [ln for ln in p.stdout.decode(errors='replace').splitlines() if ln.startswith('{')]
+            if p.returncode != 0 or not line:
+                res[name] = {'error': 'rc %d: %s' % (p.returncode, p.stderr.decode(errors='replace')[-300:]), 'flags': flags}
+                continue
+            d = json.loads(line[-1])
+            ws, rf, pc, cc = d.get('whole_step') or {}, d.get('roofline') or {}, d.get('parity_check') or {}, d.get('cycle_check') or {}
+            res[name] = {'flags': ' '.join(flags), 'metric': d['metric'], 'value': d['value'], 'unit': d['unit'], 'valid': d.get('valid'),
+                         'ms_per_step': d['ms_per_step'], 'steps': d['steps'],
+                         'whole_step': {'frac_of_dense_fp32_mfma_peak': ws.get('frac_of_dense_fp32_mfma_peak')},
+                         'roofline': {'kernel': rf.get('kernel'), 'frac': rf.get('frac'), 'achieved': rf.get('achieved'), 'peak': rf.get('peak')},
+                         'parity_check': {'ok': pc.get('ok'), 'max_rel_logit_err': pc.get('max_rel_logit_err')},
+                         'cycle_check': {'weights_finite': cc.get('weights_finite'), 'prune_events': cc.get('prune_events')},
+                         'per_gpu_batch': (d.get('config') or {}).get('per_gpu_batch'), 'process_seconds': round(time.perf_counter() - t0, 1)}
+            if d.get('task2'):
+                res[name]['task2_over_task1'] = d['task2'].get('task2_over_task1')
+        except subprocess.TimeoutExpired:
+            res[name] = {'error': 'timed out after %d s' % timeout_s, 'flags': flags}
+        except Exception as e:                                # a broken child must not take the headline line with it
+            res[name] = {'error': repr(e)[:300], 'flags': flags}
+    return res
+
+
 def _free_port():
     import socket
     sk = socket.socket()
@@ -924,6 +1035,9 @@ def main():
     ap.add_argument('--task-sequence', type=int, default=0,
                     help='T > 0: T tasks back to back through cpg_amd.driver.CPGSession at full size, growth forced on the last one; prints its '
                          'own JSON line (per-task step time, owner-id histogram, shared_ratio, data-parallel payload) instead of the cycle bench')
+    ap.add_argument('--grow-at-task', type=int, default=0,
+                    help='--task-sequence: force the growth step (exit code 2 -> raw multiplier + 0.5) on this task (default: the last task of a '
+                         'vgg16 sequence, never on the other topologies)')
     ap.add_argument('--arch', default='vgg16', choices=sorted(ARCHS),
                     help="topology of the cycle: 'vgg16' = the headline (BASELINE.json configs[1]); 'resnet50' / 'spherenet20' = the "
                          'topologies of configs[3] / configs[4] through the same cycle (their own lines, never the headline)')
@@ -934,8 +1048,12 @@ def main():
                     help='after the timed cycle, also time this many train steps in each opt-in conv arithmetic (reported beside the '
                          'headline as opt_in_conv_math, never as value); 0 = skip')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-workloads', action='store_true',
+                    help='the default headline run (vgg16, task 1, width 1.0, one GPU) also runs 20-step cycles of the other single-GPU '
+                         "workloads (resnet50, spherenet20, the grown VGG16, task 2) in child processes after its own timed region and reports "
+                         'them under "other_workloads"; this flag skips that')
     ap.add_argument('--cpu-baseline', default='full', choices=['full', 'quick'],
-                    help="'full' (default, ~8 min of host time): SURVEY 8d's CPU baseline -- 3 train steps at batch 256 on the faster thread "
+                    help="'full' (default, ~6 min of host time): SURVEY 8d's CPU baseline -- 2 timed train steps at batch 256 on the faster thread "
                          "setting + BASELINE.md section 4's configs[0] plumbing cycle; 'quick': the batch-64 probe only (~1.5 min)")
     ap.add_argument('--no-kernel-clock', action='store_true')
     ap.add_argument('--clock-every', type=int, default=4,
@@ -976,8 +1094,8 @@ def main():
     device = torch.device('cuda', torch.cuda.current_device())
 
     if a.task_sequence > 0:
-        if world != 1 or a.arch != 'vgg16':
-            sys.exit('bench.py: --task-sequence runs on one GPU with --arch vgg16')
+        if world != 1:
+            sys.exit('bench.py: --task-sequence runs on one GPU')
         print(json.dumps(run_task_sequence(a, device)), flush=True)
         return
     global DATASET, WIDTH, LRS
@@ -1158,13 +1276,14 @@ def main():
             # so its algorithmic ceiling is 2.25 x the dense MFMA peak; a direct launch's is the dense peak.  Weighted by MFMA
             # time that is dense_peak x (algorithmic flops / executed flops) -- and achieved / peak == executed rate / dense peak.
             peak = dense * fl / ex
-            out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': round(peak, 2),
-                               'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                               'achieved_executed': round(exe, 2), 'peak_dense': dense,
+            out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(exe, 2), 'peak': dense,
+                               'unit': 'TFLOP/s', 'frac': round(exe / dense, 4),
+                               'achieved_algorithmic': round(ach, 2), 'launch_mix_ceiling': round(peak, 2),
                                'winograd_share_of_algorithmic_flops': round((fl - ex) / (fl * (1 - 16.0 / 36.0)), 4),
-                               'note': 'achieved = algorithmic flops of the launches / their HIP-event time; peak = the launch-mix ceiling '
-                                       '(dense fp32 MFMA peak x algorithmic / executed flops: Winograd F(2x2,3x3) launches execute 16/36 of '
-                                       'their algorithmic multiply-adds); frac = achieved / peak = achieved_executed / peak_dense',
+                               'note': 'achieved = multiply-adds the MFMA pipe EXECUTED (x 2) / HIP-event time of the launches; peak = the dense fp32 '
+                                       'MFMA peak of the guide.  achieved_algorithmic counts SURVEY 8d\'s flops instead (a Winograd F(2x2,3x3) launch '
+                                       'executes 16/36 of them, so it can exceed the dense peak); launch_mix_ceiling = dense peak x algorithmic / '
+                                       'executed.  frac = achieved / peak = achieved_algorithmic / launch_mix_ceiling',
                                'traffic': (traffic or {}).get('hbm_bytes_per_launch'),
                                'traffic_source': 'static: %s (rocprofv3 --pmc passes of this workload, committed; not collected in this run)'
                                                  % traffic['source'] if traffic else None,
@@ -1217,9 +1336,12 @@ def main():
         out['cycle_check'] = {'prune_events': counts.get('prune_events'), 'sparsity_after_cycle': spars,
                               'expected_sparsity': 0.1 if (a.task == 1 and counts.get('prune_events', 0) >= 4) else None,
                               'weights_finite': bool(all(torch.isfinite(p).all() for p in net.parameters()))}
+        out['valid'] = True
         if not out['cycle_check']['weights_finite']:
-            # a cycle that left NaN / inf weights times kernels on garbage: say so in the metric itself, not only in cycle_check
+            # a cycle that left NaN / inf weights times kernels on garbage: no throughput is reported for it (machine-readable: valid false,
+            # value null, the measured number under invalid_value) and the metric string says so too
             out['metric'] += ' (INVALID RUN: non-finite weights after the cycle)'
+            out['valid'], out['invalid_value'], out['value'] = False, out['value'], None
         out['parity_check'] = parity_check(net, pool[0][0], WIDTH) if world == 1 else None
         if a.task == 2:
             out['task2'] = {'task1_ms_per_step': round(task1_ms, 3), 'task2_over_task1': round(1000.0 * dt / a.steps / task1_ms, 4),
@@ -1230,6 +1352,11 @@ def main():
                                     'fresh piggymasks), train steps only, timed after the cycle'}
         if a.math == 'fp32' and world == 1 and a.optin_steps > 0 and a.arch == 'vgg16' and a.task == 1 and a.batch == 256 and a.width_multiplier == 1.0:
             out['opt_in_conv_math'] = optin_modes(model, masks, pool, a.optin_steps, a.batch)
+        if (not a.no_other_workloads and world == 1 and a.arch == 'vgg16' and a.task == 1 and a.width_multiplier == 1.0 and a.batch == 256
+                and a.math == 'fp32'):
+            # free this process's cached blocks first: the children allocate their own pools on the same GPU
+            torch.cuda.empty_cache()
+            out['other_workloads'] = other_workloads(20, a.warmup)
         if not a.no_cpu_baseline and world == 1:
             if a.task == 1 and a.width_multiplier == 1.0:
                 out['cpu_baseline'] = cpu_baseline(steps=a.steps, batch=a.batch, validates=counts['validates'],

@@ -106,7 +106,7 @@ class CPGSession(object):
             self.width_multiplier, self.width = float(width_multiplier), math.sqrt(width_multiplier)      # (:115)
         else:
             self.width = 1.0 if width is None else width
-            self.width_multiplier = self.width * self.width
+            self.width_multiplier = round(self.width * self.width, 9)     # (sqrt(1.5) ** 2 = 1.4999999999999998 must still read as the 1.5 cap)
         self.arch, self.device = arch, torch.device(device)
         self.cfg = cfg
         self.seed = seed
@@ -157,6 +157,8 @@ class CPGSession(object):
         if dataset not in self.shared_layer_info:
             self.shared_layer_info[dataset] = {k: {} for k in ('bias', 'bn_layer_running_mean', 'bn_layer_running_var',
                                                                'bn_layer_weight', 'bn_layer_bias', 'piggymask')}
+            if any(isinstance(m, nn.PReLU) for m in self.net.modules()):
+                self.shared_layer_info[dataset]['prelu_layer_weight'] = {}          # (CPG_face_main.py:253-262)
             if task_id > 1:
                 self._fresh_piggymasks()
             else:
@@ -253,6 +255,7 @@ class CPGSession(object):
         model with sqrt(raw); weights and BatchNorm vectors land in the top-left corner (utils/manager.py:233-264), the new rows /
         columns keep their fresh initialisation, owner masks are zero-padded = the new slots are free
         (CPG_cifar100_main_normal.py:208-232)."""
+        assert new_width_multiplier >= self.width_multiplier - 1e-9, 'grow() takes the RAW multiplier (bash adds 0.5 to it), and only widens'
         new_width = math.sqrt(new_width_multiplier)
         datasets = list(snap.datasets) if snap is not None else []
         d2n = dict(snap.dataset2num_classes) if snap is not None else {}
@@ -278,18 +281,36 @@ class CPGSession(object):
     def _manager(self, args, train_loader, val_loader, begin, end):
         return Manager(args, self.model, self.shared_layer_info, self.masks, train_loader, val_loader, begin, end)
 
-    def finetune(self, args, train_loader, val_loader, epochs, lr_drops=(50, 80), patience=5):
+    def _validate(self, mgr, epoch):
+        """Manager.validate -- except for the `face_verification` task, whose evaluation in the reference is evalLFW
+        (CPG_face_main.py:337-341,370-373,403-404,417; utils/manager.py:156-195): apply_mask + eval-mode embeddings.  The embeddings are
+        kept in `self.last_embeddings`; `self.embedding_scorer` (a callable taking that list, e.g. an LFW pair scorer on the host) turns
+        them into the accuracy the goal / early-stop logic compares -- without one the phase reports 0.0."""
+        if mgr.args.dataset != 'face_verification':
+            return mgr.validate(epoch)
+        self.last_embeddings = mgr.eval_embeddings(epoch)
+        scorer = getattr(self, 'embedding_scorer', None)
+        return float(scorer(self.last_embeddings)) if scorer is not None else 0.0
+
+    def finetune(self, args, train_loader, val_loader, epochs, lr_drops=(50, 80), patience=5, pass_through=False):
         """`--mode finetune` (:386-388, :401-444).  Returns (manager, last train acc, last val acc).  With
         args.finetune_again (the piggymask retrain) the best epoch is kept as a snapshot and training stops after
-        `patience` epochs without improvement (:407-429); `self.last_retrain` = (best val acc, snapshot or None)."""
+        `patience` epochs without improvement (:407-429); `self.last_retrain` = (best val acc, snapshot or None).
+        pass_through=True is the first task of experiment2 / experiment3: the weights are a pretrained model's, the task only
+        CLAIMS every slot (make_finetuning_mask), validates and is saved -- no training step (CPG_imagenet_main.py:411-414,
+        CPG_face_main.py:403-406)."""
         args = copy.copy(args)
         args.mode = 'finetune'
         mgr = self._manager(args, train_loader, val_loader, 0, 0)
         best, best_snap, stale = None, None, 0
+        if pass_through:
+            mgr.pruner.make_finetuning_mask()
+            self.last_retrain = (None, None)
+            return mgr, 0.0, self._validate(mgr, 0)
         if not args.finetune_again:
             mgr.pruner.make_finetuning_mask()
         else:
-            best = mgr.validate(-1)
+            best = self._validate(mgr, -1)
         opts = self.make_optimizers(args, mgr.pruner)
         lrs = list(opts.lrs)
         stop_lr_mask = mgr.pruner.calculate_curr_task_ratio() != 0.0
@@ -297,7 +318,7 @@ class CPGSession(object):
         step = 0
         for epoch in range(epochs):
             tr, step = mgr.train(opts, epoch, lrs, step)
-            va = mgr.validate(epoch)
+            va = self._validate(mgr, epoch)
             if args.finetune_again:
                 if va > best:
                     best, stale = va, 0
@@ -329,14 +350,14 @@ class CPGSession(object):
         args.lr, args.lr_mask = getattr(args, 'prune_lr', 1e-3), 0.0
         steps_per_epoch = len(train_loader)
         mgr = self._manager(args, train_loader, val_loader, 0, args.pruning_interval * steps_per_epoch)
-        mgr.validate(-1)
+        self._validate(mgr, -1)
         opts = self.make_optimizers(args, mgr.pruner)
         lrs = list(opts.lrs)
         tr = va = 0.0
         step = 0
         for epoch in range(epochs):
             tr, step = mgr.train(opts, epoch, lrs, step)
-            va = mgr.validate(epoch)
+            va = self._validate(mgr, epoch)
         return mgr, tr, va
 
     def evaluate(self, dataset, val_loader, crop=True):
@@ -346,7 +367,8 @@ class CPGSession(object):
         the task's index).  The live training model is not touched.  Returns (accuracy, logits of every batch).
         crop=False serves the task from a model of the CURRENT (grown) width instead -- what a server that keeps one
         resident network for all tasks does: apply_mask zeroes every slot of later tasks, the inference conv kernels skip
-        the channels that died with them (cpg_conv2d_fwd_bn_eval), and the head reads the task's own share of the features."""
+        the channels that died with them (cpg_conv2d_fwd_bn_eval), and the head reads the task's own share of the features.
+        The `face_verification` task returns (0.0 or the scorer's value, embeddings of every batch): its evaluation is evalLFW's."""
         info = self.shared_layer_info[dataset]
         width = info.get('network_width_multiplier', self.width) if crop else self.width
         saved_info = self.shared_layer_info
@@ -359,6 +381,9 @@ class CPGSession(object):
         ckpt.resize_masks(model, masks, 'inference')
         args = default_args(mode='inference', dataset=dataset, network_width_multiplier=width)
         mgr = Manager(args, model, saved_info, masks, None, val_loader, 0, 0)
+        if dataset == 'face_verification':
+            acc = self._validate(mgr, 0)
+            return acc, self.last_embeddings
         outs = []
         h = model.register_forward_hook(lambda m, i, o: outs.append(o.detach() if torch.is_tensor(o) else o))
         acc = mgr.validate(0)
@@ -367,13 +392,16 @@ class CPGSession(object):
 
     def run_task(self, dataset, num_classes, train_loader, val_loader, accuracy_goal=0.0, finetune_epochs=1,
                  prune_epochs=1, sparsities=(0.1, 0.2, 0.3), args=None, min_train_acc=0.95, allow_acc_loss=0.0,
-                 max_width_multiplier=None, width_step=0.5, retrain_epochs=1, total_num_tasks=None):
+                 max_width_multiplier=None, width_step=0.5, retrain_epochs=1, total_num_tasks=None, pretrained_pass_through=False,
+                 piggymask_retrain=True):
         """finetune [-> grow and retry] -> prune sweep -> choose ratio -> (task >= 2) piggymask retrain -> keep the better.
 
         accuracy_goal plays baseline_cifar100_acc.txt's role, min_train_acc the reference's hard-coded 0.95
         (CPG_cifar100_main_normal.py:452,469,487), max_width_multiplier its --max_allowed_network_width_multiplier (None: never
         grow) and width_step the 0.5 bash adds per exit 2 -- both in RAW multiplier units, as on the reference's command line --,
-        total_num_tasks its --total_num_tasks (forced pruning at the width cap, :494-506)."""
+        total_num_tasks its --total_num_tasks (forced pruning at the width cap, :494-506).
+        pretrained_pass_through: the first task of experiment2 / experiment3 -- no finetune training, see finetune(); piggymask_retrain=False:
+        their task >= 2 flow, which has no `--finetune_again` pass (experiment2/CPG_imagenet.sh, experiment3/FvGeEm_CPG_face.sh)."""
         res = TaskResult()
         args = args or default_args()
         args = copy.copy(args)
@@ -383,11 +411,11 @@ class CPGSession(object):
         while True:
             args.network_width_multiplier = self.width
             task_id = self.start_task(dataset, num_classes)
-            mgr, tr, va = self.finetune(args, train_loader, val_loader, finetune_epochs)
+            mgr, tr, va = self.finetune(args, train_loader, val_loader, finetune_epochs, pass_through=pretrained_pass_through)
             res.finetune_acc, res.finetune_train_acc = va, tr
             res.ratio_to_acc = {0.0: round(va, 4)}
-            at_cap = self.width_multiplier >= max_raw
-            if (tr > min_train_acc and va >= accuracy_goal) or at_cap:
+            at_cap = self.width_multiplier >= max_raw - 1e-9
+            if (tr > min_train_acc and va >= accuracy_goal) or at_cap or pretrained_pass_through:
                 # capacity is enough -- or the width cap is reached, where the reference carries on with what it has
                 # (exit 0 / 5, :474-478; a train accuracy below the bar at the cap would make its bash loop exit 2 forever)
                 break
@@ -405,7 +433,7 @@ class CPGSession(object):
         stages = {}
         prev = 0.0
         must = 0.0
-        if self.width_multiplier >= max_raw and va < accuracy_goal and total_num_tasks:
+        if self.width_multiplier >= max_raw - 1e-9 and va < accuracy_goal and total_num_tasks:
             remain = total_num_tasks - len(self.net.datasets)
             must = 1.0 - round(1.0 / (remain + 1), 1)               # :494-506
         for s in sparsities:
@@ -420,12 +448,12 @@ class CPGSession(object):
             if must and s >= must:
                 break
         # ---- tools/choose_appropriate_pruning_ratio_for_next_task.py: sparsest recorded ratio that holds the goal
-        forced = self.width_multiplier >= max_raw and res.ratio_to_acc[0.0] < accuracy_goal
+        forced = self.width_multiplier >= max_raw - 1e-9 and res.ratio_to_acc[0.0] < accuracy_goal
         res.chosen_ratio = choose_ratio(res.ratio_to_acc, accuracy_goal, allow_acc_loss, forced)
         self.restore(stages[res.chosen_ratio] if res.chosen_ratio else scratch)
         self.commit_task(dataset)
         # ---- task >= 2: retrain the piggymasks (and the task's weights); keep it only if it improves (choose_retrain_or_not.py)
-        if task_id > 1:
+        if task_id > 1 and piggymask_retrain:
             again = copy.copy(args)
             again.finetune_again, again.lr_mask, again.lr = True, 1e-4, getattr(args, 'prune_lr', 1e-3)
             pruned = self.snapshot()

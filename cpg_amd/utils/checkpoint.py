@@ -44,8 +44,10 @@ def collect_task_layers(model, shared_layer_info, dataset):
     training the very same BatchNorm / bias / PReLU tensors, so COPIES are stored: `shared_layer_info[task]` is what the
     task looked like when it was collected, whatever trains afterwards (CPG's no-forgetting property depends on it)."""
     info = shared_layer_info.setdefault(dataset, {})
+    has_prelu = any(isinstance(m, nn.PReLU) for m in _root(model).modules())
     for k in _TASK_KEYS:
-        info.setdefault(k, {})
+        if k != 'prelu_layer_weight' or has_prelu:      # (only CPG_face_main.py:253-262 creates that key: the file keeps the reference's key set)
+            info.setdefault(k, {})
     info['piggymask'] = {}                       # a task whose piggymasks were dropped must not keep stale ones
     for name, module in _root(model).named_modules():
         if _masked(module):

@@ -194,6 +194,31 @@ class Manager(object):
                           + ', '.join(['{}: {}'.format(k, v) for k, v in summary.items()])))
         return val_accuracy.avg.item()
 
+    def eval_embeddings(self, epoch_idx=0):
+        """The device half of the reference's evalLFW (utils/manager.py:156-175), which is what CPG_face_main.py runs instead of
+        `validate` for the `face_verification` task (:337-341,:370-373,:417): apply_mask() first, eval mode, then
+        `forward_to_embeddings` of every validation batch.  Returns the list of embedding tensors (on the device); scoring them as
+        LFW pairs (utils/metrics.py: 10-fold ROC on the host with sklearn) needs the real pairs and is out of scope.  A loader
+        that yields (a, p, label) pairs, as the reference's LFWDataset does, gives a list of (emb_a, emb_p, label)."""
+        self.pruner.apply_mask()
+        if hasattr(self.model, 'sync_buffers'):
+            self.model.sync_buffers()
+        self.model.eval()
+        root = self.model.module if hasattr(self.model, 'module') else self.model
+        out = []
+        with torch.no_grad():
+            for batch in self.val_loader:
+                if len(batch) == 3:
+                    a, p, label = batch
+                    a, p = self._to_device(a, p)
+                    out.append((root.forward_to_embeddings(a), root.forward_to_embeddings(p), label))
+                else:
+                    data, _ = self._to_device(*batch)
+                    out.append(root.forward_to_embeddings(data))
+                self.last_stats = {'sparsity': self.pruner.calculate_sparsity(),
+                                   'task{} ratio'.format(self.inference_dataset_idx): self.pruner.calculate_curr_task_ratio()}
+        return out
+
     # ------------------------------------------------------------------ checkpoints (utils/manager.py:198-320)
     def _path(self, folder, epoch):
         return self.args.checkpoint_format.format(save_folder=folder, epoch=epoch)

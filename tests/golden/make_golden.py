@@ -879,12 +879,297 @@ def gen_full_width_logits():
         save('full_width_logits_' + arch, x=x, y=y, param_digest=digest, num_classes=ncls, width=1.0, **arrs)
 
 
+# --------------------------------------------------------------------------
+# 18. configs[3] / configs[4] AS SEQUENCES (round 6): ResNet-50 imagenet -> cubs_cropped, SphereNet-20 face_verification -> gender ->
+#     emotion, every phase one "process" of the reference: state is handed over ONLY through checkpoint files written by the reference's
+#     Manager.save_checkpoint and read back by its load_checkpoint / load_checkpoint_only_for_evaluate, the per-phase set-up is main()'s
+#     (CPG_imagenet_main.py:170-380, CPG_face_main.py:150-345: restated below in this script's own words -- it is inline code of main(), not
+#     callable), train / validate / prune are the reference's Manager and SparsePruner.
+#       task 1          = pretrained-weights pass-through: make_finetuning_mask, validate, save -- NO training
+#                         (CPG_imagenet_main.py:411-414, CPG_face_main.py:403-406), then a gradual-prune run
+#       task >= 2       = finetune with piggymask Parameters (full(0.01), Adam) over the older tasks' frozen weights, then a prune run
+#       loss / head     = face_verification: Sequential(Linear, AngleLinear) + AngleLoss; gender: nn.Linear + CE; emotion: nn.Linear +
+#                         class-weighted CE (utils/manager.py:29-36, models/spherenet.py:160-192)
+#       inference       = per task: model of the task's width, load_checkpoint_only_for_evaluate (re-attaches the task's bias / BatchNorm /
+#                         PReLU tensors, utils/manager.py:301-319), the task's piggymasks from shared_layer_info (main(): else-branch of the
+#                         piggymask set-up), validate.  The face task has no classification validate (evalLFW needs LFW pairs + sklearn):
+#                         its device half -- apply_mask, eval-mode forward_to_embeddings (utils/manager.py:156-175) -- is recorded instead.
+#     Deviations, all so that 5-step phases exercise every branch: lr_mask 2e-3 (the scripts' 1e-4 / 5e-4 would need > 10 Adam steps to take
+#     a piggymask from 0.01 below the 5e-3 threshold), pruning_frequency 1, the "pretrained" weights are the seeded initialisation
+#     (ResNet-50: the He re-draw of reinit_resnet + BatchNorm statistics off their initial values), SphereNet-20's weight learning rate is
+#     5e-5 instead of the script's 5e-4 (this BatchNorm-free net at 4 samples is chaotic at 5e-4: the AngleLoss went 6.5 -> 36.7 -> 11.7, so
+#     a replay on other arithmetic could not be compared step by step), checkpoints are saved at the end of a
+#     phase (the scripts keep the best-validation epoch: policy).
+# --------------------------------------------------------------------------
+SEQ_FMT = '{save_folder}/checkpoint-{epoch}.pth.tar'
+SEQ_CASES = {
+    'resnet50': dict(width=0.125, shape=(3, 64, 64), batch=8, steps=5, lr_mask=2e-3,
+                     tasks=[('imagenet', 6, None, 3e-4), ('cubs_cropped', 5, 1e-3, 1e-3)]),
+    'spherenet20': dict(width=0.0625, shape=(3, 112, 112), batch=4, steps=5, lr_mask=2e-3,
+                        tasks=[('face_verification', 10, None, 5e-5), ('gender', 3, 5e-5, 5e-5), ('emotion', 7, 5e-5, 5e-5)]),
+}
+SEQ_INFO_KEYS = ('bias', 'bn_layer_running_mean', 'bn_layer_running_var', 'bn_layer_weight', 'bn_layer_bias', 'piggymask')
+
+
+def _seq_is_masked(mod):
+    return isinstance(mod, (nl.SharableConv2d, nl.SharableLinear))
+
+
+def _seq_process(arch, case, mode, dataset, ncls, load_dir, save_dir, train, val, lr, initial=0.0, target=0.0, pretrained=None):
+    """One `python CPG_{imagenet,face}_main.py --mode ...` process.  Returns a record of what it computed."""
+    import torch.optim as optim
+    from torch.nn.parameter import Parameter
+    from utils.manager import Manager
+    width = case['width']
+    if load_dir:                                                   # previous phase's checkpoint: history, owner masks, per-task tensors
+        ck = torch.load(SEQ_FMT.format(save_folder=load_dir, epoch=1), weights_only=False)
+        history, d2n, masks, shared = ck['dataset_history'], ck['dataset2num_classes'], ck['masks'], ck['shared_layer_info']
+    else:
+        history, d2n, masks, shared = [], {}, {}, {}
+    if mode == 'inference':
+        width = shared[dataset]['network_width_multiplier']
+    torch.manual_seed(1)                                           # main() seeds once per process, before the model exists
+    net = getattr(models, arch)(dataset_history=history, dataset2num_classes=d2n, network_width_multiplier=width, shared_layer_info=shared)
+    net.add_dataset(dataset, ncls)
+    net.set_dataset(dataset)
+    model = nn.DataParallel(net)
+    if pretrained is not None:                                     # stands in for --use_imagenet_pretrained / --use_vgg_pretrained
+        pretrained(net)
+    if not masks:
+        for name, mod in model.named_modules():
+            if _seq_is_masked(mod):
+                masks[name] = torch.zeros(mod.weight.shape, dtype=torch.uint8)
+    task_id = net.datasets.index(dataset) + 1
+    if dataset not in shared:
+        shared[dataset] = {k: {} for k in SEQ_INFO_KEYS}
+        if arch == 'spherenet20':
+            shared[dataset]['prelu_layer_weight'] = {}
+        if task_id > 1:
+            for name, mod in net.named_modules():
+                if _seq_is_masked(mod):
+                    mod.piggymask = Parameter(torch.full(mod.weight.shape, 0.01))
+    elif task_id > 1:
+        for name, mod in net.named_modules():
+            if _seq_is_masked(mod):
+                mod.piggymask = shared[dataset]['piggymask'][name]
+    shared[dataset]['network_width_multiplier'] = width
+    args = types.SimpleNamespace(mode=mode, dataset=dataset, finetune_again=False, target_sparsity=target, initial_sparsity=initial,
+                                 pruning_frequency=1, weight_decay=4e-5, network_width_multiplier=width, cuda=False, log_path=None,
+                                 checkpoint_format=SEQ_FMT)
+    mgr = Manager(args, model, shared, masks, train, val, 0, len(train) if train else 0)        # pruning_interval = 1 epoch
+    rec = {'train_logits': [], 'losses': [], 'val': []}
+    phase = ['train']
+
+    def on_forward(m, i, o):
+        first = o[0] if isinstance(o, tuple) else o
+        (rec['train_logits'] if phase[0] == 'train' else rec['val']).append(first.detach().clone())
+    hooks = [model.register_forward_hook(on_forward),
+             mgr.criterion.register_forward_hook(lambda m, i, o: rec['losses'].append(float(o)) if phase[0] == 'train' else None)]
+    face = dataset == 'face_verification'
+
+    def evaluate():
+        phase[0] = 'val'
+        if not face:
+            acc = mgr.validate(0)
+        else:                                                      # evalLFW's device half
+            mgr.pruner.apply_mask()
+            model.eval()
+            with torch.no_grad():
+                for data, _ in val:
+                    rec['val'].append(net.forward_to_embeddings(data).detach().clone())
+            acc = 0.0
+        phase[0] = 'train'
+        return acc
+
+    if mode == 'inference':
+        mgr.load_checkpoint_only_for_evaluate(1, load_dir)
+        rec['val_acc'] = evaluate()
+    else:
+        idx = net.datasets.index(dataset)
+        sgd, adam = [], []
+        for name, p in model.named_parameters():
+            if 'classifiers' in name:
+                if '.{}.'.format(idx) in name:
+                    sgd.append(p)
+            elif 'piggymask' in name:
+                adam.append(p)
+            else:
+                sgd.append(p)
+        optimizers = Optimizers()
+        optimizers.add(optim.SGD(sgd, lr=lr, weight_decay=0.0, momentum=0.9, nesterov=True), lr)
+        if adam:
+            lr_mask = case['lr_mask'] if mode == 'finetune' else 0.0
+            optimizers.add(optim.Adam(adam, lr=lr_mask), lr_mask)
+        mgr.load_checkpoint(optimizers, 1 if load_dir else 0, load_dir)
+        rec['head_init'] = {k: v.detach().clone() for k, v in net.classifier.state_dict().items()}
+        if mode == 'prune':
+            rec['pre_val_acc'] = evaluate()                        # "Before pruning:" validate = apply_mask on the loaded weights
+            rec['pre_val'] = rec['val']
+            rec['val'] = []
+        else:
+            mgr.pruner.make_finetuning_mask()
+        if mode == 'finetune' and task_id == 1:
+            rec['val_acc'] = evaluate()                            # pass-through: no training
+        else:
+            rec['train_acc'], rec['prune_step'] = mgr.train(optimizers, 0, [lr], 0)
+            rec['val_acc'] = evaluate()
+        mgr.save_checkpoint(optimizers, 0, save_dir)
+    for h in hooks:
+        h.remove()
+    pr = mgr.pruner
+    rec['stats'] = np.array([pr.calculate_sparsity(), pr.calculate_zero_ratio(), pr.calculate_curr_task_ratio(),
+                             pr.calculate_shared_part_ratio() if task_id > 1 else -1.0], dtype=np.float64)
+    names = [n for n, m in model.named_modules() if _seq_is_masked(m)]
+    rec['owner_hist'] = np.array([[int((masks[n] == k).sum()) for k in range(5)] for n in names], dtype=np.int64)
+    mods = dict(model.named_modules())
+    rec['pm_off'] = np.array([int((mods[n].piggymask.detach() <= 0.005).sum()) if mods[n].piggymask is not None else -1 for n in names],
+                             dtype=np.int64)
+    rec['net'], rec['masks'], rec['shared'] = net, masks, shared
+    return rec
+
+
+def gen_sequence_other_nets():
+    import shutil
+    import tempfile
+    os.environ['TQDM_DISABLE'] = '1'
+    for arch, case in SEQ_CASES.items():
+        B, steps = case['batch'], case['steps']
+        g = torch.Generator().manual_seed(61)
+        arrs = dict(width=case['width'], batch=B, steps=steps, data_seed=61, shape=np.array(case['shape']), lr_mask=case['lr_mask'], wd=4e-5,
+                    tasks=np.array([t[0] for t in case['tasks']]), num_classes=np.array([t[1] for t in case['tasks']]),
+                    lr_finetune=np.array([t[2] or 0.0 for t in case['tasks']]), lr_prune=np.array([t[3] for t in case['tasks']]),
+                    targets=np.array([0.3, 0.2, 0.2][:len(case['tasks'])]))
+        data = {}
+        for ti, (dataset, ncls, _, _) in enumerate(case['tasks']):
+            # the batches are NOT stored: the test draws them again from the same CPU generator (seed 61, this order) and checks the crc
+            xs = quant(torch.randn(steps, B, *case['shape'], generator=g), 8.0)
+            ts = torch.randint(0, ncls, (steps, B), generator=g)
+            xv = quant(torch.randn(2, B, *case['shape'], generator=g), 8.0)
+            tv = torch.randint(0, ncls, (2, B), generator=g)
+            data[dataset] = ([(xs[i], ts[i]) for i in range(steps)], [(xv[i], tv[i]) for i in range(2)])
+            arrs['data_crc/%d' % ti] = np.array([tensor_crc(xs), tensor_crc(ts), tensor_crc(xv), tensor_crc(tv)], dtype=np.uint32)
+
+        def pretrained(net):
+            if arch != 'resnet50':
+                return                                             # SphereNet-20: the seeded kaiming initialisation as it stands
+            reinit_resnet(net, 2)
+            gg = torch.Generator().manual_seed(29)
+            for mod in net.modules():
+                if isinstance(mod, nn.BatchNorm2d):
+                    mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=gg) * 0.1)
+                    mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=gg) + 0.5)
+
+        tmp = tempfile.mkdtemp()
+        try:
+            prev = None
+            phases = []
+            for ti, (dataset, ncls, lr_ft, lr_pr) in enumerate(case['tasks']):
+                train, val = data[dataset]
+                d_ft, d_pr = os.path.join(tmp, dataset, 'scratch'), os.path.join(tmp, dataset, 'gradual_prune')
+                os.makedirs(d_ft)
+                os.makedirs(d_pr)
+                r = _seq_process(arch, case, 'finetune', dataset, ncls, prev, d_ft, train, val, lr_ft or 1e-3,
+                                 pretrained=pretrained if ti == 0 else None)
+                phases.append(('t%d_finetune' % (ti + 1), r))
+                if ti == 0:
+                    sd = r['net'].state_dict()
+                    arrs['init_digest'] = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in sd.values()])
+                    arrs['init_names'] = np.array(list(sd.keys()))
+                    for k, v in sd.items():
+                        if 'running_' in k:
+                            arrs['init_bn/' + k] = v.clone()
+                else:
+                    for k, v in r['head_init'].items():
+                        arrs['head_init/%d/%s' % (ti, k)] = v
+                r = _seq_process(arch, case, 'prune', dataset, ncls, d_ft, d_pr, train, val, lr_pr, 0.0, float(arrs['targets'][ti]))
+                phases.append(('t%d_prune' % (ti + 1), r))
+                if ti == 1:
+                    # What "the same run" means on THIS network: the two task-2 phases again, by the reference, from the same checkpoints,
+                    # with the training images multiplied by (1 + 1e-6 N(0,1)) -- the size of fp32 round-off in a conv output.  A narrow
+                    # train-mode BatchNorm net on a handful of samples amplifies that ~300 x per forward and, through ReLU / binarizer
+                    # flips, ~100 x per step: `band/*` is the relative logit deviation per step and the number of owner bytes / piggymask
+                    # bits that land on the other side of their threshold.  A replay on other fp32 arithmetic is held to this band, the
+                    # first step of a phase (identical inputs) to 1e-4.
+                    gn = torch.Generator().manual_seed(97)
+                    noisy = [(x * (1 + 1e-6 * torch.randn(x.shape, generator=gn)), t) for x, t in train]
+                    d_n1, d_n2 = os.path.join(tmp, 'noisy_ft'), os.path.join(tmp, 'noisy_pr')
+                    os.makedirs(d_n1)
+                    os.makedirs(d_n2)
+                    base_ft, base_pr = phases[-2][1], phases[-1][1]
+                    for tag, base, rn in (('t2_finetune', base_ft, _seq_process(arch, case, 'finetune', dataset, ncls, prev, d_n1, noisy, val, lr_ft)),
+                                          ('t2_prune', base_pr, _seq_process(arch, case, 'prune', dataset, ncls, d_ft, d_n2, noisy, val, lr_pr, 0.0,
+                                                                             float(arrs['targets'][ti])))):
+                        a_, b_ = torch.stack(base['train_logits']), torch.stack(rn['train_logits'])
+                        arrs['band/%s/logits' % tag] = np.array([float((a_[i] - b_[i]).abs().max() / a_[i].abs().max()) for i in range(len(a_))])
+                        va_, vb_ = torch.stack(base['val']), torch.stack(rn['val'])
+                        arrs['band/%s/val' % tag] = float((va_ - vb_).abs().max() / va_.abs().max())
+                        arrs['band/%s/owner_moved' % tag] = int(np.abs(base['owner_hist'] - rn['owner_hist']).sum()) // 2
+                        arrs['band/%s/pm_off_moved' % tag] = int(np.abs(base['pm_off'] - rn['pm_off']).sum())
+                    # the prune run of task 2 starts from this checkpoint (its piggymasks do not move in that phase: lr_mask 0 -- they are the
+                    # ones final/info/<task 2>/piggymask holds): the trunk in full
+                    ck_ft = torch.load(SEQ_FMT.format(save_folder=d_ft, epoch=1), weights_only=False)
+                    for k, v in ck_ft['model_state_dict'].items():
+                        if not k.startswith('classifier.') and not k.startswith('classifiers.0'):
+                            arrs['t2prune_start/' + k] = v
+                    for k, v in ck_ft['masks'].items():
+                        arrs['t2prune_start_mask/' + k] = v
+                if ti == 0:                                        # task 2 starts from this checkpoint: the trunk in full (phase-fed test)
+                    for k, v in r['net'].state_dict().items():
+                        if not k.startswith('classifier'):
+                            arrs['t2start/' + k] = v.clone()
+                    for k, v in r['masks'].items():
+                        arrs['t2start_mask/' + k] = v.clone()
+                prev = d_pr
+            # ---- the final checkpoint, as the file holds it
+            ck = torch.load(SEQ_FMT.format(save_folder=prev, epoch=1), weights_only=False)
+            for k, v in ck['model_state_dict'].items():
+                if not k.startswith('classifier.'):                # (`classifier` aliases the active head: classifiers.N holds the same tensors)
+                    arrs['final/state/' + k] = v
+            for k, v in ck['masks'].items():
+                arrs['final/mask/' + k] = v
+            keysets = {}
+            for dataset, info in ck['shared_layer_info'].items():
+                keysets[dataset] = {}
+                for key, val_ in info.items():
+                    if isinstance(val_, dict):
+                        keysets[dataset][key] = sorted(val_)
+                        for name, tns in val_.items():
+                            arrs['final/info/%s/%s/%s' % (dataset, key, name)] = tns.detach()
+                    else:
+                        keysets[dataset][key] = float(val_)
+            arrs['final/info_keys'] = np.array(json.dumps(keysets, sort_keys=True))
+            arrs['final/dataset_history'] = np.array(ck['dataset_history'])
+            # ---- every task served from the final checkpoint through the reference's inference path
+            for ti, (dataset, ncls, _, _) in enumerate(case['tasks']):
+                r = _seq_process(arch, case, 'inference', dataset, ncls, prev, None, None, data[dataset][1], 0.0)
+                arrs['infer/%d/logits' % ti] = torch.stack(r['val'])
+                arrs['infer/%d/acc' % ti] = r['val_acc']
+                arrs['infer/%d/stats' % ti] = r['stats']
+        finally:
+            shutil.rmtree(tmp)
+        for tag, r in phases:
+            if r['train_logits']:
+                arrs[tag + '/logits'] = torch.stack(r['train_logits'])
+                arrs[tag + '/losses'] = np.array(r['losses'])
+                arrs[tag + '/train_acc'] = r['train_acc']
+            arrs[tag + '/val'] = torch.stack(r['val'])
+            if 'pre_val' in r:
+                arrs[tag + '/pre_val'] = torch.stack(r['pre_val'])
+            arrs[tag + '/val_acc'] = r['val_acc']
+            arrs[tag + '/stats'] = r['stats']
+            arrs[tag + '/owner_hist'] = r['owner_hist']
+            arrs[tag + '/pm_off'] = r['pm_off']
+        arrs['phases'] = np.array([t for t, _ in phases])
+        save('sequence_' + arch, **arrs)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     if only:                                  # regenerate selected fixtures: python make_golden.py gen_one_shot ...
         for fn in only:
             globals()[fn]()
         sys.exit(0)
+    gen_sequence_other_nets()
     gen_growth()
     gen_full_width_logits()
     gen_one_shot()

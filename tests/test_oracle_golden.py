@@ -294,3 +294,95 @@ def test_oracle_train_steps_match_reference(arch):
         np.testing.assert_array_equal(pruner.owners[n], g['mask/module.' + n])
         np.testing.assert_allclose(mods[n].weight.detach().numpy(), g['final/' + n], rtol=1e-5, atol=1e-7)
     assert abs(pruner.sparsity() - float(g['sparsity'])) < 1e-12
+
+
+# --------------------------------------------------------------------------- round 6: configs[3] / configs[4] as SEQUENCES
+def _oracle_phase(m, owners, mode, task_idx, train, val, lr, lr_mask, target, wd, width, dataset):
+    """One phase of a task >= 2 on the oracle: the set-up of CPG_imagenet_main.py:320-346 / CPG_face_main.py:318-345 (SGD-nesterov over the
+    shared tensors + the task's head, Adam over the piggymasks), Manager's loss choice (utils/manager.py:29-36) and its train loop."""
+    cur = task_idx + 1
+    pruner = onet.OraclePruner(m, owners, mode, cur - 1 if mode == 'finetune' else cur, cur, 0, len(train), 1, 0.0, target, wd, width)
+    head = m.classifiers[task_idx]
+    sgd = [p for n, p in m.named_parameters() if 'classifiers' not in n and 'piggymask' not in n] + list(head.parameters())
+    adam = [l.piggymask for _, l in m.masked_layers()]
+    opts = [torch.optim.SGD(sgd, lr=lr, momentum=0.9, nesterov=True, weight_decay=0.0), torch.optim.Adam(adam, lr=lr_mask)]
+    if dataset == 'face_verification':
+        crit = onet.OracleAngleLoss()
+    elif dataset == 'emotion':
+        counts = torch.tensor([74874, 134415, 25459, 14090, 6378, 3803, 24882], dtype=torch.float32)
+        crit = torch.nn.CrossEntropyLoss(weight=(counts.sum() - counts) / counts)
+    else:
+        crit = torch.nn.CrossEntropyLoss()
+    pre = None
+    if mode == 'finetune':
+        pruner.claim_free()
+    else:
+        pruner.apply_mask()                                   # the "Before pruning:" validate
+        m.eval()
+        with torch.no_grad():
+            pre = torch.stack([m(x) for x, _ in val])
+    logits, losses = [], []
+    m.train()
+    for s, (x, t) in enumerate(train):
+        for o in opts:
+            o.zero_grad()
+        out = m(x)
+        loss = crit(out, t)
+        loss.backward()
+        pruner.route()
+        for o in opts:
+            o.step()
+        if mode == 'prune':
+            pruner.gradually_prune(s)
+        logits.append(out.detach())
+        losses.append(float(loss.detach()))
+    pruner.apply_mask()
+    m.eval()
+    with torch.no_grad():
+        ev = torch.stack([m(x) for x, _ in val])
+    return torch.stack(logits), np.array(losses), ev, pre, pruner
+
+
+@pytest.mark.parametrize('arch', ['resnet50', 'spherenet20'])
+def test_oracle_sequence_tasks_after_the_first(arch):
+    """The oracle through every phase AFTER task 1 of the reference-run sequences (sequence_*.npz: ResNet-50 imagenet -> cubs_cropped;
+    SphereNet-20 face_verification -> gender -> emotion), starting from the reference's own task-1 checkpoint: finetune with piggymasks
+    (Adam) over task 1's frozen weights, the head / loss switch (nn.Linear + CE; class-weighted CE for `emotion`), the prune run with its
+    'before pruning' validate.  Same torch-CPU ops in the same order as the reference's processes: per-step logits and losses 1e-5,
+    owner histograms and piggymask-off counts equal."""
+    import _sequence as sq
+    fx = sq.load(arch)
+    width, wd, lr_mask = float(fx['width']), float(fx['wd']), float(fx['lr_mask'])
+    names = sq.tasks(fx)
+    data = sq.batches(fx)
+    torch.manual_seed(1)
+    m = onet.OracleResNet(width) if arch == 'resnet50' else onet.OracleSphereNet(width)
+    m.add_dataset(*names[0])
+    missing, unexpected = m.load_state_dict(sq.group(fx, 't2start'), strict=False)
+    assert not unexpected and all(k.startswith('classifiers.0') for k in missing), (missing, unexpected)
+    owners = {n: sq.group(fx, 't2start_mask')['module.' + n].numpy().copy() for n, _ in m.masked_layers()}
+    layer_names = [n for n, _ in m.masked_layers()]
+    for ti in range(1, len(names)):
+        dataset, ncls = names[ti]
+        m.add_dataset(dataset, ncls)
+        m.set_dataset(dataset)
+        m.classifiers[ti].load_state_dict(sq.group(fx, 'head_init/%d' % ti))
+        for _, l in m.masked_layers():
+            l.piggymask = torch.nn.Parameter(torch.full(l.weight.shape, 0.01))       # (CPG_face_main.py:263-270)
+        train, val = data[ti]
+        for mode, lr, target in (('finetune', float(fx['lr_finetune'][ti]), 0.0), ('prune', float(fx['lr_prune'][ti]), float(fx['targets'][ti]))):
+            tag = 't%d_%s' % (ti + 1, mode)
+            logits, losses, ev, pre, pruner = _oracle_phase(m, owners, mode, ti, train, val, lr, lr_mask if mode == 'finetune' else 0.0,
+                                                            target, wd, width, dataset)
+            sc = float(np.abs(fx[tag + '/logits']).max())
+            np.testing.assert_allclose(logits.numpy(), fx[tag + '/logits'], rtol=1e-5, atol=2e-5 * sc, err_msg=tag)
+            np.testing.assert_allclose(losses, fx[tag + '/losses'], rtol=2e-5, atol=1e-5, err_msg=tag)
+            np.testing.assert_allclose(ev.numpy(), fx[tag + '/val'], rtol=1e-5, atol=2e-5 * float(np.abs(fx[tag + '/val']).max()), err_msg=tag)
+            if pre is not None:
+                np.testing.assert_allclose(pre.numpy(), fx[tag + '/pre_val'], rtol=1e-5, atol=2e-5 * float(np.abs(fx[tag + '/pre_val']).max()))
+            hist = np.array([[int((pruner.owners[n] == k).sum()) for k in range(5)] for n in layer_names])
+            np.testing.assert_array_equal(hist, fx[tag + '/owner_hist'], err_msg=tag)
+            mods = dict(m.named_modules())
+            off = np.array([int((mods[n].piggymask.detach() <= 0.005).sum()) for n in layer_names])
+            np.testing.assert_array_equal(off, fx[tag + '/pm_off'], err_msg=tag)
+            assert abs(pruner.sparsity() - float(fx[tag + '/stats'][0])) < 1e-12
