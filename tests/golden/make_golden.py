@@ -1083,28 +1083,28 @@ def gen_sequence_other_nets():
                         arrs['head_init/%d/%s' % (ti, k)] = v
                 r = _seq_process(arch, case, 'prune', dataset, ncls, d_ft, d_pr, train, val, lr_pr, 0.0, float(arrs['targets'][ti]))
                 phases.append(('t%d_prune' % (ti + 1), r))
+                # What "the same run" means on THIS network: every training phase again, by the reference, from the same checkpoint, with the
+                # training images multiplied by (1 + 1e-6 N(0,1)) -- the size of fp32 round-off in a conv output.  A narrow train-mode
+                # BatchNorm net on a handful of samples amplifies that ~300 x per forward and, through ReLU / binarizer flips, ~100 x per
+                # step: `band/*` is the relative logit deviation per step and the number of owner bytes / piggymask bits that land on the
+                # other side of their threshold.  A replay on other fp32 arithmetic is held to this band, the first step of a phase
+                # (identical inputs) to 1e-4.
+                gn = torch.Generator().manual_seed(97 + ti)
+                noisy = [(x * (1 + 1e-6 * torch.randn(x.shape, generator=gn)), t) for x, t in train]
+                twins = [('t%d_prune' % (ti + 1), phases[-1][1], 'prune', d_ft, lr_pr, float(arrs['targets'][ti]))]
+                if ti > 0:
+                    twins.insert(0, ('t%d_finetune' % (ti + 1), phases[-2][1], 'finetune', prev, lr_ft, 0.0))
+                for tag, base, mode, src, lr_, target_ in twins:
+                    d_n = os.path.join(tmp, 'noisy_' + tag)
+                    os.makedirs(d_n)
+                    rn = _seq_process(arch, case, mode, dataset, ncls, src, d_n, noisy, val, lr_, 0.0, target_)
+                    a_, b_ = torch.stack(base['train_logits']), torch.stack(rn['train_logits'])
+                    arrs['band/%s/logits' % tag] = np.array([float((a_[i] - b_[i]).abs().max() / a_[i].abs().max()) for i in range(len(a_))])
+                    va_, vb_ = torch.stack(base['val']), torch.stack(rn['val'])
+                    arrs['band/%s/val' % tag] = float((va_ - vb_).abs().max() / va_.abs().max())
+                    arrs['band/%s/owner_moved' % tag] = int(np.abs(base['owner_hist'] - rn['owner_hist']).sum()) // 2
+                    arrs['band/%s/pm_off_moved' % tag] = int(np.abs(base['pm_off'] - rn['pm_off']).sum())
                 if ti == 1:
-                    # What "the same run" means on THIS network: the two task-2 phases again, by the reference, from the same checkpoints,
-                    # with the training images multiplied by (1 + 1e-6 N(0,1)) -- the size of fp32 round-off in a conv output.  A narrow
-                    # train-mode BatchNorm net on a handful of samples amplifies that ~300 x per forward and, through ReLU / binarizer
-                    # flips, ~100 x per step: `band/*` is the relative logit deviation per step and the number of owner bytes / piggymask
-                    # bits that land on the other side of their threshold.  A replay on other fp32 arithmetic is held to this band, the
-                    # first step of a phase (identical inputs) to 1e-4.
-                    gn = torch.Generator().manual_seed(97)
-                    noisy = [(x * (1 + 1e-6 * torch.randn(x.shape, generator=gn)), t) for x, t in train]
-                    d_n1, d_n2 = os.path.join(tmp, 'noisy_ft'), os.path.join(tmp, 'noisy_pr')
-                    os.makedirs(d_n1)
-                    os.makedirs(d_n2)
-                    base_ft, base_pr = phases[-2][1], phases[-1][1]
-                    for tag, base, rn in (('t2_finetune', base_ft, _seq_process(arch, case, 'finetune', dataset, ncls, prev, d_n1, noisy, val, lr_ft)),
-                                          ('t2_prune', base_pr, _seq_process(arch, case, 'prune', dataset, ncls, d_ft, d_n2, noisy, val, lr_pr, 0.0,
-                                                                             float(arrs['targets'][ti])))):
-                        a_, b_ = torch.stack(base['train_logits']), torch.stack(rn['train_logits'])
-                        arrs['band/%s/logits' % tag] = np.array([float((a_[i] - b_[i]).abs().max() / a_[i].abs().max()) for i in range(len(a_))])
-                        va_, vb_ = torch.stack(base['val']), torch.stack(rn['val'])
-                        arrs['band/%s/val' % tag] = float((va_ - vb_).abs().max() / va_.abs().max())
-                        arrs['band/%s/owner_moved' % tag] = int(np.abs(base['owner_hist'] - rn['owner_hist']).sum()) // 2
-                        arrs['band/%s/pm_off_moved' % tag] = int(np.abs(base['pm_off'] - rn['pm_off']).sum())
                     # the prune run of task 2 starts from this checkpoint (its piggymasks do not move in that phase: lr_mask 0 -- they are the
                     # ones final/info/<task 2>/piggymask holds): the trunk in full
                     ck_ft = torch.load(SEQ_FMT.format(save_folder=d_ft, epoch=1), weights_only=False)
