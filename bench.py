@@ -63,7 +63,7 @@ ARCHS = {
                      workload='configs[3] topology on one GPU: ResNet-50 (Bottleneck, masked 7x7 s2 / 1x1 / 3x3 s1 / 3x3 s2 convs) 224x224'),
     # lrs: the reference's own learning rates for this configuration (experiment3/FvGeEm_CPG_face.sh:21-25,130: finetune 1e-3, prune run
     # 5e-4).  The VGG16 cycle's 1e-2 / 1e-3 makes this BatchNorm-free network diverge on random labels within 5 steps -- on torch's own ops
-    # exactly as on the HIP kernels (tools/diag_sph_nan.py) -- and every K >= 60 cycle then ran on NaN weights (`cycle_check` said so).
+    # exactly as on the HIP kernels (tools/attic/diag_sph_nan.py) -- and every K >= 60 cycle then ran on NaN weights (`cycle_check` said so).
     'spherenet20': dict(size=112, dataset='face_verification', classes=4630, dataset2='gender', classes2=2, flop_train=2 * (3 * 2.029e9 - 0.0054e9), flop_fwd=2 * 2.029e9,
                         workload='configs[4] topology on one GPU: SphereNet-20 112x112, AngleLinear head + AngleLoss', lrs=(1e-3, 5e-4)),
 }
@@ -718,7 +718,7 @@ def run_task_sequence(a, device):
         passthrough = plan['pass_through_first'] and t == 1
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = sess.run_task(name, ncls, train, val, accuracy_goal=2.0 if grow else 0.0, finetune_epochs=1, prune_epochs=10, sparsities=(0.1,),
+        res = sess.run_task(name, ncls, train, val, accuracy_goal=2.0 if grow else 0.0, finetune_epochs=1, prune_epochs=10, sparsities=(a.sequence_sparsity,),
                             args=args, min_train_acc=-1.0, max_width_multiplier=(sess.width_multiplier + 0.5) if grow else None,
                             width_step=0.5, retrain_epochs=1, total_num_tasks=T, pretrained_pass_through=passthrough,
                             piggymask_retrain=plan['piggymask_retrain'])
@@ -745,7 +745,7 @@ def run_task_sequence(a, device):
                       'width_multiplier_raw': sess.width_multiplier, 'width_multiplier_rooted': round(sess.width, 6), 'grown_to': res.grown_to,
                       'masked_weights': n_all, 'owner_histogram': {str(i): c for i, c in enumerate(hist) if c},
                       'ratio_to_acc': {str(k): v for k, v in res.ratio_to_acc.items()}, 'chosen_ratio': res.chosen_ratio,
-                      'retrain_kept': res.retrain_kept, 'shared_ratio': round(pr.calculate_shared_part_ratio(), 6) if t > 1 else None,
+                      'prune_run_exit2_at': res.prune_exit2, 'retrain_kept': res.retrain_kept, 'shared_ratio': round(pr.calculate_shared_part_ratio(), 6) if t > 1 else None,
                       'sparsity': pr.calculate_sparsity(),
                       'dp_payload_bytes_per_step': {'dense_weights': 4 * n_all, 'prune_mode': 4 * owned,
                                                     'finetune_mode': 4 * (owned + (older if t > 1 else 0)),
@@ -769,6 +769,7 @@ def run_task_sequence(a, device):
             'dtype': 'f32', 'config': {'workload': '%s, %d-task sequence %s (epochs of %d steps: %s, validate after every epoch), batch %d'
                                                    % (ARCHS[a.arch]['workload'], T, [p_[0] for p_ in plan['tasks'][:T]], E, plan['epochs'], a.batch),
                                        'arch': a.arch, 'tasks': T, 'epoch_steps': E, 'per_gpu_batch': a.batch, 'grow_at_task': grow_at,
+                                       'prune_run_target_sparsity': a.sequence_sparsity,
                                        'start_width_multiplier_raw': a.width_multiplier},
             'tasks': tasks, 'task1_after_sequence': {'logits_finite': bool(all(torch.isfinite(o).all() for o in logits1)), 'accuracy': acc1},
             'note': 'wall time includes validates, snapshots, the ratio choice, the growth rebuild (last task: a finetune at the old width, then '
@@ -924,7 +925,7 @@ def cpu_baseline(steps=220, batch=256, validates=11, prune_events=4, probe_batch
 # ---- 8-GPU prediction: what a SCALE run should show, so that a first hardware run can be judged in one read
 XGMI_LINK_GBS = 153.0                # MI355X_MICROARCH / task statement: 7 links x ~153 GB/s per GPU, point to point
 RCCL_ALLREDUCE_BUSBW_GBS = 310.0     # assumed large-message bus bandwidth of an 8-GPU RCCL all-reduce over xGMI (two links' worth)
-OVERLAP_SLOWDOWN = 1.17              # conv kernels beside 16 busy CUs' worth of other streams' kernels (tools/diag_interference.py)
+OVERLAP_SLOWDOWN = 1.17              # conv kernels beside 16 busy CUs' worth of other streams' kernels (tools/attic/diag_interference.py)
 # cycle ms per step on ONE GPU by per-GPU batch (profiles/r04c_bench*.json; the 128 / 64 / 32 rows are the reference's own split: 256 images over 2 / 4 / 8 GPUs)
 SINGLE_GPU_MS_PER_STEP = {'vgg16': {256: 109.3, 128: 57.5, 64: 31.7, 32: 18.7}, 'resnet50': {256: 69.8}, 'spherenet20': {256: 20.6}}
 # What the exchange machinery costs a step BEFORE any link time, measured on one GPU with a world-1 RCCL group (CPG_DP_FORCE=1: every hook,
@@ -1035,6 +1036,11 @@ def main():
     ap.add_argument('--task-sequence', type=int, default=0,
                     help='T > 0: T tasks back to back through cpg_amd.driver.CPGSession at full size, growth forced on the last one; prints its '
                          'own JSON line (per-task step time, owner-id histogram, shared_ratio, data-parallel payload) instead of the cycle bench')
+    ap.add_argument('--sequence-sparsity', type=float, default=0.1,
+                    help="--task-sequence: target of every task's one gradual-prune run (default 0.1, the first run of the reference's sweep). "
+                         'The reference sweeps on to 0.9 / 0.95 and keeps the sparsest stage that holds the accuracy goal, so a task normally '
+                         'hands MOST of its slots on; at 0.1 the free capacity shrinks 10 x per task and the smallest layer (1 728 weights) runs out '
+                         'of candidates at task 4 (exit code 2, utils/prune.py:38-42): use 0.5 for sequences longer than 3 tasks')
     ap.add_argument('--grow-at-task', type=int, default=0,
                     help='--task-sequence: force the growth step (exit code 2 -> raw multiplier + 0.5) on this task (default: the last task of a '
                          'vgg16 sequence, never on the other topologies)')

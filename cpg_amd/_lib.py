@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CPG_HIP_LIB') or os.path.join(_HERE, 'lib', 'libcpg_hip.so')   # override: A/B kernel experiments
 
-ABI_VERSION = 2         # include/cpg_hip.h: CPG_ABI_VERSION
+ABI_VERSION = 3         # include/cpg_hip.h: CPG_ABI_VERSION
 CPG_OK = 0
 CPG_E_KRANGE = 2
 MODE_FINETUNE = 0
@@ -32,6 +32,16 @@ class ConvDesc(ctypes.Structure):
 class PruneResult(ctypes.Structure):
     _fields_ = [('n_candidates', ctypes.c_int64), ('k', ctypes.c_int64), ('n_released', ctypes.c_int64),
                 ('cutoff', ctypes.c_float), ('status', ctypes.c_int32)]
+
+
+class SgdItem(ctypes.Structure):                  # cpg_sgd_item
+    _fields_ = [('w', ctypes.c_void_p), ('gw', ctypes.c_void_p), ('momentum_buf', ctypes.c_void_p), ('owner', ctypes.c_void_p),
+                ('n', ctypes.c_int64)]
+
+
+class AdamItem(ctypes.Structure):                 # cpg_adam_item
+    _fields_ = [('pm', ctypes.c_void_p), ('gpm', ctypes.c_void_p), ('exp_avg', ctypes.c_void_p), ('exp_avg_sq', ctypes.c_void_p),
+                ('owner', ctypes.c_void_p), ('n', ctypes.c_int64)]
 
 
 PRUNE_RESULT_BYTES = ctypes.sizeof(PruneResult)
@@ -52,6 +62,10 @@ _SIGNATURES = {
     'cpg_conv2d_dgrad_add_supported': (ctypes.c_int32, [ctypes.POINTER(ConvDesc)]),
     'cpg_conv2d_dgrad_add': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     'cpg_conv2d_wgrad': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    'cpg_conv2d_pack_bytes': (ctypes.c_size_t, [ctypes.POINTER(ConvDesc), ctypes.c_int32]),
+    'cpg_conv2d_pack': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, ctypes.c_float, ctypes.c_int32, _vp, ctypes.c_size_t, ctypes.c_int32, _vp,
+                                       ctypes.c_size_t, _vp]),
+    'cpg_conv2d_use_packed': (ctypes.c_int, [_vp, ctypes.c_size_t]),
     'cpg_linear_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'cpg_linear_fwd': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
     'cpg_linear_dgrad': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
@@ -69,6 +83,11 @@ _SIGNATURES = {
     'cpg_unpack_owned': (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _vp, _vp, _vp]),
     'cpg_sgd_route_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _vp]),
+    'cpg_multi_tensor_max': (ctypes.c_int32, []),
+    'cpg_sgd_route_step_multi': (ctypes.c_int, [ctypes.POINTER(SgdItem), ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                                ctypes.c_int32, ctypes.c_int32, _vp]),
+    'cpg_adam_route_step_multi': (ctypes.c_int, [ctypes.POINTER(AdamItem), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_double,
+                                                 ctypes.c_double, ctypes.c_double, ctypes.c_int32, _vp]),
     'cpg_adam_route_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_double,
                                            ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.c_int64, _vp]),
     'cpg_bn_workspace_bytes': (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
@@ -116,6 +135,8 @@ _SIGNATURES = {
     'cpg_stem_bn_wgrad_workspace': (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     'cpg_stem_bn_relu_bwd_wgrad': (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                   _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    'cpg_bn_stats_finalize_count': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
+                                                   ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
     'cpg_bn_stats_finalize': (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                              ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),
     'cpg_bn_add_relu_mask_bytes': (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
@@ -184,6 +205,9 @@ def set_option(name, value):
     if isinstance(value, str):
         value = _WINO_KERNEL[value] if name == 'CPG_WINO_KERNEL' else int(value)
     check('cpg_set_option', lib().cpg_set_option(name.encode(), OPT_UNSET if value is None else int(value)))
+    mod = sys.modules.get('cpg_amd.models.layers')
+    if mod is not None:
+        mod._PACK_BYTES.clear()             # which kernel family (hence which packed operand) a shape gets depends on the switches
 
 
 class option(object):

@@ -401,9 +401,11 @@ extern "C" int cpg_bn_relu_fwd_eval(const float *x, const float *gamma, const fl
 namespace {
 __global__ __launch_bounds__(kThreads) void k_bn_finalize_tiles(const float *__restrict__ partials, int tiles, double count, float eps,
                                                                 float momentum, float *__restrict__ mean, float *__restrict__ invstd,
-                                                                float *__restrict__ running_mean, float *__restrict__ running_var) {
+                                                                float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                                long long *__restrict__ num_batches_tracked) {
     __shared__ double red[4];
     const int c = blockIdx.x;
+    if (num_batches_tracked != nullptr && c == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     const float2 *p = reinterpret_cast<const float2 *>(partials) + (int64_t)c * tiles;
     // four loads in flight per thread (a 224 x 224 x 256-image layer has 28 672 tiles per channel and only 64 channels = 64 blocks:
     // the loop is latency-bound); four partial sums merged in a fixed order
@@ -443,16 +445,29 @@ __global__ __launch_bounds__(kThreads) void k_bn_finalize_tiles(const float *__r
 }
 }  // namespace
 
+static int bn_stats_finalize(const char *what, const float *partials, int32_t tiles, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
+                             float *running_mean, float *running_var, float *mean, float *invstd, int64_t *nbt, void *stream_v) {
+    CPG_REQUIRE(partials && mean && invstd, "%s: null pointer", what);
+    CPG_REQUIRE(tiles > 0 && N > 0 && C > 0 && HW > 0, "%s: non-positive dimension", what);
+    CPG_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "%s: running stats must come as a pair", what);
+    CPG_REQUIRE((((uintptr_t)partials) & 7) == 0, "%s: partials must be 8-byte aligned", what);
+    CPG_REQUIRE((((uintptr_t)nbt) & 7) == 0, "%s: num_batches_tracked must be 8-byte aligned", what);
+    hipLaunchKernelGGL(k_bn_finalize_tiles, dim3(C), dim3(kThreads), 0, (hipStream_t)stream_v, partials, tiles, (double)N * HW, eps,
+                       momentum, mean, invstd, running_mean, running_var, (long long *)nbt);
+    CPG_CHECK_LAUNCH(what);
+    return CPG_OK;
+}
+
 extern "C" int cpg_bn_stats_finalize(const float *partials, int32_t tiles, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
                                      float *running_mean, float *running_var, float *mean, float *invstd, void *stream_v) {
-    CPG_REQUIRE(partials && mean && invstd, "cpg_bn_stats_finalize: null pointer");
-    CPG_REQUIRE(tiles > 0 && N > 0 && C > 0 && HW > 0, "cpg_bn_stats_finalize: non-positive dimension");
-    CPG_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "cpg_bn_stats_finalize: running stats must come as a pair");
-    CPG_REQUIRE((((uintptr_t)partials) & 7) == 0, "cpg_bn_stats_finalize: partials must be 8-byte aligned");
-    hipLaunchKernelGGL(k_bn_finalize_tiles, dim3(C), dim3(kThreads), 0, (hipStream_t)stream_v, partials, tiles, (double)N * HW, eps,
-                       momentum, mean, invstd, running_mean, running_var);
-    CPG_CHECK_LAUNCH("cpg_bn_stats_finalize");
-    return CPG_OK;
+    return bn_stats_finalize("cpg_bn_stats_finalize", partials, tiles, N, C, HW, eps, momentum, running_mean, running_var, mean, invstd, nullptr, stream_v);
+}
+
+extern "C" int cpg_bn_stats_finalize_count(const float *partials, int32_t tiles, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
+                                           float *running_mean, float *running_var, float *mean, float *invstd, int64_t *num_batches_tracked,
+                                           void *stream_v) {
+    return bn_stats_finalize("cpg_bn_stats_finalize_count", partials, tiles, N, C, HW, eps, momentum, running_mean, running_var, mean, invstd,
+                             num_batches_tracked, stream_v);
 }
 
 // Backward of y = relu(bn(x)) whose reduction already happened in the epilogue of the NEXT layer's input-gradient kernel

@@ -1146,6 +1146,7 @@ int run_fwd(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, co
         if (dry) return CPG_OK;
         return cpg_conv3x3_wino_run(dgrad ? 1 : 0, N, c_read, m, H, W, K, C, x, w, pm, thr, bias, y, stats, ws, ws_bytes, stream);
     }
+    if (!dry && cpg::pack_query()) return CPG_OK;       // (cpg_conv2d_pack's query: only the Winograd route above records a job)
     // ... and the inference forward with the eval-mode BatchNorm epilogue and the dead-channel skip (k_wg1<.., BNE>).  Workspace layout:
     // [the direct kernels' packed-weight region (unused) | liveness words, where cpg_conv3x3_fwd_bn_eval looks for them | U]
     if (bn != nullptr && bb == nullptr && !dgrad && stats == nullptr && !dry && cpg_conv3x3_wino_eval_ok(N, c_read, m, H, W)) {

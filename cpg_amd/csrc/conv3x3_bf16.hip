@@ -355,7 +355,7 @@ int run(bool dgrad, int N, int c_read, int m, int H, int W, int K, int C, const 
 // Staging: thread = (channel, group): eight range-checked dword buffer loads (8 consecutive pixels = one 32-byte sector; groups
 // outside the image get an out-of-range offset and read as 0; a 16-lane group of a wave covers 16 channels x 4 consecutive
 // groups = one 128-byte line per channel), four v_cvt_pk_bf16_f32, one ds_write_b128.  (buffer_load_dwordx4 through the
-// same raw descriptor returned its first dword four times on gfx950 -- tools/diag_wgrad16.py -- and bought 4 % at best.)  The loads of unit u+1 are issued before the
+// same raw descriptor returned its first dword four times on gfx950 -- tools/attic/diag_wgrad16.py -- and bought 4 % at best.)  The loads of unit u+1 are issued before the
 // MFMAs of unit u and stored into the other LDS stage after them (two stages, one barrier per unit, one block per CU).
 // MASKW: W is not a multiple of 8 (28-wide maps): the group that straddles the right image border is masked per element.
 // Split-K over units exactly like the fp32 kernel (k_c3_wgrad): tap-major partials, reduced (with the autograd epilogue

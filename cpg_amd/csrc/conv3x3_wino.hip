@@ -482,11 +482,10 @@ constexpr int W1_RAW = 4 * 4 * W1_ROW;                    // one stage: [channel
 constexpr int W1_U = 16 * 32 * WG_CK;                     // floats of U per (k block, chunk)
 
 // U in per-lane order (see above); rec = kb * nch + ch
-__global__ __launch_bounds__(256) void k_wg1_pack(const float *__restrict__ w, const float *__restrict__ pm, float thr,
-                                                  float *__restrict__ up, int K, int C, int M, int Cin, int nch, int dgrad,
-                                                  int *__restrict__ live, int Mp) {
-    const int64_t total = (int64_t)((M + 31) / 32) * nch * 32 * WG_CK;
-    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void wg1_pack_one(int64_t o, const float *__restrict__ w, const float *__restrict__ pm, float thr,
+                                             float *__restrict__ up, int C, int M, int Cin, int nch, int dgrad,
+                                             int *__restrict__ live, int Mp) {
+    {
         const int cl = (int)(o % WG_CK);
         const int kl = (int)((o / WG_CK) % 32);
         const int64_t rec = o / (WG_CK * 32);
@@ -543,6 +542,49 @@ __global__ __launch_bounds__(256) void k_wg1_pack(const float *__restrict__ w, c
     }
 }
 
+__global__ __launch_bounds__(256) void k_wg1_pack(const float *__restrict__ w, const float *__restrict__ pm, float thr,
+                                                  float *__restrict__ up, int K, int C, int M, int Cin, int nch, int dgrad,
+                                                  int *__restrict__ live, int Mp) {
+    const int64_t total = (int64_t)((M + 31) / 32) * nch * 32 * WG_CK;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x)
+        wg1_pack_one(o, w, pm, thr, up, C, M, Cin, nch, dgrad, live, Mp);
+}
+
+// Up to two pack jobs in ONE launch (cpg_conv2d_pack: a training step's forward and input-gradient operands of a layer -- the same
+// weights in two layouts): work items [0, a.total) are job a's, [a.total, a.total + b.total) job b's.  Family 1 is pointwise.hip's
+// k_pw_pack (Wp[c][m] = W[co][ci] * bin(pm), fwd: c = ci, m = co; dgrad: c = co, m = ci), family 2 wg1_pack_one above.
+struct PackArgs {
+    int family, K, C, a, b, c, d;
+    long long total;
+    float *out;
+};
+__device__ __forceinline__ void pack_job_one(const PackArgs &j, int64_t o, const float *__restrict__ w, const float *__restrict__ pm, float thr) {
+    if (j.family == 1) {
+        const int Mp = j.b, dgrad = j.c;
+        const int m = (int)(o % Mp), c = (int)(o / Mp);
+        const int co = dgrad ? c : m, ci = dgrad ? m : c;
+        float v = 0.0f;
+        if (co < j.K && ci < j.C) {
+            const int64_t off = (int64_t)co * j.C + ci;
+            v = w[off];
+            if (pm != nullptr) v *= binarize(pm[off], thr);
+        }
+        j.out[o] = v;
+    } else {
+        wg1_pack_one(o, w, pm, thr, j.out, j.C, j.a, j.b, j.c, j.d, nullptr, 0);
+    }
+}
+__global__ __launch_bounds__(256) void k_pack_jobs(const PackArgs a, const PackArgs b, const float *__restrict__ w,
+                                                   const float *__restrict__ pm, float thr) {
+    const int64_t total = a.total + b.total;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        if (o < a.total)
+            pack_job_one(a, o, w, pm, thr);
+        else
+            pack_job_one(b, o - a.total, w, pm, thr);
+    }
+}
+
 // Inference: eval-mode BatchNorm (+ ReLU) in the epilogue -- the expression of conv3x3.hip's C3BnEval -- and the dead-channel skip:
 // `live` (may be null) are the flags k_wg1_pack wrote, same layout as k_c3_pack's (live[m]: output channel m has a non-zero
 // weight; live[Mp + 4 + q]: input chunk q has one; live[Mp] receives 4 x the chunks up to the last live one, live[Mp + 1] counts
@@ -555,7 +597,7 @@ struct WgBnEval {
     int Mp;
 };
 
-// -DWG_TIMING (development builds only, tools/diag_wg_timing.py): every wave of k_wg1 leaves the constant-clock time of its
+// -DWG_TIMING (development builds only, tools/attic/diag_wg_timing.py): every wave of k_wg1 leaves the constant-clock time of its
 // entry / prologue start / main loop start / epilogue start / exit and its hardware slot in wg_dbg.
 #ifdef WG_TIMING
 __device__ unsigned long long wg_dbg[65536 * 8];
@@ -890,7 +932,7 @@ void k_wg1(WgGeom g, const float *__restrict__ x, const float *__restrict__ up, 
     // hb: with / without a conv bias, decided ONCE outside (the two epilogues are separate code).  With the bias load behind a
     // branch inside the per-channel code the compiler's s_waitcnt vmcnt(0) for it sat in the common path: every channel waited for
     // the previous channel's stores to be acknowledged, 16 round trips = 3.9 us of a 29 us unit on the 64-channel layers
-    // (tools/diag_wg_timing.py); without it 2.7 us.
+    // (tools/attic/diag_wg_timing.py); without it 2.7 us.
     auto out_e = [&](auto hb, int e, const float (&m)[16]) {       // m[4 i + j] = M[i][j] of output channel element e
         float r_[4][2];
 #pragma unroll
@@ -2198,8 +2240,19 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
         wino_geom(g, N, c_read, m, H, W);
         float *up = (float *)ws;
         const WgBnEval none{nullptr, nullptr, nullptr, nullptr, 0.0f, 0, nullptr, 0};
-        hipLaunchKernelGGL(k_wg1_pack, dim3(stream_grid((int64_t)g.nkb * g.nch * 32 * WG_CK, 256)), dim3(256), 0, stream, w, pm, thr, up,
-                           K, C, m, c_read, g.nch, dgrad ? 1 : 0, bne ? bne->live : nullptr, bne ? bne->Mp : 0);
+        int ps = 0;
+        if (bne == nullptr) {      // (the inference epilogue's pack also writes the liveness flags: never taken from a caller's operand)
+            const float *pre = nullptr;
+            ps = cpg::pack_site(cpg::PackJob{2, K, C, m, c_read, g.nch, dgrad ? 1 : 0, (long long)((m + 31) / 32) * g.nch * 32 * WG_CK, need}, &pre, what);
+            if (ps == 1) return CPG_OK;
+            if (ps < 0) return ps;
+            if (ps == 2) up = const_cast<float *>(pre);
+        } else if (cpg::pack_query()) {
+            return CPG_OK;
+        }
+        if (ps != 2)
+            hipLaunchKernelGGL(k_wg1_pack, dim3(stream_grid((int64_t)g.nkb * g.nch * 32 * WG_CK, 256)), dim3(256), 0, stream, w, pm, thr, up,
+                               K, C, m, c_read, g.nch, dgrad ? 1 : 0, bne ? bne->live : nullptr, bne ? bne->Mp : 0);
         const int64_t runs = (g.tiles_total + W1_T - 1) / W1_T;
         const bool persist = wino_persist();
         if (variant == WV_PAIR64) {
@@ -2319,6 +2372,7 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
         return CPG_OK;
     }
     if (bne != nullptr) return fail(CPG_E_UNSUPPORTED, "%s: the block kernels have no inference epilogue", what);
+    if (cpg::pack_query()) return CPG_OK;        // (the block kernels pack for themselves: no job recorded)
     const int nw = wino_nw(c_read, m), BK = 8 * nw;
     WgGeom g;
     g.N = N, g.C = c_read, g.H = H, g.W = W, g.M = m;
@@ -2335,5 +2389,19 @@ static int wino_run(int dgrad, int N, int c_read, int m, int H, int W, int K, in
                            : wino_launch<4>(dgrad != 0, g, tblocks, x, up, bias, y, stats, stream);
     if (rc != CPG_OK) return rc;
     CPG_CHECK_LAUNCH(what);
+    return CPG_OK;
+}
+
+// cpg_conv2d_pack's launch (declared in cpg_common.h): job b may be null
+int cpg::pack_jobs_launch(const cpg::PackJob *ja, float *dst_a, const cpg::PackJob *jb, float *dst_b, const float *w, const float *pm, float thr,
+                          hipStream_t stream) {
+    auto args = [](const cpg::PackJob *j, float *dst) {
+        if (j == nullptr) return PackArgs{0, 0, 0, 0, 0, 0, 0, 0, nullptr};
+        return PackArgs{j->family, j->K, j->C, j->a, j->b, j->c, j->d, j->total, dst};
+    };
+    const PackArgs a = args(ja, dst_a), b = args(jb, dst_b);
+    if (a.total + b.total <= 0) return CPG_OK;
+    hipLaunchKernelGGL(k_pack_jobs, dim3(stream_grid(a.total + b.total, 256)), dim3(256), 0, stream, a, b, w, pm, thr);
+    CPG_CHECK_LAUNCH("cpg_conv2d_pack");
     return CPG_OK;
 }

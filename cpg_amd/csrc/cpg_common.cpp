@@ -18,6 +18,27 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+static thread_local PackCtx g_pack = {};
+PackCtx &pack_ctx() { return g_pack; }
+
+int pack_site(const PackJob &job, const float **pre, const char *what) {
+    PackCtx &c = g_pack;
+    if (c.mode == PACK_QUERY) {
+        c.job = job;
+        c.hit = true;
+        return 1;
+    }
+    if (c.mode == PACK_USE && !c.hit) {
+        if (c.use == nullptr || c.use_bytes != job.bytes || (((uintptr_t)c.use) & 15) != 0)
+            return fail(CPG_E_INVALID, "%s: the packed operand handed in (%zu bytes) is not the one this launch streams (%zu bytes, 16-byte aligned)",
+                        what, c.use_bytes, job.bytes);
+        *pre = c.use;
+        c.hit = true;
+        return 2;
+    }
+    return 0;
+}
+
 // Process-wide: the weight-gradient planners that read it run inside autograd's backward, i.e. on the engine's per-device worker
 // thread, not on the thread that called cpg_set_shared_chip_hint (round 3 kept it thread-local and the planners never saw it).
 static std::atomic<int> g_shared_chip{0};

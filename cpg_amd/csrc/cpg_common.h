@@ -57,6 +57,36 @@ int opt(Opt o);                                   // the value, or OPT_UNSET
 inline bool opt_on(Opt o) { const int v = opt(o); return v != OPT_UNSET && v != 0; }     // boolean switches
 inline int opt_or(Opt o, int dflt) { const int v = opt(o); return v == OPT_UNSET ? dflt : v; }
 
+// ---- packed weight operands handed in by the caller (include/cpg_hip.h: cpg_conv2d_pack / cpg_conv2d_use_packed, ABI 3) ------------
+// The pointwise and the one-/two-wave Winograd kernels stream the effective weight W * bin(pm) from a packed copy that every call used
+// to produce into its own workspace first.  A caller may now produce it ONCE (and the forward's and the input gradient's in one launch)
+// and hand it to the calls that need it.  The plumbing is a per-THREAD one-shot context: cpg_conv2d_use_packed arms it, the next conv
+// entry point on that thread consumes (or drops) it; the same context in QUERY mode is how cpg_conv2d_pack finds out what a call of
+// this shape would pack -- the call runs to its pack site, records the job and returns before anything is launched.
+struct PackJob {
+    int family;               // 0 none, 1 pointwise (k_pw_pack's layout), 2 Winograd per-lane U (k_wg1_pack's layout)
+    int K, C;                 // the layer's weight is [K][C][R][S]
+    int a, b, c, d;           // family 1: rows, Mp, dgrad, 0;  family 2: M, Cin, nch, dgrad
+    long long total;          // work items of the pack pass
+    size_t bytes;             // size of the packed operand
+};
+enum { PACK_NONE = 0, PACK_QUERY = 1, PACK_USE = 2 };
+struct PackCtx {
+    int mode;
+    bool hit;                 // QUERY: a job was recorded;  USE: the operand was consumed
+    PackJob job;
+    const float *use;
+    size_t use_bytes;
+};
+PackCtx &pack_ctx();          // thread-local
+inline bool pack_query() { return pack_ctx().mode == PACK_QUERY; }
+// At a pack site: 0 = pack into the workspace as always; 1 = QUERY (job recorded: return CPG_OK now); 2 = *pre is the caller's operand
+// (skip the pack); < 0 = the caller's operand does not fit this launch (status to return).
+int pack_site(const PackJob &job, const float **pre, const char *what);
+// one launch that carries out up to two jobs (conv3x3_wino.hip)
+int pack_jobs_launch(const PackJob *ja, float *dst_a, const PackJob *jb, float *dst_b, const float *w, const float *pm, float thr,
+                     hipStream_t stream);
+
 inline int hip_status(hipError_t e, const char *what) {
     if (e == hipSuccess) return CPG_OK;
     return fail(CPG_E_HIP_BASE + (int)e, "%s: %s", what, hipGetErrorString(e));

@@ -658,10 +658,23 @@ extern "C" int cpg_conv2d_dgrad_generic(const cpg_conv_desc *d, const float *gy,
     return CPG_OK;
 }
 
+// Drops the calling thread's packed-operand context when a conv entry point returns, whether or not the launch consumed it
+// (cpg_conv2d_use_packed is one-shot).  QUERY mode is cpg_conv2d_pack's own and is cleared by it.
+namespace {
+struct PackScope {
+    ~PackScope() {
+        cpg::PackCtx &c = cpg::pack_ctx();
+        if (c.mode == cpg::PACK_USE) c = cpg::PackCtx{};
+    }
+};
+}  // namespace
+
 extern "C" int cpg_conv2d_fwd(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr,
                               const float *bias, float *y, void *ws, size_t ws_bytes, void *stream) {
+    PackScope scope;
     if (d && cpg_conv3x3_supported(d)) return cpg_conv3x3_fwd(d, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream);
     if (d && cpg_conv1x1_supported(d)) return cpg_conv1x1_fwd(d, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream);
+    if (cpg::pack_query()) return CPG_OK;
     if (d && cpg_conv3x3s2_supported(d)) return cpg_conv3x3s2_fwd(d, x, w, pm, thr, bias, y, nullptr, ws, ws_bytes, (hipStream_t)stream);
     if (d && cpg_conv_stem2_ok(d)) return cpg_conv_stem2_fwd(d, x, w, pm, thr, bias, y, nullptr, (hipStream_t)stream);
     return cpg_conv2d_fwd_generic(d, x, w, pm, thr, bias, y, stream);
@@ -677,11 +690,13 @@ extern "C" int32_t cpg_conv2d_bnstats_tiles(const cpg_conv_desc *d) {
 extern "C" int cpg_conv2d_fwd_bnstats(const cpg_conv_desc *d, const float *x, const float *w, const float *pm, float thr,
                                       const float *bias, float *y, float *stats, size_t stats_bytes, void *ws, size_t ws_bytes,
                                       void *stream) {
+    PackScope scope;
     const int tiles = cpg_conv2d_bnstats_tiles(d);
     if (tiles <= 0) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_fwd_bnstats: no fused-statistics kernel for this shape");
     const size_t need = (size_t)d->K * tiles * 2 * sizeof(float);
     if (stats == nullptr || stats_bytes < need)
         return fail(CPG_E_WORKSPACE, "cpg_conv2d_fwd_bnstats: statistics buffer %zu < %zu bytes", stats_bytes, need);
+    if (cpg::pack_query() && (cpg_conv3x3s2_supported(d) || cpg_conv_stem2_ok(d))) return CPG_OK;
     if (cpg_conv3x3s2_supported(d)) return cpg_conv3x3s2_fwd(d, x, w, pm, thr, bias, y, stats, ws, ws_bytes, (hipStream_t)stream);
     if (cpg_conv_stem2_ok(d)) return cpg_conv_stem2_fwd(d, x, w, pm, thr, bias, y, stats, (hipStream_t)stream);
     if (!cpg_conv3x3_supported(d)) return cpg_conv1x1_fwd(d, x, w, pm, thr, bias, y, ws, ws_bytes, (hipStream_t)stream, stats);
@@ -725,6 +740,7 @@ extern "C" int32_t cpg_conv2d_dgrad_bnbwd_tiles(const cpg_conv_desc *d) {
 extern "C" int cpg_conv2d_dgrad_bnbwd(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr,
                                       const float *ypre, const float *gamma, const float *beta, const float *mean, const float *invstd,
                                       float *gm, float *partials, size_t partial_bytes, void *ws, size_t ws_bytes, void *stream) {
+    PackScope scope;
     ConvGeom g;
     int rc = make_geom(d, g);
     if (rc) return rc;
@@ -736,8 +752,10 @@ extern "C" int cpg_conv2d_dgrad_bnbwd(const cpg_conv_desc *d, const float *gy, c
 
 extern "C" int cpg_conv2d_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr,
                                 float *gx, void *ws, size_t ws_bytes, void *stream) {
+    PackScope scope;
     if (d && cpg_conv3x3_supported(d)) return cpg_conv3x3_dgrad(d, gy, w, pm, thr, gx, ws, ws_bytes, (hipStream_t)stream);
     if (d && cpg_conv1x1_supported(d)) return cpg_conv1x1_dgrad(d, gy, w, pm, thr, gx, ws, ws_bytes, (hipStream_t)stream);
+    if (cpg::pack_query()) return CPG_OK;
     if (d && cpg_conv3x3s2_supported(d)) return cpg_conv3x3s2_dgrad(d, gy, w, pm, thr, gx, ws, ws_bytes, (hipStream_t)stream);
     return cpg_conv2d_dgrad_generic(d, gy, w, pm, thr, gx, stream);
 }
@@ -754,12 +772,74 @@ extern "C" int32_t cpg_conv2d_dgrad_add_supported(const cpg_conv_desc *d) {
 }
 extern "C" int cpg_conv2d_dgrad_add(const cpg_conv_desc *d, const float *gy, const float *w, const float *pm, float thr, const float *addend,
                                     float *gx, void *ws, size_t ws_bytes, void *stream) {
+    PackScope scope;
     if (!cpg_conv2d_dgrad_add_supported(d))
         return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_dgrad_add: dense 1x1 layers and the 3x3 layers of the two-wave Winograd kernel fuse the addend");
     CPG_REQUIRE(addend != nullptr && gy && w && gx, "cpg_conv2d_dgrad_add: null pointer");
     if (cpg_conv3x3_supported(d))
         return cpg_conv3x3_wino_dgrad_add(d->N, d->K, d->C, d->H, d->W, d->K, d->C, gy, w, pm, thr, addend, gx, ws, ws_bytes, (hipStream_t)stream);
     return cpg_conv1x1_dgrad(d, gy, w, pm, thr, gx, ws, ws_bytes, (hipStream_t)stream, addend);
+}
+
+// ---- caller-owned packed weight operands (include/cpg_hip.h, ABI 3) ------------------------------------------------------------------
+namespace {
+// What a call of this pass would pack: run the REAL dispatch in query mode -- it stops at the pack site.  Only shape classes whose every
+// route ends at a hooked site may enter (3x3 s1 p1 layers on the Winograd kernels, pointwise layers): the pointers below are never
+// dereferenced, but a route without a site would launch on them.
+bool query_pack_job(const cpg_conv_desc *d, int pass, cpg::PackJob *out) {
+    ConvGeom g;
+    if (d == nullptr || pass < 0 || pass > 2 || make_geom(d, g) != CPG_OK) return false;
+    if (d->N <= 0 || d->K <= 0 || d->C <= 0) return false;
+    bool eligible = false;
+    if (cpg_conv3x3_supported(d))
+        eligible = cpg_conv2d_winograd(d, pass == 1 ? 1 : 0) != 0;
+    else if (cpg_conv1x1_supported(d))
+        eligible = true;
+    if (!eligible || (pass == 2 && cpg_conv2d_bnstats_tiles(d) <= 0)) return false;
+    float *const fake = reinterpret_cast<float *>((uintptr_t)1 << 20);
+    const size_t big = (size_t)1 << 46;
+    cpg::PackCtx &c = cpg::pack_ctx();
+    c = cpg::PackCtx{};
+    c.mode = cpg::PACK_QUERY;
+    const int rc = pass == 1   ? cpg_conv2d_dgrad(d, fake, fake, nullptr, 0.0f, fake, fake, big, nullptr)
+                   : pass == 2 ? cpg_conv2d_fwd_bnstats(d, fake, fake, nullptr, 0.0f, nullptr, fake, fake, big, fake, big, nullptr)
+                               : cpg_conv2d_fwd(d, fake, fake, nullptr, 0.0f, nullptr, fake, fake, big, nullptr);
+    const bool hit = c.hit;
+    const cpg::PackJob job = c.job;
+    c = cpg::PackCtx{};
+    if (rc != CPG_OK || !hit || job.family == 0) return false;
+    *out = job;
+    return true;
+}
+}  // namespace
+
+extern "C" size_t cpg_conv2d_pack_bytes(const cpg_conv_desc *d, int32_t pass) {
+    cpg::PackJob j;
+    return query_pack_job(d, pass, &j) ? j.bytes : 0;
+}
+
+extern "C" int cpg_conv2d_pack(const cpg_conv_desc *d, const float *w, const float *pm, float thr, int32_t pass_a, void *packed_a,
+                               size_t bytes_a, int32_t pass_b, void *packed_b, size_t bytes_b, void *stream) {
+    CPG_REQUIRE(d && w && packed_a, "cpg_conv2d_pack: null pointer");
+    cpg::PackJob ja, jb;
+    if (!query_pack_job(d, pass_a, &ja)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_pack: pass %d of this shape streams no packed operand", pass_a);
+    if (bytes_a != ja.bytes) return fail(CPG_E_WORKSPACE, "cpg_conv2d_pack: buffer of %zu bytes for a %zu-byte operand (pass %d)", bytes_a, ja.bytes, pass_a);
+    CPG_REQUIRE((((uintptr_t)packed_a) & 15) == 0 && (((uintptr_t)packed_b) & 15) == 0, "cpg_conv2d_pack: packed operands must be 16-byte aligned");
+    if (packed_b != nullptr) {
+        if (!query_pack_job(d, pass_b, &jb)) return fail(CPG_E_UNSUPPORTED, "cpg_conv2d_pack: pass %d of this shape streams no packed operand", pass_b);
+        if (bytes_b != jb.bytes) return fail(CPG_E_WORKSPACE, "cpg_conv2d_pack: buffer of %zu bytes for a %zu-byte operand (pass %d)", bytes_b, jb.bytes, pass_b);
+    }
+    return cpg::pack_jobs_launch(&ja, (float *)packed_a, packed_b ? &jb : nullptr, (float *)packed_b, w, pm, thr, (hipStream_t)stream);
+}
+
+extern "C" int cpg_conv2d_use_packed(const void *packed, size_t bytes) {
+    cpg::PackCtx &c = cpg::pack_ctx();
+    c = cpg::PackCtx{};
+    if (packed == nullptr) return CPG_OK;        // (disarms)
+    c.mode = cpg::PACK_USE;
+    c.use = (const float *)packed;
+    c.use_bytes = bytes;
+    return CPG_OK;
 }
 
 extern "C" int cpg_conv2d_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, const float *w, const float *pm,

@@ -48,7 +48,7 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
 
 // Sum over the 32 lanes of each half-wave by DPP (quad swaps, half-row / row mirrors, then lane 15 of rows 0 / 2 into rows 1 / 3):
 // five v_add_f32_dpp per value, the result valid in lanes 16-31 and 48-63.  The ds_bpermute butterfly this replaces cost the
-// statistics epilogue of the Winograd kernel k_wg3 4.7 us per unit (tools/diag_wg_timing.py --stats): 320 LDS-crossbar round trips.  Eight values per
+// statistics epilogue of the Winograd kernel k_wg3 4.7 us per unit (tools/attic/diag_wg_timing.py --stats): 320 LDS-crossbar round trips.  Eight values per
 // asm block, step by step across the eight: a DPP operand must not be read within two instructions of the VALU write that produced
 // it, and neither the assembler nor the compiler looks into inline asm for that.
 #define CPG_DPP8(OP)                                                                                                                \

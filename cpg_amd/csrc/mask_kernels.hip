@@ -311,7 +311,182 @@ __global__ __launch_bounds__(kThreads) void k_adam_route(float *__restrict__ pm,
 
 inline int is16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
+// ---------------------------------------------------------------- multi-tensor forms of the two fused optimizer passes (ABI 3)
+// One launch for up to kMultiMax layers: the per-layer pointers travel BY VALUE in the kernel arguments (no device table, no copy),
+// a block owns one kChunk-element piece of one layer and finds it by walking the (block-uniform, scalar) prefix of pieces per layer.
+// The arithmetic per element is k_sgd_route's / k_adam_route's own `one`: results do not depend on how the work is cut.
+constexpr int kMultiMax = 48;
+constexpr int kChunk = kThreads * 16;           // elements per block: 4 float4 per thread
+struct SgdItems {
+    float *w[kMultiMax], *gw[kMultiMax], *buf[kMultiMax];
+    const uint8_t *owner[kMultiMax];
+    long long n[kMultiMax];
+    int first_block[kMultiMax + 1];             // pieces before layer i; [count] = grid size
+    unsigned char vec[kMultiMax];
+    int count;
+};
+struct AdamItems {
+    float *pm[kMultiMax], *gpm[kMultiMax], *m1[kMultiMax], *m2[kMultiMax];
+    const uint8_t *owner[kMultiMax];
+    long long n[kMultiMax];
+    int first_block[kMultiMax + 1];
+    unsigned char vec[kMultiMax];
+    int count;
+};
+static_assert(sizeof(SgdItems) <= 4096 && sizeof(AdamItems) <= 4096, "kernel arguments are limited to 4 KB");
+
+template <class Items>
+__device__ __forceinline__ int find_item(const Items &it, int block) {
+    int i = 0;
+    while (i + 1 < it.count && it.first_block[i + 1] <= block) ++i;
+    return i;
+}
+
+__global__ __launch_bounds__(kThreads) void k_sgd_route_multi(const SgdItems it, int cur, float wd, float lr, float momentum, int nesterov,
+                                                              int first) {
+    const int item = find_item(it, (int)blockIdx.x);
+    const int64_t base = (int64_t)((int)blockIdx.x - it.first_block[item]) * kChunk;
+    const int64_t n = it.n[item];
+    const int64_t end = base + kChunk < n ? base + kChunk : n;
+    float *__restrict__ w = it.w[item], *__restrict__ gw = it.gw[item], *__restrict__ buf = it.buf[item];
+    const uint8_t *__restrict__ owner = it.owner[item];
+    auto one = [&](float &wv, float &gv, float &bv, int o) {
+        const float g = (o == cur) ? fmaf(wd, wv, gv) : 0.0f;
+        const float b = first ? g : __fadd_rn(__fmul_rn(momentum, bv), g);
+        const float d = nesterov ? fmaf(momentum, b, g) : b;
+        wv = fmaf(-lr, d, wv);
+        gv = g;
+        bv = b;
+    };
+    if (it.vec[item]) {
+        const int64_t e4 = end >> 2;                // (base is a multiple of kChunk, hence of 4)
+        for (int64_t i = (base >> 2) + threadIdx.x; i < e4; i += kThreads) {
+            const uint32_t o4 = reinterpret_cast<const uint32_t *>(owner)[i];
+            F4 wv = reinterpret_cast<F4 *>(w)[i], gv = reinterpret_cast<F4 *>(gw)[i];
+            F4 bv = first ? F4{0.f, 0.f, 0.f, 0.f} : reinterpret_cast<F4 *>(buf)[i];
+            one(wv.x, gv.x, bv.x, o4 & 255);
+            one(wv.y, gv.y, bv.y, (o4 >> 8) & 255);
+            one(wv.z, gv.z, bv.z, (o4 >> 16) & 255);
+            one(wv.w, gv.w, bv.w, o4 >> 24);
+            reinterpret_cast<F4 *>(w)[i] = wv;
+            reinterpret_cast<F4 *>(gw)[i] = gv;
+            reinterpret_cast<F4 *>(buf)[i] = bv;
+        }
+        for (int64_t i = (e4 << 2) + threadIdx.x; i < end; i += kThreads) {
+            float bv = first ? 0.f : buf[i];
+            one(w[i], gw[i], bv, owner[i]);
+            buf[i] = bv;
+        }
+    } else {
+        for (int64_t i = base + threadIdx.x; i < end; i += kThreads) {
+            float bv = first ? 0.f : buf[i];
+            one(w[i], gw[i], bv, owner[i]);
+            buf[i] = bv;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_adam_route_multi(const AdamItems it, int cur, int mode, float step_size, float omb1, float beta2,
+                                                               float omb2, float eps, float bc2_sqrt) {
+    const int item = find_item(it, (int)blockIdx.x);
+    const int64_t base = (int64_t)((int)blockIdx.x - it.first_block[item]) * kChunk;
+    const int64_t n = it.n[item];
+    const int64_t end = base + kChunk < n ? base + kChunk : n;
+    float *__restrict__ pm = it.pm[item], *__restrict__ gpm = it.gpm[item], *__restrict__ m1 = it.m1[item], *__restrict__ m2 = it.m2[item];
+    const uint8_t *__restrict__ owner = it.owner[item];
+    auto one = [&](float &p, float &g, float &a, float &b, int o) {
+        const bool keep = mode == CPG_MODE_FINETUNE && o != 0 && o < cur;
+        const float gr = keep ? g : 0.0f;
+        a = fmaf(omb1, gr - a, a);
+        b = fmaf(omb2, gr * gr, beta2 * b);
+        const float denom = sqrtf(b) / bc2_sqrt + eps;
+        p = fmaf(-step_size, a / denom, p);
+        g = gr;
+    };
+    if (it.vec[item]) {
+        const int64_t e4 = end >> 2;
+        for (int64_t i = (base >> 2) + threadIdx.x; i < e4; i += kThreads) {
+            const uint32_t o4 = reinterpret_cast<const uint32_t *>(owner)[i];
+            F4 pv = reinterpret_cast<F4 *>(pm)[i], gv = reinterpret_cast<F4 *>(gpm)[i];
+            F4 av = reinterpret_cast<F4 *>(m1)[i], bv = reinterpret_cast<F4 *>(m2)[i];
+            one(pv.x, gv.x, av.x, bv.x, o4 & 255);
+            one(pv.y, gv.y, av.y, bv.y, (o4 >> 8) & 255);
+            one(pv.z, gv.z, av.z, bv.z, (o4 >> 16) & 255);
+            one(pv.w, gv.w, av.w, bv.w, o4 >> 24);
+            reinterpret_cast<F4 *>(pm)[i] = pv;
+            reinterpret_cast<F4 *>(gpm)[i] = gv;
+            reinterpret_cast<F4 *>(m1)[i] = av;
+            reinterpret_cast<F4 *>(m2)[i] = bv;
+        }
+        for (int64_t i = (e4 << 2) + threadIdx.x; i < end; i += kThreads) one(pm[i], gpm[i], m1[i], m2[i], owner[i]);
+    } else {
+        for (int64_t i = base + threadIdx.x; i < end; i += kThreads) one(pm[i], gpm[i], m1[i], m2[i], owner[i]);
+    }
+}
+
 }  // namespace
+
+extern "C" int32_t cpg_multi_tensor_max(void) { return kMultiMax; }
+
+extern "C" int cpg_sgd_route_step_multi(const cpg_sgd_item *items_host, int32_t n_items, int32_t cur, float wd, float lr, float momentum,
+                                        int32_t nesterov, int32_t first_step, void *stream) {
+    CPG_REQUIRE(n_items >= 0 && (n_items == 0 || items_host), "cpg_sgd_route_step_multi: null item table or negative count");
+    CPG_REQUIRE(cur >= 0 && cur <= 255, "cpg_sgd_route_step_multi: owner id %d out of uint8 range", cur);
+    for (int32_t at = 0; at < n_items;) {
+        SgdItems it;
+        int blocks = 0;
+        it.count = 0;
+        for (; at < n_items && it.count < kMultiMax; ++at) {
+            const cpg_sgd_item &s = items_host[at];
+            CPG_REQUIRE(s.n >= 0 && (s.n == 0 || (s.w && s.gw && s.momentum_buf && s.owner)), "cpg_sgd_route_step_multi: item %d: null pointer or negative n", at);
+            if (s.n == 0) continue;
+            const int64_t pieces = (s.n + kChunk - 1) / kChunk;
+            CPG_REQUIRE(blocks + pieces < (1ll << 30), "cpg_sgd_route_step_multi: item %d is too large for one launch", at);
+            const int i = it.count++;
+            it.w[i] = s.w, it.gw[i] = s.gw, it.buf[i] = s.momentum_buf, it.owner[i] = s.owner, it.n[i] = s.n;
+            it.vec[i] = is16(s.w) && is16(s.gw) && is16(s.momentum_buf) && (((uintptr_t)s.owner) & 3) == 0;
+            it.first_block[i] = blocks;
+            blocks += (int)pieces;
+        }
+        if (it.count == 0) continue;
+        it.first_block[it.count] = blocks;
+        hipLaunchKernelGGL(k_sgd_route_multi, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, it, cur, wd, lr, momentum, nesterov, first_step);
+        CPG_CHECK_LAUNCH("cpg_sgd_route_step_multi");
+    }
+    return CPG_OK;
+}
+
+extern "C" int cpg_adam_route_step_multi(const cpg_adam_item *items_host, int32_t n_items, int32_t cur, int32_t mode, double lr, double beta1,
+                                         double beta2, double eps, int32_t step, void *stream) {
+    CPG_REQUIRE(n_items >= 0 && (n_items == 0 || items_host), "cpg_adam_route_step_multi: null item table or negative count");
+    CPG_REQUIRE(mode == CPG_MODE_FINETUNE || mode == CPG_MODE_PRUNE, "cpg_adam_route_step_multi: unknown mode %d", mode);
+    CPG_REQUIRE(cur >= 0 && cur <= 255 && step >= 1, "cpg_adam_route_step_multi: owner id %d / step %d out of range", cur, step);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    for (int32_t at = 0; at < n_items;) {
+        AdamItems it;
+        int blocks = 0;
+        it.count = 0;
+        for (; at < n_items && it.count < kMultiMax; ++at) {
+            const cpg_adam_item &s = items_host[at];
+            CPG_REQUIRE(s.n >= 0 && (s.n == 0 || (s.pm && s.gpm && s.exp_avg && s.exp_avg_sq && s.owner)),
+                        "cpg_adam_route_step_multi: item %d: null pointer or negative n", at);
+            if (s.n == 0) continue;
+            const int64_t pieces = (s.n + kChunk - 1) / kChunk;
+            CPG_REQUIRE(blocks + pieces < (1ll << 30), "cpg_adam_route_step_multi: item %d is too large for one launch", at);
+            const int i = it.count++;
+            it.pm[i] = s.pm, it.gpm[i] = s.gpm, it.m1[i] = s.exp_avg, it.m2[i] = s.exp_avg_sq, it.owner[i] = s.owner, it.n[i] = s.n;
+            it.vec[i] = is16(s.pm) && is16(s.gpm) && is16(s.exp_avg) && is16(s.exp_avg_sq) && (((uintptr_t)s.owner) & 3) == 0;
+            it.first_block[i] = blocks;
+            blocks += (int)pieces;
+        }
+        if (it.count == 0) continue;
+        it.first_block[it.count] = blocks;
+        hipLaunchKernelGGL(k_adam_route_multi, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, it, cur, mode, (float)(lr / bc1),
+                           (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)sqrt(bc2));
+        CPG_CHECK_LAUNCH("cpg_adam_route_step_multi");
+    }
+    return CPG_OK;
+}
 
 extern "C" int cpg_adam_route_step(float *pm, float *gpm, float *exp_avg, float *exp_avg_sq, const uint8_t *owner, int32_t cur,
                                    int32_t mode, double lr, double beta1, double beta2, double eps, int32_t step, int64_t n, void *stream) {

@@ -800,7 +800,16 @@ int cpg_conv1x1_fwd(const cpg_conv_desc *d, const float *x, const float *w, cons
     CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
     float *wp = (float *)ws;
     const int rows = pad_to(d->C, 16), Mp = pad_to(d->K, 128);
-    hipLaunchKernelGGL(k_pw_pack, dim3(stream_grid((int64_t)rows * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, d->K, d->C, rows, Mp, 0);
+    {
+        const float *pre = nullptr;
+        const int ps = cpg::pack_site(cpg::PackJob{1, d->K, d->C, rows, Mp, 0, 0, (long long)rows * Mp, need}, &pre, what);
+        if (ps == 1) return CPG_OK;
+        if (ps < 0) return ps;
+        if (ps == 2)
+            wp = const_cast<float *>(pre);
+        else
+            hipLaunchKernelGGL(k_pw_pack, dim3(stream_grid((int64_t)rows * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, d->K, d->C, rows, Mp, 0);
+    }
     const int OH = (d->H - 1) / d->stride_h + 1, OW = (d->W - 1) / d->stride_w + 1;
     PwGeom g{d->N, d->C, d->K, Mp, OW, OH * OW, d->H * d->W, d->stride_h * d->W, d->stride_w, OH * OW, OW, 1, 0, (long long)d->N * OH * OW};
     const bool dense = d->stride_h == 1 && d->stride_w == 1;
@@ -824,7 +833,16 @@ int cpg_conv1x1_dgrad(const cpg_conv_desc *d, const float *gy, const float *w, c
     CPG_REQUIRE((((uintptr_t)ws) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
     float *wp = (float *)ws;
     const int rows = pad_to(d->K, 16), Mp = pad_to(d->C, 128);
-    hipLaunchKernelGGL(k_pw_pack, dim3(stream_grid((int64_t)rows * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, d->K, d->C, rows, Mp, 1);
+    {
+        const float *pre = nullptr;
+        const int ps = cpg::pack_site(cpg::PackJob{1, d->K, d->C, rows, Mp, 1, 0, (long long)rows * Mp, need}, &pre, what);
+        if (ps == 1) return CPG_OK;
+        if (ps < 0) return ps;
+        if (ps == 2)
+            wp = const_cast<float *>(pre);
+        else
+            hipLaunchKernelGGL(k_pw_pack, dim3(stream_grid((int64_t)rows * Mp, 256)), dim3(256), 0, stream, w, pm, thr, wp, d->K, d->C, rows, Mp, 1);
+    }
     const int OH = (d->H - 1) / d->stride_h + 1, OW = (d->W - 1) / d->stride_w + 1;
     const bool dense = d->stride_h == 1 && d->stride_w == 1;
     if (!dense) {       // positions the strided conv never read receive no gradient

@@ -75,6 +75,7 @@ class TaskResult(object):
         self.chosen_ratio = 0.0
         self.needs_growth = False       # the accuracy goal was missed even at the width cap (the reference's exit code 2 with nowhere to go)
         self.no_free_capacity = False   # reference exit code 5
+        self.prune_exit2 = None         # the sparsity of the prune run that died with exit code 2 (a layer ran out of candidates), if any
         self.grown_to = []              # RAW width multipliers tried after the first one (the model widths are their square roots)
         self.retrain_kept = None        # task >= 2: did the piggymask retrain beat the pruned model (choose_retrain_or_not.py)
         self.retrain_acc = None
@@ -439,7 +440,18 @@ class CPGSession(object):
         for s in sparsities:
             if must and prev >= must:
                 break                                              # exit 6 at the start of a run (:379-380)
-            mgr, tr, va = self.prune(args, train_loader, val_loader, prev, s, prune_epochs)
+            try:
+                mgr, tr, va = self.prune(args, train_loader, val_loader, prev, s, prune_epochs)
+            except SystemExit as e:
+                # exit code 2 out of a prune run: a layer has fewer candidates than the rank asks for (utils/prune.py:38-42, "too little
+                # space for new task").  The reference's process dies without saving; bash carries on (the `-ne 6` tests of
+                # experiment1/CPG_cifar100_scratch_mul_1.5.sh:134,168 let it through), no stage is recorded for this ratio and the
+                # selection below works with what earlier runs left.  Here: back to the last recorded stage, the sweep ends.
+                if e.code != 2:
+                    raise
+                res.prune_exit2 = s
+                self.restore(stages[prev] if prev in stages else scratch)
+                break
             if tr <= min_train_acc:                                # exit 6: this run is not recorded, the sweep stops
                 break
             res.ratio_to_acc[s] = round(va, 4)

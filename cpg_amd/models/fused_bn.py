@@ -9,6 +9,7 @@ backward (csrc/bn_kernels.hip).  Semantics are torch.nn.BatchNorm2d's: batch sta
 running statistics in eval mode.  SURVEY.md section 8(f) item 2.
 """
 import ctypes
+import threading
 
 import torch
 import torch.nn as nn
@@ -102,11 +103,38 @@ class _BnReluFn(torch.autograd.Function):
         return gx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
+_tls = threading.local()
+
+
+def _count_batch(bn):
+    """nn.BatchNorm2d's `num_batches_tracked += 1` of a training-mode forward, handed to the kernel that finalises this layer's batch
+    statistics (cpg_bn_stats_finalize_count bumps the counter in the same launch: stock torch spends one `add<long>` launch per layer on
+    it, 53 per ResNet-50 step).  _settle_count() right behind the fused call does the plain add when no such kernel took it."""
+    _tls.nbt = bn.num_batches_tracked
+
+
+def _settle_count():
+    nbt = getattr(_tls, 'nbt', None)
+    if nbt is not None:
+        _tls.nbt = None
+        nbt.add_(1)
+
+
 def _finalize_stats(stats, N, C, HW, eps, momentum, running_mean, running_var, device):
-    """mean / invstd (+ running statistics update) from a conv's [C][tiles][2] partial sums (cpg_bn_stats_finalize)."""
+    """mean / invstd (+ running statistics update, + the pending num_batches_tracked bump) from a conv's [C][tiles][2] partial sums
+    (cpg_bn_stats_finalize / cpg_bn_stats_finalize_count)."""
     L = _lib.lib()
     mean = torch.empty(C, dtype=torch.float32, device=device)
     invstd = torch.empty(C, dtype=torch.float32, device=device)
+    nbt = getattr(_tls, 'nbt', None)
+    if nbt is not None and running_mean is not None and nbt.is_cuda and nbt.dtype == torch.int64 and nbt.numel() == 1:
+        _tls.nbt = None
+        rc = L.cpg_bn_stats_finalize_count(_lib.dptr(stats, name='bn partial sums'), stats.shape[1], N, C, HW, float(eps), float(momentum),
+                                           _lib.dptr(running_mean, name='running_mean'), _lib.dptr(running_var, name='running_var'),
+                                           _lib.dptr(mean), _lib.dptr(invstd), _lib.dptr(nbt, torch.int64, 'num_batches_tracked'),
+                                           _lib.stream_ptr())
+        _lib.check('cpg_bn_stats_finalize_count', rc)
+        return mean, invstd
     rc = L.cpg_bn_stats_finalize(_lib.dptr(stats, name='bn partial sums'), stats.shape[1], N, C, HW, float(eps), float(momentum),
                                  _lib.dptr(running_mean, name='running_mean'), _lib.dptr(running_var, name='running_var'),
                                  _lib.dptr(mean), _lib.dptr(invstd), _lib.stream_ptr())
@@ -281,9 +309,11 @@ def conv_bn_act_pool(conv, bn, act, pool, x):
             and _lib.lib().cpg_bn_relu_pool3_supported(int(y.shape[2]), int(y.shape[3]))):
         training = bn.training
         if training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-        return _BnReluPool3Fn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, training,
-                                    stats if training else None)
+            _count_batch(bn)
+        out = _BnReluPool3Fn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, training,
+                                   stats if training else None)
+        _settle_count()
+        return out
     if stats is not None and type(act) is nn.ReLU and fusable(bn, y):
         return pool(bn_relu(y, bn, relu=True, stats=stats))
     return pool(bn_act(bn, act, y))
@@ -302,8 +332,10 @@ def bn_relu_pool(x, bn, stats=None):
     training = bn.training or not bn.track_running_stats
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    return _BnReluPoolFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, training, stats if training else None)
+        _count_batch(bn)
+    out = _BnReluPoolFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, training, stats if training else None)
+    _settle_count()
+    return out
 
 
 def fusable(bn, x):
@@ -319,9 +351,11 @@ def bn_relu(x, bn, relu=True, stats=None, hint=None):
     training = bn.training or not bn.track_running_stats
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    return _BnReluFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, training, relu,
-                           stats if (training and rm is not None) else None, hint if training else None)
+        _count_batch(bn)
+    out = _BnReluFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, training, relu,
+                          stats if (training and rm is not None) else None, hint if training else None)
+    _settle_count()
+    return out
 
 
 class _PReluFn(torch.autograd.Function):
@@ -426,9 +460,11 @@ def bn_add_act(bn, act, x, res, stats=None):
     if ENABLED and type(act) is nn.ReLU and fusable(bn, x) and bn.track_running_stats and res.shape == x.shape:
         training = bn.training
         if training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-        return _BnAddReluFn.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, training,
-                                  stats if training else None)
+            _count_batch(bn)
+        out = _BnAddReluFn.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, training,
+                                 stats if training else None)
+        _settle_count()
+        return out
     out = bn(x)
     out = out + res
     return act(out)
@@ -536,9 +572,11 @@ def stem_conv_bn_relu(conv, bn, x):
     if not _lib.lib().cpg_stem_bn_supported(ctypes.byref(d)):
         return None
     if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    return _StemConvBnReluFn.apply(x, conv.weight, conv.piggymask, conv.info['threshold'], bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                   bn.eps, bn.momentum)
+        _count_batch(bn)
+    out = _StemConvBnReluFn.apply(x, conv.weight, conv.piggymask, conv.info['threshold'], bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                  bn.eps, bn.momentum)
+    _settle_count()
+    return out
 
 
 FUSE_SKIP_ADD = True       # residual blocks: the identity branch's gradient is added in conv1's input-gradient epilogue

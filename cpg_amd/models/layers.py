@@ -14,6 +14,7 @@ Ternarizer (models/layers.py:25-40) is dead code in the reference (pre-0.4 autog
 selected by any script); asking for it raises NotImplementedError here.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -71,6 +72,28 @@ def _out_hw(d):
     oh = (d.H + 2 * d.pad_h - d.dil_h * (d.R - 1) - 1) // d.stride_h + 1
     ow = (d.W + 2 * d.pad_w - d.dil_w * (d.S - 1) - 1) // d.stride_w + 1
     return oh, ow
+
+
+# CPG_PACK_CACHE=0: every conv call packs its own weight operand (the behaviour up to round 5; A/B switch)
+PACK_CACHE = os.environ.get('CPG_PACK_CACHE', '1') not in ('0', '')
+_PACK_BYTES = {}
+
+
+def _pack_bytes(L, d, which):
+    """cpg_conv2d_pack_bytes per (shape, pass), memoised: the answer depends on the shape and the library options only
+    (cpg_amd._lib.set_option clears the table)."""
+    key = (d.N, d.C, d.H, d.W, d.K, d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.dil_h, d.dil_w, d.groups, which)
+    v = _PACK_BYTES.get(key)
+    if v is None:
+        v = _PACK_BYTES[key] = int(L.cpg_conv2d_pack_bytes(ctypes.byref(d), which))
+    return v
+
+
+def _arm_packed(L, ctx):
+    """hand the input-gradient operand packed at forward time to the launch that follows on this thread (one-shot)"""
+    pk, ctx.packed_dgrad = getattr(ctx, 'packed_dgrad', None), None
+    if pk is not None:
+        _lib.check('cpg_conv2d_use_packed', L.cpg_conv2d_use_packed(_lib.dptr(pk), pk.numel() * 4))
 
 
 class BiasGradSink(object):
@@ -139,6 +162,21 @@ class _MaskedConv2dFn(torch.autograd.Function):
         ws, nbytes = _lib.workspace(L.cpg_conv2d_workspace_bytes(ctypes.byref(d)), x.device)
         tiles = L.cpg_conv2d_bnstats_tiles(ctypes.byref(d)) if bn_stats else 0
         stats = None
+        # Packed weight operands (cpg_conv2d_pack, ABI 3): when this layer's forward AND its input gradient stream one, both are produced
+        # here in ONE launch; the forward takes its own now, the input gradient's rides in ctx until backward (the weights cannot change in
+        # between: autograd's version check on the saved w / pm guards exactly that).  One launch instead of two per layer and step.
+        ctx.packed_dgrad = None
+        if PACK_CACHE and ctx.needs_input_grad[0]:
+            uses_bnbwd = bn_hint is not None and L.cpg_conv2d_dgrad_bnbwd_tiles(ctypes.byref(d)) > 0      # (that launch packs for the direct kernels)
+            nb_f, nb_d = _pack_bytes(L, d, 2 if tiles > 0 else 0), (0 if uses_bnbwd else _pack_bytes(L, d, 1))
+            if nb_f and nb_d:
+                pk_f = torch.empty(nb_f // 4, dtype=torch.float32, device=x.device)
+                pk_d = torch.empty(nb_d // 4, dtype=torch.float32, device=x.device)
+                rc = L.cpg_conv2d_pack(ctypes.byref(d), _lib.dptr(w, name='weight'), _lib.dptr(p, name='piggymask'), float(thr),
+                                       2 if tiles > 0 else 0, _lib.dptr(pk_f), nb_f, 1, _lib.dptr(pk_d), nb_d, _lib.stream_ptr())
+                _lib.check('cpg_conv2d_pack', rc)
+                _lib.check('cpg_conv2d_use_packed', L.cpg_conv2d_use_packed(_lib.dptr(pk_f), nb_f))
+                ctx.packed_dgrad = pk_d
         if tiles > 0:
             stats = torch.empty((d.K, tiles, 2), dtype=torch.float32, device=x.device)
             rc = L.cpg_conv2d_fwd_bnstats(ctypes.byref(d), _lib.dptr(x, name='input'), _lib.dptr(w, name='weight'),
@@ -199,11 +237,13 @@ class _MaskedConv2dFn(torch.autograd.Function):
                 hint.partials, hint.tiles = partials, tiles
             elif addend is not None and L.cpg_conv2d_dgrad_add_supported(ctypes.byref(d)) and addend.shape == x.shape:
                 addend = addend.contiguous()
+                _arm_packed(L, ctx)
                 rc = L.cpg_conv2d_dgrad_add(ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr,
                                             _lib.dptr(addend, name='skip gradient'), _lib.dptr(gx), _lib.dptr(ws), nbytes, s)
                 _lib.check('cpg_conv2d_dgrad_add', rc)
                 addend = None
             else:
+                _arm_packed(L, ctx)
                 rc = L.cpg_conv2d_dgrad(ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr,
                                         _lib.dptr(gx), _lib.dptr(ws), nbytes, s)
                 _lib.check('cpg_conv2d_dgrad', rc)

@@ -47,6 +47,9 @@ class MaskedSGD(torch.optim.SGD):
         pr = self.pruner
         held = []
         for group in self.param_groups:
+            # every masked weight of the group that shares `first` (no momentum buffer yet / has one) goes into ONE multi-tensor launch
+            # (cpg_sgd_route_step_multi: 53 layers of ResNet-50 = 2 launches instead of 53)
+            batches = {True: [], False: []}
             for p in group['params']:
                 name = self._masked.get(id(p))
                 if name is None or p.grad is None:
@@ -56,13 +59,18 @@ class MaskedSGD(torch.optim.SGD):
                 if first:
                     state['momentum_buffer'] = torch.empty_like(p, memory_format=torch.contiguous_format)
                 owner = pr._owner(name, p.data)
-                rc = L.cpg_sgd_route_step(_lib.dptr(p.data, name='weight'), _lib.dptr(p.grad, name='weight.grad'),
-                                          _lib.dptr(state['momentum_buffer'], name='momentum'), _lib.dptr(owner, torch.uint8, 'mask'),
-                                          int(pr.current_dataset_idx), float(pr.args.weight_decay), float(group['lr']),
-                                          float(group['momentum']), int(bool(group['nesterov'])), int(first), p.numel(), s)
-                _lib.check('cpg_sgd_route_step', rc)
+                batches[first].append((_lib.dptr(p.data, name='weight').value, _lib.dptr(p.grad, name='weight.grad').value,
+                                       _lib.dptr(state['momentum_buffer'], name='momentum').value,
+                                       _lib.dptr(owner, torch.uint8, 'mask').value, p.numel()))
                 held.append((p, p.grad))
                 p.grad = None                    # hide from torch's SGD for the rest of this step
+            for first, rows in batches.items():
+                if not rows:
+                    continue
+                items = (_lib.SgdItem * len(rows))(*rows)
+                rc = L.cpg_sgd_route_step_multi(items, len(rows), int(pr.current_dataset_idx), float(pr.args.weight_decay), float(group['lr']),
+                                                float(group['momentum']), int(bool(group['nesterov'])), int(first), s)
+                _lib.check('cpg_sgd_route_step_multi', rc)
         loss = super().step(closure)
         for p, g in held:
             p.grad = g
@@ -100,6 +108,7 @@ class MaskedAdam(torch.optim.Adam):
         held, idle = [], []
         for group in self.param_groups:
             beta1, beta2 = group['betas']
+            batches = {}                         # Adam step count -> rows of one multi-tensor launch
             for p in group['params']:
                 name = self._masked.get(id(p))
                 if name is None or p.grad is None or mode is None:
@@ -124,13 +133,16 @@ class MaskedAdam(torch.optim.Adam):
                     continue
                 state.pop('_pristine', None)
                 owner = pr._owner(name, p.data)
-                rc = L.cpg_adam_route_step(_lib.dptr(p.data, name='piggymask'), _lib.dptr(p.grad, name='piggymask.grad'),
-                                           _lib.dptr(state['exp_avg']), _lib.dptr(state['exp_avg_sq']),
-                                           _lib.dptr(owner, torch.uint8, 'mask'), int(pr.current_dataset_idx), mode,
-                                           float(group['lr']), float(beta1), float(beta2), float(group['eps']),
-                                           int(state['step']), p.numel(), s)
-                _lib.check('cpg_adam_route_step', rc)
+                batches.setdefault(int(state['step']), []).append(
+                    (_lib.dptr(p.data, name='piggymask').value, _lib.dptr(p.grad, name='piggymask.grad').value,
+                     _lib.dptr(state['exp_avg']).value, _lib.dptr(state['exp_avg_sq']).value,
+                     _lib.dptr(owner, torch.uint8, 'mask').value, p.numel()))
                 p.grad = None
+            for step, rows in batches.items():   # (cpg_adam_route_step_multi: every piggymask of the group in one launch)
+                items = (_lib.AdamItem * len(rows))(*rows)
+                rc = L.cpg_adam_route_step_multi(items, len(rows), int(pr.current_dataset_idx), mode, float(group['lr']), float(beta1),
+                                                 float(beta2), float(group['eps']), step, s)
+                _lib.check('cpg_adam_route_step_multi', rc)
         if idle:
             torch._foreach_zero_(idle)           # (one multi-tensor kernel)
         if len(held) > len(idle):

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CPG_ABI_VERSION 2
+#define CPG_ABI_VERSION 3
 
 #define CPG_OK 0
 #define CPG_E_INVALID (-1)
@@ -151,6 +151,27 @@ int cpg_conv2d_wgrad(const cpg_conv_desc *d, const float *x, const float *gy, co
                      const float *pm, float thr, float *gw, float *gpm, float *gb,
                      void *ws, size_t ws_bytes, void *stream);
 
+/* Caller-owned packed weight operands (ABI version 3; SURVEY.md section 8b "an explicit, re-creatable cache (packed keep-bits / W_eff)").
+ * The pointwise kernels and the one- / two-wave Winograd kernels stream W_eff = W * bin(pm) from a packed copy (K-major, resp. the
+ * transformed filter in per-lane order) that every cpg_conv2d_fwd / _dgrad call otherwise produces into its own workspace first -- one
+ * small launch per call, 109 per ResNet-50 step.  With these three calls the caller produces the operands ONCE per weight state -- the
+ * forward's and the input gradient's of a layer in ONE launch -- and hands them to the calls that stream them:
+ *   cpg_conv2d_pack_bytes(desc, pass): size of the operand of pass 0 (cpg_conv2d_fwd), 1 (cpg_conv2d_dgrad / _dgrad_add) or
+ *       2 (cpg_conv2d_fwd_bnstats); 0 = a call of this shape streams no packed operand (it needs no cache).
+ *   cpg_conv2d_pack(desc, w, pm, thr, pass_a, packed_a, bytes_a, pass_b, packed_b, bytes_b, stream): packs for one or (packed_b
+ *       != NULL) two passes in one launch; bytes_* must equal cpg_conv2d_pack_bytes.  The buffers are the caller's; they are valid
+ *       for as long as w, pm, thr, the shape in `desc` and the library options do not change (key them on the tensors' versions).
+ *   cpg_conv2d_use_packed(packed, bytes): arms THE CALLING THREAD -- the next cpg_conv2d_fwd / _fwd_bnstats / _dgrad / _dgrad_add /
+ *       _dgrad_bnbwd call on this thread streams `packed` instead of packing w / pm (which it still takes: a launch of another kernel
+ *       family ignores the operand and packs for itself).  One-shot: that call disarms the thread whether it used the operand or
+ *       not; a size that does not match what the launch streams is CPG_E_INVALID.  NULL disarms.
+ * Results are bit-equal to the self-packing calls.  Reference: the `W_eff` the reference materialises in every forward
+ * (models/layers.py:99-105) and autograd keeps for the backward. */
+size_t cpg_conv2d_pack_bytes(const cpg_conv_desc *desc, int32_t pass);
+int cpg_conv2d_pack(const cpg_conv_desc *desc, const float *w, const float *piggymask, float threshold, int32_t pass_a, void *packed_a,
+                    size_t bytes_a, int32_t pass_b, void *packed_b, size_t bytes_b, void *stream);
+int cpg_conv2d_use_packed(const void *packed, size_t bytes);
+
 /* ---- K5: F.linear of models/layers.py:194 and its autograd ----
  * x [batch][in], w [out][in], y [batch][out]; same masking / gradient rules as conv. */
 size_t cpg_linear_workspace_bytes(int32_t batch, int32_t in_features, int32_t out_features);
@@ -227,6 +248,29 @@ int cpg_sgd_route_step(float *w, float *gw, float *momentum_buf, const uint8_t *
 int cpg_adam_route_step(float *pm, float *gpm, float *exp_avg, float *exp_avg_sq, const uint8_t *owner, int32_t cur,
                         int32_t mode, double lr, double beta1, double beta2, double eps, int32_t step, int64_t n, void *stream);
 
+/* The two fused optimizer passes over MANY layers in one launch (ABI version 3): ResNet-50 has 53 masked layers of 4 k - 2.4 M weights
+ * each, and 53 launches of a few microseconds cost the queue more than the bytes they move.  `items_host` is a HOST array (the pointers
+ * inside are device pointers, as everywhere else); the library passes them to the kernel by value, cpg_multi_tensor_max() layers per
+ * launch, so nothing is copied to the device and the array may be freed or reused when the call returns.  All items share the scalar
+ * arguments -- callers group parameters by (lr, momentum, nesterov, first_step) / (lr, betas, eps, step) as torch's own foreach path
+ * does.  Element for element the arithmetic is cpg_sgd_route_step's / cpg_adam_route_step's: results are bit-equal to per-layer calls.
+ * Replaces the same reference lines: utils/prune.py:195-211 + CPG_cifar100_main_normal.py:339-346. */
+typedef struct cpg_sgd_item {
+    float *w, *gw, *momentum_buf;
+    const uint8_t *owner;
+    int64_t n;
+} cpg_sgd_item;
+typedef struct cpg_adam_item {
+    float *pm, *gpm, *exp_avg, *exp_avg_sq;
+    const uint8_t *owner;
+    int64_t n;
+} cpg_adam_item;
+int32_t cpg_multi_tensor_max(void);
+int cpg_sgd_route_step_multi(const cpg_sgd_item *items_host, int32_t n_items, int32_t cur, float wd, float lr, float momentum,
+                             int32_t nesterov, int32_t first_step, void *stream);
+int cpg_adam_route_step_multi(const cpg_adam_item *items_host, int32_t n_items, int32_t cur, int32_t mode, double lr, double beta1,
+                              double beta2, double eps, int32_t step, void *stream);
+
 /* ---- nn.BatchNorm2d -> nn.ReLU(inplace) after each masked conv ----
  * (models/vgg.py:137-141: `layers += [conv2d, nn.BatchNorm2d(c), nn.ReLU(inplace=True)]`).
  * x, y, gy, gx: NCHW fp32 with HW = H*W; gamma/beta/mean/invstd/running_*: C floats.
@@ -273,6 +317,12 @@ int cpg_conv2d_fwd_bnstats(const cpg_conv_desc *desc, const float *x, const floa
                            size_t workspace_bytes, void *stream);
 int cpg_bn_stats_finalize(const float *stats, int32_t tiles, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
                           float *running_mean, float *running_var, float *mean, float *invstd, void *stream);
+/* ... and (ABI version 3) nn.BatchNorm2d's `num_batches_tracked += 1` in the same launch (torch.nn.modules.batchnorm: the counter every
+ * training-mode forward bumps; one `add<long>` launch per layer in stock torch -- 53 per ResNet-50 step).  num_batches_tracked: one int64
+ * in device memory, may be NULL. */
+int cpg_bn_stats_finalize_count(const float *stats, int32_t tiles, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
+                                float *running_mean, float *running_var, float *mean, float *invstd, int64_t *num_batches_tracked,
+                                void *stream);
 
 /* Inference (Manager.validate, utils/manager.py:103-121: apply_mask, then model.eval() forward): conv -> BatchNorm2d in
  * eval mode (-> ReLU) of models/vgg.py:137-141 as ONE kernel -- y = [max(0,] (conv(x, W_eff) + bias - running_mean) /

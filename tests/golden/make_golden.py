@@ -649,7 +649,7 @@ def gen_net_train_steps():
 #      sides in two implementations, and ONE flipped element moves every weight-gradient entry it touches by ~1/sqrt(N H W) of its
 #      value (0.3 % of the tensor's scale on a 16 x 16 plane) -- measured here: the reference's own fp32 and fp64 train-mode runs
 #      differ in 3-17 ReLU elements of layer3 / layer4 for every one of 180 input seeds at batch 32.  Train-mode BatchNorm over few
-#      samples amplifies the round-off ~300x (tools/diag_train_steps.py), so this fixture takes BatchNorm in EVAL mode (running
+#      samples amplifies the round-off ~300x (tools/attic/diag_train_steps.py), so this fixture takes BatchNorm in EVAL mode (running
 #      statistics populated by one train-mode pass over another batch; the train-mode BatchNorm kernels are pinned against fp64 in
 #      test_fused_bn_small_planes_fp64) and the input seed, of 120 candidates, whose smallest |ReLU input| / rms(layer) in the fp64
 #      run is largest -- no knife-edge activation exists, so every gradient is held to 1e-4 of its scale.

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     declared -= {'cpg_conv_desc', 'cpg_prune_result'}
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     lib = L.lib()                      # raises if the .so is missing or a symbol is absent
-    assert lib.cpg_version() == L.ABI_VERSION == 2
+    assert lib.cpg_version() == L.ABI_VERSION == 3
     assert lib.cpg_rank_prune_workspace_bytes() > 0
 
 

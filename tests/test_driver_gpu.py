@@ -175,3 +175,22 @@ def test_serving_old_task_from_grown_network_skips_dead_channels():
     names = [m for m in sess.net.features if hasattr(m, 'piggymask') and getattr(m, 'kernel_size', None) == (3, 3)]
     per_call = {m.in_channels: None for m in names}
     assert any(c > 0 and c <= max(per_call) // 2 for c in widths), (widths, sorted(per_call))
+
+
+def test_prune_run_that_runs_out_of_candidates_is_dropped_like_the_reference_process_that_exits_2():
+    """At a 0.1 target every task hands on a tenth of what it got: by task 3 the smallest layer of the narrow net (216 weights) holds two
+    slots of the task and the rank k = round(ratio * candidates) is 0 -- utils/prune.py:38-42 prints "Not enough weights for pruning" and
+    exits with code 2.  The reference's process dies without saving and bash carries on with what earlier runs recorded; the session does
+    the same: the run leaves no stage, the model goes back to the pre-prune state, earlier tasks still answer bit-identically."""
+    sess, args = _session()
+    kept = {}
+    for t in range(3):
+        tr, va = _loaders(t)
+        res = sess.run_task('t%d' % (t + 1), 5, tr, va, accuracy_goal=0.0, finetune_epochs=1, prune_epochs=1, sparsities=(0.1,), args=args,
+                            min_train_acc=-1.0, retrain_epochs=1)
+        kept['t%d' % (t + 1)] = (va, sess.evaluate('t%d' % (t + 1), va))
+        for name, (v, (acc0, outs0)) in kept.items():
+            acc, outs = sess.evaluate(name, v)
+            assert acc == acc0 and all(torch.equal(a, b) for a, b in zip(outs0, outs)), name
+    assert res.prune_exit2 == 0.1 and res.chosen_ratio == 0.0 and set(res.ratio_to_acc) == {0.0}
+    assert int(sum((m == 0).sum() for m in sess.masks.values())) == 0                  # nothing of task 3 was released

@@ -1407,7 +1407,7 @@ def test_train_steps_golden(arch):
     is well conditioned end to end and its gradients are held to 1e-4 of their scale too.  The ResNet-50 gradients are not:
     train-mode BatchNorm over 16-64 samples per channel amplifies fp32 round-off to ~1e-4 of a gradient's scale already
     between torch-CPU fp32 and fp64, and forward values that differ by 2e-5 flip the ReLU of an activation that sits at 3e-6
-    (1 of 8192 in layer4.0 in this fixture: tools/diag_train_steps.py) -- ONE such flip moves that channel's d(beta) by 4 %
+    (1 of 8192 in layer4.0 in this fixture: tools/attic/diag_train_steps.py) -- ONE such flip moves that channel's d(beta) by 4 %
     and every upstream weight gradient by ~0.5 % of its scale.  They get 2e-2 of scale elementwise and 1e-2 in relative L2;
     the per-kernel accuracy behind them is pinned separately (conv / linear oracle tests at 1e-4, the fused BatchNorm kernels
     against fp64 at 1e-6 in test_fused_bn_small_planes_fp64)."""
@@ -2005,7 +2005,7 @@ def test_fused_sequential_equals_unfused(algo, libopt):
     """the same VGG with FusedSequential.fuse on / off: logits and every parameter gradient agree.  Both runs use the same conv
     kernels; what differs is the BatchNorm arithmetic (~1e-7), which this tiny train-mode net (batch 16, 2x2 maps at the end)
     amplifies through ReLU flips.  With the direct conv kernels the gradients agree to 2e-3; with the
-    Winograd kernels (4x the rounding error per conv, an independent realisation in each run) a flip does occur (tools/diag_fused2.py
+    Winograd kernels (4x the rounding error per conv, an independent realisation in each run) a flip does occur (tools/attic/diag_fused2.py
     finds it: the ReLU behind features.47, forward outputs equal to 4e-6): the logits still hold 1e-4, the gradients are compared
     by direction."""
     from cpg_amd.models.fused_bn import FusedSequential
@@ -2032,7 +2032,7 @@ def test_fused_sequential_equals_unfused(algo, libopt):
         sc = float(np.abs(res[False][1][n]).max()) + 1e-12
         if algo == 'direct':
             np.testing.assert_allclose(res[True][1][n], res[False][1][n], rtol=2e-3, atol=2e-4 * sc, err_msg=n)
-        else:       # a flipped ReLU element moves single gradient entries by percents of the scale (tools/diag_fused2.py): direction only
+        else:       # a flipped ReLU element moves single gradient entries by percents of the scale (tools/attic/diag_fused2.py): direction only
             u, v = res[True][1][n].ravel().astype(np.float64), res[False][1][n].ravel().astype(np.float64)
             assert float(u @ v) > 0.999 * float(np.linalg.norm(u) * np.linalg.norm(v)), n
     for n in res[True][2]:
@@ -2176,7 +2176,7 @@ def test_spherenet_training_trajectory_matches_torch_ops(monkeypatch):
     """SphereNet-20 at full width (112 x 112, AngleLinear + AngleLoss) through 15 SGD-nesterov steps at the reference's learning rate for
     this configuration (experiment3/FvGeEm_CPG_face.sh:21-25: 1e-3): the loss trajectory on the HIP kernels (Winograd convs, fused PReLU,
     skip-gradient epilogue, HeadLinear) against the SAME run on torch's own ops from the same state -- a BatchNorm-free network, so the
-    comparison is not chaotic over this many steps (tools/diag_sph_nan.py: within 1e-3 for 36 steps at batch 256)."""
+    comparison is not chaotic over this many steps (tools/attic/diag_sph_nan.py: within 1e-3 for 36 steps at batch 256)."""
     import torch.nn.functional as F
     from cpg_amd.models import fused_bn
     from cpg_amd.models.spherenet import AngleLoss
@@ -3272,3 +3272,177 @@ def test_data_parallel_wrapper_over_rccl_world1(monkeypatch):
                 assert torch.equal(a, b), 'chunked and one-piece gradients differ (piggymask %s)' % pm_on
     finally:
         dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------- ABI 3: multi-tensor optimizer passes, counted BN finalize
+@pytest.mark.parametrize('first', [1, 0])
+def test_multi_tensor_sgd_and_adam_are_bit_equal_to_per_layer_calls(first):
+    """cpg_sgd_route_step_multi / cpg_adam_route_step_multi (one launch for many layers, pointers by value in the kernel arguments) against
+    one cpg_sgd_route_step / cpg_adam_route_step per layer on the same inputs: every output tensor BIT-equal.  70 ragged layers (more than
+    one launch's worth: cpg_multi_tensor_max = 48), sizes from 1 element to 1.3 M, one empty, some starting off 16-byte alignment (the
+    scalar path), owner ids mixed."""
+    import ctypes
+    L = __import__('cpg_amd._lib', fromlist=['x'])
+    lib = L.lib()
+    assert lib.cpg_multi_tensor_max() == 48
+    g = torch.Generator().manual_seed(31)
+    sizes = [1, 3, 4, 0, 5, 4096, 4097, 8191, 1 << 20, 1300001] + [int(v) for v in torch.randint(2, 70000, (60,), generator=g)]
+    cur = 2
+
+    def tensors(n, off):
+        """n-element views `off` elements into their storages (off = 1: not 16-byte aligned)"""
+        def f():
+            return torch.randn(n + off, generator=g).to(DEV)[off:]
+        owner = torch.randint(0, 4, (n + 4 * off,), generator=g, dtype=torch.uint8).to(DEV)[4 * off:] if off else \
+            torch.randint(0, 4, (n,), generator=g, dtype=torch.uint8).to(DEV)
+        return f(), f(), f(), f(), owner
+    layers = [tensors(n, 1 if i % 7 == 3 else 0) for i, n in enumerate(sizes)]
+    s = L.stream_ptr()
+
+    def ptr(t, dt=torch.float32):
+        return ctypes.c_void_p(t.data_ptr()) if t.numel() else None
+    # ---- SGD
+    ref = [[t.clone() for t in lay[:3]] for lay in layers]
+    got = [[t.clone() for t in lay[:3]] for lay in layers]
+    for (w, gw, buf), lay in zip(ref, layers):
+        L.check('sgd', lib.cpg_sgd_route_step(ptr(w), ptr(gw), ptr(buf), ptr(lay[4]), cur, 4e-5, 1e-2, 0.9, 1, first, w.numel(), s))
+    items = (L.SgdItem * len(layers))(*[(t[0].data_ptr() if t[0].numel() else None, t[1].data_ptr() if t[0].numel() else None,
+                                         t[2].data_ptr() if t[0].numel() else None, lay[4].data_ptr() if t[0].numel() else None, t[0].numel())
+                                        for t, lay in zip(got, layers)])
+    L.check('sgd_multi', lib.cpg_sgd_route_step_multi(items, len(layers), cur, 4e-5, 1e-2, 0.9, 1, first, s))
+    for i, (a, b) in enumerate(zip(ref, got)):
+        for k in range(3):
+            assert torch.equal(a[k], b[k]), ('sgd', i, sizes[i], k)
+    # ---- Adam (finetune routing), step 1 on zero moments / step 3 on live ones
+    step = 1 if first else 3
+    ref = [[lay[0].clone(), lay[1].clone(), torch.zeros_like(lay[2]) if first else lay[2].clone().abs(),
+            torch.zeros_like(lay[3]) if first else lay[3].clone().abs()] for lay in layers]
+    got = [[t.clone() for t in r] for r in ref]
+    for (pm, gpm, m1, m2), lay in zip(ref, layers):
+        L.check('adam', lib.cpg_adam_route_step(ptr(pm), ptr(gpm), ptr(m1), ptr(m2), ptr(lay[4]), cur, L.MODE_FINETUNE, 5e-4, 0.9, 0.999, 1e-8,
+                                                step, pm.numel(), s))
+    items = (L.AdamItem * len(layers))(*[tuple((x.data_ptr() if x.numel() else None) for x in t) + (lay[4].data_ptr() if t[0].numel() else None, t[0].numel())
+                                         for t, lay in zip(got, layers)])
+    L.check('adam_multi', lib.cpg_adam_route_step_multi(items, len(layers), cur, L.MODE_FINETUNE, 5e-4, 0.9, 0.999, 1e-8, step, s))
+    for i, (a, b) in enumerate(zip(ref, got)):
+        for k in range(4):
+            assert torch.equal(a[k], b[k]), ('adam', i, sizes[i], k)
+    # a null pointer inside a non-empty item is refused, not dereferenced
+    bad = (L.SgdItem * 1)((None, None, None, None, 16))
+    assert lib.cpg_sgd_route_step_multi(bad, 1, cur, 0.0, 0.1, 0.9, 1, 1, s) < 0
+
+
+def test_bn_stats_finalize_count_bumps_num_batches_tracked_and_changes_nothing_else():
+    """cpg_bn_stats_finalize_count == cpg_bn_stats_finalize + `num_batches_tracked += 1` in the same launch; through the fused
+    conv -> BatchNorm -> ReLU path of a narrow ResNet-50 every BatchNorm layer's counter reads exactly the number of training forwards
+    (torch.nn.BatchNorm2d's rule) and eval forwards do not move it."""
+    import ctypes
+    L = __import__('cpg_amd._lib', fromlist=['x'])
+    g = torch.Generator().manual_seed(5)
+    C, tiles = 37, 23
+    stats = torch.rand(C, tiles, 2, generator=g).to(DEV)
+    outs = []
+    for counted in (False, True):
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        mean, invstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        nbt = torch.tensor(7, dtype=torch.int64, device=DEV)
+        args = [L.dptr(stats), tiles, 4, C, 100, 1e-5, 0.1, L.dptr(rm), L.dptr(rv), L.dptr(mean), L.dptr(invstd)]
+        if counted:
+            L.check('count', L.lib().cpg_bn_stats_finalize_count(*args, ctypes.c_void_p(nbt.data_ptr()), L.stream_ptr()))
+        else:
+            L.check('plain', L.lib().cpg_bn_stats_finalize(*args, L.stream_ptr()))
+        outs.append((rm, rv, mean, invstd, int(nbt)))
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(a, b)
+    assert outs[0][4] == 7 and outs[1][4] == 8
+    net = build('resnet50', 0.25).to(DEV)
+    x = torch.randn(4, 3, 64, 64, generator=g).to(DEV)
+    net.train()
+    for _ in range(3):
+        net(x)
+    net.eval()
+    with torch.no_grad():
+        net(x)
+    counts = {int(m.num_batches_tracked) for m in net.modules() if isinstance(m, nn.BatchNorm2d)}
+    assert counts == {3}, counts
+
+
+@pytest.mark.parametrize('shape', [(8, 64, 56, 56, 256, 1, 1, 0), (8, 256, 28, 28, 64, 1, 1, 0), (4, 128, 28, 28, 128, 3, 1, 1), (4, 64, 56, 56, 64, 3, 1, 1),
+                                   (2, 78, 28, 28, 156, 3, 1, 1), (4, 512, 7, 7, 512, 3, 1, 1), (6, 48, 14, 14, 80, 1, 1, 0)])
+@pytest.mark.parametrize('with_pm', [False, True])
+def test_caller_packed_operands_are_bit_equal_to_self_packing_calls(shape, with_pm):
+    """cpg_conv2d_pack (forward + input-gradient operand in ONE launch) + cpg_conv2d_use_packed against the self-packing entry points on
+    the same inputs: y, the BatchNorm partial sums, gx and gx + addend BIT-equal; the context is one-shot (the call after an armed call
+    packs for itself again) and a wrong-sized operand is refused."""
+    import ctypes
+    L = __import__('cpg_amd._lib', fromlist=['x'])
+    lib = L.lib()
+    N, C, H, W, K, R, stride, pad = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, C, H, W, generator=g).to(DEV)
+    w = (torch.randn(K, C, R, R, generator=g) * 0.1).to(DEV)
+    pm = (torch.rand(K, C, R, R, generator=g) * 0.012).to(DEV) if with_pm else None
+    d = nl._conv_desc(x.shape, w.shape, (stride, stride), (pad, pad), (1, 1), 1)
+    gy = torch.randn(N, K, H, W, generator=g).to(DEV)
+    add = torch.randn(N, C, H, W, generator=g).to(DEV)
+    s = L.stream_ptr()
+    nb = [lib.cpg_conv2d_pack_bytes(ctypes.byref(d), p) for p in (0, 1, 2)]
+    assert nb[0] > 0 and nb[1] > 0, nb
+    ws, wsb = L.workspace(lib.cpg_conv2d_workspace_bytes(ctypes.byref(d)), DEV)
+    tiles = lib.cpg_conv2d_bnstats_tiles(ctypes.byref(d))
+
+    def run(packed):
+        out = {}
+        pk = {}
+        if packed:
+            pk[0] = torch.full((nb[0] // 4,), float('nan'), device=DEV)
+            pk[1] = torch.full((nb[1] // 4,), float('nan'), device=DEV)
+            L.check('pack', lib.cpg_conv2d_pack(ctypes.byref(d), L.dptr(w), L.dptr(pm), 0.005, 0, L.dptr(pk[0]), nb[0], 1, L.dptr(pk[1]), nb[1], s))
+            if nb[2]:
+                pk[2] = torch.full((nb[2] // 4,), float('nan'), device=DEV)
+                L.check('pack', lib.cpg_conv2d_pack(ctypes.byref(d), L.dptr(w), L.dptr(pm), 0.005, 2, L.dptr(pk[2]), nb[2], 0, None, 0, s))
+
+        def arm(which):
+            if packed:
+                L.check('use', lib.cpg_conv2d_use_packed(L.dptr(pk[which]), nb[which]))
+        y = torch.empty(N, K, H, W, device=DEV)
+        arm(0)
+        L.check('fwd', lib.cpg_conv2d_fwd(ctypes.byref(d), L.dptr(x), L.dptr(w), L.dptr(pm), 0.005, None, L.dptr(y), L.dptr(ws), wsb, s))
+        out['y'] = y
+        if tiles > 0 and nb[2]:
+            y2, st = torch.empty_like(y), torch.empty(K, tiles, 2, device=DEV)
+            arm(2)
+            L.check('fwd_bnstats', lib.cpg_conv2d_fwd_bnstats(ctypes.byref(d), L.dptr(x), L.dptr(w), L.dptr(pm), 0.005, None, L.dptr(y2), L.dptr(st),
+                                                            st.numel() * 4, L.dptr(ws), wsb, s))
+            out['y2'], out['stats'] = y2, st
+        gx = torch.empty_like(x)
+        arm(1)
+        L.check('dgrad', lib.cpg_conv2d_dgrad(ctypes.byref(d), L.dptr(gy), L.dptr(w), L.dptr(pm), 0.005, L.dptr(gx), L.dptr(ws), wsb, s))
+        out['gx'] = gx
+        if lib.cpg_conv2d_dgrad_add_supported(ctypes.byref(d)):
+            gxa = torch.empty_like(x)
+            arm(1)
+            L.check('dgrad_add', lib.cpg_conv2d_dgrad_add(ctypes.byref(d), L.dptr(gy), L.dptr(w), L.dptr(pm), 0.005, L.dptr(add), L.dptr(gxa),
+                                                          L.dptr(ws), wsb, s))
+            out['gx_add'] = gxa
+        if packed:      # one-shot: this call was not armed and must pack for itself (the buffers are poisoned to prove it)
+            for t in pk.values():
+                t.fill_(float('nan'))
+            y3 = torch.empty_like(y)
+            L.check('fwd', lib.cpg_conv2d_fwd(ctypes.byref(d), L.dptr(x), L.dptr(w), L.dptr(pm), 0.005, None, L.dptr(y3), L.dptr(ws), wsb, s))
+            out['y_unarmed'] = y3
+        return out
+    ref, got = run(False), run(True)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), k
+    assert torch.equal(got['y_unarmed'], ref['y'])
+    # a wrong-sized operand is refused and leaves the thread disarmed
+    junk = torch.zeros(64, device=DEV)
+    L.check('use', lib.cpg_conv2d_use_packed(L.dptr(junk), 256))
+    y = torch.empty(N, K, H, W, device=DEV)
+    assert lib.cpg_conv2d_fwd(ctypes.byref(d), L.dptr(x), L.dptr(w), L.dptr(pm), 0.005, None, L.dptr(y), L.dptr(ws), wsb, s) < 0
+    L.check('fwd', lib.cpg_conv2d_fwd(ctypes.byref(d), L.dptr(x), L.dptr(w), L.dptr(pm), 0.005, None, L.dptr(y), L.dptr(ws), wsb, s))
+    assert torch.equal(y, ref['y'])
+    # shapes of the other kernel families report no operand
+    d2 = nl._conv_desc((2, 3, 224, 224), (64, 3, 7, 7), (2, 2), (3, 3), (1, 1), 1)
+    assert [lib.cpg_conv2d_pack_bytes(ctypes.byref(d2), p) for p in (0, 1, 2)] == [0, 0, 0]

@@ -2,7 +2,7 @@
 """dump logits of the tiny VGG (fused / unfused) and plain conv outputs to a file, for A/B of two library builds"""
 import sys, os
 import numpy as np, torch, torch.nn as nn
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import cpg_amd.models as M
 VGG_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
 def build(arch, width, ncls=5):

@@ -4,11 +4,11 @@ run): HOGS single-wave spin kernels (torch.cuda._sleep, one stream each) are par
 launch is timed with different grid policies (CPG_WINO_GRIDS, CPG_WW_UNITS, CPG_STEM_BLOCKS).  A wave of the Winograd kernels
 needs a whole SIMD's registers, so every parked wave takes its CU out of the launch.
 
-    python tools/diag_interference.py [--hogs 16]
+    python tools/attic/diag_interference.py [--hogs 16]
 """
 import argparse, ctypes, os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cpg_amd import _lib
 from cpg_amd.models.layers import _conv_desc
 

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """SphereNet-20 + AngleLoss on bench.py's synthetic data (random images, random labels): where does the loss stop being finite, and does the
 SAME run on torch's own ops (MIOpen convolutions, nn.PReLU, nn.Linear; same initial state, data and optimizer) do the same?
-   python tools/diag_sph_nan.py [steps] [lr]"""
+   python tools/attic/diag_sph_nan.py [steps] [lr]"""
 import os
 import sys
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench                                             # noqa: E402
 from cpg_amd.models import layers as nl, fused_bn        # noqa: E402
 from cpg_amd.models.spherenet import AngleLoss           # noqa: E402

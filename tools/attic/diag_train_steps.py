@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: step-0 gradients of the train_steps_* fixtures (reference, CPU) against the HIP path, per watched layer,
-with the fused BatchNorm kernels on and off.  python tools/diag_train_steps.py [resnet50|spherenet20]"""
+with the fused BatchNorm kernels on and off.  python tools/attic/diag_train_steps.py [resnet50|spherenet20]"""
 import os
 import sys
 
@@ -8,7 +8,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import cpg_amd.models as M                       # noqa: E402
 from cpg_amd.models import fused_bn              # noqa: E402

@@ -5,7 +5,7 @@ the same SIMD (development tool)."""
 import ctypes, os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cpg_amd import _lib
 from cpg_amd.models.layers import _conv_desc
 

@@ -7,7 +7,7 @@ import sys
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cpg_amd import _lib                      # noqa: E402
 from cpg_amd.models.layers import _conv_desc  # noqa: E402
 

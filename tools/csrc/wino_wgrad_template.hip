@@ -58,7 +58,7 @@ struct WwGeom {
 @@RD@@
 #define WW_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-// -DWG_TIMING (development builds, tools/diag_wg_timing.py --wgrad): per-wave constant-clock stamps, as in conv3x3_wino.hip
+// -DWG_TIMING (development builds, tools/attic/diag_wg_timing.py --wgrad): per-wave constant-clock stamps, as in conv3x3_wino.hip
 #ifdef WG_TIMING
 __device__ unsigned long long ww_dbg[65536 * 8];
 #define WW_STAMP(i) do { if (lane == 0 && u < 65536) ww_dbg[u * 8 + (i)] = wall_clock64(); } while (0)
