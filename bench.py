@@ -239,7 +239,7 @@ def csrc_digest():
     return h.hexdigest()
 
 
-TRAFFIC_FILES = ('r05_traffic_bench.json', 'r04_traffic_bench.json', 'r03_traffic_bench.json')
+TRAFFIC_FILES = ('r06_traffic_bench.json', 'r05_traffic_bench.json', 'r04_traffic_bench.json', 'r03_traffic_bench.json')
 
 
 def pmc_traffic(arch, family, batch):
@@ -1358,8 +1358,9 @@ def main():
                                     'fresh piggymasks), train steps only, timed after the cycle'}
         if a.math == 'fp32' and world == 1 and a.optin_steps > 0 and a.arch == 'vgg16' and a.task == 1 and a.batch == 256 and a.width_multiplier == 1.0:
             out['opt_in_conv_math'] = optin_modes(model, masks, pool, a.optin_steps, a.batch)
-        if (not a.no_other_workloads and world == 1 and a.arch == 'vgg16' and a.task == 1 and a.width_multiplier == 1.0 and a.batch == 256
-                and a.math == 'fp32'):
+        if (not a.no_other_workloads and not a.no_cpu_baseline and world == 1 and a.arch == 'vgg16' and a.task == 1 and a.width_multiplier == 1.0
+                and a.batch == 256 and a.math == 'fp32'):
+            # (the full default line only: tooling runs -- profilers, A/B scripts -- pass --no-cpu-baseline and get the headline cycle alone)
             # free this process's cached blocks first: the children allocate their own pools on the same GPU
             torch.cuda.empty_cache()
             out['other_workloads'] = other_workloads(20, a.warmup)

@@ -16,9 +16,14 @@ Usage (drop-in for CPG_cifar100_main_normal.py:339-341 + utils/manager.py:67-70)
 While a MaskedSGD is attached, `do_weight_decay_and_make_grads_zero()` skips the weight part (piggymask
 gradients are still routed there) and step() does it fused; `.grad` ends up routed exactly as before.
 """
+import os
+
 import torch
 
 from .. import _lib
+
+# CPG_MULTI_TENSOR=0: one cpg_sgd_route_step / cpg_adam_route_step launch per layer (the behaviour up to round 5; A/B switch)
+MULTI_TENSOR = os.environ.get('CPG_MULTI_TENSOR', '1') not in ('0', '')
 from ..models import layers as nl
 
 
@@ -66,6 +71,12 @@ class MaskedSGD(torch.optim.SGD):
                 p.grad = None                    # hide from torch's SGD for the rest of this step
             for first, rows in batches.items():
                 if not rows:
+                    continue
+                if not MULTI_TENSOR:
+                    for w_, g_, b_, o_, n_ in rows:
+                        rc = L.cpg_sgd_route_step(w_, g_, b_, o_, int(pr.current_dataset_idx), float(pr.args.weight_decay), float(group['lr']),
+                                                  float(group['momentum']), int(bool(group['nesterov'])), int(first), n_, s)
+                        _lib.check('cpg_sgd_route_step', rc)
                     continue
                 items = (_lib.SgdItem * len(rows))(*rows)
                 rc = L.cpg_sgd_route_step_multi(items, len(rows), int(pr.current_dataset_idx), float(pr.args.weight_decay), float(group['lr']),
@@ -139,6 +150,12 @@ class MaskedAdam(torch.optim.Adam):
                      _lib.dptr(owner, torch.uint8, 'mask').value, p.numel()))
                 p.grad = None
             for step, rows in batches.items():   # (cpg_adam_route_step_multi: every piggymask of the group in one launch)
+                if not MULTI_TENSOR:
+                    for p_, g_, a_, b_, o_, n_ in rows:
+                        rc = L.cpg_adam_route_step(p_, g_, a_, b_, o_, int(pr.current_dataset_idx), mode, float(group['lr']), float(beta1),
+                                                   float(beta2), float(group['eps']), step, n_, s)
+                        _lib.check('cpg_adam_route_step', rc)
+                    continue
                 items = (_lib.AdamItem * len(rows))(*rows)
                 rc = L.cpg_adam_route_step_multi(items, len(rows), int(pr.current_dataset_idx), mode, float(group['lr']), float(beta1),
                                                  float(beta2), float(group['eps']), step, s)

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 for a in ${ARCHS:-vgg16 resnet50 spherenet20}; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $R/gpurun_out/btraffic/${a}_$c
-    timeout -s KILL ${LIMIT:-1200} rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/btraffic/${a}_$c -o run --output-format csv -- python $R/bench.py --arch $a --steps 20 --warmup 1 --no-cpu-baseline --optin-steps 0 --clock-every 1 > $R/gpurun_out/btraffic_${a}_$c.log 2>&1
+    timeout -s KILL ${LIMIT:-1200} rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/btraffic/${a}_$c -o run --output-format csv -- python $R/bench.py --arch $a --steps 20 --warmup 1 --no-cpu-baseline --no-other-workloads --optin-steps 0 --clock-every 1 > $R/gpurun_out/btraffic_${a}_$c.log 2>&1
     [ -n "$(find $R/gpurun_out/btraffic/${a}_$c -name '*counter_collection.csv')" ] && touch $R/gpurun_out/btraffic/${a}_$c/.collected
     echo "$a $c: $(find $R/gpurun_out/btraffic/${a}_$c -name '*counter_collection.csv' | wc -l) csv, $(tail -c 300 $R/gpurun_out/btraffic_${a}_$c.log | tr '\n' ' ' | cut -c1-120)"
   done
