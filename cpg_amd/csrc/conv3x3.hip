@@ -1,6 +1,6 @@
 // Specialised masked 3x3 / stride 1 / pad 1 convolution on fp32 MFMA -- the shape class of every
 // VGG16 conv (100 % of config 1-3 conv FLOPs), 16 of SphereNet-20's 20 convs and ResNet's 3x3 s1.
-// (DESIGN.md section 4.1 has the measurements behind every choice below.)
+// (docs/LAB_NOTEBOOK.md section 4.1 has the measurements behind every choice below.)
 //
 // forward + input-gradient (one kernel, k_c3_fwd; only the packed weights differ):
 //   k_c3_pack writes Wp[(c*9 + tap)][m] = W * bin(piggymask), K-major and zero padded (binarise +

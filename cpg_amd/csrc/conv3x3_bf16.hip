@@ -21,7 +21,7 @@
 //   channels 0-7, lanes 32-63 channels 8-15 of A (row = output channel) and B (column = pixel); both operand reads are one
 //   ds_read_b128 per fragment whose 16 consecutive lanes cover 256 contiguous bytes (conflict free).
 //   Work per staged byte is 16x lower than in the fp32 kernel, so this kernel is bound by L2 / HBM delivery of the patch
-//   and the packed weights on most VGG layers, not by the matrix pipe (DESIGN.md section 4.6 has the measurements).
+//   and the packed weights on most VGG layers, not by the matrix pipe (docs/LAB_NOTEBOOK.md section 4.6 has the measurements).
 #include <algorithm>
 #include "igemm_core.h"
 

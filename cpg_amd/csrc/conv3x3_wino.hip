@@ -5,7 +5,7 @@
 // 16 multiplies per 2x2 output tile and (c, k) pair instead of 36: the contraction over input channels becomes 16
 // independent GEMMs  M_p[k][t] = sum_c U_p[k][c] * V_p[c][t]  (p = transform-domain position, t = tile), 2.25x fewer MFMAs
 // than the direct kernels of conv3x3.hip for the same result up to fp32 rounding (the transforms only add, subtract and
-// halve; measured 1-4e-6 of the output scale against fp64, the direct kernels 0.5-1e-6).  DESIGN.md section 4.9 has the
+// halve; measured 1-4e-6 of the output scale against fp64, the direct kernels 0.5-1e-6).  docs/LAB_NOTEBOOK.md section 4.9 has the
 // measurements behind the choices below.
 //
 //   k_wg_pack   U = G (W .* bin(piggymask)) G^T per (k, c), written in the order the conv kernel streams it:
@@ -2067,7 +2067,7 @@ static WgTail wino_tail_plan(const WgGeom &g0, int64_t nblocks, bool sh) {
 
 // waves per block for a launch.  The 8-wave / 64-channel block does half the staging work per MFMA, but its eight waves run in
 // lock step behind one barrier and it measured 3-4 % SLOWER than two independent 4-wave blocks per CU on every VGG16 layer
-// (DESIGN.md section 4.9), so it is only reachable through CPG_WINO_NW=8 (A/B experiments, tests).
+// (docs/LAB_NOTEBOOK.md section 4.9), so it is only reachable through CPG_WINO_NW=8 (A/B experiments, tests).
 inline int wino_nw(int c_read, int m) {
     return opt_or(OPT_WINO_NW, 4) == 8 ? 8 : 4;
 }

@@ -921,7 +921,7 @@ int cpg_pw_gemm_nt(const float *A, const float *B, int M, int C, int64_t K, cons
                    hipStream_t stream, const char *what);
 int cpg_pw_gemm_nt_maskb(const float *A, const float *B, const float *pmB, float thr, int M, int C, int64_t K, const Epilogue &ep, void *ws,
                          size_t ws_bytes, hipStream_t stream, const char *what);
-bool cpg_pw_gemm_nn_ok(const float *X, int M, int Mp, int Kd, int64_t G);
+bool cpg_pw_gemm_nn_ok(const float *X, int M, int Mp, int Kd, int64_t G, bool masked = false);
 int cpg_pw_gemm_nn(const float *wp, int Mp, const float *X, int M, int Kd, int64_t G, const float *bias, float *y, hipStream_t stream,
                    const char *what);
 int cpg_pw_gemm_nn_masked(const float *wp, int Mp, const float *X, int M, int Kd, int64_t G, const float *pm, const float *w, float thr,
@@ -1004,7 +1004,7 @@ extern "C" int cpg_linear_dgrad(const float *gy, const float *w, const float *pm
         return cpg_fc_small_dgrad(gy, w, pm, thr, gx, batch, in_f, out_f, ws, ws_bytes, (hipStream_t)stream, "cpg_linear_dgrad");
     const int Mp_b = (batch + 127) / 128 * 128;
     if (ws != nullptr && ws_bytes >= cpg_pw_pack_transpose_bytes(batch, out_f) && (((uintptr_t)ws) & 15) == 0 &&
-        cpg_pw_gemm_nn_ok(w, batch, Mp_b, out_f, in_f) && (pm == nullptr || (in_f % 4 == 0 && (((uintptr_t)pm) & 15) == 0))) {
+        cpg_pw_gemm_nn_ok(w, batch, Mp_b, out_f, in_f, pm != nullptr) && (pm == nullptr || (in_f % 4 == 0 && (((uintptr_t)pm) & 15) == 0))) {
         // gx[b][i] = sum_o gy[b][o] W[o][i]: gy^T packed K-major (4 MB) is the "weight", W[o][:] the K-major operand -- with a piggymask
         // (round 5) the operand is W * bin(pm), formed in the kernel's staging (k_pw<.., MASKX>): W and pm are read once
         cpg_pw_pack_transpose(gy, batch, out_f, (float *)ws, (hipStream_t)stream);
@@ -1027,7 +1027,7 @@ extern "C" int cpg_linear_wgrad(const float *x, const float *gy, const float *w,
     if (pm == nullptr && (((uintptr_t)gy) & 15) == 0 && cpg_pw_gemm_nn_ok(x, out_f, out_f, batch, in_f))
         // gW[o][i] = sum_b gy[b][o] x[b][i]: gy is already K-major ([b][o], o a multiple of 128), x[b][:] the other operand
         rc = cpg_pw_gemm_nn(gy, out_f, x, out_f, batch, in_f, nullptr, gw, (hipStream_t)stream, "cpg_linear_wgrad");
-    else if (pm != nullptr && (((uintptr_t)gy) & 15) == 0 && cpg_pw_gemm_nn_ok(x, out_f, out_f, batch, in_f))
+    else if (pm != nullptr && (((uintptr_t)gy) & 15) == 0 && cpg_pw_gemm_nn_ok(x, out_f, out_f, batch, in_f, true))
         // ... and with a piggymask the same GEMM with the autograd epilogue of bin(pm) * W (gW = g bin(pm), gPM = g W from ONE accumulator tile)
         rc = cpg_pw_gemm_nn_masked(gy, out_f, x, out_f, batch, in_f, pm, w, thr, gw, gpm, (hipStream_t)stream, "cpg_linear_wgrad");
     else

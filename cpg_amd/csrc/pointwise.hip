@@ -8,7 +8,7 @@
 // BN = 224 flattened pixels = 7 MFMA fragments, with zero tile waste for 56x56, 28x28, 14x14 and 7x7
 // maps alike (a per-image tile would waste 12.5 % at 28x28 and 56 % at 7x7).
 //
-// Same loop discipline as conv3x3.hip's k_c3_fwd: packed K-major weights,
+// Same loop discipline as conv3x3.hip's k_c3_fwd (see docs/LAB_NOTEBOOK.md section 4.1): packed K-major weights,
 // two LDS stages with one barrier per chunk, operands of k-step s+1 read while the MFMAs of step s
 // run, a branch-free chunk body with pinned instruction order in which the staging of later chunks
 // rides between the MFMAs (registers holding chunk ch+1 are stored to the other LDS stage and
@@ -964,9 +964,11 @@ int cpg_pw_gemm_nt_maskb(const float *A, const float *B, const float *pmB, float
     return nt_launch<PwW128, true>(A, B, pmB, thr, M, C, K, ep, ws, ws_bytes, stream, what);
 }
 
-bool cpg_pw_gemm_nn_ok(const float *X, int M, int Mp, int Kd, int64_t G) {
+bool cpg_pw_gemm_nn_ok(const float *X, int M, int Mp, int Kd, int64_t G, bool masked) {
     // no split-K here: the output tiles alone must fill the chip (4096 -> 4096 dgrad at batch 256 has 38 of them: 4x slower)
-    const int64_t bn = (G % 4 == 0 && pw_wide()) ? PwV2::BN : PwV::BN;      // (the pixel tile of the launch cpg_pw_gemm_nn makes)
+    // (the pixel tile of the launch that follows: cpg_pw_gemm_nn takes the wide tile under pw_wide(); the masked forms -- cpg_pw_gemm_nn_masked /
+    //  _maskx, `masked` -- always run the 224-pixel PwV / PwVM tiles)
+    const int64_t bn = (!masked && G % 4 == 0 && pw_wide()) ? PwV2::BN : PwV::BN;
     if (((G + bn - 1) / bn) * ((M + 127) / 128) < 192) return false;
     return !cpg::opt_on(cpg::OPT_DISABLE_PW_GEMM) && Kd % 16 == 0 && M % 8 == 0 && Mp % 128 == 0 && Mp >= M && G < (1ll << 28) &&
            (int64_t)Kd * G * 4 < (1ll << 31) && (int64_t)M * G < (1ll << 31) && (((uintptr_t)X) & 15) == 0;

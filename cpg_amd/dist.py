@@ -278,11 +278,6 @@ class DataParallel(nn.Module):
                 _lib.check('cpg_unpack_owned', rc)
         self._handles = []
         for p, ch in self._chunked:
-            if p.grad is None:                                    # (the backward pass produced row blocks but no gradient was kept)
-                for work, _, _ in ch.pending:
-                    work.wait()
-                ch.pending = []
-                continue
             adopted = p.grad.data_ptr() == ch.base_ptr           # autograd took the gradient tensor itself: the rows ARE p.grad's
             for work, rows, r0 in ch.pending:
                 work.wait()
@@ -292,6 +287,15 @@ class DataParallel(nn.Module):
                     p.grad[r0:r0 + rows.shape[0]].copy_(rows)
             ch.pending = []
         self._chunked = []
+        # Row blocks of a backward pass that kept NO gradient for their weight (the hook above never saw the parameter, so it is not in
+        # _chunked): wait for them here and drop them -- left pending they would only be drained by the weight's next active() call,
+        # which silently puts that step on the whole-tensor path.
+        for q in self.module.parameters():
+            ch = getattr(q, '_cpg_dp_chunk', None)
+            if ch is not None and ch.pending:
+                for work, _, _ in ch.pending:
+                    work.wait()
+                ch.pending = []
         self.last_bucket_log, self.bucket_log = self.bucket_log, []
         self.last_payload, self._step_payload = self._step_payload, {'dense_elems': 0, 'sent_elems': 0}
         if ev is not None:

@@ -853,6 +853,72 @@ def gen_growth():
     save('growth', **arrs)
 
 
+def gen_growth_other_nets():
+    """gen_growth for the topologies of configs[3] / configs[4]: the reference's growth path (exit code 2 -> raw multiplier + step -> sqrt ->
+    wider model -> mask padding -> top-left copy) on ResNet-50 (the int() placement of models/resnet.py:68-75,115,173: Bottleneck widths,
+    expansion x 4, the downsample convs) and SphereNet-20 (biased convs + PReLU slopes: 1-D tensors grow by Manager.load_checkpoint's
+    `[:param.size(0)]` rule, utils/manager.py:253-255).  Mask padding: CPG_imagenet_main.py:236-262 / CPG_face_main.py:203-229 (inline
+    code of main(): restated).  Task 1 at raw 1/64 (width 0.125), grown to raw 2/64 (width 0.17678: ragged channel counts)."""
+    import math
+    import shutil
+    import tempfile
+    from utils.manager import Manager
+    raw0, step = 1.0 / 64, 1.0 / 64
+    w0, w1 = math.sqrt(raw0), math.sqrt(raw0 + step)
+    fmt = '{save_folder}/checkpoint-{epoch}.pth.tar'
+    for arch, first, second in (('resnet50', 'imagenet', 'cubs_cropped'), ('spherenet20', 'face_verification', 'gender')):
+        tmp = tempfile.mkdtemp()
+        try:
+            net = build_ref(arch, w0, num_classes=6, dataset=first)
+            model = nn.DataParallel(net)
+            g = torch.Generator().manual_seed(78)
+            keys = ['bias', 'bn_layer_running_mean', 'bn_layer_running_var', 'bn_layer_weight', 'bn_layer_bias', 'piggymask']
+            if arch == 'spherenet20':
+                keys.append('prelu_layer_weight')
+            masks, shared = {}, {first: {k: {} for k in keys}}
+            shared[first]['network_width_multiplier'] = w0
+            for name, mod in model.named_modules():
+                if isinstance(mod, (nl.SharableConv2d, nl.SharableLinear)):
+                    masks[name] = torch.randint(0, 2, mod.weight.shape, generator=g, dtype=torch.uint8)
+                elif isinstance(mod, nn.BatchNorm2d):
+                    mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+                    mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+                elif isinstance(mod, nn.PReLU):
+                    mod.weight.data.copy_(torch.rand(mod.weight.shape, generator=g) * 0.5)
+            fake = types.SimpleNamespace(args=types.SimpleNamespace(checkpoint_format=fmt, dataset=first), model=model,
+                                         shared_layer_info=shared, pruner=types.SimpleNamespace(masks=masks))
+            Manager.save_checkpoint(fake, None, 0, tmp)
+            checkpoint = torch.load(fmt.format(save_folder=tmp, epoch=1), weights_only=False)
+            masks, shared_layer_info = checkpoint['masks'], checkpoint['shared_layer_info']
+            torch.manual_seed(1)
+            model = getattr(models, arch)(dataset_history=checkpoint['dataset_history'], dataset2num_classes=checkpoint['dataset2num_classes'],
+                                          network_width_multiplier=w1, shared_layer_info=shared_layer_info)
+            model.add_dataset(second, 5)
+            model.set_dataset(second)
+            model = nn.DataParallel(model)
+            for name, module in model.named_modules():            # mode finetune: zero-pad = the new slots are free
+                if isinstance(module, nl.SharableConv2d):
+                    assert masks[name].size(1) <= module.weight.data.size(1)
+                    mask = torch.ByteTensor(module.weight.data.size()).fill_(0)
+                    mask[:masks[name].size(0), :masks[name].size(1), :, :].copy_(masks[name])
+                    masks[name] = mask
+            fake = types.SimpleNamespace(args=types.SimpleNamespace(checkpoint_format=fmt, dataset=second), model=model)
+            Manager.load_checkpoint(fake, None, 1, tmp)
+        finally:
+            shutil.rmtree(tmp)
+        sd = model.module.state_dict()
+        names = list(sd.keys())
+        arrs = dict(raw0=raw0, raw1=raw0 + step, step=step, width0=w0, width1=w1, seed=1, mask_seed=78, first=np.array(first), second=np.array(second),
+                    names=np.array(names), shapes=np.array([list(sd[k].shape) + [0] * (4 - sd[k].dim()) for k in names]),
+                    crc=np.array([tensor_crc(sd[k]) for k in names], dtype=np.uint32),
+                    mask_names=np.array(sorted(masks)), mask_crc=np.array([tensor_crc(masks[k]) for k in sorted(masks)], dtype=np.uint32),
+                    mask_shapes=np.array([list(masks[k].shape) for k in sorted(masks)]))
+        for k in names:
+            if sd[k].numel() <= 512:
+                arrs['t/' + k] = sd[k]
+        save('growth_' + arch, **arrs)
+
+
 def gen_full_width_logits():
     """Eval-mode logits of the three topologies at WIDTH 1.0 and the input sizes BASELINE.json's configs name (models/vgg.py:124-154,280-282;
     models/resnet.py:103-222; models/spherenet.py:201-251): the whole-network check of north_star's 1e-4 logit bar at full size (the
@@ -1171,6 +1237,7 @@ if __name__ == '__main__':
         sys.exit(0)
     gen_sequence_other_nets()
     gen_growth()
+    gen_growth_other_nets()
     gen_full_width_logits()
     gen_one_shot()
     gen_manager_trajectory()

@@ -357,6 +357,49 @@ def test_growth_matches_reference_gpu():
     _growth_session_vs_reference('cuda:0')
 
 
+@pytest.mark.parametrize('arch', ['resnet50', 'spherenet20'])
+def test_growth_of_the_other_topologies_matches_reference_host(arch):
+    """CPGSession.grow on ResNet-50 (the int() placement of models/resnet.py:68-75,115,173: Bottleneck widths, expansion x 4, downsample
+    convs) and SphereNet-20 (biased convs, PReLU slopes) against the reference's own growth path (make_golden.py::gen_growth_other_nets):
+    same names in the same order, same shapes, every tensor of the grown model crc-equal, owner masks zero-padded bit for bit."""
+    import math
+    import zlib
+    from cpg_amd.driver import CPGSession
+
+    def crc(t):
+        return zlib.crc32(t.detach().cpu().contiguous().numpy().tobytes()) & 0xFFFFFFFF
+    g = load_golden('growth_' + arch)
+    raw0, step = float(g['raw0']), float(g['step'])
+    first, second = str(g['first']), str(g['second'])
+    sess = CPGSession(arch, width_multiplier=raw0, device='cpu', seed=int(g['seed']))
+    sess.start_task(first, 6)
+    gen = torch.Generator().manual_seed(int(g['mask_seed']))
+    for name, mod in sess.model.named_modules():
+        if isinstance(mod, (nl.SharableConv2d, nl.SharableLinear)):
+            sess.masks[name].copy_(torch.randint(0, 2, mod.weight.shape, generator=gen, dtype=torch.uint8))
+        elif isinstance(mod, nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=gen) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=gen) + 0.5)
+        elif isinstance(mod, nn.PReLU):
+            mod.weight.data.copy_(torch.rand(mod.weight.shape, generator=gen) * 0.5)
+    sess.commit_task(first)
+    snap = sess.snapshot()
+    sess.grow(sess.width_multiplier + step, snap)
+    sess.start_task(second, 5)
+    assert sess.width == float(g['width1']) == math.sqrt(raw0 + step)
+    sd = sess.net.state_dict()
+    ours = [k for k in sd if not k.endswith('piggymask')]
+    assert ours == [str(n) for n in g['names']]
+    for n, shape, c in zip(ours, g['shapes'], g['crc']):
+        assert list(sd[n].shape) == [int(v) for v in shape[:sd[n].dim()]], n
+        if 't/' + n in g.files:
+            assert np.array_equal(sd[n].detach().cpu().numpy(), g['t/' + n]), n
+        assert crc(sd[n]) == int(c), 'grown tensor %s differs from the reference' % n
+    assert sorted(sess.masks) == [str(n) for n in g['mask_names']]
+    for n, c, shape in zip(sorted(sess.masks), g['mask_crc'], g['mask_shapes']):
+        assert list(sess.masks[n].shape) == [int(v) for v in shape] and crc(sess.masks[n]) == int(c), n
+
+
 def test_growth_from_raw_1_to_1p5_gives_the_reference_channel_counts():
     """experiment1's one growth step: raw 1.0 + 0.5 -> sqrt(1.5) = 1.2247 -> int(v * 1.2247) = 78 / 156 / 313 / 627 channels and
     5016-wide FC layers (models/vgg.py:104-121) -- not 1.5 x the channels (96 / 192 / 384 / 768), which is what an additive step in

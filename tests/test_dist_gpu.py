@@ -302,3 +302,66 @@ def test_bench_task2_line(arch):
     assert t2['task1_ms_per_step'] > 0 and t2['finetune_again_ms_per_step'] > 0 and abs(t2['free_share_handed_to_task2'] - 0.3) < 0.01
     assert out['config']['cycle']['prune_events'] >= 1 and 'roofline' in out and out.get('cpu_baseline') is None
 
+
+
+# ---- a large SharableLinear weight used TWICE in one graph, exchanged as row blocks (_ChunkedGradient.active()'s join path)
+def _shared_weight_grads(rank, world, data_parallel, dev='cuda:0'):
+    import torch.nn as nn
+    from cpg_amd import dist as cdist
+    from cpg_amd.models import layers as nl
+
+    class Twice(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = nl.SharableLinear(96, 96)
+            self.head = nn.Linear(96, 5)
+
+        def forward(self, x):
+            return self.head(self.fc(torch.relu(self.fc(x))))            # the same masked weight in two places of the graph
+    torch.manual_seed(3)
+    net = Twice()
+    nn.init.normal_(net.fc.weight, 0, 0.1)
+    nn.init.zeros_(net.fc.bias)
+    net = net.to(dev)
+    model = cdist.DataParallel(net, large_numel=1 << 10, chunk_numel=1 << 10, nchunks=4) if data_parallel else net
+    g = torch.Generator().manual_seed(9)
+    x, t = torch.randn(16, 96, generator=g), torch.randint(0, 5, (16,), generator=g)
+    out = {}
+    for step in range(2):                                  # second step: nothing may be left pending from the first
+        xs, ts = cdist.shard_batch(x, t, rank, world)
+        net.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(model(xs.to(dev)), ts.to(dev)).backward()
+        if data_parallel:
+            model.finish_gradient_sync()
+            assert not net.fc.weight._cpg_dp_chunk.pending
+            out['chunks_step%d' % step] = [k for k, _ in model.last_bucket_log].count('chunk')
+        out['g%d' % step] = {n: p.grad.detach().cpu().clone() for n, p in net.named_parameters()}
+    torch.cuda.synchronize()
+    return out
+
+
+def _shared_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.save(_shared_weight_grads(rank, world, True), os.path.join(out_dir, 'shared%d.pt' % rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chunked_exchange_of_a_weight_used_twice_equals_single_process(tmp_path):
+    """The first backward call of the shared weight sends its gradient as 4 row blocks; the second call arrives while they are on the
+    wire: active() joins them and falls back to the whole-tensor path, autograd sums the two, the hook all-reduces mean(g1) + g2_local.
+    Result: every rank holds the single-process full-batch gradient, on both steps, and no row block is left pending."""
+    import torch.multiprocessing as mp
+    mp.spawn(_shared_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(os.path.join(tmp_path, 'shared0.pt')), torch.load(os.path.join(tmp_path, 'shared1.pt'))
+    ref = _shared_weight_grads(0, 1, False)
+    for step in range(2):
+        assert r0['chunks_step%d' % step] == 4, r0                     # the row-block path really ran
+        for n, want in ref['g%d' % step].items():
+            assert torch.equal(r0['g%d' % step][n], r1['g%d' % step][n]), n
+            np.testing.assert_allclose(r0['g%d' % step][n].numpy(), want.numpy(), rtol=1e-4, atol=1e-6 * float(want.abs().max()), err_msg=n)

@@ -1259,7 +1259,7 @@ def test_full_width_logits_golden(arch):
 @pytest.mark.parametrize('mode', ['prune', 'finetune'])
 def test_trajectory_golden(mode, math):
     """12 steps of the Manager.train op order on a narrow VGG16-BN: logits per step, prune ratios,
-    sparsities; owner masks compared bit-exact where fp32 round-off cannot flip a rank (see DESIGN.md)."""
+    sparsities; owner masks compared bit-exact where fp32 round-off cannot flip a rank (see DESIGN.md section 2)."""
     g = load_golden('trajectory_' + mode)
     width = float(g['width'])
     net = build('vgg_cifar100', width)

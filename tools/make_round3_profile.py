@@ -100,7 +100,7 @@ with open(os.path.join(P, '%s_final.md' % out), 'w') as f:
     w('                                                      -> tables below; its bench line: profiles/%s_bench_under_rocprof_vgg16.json (%.1f img/s)\n\n'
       % (out, under['vgg16']['value']))
     w('Counters of this state\'s kernels over whole train steps: profiles/r03_pmc_step_{vgg16,resnet50,spherenet20}.md (MFMA-busy, other vector '
-      'instructions per MFMA); per-unit phase times: DESIGN.md section 8 (tools/attic/diag_wg_timing.py); HBM bytes: the traffic table below.\n\n* %s\n' % roof(b20))
+      'instructions per MFMA); per-unit phase times: docs/LAB_NOTEBOOK.md section 8 (tools/attic/diag_wg_timing.py); HBM bytes: the traffic table below.\n\n* %s\n' % roof(b20))
     w('* `cpu_baseline`: %s\n\n' % json.dumps({k: v for k, v in b20['cpu_baseline'].items() if k != 'sample'}))
     w('## bench.py, K = 20 (HIP events around every C-ABI launch of the timed region)\n\n%s\n\n' % fam_table(b20))
     w('phases: `%s`\n\n' % json.dumps(b20['phases']))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Does a second read of a buffer hit the 256 MiB Infinity Cache?  Reads a buffer twice back to back (float4 copy-rate reduction
 kernels of torch) after evicting everything with a 2 GiB sweep, for several buffer sizes: first-read vs second-read GB/s.
-Behind the BatchNorm-backward channel-group experiment."""
+Behind the BatchNorm-backward channel-group experiment (docs/LAB_NOTEBOOK.md section 8)."""
 import torch
 
 dev = 'cuda:0'
