@@ -113,7 +113,9 @@ int32_t cpg_get_shared_chip_hint(void);
  * A run is bit-reproducible for a fixed set of switch values and a fixed hint; the defaults are what every committed number used.
  * The table is global state, but not per-call mutable state: no entry point writes it, and a concurrent cpg_set_option only ever
  * changes which of the above equivalent plans a LATER call picks (the workspace caveat of the hint applies to CPG_WW_UNITS,
- * CPG_C3W_BPC, CPG_PWW_BPC and CPG_PW_TILE as well). */
+ * CPG_C3W_BPC, CPG_PWW_BPC, CPG_PW_TILE, CPG_WINO_TAIL and CPG_FC_SMALL as well: a switch that sizes a workspace must not change
+ * between the *_workspace_bytes query and the call it sized -- the Winograd tail falls back to one launch on a workspace that is too
+ * small, the <= 64-row linear kernels return CPG_E_WORKSPACE). */
 #define CPG_OPT_UNSET INT32_MIN
 int cpg_set_option(const char *name, int32_t value);
 int cpg_get_option(const char *name, int32_t *value);
