@@ -365,3 +365,23 @@ def test_chunked_exchange_of_a_weight_used_twice_equals_single_process(tmp_path)
         for n, want in ref['g%d' % step].items():
             assert torch.equal(r0['g%d' % step][n], r1['g%d' % step][n]), n
             np.testing.assert_allclose(r0['g%d' % step][n].numpy(), want.numpy(), rtol=1e-4, atol=1e-6 * float(want.abs().max()), err_msg=n)
+
+
+@pytest.mark.parametrize('arch', ['spherenet20', 'resnet50'])
+def test_bench_task_sequence_line(arch):
+    """`bench.py --task-sequence 2 --arch A` end to end at a tiny batch: configs[3] / configs[4]'s flow through CPGSession at FULL width --
+    pass-through task 1 + prune run, task 2 with piggymasks (SphereNet-20: AngleLinear / AngleLoss -> nn.Linear / CE, embeddings as task 1's
+    evaluation) -- and the line's own assertions: weights finite, every earlier task bit-identical after the later one."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--arch', arch, '--task-sequence', '2', '--steps', '22', '--batch', '4'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
+    assert out['valid'] is True and out['weights_finite'] and out['earlier_tasks_bit_identical'] == {'checked': 3, 'bit_identical': True}
+    t1, t2 = out['tasks']
+    assert t1['pass_through'] is True and t2['pass_through'] is False and 'NOT the headline' in out['metric']
+    assert set(t2['owner_histogram']) >= {'1', '2'} and t2['shared_ratio'] is not None and t1['first_rank_prune_event']['k_total'] > 0
