@@ -89,11 +89,18 @@ def _pack_bytes(L, d, which):
     return v
 
 
-def _arm_packed(L, ctx):
-    """hand the input-gradient operand packed at forward time to the launch that follows on this thread (one-shot)"""
-    pk, ctx.packed_dgrad = getattr(ctx, 'packed_dgrad', None), None
-    if pk is not None:
-        _lib.check('cpg_conv2d_use_packed', L.cpg_conv2d_use_packed(_lib.dptr(pk), pk.numel() * 4))
+def _with_packed(L, pk, call):
+    """Run `call()` -- ONE conv entry point -- with the calling thread armed to stream the packed operand `pk` (None: plain call).
+    The library disarms itself inside that entry point; an exception raised on the way there (an argument that does not convert: a CPU
+    or non-fp32 tensor) disarms here, so that no LATER call of this thread can pick up an operand that was not meant for it."""
+    if pk is None:
+        return call()
+    _lib.check('cpg_conv2d_use_packed', L.cpg_conv2d_use_packed(_lib.dptr(pk), pk.numel() * 4))
+    try:
+        return call()
+    except BaseException:
+        L.cpg_conv2d_use_packed(None, 0)
+        raise
 
 
 class BiasGradSink(object):
@@ -165,7 +172,7 @@ class _MaskedConv2dFn(torch.autograd.Function):
         # Packed weight operands (cpg_conv2d_pack, ABI 3): when this layer's forward AND its input gradient stream one, both are produced
         # here in ONE launch; the forward takes its own now, the input gradient's rides in ctx until backward (the weights cannot change in
         # between: autograd's version check on the saved w / pm guards exactly that).  One launch instead of two per layer and step.
-        ctx.packed_dgrad = None
+        ctx.packed_dgrad = pk_f = None
         if PACK_CACHE and ctx.needs_input_grad[0]:
             uses_bnbwd = bn_hint is not None and L.cpg_conv2d_dgrad_bnbwd_tiles(ctypes.byref(d)) > 0      # (that launch packs for the direct kernels)
             nb_f, nb_d = _pack_bytes(L, d, 2 if tiles > 0 else 0), (0 if uses_bnbwd else _pack_bytes(L, d, 1))
@@ -175,18 +182,17 @@ class _MaskedConv2dFn(torch.autograd.Function):
                 rc = L.cpg_conv2d_pack(ctypes.byref(d), _lib.dptr(w, name='weight'), _lib.dptr(p, name='piggymask'), float(thr),
                                        2 if tiles > 0 else 0, _lib.dptr(pk_f), nb_f, 1, _lib.dptr(pk_d), nb_d, _lib.stream_ptr())
                 _lib.check('cpg_conv2d_pack', rc)
-                _lib.check('cpg_conv2d_use_packed', L.cpg_conv2d_use_packed(_lib.dptr(pk_f), nb_f))
                 ctx.packed_dgrad = pk_d
         if tiles > 0:
             stats = torch.empty((d.K, tiles, 2), dtype=torch.float32, device=x.device)
-            rc = L.cpg_conv2d_fwd_bnstats(ctypes.byref(d), _lib.dptr(x, name='input'), _lib.dptr(w, name='weight'),
-                                          _lib.dptr(p, name='piggymask'), float(thr), _lib.dptr(bias, name='bias'), _lib.dptr(y),
-                                          _lib.dptr(stats), stats.numel() * 4, _lib.dptr(ws), nbytes, _lib.stream_ptr())
+            rc = _with_packed(L, pk_f, lambda: L.cpg_conv2d_fwd_bnstats(
+                ctypes.byref(d), _lib.dptr(x, name='input'), _lib.dptr(w, name='weight'), _lib.dptr(p, name='piggymask'), float(thr),
+                _lib.dptr(bias, name='bias'), _lib.dptr(y), _lib.dptr(stats), stats.numel() * 4, _lib.dptr(ws), nbytes, _lib.stream_ptr()))
             _lib.check('cpg_conv2d_fwd_bnstats', rc)
         else:
-            rc = L.cpg_conv2d_fwd(ctypes.byref(d), _lib.dptr(x, name='input'), _lib.dptr(w, name='weight'),
-                                  _lib.dptr(p, name='piggymask'), float(thr), _lib.dptr(bias, name='bias'),
-                                  _lib.dptr(y), _lib.dptr(ws), nbytes, _lib.stream_ptr())
+            rc = _with_packed(L, pk_f, lambda: L.cpg_conv2d_fwd(
+                ctypes.byref(d), _lib.dptr(x, name='input'), _lib.dptr(w, name='weight'), _lib.dptr(p, name='piggymask'), float(thr),
+                _lib.dptr(bias, name='bias'), _lib.dptr(y), _lib.dptr(ws), nbytes, _lib.stream_ptr()))
             _lib.check('cpg_conv2d_fwd', rc)
         ctx.save_for_backward(x, w, p)
         ctx.desc, ctx.thr, ctx.has_bias = d, float(thr), bias is not None
@@ -237,15 +243,17 @@ class _MaskedConv2dFn(torch.autograd.Function):
                 hint.partials, hint.tiles = partials, tiles
             elif addend is not None and L.cpg_conv2d_dgrad_add_supported(ctypes.byref(d)) and addend.shape == x.shape:
                 addend = addend.contiguous()
-                _arm_packed(L, ctx)
-                rc = L.cpg_conv2d_dgrad_add(ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr,
-                                            _lib.dptr(addend, name='skip gradient'), _lib.dptr(gx), _lib.dptr(ws), nbytes, s)
+                pk, ctx.packed_dgrad = getattr(ctx, 'packed_dgrad', None), None      # (the operand packed at forward time, one-shot)
+                ad = addend
+                rc = _with_packed(L, pk, lambda: L.cpg_conv2d_dgrad_add(
+                    ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr, _lib.dptr(ad, name='skip gradient'),
+                    _lib.dptr(gx), _lib.dptr(ws), nbytes, s))
                 _lib.check('cpg_conv2d_dgrad_add', rc)
                 addend = None
             else:
-                _arm_packed(L, ctx)
-                rc = L.cpg_conv2d_dgrad(ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr,
-                                        _lib.dptr(gx), _lib.dptr(ws), nbytes, s)
+                pk, ctx.packed_dgrad = getattr(ctx, 'packed_dgrad', None), None
+                rc = _with_packed(L, pk, lambda: L.cpg_conv2d_dgrad(
+                    ctypes.byref(d), _lib.dptr(gy, name='grad_output'), _lib.dptr(w), _lib.dptr(p), thr, _lib.dptr(gx), _lib.dptr(ws), nbytes, s))
                 _lib.check('cpg_conv2d_dgrad', rc)
         if addend is not None:                  # (no fused path for this launch)
             gx = addend.clone() if gx is None else gx.add_(addend)

@@ -3446,3 +3446,20 @@ def test_caller_packed_operands_are_bit_equal_to_self_packing_calls(shape, with_
     # shapes of the other kernel families report no operand
     d2 = nl._conv_desc((2, 3, 224, 224), (64, 3, 7, 7), (2, 2), (3, 3), (1, 1), 1)
     assert [lib.cpg_conv2d_pack_bytes(ctypes.byref(d2), p) for p in (0, 1, 2)] == [0, 0, 0]
+
+
+def test_a_failed_conv_call_leaves_no_packed_operand_armed():
+    """The packed-operand context is per thread and one-shot; the Python layer arms it right before the conv call.  If an argument then
+    fails to convert (an fp16 input: cpg_amd._lib.dptr raises before the library is entered) the thread must NOT stay armed: the next,
+    correct forward of the same layer -- same shapes, so the stale operand would fit -- after a weight update must use the NEW weights."""
+    conv = nl.SharableConv2d(64, 64, 3, padding=1, bias=False).to(DEV)
+    nn.init.normal_(conv.weight, 0, 0.05)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(4, 64, 28, 28, generator=g).to(DEV).requires_grad_(True)
+    y0 = conv(x).detach().clone()
+    with pytest.raises(TypeError):
+        conv(x.detach().half().requires_grad_(True))              # arms, then fails while converting the input
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+    y1 = conv(x.detach())                                            # (no gradient: this call packs for itself -- unless a stale operand is armed)
+    np.testing.assert_allclose(y1.detach().cpu().numpy(), 2.0 * y0.cpu().numpy(), rtol=1e-5, atol=1e-5)
