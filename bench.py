@@ -645,9 +645,10 @@ SEQUENCES = {
                      flow="configs[3]'s flow: task 1 = pretrained pass-through (claim, validate, no training) + prune run; tasks >= 2 = finetune with "
                           'piggymasks + prune run', epochs='task 1: 10 prune; tasks >= 2: 1 finetune + 10 prune'),
     'spherenet20': dict(builder='spherenet20', pass_through_first=True, piggymask_retrain=False,          # experiment3/FvGeEm_CPG_face.sh:7-26,130
-                        tasks=[('face_verification', 4630, 1e-3, 5e-4, 5e-4), ('gender', 3, 5e-4, 5e-4, 5e-4), ('emotion', 7, 5e-4, 5e-4, 5e-4)],
+                        tasks=[('face_verification', 4630, 1e-3, 5e-4, 5e-4), ('gender', 3, 5e-4, 5e-4, 5e-4), ('emotion', 7, 5e-4, 5e-4, 5e-4),
+                               ('age0', 8, 5e-4, 5e-4, 5e-4)],                                            # (FvGeEmAg0_CPG_face.sh:7-29: the fourth task)
                         flow="configs[4]'s flow: face_verification (AngleLinear + AngleLoss, pass-through + prune run, evaluated as embeddings) -> gender "
-                             '(nn.Linear + CE) -> emotion (class-weighted CE), per-task bias / PReLU stash', epochs='task 1: 10 prune; tasks >= 2: 1 finetune + 10 prune'),
+                             '(nn.Linear + CE) -> emotion (class-weighted CE) -> age (CE), per-task bias / PReLU stash', epochs='task 1: 10 prune; tasks >= 2: 1 finetune + 10 prune'),
 }
 
 
