@@ -1365,6 +1365,13 @@ def main():
             # free this process's cached blocks first: the children allocate their own pools on the same GPU
             torch.cuda.empty_cache()
             out['other_workloads'] = other_workloads(20, a.warmup)
+            # ... and flat in `config`, for readers that keep only the scalar fields of the contract's objects
+            for name, w_ in out['other_workloads'].items():
+                ok = ('error' not in w_ and bool(w_.get('valid', True)) and bool((w_.get('parity_check') or {}).get('ok'))
+                      and bool((w_.get('cycle_check') or {}).get('weights_finite')))
+                out['config']['other_%s_images_per_sec' % name] = w_.get('value')
+                out['config']['other_%s_whole_step_frac_of_dense_peak' % name] = (w_.get('whole_step') or {}).get('frac_of_dense_fp32_mfma_peak')
+                out['config']['other_%s_parity_and_finite' % name] = ok
         if not a.no_cpu_baseline and world == 1:
             if a.task == 1 and a.width_multiplier == 1.0:
                 out['cpu_baseline'] = cpu_baseline(steps=a.steps, batch=a.batch, validates=counts['validates'],
